@@ -1,0 +1,145 @@
+/* scri_amd -- C ABI of the MI355X-native BMS-transformation engine.
+ *
+ * Drop-in boundary for the BMS hot path of moble/scri (reference scri 2024.0.13).  The reference has no FFI:
+ * its seam is Python attribute grafting (scri/__init__.py:125-150, scri/waveform_modes.py:705-719,
+ * scri/asymptotic_bondi_data/__init__.py:235-263).  Each entry point below replaces the arithmetic of the
+ * cited reference function; argument parsing / validation / bookkeeping (kwargs precedence, history, frame
+ * update) stays in the Python shim `scri_amd` which mirrors the reference's behaviour and binds these symbols
+ * with ctypes (INTEGRATION.md shows the stub a scri maintainer would add).
+ *
+ * Conventions
+ *   - complex data are interleaved (re, im) float64 = numpy complex128; "c16[N][ld]" means N rows with a
+ *     row stride of `ld` complex elements (C-contiguous when ld == row length);
+ *   - `mem` selects where the bulk buffers live: BMS_HOST (numpy memory; the library copies to the GPU and
+ *     back) or BMS_DEVICE (HIP device pointers, e.g. torch.Tensor.data_ptr()); time arrays and all small
+ *     parameter arrays are always host memory;
+ *   - the caller owns every buffer; the library keeps no pointer after return.  Device work space is cached
+ *     behind the opaque context and released by bms_ctx_destroy;
+ *   - every function returns 0 on success or a negative bms_status; bms_last_error(ctx) gives the text;
+ *   - a context is bound to one GPU and one HIP stream; calls on one context are serialised by the caller,
+ *     different contexts are independent.  There is NO CPU fallback: without a gfx950 device
+ *     bms_ctx_create fails.
+ */
+#ifndef SCRI_AMD_H
+#define SCRI_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct bms_ctx bms_ctx;
+
+enum bms_status {
+  BMS_OK = 0,
+  BMS_ERR_INVALID = -1,     /* bad argument (maps to ValueError in the shim) */
+  BMS_ERR_HIP = -2,         /* HIP runtime failure */
+  BMS_ERR_NOMEM = -3,       /* device allocation failed */
+  BMS_ERR_UNSUPPORTED = -4, /* valid request outside the implemented range */
+  BMS_ERR_NODEVICE = -5     /* no usable GPU */
+};
+
+enum bms_mem { BMS_HOST = 0, BMS_DEVICE = 1 };
+
+/* type-specific inhomogeneous term of the WaveformModes path, scri/waveform_grid.py:485-557 */
+enum bms_type_term {
+  BMS_TERM_NONE = 0,  /* psi4, hdot, news (and unknown types, which the reference treats as psi4) */
+  BMS_TERM_H = 1,     /* h:     f -= ethbar^2 alpha (NP normalisation), waveform_grid.py:486-494 */
+  BMS_TERM_SIGMA = 2, /* sigma: f -= eth^2 alpha / 2 ... GHP,            waveform_grid.py:495-503 */
+  BMS_TERM_PSI = 3    /* psi0..psi3: sum over higher Weyl scalars,       waveform_grid.py:504-550 */
+};
+
+int bms_version(void);
+
+/* ---- context ------------------------------------------------------------------------------------------- */
+int bms_ctx_create(int device, bms_ctx** ctx);
+void bms_ctx_destroy(bms_ctx* ctx);
+const char* bms_last_error(const bms_ctx* ctx); /* ctx may be NULL: error of the last failed bms_ctx_create */
+/* run on a caller-provided hipStream_t (NULL: the context's own stream) */
+int bms_ctx_set_stream(bms_ctx* ctx, void* hip_stream);
+/* cap on the grid work space in bytes (time axis is processed in chunks that fit); 0 = default */
+int bms_ctx_set_workspace_limit(bms_ctx* ctx, uint64_t bytes);
+/* block until all work queued by this context has finished */
+int bms_ctx_synchronize(bms_ctx* ctx);
+
+/* ---- rotation of modes ----------------------------------------------------------------------------------
+ * replaces _rotate_decomposition_basis_by_constant (scri/rotations.py:346-367) and
+ * _rotate_decomposition_basis_by_series (scri/rotations.py:370-392), including the Wigner-D evaluation
+ * (sf._Wigner_D_matrices, rotations.py:327,381).  In place on data c16[n_times][ld], modes (l,m),
+ * l = ell_min..ell_max at columns l(l+1) - ell_min^2 + m.
+ */
+int bms_rotate_const(bms_ctx* ctx, void* data, int mem, int64_t n_times, int64_t ld, int ell_min, int ell_max,
+                     const double quaternion[4] /* w,x,y,z */);
+int bms_rotate_series(bms_ctx* ctx, void* data, int mem, int64_t n_times, int64_t ld, int ell_min, int ell_max,
+                      const void* spinors /* c16[n_times][2] = (w + i z, y + i x), same memory space as data */);
+/* packed Wigner-D matrices of one rotor, layout of sf.Wigner_D_matrices (tests/test_rotations.py:163-165):
+ * host c16[(4 L^3 - L)/3 ...], block l at sf._linear_matrix_offset(l, ell_min), row-major (m', m) */
+int bms_wigner_D(bms_ctx* ctx, const double quaternion[4], int ell_min, int ell_max, void* D_host);
+
+/* ---- BMS transformation of WaveformModes ---------------------------------------------------------------
+ * replaces WaveformGrid.from_modes + WaveformGrid.to_modes (scri/waveform_grid.py:331-613, 274-329), i.e.
+ * WaveformModes.transform (scri/waveform_modes.py:705-719), after the kwargs have been parsed
+ * (process_transformation_kwargs, scri/waveform_grid.py:20-127).
+ */
+typedef struct {
+  int64_t n_times;
+  const double* t;      /* host f8[n_times], strictly increasing */
+  const void* data;     /* c16[n_times][ld] */
+  int64_t ld;           /* row stride (complex elements) */
+  int mem;              /* memory space of data, aux_data and of data_out */
+  int ell_min, ell_max; /* modes present in data */
+  int spin_weight;      /* SpinWeights[dataType], scri/__init__.py:81 */
+  int conformal_weight; /* waveform_base.py:445-446 */
+  int type_term;        /* enum bms_type_term */
+  /* BMS_TERM_PSI only: the n_aux higher-index Weyl scalars psi_{n+1}..psi_4 (psi*_modes kwargs) */
+  int n_aux;
+  const void* aux_data[4]; /* c16[n_times][aux_ld[i]] */
+  int64_t aux_ld[4];
+  int aux_ell_min[4], aux_ell_max[4], aux_spin[4];
+  double aux_coeff[4]; /* scipy.special.comb(5 - n, 5 - n_i), waveform_grid.py:547 */
+  int aux_power[4];    /* n_i - n */
+} bms_wm_input;
+
+typedef struct {
+  const void* supertranslation; /* host c16[(ell_max_supertranslation+1)^2], l from 0 */
+  int ell_max_supertranslation; /* >= 1 (the reference pads to 4 modes) */
+  double frame_rotation[4];     /* unit quaternion w,x,y,z */
+  double boost_velocity[3];
+  int n_theta, n_phi;           /* equiangular grid, theta includes both poles */
+  int ell_max_out;              /* largest l of the output modes (smallest is |spin_weight|) */
+} bms_transformation;
+
+/* t_out: host f8[n_times]; data_out: c16[n_times][(ell_max_out+1)^2 - s^2] (caller allocates n_times rows);
+ * the first *n_times_out rows are valid on return. */
+int bms_transform_modes(bms_ctx* ctx, const bms_wm_input* in, const bms_transformation* tr, double* t_out,
+                        void* data_out, int64_t* n_times_out);
+
+/* ---- BMS transformation of AsymptoticBondiData ---------------------------------------------------------
+ * replaces AsymptoticBondiData.transform (scri/asymptotic_bondi_data/transformations.py:199-431) after
+ * _process_transformation_kwargs (:8-97).  raw: c16[6][n_times][(ell_max+1)^2] = psi0..psi4, sigma
+ * (scri/asymptotic_bondi_data/__init__.py:36-75).  tr->n_theta = tr->n_phi = 2 working_ell_max + 1;
+ * tr->ell_max_out = output_ell_max.  raw_out: c16[6][n_times][(ell_max_out+1)^2] (field stride n_times rows).
+ */
+int bms_transform_abd(bms_ctx* ctx, const double* u, const void* raw, int mem, int64_t n_times, int ell_max,
+                      const bms_transformation* tr, double* u_out, void* raw_out, int64_t* n_times_out);
+
+/* ---- building blocks (exported for the parity tests and for the "next" rows of the scope table) --------- */
+/* boosted_grid / R_j_k (transformations.py:100-148, waveform_grid.py:130-174): host f8[n_theta][n_phi][4] */
+int bms_rotor_grid(bms_ctx* ctx, const double frame_rotation[4], const double boost_velocity[3], int n_theta,
+                   int n_phi, double* rotors_host);
+/* sf.SWSH_grid(R, s, ell_max)[..., ell_min^2:] : host c16[n_rotors][(ell_max+1)^2 - ell_min^2] */
+int bms_swsh_grid(bms_ctx* ctx, const double* rotors_host /* f8[n][4] */, int64_t n_rotors, int spin, int ell_min,
+                  int ell_max, void* Y_host);
+/* spinsfast.map2salm(grid[n_maps][n_theta][n_phi], s, ell_max)[..., ell_min^2:] (waveform_grid.py:303-307) */
+int bms_map2salm(bms_ctx* ctx, const void* grid, int mem, int64_t n_maps, int n_theta, int n_phi, int spin,
+                 int ell_min, int ell_max, void* modes_out);
+/* not-a-knot cubic spline through (x[n], y c16[n][n_cols]) evaluated at x_new[n_new] (all x host; y/out in
+ * `mem`): scipy CubicSpline(x, y)(x_new) of waveform_base.py:964 / modes_time_series.py:90 */
+int bms_cubic_spline(bms_ctx* ctx, const double* x, int64_t n, const void* y, int64_t ld, int64_t n_cols, int mem,
+                     const double* x_new, int64_t n_new, void* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SCRI_AMD_H */

@@ -1,0 +1,44 @@
+"""scri_amd -- MI355X-native BMS-transformation engine with the interface of moble/scri's hot path.
+
+Mirrors (same names, argument meaning and error behaviour) the part of scri that lies on the
+BMS-transformation path:
+
+    WaveformModes.transform / rotate_decomposition_basis / rotate_physical_system / to_inertial_frame
+    AsymptoticBondiData.transform
+    bms_transformations.LorentzTransformation / BMSTransformation / transform_supertranslation
+
+All arithmetic on the data runs in hand-written HIP kernels for gfx950 behind the C ABI in
+``include/scri_amd.h`` (``scri_amd/libscri_amd.so``).  There is no CPU fallback.
+"""
+import sys
+
+# type tables: scri/__init__.py:78-86
+FrameType = [UnknownFrameType, Inertial, Coprecessing, Coorbital, Corotating] = range(5)
+FrameNames = ["UnknownFrameType", "Inertial", "Coprecessing", "Coorbital", "Corotating"]
+DataType = [UnknownDataType, psi0, psi1, psi2, psi3, psi4, sigma, h, hdot, news, psin, psim] = range(12)
+DataNames = ["UnknownDataType", "Psi0", "Psi1", "Psi2", "Psi3", "Psi4", "sigma", "h", "hdot", "news", "psin", "PsiM"]
+SpinWeights = [sys.maxsize, 2, 1, 0, -1, -2, 2, -2, -2, -2, sys.maxsize, 0]
+ConformalWeights = [sys.maxsize, 2, 1, 0, -1, -2, 1, 0, -1, -1, -3, 0]
+RScaling = [sys.maxsize, 5, 4, 3, 2, 1, 2, 1, 1, 1, 0, 0]
+MScaling = [sys.maxsize, 2, 2, 2, 2, 2, 0, 0, 1, 1, 2, 1]
+
+from . import _lib  # noqa: E402  (raises ImportError if libscri_amd.so has not been built)
+from ._lib import Context, default_context, BMSError  # noqa: E402,F401
+from . import engine  # noqa: E402,F401
+from .waveform_modes import WaveformModes  # noqa: E402,F401
+from .rotations import rotate_decomposition_basis, rotate_physical_system, to_inertial_frame  # noqa: E402,F401
+from .asymptotic_bondi_data import AsymptoticBondiData  # noqa: E402,F401
+from . import bms_transformations  # noqa: E402,F401
+from .bms_transformations import LorentzTransformation, BMSTransformation  # noqa: E402,F401
+
+# Same grafting the reference performs at import (scri/__init__.py:140-142)
+WaveformModes.rotate_decomposition_basis = rotate_decomposition_basis
+WaveformModes.rotate_physical_system = rotate_physical_system
+WaveformModes.to_inertial_frame = to_inertial_frame
+
+
+def patch_scri():
+    """Graft the GPU implementations onto an installed `scri` (opt-in drop-in)."""
+    from .integration import patch_scri as _patch
+
+    return _patch()

@@ -1,0 +1,191 @@
+"""ctypes binding of libscri_amd.so (C ABI declared in include/scri_amd.h).
+
+There is no CPU fallback: importing this module needs the built shared library, and creating a
+context needs an MI355X (gfx950).  Both failures raise immediately with the library's message.
+"""
+import ctypes
+import os
+import threading
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libscri_amd.so")
+
+BMS_HOST, BMS_DEVICE = 0, 1
+BMS_TERM_NONE, BMS_TERM_H, BMS_TERM_SIGMA, BMS_TERM_PSI = 0, 1, 2, 3
+BMS_ERR_INVALID, BMS_ERR_HIP, BMS_ERR_NOMEM, BMS_ERR_UNSUPPORTED, BMS_ERR_NODEVICE = -1, -2, -3, -4, -5
+
+c_i64 = ctypes.c_int64
+c_int = ctypes.c_int
+c_vp = ctypes.c_void_p
+c_dp = ctypes.POINTER(ctypes.c_double)
+
+
+class bms_wm_input(ctypes.Structure):
+    _fields_ = [
+        ("n_times", c_i64),
+        ("t", c_dp),
+        ("data", c_vp),
+        ("ld", c_i64),
+        ("mem", c_int),
+        ("ell_min", c_int),
+        ("ell_max", c_int),
+        ("spin_weight", c_int),
+        ("conformal_weight", c_int),
+        ("type_term", c_int),
+        ("n_aux", c_int),
+        ("aux_data", c_vp * 4),
+        ("aux_ld", c_i64 * 4),
+        ("aux_ell_min", c_int * 4),
+        ("aux_ell_max", c_int * 4),
+        ("aux_spin", c_int * 4),
+        ("aux_coeff", ctypes.c_double * 4),
+        ("aux_power", c_int * 4),
+    ]
+
+
+class bms_transformation(ctypes.Structure):
+    _fields_ = [
+        ("supertranslation", c_vp),
+        ("ell_max_supertranslation", c_int),
+        ("frame_rotation", ctypes.c_double * 4),
+        ("boost_velocity", ctypes.c_double * 3),
+        ("n_theta", c_int),
+        ("n_phi", c_int),
+        ("ell_max_out", c_int),
+    ]
+
+
+# every symbol include/scri_amd.h declares: (restype, argtypes)
+SIGNATURES = {
+    "bms_version": (c_int, []),
+    "bms_ctx_create": (c_int, [c_int, ctypes.POINTER(c_vp)]),
+    "bms_ctx_destroy": (None, [c_vp]),
+    "bms_last_error": (ctypes.c_char_p, [c_vp]),
+    "bms_ctx_set_stream": (c_int, [c_vp, c_vp]),
+    "bms_ctx_set_workspace_limit": (c_int, [c_vp, ctypes.c_uint64]),
+    "bms_ctx_synchronize": (c_int, [c_vp]),
+    "bms_rotate_const": (c_int, [c_vp, c_vp, c_int, c_i64, c_i64, c_int, c_int, c_dp]),
+    "bms_rotate_series": (c_int, [c_vp, c_vp, c_int, c_i64, c_i64, c_int, c_int, c_vp]),
+    "bms_wigner_D": (c_int, [c_vp, c_dp, c_int, c_int, c_vp]),
+    "bms_transform_modes": (
+        c_int,
+        [c_vp, ctypes.POINTER(bms_wm_input), ctypes.POINTER(bms_transformation), c_dp, c_vp, ctypes.POINTER(c_i64)],
+    ),
+    "bms_transform_abd": (
+        c_int,
+        [c_vp, c_dp, c_vp, c_int, c_i64, c_int, ctypes.POINTER(bms_transformation), c_dp, c_vp, ctypes.POINTER(c_i64)],
+    ),
+    "bms_rotor_grid": (c_int, [c_vp, c_dp, c_dp, c_int, c_int, c_dp]),
+    "bms_swsh_grid": (c_int, [c_vp, c_dp, c_i64, c_int, c_int, c_int, c_vp]),
+    "bms_map2salm": (c_int, [c_vp, c_vp, c_int, c_i64, c_int, c_int, c_int, c_int, c_int, c_vp]),
+    "bms_cubic_spline": (c_int, [c_vp, c_dp, c_i64, c_vp, c_i64, c_i64, c_int, c_dp, c_i64, c_vp]),
+}
+
+_lib = None
+_lock = threading.Lock()
+
+
+class BMSError(RuntimeError):
+    pass
+
+
+def load():
+    """Load libscri_amd.so (once).  Raises ImportError with build instructions if it is missing."""
+    global _lib
+    with _lock:
+        if _lib is None:
+            if not os.path.exists(LIB_PATH):
+                raise ImportError(
+                    f"{LIB_PATH} not found: build it with `make -C {os.path.join(_HERE, 'csrc')}` "
+                    "(or `python -c 'import __graft_entry__ as g; g.build()'`).  scri_amd has no CPU fallback."
+                )
+            lib = ctypes.CDLL(LIB_PATH)
+            for name, (res, args) in SIGNATURES.items():
+                fn = getattr(lib, name)  # AttributeError if the library lacks a declared symbol
+                fn.restype = res
+                fn.argtypes = args
+            _lib = lib
+    return _lib
+
+
+def _raise(code, ctx, what):
+    msg = load().bms_last_error(ctx)
+    msg = msg.decode() if msg else ""
+    text = f"{what}: {msg} (status {code})"
+    if code in (BMS_ERR_INVALID,):
+        raise ValueError(text)
+    if code == BMS_ERR_NOMEM:
+        raise MemoryError(text)
+    if code == BMS_ERR_UNSUPPORTED:
+        raise NotImplementedError(text)
+    raise BMSError(text)
+
+
+class Context:
+    """Owns one bms_ctx (one GPU, one stream).  `stream`: optional hipStream_t handle (int), e.g.
+    torch.cuda.current_stream().cuda_stream, so that work is ordered with the caller's."""
+
+    def __init__(self, device=0, stream=None, workspace_limit=None):
+        lib = load()
+        h = c_vp()
+        rc = lib.bms_ctx_create(int(device), ctypes.byref(h))
+        if rc != 0:
+            _raise(rc, None, "bms_ctx_create")
+        self._h = h
+        self.device = int(device)
+        if stream is not None:
+            self.set_stream(stream)
+        if workspace_limit:
+            self.check(lib.bms_ctx_set_workspace_limit(self._h, int(workspace_limit)), "bms_ctx_set_workspace_limit")
+
+    def check(self, rc, what):
+        if rc != 0:
+            _raise(rc, self._h, what)
+
+    def set_stream(self, stream):
+        self.check(load().bms_ctx_set_stream(self._h, c_vp(int(stream) if stream else 0)), "bms_ctx_set_stream")
+
+    def synchronize(self):
+        self.check(load().bms_ctx_synchronize(self._h), "bms_ctx_synchronize")
+
+    @property
+    def handle(self):
+        return self._h
+
+    def close(self):
+        if getattr(self, "_h", None):
+            load().bms_ctx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+_default_ctx = None
+
+
+def default_context():
+    """Process-wide context on device int(os.environ.get('SCRI_AMD_DEVICE', LOCAL_RANK or 0))."""
+    global _default_ctx
+    if _default_ctx is None:
+        dev = int(os.environ.get("SCRI_AMD_DEVICE", os.environ.get("LOCAL_RANK", "0")))
+        _default_ctx = Context(dev)
+    return _default_ctx
+
+
+def as_c16(a):
+    """C-contiguous complex128 view/copy of `a` (the shim copies if the last-dim stride is not 16 B)."""
+    return np.ascontiguousarray(a, dtype=np.complex128)
+
+
+def dptr(a):
+    return a.ctypes.data_as(c_dp)
+
+
+def vptr(a):
+    return c_vp(a.ctypes.data)

@@ -1,0 +1,110 @@
+"""`AsymptoticBondiData`: storage of psi0..psi4 and sigma as mode time series
+(scri/asymptotic_bondi_data/__init__.py:9-263) and its BMS ``transform``
+(scri/asymptotic_bondi_data/transformations.py:8-431), computed by ``bms_transform_abd`` on the GPU."""
+import numpy as np
+
+from . import engine
+from .waveform_grid import _parse_translations, _parse_lorentz
+
+_FIELDS = ("psi0", "psi1", "psi2", "psi3", "psi4", "sigma")
+_SPINS = (2, 1, 0, -1, -2, 2)
+
+
+def _process_transformation_kwargs(input_ell_max, **kwargs):
+    """scri/asymptotic_bondi_data/transformations.py:8-97: reality of the supertranslation is imposed
+    silently; unknown kwargs are ignored (the reference never warns here)."""
+    supertranslation, ell_max_supertranslation = _parse_translations(kwargs, impose_reality=True)
+    output_ell_max = kwargs.pop("output_ell_max", input_ell_max)
+    working_ell_max = kwargs.pop("working_ell_max", 2 * input_ell_max + ell_max_supertranslation)
+    if working_ell_max < input_ell_max:
+        raise ValueError(f"working_ell_max={working_ell_max} is too small; it must be at least ell_max={input_ell_max}")
+    try:
+        frame_rotation, boost_velocity = _parse_lorentz(kwargs, single=True)
+    except ValueError as e:
+        if "boost_velocity" in str(e):
+            raise ValueError(str(e).rstrip(".")) from None
+        raise
+    return frame_rotation, boost_velocity, supertranslation, working_ell_max, output_ell_max
+
+
+class AsymptoticBondiData:
+    """Asymptotic Bondi data on future null infinity: u [n_times] and the six fields
+    psi0, psi1, psi2, psi3, psi4, sigma as complex mode weights [n_times, (ell_max+1)^2]
+    (l from 0; modes with l < |s| are zero), stored contiguously as `_raw_data[6, n_times, n_modes]`."""
+
+    def __init__(self, time, ell_max, multiplication_truncator=sum, frameType=None, ctx=None):
+        from . import Inertial
+
+        self._time = np.array(time, dtype=float)
+        if self._time.ndim != 1:
+            raise ValueError(f"Input `time` parameter must be a 1-d array of floats; it has shape {self._time.shape}")
+        self._ell_max = int(ell_max)
+        self._raw_data = np.zeros((6, self._time.size, (self._ell_max + 1) ** 2), dtype=complex)
+        self.frameType = Inertial if frameType is None else frameType
+        self.frame = np.zeros((0, 4))
+        self._ctx = ctx
+
+    @property
+    def time(self):
+        return self._time
+
+    u = t = time
+
+    @property
+    def n_times(self):
+        return self._time.size
+
+    @property
+    def ell_min(self):
+        return 0
+
+    @property
+    def ell_max(self):
+        return self._ell_max
+
+    @property
+    def n_modes(self):
+        return self._raw_data.shape[-1]
+
+    def copy(self):
+        new = type(self)(self._time.copy(), self._ell_max, frameType=self.frameType, ctx=self._ctx)
+        new._raw_data[:] = self._raw_data
+        return new
+
+    def interpolate(self, new_times):
+        """scri/asymptotic_bondi_data/__init__.py:218-233: cubic-spline all six fields to `new_times`."""
+        new_times = np.asarray(new_times, dtype=float)
+        new = type(self)(new_times, self._ell_max, frameType=self.frameType, ctx=self._ctx)
+        y = np.ascontiguousarray(np.moveaxis(self._raw_data, 0, 1)).reshape(self.n_times, -1)
+        out = engine.cubic_spline(self._time, y, new_times, ctx=self._ctx)
+        new._raw_data[:] = np.moveaxis(out.reshape(new_times.size, 6, -1), 1, 0)
+        return new
+
+    def transform(self, **kwargs):
+        """Apply a BMS transformation (scri/asymptotic_bondi_data/transformations.py:199-431).
+
+        Keyword arguments: time_translation, space_translation, spacetime_translation,
+        supertranslation, frame_rotation, boost_velocity, output_ell_max, working_ell_max."""
+        frame_rotation, boost_velocity, supertranslation, working_ell_max, output_ell_max = _process_transformation_kwargs(
+            self.ell_max, **kwargs
+        )
+        n_theta = 2 * working_ell_max + 1
+        tr = engine.make_transformation(supertranslation, frame_rotation, boost_velocity, n_theta, n_theta, output_ell_max)
+        u_new, raw_new = engine.transform_abd(self._time, self._raw_data, self.ell_max, tr, ctx=self._ctx)
+        abdprime = type(self)(u_new, output_ell_max, frameType=self.frameType, ctx=self._ctx)
+        abdprime._raw_data[:] = raw_new
+        return abdprime
+
+
+def _field_property(i):
+    def get(self):
+        return self._raw_data[i]
+
+    def set(self, value):
+        self._raw_data[i] = value
+
+    return property(get, set)
+
+
+for _i, _name in enumerate(_FIELDS):
+    setattr(AsymptoticBondiData, _name, _field_property(_i))

@@ -1,0 +1,901 @@
+// Host side of the engine: context, set-up tables, chunked pipeline, C ABI (include/scri_amd.h).
+//
+// Pipeline of one BMS transformation (WaveformModes flavour, scri/waveform_grid.py:331-613 + 274-329):
+//   host   : rotor grid R_jk (n_pix quaternions), per-pixel scalars (k, alpha, inhomogeneous term), output
+//            time window, theta-quadrature weights                       [O(n_pix) work, no time dependence]
+//   GPU    : SWSH synthesis matrix and quadrature matrix (kernels_swsh.hip), spline factor table
+//   GPU xN : per chunk of output times:  synthesis GEMM (+ fused affine epilogue)  ->  spline forward
+//            -> spline backward + evaluation on the distorted time slices  ->  analysis GEMM
+// Nothing in this file falls back to the CPU for the data path; the host only prepares O(n_pix) tables.
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/scri_amd.h"
+#include "kernels.h"
+#include "wigner.h"
+
+using namespace bms;
+
+// ====================================================================================================== context
+
+struct DevBuf {
+  void* p = nullptr;
+  size_t cap = 0;
+};
+
+struct bms_ctx {
+  int device = 0;
+  hipStream_t own_stream = nullptr;
+  hipStream_t stream = nullptr;
+  std::string err;
+  uint64_t ws_limit = 32ull << 30;
+  std::map<std::string, DevBuf> bufs;  // grow-only named work space
+  int delta_lmax = -1;                 // Delta tables cached up to this l
+  std::vector<long long> delta_off_host;
+};
+
+static thread_local std::string g_create_error;
+
+static int fail(bms_ctx* c, int code, const char* fmt, ...) {
+  char buf[1024];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  if (c)
+    c->err = buf;
+  else
+    g_create_error = buf;
+  return code;
+}
+
+#define HIP_TRY(ctx, expr)                                                                                   \
+  do {                                                                                                       \
+    hipError_t e__ = (expr);                                                                                 \
+    if (e__ != hipSuccess)                                                                                   \
+      return fail(ctx, e__ == hipErrorOutOfMemory ? BMS_ERR_NOMEM : BMS_ERR_HIP, "%s failed: %s (%s:%d)", #expr, \
+                  hipGetErrorString(e__), __FILE__, __LINE__);                                               \
+  } while (0)
+
+// grow-only device buffer by name
+static int dev_buf(bms_ctx* c, const char* name, size_t bytes, void** out) {
+  DevBuf& b = c->bufs[name];
+  if (b.cap < bytes) {
+    if (b.p) {
+      HIP_TRY(c, hipStreamSynchronize(c->stream));
+      HIP_TRY(c, hipFree(b.p));
+      b.p = nullptr;
+      b.cap = 0;
+    }
+    size_t want = bytes + bytes / 16 + 4096;
+    hipError_t e = hipMalloc(&b.p, want);
+    if (e != hipSuccess) {
+      (void)hipGetLastError();
+      b.p = nullptr;
+      return fail(c, BMS_ERR_NOMEM, "hipMalloc of %zu bytes for work space '%s' failed: %s", want, name,
+                  hipGetErrorString(e));
+    }
+    b.cap = want;
+  }
+  *out = b.p;
+  return BMS_OK;
+}
+template <class T>
+static int dev_buf_t(bms_ctx* c, const char* name, size_t count, T** out) {
+  void* p = nullptr;
+  int rc = dev_buf(c, name, count * sizeof(T), &p);
+  *out = static_cast<T*>(p);
+  return rc;
+}
+
+extern "C" int bms_version(void) { return 1; }
+
+extern "C" int bms_ctx_create(int device, bms_ctx** out) {
+  if (!out) return fail(nullptr, BMS_ERR_INVALID, "bms_ctx_create: ctx pointer is NULL");
+  *out = nullptr;
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || n <= 0) {
+    (void)hipGetLastError();
+    return fail(nullptr, BMS_ERR_NODEVICE,
+                "no HIP device available (%s): scri_amd has no CPU fallback and needs an MI355X (gfx950)",
+                e == hipSuccess ? "device count is 0" : hipGetErrorString(e));
+  }
+  if (device < 0 || device >= n) return fail(nullptr, BMS_ERR_INVALID, "device %d out of range [0, %d)", device, n);
+  hipDeviceProp_t prop;
+  e = hipGetDeviceProperties(&prop, device);
+  if (e != hipSuccess) return fail(nullptr, BMS_ERR_HIP, "hipGetDeviceProperties: %s", hipGetErrorString(e));
+  if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+    return fail(nullptr, BMS_ERR_NODEVICE, "device %d is %s; this library contains gfx950 (MI355X) code only", device,
+                prop.gcnArchName);
+  e = hipSetDevice(device);
+  if (e != hipSuccess) return fail(nullptr, BMS_ERR_HIP, "hipSetDevice: %s", hipGetErrorString(e));
+  bms_ctx* c = new bms_ctx;
+  c->device = device;
+  e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking);
+  if (e != hipSuccess) {
+    delete c;
+    return fail(nullptr, BMS_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(e));
+  }
+  c->stream = c->own_stream;
+  *out = c;
+  return BMS_OK;
+}
+
+extern "C" void bms_ctx_destroy(bms_ctx* c) {
+  if (!c) return;
+  (void)hipSetDevice(c->device);
+  (void)hipStreamSynchronize(c->stream);
+  for (auto& kv : c->bufs)
+    if (kv.second.p) (void)hipFree(kv.second.p);
+  if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+  delete c;
+}
+
+extern "C" const char* bms_last_error(const bms_ctx* c) { return c ? c->err.c_str() : g_create_error.c_str(); }
+
+extern "C" int bms_ctx_set_stream(bms_ctx* c, void* s) {
+  if (!c) return BMS_ERR_INVALID;
+  c->stream = s ? (hipStream_t)s : c->own_stream;
+  return BMS_OK;
+}
+
+extern "C" int bms_ctx_set_workspace_limit(bms_ctx* c, uint64_t bytes) {
+  if (!c) return BMS_ERR_INVALID;
+  c->ws_limit = bytes ? bytes : (32ull << 30);
+  return BMS_OK;
+}
+
+extern "C" int bms_ctx_synchronize(bms_ctx* c) {
+  if (!c) return BMS_ERR_INVALID;
+  HIP_TRY(c, hipSetDevice(c->device));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  return BMS_OK;
+}
+
+// ====================================================================================================== host math
+
+namespace {
+
+struct Quat {
+  double w, x, y, z;
+};
+inline Quat qmul(const Quat& a, const Quat& b) {
+  return {a.w * b.w - a.x * b.x - a.y * b.y - a.z * b.z, a.w * b.x + a.x * b.w + a.y * b.z - a.z * b.y,
+          a.w * b.y - a.x * b.z + a.y * b.w + a.z * b.x, a.w * b.z + a.x * b.y - a.y * b.x + a.z * b.w};
+}
+inline Quat from_spherical_coords(double theta, double phi) {
+  const double ct = std::cos(theta / 2), st = std::sin(theta / 2), cp = std::cos(phi / 2), sp = std::sin(phi / 2);
+  return {cp * ct, -sp * st, cp * st, sp * ct};
+}
+// (theta, phi) of a rotor = (beta, alpha) of its Euler angles (numpy-quaternion as_spherical_coords)
+inline void as_spherical_coords(const Quat& q, double& theta, double& phi) {
+  const double n = q.w * q.w + q.x * q.x + q.y * q.y + q.z * q.z;
+  phi = std::atan2(q.z, q.w) + std::atan2(-q.x, q.y);
+  double c = std::sqrt((q.w * q.w + q.z * q.z) / n);
+  if (c > 1.0) c = 1.0;
+  theta = 2 * std::acos(c);
+}
+// q z q^-1
+inline void rotate_z(const Quat& q, double r[3]) {
+  const double n = q.w * q.w + q.x * q.x + q.y * q.y + q.z * q.z;
+  r[0] = 2 * (q.x * q.z + q.w * q.y) / n;
+  r[1] = 2 * (q.y * q.z - q.w * q.x) / n;
+  r[2] = (q.w * q.w - q.x * q.x - q.y * q.y + q.z * q.z) / n;
+}
+
+// R_jk of scri/waveform_grid.py:130-174 == boosted_grid, transformations.py:100-148
+void build_rotor_grid(const double fr[4], const double v[3], int n_theta, int n_phi, std::vector<Quat>& R) {
+  R.resize((size_t)n_theta * n_phi);
+  const double beta = std::sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+  const double rapidity = std::atanh(beta);
+  const bool boosted = beta > 3e-14;
+  double vhat[3] = {0, 0, 0};
+  if (boosted)
+    for (int i = 0; i < 3; ++i) vhat[i] = v[i] / beta;
+  const Quat frq = {fr[0], fr[1], fr[2], fr[3]};
+  for (int j = 0; j < n_theta; ++j) {
+    const double th = M_PI * j / (n_theta - 1);  // np.linspace(0, pi, n_theta)
+    for (int k = 0; k < n_phi; ++k) {
+      const double ph = (2 * M_PI) * k / n_phi;  // np.linspace(0, 2 pi, n_phi, endpoint=False)
+      const Quat rq = qmul(frq, from_spherical_coords(th, ph));
+      Quat out = rq;
+      if (boosted) {
+        double tp, pp;
+        as_spherical_coords(rq, tp, pp);
+        const double rp[3] = {std::cos(pp) * std::sin(tp), std::sin(pp) * std::sin(tp), std::cos(tp)};
+        double dot = vhat[0] * rp[0] + vhat[1] * rp[1] + vhat[2] * rp[2];
+        if (dot > 1.0) dot = 1.0;
+        if (dot < -1.0) dot = -1.0;
+        const double Thetaprm = std::acos(dot);
+        const double Theta = 2 * std::atan(std::exp(-rapidity) * std::tan(Thetaprm / 2.0));
+        const double c[3] = {rp[1] * vhat[2] - rp[2] * vhat[1], rp[2] * vhat[0] - rp[0] * vhat[2],
+                             rp[0] * vhat[1] - rp[1] * vhat[0]};
+        const double cn = std::sqrt(c[0] * c[0] + c[1] * c[1] + c[2] * c[2]);
+        if (cn > 1e-200) {
+          const double ang = (Thetaprm - Theta) / 2;
+          const double s = std::sin(ang), co = std::cos(ang);
+          const Quat B = {co, s * c[0] / cn, s * c[1] / cn, s * c[2] / cn};
+          out = qmul(B, rq);
+        }
+      }
+      R[(size_t)j * n_phi + k] = out;
+    }
+  }
+}
+
+// sum_k coef[k] sYlm_k(R) for modes l = 0..lmax (host; small lmax)
+cplx eval_modes_host(const cplx* coef, int lmax, int spin, const Quat& q) {
+  cplx Ra = {q.w, q.z}, Rb = {q.y, q.x};
+  double ra, rb;
+  cplx ea, eb;
+  spinor_polar(Ra, Rb, ra, rb, ea, eb);
+  const double sgn = (spin & 1) ? -1.0 : 1.0;
+  cplx sum = {0.0, 0.0};
+  for (int m = -lmax; m <= lmax; ++m) {
+    const cplx phase = cmul(cpow_unit(ea, m - spin), cpow_unit(eb, -spin - m));
+    DChain ch;
+    ch.init(m, -spin, ra, rb);
+    for (int ell = ch.ell; ell <= lmax; ++ell) {
+      const cplx c = coef[LM_index(ell, m, 0)];
+      if (c.re != 0.0 || c.im != 0.0) {
+        const double a = sgn * std::sqrt((2.0 * ell + 1.0) / (4.0 * M_PI)) * ch.value();
+        const cplx y = {a * phase.re, a * phase.im};
+        const cplx t = cmul(c, y);
+        sum.re += t.re;
+        sum.im += t.im;
+      }
+      if (ell < lmax) ch.next();
+    }
+  }
+  return sum;
+}
+
+// theta quadrature weights of the equiangular analysis (spinsfast.map2salm; H&W 2010): with M = 2 n_theta - 2,
+//   q_j = (2 pi / M) e_j sum_{p even, -M/2 < p <= M/2} 2 cos(p theta_j) / (1 - p^2),  e_j = 1 at the poles else 2
+void theta_quadrature_weights(int n_theta, std::vector<double>& q) {
+  const int M = 2 * n_theta - 2;
+  q.assign(n_theta, 0.0);
+  for (int j = 0; j < n_theta; ++j) {
+    const double th = M_PI * j / (n_theta - 1);
+    double E = 0.0;
+    for (int p = -M / 2 + 1; p <= M / 2; ++p)
+      if ((p & 1) == 0) E += 2.0 / (1.0 - (double)p * p) * std::cos(p * th);
+    q[j] = (2 * M_PI / M) * E * ((j == 0 || j == n_theta - 1) ? 1.0 : 2.0);
+  }
+}
+
+// Delta^l = d^l(pi/2) in extended precision (same recurrence as DChain), packed for kernels_rotate.hip
+template <class T>
+void delta_matrix(int ell, std::vector<double>& D /* (2l+1)^2 row-major [mu][m] */) {
+  const int n = 2 * ell + 1;
+  D.assign((size_t)n * n, 0.0);
+  const T r = std::sqrt((T)0.5);
+  for (int mp = -ell; mp <= ell; ++mp)
+    for (int m = -ell; m <= ell; ++m) {
+      const int l0 = std::max(std::abs(mp), std::abs(m));
+      // start value
+      auto sb = [&](int k) {
+        T c = 1;
+        int nn = 2 * l0, kk = std::min(k, 2 * l0 - k);
+        for (int i = 1; i <= kk; ++i) c = c * (T)(nn - kk + i) / (T)i;
+        return std::sqrt(c);
+      };
+      T d0;
+      const T pw = std::pow(r, (T)(2 * l0));
+      if (l0 == mp)
+        d0 = (((l0 - m) & 1) ? -1 : 1) * sb(l0 - m) * pw;
+      else if (l0 == -mp)
+        d0 = sb(l0 + m) * pw;
+      else if (l0 == m)
+        d0 = sb(l0 - mp) * pw;
+      else
+        d0 = (((l0 + mp) & 1) ? -1 : 1) * sb(l0 + mp) * pw;
+      T dm1 = 0;
+      for (int l = l0; l < ell; ++l) {
+        T d1;
+        if (l == 0) {
+          d1 = 0;  // cos(pi/2) = 0
+        } else {
+          const T L = l, L1 = l + 1;
+          const T c1 = (2 * L + 1) * (-(T)(mp * m));  // l(l+1) cos(b) = 0
+          const T c2 = L1 * std::sqrt((L * L - (T)(mp * mp)) * (L * L - (T)(m * m)));
+          const T den = L * std::sqrt((L1 * L1 - (T)(mp * mp)) * (L1 * L1 - (T)(m * m)));
+          d1 = (c1 * d0 - c2 * dm1) / den;
+        }
+        dm1 = d0;
+        d0 = d1;
+      }
+      D[(size_t)(mp + ell) * n + (m + ell)] = (double)d0;
+    }
+}
+
+}  // namespace
+
+static int ensure_delta(bms_ctx* c, int lmax, const double** d_delta, const long long** d_off) {
+  double* dd = nullptr;
+  long long* doff = nullptr;
+  if (c->delta_lmax >= lmax) {
+    *d_delta = (const double*)c->bufs["delta"].p;
+    *d_off = (const long long*)c->bufs["delta_off"].p;
+    return BMS_OK;
+  }
+  std::vector<long long> off(lmax + 1);
+  long long total = 0;
+  for (int l = 0; l <= lmax; ++l) {
+    off[l] = total;
+    const int n = 2 * l + 1, nblk = (n + ROT_MB - 1) / ROT_MB;
+    total += 2LL * nblk * ROT_MB * n;
+  }
+  std::vector<double> packed((size_t)total, 0.0), D;
+  for (int l = 0; l <= lmax; ++l) {
+    delta_matrix<long double>(l, D);
+    const int n = 2 * l + 1, nblk = (n + ROT_MB - 1) / ROT_MB;
+    double* direct = packed.data() + off[l];
+    double* transp = direct + (size_t)nblk * ROT_MB * n;
+    for (int b = 0; b < nblk; ++b)
+      for (int col = 0; col < n; ++col)
+        for (int j = 0; j < ROT_MB; ++j) {
+          const int row = b * ROT_MB + j;
+          if (row < n) {
+            direct[((size_t)b * n + col) * ROT_MB + j] = D[(size_t)row * n + col];  // Delta[mu=row][m'=col]
+            transp[((size_t)b * n + col) * ROT_MB + j] = D[(size_t)col * n + row];  // Delta[mu=col][m=row]
+          }
+        }
+  }
+  int rc = dev_buf_t(c, "delta", (size_t)total, &dd);
+  if (rc) return rc;
+  rc = dev_buf_t(c, "delta_off", (size_t)lmax + 1, &doff);
+  if (rc) return rc;
+  HIP_TRY(c, hipMemcpyAsync(dd, packed.data(), sizeof(double) * total, hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(c, hipMemcpyAsync(doff, off.data(), sizeof(long long) * (lmax + 1), hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));  // host vectors go out of scope
+  c->delta_lmax = lmax;
+  *d_delta = dd;
+  *d_off = doff;
+  return BMS_OK;
+}
+
+// ====================================================================================================== rotation
+
+static int rotate_impl(bms_ctx* c, void* data, int mem, int64_t n_times, int64_t ld, int ell_min, int ell_max,
+                       const void* spinors, bool series) {
+  if (!c) return BMS_ERR_INVALID;
+  HIP_TRY(c, hipSetDevice(c->device));
+  if (n_times < 0 || ell_min < 0 || ell_max < ell_min) return fail(c, BMS_ERR_INVALID, "bad sizes");
+  const int64_t n_modes = LM_total_size(ell_min, ell_max);
+  if (ld < n_modes) return fail(c, BMS_ERR_INVALID, "row stride %lld smaller than %lld modes", (long long)ld, (long long)n_modes);
+  if (n_times == 0) return BMS_OK;
+  if (rotate_waves_per_block(ell_max) < 1) return fail(c, BMS_ERR_UNSUPPORTED, "ell_max=%d too large for the rotation kernel", ell_max);
+  const double* d_delta;
+  const long long* d_off;
+  int rc = ensure_delta(c, ell_max, &d_delta, &d_off);
+  if (rc) return rc;
+  double* d_data = (double*)data;
+  const double* d_rot = (const double*)spinors;
+  const size_t data_bytes = (size_t)n_times * ld * 16;
+  const size_t rot_bytes = (series ? (size_t)n_times : 1) * 32;
+  if (mem == BMS_HOST || !series) {
+    double* r = nullptr;
+    rc = dev_buf_t(c, "rot_spinors", rot_bytes / 8, &r);
+    if (rc) return rc;
+    HIP_TRY(c, hipMemcpyAsync(r, spinors, rot_bytes, hipMemcpyHostToDevice, c->stream));
+    d_rot = r;
+  }
+  if (mem == BMS_HOST) {
+    rc = dev_buf_t(c, "rot_data", data_bytes / 8, &d_data);
+    if (rc) return rc;
+    HIP_TRY(c, hipMemcpyAsync(d_data, data, data_bytes, hipMemcpyHostToDevice, c->stream));
+  }
+  HIP_TRY(c, launch_rotate_modes(c->stream, d_data, n_times, ld, ell_min, ell_max, d_rot, series ? 4 : 0, d_delta, d_off));
+  if (mem == BMS_HOST) {
+    HIP_TRY(c, hipMemcpyAsync(data, d_data, data_bytes, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+  } else if (!series) {
+    HIP_TRY(c, hipStreamSynchronize(c->stream));  // the constant rotor was staged from a host stack copy
+  }
+  return BMS_OK;
+}
+
+extern "C" int bms_rotate_const(bms_ctx* c, void* data, int mem, int64_t n_times, int64_t ld, int ell_min, int ell_max,
+                                const double q[4]) {
+  if (!c || !q) return BMS_ERR_INVALID;
+  const double sp[4] = {q[0], q[3], q[2], q[1]};  // (w + i z, y + i x)
+  return rotate_impl(c, data, mem, n_times, ld, ell_min, ell_max, sp, false);
+}
+
+extern "C" int bms_rotate_series(bms_ctx* c, void* data, int mem, int64_t n_times, int64_t ld, int ell_min,
+                                 int ell_max, const void* spinors) {
+  if (!c || !spinors) return BMS_ERR_INVALID;
+  return rotate_impl(c, data, mem, n_times, ld, ell_min, ell_max, spinors, true);
+}
+
+// D matrices through the rotation kernel itself: rotate the identity blocks (row (l, m') = delta_{m'})
+extern "C" int bms_wigner_D(bms_ctx* c, const double q[4], int ell_min, int ell_max, void* D_host) {
+  if (!c || !q || !D_host) return BMS_ERR_INVALID;
+  if (ell_min < 0 || ell_max < ell_min) return fail(c, BMS_ERR_INVALID, "bad ell range");
+  const int n_modes = LM_total_size(ell_min, ell_max);
+  const int n_rows = 2 * ell_max + 1;  // row r: in every l block, unit vector at m' = r - l_max (if |m'| <= l)
+  std::vector<double> buf((size_t)n_rows * n_modes * 2, 0.0);
+  for (int r = 0; r < n_rows; ++r) {
+    const int mp = r - ell_max;
+    for (int l = std::max(ell_min, std::abs(mp)); l <= ell_max; ++l) buf[((size_t)r * n_modes + LM_index(l, mp, ell_min)) * 2] = 1.0;
+  }
+  int rc = bms_rotate_const(c, buf.data(), BMS_HOST, n_rows, n_modes, ell_min, ell_max, q);
+  if (rc) return rc;
+  double* D = (double*)D_host;
+  for (int l = ell_min; l <= ell_max; ++l) {
+    const long long off = linear_matrix_offset(l, ell_min);
+    const int n = 2 * l + 1;
+    for (int mp = -l; mp <= l; ++mp)
+      for (int m = -l; m <= l; ++m) {
+        const size_t src = ((size_t)(mp + ell_max) * n_modes + LM_index(l, m, ell_min)) * 2;
+        const size_t dst = (size_t)(off + (long long)(mp + l) * n + (m + l)) * 2;
+        D[dst] = buf[src];
+        D[dst + 1] = buf[src + 1];
+      }
+  }
+  return BMS_OK;
+}
+
+// ====================================================================================================== transform
+
+namespace {
+
+constexpr int SPLINE_TILE = 256;
+constexpr int SPLINE_HALO = 32;
+
+inline long long round_up(long long a, long long b) { return (a + b - 1) / b * b; }
+
+struct PixelTables {
+  int n_theta = 0, n_phi = 0, n_pix = 0;
+  std::vector<Quat> R;
+  std::vector<double> k, alpha, skew_a, skew_b;
+  double beta = 0, gamma = 1, tt = 0;
+  bool nontrivial = false;  // beta != 0 or any supertranslation mode beyond l = 0 nonzero
+  double uprm_scale_min = 0, uprm_scale_max = 0;
+};
+
+// per-pixel scalars common to both flavours (waveform_grid.py:470-474; transformations.py:306-321)
+void build_pixel_tables(const bms_transformation* tr, PixelTables& T) {
+  T.n_theta = tr->n_theta;
+  T.n_phi = tr->n_phi;
+  T.n_pix = tr->n_theta * tr->n_phi;
+  build_rotor_grid(tr->frame_rotation, tr->boost_velocity, tr->n_theta, tr->n_phi, T.R);
+  const double* v = tr->boost_velocity;
+  T.beta = std::sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+  T.gamma = 1 / std::sqrt(1 - T.beta * T.beta);
+  const cplx* st = (const cplx*)tr->supertranslation;
+  const int nst = (tr->ell_max_supertranslation + 1) * (tr->ell_max_supertranslation + 1);
+  T.tt = st[0].re / std::sqrt(4 * M_PI);  // constant_from_ell_0_mode(supertranslation[0]).real
+  T.nontrivial = T.beta != 0;
+  for (int i = 1; i < nst; ++i)
+    if (st[i].re != 0 || st[i].im != 0) T.nontrivial = true;
+  T.k.resize(T.n_pix);
+  T.alpha.resize(T.n_pix);
+  T.skew_a.resize(T.n_pix);
+  T.skew_b.resize(T.n_pix);
+  for (int p = 0; p < T.n_pix; ++p) {
+    double r[3];
+    rotate_z(T.R[p], r);
+    const double vr = v[0] * r[0] + v[1] * r[1] + v[2] * r[2];
+    T.k[p] = 1.0 / (T.gamma * (1 - vr));
+    T.alpha[p] = eval_modes_host(st, tr->ell_max_supertranslation, 0, T.R[p]).re;
+    T.skew_a[p] = -vr;  // 1/(gamma k) - 1
+    T.skew_b[p] = T.alpha[p] - T.tt;
+  }
+}
+
+// output time window (waveform_grid.py:564-568 == transformations.py:391-396)
+void output_window(const PixelTables& T, const double* t, int64_t n, int64_t& i_lo, int64_t& i_hi) {
+  double umin = -INFINITY, umax = INFINITY;
+  for (int p = 0; p < T.n_pix; ++p) {
+    umin = std::max(umin, T.k[p] * (t[0] - T.alpha[p]));
+    umax = std::min(umax, T.k[p] * (t[n - 1] - T.alpha[p]));
+  }
+  const double ig = 1 / T.gamma;
+  // uprm_i = (1/gamma) (t_i - tt) is non-decreasing in i
+  i_lo = std::partition_point(t, t + n, [&](double ti) { return ig * (ti - T.tt) < umin; }) - t;
+  i_hi = std::partition_point(t, t + n, [&](double ti) { return ig * (ti - T.tt) <= umax; }) - t;
+  if (i_hi < i_lo) i_hi = i_lo;
+}
+
+// knots needed to evaluate output samples [c0, c1): [ja, jb] inclusive (before halo)
+void needed_knots(const PixelTables& T, const double* t, int64_t n, int64_t c0, int64_t c1, int64_t& ja, int64_t& jb) {
+  double lo = INFINITY, hi = -INFINITY;
+  const double x0 = t[c0], x1 = t[c1 - 1];
+  for (int p = 0; p < T.n_pix; ++p) {
+    lo = std::min(lo, x0 + (T.skew_a[p] * (x0 - T.tt) + T.skew_b[p]));
+    hi = std::max(hi, x1 + (T.skew_a[p] * (x1 - T.tt) + T.skew_b[p]));
+  }
+  ja = (std::upper_bound(t, t + n, lo) - t) - 1;  // last knot <= lo
+  jb = std::lower_bound(t, t + n, hi) - t;        // first knot >= hi
+  ja = std::max<int64_t>(ja, 0);
+  jb = std::min<int64_t>(jb, n - 1);
+}
+
+struct FieldPlan {  // one field to synthesise: input modes, its SWSH matrix
+  const double* d_data = nullptr;  // device c16[n][ld]
+  int64_t ld = 0;
+  int ell_min = 0, ell_max = 0, spin = 0;
+  double* d_B = nullptr;  // synthesis matrix
+  long long ldb = 0;
+  int K = 0;  // 2 * n_modes
+};
+
+}  // namespace
+
+static int upload(bms_ctx* c, const char* name, const void* host, size_t bytes, void** dev) {
+  int rc = dev_buf(c, name, bytes, dev);
+  if (rc) return rc;
+  HIP_TRY(c, hipMemcpyAsync(*dev, host, bytes, hipMemcpyHostToDevice, c->stream));
+  return BMS_OK;
+}
+
+static int stage_in(bms_ctx* c, const char* name, const void* src, int mem, size_t bytes, const double** dev) {
+  if (mem == BMS_DEVICE) {
+    *dev = (const double*)src;
+    return BMS_OK;
+  }
+  void* p;
+  int rc = upload(c, name, src, bytes, &p);
+  *dev = (const double*)p;
+  return rc;
+}
+
+static int validate_common(bms_ctx* c, int64_t n, const double* t, const bms_transformation* tr) {
+  if (n < 4) return fail(c, BMS_ERR_INVALID, "need at least 4 time steps for the cubic spline, got %lld", (long long)n);
+  for (int64_t i = 1; i < n; ++i)
+    if (!(t[i] > t[i - 1])) return fail(c, BMS_ERR_INVALID, "time array must be strictly increasing (index %lld)", (long long)i);
+  if (tr->n_theta < 2 || tr->n_phi < 1) return fail(c, BMS_ERR_INVALID, "bad grid size %d x %d", tr->n_theta, tr->n_phi);
+  if (tr->ell_max_supertranslation < 1 || !tr->supertranslation) return fail(c, BMS_ERR_INVALID, "supertranslation must hold at least l <= 1");
+  const double* v = tr->boost_velocity;
+  if (!(v[0] * v[0] + v[1] * v[1] + v[2] * v[2] < 1.0)) return fail(c, BMS_ERR_INVALID, "boost speed must be < 1");
+  return BMS_OK;
+}
+
+// The shared pipeline: `nf` synthesised fields -> pointwise stage -> spline -> analysis, chunked over time.
+struct PointwiseWM {
+  // WM flavour: y = (f0 + sum_i coeff_i f_i X^power_i - off) * scale, see bms_transform_modes
+  const double* d_off = nullptr;
+  const double* d_scale = nullptr;
+  int n_aux = 0;
+  double coeff[4];
+  int power[4];
+  const double *d_alpha = nullptr, *d_xa = nullptr, *d_xb = nullptr;
+};
+
+extern "C" int bms_transform_modes(bms_ctx* c, const bms_wm_input* in, const bms_transformation* tr, double* t_out,
+                                   void* data_out, int64_t* n_times_out) {
+  if (!c) return BMS_ERR_INVALID;
+  if (!in || !tr || !t_out || !data_out || !n_times_out) return fail(c, BMS_ERR_INVALID, "NULL argument");
+  HIP_TRY(c, hipSetDevice(c->device));
+  const int64_t n = in->n_times;
+  int rc = validate_common(c, n, in->t, tr);
+  if (rc) return rc;
+  const int s = in->spin_weight;
+  if (in->ell_min < 0 || in->ell_max < in->ell_min) return fail(c, BMS_ERR_INVALID, "bad ell range");
+  const int n_modes = LM_total_size(in->ell_min, in->ell_max);
+  if (in->ld < n_modes) return fail(c, BMS_ERR_INVALID, "row stride smaller than the number of modes");
+  if (tr->ell_max_out < std::abs(s)) return fail(c, BMS_ERR_INVALID, "ell_max_out < |s|");
+  if (in->type_term == BMS_TERM_PSI && (in->n_aux < 1 || in->n_aux > 4)) return fail(c, BMS_ERR_INVALID, "BMS_TERM_PSI needs 1..4 auxiliary fields");
+  const int ell_min_out = std::abs(s);
+  const int n_out = LM_total_size(ell_min_out, tr->ell_max_out);
+  const int lst = tr->ell_max_supertranslation;
+  const cplx* st = (const cplx*)tr->supertranslation;
+
+  // ---------------------------------------------------------------- host tables
+  PixelTables T;
+  build_pixel_tables(tr, T);
+  const int n_pix = T.n_pix;
+  int64_t i_lo, i_hi;
+  output_window(T, in->t, n, i_lo, i_hi);
+  const int64_t n_new = i_hi - i_lo;
+  *n_times_out = n_new;
+  for (int64_t i = 0; i < n_new; ++i) t_out[i] = (1 / T.gamma) * (in->t[i_lo + i] - T.tt);
+  if (n_new == 0) return BMS_OK;
+
+  std::vector<double> col_off(2 * (size_t)n_pix, 0.0), col_scale(2 * (size_t)n_pix, 1.0);
+  const bool apply_term = T.nontrivial;
+  if (apply_term && (in->type_term == BMS_TERM_H || in->type_term == BMS_TERM_SIGMA)) {
+    // h:     2 ethbar_GHP(ethbar_GHP(alpha, 0), -1) = +sqrt((l-1) l (l+1) (l+2)) alpha_lm, evaluated with s = -2
+    // sigma: eth_GHP(eth_GHP(alpha, 0), 1) = (1/2) sqrt(l (l+1)) sqrt((l-1)(l+2)) alpha_lm, evaluated with s = +2
+    std::vector<cplx> d((size_t)(lst + 1) * (lst + 1));
+    for (int l = 0; l <= lst; ++l)
+      for (int m = -l; m <= l; ++m) {
+        const cplx a = st[LM_index(l, m, 0)];
+        double f;
+        if (in->type_term == BMS_TERM_H)
+          f = 2 * ((-std::sqrt((double)l * (l + 1.0))) / std::sqrt(2.0)) * ((l >= 1 ? -std::sqrt((l - 1.0) * (l + 2.0)) : 0.0) / std::sqrt(2.0));
+        else
+          f = (std::sqrt((double)l * (l + 1.0)) / std::sqrt(2.0)) * ((l >= 1 ? std::sqrt((l - 1.0) * (l + 2.0)) : 0.0) / std::sqrt(2.0));
+        if (l < 2) f = 0.0;
+        d[LM_index(l, m, 0)] = {f * a.re, f * a.im};
+      }
+    for (int p = 0; p < n_pix; ++p) {
+      const cplx v = eval_modes_host(d.data(), lst, s, T.R[p]);
+      col_off[2 * p] = v.re;
+      col_off[2 * p + 1] = v.im;
+    }
+  }
+  for (int p = 0; p < n_pix; ++p) {
+    const double kw = std::pow(T.k[p], (double)in->conformal_weight);
+    col_scale[2 * p] = kw;
+    col_scale[2 * p + 1] = kw;
+  }
+  const bool psi = apply_term && in->type_term == BMS_TERM_PSI;
+  std::vector<double> xa, xb;
+  if (psi) {
+    // eth u'/k = (t - alpha) gamma k eth(v.r)/sqrt2... exactly as waveform_grid.py:508-523
+    std::vector<cplx> ea((size_t)(lst + 1) * (lst + 1)), ev(4);
+    for (int l = 0; l <= lst; ++l)
+      for (int m = -l; m <= l; ++m) {
+        const cplx a = st[LM_index(l, m, 0)];
+        const double f = (1 / std::sqrt(2.0)) * (std::sqrt((double)l * (l + 1.0)) / std::sqrt(2.0));
+        ea[LM_index(l, m, 0)] = {f * a.re, f * a.im};
+      }
+    const double* v = tr->boost_velocity;
+    const double is2 = 1 / std::sqrt(2.0);
+    ev[0] = {0, 0};
+    ev[1] = {is2 * v[0] * std::sqrt(2 * M_PI / 3), is2 * v[1] * std::sqrt(2 * M_PI / 3)};
+    ev[2] = {is2 * v[2] * std::sqrt(4 * M_PI / 3), 0};
+    ev[3] = {-is2 * v[0] * std::sqrt(2 * M_PI / 3), is2 * v[1] * std::sqrt(2 * M_PI / 3)};
+    xa.resize(2 * (size_t)n_pix);
+    xb.resize(2 * (size_t)n_pix);
+    for (int p = 0; p < n_pix; ++p) {
+      const cplx A = eval_modes_host(ea.data(), lst, 1, T.R[p]);
+      const cplx V = eval_modes_host(ev.data(), 1, 1, T.R[p]);
+      xa[2 * p] = T.gamma * T.k[p] * V.re;
+      xa[2 * p + 1] = T.gamma * T.k[p] * V.im;
+      xb[2 * p] = A.re;
+      xb[2 * p + 1] = A.im;
+    }
+  }
+  // quadrature: undistorted grid rotors and pixel weights q_j / n_phi
+  std::vector<double> qth, wpix((size_t)n_pix), grid_rot(4 * (size_t)n_pix);
+  theta_quadrature_weights(T.n_theta, qth);
+  for (int j = 0; j < T.n_theta; ++j)
+    for (int k = 0; k < T.n_phi; ++k) {
+      const int p = j * T.n_phi + k;
+      wpix[p] = qth[j] / T.n_phi;
+      const Quat q = from_spherical_coords(M_PI * j / (T.n_theta - 1), (2 * M_PI) * k / T.n_phi);
+      grid_rot[4 * p] = q.w;
+      grid_rot[4 * p + 1] = q.x;
+      grid_rot[4 * p + 2] = q.y;
+      grid_rot[4 * p + 3] = q.z;
+    }
+
+  // ---------------------------------------------------------------- device tables
+  hipStream_t S = c->stream;
+  void* vp;
+  double *d_rot, *d_grot, *d_wpix, *d_off, *d_scale, *d_skewa, *d_skewb, *d_x, *d_alpha = nullptr, *d_xa = nullptr, *d_xb = nullptr;
+  if ((rc = upload(c, "rotors", T.R.data(), sizeof(Quat) * n_pix, &vp))) return rc;
+  d_rot = (double*)vp;
+  if ((rc = upload(c, "grid_rotors", grid_rot.data(), 32 * (size_t)n_pix, &vp))) return rc;
+  d_grot = (double*)vp;
+  if ((rc = upload(c, "wpix", wpix.data(), 8 * (size_t)n_pix, &vp))) return rc;
+  d_wpix = (double*)vp;
+  if ((rc = upload(c, "col_off", col_off.data(), 16 * (size_t)n_pix, &vp))) return rc;
+  d_off = (double*)vp;
+  if ((rc = upload(c, "col_scale", col_scale.data(), 16 * (size_t)n_pix, &vp))) return rc;
+  d_scale = (double*)vp;
+  if ((rc = upload(c, "skew_a", T.skew_a.data(), 8 * (size_t)n_pix, &vp))) return rc;
+  d_skewa = (double*)vp;
+  if ((rc = upload(c, "skew_b", T.skew_b.data(), 8 * (size_t)n_pix, &vp))) return rc;
+  d_skewb = (double*)vp;
+  if ((rc = upload(c, "times", in->t, 8 * (size_t)n, &vp))) return rc;
+  d_x = (double*)vp;
+  if (psi) {
+    if ((rc = upload(c, "alpha", T.alpha.data(), 8 * (size_t)n_pix, &vp))) return rc;
+    d_alpha = (double*)vp;
+    if ((rc = upload(c, "xa", xa.data(), 16 * (size_t)n_pix, &vp))) return rc;
+    d_xa = (double*)vp;
+    if ((rc = upload(c, "xb", xb.data(), 16 * (size_t)n_pix, &vp))) return rc;
+    d_xb = (double*)vp;
+  }
+
+  const long long P2 = 2LL * n_pix;
+  const long long ldg = round_up(P2, 16);
+  // synthesis matrices
+  const int n_fields = 1 + (psi ? in->n_aux : 0);
+  FieldPlan F[5];
+  F[0].ell_min = in->ell_min;
+  F[0].ell_max = in->ell_max;
+  F[0].spin = s;
+  F[0].ld = in->ld;
+  if ((rc = stage_in(c, "in_data", in->data, in->mem, (size_t)n * in->ld * 16, &F[0].d_data))) return rc;
+  for (int a = 0; a < (psi ? in->n_aux : 0); ++a) {
+    FieldPlan& f = F[1 + a];
+    f.ell_min = in->aux_ell_min[a];
+    f.ell_max = in->aux_ell_max[a];
+    f.spin = in->aux_spin[a];
+    f.ld = in->aux_ld[a];
+    if (f.ell_min < 0 || f.ell_max < f.ell_min || f.ld < LM_total_size(f.ell_min, f.ell_max)) return fail(c, BMS_ERR_INVALID, "bad auxiliary field %d", a);
+    char nm[32];
+    snprintf(nm, sizeof nm, "in_aux%d", a);
+    if ((rc = stage_in(c, nm, in->aux_data[a], in->mem, (size_t)n * f.ld * 16, &f.d_data))) return rc;
+  }
+  const long long ldb = round_up(P2, 128);
+  for (int fi = 0; fi < n_fields; ++fi) {
+    FieldPlan& f = F[fi];
+    f.K = 2 * LM_total_size(f.ell_min, f.ell_max);
+    f.ldb = ldb;
+    const long long rows = round_up(f.K, 16);
+    char nm[32];
+    snprintf(nm, sizeof nm, "Bsyn%d", fi);
+    if ((rc = dev_buf_t(c, nm, (size_t)rows * ldb, &f.d_B))) return rc;
+    HIP_TRY(c, hipMemsetAsync(f.d_B, 0, sizeof(double) * rows * ldb, S));
+    HIP_TRY(c, launch_swsh_matrix(S, d_rot, n_pix, f.spin, f.ell_min, f.ell_max, f.d_B, ldb));
+  }
+  // analysis matrix [2 n_pix (rounded to 16)] x [2 n_out (rounded to 128)]
+  const long long ldw = round_up(2LL * n_out, 128);
+  const long long wrows = round_up(P2, 16);
+  double* d_W;
+  if ((rc = dev_buf_t(c, "Wana", (size_t)wrows * ldw, &d_W))) return rc;
+  HIP_TRY(c, hipMemsetAsync(d_W, 0, sizeof(double) * wrows * ldw, S));
+  HIP_TRY(c, launch_quadrature_matrix(S, d_grot, d_wpix, n_pix, s, ell_min_out, tr->ell_max_out, d_W, ldw));
+  // spline factors
+  SplineTable* d_tab;
+  if ((rc = dev_buf_t(c, "spline_table", (size_t)n, &d_tab))) return rc;
+  HIP_TRY(c, launch_spline_table(S, d_x, n, d_tab));
+
+  // output staging
+  double* d_out = (double*)data_out;
+  if (in->mem == BMS_HOST)
+    if ((rc = dev_buf_t(c, "out_data", (size_t)n_new * n_out * 2, &d_out))) return rc;
+
+  // ---------------------------------------------------------------- chunk loop over output samples
+  const int margin = SPLINE_HALO + 2;
+  // bytes per output row ~ (Y + R + G [+ Yaux]) * ldg * 8
+  const double bytes_per_row = (3.0 + (psi ? 1.0 : 0.0)) * ldg * 8.0;
+  int64_t chunk = (int64_t)std::max(1024.0, (double)c->ws_limit / bytes_per_row - 4.0 * margin);
+  chunk = std::min<int64_t>(chunk, n_new);
+  for (int64_t c0 = i_lo; c0 < i_hi; c0 += chunk) {
+    const int64_t c1 = std::min<int64_t>(c0 + chunk, i_hi);
+    int64_t ja, jb;
+    needed_knots(T, in->t, n, c0, c1, ja, jb);
+    const int64_t g0 = std::max<int64_t>(0, ja - margin), g1 = std::min<int64_t>(n, jb + margin + 1);
+    const int64_t rows_in = g1 - g0, rows_out = c1 - c0;
+    double *d_Y, *d_R, *d_G, *d_Yaux = nullptr;
+    if ((rc = dev_buf_t(c, "Y", (size_t)rows_in * ldg, &d_Y))) return rc;
+    if ((rc = dev_buf_t(c, "R", (size_t)rows_in * ldg, &d_R))) return rc;
+    if ((rc = dev_buf_t(c, "G", (size_t)rows_out * ldg, &d_G))) return rc;
+    if (psi)
+      if ((rc = dev_buf_t(c, "Yaux", (size_t)rows_in * ldg, &d_Yaux))) return rc;
+    // synthesis (+ fused affine map when there is no psi mixing)
+    HIP_TRY(c, launch_dgemm(S, F[0].d_data + g0 * F[0].ld * 2, F[0].ld * 2, F[0].d_B, ldb, d_Y, ldg, rows_in, (int)P2,
+                            F[0].K, psi ? nullptr : d_off, psi ? nullptr : d_scale));
+    if (psi) {
+      for (int a = 0; a < in->n_aux; ++a) {
+        const FieldPlan& f = F[1 + a];
+        HIP_TRY(c, launch_dgemm(S, f.d_data + g0 * f.ld * 2, f.ld * 2, f.d_B, ldb, d_Yaux, ldg, rows_in, (int)P2, f.K,
+                                nullptr, nullptr));
+        HIP_TRY(c, launch_psi_mix(S, d_Y, d_Yaux, ldg, n_pix, rows_in, d_x + g0, d_alpha, d_xa, d_xb, in->aux_coeff[a],
+                                  in->aux_power[a]));
+      }
+      HIP_TRY(c, launch_affine_cols(S, d_Y, ldg, (int)P2, rows_in, d_off, d_scale));
+    }
+    // spline along time on the shared knots, evaluated on the distorted slices
+    HIP_TRY(c, launch_spline_forward(S, d_Y, d_R, ldg, n_pix, g0, rows_in, n, d_x, d_tab, SPLINE_TILE, SPLINE_HALO));
+    HIP_TRY(c, launch_spline_backward_eval(S, d_Y, d_R, ldg, n_pix, g0, rows_in, n, d_x, d_tab, SPLINE_TILE, SPLINE_HALO,
+                                           d_x, d_skewa, d_skewb, T.tt, c0, c1, d_G, ldg));
+    // analysis
+    HIP_TRY(c, launch_dgemm(S, d_G, ldg, d_W, ldw, d_out + (c0 - i_lo) * n_out * 2, 2LL * n_out, rows_out, 2 * n_out,
+                            (int)P2, nullptr, nullptr));
+  }
+  if (in->mem == BMS_HOST)
+    HIP_TRY(c, hipMemcpyAsync(data_out, d_out, (size_t)n_new * n_out * 16, hipMemcpyDeviceToHost, S));
+  // host tables above are stack/vector memory: wait for the uploads (and results) before returning
+  HIP_TRY(c, hipStreamSynchronize(S));
+  return BMS_OK;
+}
+
+// ====================================================================================================== building blocks
+
+extern "C" int bms_rotor_grid(bms_ctx* c, const double fr[4], const double v[3], int n_theta, int n_phi, double* out) {
+  if (!c || !fr || !v || !out) return BMS_ERR_INVALID;
+  if (n_theta < 2 || n_phi < 1) return fail(c, BMS_ERR_INVALID, "bad grid size");
+  std::vector<Quat> R;
+  build_rotor_grid(fr, v, n_theta, n_phi, R);
+  std::memcpy(out, R.data(), sizeof(Quat) * R.size());
+  return BMS_OK;
+}
+
+extern "C" int bms_swsh_grid(bms_ctx* c, const double* rotors, int64_t n, int spin, int ell_min, int ell_max, void* Y) {
+  if (!c || !rotors || !Y) return BMS_ERR_INVALID;
+  HIP_TRY(c, hipSetDevice(c->device));
+  if (n <= 0) return BMS_OK;
+  const size_t nm = LM_total_size(ell_min, ell_max);
+  void* vp;
+  int rc = upload(c, "rotors", rotors, 32 * (size_t)n, &vp);
+  if (rc) return rc;
+  double* dY;
+  if ((rc = dev_buf_t(c, "swsh_vals", (size_t)n * nm * 2, &dY))) return rc;
+  HIP_TRY(c, hipMemsetAsync(dY, 0, 16 * (size_t)n * nm, c->stream));
+  HIP_TRY(c, launch_swsh_values(c->stream, (const double*)vp, (int)n, spin, ell_min, ell_max, dY));
+  HIP_TRY(c, hipMemcpyAsync(Y, dY, 16 * (size_t)n * nm, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  return BMS_OK;
+}
+
+extern "C" int bms_map2salm(bms_ctx* c, const void* grid, int mem, int64_t n_maps, int n_theta, int n_phi, int spin,
+                            int ell_min, int ell_max, void* modes_out) {
+  if (!c || !grid || !modes_out) return BMS_ERR_INVALID;
+  HIP_TRY(c, hipSetDevice(c->device));
+  if (n_theta < 2 || n_phi < 1 || ell_min < 0 || ell_max < ell_min) return fail(c, BMS_ERR_INVALID, "bad sizes");
+  if (n_maps <= 0) return BMS_OK;
+  const int n_pix = n_theta * n_phi, n_out = LM_total_size(ell_min, ell_max);
+  std::vector<double> qth, wpix((size_t)n_pix), rot(4 * (size_t)n_pix);
+  theta_quadrature_weights(n_theta, qth);
+  for (int j = 0; j < n_theta; ++j)
+    for (int k = 0; k < n_phi; ++k) {
+      const int p = j * n_phi + k;
+      wpix[p] = qth[j] / n_phi;
+      const Quat q = from_spherical_coords(M_PI * j / (n_theta - 1), (2 * M_PI) * k / n_phi);
+      rot[4 * p] = q.w, rot[4 * p + 1] = q.x, rot[4 * p + 2] = q.y, rot[4 * p + 3] = q.z;
+    }
+  void *d_rot, *d_w;
+  int rc;
+  if ((rc = upload(c, "grid_rotors", rot.data(), 32 * (size_t)n_pix, &d_rot))) return rc;
+  if ((rc = upload(c, "wpix", wpix.data(), 8 * (size_t)n_pix, &d_w))) return rc;
+  const long long P2 = 2LL * n_pix, ldw = round_up(2LL * n_out, 128), wrows = round_up(P2, 16);
+  double* d_W;
+  if ((rc = dev_buf_t(c, "Wana", (size_t)wrows * ldw, &d_W))) return rc;
+  HIP_TRY(c, hipMemsetAsync(d_W, 0, sizeof(double) * wrows * ldw, c->stream));
+  HIP_TRY(c, launch_quadrature_matrix(c->stream, (const double*)d_rot, (const double*)d_w, n_pix, spin, ell_min, ell_max, d_W, ldw));
+  const double* d_in;
+  if ((rc = stage_in(c, "in_data", grid, mem, (size_t)n_maps * n_pix * 16, &d_in))) return rc;
+  double* d_out = (double*)modes_out;
+  if (mem == BMS_HOST)
+    if ((rc = dev_buf_t(c, "out_data", (size_t)n_maps * n_out * 2, &d_out))) return rc;
+  HIP_TRY(c, launch_dgemm(c->stream, d_in, P2, d_W, ldw, d_out, 2LL * n_out, n_maps, 2 * n_out, (int)P2, nullptr, nullptr));
+  if (mem == BMS_HOST) HIP_TRY(c, hipMemcpyAsync(modes_out, d_out, (size_t)n_maps * n_out * 16, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  return BMS_OK;
+}
+
+extern "C" int bms_cubic_spline(bms_ctx* c, const double* x, int64_t n, const void* y, int64_t ld, int64_t n_cols, int mem,
+                                const double* x_new, int64_t n_new, void* out) {
+  if (!c || !x || !y || !x_new || !out) return BMS_ERR_INVALID;
+  HIP_TRY(c, hipSetDevice(c->device));
+  if (n < 4) return fail(c, BMS_ERR_UNSUPPORTED, "cubic spline needs at least 4 knots, got %lld", (long long)n);
+  if (ld < n_cols || n_cols <= 0) return fail(c, BMS_ERR_INVALID, "bad column count / stride");
+  for (int64_t i = 1; i < n; ++i)
+    if (!(x[i] > x[i - 1])) return fail(c, BMS_ERR_INVALID, "knots must be strictly increasing");
+  for (int64_t i = 1; i < n_new; ++i)
+    if (!(x_new[i] >= x_new[i - 1])) return fail(c, BMS_ERR_INVALID, "evaluation points must be non-decreasing");
+  if (n_new <= 0) return BMS_OK;
+  int rc;
+  void *d_x, *d_xn;
+  if ((rc = upload(c, "times", x, 8 * (size_t)n, &d_x))) return rc;
+  if ((rc = upload(c, "times_new", x_new, 8 * (size_t)n_new, &d_xn))) return rc;
+  const double* d_y;
+  if ((rc = stage_in(c, "in_data", y, mem, (size_t)n * ld * 16, &d_y))) return rc;
+  SplineTable* d_tab;
+  if ((rc = dev_buf_t(c, "spline_table", (size_t)n, &d_tab))) return rc;
+  HIP_TRY(c, launch_spline_table(c->stream, (const double*)d_x, n, d_tab));
+  double* d_R;
+  if ((rc = dev_buf_t(c, "R", (size_t)n * ld * 2, &d_R))) return rc;
+  double* d_out = (double*)out;
+  if (mem == BMS_HOST)
+    if ((rc = dev_buf_t(c, "out_data", (size_t)n_new * n_cols * 2, &d_out))) return rc;
+  HIP_TRY(c, launch_spline_forward(c->stream, d_y, d_R, 2 * ld, (int)n_cols, 0, n, n, (const double*)d_x, d_tab, SPLINE_TILE, SPLINE_HALO));
+  HIP_TRY(c, launch_spline_backward_eval(c->stream, d_y, d_R, 2 * ld, (int)n_cols, 0, n, n, (const double*)d_x, d_tab, SPLINE_TILE,
+                                         SPLINE_HALO, (const double*)d_xn, nullptr, nullptr, 0.0, 0, n_new, d_out, 2 * n_cols));
+  if (mem == BMS_HOST) HIP_TRY(c, hipMemcpyAsync(out, d_out, (size_t)n_new * n_cols * 16, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  return BMS_OK;
+}
+
+// ====================================================================================================== ABD flavour
+extern "C" int bms_transform_abd(bms_ctx* c, const double* u, const void* raw, int mem, int64_t n_times, int ell_max,
+                                 const bms_transformation* tr, double* u_out, void* raw_out, int64_t* n_times_out) {
+  if (!c) return BMS_ERR_INVALID;
+  return fail(c, BMS_ERR_UNSUPPORTED, "bms_transform_abd: not implemented yet");
+}

@@ -1,0 +1,60 @@
+// Launchers of the gfx950 kernels (C++ internal interface between the engine and the kernels).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace bms {
+
+constexpr int ROT_MB = 4;  // mu-block of the packed Delta tables (see kernels_rotate.hip)
+
+// ---- rotation (scri/rotations.py:346-392)
+int rotate_waves_per_block(int ell_max);
+hipError_t launch_rotate_modes(hipStream_t stream, double* data, long long n_times, long long ld, int ell_min, int ell_max,
+                               const double* RaRb, long long rotor_stride, const double* delta,
+                               const long long* delta_off);
+
+// ---- SWSH matrices (sf.SWSH_grid, waveform_grid.py:470-484)
+// Bmat[2k][2p] = Re Y_k(R_p), [2k][2p+1] = Im, [2k+1][2p] = -Im, [2k+1][2p+1] = Re;  k = LM_index(l,m,ell_min)
+hipError_t launch_swsh_matrix(hipStream_t stream, const double* rotors /* f8[n_pix][4] */, int n_pix, int spin,
+                              int ell_min, int ell_max, double* Bmat, long long ldb);
+// analysis (quadrature) matrix: W[p][k] = w_pix[p] conj(Y_k(R_p)) in the real layout with pixels as rows:
+// Wmat[2p][2k] = Re W, [2p][2k+1] = Im W, [2p+1][2k] = -Im W, [2p+1][2k+1] = Re W
+hipError_t launch_quadrature_matrix(hipStream_t stream, const double* rotors, const double* w_pix, int n_pix, int spin,
+                                    int ell_min, int ell_max, double* Wmat, long long ldw);
+// complex values Y[p][k] (row = pixel), for tests / small per-pixel tables
+hipError_t launch_swsh_values(hipStream_t stream, const double* rotors, int n_pix, int spin, int ell_min, int ell_max,
+                              double* Y /* c16[n_pix][n_modes] */);
+
+// ---- dense fp64 GEMM on MFMA: C[M x N] = (A[M x K] * B[K x N] - col_off[N]) * col_scale[N]
+// A row-major (lda), B row-major (ldb, zero padded to a multiple of 128 columns and 16 rows), C row-major (ldc).
+hipError_t launch_dgemm(hipStream_t stream, const double* A, long long lda, const double* B, long long ldb, double* C,
+                        long long ldc, long long M, int N, int K, const double* col_off, const double* col_scale);
+
+// ---- shared-matrix not-a-knot cubic spline along time (waveform_grid.py:574-588)
+struct SplineTable {  // per knot j
+  double P, Q, A, C;  // r'_j = P (y_j - y_{j-1}) + Q (y_{j+1} - y_j) - A r'_{j-1};  s_j = r'_j - C s_{j+1}
+};
+hipError_t launch_spline_table(hipStream_t stream, const double* x, long long n, SplineTable* table);
+// forward elimination over rows [row_lo, row_hi) of the knot axis; Y, R are [rows][ld] doubles holding
+// global rows g0.. (row index r maps to knot g0 + r)
+hipError_t launch_spline_forward(hipStream_t stream, const double* Y, double* R, long long ld, int n_cols /* complex */,
+                                 long long g0, long long n_rows, long long n_knots, const double* x,
+                                 const SplineTable* table, int tile, int halo);
+// back substitution + evaluation at u_eval(i) = base_i + skew_a[p] (base_i - tt) + skew_b[p] for output rows
+// i in [i_lo, i_hi) (indices into base); out row index = i - i_lo.  skew_a/skew_b may be NULL (= 0).
+hipError_t launch_spline_backward_eval(hipStream_t stream, const double* Y, const double* R, long long ld, int n_cols,
+                                       long long g0, long long n_rows, long long n_knots, const double* x,
+                                       const SplineTable* table, int tile, int halo, const double* base,
+                                       const double* skew_a, const double* skew_b, double tt, long long i_lo,
+                                       long long i_hi, double* out, long long ldo);
+
+// ---- pointwise helpers
+// Y[t][p] += coeff * Yaux[t][p] * X[t][p]^power,  X = (x_t - alpha_p) * xa_p - xb_p   (waveform_grid.py:516-550)
+hipError_t launch_psi_mix(hipStream_t stream, double* Y, const double* Yaux, long long ld, int n_pix, long long n_rows,
+                          const double* x /* times of the rows */, const double* alpha, const double* xa /* c16[n_pix] */,
+                          const double* xb /* c16[n_pix] */, double coeff, int power);
+// y[t][col] = (y[t][col] - off[col]) * scale[col]
+hipError_t launch_affine_cols(hipStream_t stream, double* Y, long long ld, int n_cols, long long n_rows,
+                              const double* off, const double* scale);
+
+}  // namespace bms

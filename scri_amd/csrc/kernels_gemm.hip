@@ -1,0 +1,158 @@
+// Dense fp64 contraction on the CDNA4 matrix cores: the mode x harmonic synthesis
+// (np.tensordot at scri/waveform_grid.py:475-484; sf.Modes.evaluate at
+// scri/asymptotic_bondi_data/transformations.py:324-334) and the dense quadrature analysis
+// (spinsfast.map2salm at scri/waveform_grid.py:303-307) both run through this kernel.
+//
+// The complex product over interleaved (re, im) data is a *real* GEMM against the 2K x 2N matrices built by
+// kernels_swsh.hip, so one kernel, no complex arithmetic, no wasted MFMA work:
+//     C[M x N] = (A[M x K] . B[K x N] - col_off[N]) * col_scale[N]          (all fp64, row-major)
+//
+// v_mfma_f64_16x16x4_f64 (64 cycles / 2048 flop per SIMD => 78.6 TFLOP/s chip peak): per lane one f64 of
+// A[i = lane&15][k = lane>>4], one of B[k = lane>>4][j = lane&15], 4 results D[row = (lane>>4) + 4 r][col = lane&15].
+// Workgroup tile 128 x 128 x 16, 4 wavefronts (2 x 2), 64 x 64 per wavefront = 16 independent accumulator tiles;
+// operands are staged global -> registers -> LDS with a two-deep LDS ring (one barrier per K-step); the LDS
+// pitches (A rows 18 doubles, B rows 144 doubles) make every ds_read_b64 fragment read conflict free.
+// Blocks are dealt so that all column-blocks of one 128-row slab of A run on one XCD (its L2 then serves
+// the 20-fold re-read of the slab); B (<= a few tens of MB) lives in L2 / Infinity Cache.
+#include "kernels.h"
+
+namespace bms {
+
+typedef double v4d __attribute__((ext_vector_type(4)));
+
+constexpr int G_BM = 128, G_BN = 128, G_BK = 16;
+constexpr int G_LDA = G_BK + 2;    // LDS pitch of an A row (doubles)
+constexpr int G_LDB = G_BN + 16;   // LDS pitch of a B row (doubles)
+constexpr int G_ASZ = G_BM * G_LDA;
+constexpr int G_BSZ = G_BK * G_LDB;
+
+__global__ __launch_bounds__(256, 2) void dgemm_mfma_kernel(const double* __restrict__ A, long long lda,
+                                                            const double* __restrict__ B, long long ldb,
+                                                            double* __restrict__ C, long long ldc, long long M, int N,
+                                                            int K, int nbm, int nbn,
+                                                            const double* __restrict__ col_off,
+                                                            const double* __restrict__ col_scale) {
+  __shared__ __attribute__((aligned(16))) double lds[2 * G_ASZ + 2 * G_BSZ];
+  double* As = lds;
+  double* Bs = lds + 2 * G_ASZ;
+
+  // XCD-aware block -> tile map: blocks b and b+8 share an XCD; give each XCD whole row slabs.
+  const int b = blockIdx.x;
+  const int xcd = b & 7;
+  const int q = b >> 3;
+  const int bm = (q / nbn) * 8 + xcd;
+  const int bn = q % nbn;
+  if (bm >= nbm) return;
+  const long long m0 = (long long)bm * G_BM;
+  const int n0 = bn * G_BN;
+
+  const int tid = threadIdx.x;
+  const int wave = tid >> 6, lane = tid & 63;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int fi = lane & 15, fk = lane >> 4;
+
+  v4d acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = v4d{0.0, 0.0, 0.0, 0.0};
+
+  double2 ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3;
+  const int nk = (K + G_BK - 1) / G_BK;
+  // staging maps: A tile 128 rows x 8 double2 (thread -> row = idx>>3, chunk = idx&7);
+  //               B tile 16 rows x 64 double2 (thread -> row = idx>>6, chunk = idx&63)
+  const int a_row = tid >> 3, a_ch = tid & 7;   // + 32 rows per pass
+  const int b_row = tid >> 6, b_ch = tid & 63;  // + 4 rows per pass
+  const double* a_ptr = A + (m0 + a_row) * lda + 2 * a_ch;
+  const double* b_ptr = B + (long long)b_row * ldb + n0 + 2 * b_ch;
+  const bool a_ok0 = (m0 + a_row) < M, a_ok1 = (m0 + a_row + 32) < M, a_ok2 = (m0 + a_row + 64) < M,
+             a_ok3 = (m0 + a_row + 96) < M;
+  const double2 zero2 = {0.0, 0.0};
+
+#define G_LOAD_GLOBAL(kt)                                                                              \
+  {                                                                                                    \
+    const int k0 = (kt)*G_BK;                                                                          \
+    const bool kok = (k0 + 2 * a_ch) < K;                                                              \
+    ra0 = (a_ok0 && kok) ? *reinterpret_cast<const double2*>(a_ptr + k0) : zero2;                      \
+    ra1 = (a_ok1 && kok) ? *reinterpret_cast<const double2*>(a_ptr + 32 * lda + k0) : zero2;           \
+    ra2 = (a_ok2 && kok) ? *reinterpret_cast<const double2*>(a_ptr + 64 * lda + k0) : zero2;           \
+    ra3 = (a_ok3 && kok) ? *reinterpret_cast<const double2*>(a_ptr + 96 * lda + k0) : zero2;           \
+    const double* bp = b_ptr + (long long)k0 * ldb;                                                    \
+    rb0 = *reinterpret_cast<const double2*>(bp);                                                       \
+    rb1 = *reinterpret_cast<const double2*>(bp + 4 * ldb);                                             \
+    rb2 = *reinterpret_cast<const double2*>(bp + 8 * ldb);                                             \
+    rb3 = *reinterpret_cast<const double2*>(bp + 12 * ldb);                                            \
+  }
+#define G_STORE_LDS(buf)                                                                               \
+  {                                                                                                    \
+    double* as_w = As + (buf)*G_ASZ + a_row * G_LDA + 2 * a_ch;                                        \
+    *reinterpret_cast<double2*>(as_w) = ra0;                                                           \
+    *reinterpret_cast<double2*>(as_w + 32 * G_LDA) = ra1;                                              \
+    *reinterpret_cast<double2*>(as_w + 64 * G_LDA) = ra2;                                              \
+    *reinterpret_cast<double2*>(as_w + 96 * G_LDA) = ra3;                                              \
+    double* bs_w = Bs + (buf)*G_BSZ + b_row * G_LDB + 2 * b_ch;                                        \
+    *reinterpret_cast<double2*>(bs_w) = rb0;                                                           \
+    *reinterpret_cast<double2*>(bs_w + 4 * G_LDB) = rb1;                                               \
+    *reinterpret_cast<double2*>(bs_w + 8 * G_LDB) = rb2;                                               \
+    *reinterpret_cast<double2*>(bs_w + 12 * G_LDB) = rb3;                                              \
+  }
+
+  G_LOAD_GLOBAL(0);
+  G_STORE_LDS(0);
+  __syncthreads();
+
+  for (int kt = 0; kt < nk; ++kt) {
+    const int buf = kt & 1;
+    if (kt + 1 < nk) G_LOAD_GLOBAL(kt + 1);
+    const double* as = As + buf * G_ASZ + (wm * 64 + fi) * G_LDA + fk;
+    const double* bs = Bs + buf * G_BSZ + fk * G_LDB + wn * 64 + fi;
+#pragma unroll
+    for (int kk = 0; kk < G_BK / 4; ++kk) {
+      double a[4], bb[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) a[i] = as[i * 16 * G_LDA + kk * 4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) bb[j] = bs[kk * 4 * G_LDB + j * 16];
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], bb[j], acc[i][j], 0, 0, 0);
+    }
+    if (kt + 1 < nk) G_STORE_LDS(buf ^ 1);
+    __syncthreads();
+  }
+
+  // epilogue: affine per-column map (type-specific inhomogeneous term and conformal factor,
+  // scri/waveform_grid.py:485-503,559) fused into the store
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int col = n0 + wn * 64 + j * 16 + fi;
+    if (col >= N) continue;
+    const double off = col_off ? col_off[col] : 0.0;
+    const double sc = col_scale ? col_scale[col] : 1.0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const long long row = m0 + wm * 64 + i * 16 + fk + 4 * r;
+        if (row < M) C[row * ldc + col] = (acc[i][j][r] - off) * sc;
+      }
+    }
+  }
+}
+
+#undef G_LOAD_GLOBAL
+#undef G_STORE_LDS
+
+hipError_t launch_dgemm(hipStream_t stream, const double* A, long long lda, const double* B, long long ldb, double* C,
+                        long long ldc, long long M, int N, int K, const double* col_off, const double* col_scale) {
+  if (M <= 0 || N <= 0) return hipSuccess;
+  const int nbm = (int)((M + G_BM - 1) / G_BM);
+  const int nbn = (N + G_BN - 1) / G_BN;
+  const long long grid = (long long)((nbm + 7) / 8) * 8 * nbn;
+  hipLaunchKernelGGL(dgemm_mfma_kernel, dim3((unsigned)grid), dim3(256), 0, stream, A, lda, B, ldb, C, ldc, M, N, K, nbm,
+                     nbn, col_off, col_scale);
+  return hipGetLastError();
+}
+
+}  // namespace bms

@@ -1,0 +1,148 @@
+// Spin-weighted spherical harmonics at a grid of rotors: the matrices the dense synthesis contracts with
+// (sf.SWSH_grid at scri/waveform_grid.py:470-471; sf.Modes.evaluate at
+// scri/asymptotic_bondi_data/transformations.py:324-334).
+//
+// One thread per (pixel, m): a single l-chain of the Wigner small-d recurrence gives
+// sYlm(R_p) = (-1)^s sqrt((2l+1)/4pi) ea^(m-s) eb^(-s-m) d^l_{m,-s}(ra, rb) for every l at once.
+// The matrix is written directly in the *real* layout the fp64 MFMA GEMM consumes: the complex product
+// (ar + i ai)(yr + i yi) over interleaved (re, im) data is the real product of the row [ar ai] with
+//   | yr  yi |
+//   |-yi  yr |
+// so row 2k holds (yr, yi) and row 2k+1 holds (-yi, yr) at columns (2p, 2p+1).
+#include "wigner.h"
+#include "kernels.h"
+
+namespace bms {
+
+// MODE 0: complex values Y[p][k]; MODE 1: synthesis matrix (modes as rows); MODE 2: quadrature matrix (pixels as rows)
+template <int MODE>
+__global__ __launch_bounds__(256) void swsh_kernel(const double* __restrict__ rotors, const double* __restrict__ w_pix,
+                                                   int n_pix, int spin, int ell_min, int ell_max,
+                                                   double* __restrict__ out, long long ldb) {
+  const int nm = 2 * ell_max + 1;
+  const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= (long long)n_pix * nm) return;
+  // consecutive threads -> consecutive pixels (coalesced matrix rows)
+  const int p = (int)(gid % n_pix);
+  const int m = (int)(gid / n_pix) - ell_max;
+  const double* q = rotors + 4LL * p;
+  cplx Ra = {q[0], q[3]}, Rb = {q[2], q[1]};
+  double ra, rb;
+  cplx ea, eb;
+  spinor_polar(Ra, Rb, ra, rb, ea, eb);
+  const cplx phase = cmul(cpow_unit(ea, m - spin), cpow_unit(eb, -spin - m));
+  const double sgn = (spin & 1) ? -1.0 : 1.0;
+  DChain ch;
+  ch.init(m, -spin, ra, rb);
+  const int n_modes = LM_total_size(ell_min, ell_max);
+  for (int ell = ch.ell; ell <= ell_max; ++ell) {
+    if (ell >= ell_min) {
+      const double a = sgn * sqrt((2.0 * ell + 1.0) / (4.0 * M_PI)) * ch.value();
+      const double yr = a * phase.re, yi = a * phase.im;
+      const long long k = LM_index(ell, m, ell_min);
+      if (MODE == 1) {
+        double* r0 = out + (2 * k) * ldb + 2LL * p;
+        double* r1 = r0 + ldb;
+        r0[0] = yr;
+        r0[1] = yi;
+        r1[0] = -yi;
+        r1[1] = yr;
+      } else if (MODE == 2) {
+        const double w = w_pix[p];
+        const double wr = w * yr, wi = -w * yi;  // w conj(Y)
+        double* r0 = out + (2LL * p) * ldb + 2 * k;
+        double* r1 = r0 + ldb;
+        r0[0] = wr;
+        r0[1] = wi;
+        r1[0] = -wi;
+        r1[1] = wr;
+      } else {
+        out[((long long)p * n_modes + k) * 2] = yr;
+        out[((long long)p * n_modes + k) * 2 + 1] = yi;
+      }
+    }
+    if (ell < ell_max) ch.next();
+  }
+}
+
+hipError_t launch_swsh_matrix(hipStream_t stream, const double* rotors, int n_pix, int spin, int ell_min, int ell_max,
+                              double* Bmat, long long ldb) {
+  const long long n = (long long)n_pix * (2 * ell_max + 1);
+  if (n <= 0) return hipSuccess;
+  hipLaunchKernelGGL(swsh_kernel<1>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, rotors,
+                     (const double*)nullptr, n_pix, spin, ell_min, ell_max, Bmat, ldb);
+  return hipGetLastError();
+}
+
+hipError_t launch_quadrature_matrix(hipStream_t stream, const double* rotors, const double* w_pix, int n_pix, int spin,
+                                    int ell_min, int ell_max, double* Wmat, long long ldw) {
+  const long long n = (long long)n_pix * (2 * ell_max + 1);
+  if (n <= 0) return hipSuccess;
+  hipLaunchKernelGGL(swsh_kernel<2>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, rotors, w_pix, n_pix, spin,
+                     ell_min, ell_max, Wmat, ldw);
+  return hipGetLastError();
+}
+
+hipError_t launch_swsh_values(hipStream_t stream, const double* rotors, int n_pix, int spin, int ell_min, int ell_max,
+                              double* Y) {
+  const long long n = (long long)n_pix * (2 * ell_max + 1);
+  if (n <= 0) return hipSuccess;
+  hipLaunchKernelGGL(swsh_kernel<0>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, rotors,
+                     (const double*)nullptr, n_pix, spin, ell_min, ell_max, Y, 0);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------- pointwise
+
+__global__ __launch_bounds__(256) void psi_mix_kernel(double* __restrict__ Y, const double* __restrict__ Yaux,
+                                                      long long ld, int n_pix, long long n_rows,
+                                                      const double* __restrict__ x, const double* __restrict__ alpha,
+                                                      const double* __restrict__ xa, const double* __restrict__ xb,
+                                                      double coeff, int power) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n_pix) return;
+  const double al = alpha[p];
+  const cplx a = {xa[2 * p], xa[2 * p + 1]}, b = {xb[2 * p], xb[2 * p + 1]};
+  for (long long r = blockIdx.y; r < n_rows; r += gridDim.y) {
+    const double dt = x[r] - al;
+    cplx X = {dt * a.re - b.re, dt * a.im - b.im};
+    cplx Xn = X;
+    for (int i = 1; i < power; ++i) Xn = cmul(Xn, X);
+    const double2 f = *reinterpret_cast<const double2*>(Yaux + r * ld + 2LL * p);
+    cplx v = cmul(cplx{f.x, f.y}, Xn);
+    double2* y = reinterpret_cast<double2*>(Y + r * ld + 2LL * p);
+    double2 cur = *y;
+    cur.x += coeff * v.re;
+    cur.y += coeff * v.im;
+    *y = cur;
+  }
+}
+
+hipError_t launch_psi_mix(hipStream_t stream, double* Y, const double* Yaux, long long ld, int n_pix, long long n_rows,
+                          const double* x, const double* alpha, const double* xa, const double* xb, double coeff,
+                          int power) {
+  if (n_rows <= 0 || n_pix <= 0) return hipSuccess;
+  dim3 grid((n_pix + 255) / 256, (unsigned)(n_rows < 4096 ? n_rows : 4096));
+  hipLaunchKernelGGL(psi_mix_kernel, grid, dim3(256), 0, stream, Y, Yaux, ld, n_pix, n_rows, x, alpha, xa, xb, coeff,
+                     power);
+  return hipGetLastError();
+}
+
+__global__ __launch_bounds__(256) void affine_cols_kernel(double* __restrict__ Y, long long ld, int n_cols,
+                                                          long long n_rows, const double* __restrict__ off,
+                                                          const double* __restrict__ scale) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= n_cols) return;
+  const double o = off[c], s = scale[c];
+  for (long long r = blockIdx.y; r < n_rows; r += gridDim.y) Y[r * ld + c] = (Y[r * ld + c] - o) * s;
+}
+
+hipError_t launch_affine_cols(hipStream_t stream, double* Y, long long ld, int n_cols, long long n_rows,
+                              const double* off, const double* scale) {
+  if (n_rows <= 0 || n_cols <= 0) return hipSuccess;
+  dim3 grid((n_cols + 255) / 256, (unsigned)(n_rows < 4096 ? n_rows : 4096));
+  hipLaunchKernelGGL(affine_cols_kernel, grid, dim3(256), 0, stream, Y, ld, n_cols, n_rows, off, scale);
+  return hipGetLastError();
+}
+
+}  // namespace bms

@@ -1,0 +1,255 @@
+"""numpy-level wrappers of the C ABI (one function per exported entry point).
+
+These take and return plain numpy arrays (host memory) or, with `device=True`, raw device
+pointers (ints, e.g. ``torch.Tensor.data_ptr()``) for callers that keep data resident in HBM.
+The scri-compatible classes in ``scri_amd.waveform_modes`` etc. are built on top of these.
+"""
+import ctypes
+import numpy as np
+
+from . import _lib
+from ._lib import (
+    BMS_HOST,
+    BMS_DEVICE,
+    BMS_TERM_NONE,
+    BMS_TERM_H,
+    BMS_TERM_SIGMA,
+    BMS_TERM_PSI,
+    bms_wm_input,
+    bms_transformation,
+    c_i64,
+    c_vp,
+    dptr,
+    vptr,
+)
+
+
+def _ctx(ctx):
+    return ctx if ctx is not None else _lib.default_context()
+
+
+def LM_total_size(ell_min, ell_max):
+    return (ell_max + 1) ** 2 - ell_min**2
+
+
+def LM_index(ell, m, ell_min):
+    return ell * (ell + 1) - ell_min**2 + m
+
+
+def total_size_D_matrices(ell_min, ell_max):
+    f = lambda l: (4 * l**3 - l) // 3
+    return f(ell_max + 1) - f(ell_min)
+
+
+# ---------------------------------------------------------------------------------- rotation
+
+
+def rotate_const(data, ell_min, ell_max, quaternion, ctx=None):
+    """In place: data[t, l, m] <- sum_m' data[t, l, m'] D^l_{m',m}(q)   (scri/rotations.py:346-367).
+    `data`: C-contiguous complex128 [N, >= n_modes] numpy array."""
+    ctx = _ctx(ctx)
+    assert data.dtype == np.complex128 and data.ndim == 2 and data.strides[1] == 16
+    q = np.ascontiguousarray(quaternion, dtype=float)
+    rc = _lib.load().bms_rotate_const(
+        ctx.handle, vptr(data), BMS_HOST, data.shape[0], data.strides[0] // 16, ell_min, ell_max, dptr(q)
+    )
+    ctx.check(rc, "bms_rotate_const")
+    return data
+
+
+def rotate_series(data, ell_min, ell_max, spinors, ctx=None):
+    """In place, one rotor per time step; spinors complex128 [N, 2] = (w + i z, y + i x)
+    (scri/rotations.py:370-392)."""
+    ctx = _ctx(ctx)
+    assert data.dtype == np.complex128 and data.ndim == 2 and data.strides[1] == 16
+    sp = np.ascontiguousarray(spinors, dtype=np.complex128)
+    if sp.shape != (data.shape[0], 2):
+        raise ValueError(f"spinors must have shape ({data.shape[0]}, 2), got {sp.shape}")
+    rc = _lib.load().bms_rotate_series(
+        ctx.handle, vptr(data), BMS_HOST, data.shape[0], data.strides[0] // 16, ell_min, ell_max, vptr(sp)
+    )
+    ctx.check(rc, "bms_rotate_series")
+    return data
+
+
+def rotate_device(data_ptr, n_times, ld, ell_min, ell_max, spinors_ptr=None, quaternion=None, ctx=None):
+    """Device-resident variant: data_ptr / spinors_ptr are device addresses."""
+    ctx = _ctx(ctx)
+    lib = _lib.load()
+    if spinors_ptr is not None:
+        rc = lib.bms_rotate_series(ctx.handle, c_vp(data_ptr), BMS_DEVICE, n_times, ld, ell_min, ell_max, c_vp(spinors_ptr))
+        ctx.check(rc, "bms_rotate_series")
+    else:
+        q = np.ascontiguousarray(quaternion, dtype=float)
+        rc = lib.bms_rotate_const(ctx.handle, c_vp(data_ptr), BMS_DEVICE, n_times, ld, ell_min, ell_max, dptr(q))
+        ctx.check(rc, "bms_rotate_const")
+
+
+def wigner_D(quaternion, ell_min, ell_max, ctx=None):
+    """Packed D^l_{m',m}(q), layout of sf.Wigner_D_matrices."""
+    ctx = _ctx(ctx)
+    q = np.ascontiguousarray(quaternion, dtype=float)
+    D = np.zeros(total_size_D_matrices(ell_min, ell_max), dtype=np.complex128)
+    ctx.check(_lib.load().bms_wigner_D(ctx.handle, dptr(q), ell_min, ell_max, vptr(D)), "bms_wigner_D")
+    return D
+
+
+# ---------------------------------------------------------------------------------- transform
+
+
+def make_transformation(supertranslation, frame_rotation, boost_velocity, n_theta, n_phi, ell_max_out):
+    st = np.ascontiguousarray(supertranslation, dtype=np.complex128)
+    lst = int(round(np.sqrt(st.size))) - 1
+    if (lst + 1) ** 2 != st.size or lst < 1:
+        raise ValueError("supertranslation must hold (L+1)^2 modes with L >= 1")
+    tr = bms_transformation()
+    tr.supertranslation = st.ctypes.data
+    tr.ell_max_supertranslation = lst
+    tr.frame_rotation[:] = [float(x) for x in frame_rotation]
+    tr.boost_velocity[:] = [float(x) for x in boost_velocity]
+    tr.n_theta, tr.n_phi, tr.ell_max_out = int(n_theta), int(n_phi), int(ell_max_out)
+    tr._keep = st  # keep the array alive
+    return tr
+
+
+def transform_modes(
+    t,
+    data,
+    ell_min,
+    ell_max,
+    spin_weight,
+    conformal_weight,
+    type_term,
+    transformation,
+    aux=(),
+    ctx=None,
+    device=False,
+    ld=None,
+    out_ptr=None,
+):
+    """bms_transform_modes.  Host mode: data complex128 [N, n_modes] -> (t_out[N'], data_out[N', n_out]).
+    Device mode (device=True): `data` and each aux data are device addresses, `ld` the row stride,
+    `out_ptr` a device buffer of N * n_out complex; returns (t_out[N'], N').
+    aux: sequence of (data, ell_min, ell_max, spin, coeff, power[, ld])."""
+    ctx = _ctx(ctx)
+    t = np.ascontiguousarray(t, dtype=float)
+    n = t.shape[0]
+    inp = bms_wm_input()
+    inp.n_times = n
+    inp.t = dptr(t)
+    keep = [t]
+    if device:
+        inp.data = int(data)
+        inp.ld = int(ld)
+        inp.mem = BMS_DEVICE
+    else:
+        data = _lib.as_c16(data)
+        if data.shape != (n, LM_total_size(ell_min, ell_max)):
+            raise ValueError(f"data shape {data.shape} inconsistent with n_times={n}, ell range [{ell_min}, {ell_max}]")
+        inp.data = data.ctypes.data
+        inp.ld = data.shape[1]
+        inp.mem = BMS_HOST
+        keep.append(data)
+    inp.ell_min, inp.ell_max = int(ell_min), int(ell_max)
+    inp.spin_weight, inp.conformal_weight, inp.type_term = int(spin_weight), int(conformal_weight), int(type_term)
+    inp.n_aux = len(aux)
+    for i, a in enumerate(aux):
+        adata, amin, amax, aspin, acoeff, apower = a[:6]
+        if device:
+            inp.aux_data[i] = int(adata)
+            inp.aux_ld[i] = int(a[6])
+        else:
+            adata = _lib.as_c16(adata)
+            if adata.shape != (n, LM_total_size(amin, amax)):
+                raise ValueError("auxiliary data shape mismatch")
+            keep.append(adata)
+            inp.aux_data[i] = adata.ctypes.data
+            inp.aux_ld[i] = adata.shape[1]
+        inp.aux_ell_min[i], inp.aux_ell_max[i], inp.aux_spin[i] = int(amin), int(amax), int(aspin)
+        inp.aux_coeff[i], inp.aux_power[i] = float(acoeff), int(apower)
+    s = abs(int(spin_weight))
+    n_out = LM_total_size(s, transformation.ell_max_out)
+    t_out = np.empty(n, dtype=float)
+    n_new = c_i64(0)
+    if device:
+        rc = _lib.load().bms_transform_modes(
+            ctx.handle, ctypes.byref(inp), ctypes.byref(transformation), dptr(t_out), c_vp(int(out_ptr)), ctypes.byref(n_new)
+        )
+        ctx.check(rc, "bms_transform_modes")
+        return t_out[: n_new.value], n_new.value
+    out = np.empty((n, n_out), dtype=np.complex128)
+    rc = _lib.load().bms_transform_modes(
+        ctx.handle, ctypes.byref(inp), ctypes.byref(transformation), dptr(t_out), vptr(out), ctypes.byref(n_new)
+    )
+    ctx.check(rc, "bms_transform_modes")
+    return t_out[: n_new.value].copy(), out[: n_new.value].copy()
+
+
+def transform_abd(u, raw, ell_max, transformation, ctx=None):
+    """bms_transform_abd (host arrays): raw complex128 [6, N, (ell_max+1)^2] -> (u_out[N'], raw_out[6, N', n_out])."""
+    ctx = _ctx(ctx)
+    u = np.ascontiguousarray(u, dtype=float)
+    raw = _lib.as_c16(raw)
+    n = u.shape[0]
+    if raw.shape != (6, n, (ell_max + 1) ** 2):
+        raise ValueError(f"raw shape {raw.shape} inconsistent")
+    n_out = (transformation.ell_max_out + 1) ** 2
+    out = np.empty((6, n, n_out), dtype=np.complex128)
+    u_out = np.empty(n, dtype=float)
+    n_new = c_i64(0)
+    rc = _lib.load().bms_transform_abd(
+        ctx.handle, dptr(u), vptr(raw), BMS_HOST, n, int(ell_max), ctypes.byref(transformation), dptr(u_out), vptr(out), ctypes.byref(n_new)
+    )
+    ctx.check(rc, "bms_transform_abd")
+    return u_out[: n_new.value].copy(), out[:, : n_new.value].copy()
+
+
+# ---------------------------------------------------------------------------------- building blocks
+
+
+def rotor_grid(frame_rotation, boost_velocity, n_theta, n_phi, ctx=None):
+    ctx = _ctx(ctx)
+    fr = np.ascontiguousarray(frame_rotation, dtype=float)
+    v = np.ascontiguousarray(boost_velocity, dtype=float)
+    out = np.empty((n_theta, n_phi, 4))
+    ctx.check(_lib.load().bms_rotor_grid(ctx.handle, dptr(fr), dptr(v), n_theta, n_phi, dptr(out)), "bms_rotor_grid")
+    return out
+
+
+def swsh_grid(rotors, spin, ell_min, ell_max, ctx=None):
+    ctx = _ctx(ctx)
+    R = np.ascontiguousarray(rotors, dtype=float)
+    shape = R.shape[:-1]
+    R2 = R.reshape(-1, 4)
+    out = np.zeros((R2.shape[0], LM_total_size(ell_min, ell_max)), dtype=np.complex128)
+    ctx.check(_lib.load().bms_swsh_grid(ctx.handle, dptr(R2), R2.shape[0], spin, ell_min, ell_max, vptr(out)), "bms_swsh_grid")
+    return out.reshape(shape + (out.shape[1],))
+
+
+def map2salm(grid, spin, ell_max, ell_min=0, ctx=None):
+    """spinsfast.map2salm(grid[..., n_theta, n_phi], s, ell_max)[..., ell_min^2:]."""
+    ctx = _ctx(ctx)
+    g = _lib.as_c16(grid)
+    n_theta, n_phi = g.shape[-2:]
+    lead = g.shape[:-2]
+    g2 = g.reshape(-1, n_theta * n_phi)
+    out = np.empty((g2.shape[0], LM_total_size(ell_min, ell_max)), dtype=np.complex128)
+    rc = _lib.load().bms_map2salm(ctx.handle, vptr(g2), BMS_HOST, g2.shape[0], n_theta, n_phi, spin, ell_min, ell_max, vptr(out))
+    ctx.check(rc, "bms_map2salm")
+    return out.reshape(lead + (out.shape[1],))
+
+
+def cubic_spline(x, y, x_new, ctx=None):
+    """scipy.interpolate.CubicSpline(x, y)(x_new) for complex y[N, ...] (axis 0 = time)."""
+    ctx = _ctx(ctx)
+    x = np.ascontiguousarray(x, dtype=float)
+    xn = np.ascontiguousarray(x_new, dtype=float)
+    y = _lib.as_c16(y)
+    tail = y.shape[1:]
+    y2 = y.reshape(y.shape[0], -1)
+    out = np.empty((xn.shape[0], y2.shape[1]), dtype=np.complex128)
+    rc = _lib.load().bms_cubic_spline(
+        ctx.handle, dptr(x), x.shape[0], vptr(y2), y2.shape[1], y2.shape[1], BMS_HOST, dptr(xn), xn.shape[0], vptr(out)
+    )
+    ctx.check(rc, "bms_cubic_spline")
+    return out.reshape((xn.shape[0],) + tail)

@@ -1,0 +1,69 @@
+"""Rotation of the decomposition basis of WaveformModes objects (scri/rotations.py:268-343).
+The per-time-step Wigner-D evaluation and mode mixing run in the HIP kernel
+``rotate_modes_kernel`` (scri_amd/csrc/kernels_rotate.hip) through ``bms_rotate_const`` /
+``bms_rotate_series``."""
+import numpy as np
+
+from . import engine, quaternions
+
+
+def rotate_physical_system(W, R_phys):
+    """Rotate a Waveform in place: rotate the decomposition basis by the inverse rotor(s)
+    (scri/rotations.py:268-281)."""
+    Rf = quaternions.as_float_array(R_phys)
+    W = rotate_decomposition_basis(W, quaternions.like_input(quaternions.conjugate(Rf), R_phys))
+    W._append_history(f"{W}.rotate_physical_system({R_phys})")
+    return W
+
+
+def rotate_decomposition_basis(W, R_basis):
+    """Rotate a Waveform in place (scri/rotations.py:284-343).
+
+    `R_basis`: a quaternion, or a list/array of 1 or n_times quaternions (np.quaternion objects or
+    float components [..., 4]).  The change of basis is recorded in `W.frame` by right-multiplication.
+    """
+    is_q_obj = quaternions.is_quaternion_object(R_basis)
+    if isinstance(R_basis, (list, tuple)) and len(R_basis) and not np.isscalar(R_basis[0]):
+        R = quaternions.as_float_array(list(R_basis))
+    else:
+        R = quaternions.as_float_array(R_basis)
+    # a length-1 iterable is a single rotor (rotations.py:301-302)
+    if R.ndim == 2 and R.shape[0] == 1:
+        R = R[0]
+    if R.ndim > 2:
+        raise ValueError("Input dimension mismatch.  R_basis.shape={}".format(R.shape[:-1]))
+    if not W.data.flags.c_contiguous:
+        W.data = np.ascontiguousarray(W.data)
+    if R.ndim == 2:
+        if W.n_times != R.shape[0]:
+            raise ValueError(
+                "Input dimension mismatch.  (W.n_times={}) != (len(R_basis)={})".format(W.n_times, R.shape[0])
+            )
+        engine.rotate_series(W.data, W.ell_min, W.ell_max, quaternions.as_spinor_array(R), ctx=W._ctx)
+        # right-multiplication (rotations.py:313-321)
+        if W.frame.size:
+            W.frame = quaternions.multiply(W.frame, R)  # broadcasts a single frame element
+        else:
+            W.frame = np.copy(R)
+    else:
+        engine.rotate_const(W.data, W.ell_min, W.ell_max, R, ctx=W._ctx)
+        if W.frame.size:
+            W.frame = quaternions.multiply(W.frame, R)
+        else:
+            W.frame = np.array([R])
+    opts = np.get_printoptions()
+    np.set_printoptions(threshold=6)
+    W._append_history(f"{W}.rotate_decomposition_basis({R_basis if is_q_obj else R})")
+    np.set_printoptions(**opts)
+    return W
+
+
+def to_inertial_frame(W):
+    """Undo the rotations recorded in W.frame (scri/rotations.py:106-111)."""
+    from . import Inertial
+
+    if W.frame.size:
+        W = rotate_decomposition_basis(W, quaternions.conjugate(W.frame))
+    W.frameType = Inertial
+    W._append_history(f"{W}.to_inertial_frame()")
+    return W

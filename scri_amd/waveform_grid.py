@@ -1,0 +1,230 @@
+"""BMS transformation of WaveformModes: host-side mirror of ``process_transformation_kwargs``
+(scri/waveform_grid.py:20-127) and of ``WaveformGrid.transform`` (scri/waveform_grid.py:615-630).
+
+Only the parsing/validation of the keyword arguments happens here (same names, precedence, error
+types and messages as the reference); the rotor grid, the SWSH synthesis, the conformal factor and
+inhomogeneous terms, the per-pixel cubic-spline interpolation in retarded time and the SWSH analysis
+(scri/waveform_grid.py:130-174, 470-613, 274-329) run on the GPU behind ``bms_transform_modes``.
+"""
+import math
+import pprint
+import warnings
+
+import numpy as np
+from scipy.special import comb
+
+from . import engine, quaternions
+from . import Inertial, DataNames, h, sigma, psi0, psi1, psi2, psi3, psi4, hdot, news
+from .mode_algebra import (
+    LM_index,
+    constant_as_ell_0_mode,
+    constant_from_ell_0_mode,
+    vector_as_ell_1_modes,
+    vector_from_ell_1_modes,
+)
+
+
+def _parse_translations(kwargs, impose_reality):
+    """Supertranslation / translation arguments, identical in the two flavours except that the
+    WaveformModes flavour *checks* reality (waveform_grid.py:46-58) while the ABD flavour *imposes* it
+    (asymptotic_bondi_data/transformations.py:36-44)."""
+    supertranslation = np.zeros((4,), dtype=complex)
+    ell_max_supertranslation = 1
+    if "supertranslation" in kwargs:
+        supertranslation = np.array(kwargs.pop("supertranslation"), dtype=complex)
+        if supertranslation.dtype != "complex" and supertranslation.size > 0:
+            raise TypeError(
+                "\nInput argument `supertranslation` should be a complex array with size>0.\n"
+                "Got a {} array of shape {}.".format(supertranslation.dtype, supertranslation.shape)
+            )
+        if supertranslation.size <= 4:
+            supertranslation = np.pad(
+                supertranslation, (0, 4 - supertranslation.size), "constant", constant_values=(0.0,)
+            )
+        ell_max_supertranslation = int(np.sqrt(len(supertranslation))) - 1
+        if (ell_max_supertranslation + 1) ** 2 != len(supertranslation):
+            raise ValueError(
+                "\nInput supertranslation parameter must contain modes from ell=0 up to some ell_max, "
+                "including\nall relevant m modes in standard order (see `spherical_functions` "
+                "documentation for details).\nThus, it must be an array with length given by a "
+                "perfect square; its length is {}".format(len(supertranslation))
+            )
+        for ell in range(ell_max_supertranslation + 1):
+            for m in range(ell + 1):
+                i_pos = LM_index(ell, m, 0)
+                i_neg = LM_index(ell, -m, 0)
+                a = supertranslation[i_pos]
+                b = supertranslation[i_neg]
+                if impose_reality:
+                    supertranslation[i_pos] = (a + (-1.0) ** m * b.conjugate()) / 2.0
+                    supertranslation[i_neg] = (-1.0) ** m * supertranslation[i_pos].conjugate()
+                elif abs(a - (-1.0) ** m * b.conjugate()) > 3e-16 + 1e-15 * abs(b):
+                    raise ValueError(
+                        f"\nsupertranslation[{i_pos}]={a}  # (ell,m)=({ell},{m})\n"
+                        + "supertranslation[{}]={}  # (ell,m)=({},{})\n".format(i_neg, b, ell, -m)
+                        + "Will result in an imaginary supertranslation."
+                    )
+    spacetime_translation = np.zeros((4,), dtype=float)
+    spacetime_translation[0] = constant_from_ell_0_mode(supertranslation[0]).real
+    spacetime_translation[1:4] = -vector_from_ell_1_modes(supertranslation[1:4]).real
+    if "spacetime_translation" in kwargs:
+        st_trans = np.array(kwargs.pop("spacetime_translation"), dtype=float)
+        if st_trans.shape != (4,) or st_trans.dtype != "float":
+            raise TypeError(
+                "\nInput argument `spacetime_translation` should be a float array of shape (4,).\n"
+                "Got a {} array of shape {}.".format(st_trans.dtype, st_trans.shape)
+            )
+        spacetime_translation = st_trans[:]
+        supertranslation[0] = constant_as_ell_0_mode(spacetime_translation[0])
+        supertranslation[1:4] = vector_as_ell_1_modes(-spacetime_translation[1:4])
+    if "space_translation" in kwargs:
+        s_trans = np.array(kwargs.pop("space_translation"), dtype=float)
+        if s_trans.shape != (3,) or s_trans.dtype != "float":
+            raise TypeError(
+                "\nInput argument `space_translation` should be an array of floats of shape (3,).\n"
+                "Got a {} array of shape {}.".format(s_trans.dtype, s_trans.shape)
+            )
+        spacetime_translation[1:4] = s_trans[:]
+        supertranslation[1:4] = vector_as_ell_1_modes(-spacetime_translation[1:4])
+    if "time_translation" in kwargs:
+        t_trans = kwargs.pop("time_translation")
+        if not isinstance(t_trans, float):
+            raise TypeError("\nInput argument `time_translation` should be a single float.\n" "Got {}.".format(t_trans))
+        spacetime_translation[0] = t_trans
+        supertranslation[0] = constant_as_ell_0_mode(spacetime_translation[0])
+    return supertranslation, ell_max_supertranslation
+
+
+def _parse_lorentz(kwargs, single=False):
+    fr = kwargs.pop("frame_rotation", [1, 0, 0, 0])
+    frame_rotation = np.array(quaternions.as_float_array(fr), dtype=float).reshape(-1)[:4]
+    norm = math.sqrt(float(np.sum(frame_rotation**2)))
+    if norm < 3e-16:
+        raise ValueError(
+            f"frame_rotation={frame_rotation} should be a " + ("single unit quaternion" if single else "unit quaternion")
+        )
+    frame_rotation = frame_rotation / norm
+    boost_velocity = np.array(kwargs.pop("boost_velocity", [0.0] * 3), dtype=float)
+    beta = np.linalg.norm(boost_velocity)
+    if boost_velocity.shape != (3,) or beta >= 1.0:
+        raise ValueError(
+            "Input boost_velocity=`{}` should be a 3-vector with "
+            "magnitude strictly less than 1.0.".format(boost_velocity)
+        )
+    return frame_rotation, boost_velocity
+
+
+def process_transformation_kwargs(ell_max, **kwargs):
+    """scri/waveform_grid.py:20-127 (everything up to the rotor grid, which the engine builds).
+
+    Returns (supertranslation, ell_max_supertranslation, ell_max, n_theta, n_phi, frame_rotation,
+    boost_velocity, kwargs)."""
+    supertranslation, ell_max_supertranslation = _parse_translations(kwargs, impose_reality=False)
+    w_ell_max = ell_max
+    ell_max = w_ell_max + ell_max_supertranslation
+    n_theta = kwargs.pop("n_theta", 2 * ell_max + 1)
+    n_phi = kwargs.pop("n_phi", 2 * ell_max + 1)
+    if n_theta < 2 * ell_max + 1 and abs(supertranslation[1:]).max() > 0.0:
+        warnings.warn(
+            f"n_theta={n_theta} is small; because of the supertranslation, "
+            + f"it will lose accuracy for anything less than 2*ell+1={ell_max}"
+        )
+    if n_theta < 2 * w_ell_max + 1:
+        raise ValueError(f"n_theta={n_theta} is too small; " + "must be at least 2*ell+1={}".format(2 * w_ell_max + 1))
+    if n_phi < 2 * ell_max + 1 and abs(supertranslation[1:]).max() > 0.0:
+        warnings.warn(
+            f"n_phi={n_phi} is small; because of the supertranslation, "
+            + f"it will lose accuracy for anything less than 2*ell+1={ell_max}"
+        )
+    if n_phi < 2 * w_ell_max + 1:
+        raise ValueError(f"n_phi={n_phi} is too small; " + "must be at least 2*ell+1={}".format(2 * w_ell_max + 1))
+    frame_rotation, boost_velocity = _parse_lorentz(kwargs)
+    return supertranslation, ell_max_supertranslation, ell_max, n_theta, n_phi, frame_rotation, boost_velocity, kwargs
+
+
+def transform(w_modes, **kwargs):
+    """WaveformGrid.transform (scri/waveform_grid.py:615-630): from_modes(...).to_modes(ell_max).
+
+    Returns a new WaveformModes on the retarded-time slices of the transformed frame; `ell_max` of the
+    output defaults to that of the input, the output `ell_min` is |s| (to_modes default)."""
+    from .waveform_modes import WaveformModes
+
+    if not isinstance(w_modes, WaveformModes):
+        raise TypeError(
+            "Expected WaveformModes object in argument 1; " "got `{}` instead.".format(type(w_modes).__name__)
+        )
+    ell_max_out = kwargs.pop("ell_max", w_modes.ell_max)
+    # from_modes: frame check (waveform_grid.py:417-426)
+    if w_modes.frameType != Inertial:
+        raise ValueError(
+            "\nInput waveform object must be in an inertial frame; "
+            "this is in a frame of type `{}`".format(w_modes.frame_type_string)
+        )
+    original_kwargs = kwargs.copy()
+    (supertranslation, ell_max_supertranslation, ell_max, n_theta, n_phi, frame_rotation, boost_velocity, kwargs) = (
+        process_transformation_kwargs(w_modes.ell_max, **kwargs)
+    )
+    beta = np.linalg.norm(boost_velocity)
+    s = w_modes.spin_weight
+    dt = w_modes.dataType
+
+    # type-specific term (waveform_grid.py:485-557)
+    type_term = engine.BMS_TERM_NONE
+    aux = []
+    if beta != 0 or (supertranslation[1:] != 0).any():
+        if dt == h:
+            type_term = engine.BMS_TERM_H
+        elif dt == sigma:
+            type_term = engine.BMS_TERM_SIGMA
+        elif dt in [psi0, psi1, psi2, psi3]:
+            type_term = engine.BMS_TERM_PSI
+            for DT in range(dt + 1, psi4 + 1):
+                try:
+                    w_tmp = kwargs.pop("psi{}_modes".format(DataNames[DT][-1]))
+                except KeyError:
+                    raise ValueError(
+                        "\nA BMS transformation of {} requires information from {}, which "
+                        "has not been supplied.".format(w_modes.data_type_string, DataNames[DT])
+                    )
+                if w_tmp.n_times != w_modes.n_times:
+                    raise ValueError("auxiliary waveform has a different number of time steps")
+                aux.append((w_tmp.data, w_tmp.ell_min, w_tmp.ell_max, w_tmp.spin_weight, comb(5 - dt, 5 - DT), DT - dt))
+        elif dt not in [psi4, hdot, news]:
+            warnings.warn(
+                "\nNo BMS transformation is implemented for waveform objects "
+                "of dataType '{}'. Proceeding with the transformation as if it "
+                "were dataType 'Psi4'.".format(w_modes.data_type_string)
+            )
+
+    # to_modes argument checks (waveform_grid.py:291-297)
+    import numbers
+
+    if not isinstance(ell_max_out, numbers.Integral) or ell_max_out < 0:
+        raise ValueError(f"Input `ell_max` should be a nonnegative integer; got `{ell_max_out}`.")
+    ell_min_out = abs(s)
+    if ell_min_out > ell_max_out:
+        raise ValueError(f"Input `ell_min` should be an integer between 0 and {ell_max_out}; got `{ell_min_out}`.")
+    if w_modes.data.ndim != 2:
+        raise NotImplementedError("extra trailing data dimensions are not supported by the GPU engine")
+
+    tr = engine.make_transformation(supertranslation, frame_rotation, boost_velocity, n_theta, n_phi, ell_max_out)
+    t_new, data_new = engine.transform_modes(
+        w_modes.t, w_modes.data, w_modes.ell_min, w_modes.ell_max, s, w_modes.conformal_weight, type_term, tr,
+        aux=aux, ctx=w_modes._ctx,
+    )
+    if kwargs:
+        warnings.warn("\nUnused kwargs passed to this function:\n{}".format(pprint.pformat(kwargs, width=1)))
+
+    return WaveformModes(
+        t=t_new,
+        data=data_new,
+        history=w_modes.history,
+        ell_min=ell_min_out,
+        ell_max=int(ell_max_out),
+        frameType=w_modes.frameType,
+        dataType=w_modes.dataType,
+        r_is_scaled_out=w_modes.r_is_scaled_out,
+        m_is_scaled_out=w_modes.m_is_scaled_out,
+        constructor_statement=f"WaveformGrid.from_modes({w_modes}, **{original_kwargs}).to_modes({ell_max_out})",
+        ctx=w_modes._ctx,
+    )

@@ -1,0 +1,162 @@
+"""`WaveformModes`: the container the BMS hot path works on, mirroring the fields and the methods of
+``scri.WaveformModes`` that the path touches (scri/waveform_base.py:222-231 fields, :299-367 validity
+checks, :440-446 weights, :706-729 history, :950-967 interpolate; scri/waveform_modes.py:705-719
+transform).  Everything numerical is delegated to the GPU engine."""
+import numbers
+import numpy as np
+
+from . import engine, quaternions
+from . import Inertial, UnknownFrameType, UnknownDataType, h, SpinWeights, ConformalWeights, RScaling, DataNames, FrameNames
+from .mode_algebra import LM_range, LM_total_size
+
+_next_num = [0]
+
+
+class WaveformModes:
+    """Object containing time, frame, and SWSH-mode data (subset of scri.WaveformModes).
+
+    Parameters (keyword): t, data [n_times, n_modes] complex, ell_min, ell_max, frame (quaternion array or
+    float [n,4]; default empty), frameType (default Inertial here only when given), dataType,
+    r_is_scaled_out, m_is_scaled_out, history, ctx (engine context; default process-wide).
+    """
+
+    def __init__(self, *args, **kwargs):
+        if len(args) == 1 and isinstance(args[0], WaveformModes) and not kwargs:
+            o = args[0]
+            kwargs = dict(
+                t=o.t.copy(), data=o.data.copy(), ell_min=o.ell_min, ell_max=o.ell_max, frame=np.array(o.frame, copy=True),
+                frameType=o.frameType, dataType=o.dataType, r_is_scaled_out=o.r_is_scaled_out,
+                m_is_scaled_out=o.m_is_scaled_out, history=list(o.history), ctx=o._ctx,
+            )
+        elif args:
+            raise ValueError("WaveformModes takes keyword arguments (or one WaveformModes to copy)")
+        self._ctx = kwargs.pop("ctx", None)
+        self.t = np.array(kwargs.pop("t", np.empty((0,))), dtype=float)
+        self._frame_template = kwargs.get("frame", None)
+        frame = kwargs.pop("frame", None)
+        self.frame = np.zeros((0, 4)) if frame is None or np.size(frame) == 0 else np.atleast_2d(quaternions.as_float_array(frame)).copy()
+        self.data = np.array(kwargs.pop("data", np.empty((0, 0))), dtype=complex)
+        self.ell_min = int(kwargs.pop("ell_min", 0))
+        self.ell_max = int(kwargs.pop("ell_max", -1))
+        self.frameType = int(kwargs.pop("frameType", UnknownFrameType))
+        self.dataType = int(kwargs.pop("dataType", UnknownDataType))
+        self.r_is_scaled_out = bool(kwargs.pop("r_is_scaled_out", False))
+        self.m_is_scaled_out = bool(kwargs.pop("m_is_scaled_out", False))
+        self.history = list(kwargs.pop("history", []))
+        constructor_statement = kwargs.pop("constructor_statement", None)
+        if kwargs:
+            import pprint, warnings
+
+            warnings.warn("\nUnused kwargs passed to this function:\n{}".format(pprint.pformat(kwargs, width=1)))
+        _next_num[0] += 1
+        self.num = _next_num[0]
+        self.history.append(f"{self} = {constructor_statement or 'WaveformModes(...)'}")
+        if self.ell_max >= self.ell_min and self.data.ndim >= 2 and self.data.shape[1] != LM_total_size(self.ell_min, self.ell_max):
+            raise ValueError(
+                f"data.shape[1]={self.data.shape[1]} inconsistent with ell_min={self.ell_min}, ell_max={self.ell_max}"
+            )
+
+    def __str__(self):
+        return f"{type(self).__name__}_{self.num}"
+
+    # ---- sizes / weights (waveform_base.py:430-446)
+    @property
+    def n_times(self):
+        return self.t.shape[0]
+
+    @property
+    def n_modes(self):
+        return self.data.shape[1]
+
+    @property
+    def LM(self):
+        return LM_range(self.ell_min, self.ell_max)
+
+    @property
+    def spin_weight(self):
+        return SpinWeights[self.dataType]
+
+    @property
+    def conformal_weight(self):
+        return ConformalWeights[self.dataType] + (-RScaling[self.dataType] if self.r_is_scaled_out else 0)
+
+    @property
+    def data_type_string(self):
+        return DataNames[self.dataType]
+
+    @property
+    def frame_type_string(self):
+        return FrameNames[self.frameType]
+
+    def _append_history(self, s):
+        self.history.append(s if isinstance(s, str) else "\n".join(s))
+
+    # ---- validity (core checks of waveform_base.py:299-367)
+    def ensure_validity(self, alter=True, assertions=False):
+        errors = []
+        if not (self.t.ndim == 1 and self.t.dtype == np.dtype(float)):
+            errors.append("t must be a 1-d float array")
+        if self.t.size > 1 and not np.all(np.diff(self.t) > 0):
+            errors.append("t must be strictly increasing")
+        if not np.all(np.isfinite(self.t)):
+            errors.append("t must be finite")
+        if self.frame.size and self.frame.shape[0] not in (1, self.n_times):
+            errors.append("frame must have 0, 1 or n_times elements")
+        if not np.all(np.isfinite(self.frame)):
+            errors.append("frame must be finite")
+        if self.data.shape[0] != self.n_times:
+            errors.append("data.shape[0] != n_times")
+        if not np.all(np.isfinite(self.data.view(float))):
+            errors.append("data must be finite")
+        if self.data.dtype != np.dtype(complex):
+            errors.append("data must be complex")
+        if self.data.shape[1] != LM_total_size(self.ell_min, self.ell_max):
+            errors.append("data.shape[1] inconsistent with ell range")
+        if errors:
+            if assertions:
+                raise AssertionError("; ".join(errors))
+            print("The following conditions were found to be incorrectly False:\n\t" + "\n\t".join(errors))
+            return False
+        return True
+
+    def copy(self):
+        return type(self)(self)
+
+    def copy_without_data(self):
+        W = type(self)(
+            t=np.empty((0,)), data=np.empty((0, self.n_modes), dtype=complex), ell_min=self.ell_min, ell_max=self.ell_max,
+            frameType=self.frameType, dataType=self.dataType, r_is_scaled_out=self.r_is_scaled_out,
+            m_is_scaled_out=self.m_is_scaled_out, history=list(self.history), ctx=self._ctx,
+        )
+        return W
+
+    # ---- interpolation in time (waveform_base.py:950-967): not-a-knot cubic spline on the GPU
+    def interpolate(self, tprime):
+        tprime = np.asarray(tprime, dtype=float)
+        W = self.copy_without_data()
+        W.t = np.copy(tprime)
+        if self.frame.shape[0] > 1:
+            raise NotImplementedError("interpolation of a time-dependent frame (quaternion.squad) is outside the BMS hot path")
+        W.frame = np.array(self.frame, copy=True)
+        W.data = engine.cubic_spline(self.t, self.data, tprime, ctx=self._ctx)
+        W._append_history(f"{W} = {self}.interpolate({tprime})")
+        return W
+
+    def _allclose(self, other, rtol=1e-05, atol=1e-08):
+        return (
+            np.allclose(self.t, other.t, rtol=rtol, atol=atol)
+            and np.allclose(self.data, other.data, rtol=rtol, atol=atol)
+            and self.ell_min == other.ell_min
+            and self.ell_max == other.ell_max
+            and self.dataType == other.dataType
+            and self.frameType == other.frameType
+        )
+
+    # ---- BMS transformation (scri/waveform_modes.py:705-719 -> WaveformGrid.transform)
+    def transform(self, **kwargs):
+        """Transform modes by some BMS transformation (time/space/spacetime translation,
+        supertranslation, frame_rotation, boost_velocity, n_theta, n_phi, ell_max, psi*_modes);
+        see scri.WaveformGrid.from_modes for the meaning of the parameters."""
+        from .waveform_grid import transform
+
+        return transform(self, **kwargs)

@@ -1,0 +1,23 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs an MI355X (run with `pytest -m gpu` on the GPU box)")
+    config.addinivalue_line("markers", "slow: exhaustive analytic tests of the oracle (minutes)")
+
+
+@pytest.fixture(scope="session")
+def ctx():
+    """One engine context on GPU 0 for the whole session (GPU tests only)."""
+    from scri_amd import _lib
+
+    c = _lib.Context(0)
+    yield c
+    c.close()

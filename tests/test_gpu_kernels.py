@@ -1,0 +1,102 @@
+"""GPU parity tests of the individual kernels, through the C ABI, against the CPU oracle."""
+import numpy as np
+import pytest
+from scipy.interpolate import CubicSpline
+
+from oracle import quat, wigner, spinsfast_ref, rotations_ref, sample_waveforms_ref as samples
+from oracle import waveform_grid_ref as grid_ref
+
+pytestmark = pytest.mark.gpu
+
+
+def _rotors(seed, n):
+    rng = np.random.default_rng(seed)
+    q = rng.normal(size=(n, 4))
+    return q / np.linalg.norm(q, axis=1)[:, None]
+
+
+@pytest.mark.parametrize("s", [-2, -1, 0, 1, 2])
+def test_swsh_grid_matches_oracle(ctx, s):
+    from scri_amd import engine
+
+    R = np.concatenate([_rotors(1, 50), samples.Rs()])
+    Y = engine.swsh_grid(R, s, 0, 17, ctx=ctx)
+    Yo = wigner.swsh_grid(R, s, 17)
+    assert Y.shape == Yo.shape
+    assert np.abs(Y - Yo).max() < 2e-14
+
+
+def test_rotor_grid_matches_oracle(ctx):
+    from scri_amd import engine
+
+    for fr, v in [([1, 0, 0, 0], [0, 0, 0]), ([1, 2, 3, 4], [0.01, -0.02, 0.03]), ([0.3, -1, 0.2, 0.5], [0, 0, 0.1])]:
+        fr = np.array(fr, dtype=float) / np.linalg.norm(fr)
+        R = engine.rotor_grid(fr, v, 9, 11, ctx=ctx)
+        Ro = grid_ref.rotor_grid(fr, np.array(v, dtype=float), 9, 11)
+        assert np.abs(R - Ro).max() < 1e-15
+
+
+def test_wigner_D_matches_oracle(ctx):
+    from scri_amd import engine
+
+    for q in samples.Rs()[::9]:
+        D = engine.wigner_D(q, 0, 8, ctx=ctx)
+        Ra, Rb = quat.as_spinor_array(q)
+        Do = wigner.wigner_D_matrices(Ra, Rb, 0, 8)
+        assert np.abs(D - Do).max() < 1e-14
+
+
+@pytest.mark.parametrize("ell_min,ell_max", [(2, 4), (0, 8), (2, 16), (0, 24)])
+def test_rotate_series_matches_oracle(ctx, ell_min, ell_max):
+    from scri_amd import engine
+
+    rng = np.random.default_rng(5)
+    n = 333
+    nm = wigner.LM_total_size(ell_min, ell_max)
+    data = rng.normal(size=(n, nm)) + 1j * rng.normal(size=(n, nm))
+    R = _rotors(6, n)
+    R[:100] = samples.Rs()  # special rotors: z-rotations, pi flips, identity-like
+    sp = quat.as_spinor_array(R)
+    expect = rotations_ref.rotate_by_series(data, sp, ell_min, ell_max)
+    got = engine.rotate_series(data.copy(), ell_min, ell_max, sp, ctx=ctx)
+    assert np.abs(got - expect).max() < 1e-13 * ell_max
+
+
+def test_rotate_const_and_identity_bit_exact(ctx):
+    from scri_amd import engine
+
+    rng = np.random.default_rng(7)
+    data = rng.normal(size=(1000, 77)) + 1j * rng.normal(size=(1000, 77))
+    out = engine.rotate_const(data.copy(), 2, 8, [1.0, 0, 0, 0], ctx=ctx)
+    assert np.array_equal(out, data)  # tests/test_rotations.py:14-38 of the reference
+    q = np.array([1.0, 2, 3, 4]) / np.sqrt(30)
+    Ra, Rb = quat.as_spinor_array(q)
+    expect = rotations_ref.rotate_by_constant(data, 2, 8, wigner.wigner_D_matrices(Ra, Rb, 2, 8))
+    got = engine.rotate_const(data.copy(), 2, 8, q, ctx=ctx)
+    assert np.abs(got - expect).max() < 1e-13
+
+
+@pytest.mark.parametrize("s", [-2, 0, 1])
+def test_map2salm_matches_oracle(ctx, s):
+    from scri_amd import engine
+
+    rng = np.random.default_rng(8)
+    n_theta, n_phi, L = 13, 15, 5
+    f = rng.normal(size=(7, n_theta, n_phi)) + 1j * rng.normal(size=(7, n_theta, n_phi))  # not band limited
+    a = engine.map2salm(f, s, L, ctx=ctx)
+    ao = spinsfast_ref.map2salm(f, s, L)
+    assert np.abs(a - ao).max() < 1e-13
+
+
+def test_cubic_spline_matches_scipy(ctx):
+    from scri_amd import engine
+
+    rng = np.random.default_rng(9)
+    for n in (4, 5, 37, 700, 5000):
+        x = np.cumsum(rng.uniform(0.05, 0.2, size=n))
+        y = np.sin(0.7 * x)[:, None] * (1 + 0.1 * np.arange(6)) + 1j * np.cos(0.3 * x)[:, None] * np.arange(6)
+        xn = np.sort(rng.uniform(x[0], x[-1], size=2 * n + 3))
+        xn[0], xn[-1] = x[0], x[-1]
+        got = engine.cubic_spline(x, y, xn, ctx=ctx)
+        expect = CubicSpline(x, y)(xn)
+        assert np.abs(got - expect).max() < 2e-13, n
