@@ -63,6 +63,22 @@ int bms_ctx_set_workspace_limit(bms_ctx* ctx, uint64_t bytes);
 /* block until all work queued by this context has finished */
 int bms_ctx_synchronize(bms_ctx* ctx);
 
+/* Optional per-kernel timing: when enabled every kernel launch is bracketed by two HIP events on the
+ * context's stream; bms_ctx_get_timing synchronises and returns the accumulated milliseconds and launch
+ * counts per kernel class since the last reset. */
+enum bms_kernel_tag {
+  BMS_TAG_ROTATE = 0,          /* rotate_modes_kernel */
+  BMS_TAG_SETUP = 1,           /* swsh_kernel (synthesis + quadrature matrices), spline_table_kernel */
+  BMS_TAG_GEMM_SYNTHESIS = 2,  /* dgemm_mfma_kernel, modes -> grid */
+  BMS_TAG_SPLINE_FORWARD = 3,  /* spline_forward_kernel */
+  BMS_TAG_SPLINE_BACKWARD = 4, /* spline_backward_eval_kernel */
+  BMS_TAG_GEMM_ANALYSIS = 5,   /* dgemm_mfma_kernel, grid -> modes */
+  BMS_TAG_POINTWISE = 6,       /* psi mixing / affine / Horner kernels */
+  BMS_TAG_COUNT = 7
+};
+int bms_ctx_enable_timing(bms_ctx* ctx, int on);
+int bms_ctx_get_timing(bms_ctx* ctx, double ms[BMS_TAG_COUNT], int64_t calls[BMS_TAG_COUNT], int reset);
+
 /* ---- rotation of modes ----------------------------------------------------------------------------------
  * replaces _rotate_decomposition_basis_by_constant (scri/rotations.py:346-367) and
  * _rotate_decomposition_basis_by_series (scri/rotations.py:370-392), including the Wigner-D evaluation
@@ -114,6 +130,24 @@ typedef struct {
  * the first *n_times_out rows are valid on return. */
 int bms_transform_modes(bms_ctx* ctx, const bms_wm_input* in, const bms_transformation* tr, double* t_out,
                         void* data_out, int64_t* n_times_out);
+
+/* Time-axis sharding (one process per GPU).  A rank holds rows [data_row0, data_row0 + data_rows) of the global
+ * data (in->data / in->aux_data point at row data_row0; in->t and in->n_times stay GLOBAL) and produces the
+ * output samples whose global input index lies in [out_i0, out_i1) (intersected with the valid window of
+ * scri/waveform_grid.py:564-568).  bms_shard_plan returns the rows a rank must hold for that
+ * (spline halo + boost/supertranslation time skew): need_rows = [first, one-past-last];
+ * window = the global valid output index range [i_lo, i_hi). */
+typedef struct {
+  int64_t data_row0, data_rows;
+  int64_t out_i0, out_i1;
+} bms_shard;
+int bms_shard_plan(bms_ctx* ctx, const double* t, int64_t n_times, const bms_transformation* tr, int64_t out_i0,
+                   int64_t out_i1, int64_t need_rows[2], int64_t window[2]);
+/* as bms_transform_modes; t_out/data_out receive only the rank's samples, *first_index_out their first global
+ * input index (output row r corresponds to input index *first_index_out + r).  shard == NULL: whole series. */
+int bms_transform_modes_shard(bms_ctx* ctx, const bms_wm_input* in, const bms_transformation* tr,
+                              const bms_shard* shard, double* t_out, void* data_out, int64_t* n_times_out,
+                              int64_t* first_index_out);
 
 /* ---- BMS transformation of AsymptoticBondiData ---------------------------------------------------------
  * replaces AsymptoticBondiData.transform (scri/asymptotic_bondi_data/transformations.py:199-431) after

@@ -57,6 +57,12 @@ class bms_transformation(ctypes.Structure):
     ]
 
 
+class bms_shard(ctypes.Structure):
+    _fields_ = [("data_row0", c_i64), ("data_rows", c_i64), ("out_i0", c_i64), ("out_i1", c_i64)]
+
+
+KERNEL_TAGS = ("rotate", "setup", "gemm_synthesis", "spline_forward", "spline_backward", "gemm_analysis", "pointwise")
+
 # every symbol include/scri_amd.h declares: (restype, argtypes)
 SIGNATURES = {
     "bms_version": (c_int, []),
@@ -66,6 +72,17 @@ SIGNATURES = {
     "bms_ctx_set_stream": (c_int, [c_vp, c_vp]),
     "bms_ctx_set_workspace_limit": (c_int, [c_vp, ctypes.c_uint64]),
     "bms_ctx_synchronize": (c_int, [c_vp]),
+    "bms_ctx_enable_timing": (c_int, [c_vp, c_int]),
+    "bms_ctx_get_timing": (c_int, [c_vp, c_dp, ctypes.POINTER(c_i64), c_int]),
+    "bms_shard_plan": (
+        c_int,
+        [c_vp, c_dp, c_i64, ctypes.POINTER(bms_transformation), c_i64, c_i64, ctypes.POINTER(c_i64), ctypes.POINTER(c_i64)],
+    ),
+    "bms_transform_modes_shard": (
+        c_int,
+        [c_vp, ctypes.POINTER(bms_wm_input), ctypes.POINTER(bms_transformation), ctypes.POINTER(bms_shard), c_dp, c_vp,
+         ctypes.POINTER(c_i64), ctypes.POINTER(c_i64)],
+    ),
     "bms_rotate_const": (c_int, [c_vp, c_vp, c_int, c_i64, c_i64, c_int, c_int, c_dp]),
     "bms_rotate_series": (c_int, [c_vp, c_vp, c_int, c_i64, c_i64, c_int, c_int, c_vp]),
     "bms_wigner_D": (c_int, [c_vp, c_dp, c_int, c_int, c_vp]),
@@ -149,6 +166,17 @@ class Context:
 
     def synchronize(self):
         self.check(load().bms_ctx_synchronize(self._h), "bms_ctx_synchronize")
+
+    def enable_timing(self, on=True):
+        self.check(load().bms_ctx_enable_timing(self._h, 1 if on else 0), "bms_ctx_enable_timing")
+
+    def get_timing(self, reset=True):
+        """{kernel class: (milliseconds, launches)} accumulated by HIP events since the last reset."""
+        n = len(KERNEL_TAGS)
+        ms = (ctypes.c_double * n)()
+        calls = (c_i64 * n)()
+        self.check(load().bms_ctx_get_timing(self._h, ms, calls, 1 if reset else 0), "bms_ctx_get_timing")
+        return {k: (ms[i], calls[i]) for i, k in enumerate(KERNEL_TAGS)}
 
     @property
     def handle(self):

@@ -37,8 +37,51 @@ struct bms_ctx {
   uint64_t ws_limit = 32ull << 30;
   std::map<std::string, DevBuf> bufs;  // grow-only named work space
   int delta_lmax = -1;                 // Delta tables cached up to this l
-  std::vector<long long> delta_off_host;
+  // optional per-kernel timing with HIP events on the context's stream (bms_ctx_enable_timing)
+  bool timing = false;
+  struct Timed {
+    int tag;
+    hipEvent_t a, b;
+  };
+  std::vector<Timed> timed;
+  std::vector<hipEvent_t> event_pool;
+  double tag_ms[BMS_TAG_COUNT] = {0};
+  long long tag_calls[BMS_TAG_COUNT] = {0};
 };
+
+struct ScopedTimer {  // brackets one kernel launch with two events when timing is enabled
+  bms_ctx* c;
+  int tag;
+  hipEvent_t a = nullptr, b = nullptr;
+  static hipEvent_t get(bms_ctx* c) {
+    if (!c->event_pool.empty()) {
+      hipEvent_t e = c->event_pool.back();
+      c->event_pool.pop_back();
+      return e;
+    }
+    hipEvent_t e = nullptr;
+    (void)hipEventCreate(&e);
+    return e;
+  }
+  ScopedTimer(bms_ctx* c_, int tag_) : c(c_), tag(tag_) {
+    if (c->timing) {
+      a = get(c);
+      b = get(c);
+      (void)hipEventRecord(a, c->stream);
+    }
+  }
+  ~ScopedTimer() {
+    if (c->timing) {
+      (void)hipEventRecord(b, c->stream);
+      c->timed.push_back({tag, a, b});
+    }
+  }
+};
+#define TIMED(ctx, tag, expr)     \
+  do {                            \
+    ScopedTimer st__(ctx, tag);   \
+    HIP_TRY(ctx, expr);           \
+  } while (0)
 
 static thread_local std::string g_create_error;
 
@@ -134,6 +177,11 @@ extern "C" void bms_ctx_destroy(bms_ctx* c) {
   (void)hipStreamSynchronize(c->stream);
   for (auto& kv : c->bufs)
     if (kv.second.p) (void)hipFree(kv.second.p);
+  for (auto& t : c->timed) {
+    (void)hipEventDestroy(t.a);
+    (void)hipEventDestroy(t.b);
+  }
+  for (auto e : c->event_pool) (void)hipEventDestroy(e);
   if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
   delete c;
 }
@@ -149,6 +197,38 @@ extern "C" int bms_ctx_set_stream(bms_ctx* c, void* s) {
 extern "C" int bms_ctx_set_workspace_limit(bms_ctx* c, uint64_t bytes) {
   if (!c) return BMS_ERR_INVALID;
   c->ws_limit = bytes ? bytes : (32ull << 30);
+  return BMS_OK;
+}
+
+extern "C" int bms_ctx_enable_timing(bms_ctx* c, int on) {
+  if (!c) return BMS_ERR_INVALID;
+  c->timing = on != 0;
+  return BMS_OK;
+}
+
+// accumulate finished event pairs into per-tag totals; returns totals since the last reset
+extern "C" int bms_ctx_get_timing(bms_ctx* c, double* ms /*[BMS_TAG_COUNT]*/, int64_t* calls /*[BMS_TAG_COUNT]*/, int reset) {
+  if (!c) return BMS_ERR_INVALID;
+  HIP_TRY(c, hipSetDevice(c->device));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  for (auto& t : c->timed) {
+    float f = 0.f;
+    if (hipEventElapsedTime(&f, t.a, t.b) == hipSuccess) {
+      c->tag_ms[t.tag] += f;
+      c->tag_calls[t.tag] += 1;
+    }
+    c->event_pool.push_back(t.a);
+    c->event_pool.push_back(t.b);
+  }
+  c->timed.clear();
+  for (int i = 0; i < BMS_TAG_COUNT; ++i) {
+    if (ms) ms[i] = c->tag_ms[i];
+    if (calls) calls[i] = c->tag_calls[i];
+    if (reset) {
+      c->tag_ms[i] = 0;
+      c->tag_calls[i] = 0;
+    }
+  }
   return BMS_OK;
 }
 
@@ -393,7 +473,7 @@ static int rotate_impl(bms_ctx* c, void* data, int mem, int64_t n_times, int64_t
     if (rc) return rc;
     HIP_TRY(c, hipMemcpyAsync(d_data, data, data_bytes, hipMemcpyHostToDevice, c->stream));
   }
-  HIP_TRY(c, launch_rotate_modes(c->stream, d_data, n_times, ld, ell_min, ell_max, d_rot, series ? 4 : 0, d_delta, d_off));
+  TIMED(c, BMS_TAG_ROTATE, launch_rotate_modes(c->stream, d_data, n_times, ld, ell_min, ell_max, d_rot, series ? 4 : 0, d_delta, d_off));
   if (mem == BMS_HOST) {
     HIP_TRY(c, hipMemcpyAsync(data, d_data, data_bytes, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -573,6 +653,37 @@ struct PointwiseWM {
 
 extern "C" int bms_transform_modes(bms_ctx* c, const bms_wm_input* in, const bms_transformation* tr, double* t_out,
                                    void* data_out, int64_t* n_times_out) {
+  return bms_transform_modes_shard(c, in, tr, nullptr, t_out, data_out, n_times_out, nullptr);
+}
+
+extern "C" int bms_shard_plan(bms_ctx* c, const double* t, int64_t n, const bms_transformation* tr, int64_t out_i0,
+                              int64_t out_i1, int64_t need_rows[2], int64_t window[2]) {
+  // pure host planning: ctx may be NULL (errors then go to bms_last_error(NULL))
+  if (!t || !tr || !need_rows || !window) return fail(c, BMS_ERR_INVALID, "NULL argument");
+  int rc = validate_common(c, n, t, tr);
+  if (rc) return rc;
+  PixelTables T;
+  build_pixel_tables(tr, T);
+  int64_t i_lo, i_hi;
+  output_window(T, t, n, i_lo, i_hi);
+  window[0] = i_lo;
+  window[1] = i_hi;
+  const int64_t a = std::max(i_lo, out_i0), b = std::min(i_hi, out_i1);
+  if (b <= a) {
+    need_rows[0] = need_rows[1] = 0;
+    return BMS_OK;
+  }
+  int64_t ja, jb;
+  needed_knots(T, t, n, a, b, ja, jb);
+  const int margin = SPLINE_HALO + 2;
+  need_rows[0] = std::max<int64_t>(0, ja - margin);
+  need_rows[1] = std::min<int64_t>(n, jb + margin + 1);
+  return BMS_OK;
+}
+
+extern "C" int bms_transform_modes_shard(bms_ctx* c, const bms_wm_input* in, const bms_transformation* tr,
+                                         const bms_shard* sh, double* t_out, void* data_out, int64_t* n_times_out,
+                                         int64_t* first_index_out) {
   if (!c) return BMS_ERR_INVALID;
   if (!in || !tr || !t_out || !data_out || !n_times_out) return fail(c, BMS_ERR_INVALID, "NULL argument");
   HIP_TRY(c, hipSetDevice(c->device));
@@ -596,6 +707,15 @@ extern "C" int bms_transform_modes(bms_ctx* c, const bms_wm_input* in, const bms
   const int n_pix = T.n_pix;
   int64_t i_lo, i_hi;
   output_window(T, in->t, n, i_lo, i_hi);
+  // shard: rows [row0, row0 + rows) of the global data are present; produce outputs with global index in [out_i0, out_i1)
+  const int64_t row0 = sh ? sh->data_row0 : 0;
+  const int64_t rows_avail = sh ? sh->data_rows : n;
+  if (sh) {
+    if (row0 < 0 || rows_avail < 0 || row0 + rows_avail > n) return fail(c, BMS_ERR_INVALID, "shard rows outside [0, n_times)");
+    i_lo = std::max(i_lo, sh->out_i0);
+    i_hi = std::max(i_lo, std::min(i_hi, sh->out_i1));
+  }
+  if (first_index_out) *first_index_out = i_lo;
   const int64_t n_new = i_hi - i_lo;
   *n_times_out = n_new;
   for (int64_t i = 0; i < n_new; ++i) t_out[i] = (1 / T.gamma) * (in->t[i_lo + i] - T.tt);
@@ -709,7 +829,7 @@ extern "C" int bms_transform_modes(bms_ctx* c, const bms_wm_input* in, const bms
   F[0].ell_max = in->ell_max;
   F[0].spin = s;
   F[0].ld = in->ld;
-  if ((rc = stage_in(c, "in_data", in->data, in->mem, (size_t)n * in->ld * 16, &F[0].d_data))) return rc;
+  if ((rc = stage_in(c, "in_data", in->data, in->mem, (size_t)rows_avail * in->ld * 16, &F[0].d_data))) return rc;
   for (int a = 0; a < (psi ? in->n_aux : 0); ++a) {
     FieldPlan& f = F[1 + a];
     f.ell_min = in->aux_ell_min[a];
@@ -719,7 +839,7 @@ extern "C" int bms_transform_modes(bms_ctx* c, const bms_wm_input* in, const bms
     if (f.ell_min < 0 || f.ell_max < f.ell_min || f.ld < LM_total_size(f.ell_min, f.ell_max)) return fail(c, BMS_ERR_INVALID, "bad auxiliary field %d", a);
     char nm[32];
     snprintf(nm, sizeof nm, "in_aux%d", a);
-    if ((rc = stage_in(c, nm, in->aux_data[a], in->mem, (size_t)n * f.ld * 16, &f.d_data))) return rc;
+    if ((rc = stage_in(c, nm, in->aux_data[a], in->mem, (size_t)rows_avail * f.ld * 16, &f.d_data))) return rc;
   }
   const long long ldb = round_up(P2, 128);
   for (int fi = 0; fi < n_fields; ++fi) {
@@ -731,7 +851,7 @@ extern "C" int bms_transform_modes(bms_ctx* c, const bms_wm_input* in, const bms
     snprintf(nm, sizeof nm, "Bsyn%d", fi);
     if ((rc = dev_buf_t(c, nm, (size_t)rows * ldb, &f.d_B))) return rc;
     HIP_TRY(c, hipMemsetAsync(f.d_B, 0, sizeof(double) * rows * ldb, S));
-    HIP_TRY(c, launch_swsh_matrix(S, d_rot, n_pix, f.spin, f.ell_min, f.ell_max, f.d_B, ldb));
+    TIMED(c, BMS_TAG_SETUP, launch_swsh_matrix(S, d_rot, n_pix, f.spin, f.ell_min, f.ell_max, f.d_B, ldb));
   }
   // analysis matrix [2 n_pix (rounded to 16)] x [2 n_out (rounded to 128)]
   const long long ldw = round_up(2LL * n_out, 128);
@@ -739,11 +859,11 @@ extern "C" int bms_transform_modes(bms_ctx* c, const bms_wm_input* in, const bms
   double* d_W;
   if ((rc = dev_buf_t(c, "Wana", (size_t)wrows * ldw, &d_W))) return rc;
   HIP_TRY(c, hipMemsetAsync(d_W, 0, sizeof(double) * wrows * ldw, S));
-  HIP_TRY(c, launch_quadrature_matrix(S, d_grot, d_wpix, n_pix, s, ell_min_out, tr->ell_max_out, d_W, ldw));
+  TIMED(c, BMS_TAG_SETUP, launch_quadrature_matrix(S, d_grot, d_wpix, n_pix, s, ell_min_out, tr->ell_max_out, d_W, ldw));
   // spline factors
   SplineTable* d_tab;
   if ((rc = dev_buf_t(c, "spline_table", (size_t)n, &d_tab))) return rc;
-  HIP_TRY(c, launch_spline_table(S, d_x, n, d_tab));
+  TIMED(c, BMS_TAG_SETUP, launch_spline_table(S, d_x, n, d_tab));
 
   // output staging
   double* d_out = (double*)data_out;
@@ -762,6 +882,11 @@ extern "C" int bms_transform_modes(bms_ctx* c, const bms_wm_input* in, const bms
     needed_knots(T, in->t, n, c0, c1, ja, jb);
     const int64_t g0 = std::max<int64_t>(0, ja - margin), g1 = std::min<int64_t>(n, jb + margin + 1);
     const int64_t rows_in = g1 - g0, rows_out = c1 - c0;
+    if (g0 < row0 || g1 > row0 + rows_avail)
+      return fail(c, BMS_ERR_INVALID,
+                  "shard holds rows [%lld, %lld) but outputs [%lld, %lld) need rows [%lld, %lld): halo too small "
+                  "(use bms_shard_plan)",
+                  (long long)row0, (long long)(row0 + rows_avail), (long long)c0, (long long)c1, (long long)g0, (long long)g1);
     double *d_Y, *d_R, *d_G, *d_Yaux = nullptr;
     if ((rc = dev_buf_t(c, "Y", (size_t)rows_in * ldg, &d_Y))) return rc;
     if ((rc = dev_buf_t(c, "R", (size_t)rows_in * ldg, &d_R))) return rc;
@@ -769,24 +894,24 @@ extern "C" int bms_transform_modes(bms_ctx* c, const bms_wm_input* in, const bms
     if (psi)
       if ((rc = dev_buf_t(c, "Yaux", (size_t)rows_in * ldg, &d_Yaux))) return rc;
     // synthesis (+ fused affine map when there is no psi mixing)
-    HIP_TRY(c, launch_dgemm(S, F[0].d_data + g0 * F[0].ld * 2, F[0].ld * 2, F[0].d_B, ldb, d_Y, ldg, rows_in, (int)P2,
+    TIMED(c, BMS_TAG_GEMM_SYNTHESIS, launch_dgemm(S, F[0].d_data + (g0 - row0) * F[0].ld * 2, F[0].ld * 2, F[0].d_B, ldb, d_Y, ldg, rows_in, (int)P2,
                             F[0].K, psi ? nullptr : d_off, psi ? nullptr : d_scale));
     if (psi) {
       for (int a = 0; a < in->n_aux; ++a) {
         const FieldPlan& f = F[1 + a];
-        HIP_TRY(c, launch_dgemm(S, f.d_data + g0 * f.ld * 2, f.ld * 2, f.d_B, ldb, d_Yaux, ldg, rows_in, (int)P2, f.K,
+        TIMED(c, BMS_TAG_GEMM_SYNTHESIS, launch_dgemm(S, f.d_data + (g0 - row0) * f.ld * 2, f.ld * 2, f.d_B, ldb, d_Yaux, ldg, rows_in, (int)P2, f.K,
                                 nullptr, nullptr));
-        HIP_TRY(c, launch_psi_mix(S, d_Y, d_Yaux, ldg, n_pix, rows_in, d_x + g0, d_alpha, d_xa, d_xb, in->aux_coeff[a],
+        TIMED(c, BMS_TAG_POINTWISE, launch_psi_mix(S, d_Y, d_Yaux, ldg, n_pix, rows_in, d_x + g0, d_alpha, d_xa, d_xb, in->aux_coeff[a],
                                   in->aux_power[a]));
       }
-      HIP_TRY(c, launch_affine_cols(S, d_Y, ldg, (int)P2, rows_in, d_off, d_scale));
+      TIMED(c, BMS_TAG_POINTWISE, launch_affine_cols(S, d_Y, ldg, (int)P2, rows_in, d_off, d_scale));
     }
     // spline along time on the shared knots, evaluated on the distorted slices
-    HIP_TRY(c, launch_spline_forward(S, d_Y, d_R, ldg, n_pix, g0, rows_in, n, d_x, d_tab, SPLINE_TILE, SPLINE_HALO));
-    HIP_TRY(c, launch_spline_backward_eval(S, d_Y, d_R, ldg, n_pix, g0, rows_in, n, d_x, d_tab, SPLINE_TILE, SPLINE_HALO,
+    TIMED(c, BMS_TAG_SPLINE_FORWARD, launch_spline_forward(S, d_Y, d_R, ldg, n_pix, g0, rows_in, n, d_x, d_tab, SPLINE_TILE, SPLINE_HALO));
+    TIMED(c, BMS_TAG_SPLINE_BACKWARD, launch_spline_backward_eval(S, d_Y, d_R, ldg, n_pix, g0, rows_in, n, d_x, d_tab, SPLINE_TILE, SPLINE_HALO,
                                            d_x, d_skewa, d_skewb, T.tt, c0, c1, d_G, ldg));
     // analysis
-    HIP_TRY(c, launch_dgemm(S, d_G, ldg, d_W, ldw, d_out + (c0 - i_lo) * n_out * 2, 2LL * n_out, rows_out, 2 * n_out,
+    TIMED(c, BMS_TAG_GEMM_ANALYSIS, launch_dgemm(S, d_G, ldg, d_W, ldw, d_out + (c0 - i_lo) * n_out * 2, 2LL * n_out, rows_out, 2 * n_out,
                             (int)P2, nullptr, nullptr));
   }
   if (in->mem == BMS_HOST)
@@ -799,7 +924,8 @@ extern "C" int bms_transform_modes(bms_ctx* c, const bms_wm_input* in, const bms
 // ====================================================================================================== building blocks
 
 extern "C" int bms_rotor_grid(bms_ctx* c, const double fr[4], const double v[3], int n_theta, int n_phi, double* out) {
-  if (!c || !fr || !v || !out) return BMS_ERR_INVALID;
+  // pure host set-up: ctx may be NULL
+  if (!fr || !v || !out) return fail(c, BMS_ERR_INVALID, "NULL argument");
   if (n_theta < 2 || n_phi < 1) return fail(c, BMS_ERR_INVALID, "bad grid size");
   std::vector<Quat> R;
   build_rotor_grid(fr, v, n_theta, n_phi, R);
@@ -848,13 +974,13 @@ extern "C" int bms_map2salm(bms_ctx* c, const void* grid, int mem, int64_t n_map
   double* d_W;
   if ((rc = dev_buf_t(c, "Wana", (size_t)wrows * ldw, &d_W))) return rc;
   HIP_TRY(c, hipMemsetAsync(d_W, 0, sizeof(double) * wrows * ldw, c->stream));
-  HIP_TRY(c, launch_quadrature_matrix(c->stream, (const double*)d_rot, (const double*)d_w, n_pix, spin, ell_min, ell_max, d_W, ldw));
+  TIMED(c, BMS_TAG_SETUP, launch_quadrature_matrix(c->stream, (const double*)d_rot, (const double*)d_w, n_pix, spin, ell_min, ell_max, d_W, ldw));
   const double* d_in;
   if ((rc = stage_in(c, "in_data", grid, mem, (size_t)n_maps * n_pix * 16, &d_in))) return rc;
   double* d_out = (double*)modes_out;
   if (mem == BMS_HOST)
     if ((rc = dev_buf_t(c, "out_data", (size_t)n_maps * n_out * 2, &d_out))) return rc;
-  HIP_TRY(c, launch_dgemm(c->stream, d_in, P2, d_W, ldw, d_out, 2LL * n_out, n_maps, 2 * n_out, (int)P2, nullptr, nullptr));
+  TIMED(c, BMS_TAG_GEMM_ANALYSIS, launch_dgemm(c->stream, d_in, P2, d_W, ldw, d_out, 2LL * n_out, n_maps, 2 * n_out, (int)P2, nullptr, nullptr));
   if (mem == BMS_HOST) HIP_TRY(c, hipMemcpyAsync(modes_out, d_out, (size_t)n_maps * n_out * 16, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   return BMS_OK;
@@ -879,14 +1005,14 @@ extern "C" int bms_cubic_spline(bms_ctx* c, const double* x, int64_t n, const vo
   if ((rc = stage_in(c, "in_data", y, mem, (size_t)n * ld * 16, &d_y))) return rc;
   SplineTable* d_tab;
   if ((rc = dev_buf_t(c, "spline_table", (size_t)n, &d_tab))) return rc;
-  HIP_TRY(c, launch_spline_table(c->stream, (const double*)d_x, n, d_tab));
+  TIMED(c, BMS_TAG_SETUP, launch_spline_table(c->stream, (const double*)d_x, n, d_tab));
   double* d_R;
   if ((rc = dev_buf_t(c, "R", (size_t)n * ld * 2, &d_R))) return rc;
   double* d_out = (double*)out;
   if (mem == BMS_HOST)
     if ((rc = dev_buf_t(c, "out_data", (size_t)n_new * n_cols * 2, &d_out))) return rc;
-  HIP_TRY(c, launch_spline_forward(c->stream, d_y, d_R, 2 * ld, (int)n_cols, 0, n, n, (const double*)d_x, d_tab, SPLINE_TILE, SPLINE_HALO));
-  HIP_TRY(c, launch_spline_backward_eval(c->stream, d_y, d_R, 2 * ld, (int)n_cols, 0, n, n, (const double*)d_x, d_tab, SPLINE_TILE,
+  TIMED(c, BMS_TAG_SPLINE_FORWARD, launch_spline_forward(c->stream, d_y, d_R, 2 * ld, (int)n_cols, 0, n, n, (const double*)d_x, d_tab, SPLINE_TILE, SPLINE_HALO));
+  TIMED(c, BMS_TAG_SPLINE_BACKWARD, launch_spline_backward_eval(c->stream, d_y, d_R, 2 * ld, (int)n_cols, 0, n, n, (const double*)d_x, d_tab, SPLINE_TILE,
                                          SPLINE_HALO, (const double*)d_xn, nullptr, nullptr, 0.0, 0, n_new, d_out, 2 * n_cols));
   if (mem == BMS_HOST) HIP_TRY(c, hipMemcpyAsync(out, d_out, (size_t)n_new * n_cols * 16, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(c, hipStreamSynchronize(c->stream));

@@ -17,6 +17,7 @@ from ._lib import (
     BMS_TERM_PSI,
     bms_wm_input,
     bms_transformation,
+    bms_shard,
     c_i64,
     c_vp,
     dptr,
@@ -126,11 +127,15 @@ def transform_modes(
     device=False,
     ld=None,
     out_ptr=None,
+    shard=None,
 ):
     """bms_transform_modes.  Host mode: data complex128 [N, n_modes] -> (t_out[N'], data_out[N', n_out]).
     Device mode (device=True): `data` and each aux data are device addresses, `ld` the row stride,
     `out_ptr` a device buffer of N * n_out complex; returns (t_out[N'], N').
-    aux: sequence of (data, ell_min, ell_max, spin, coeff, power[, ld])."""
+    aux: sequence of (data, ell_min, ell_max, spin, coeff, power[, ld]).
+    shard: optional (data_row0, data_rows, out_i0, out_i1) -- `t` stays the GLOBAL time array, `data` holds only
+    rows [data_row0, data_row0 + data_rows); outputs are those with global input index in [out_i0, out_i1);
+    the returned tuple then has the first global index appended."""
     ctx = _ctx(ctx)
     t = np.ascontiguousarray(t, dtype=float)
     n = t.shape[0]
@@ -144,8 +149,9 @@ def transform_modes(
         inp.mem = BMS_DEVICE
     else:
         data = _lib.as_c16(data)
-        if data.shape != (n, LM_total_size(ell_min, ell_max)):
-            raise ValueError(f"data shape {data.shape} inconsistent with n_times={n}, ell range [{ell_min}, {ell_max}]")
+        n_rows = n if shard is None else int(shard[1])
+        if data.shape != (n_rows, LM_total_size(ell_min, ell_max)):
+            raise ValueError(f"data shape {data.shape} inconsistent with rows={n_rows}, ell range [{ell_min}, {ell_max}]")
         inp.data = data.ctypes.data
         inp.ld = data.shape[1]
         inp.mem = BMS_HOST
@@ -160,7 +166,7 @@ def transform_modes(
             inp.aux_ld[i] = int(a[6])
         else:
             adata = _lib.as_c16(adata)
-            if adata.shape != (n, LM_total_size(amin, amax)):
+            if adata.shape != ((n if shard is None else int(shard[1])), LM_total_size(amin, amax)):
                 raise ValueError("auxiliary data shape mismatch")
             keep.append(adata)
             inp.aux_data[i] = adata.ctypes.data
@@ -169,20 +175,44 @@ def transform_modes(
         inp.aux_coeff[i], inp.aux_power[i] = float(acoeff), int(apower)
     s = abs(int(spin_weight))
     n_out = LM_total_size(s, transformation.ell_max_out)
-    t_out = np.empty(n, dtype=float)
     n_new = c_i64(0)
+    first = c_i64(0)
+    sh = None
+    n_alloc = n
+    if shard is not None:
+        sh = bms_shard(int(shard[0]), int(shard[1]), int(shard[2]), int(shard[3]))
+        n_alloc = max(0, min(n, int(shard[3])) - max(0, int(shard[2])))
+    t_out = np.empty(max(n_alloc, 1), dtype=float)
+    shp = ctypes.byref(sh) if sh is not None else None
     if device:
-        rc = _lib.load().bms_transform_modes(
-            ctx.handle, ctypes.byref(inp), ctypes.byref(transformation), dptr(t_out), c_vp(int(out_ptr)), ctypes.byref(n_new)
+        rc = _lib.load().bms_transform_modes_shard(
+            ctx.handle, ctypes.byref(inp), ctypes.byref(transformation), shp, dptr(t_out), c_vp(int(out_ptr)),
+            ctypes.byref(n_new), ctypes.byref(first),
         )
         ctx.check(rc, "bms_transform_modes")
-        return t_out[: n_new.value], n_new.value
-    out = np.empty((n, n_out), dtype=np.complex128)
-    rc = _lib.load().bms_transform_modes(
-        ctx.handle, ctypes.byref(inp), ctypes.byref(transformation), dptr(t_out), vptr(out), ctypes.byref(n_new)
+        res = (t_out[: n_new.value], n_new.value)
+        return res + (first.value,) if shard is not None else res
+    out = np.empty((max(n_alloc, 1), n_out), dtype=np.complex128)
+    rc = _lib.load().bms_transform_modes_shard(
+        ctx.handle, ctypes.byref(inp), ctypes.byref(transformation), shp, dptr(t_out), vptr(out), ctypes.byref(n_new),
+        ctypes.byref(first),
     )
     ctx.check(rc, "bms_transform_modes")
-    return t_out[: n_new.value].copy(), out[: n_new.value].copy()
+    res = (t_out[: n_new.value].copy(), out[: n_new.value].copy())
+    return res + (first.value,) if shard is not None else res
+
+
+def shard_plan(t, transformation, out_i0, out_i1, ctx=None):
+    """bms_shard_plan -> ((need_row0, need_row1), (i_lo, i_hi)): input rows a rank must hold to produce the
+    outputs with global input index in [out_i0, out_i1), and the global valid output window."""
+    t = np.ascontiguousarray(t, dtype=float)
+    need = (c_i64 * 2)()
+    win = (c_i64 * 2)()
+    # host-only planning: works without a GPU context
+    rc = _lib.load().bms_shard_plan(None, dptr(t), t.shape[0], ctypes.byref(transformation), int(out_i0), int(out_i1), need, win)
+    if rc != 0:
+        _lib._raise(rc, None, "bms_shard_plan")
+    return (need[0], need[1]), (win[0], win[1])
 
 
 def transform_abd(u, raw, ell_max, transformation, ctx=None):
@@ -208,11 +238,13 @@ def transform_abd(u, raw, ell_max, transformation, ctx=None):
 
 
 def rotor_grid(frame_rotation, boost_velocity, n_theta, n_phi, ctx=None):
-    ctx = _ctx(ctx)
+    """boosted_grid / R_j_k (host-only set-up: works without a GPU context)."""
     fr = np.ascontiguousarray(frame_rotation, dtype=float)
     v = np.ascontiguousarray(boost_velocity, dtype=float)
     out = np.empty((n_theta, n_phi, 4))
-    ctx.check(_lib.load().bms_rotor_grid(ctx.handle, dptr(fr), dptr(v), n_theta, n_phi, dptr(out)), "bms_rotor_grid")
+    rc = _lib.load().bms_rotor_grid(None, dptr(fr), dptr(v), n_theta, n_phi, dptr(out))
+    if rc != 0:
+        _lib._raise(rc, None, "bms_rotor_grid")
     return out
 
 

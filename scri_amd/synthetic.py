@@ -1,0 +1,55 @@
+"""Synthetic workloads of BASELINE.json / SURVEY.md section 8(d): smooth-in-time mode data (so the per-pixel
+splines are well conditioned) and the BMS transformations they are benchmarked with."""
+import numpy as np
+
+from .mode_algebra import LM_range, LM_index
+
+
+def chirp_modes(t, ell_min, ell_max, seed):
+    """data[t, (l,m)] = a_lm 10^(-l/2) exp(i m phi(t)), phi = 0.05 t + 2e-6 t^2, a ~ N(0,1) + i N(0,1)."""
+    rng = np.random.default_rng(seed)
+    LM = LM_range(ell_min, ell_max)
+    a = rng.normal(size=LM.shape[0]) + 1j * rng.normal(size=LM.shape[0])
+    amp = a * 10.0 ** (-LM[:, 0] / 2.0)
+    phase = 0.05 * t + 2e-6 * t**2
+    return amp[None, :] * np.exp(1j * LM[None, :, 1] * phase[:, None])
+
+
+def real_supertranslation(alpha):
+    """Project mode weights onto those of a real function: a_{l,m} = (-1)^m conj(a_{l,-m})."""
+    a = np.array(alpha, dtype=complex)
+    lmax = int(round(np.sqrt(a.size))) - 1
+    for ell in range(lmax + 1):
+        for m in range(ell + 1):
+            ip, im = LM_index(ell, m, 0), LM_index(ell, -m, 0)
+            a[ip] = (a[ip] + (-1.0) ** m * np.conj(a[im])) / 2
+            a[im] = (-1.0) ** m * np.conj(a[ip])
+    return a
+
+
+# supertranslation of tests/test_bms_transformations.py:298 of the reference (made real), x 1e-3
+S9 = real_supertranslation(np.array([1, 2 + 4j, 3, -2 + 4j, 7 - 5j, -3 - 2j, 4, 3 - 2j, 7 + 5j]) * 1e-3)
+
+CONFIGS = {
+    # name: (ell_max, n_times, dt, seed, transformation kwargs)
+    "cfg2": dict(ell_max=8, n_times=100_000, dt=0.1, seed=3, kwargs=dict(supertranslation=S9)),
+    "cfg3": dict(
+        ell_max=16, n_times=100_000, dt=0.1, seed=5,
+        kwargs=dict(supertranslation=S9, frame_rotation=np.array([1.0, 2, 3, 4]) / np.sqrt(30), boost_velocity=np.array([1.0, 2, 3]) * 1e-4),
+    ),
+    "cfg4": dict(
+        ell_max=16, n_times=1_000_000, dt=0.1, seed=6,
+        kwargs=dict(supertranslation=S9, frame_rotation=np.array([1.0, 2, 3, 4]) / np.sqrt(30), boost_velocity=np.array([1.0, 2, 3]) * 1e-4),
+    ),
+}
+
+
+def workload(name, n_times=None, rows=None):
+    """(t_global, data[rows], spec): `rows=(r0, r1)` generates only those rows of the global series."""
+    spec = dict(CONFIGS[name])
+    n = int(n_times or spec["n_times"])
+    spec["n_times"] = n
+    t = np.arange(n) * spec["dt"]
+    r0, r1 = rows if rows is not None else (0, n)
+    data = chirp_modes(t[r0:r1], 2, spec["ell_max"], spec["seed"])
+    return t, data, spec
