@@ -1,0 +1,71 @@
+"""The C-ABI shared library loads and exports every symbol include/scri_amd.h declares (no GPU needed);
+without a GPU the product path fails loudly instead of falling back to anything."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_functions():
+    text = open(os.path.join(ROOT, "include", "scri_amd.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(bms_[a-z_A-Z0-9]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    from scri_amd import _lib
+
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    names = _declared_functions()
+    assert len(names) >= 18
+    for name in names:
+        assert hasattr(lib, name), f"{name} declared in include/scri_amd.h but not exported"
+    # and the Python binding knows each of them
+    assert set(names) == set(_lib.SIGNATURES), set(names) ^ set(_lib.SIGNATURES)
+    assert _lib.load().bms_version() >= 1
+
+
+def test_struct_layouts_match_header_sizes():
+    from scri_amd import _lib
+
+    # sizes implied by the header on LP64: guards against drift between the header and the ctypes mirror
+    assert ctypes.sizeof(_lib.bms_shard) == 32
+    assert ctypes.sizeof(_lib.bms_transformation) == 8 + 8 + 32 + 24 + 16
+    assert ctypes.sizeof(_lib.bms_wm_input) == 8 + 8 + 8 + 8 + 4 * 8 + 32 + 32 + 16 + 16 + 16 + 32 + 16
+
+
+def _have_gpu():
+    try:
+        import torch
+
+        return torch.cuda.is_available()
+    except Exception:
+        return False
+
+
+@pytest.mark.skipif(_have_gpu(), reason="only meaningful on a machine without a GPU")
+def test_no_cpu_fallback():
+    import scri_amd
+
+    with pytest.raises(scri_amd.BMSError, match="no CPU fallback"):
+        scri_amd.Context(0)
+    w = scri_amd.WaveformModes(t=np.linspace(0, 1, 10), data=np.zeros((10, 21), dtype=complex), ell_min=2, ell_max=4,
+                               dataType=scri_amd.h, frameType=scri_amd.Inertial)
+    with pytest.raises(scri_amd.BMSError):
+        w.transform(time_translation=0.1)
+    with pytest.raises(scri_amd.BMSError):
+        w.rotate_decomposition_basis([1.0, 0, 0, 0])
+
+
+def test_product_does_not_import_the_oracle():
+    pkg = os.path.join(ROOT, "scri_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                text = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", text, flags=re.M), f"{f} imports the oracle"
+                assert "/root/reference" not in text
