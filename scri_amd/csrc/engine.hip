@@ -1023,5 +1023,167 @@ extern "C" int bms_cubic_spline(bms_ctx* c, const double* x, int64_t n, const vo
 extern "C" int bms_transform_abd(bms_ctx* c, const double* u, const void* raw, int mem, int64_t n_times, int ell_max,
                                  const bms_transformation* tr, double* u_out, void* raw_out, int64_t* n_times_out) {
   if (!c) return BMS_ERR_INVALID;
-  return fail(c, BMS_ERR_UNSUPPORTED, "bms_transform_abd: not implemented yet");
+  if (!u || !raw || !tr || !u_out || !raw_out || !n_times_out) return fail(c, BMS_ERR_INVALID, "NULL argument");
+  HIP_TRY(c, hipSetDevice(c->device));
+  const int64_t n = n_times;
+  int rc = validate_common(c, n, u, tr);
+  if (rc) return rc;
+  if (ell_max < 0 || tr->ell_max_out < 0) return fail(c, BMS_ERR_INVALID, "bad ell_max");
+  static const int spins[6] = {2, 1, 0, -1, -2, 2};  // psi0..psi4, sigma
+  const int nm = (ell_max + 1) * (ell_max + 1);
+  const int n_out = (tr->ell_max_out + 1) * (tr->ell_max_out + 1);
+  const int lst = tr->ell_max_supertranslation;
+  const cplx* st = (const cplx*)tr->supertranslation;
+
+  // ---- host tables (transformations.py:306-321, 391-396)
+  PixelTables T;
+  build_pixel_tables(tr, T);
+  const int n_pix = T.n_pix;
+  // window: timeprime = (u - tt) / gamma  (division, unlike the WaveformModes flavour)
+  double umin = -INFINITY, umax = INFINITY;
+  for (int p = 0; p < n_pix; ++p) {
+    umin = std::max(umin, T.k[p] * (u[0] - T.alpha[p]));
+    umax = std::min(umax, T.k[p] * (u[n - 1] - T.alpha[p]));
+  }
+  const int64_t i_lo = std::partition_point(u, u + n, [&](double ui) { return (ui - T.tt) / T.gamma < umin; }) - u;
+  int64_t i_hi = std::partition_point(u, u + n, [&](double ui) { return (ui - T.tt) / T.gamma <= umax; }) - u;
+  if (i_hi < i_lo) i_hi = i_lo;
+  const int64_t n_new = i_hi - i_lo;
+  *n_times_out = n_new;
+  for (int64_t i = 0; i < n_new; ++i) u_out[i] = (u[i_lo + i] - T.tt) / T.gamma;
+  if (n_new == 0) return BMS_OK;
+
+  std::vector<cplx> c1((size_t)(lst + 1) * (lst + 1)), c2((size_t)(lst + 1) * (lst + 1)), cv(4);
+  for (int l = 0; l <= lst; ++l)
+    for (int m = -l; m <= l; ++m) {
+      const cplx a = st[LM_index(l, m, 0)];
+      const double f1 = std::sqrt((double)l * (l + 1.0)) / std::sqrt(2.0);                                          // eth alpha / sqrt2
+      const double f2 = 0.5 * (std::sqrt((double)l * (l + 1.0)) * (l >= 1 ? std::sqrt((l - 1.0) * (l + 2.0)) : 0.0));  // eth eth alpha / 2
+      c1[LM_index(l, m, 0)] = {f1 * a.re, f1 * a.im};
+      c2[LM_index(l, m, 0)] = {f2 * a.re, f2 * a.im};
+    }
+  const double* v = tr->boost_velocity;
+  cv[0] = {0, 0};
+  cv[1] = {v[0] * std::sqrt(2 * M_PI / 3), v[1] * std::sqrt(2 * M_PI / 3)};
+  cv[2] = {v[2] * std::sqrt(4 * M_PI / 3), 0};
+  cv[3] = {-v[0] * std::sqrt(2 * M_PI / 3), v[1] * std::sqrt(2 * M_PI / 3)};
+  std::vector<double> ethk(2 * (size_t)n_pix), etha(2 * (size_t)n_pix), ethetha(2 * (size_t)n_pix), ik(n_pix), ik3(n_pix);
+  for (int p = 0; p < n_pix; ++p) {
+    double r[3];
+    rotate_z(T.R[p], r);
+    const double vr = v[0] * r[0] + v[1] * r[1] + v[2] * r[2];
+    const cplx ev = eval_modes_host(cv.data(), 1, 1, T.R[p]);
+    ethk[2 * p] = ev.re / (1 - vr);
+    ethk[2 * p + 1] = ev.im / (1 - vr);
+    const cplx e1 = eval_modes_host(c1.data(), lst, 1, T.R[p]);
+    const cplx e2 = eval_modes_host(c2.data(), lst, 2, T.R[p]);
+    etha[2 * p] = e1.re, etha[2 * p + 1] = e1.im;
+    ethetha[2 * p] = e2.re, ethetha[2 * p + 1] = e2.im;
+    const double one_over_k = T.gamma * (1 - vr);
+    ik[p] = one_over_k;
+    ik3[p] = one_over_k * one_over_k * one_over_k;
+  }
+  std::vector<double> qth, wpix((size_t)n_pix), grid_rot(4 * (size_t)n_pix);
+  theta_quadrature_weights(T.n_theta, qth);
+  for (int j = 0; j < T.n_theta; ++j)
+    for (int k = 0; k < T.n_phi; ++k) {
+      const int p = j * T.n_phi + k;
+      wpix[p] = qth[j] / T.n_phi;
+      const Quat q = from_spherical_coords(M_PI * j / (T.n_theta - 1), (2 * M_PI) * k / T.n_phi);
+      grid_rot[4 * p] = q.w, grid_rot[4 * p + 1] = q.x, grid_rot[4 * p + 2] = q.y, grid_rot[4 * p + 3] = q.z;
+    }
+
+  // ---- device tables
+  hipStream_t S = c->stream;
+  void* vp;
+#define UP(name, vec, dst)                                                            \
+  if ((rc = upload(c, name, (vec).data(), sizeof((vec)[0]) * (vec).size(), &vp))) return rc; \
+  double* dst = (double*)vp;
+  if ((rc = upload(c, "rotors", T.R.data(), sizeof(Quat) * n_pix, &vp))) return rc;
+  double* d_rot = (double*)vp;
+  UP("grid_rotors", grid_rot, d_grot)
+  UP("wpix", wpix, d_wpix)
+  UP("skew_a", T.skew_a, d_skewa)
+  UP("skew_b", T.skew_b, d_skewb)
+  UP("alpha", T.alpha, d_alpha)
+  UP("abd_ethk", ethk, d_ethk)
+  UP("abd_etha", etha, d_etha)
+  UP("abd_ethetha", ethetha, d_ethetha)
+  UP("abd_ik", ik, d_ik)
+  UP("abd_ik3", ik3, d_ik3)
+#undef UP
+  if ((rc = upload(c, "times", u, 8 * (size_t)n, &vp))) return rc;
+  double* d_x = (double*)vp;
+
+  const long long P2 = 2LL * n_pix, ldg = round_up(P2, 16), ldb = round_up(P2, 128);
+  const int K = 2 * nm;
+  const long long brows = round_up(K, 16);
+  const long long ldw = round_up(2LL * n_out, 128), wrows = round_up(P2, 16);
+  // five distinct spins: matrices indexed by spin + 2
+  double *d_B[5], *d_W[5];
+  for (int si = 0; si < 5; ++si) {
+    char nm1[32], nm2[32];
+    snprintf(nm1, sizeof nm1, "abd_B%d", si);
+    snprintf(nm2, sizeof nm2, "abd_W%d", si);
+    if ((rc = dev_buf_t(c, nm1, (size_t)brows * ldb, &d_B[si]))) return rc;
+    if ((rc = dev_buf_t(c, nm2, (size_t)wrows * ldw, &d_W[si]))) return rc;
+    HIP_TRY(c, hipMemsetAsync(d_B[si], 0, sizeof(double) * brows * ldb, S));
+    HIP_TRY(c, hipMemsetAsync(d_W[si], 0, sizeof(double) * wrows * ldw, S));
+    TIMED(c, BMS_TAG_SETUP, launch_swsh_matrix(S, d_rot, n_pix, si - 2, 0, ell_max, d_B[si], ldb));
+    TIMED(c, BMS_TAG_SETUP, launch_quadrature_matrix(S, d_grot, d_wpix, n_pix, si - 2, 0, tr->ell_max_out, d_W[si], ldw));
+  }
+  SplineTable* d_tab;
+  if ((rc = dev_buf_t(c, "spline_table", (size_t)n, &d_tab))) return rc;
+  TIMED(c, BMS_TAG_SETUP, launch_spline_table(S, d_x, n, d_tab));
+
+  const double* d_raw;
+  if ((rc = stage_in(c, "in_data", raw, mem, (size_t)6 * n * nm * 16, &d_raw))) return rc;
+  double* d_out = (double*)raw_out;
+  if (mem == BMS_HOST)
+    if ((rc = dev_buf_t(c, "out_data", (size_t)6 * n * n_out * 2, &d_out))) return rc;
+
+  // ---- chunk loop: 6 fields x (Y, R, G)
+  const int margin = SPLINE_HALO + 2;
+  const double bytes_per_row = 18.0 * ldg * 8.0;
+  int64_t chunk = (int64_t)std::max(256.0, (double)c->ws_limit / bytes_per_row - 4.0 * margin);
+  chunk = std::min<int64_t>(chunk, n_new);
+  for (int64_t c0 = i_lo; c0 < i_hi; c0 += chunk) {
+    const int64_t c1_ = std::min<int64_t>(c0 + chunk, i_hi);
+    int64_t ja, jb;
+    needed_knots(T, u, n, c0, c1_, ja, jb);
+    const int64_t g0 = std::max<int64_t>(0, ja - margin), g1 = std::min<int64_t>(n, jb + margin + 1);
+    const int64_t rows_in = g1 - g0, rows_out = c1_ - c0;
+    double *d_Y, *d_R, *d_G;
+    if ((rc = dev_buf_t(c, "Y", (size_t)6 * rows_in * ldg, &d_Y))) return rc;
+    if ((rc = dev_buf_t(c, "R", (size_t)6 * rows_in * ldg, &d_R))) return rc;
+    if ((rc = dev_buf_t(c, "G", (size_t)6 * rows_out * ldg, &d_G))) return rc;
+    AbdGrids grids;
+    for (int f = 0; f < 6; ++f) {
+      grids.y[f] = d_Y + (size_t)f * rows_in * ldg;
+      TIMED(c, BMS_TAG_GEMM_SYNTHESIS,
+            launch_dgemm(S, d_raw + ((size_t)f * n + g0) * nm * 2, 2LL * nm, d_B[spins[f] + 2], ldb, grids.y[f], ldg, rows_in,
+                         (int)P2, K, nullptr, nullptr));
+    }
+    TIMED(c, BMS_TAG_POINTWISE,
+          launch_abd_mix(S, grids, ldg, n_pix, rows_in, d_x + g0, d_alpha, d_ethk, d_etha, d_ethetha, d_ik, d_ik3));
+    for (int f = 0; f < 6; ++f) {
+      double* Rf = d_R + (size_t)f * rows_in * ldg;
+      double* Gf = d_G + (size_t)f * rows_out * ldg;
+      TIMED(c, BMS_TAG_SPLINE_FORWARD,
+            launch_spline_forward(S, grids.y[f], Rf, ldg, n_pix, g0, rows_in, n, d_x, d_tab, SPLINE_TILE, SPLINE_HALO));
+      TIMED(c, BMS_TAG_SPLINE_BACKWARD,
+            launch_spline_backward_eval(S, grids.y[f], Rf, ldg, n_pix, g0, rows_in, n, d_x, d_tab, SPLINE_TILE, SPLINE_HALO,
+                                        d_x, d_skewa, d_skewb, T.tt, c0, c1_, Gf, ldg));
+      TIMED(c, BMS_TAG_GEMM_ANALYSIS,
+            launch_dgemm(S, Gf, ldg, d_W[spins[f] + 2], ldw, d_out + ((size_t)f * n + (c0 - i_lo)) * n_out * 2, 2LL * n_out,
+                         rows_out, 2 * n_out, (int)P2, nullptr, nullptr));
+    }
+  }
+  if (mem == BMS_HOST) {
+    for (int f = 0; f < 6; ++f)
+      HIP_TRY(c, hipMemcpyAsync((char*)raw_out + (size_t)f * n * n_out * 16, d_out + (size_t)f * n * n_out * 2,
+                                (size_t)n_new * n_out * 16, hipMemcpyDeviceToHost, S));
+  }
+  HIP_TRY(c, hipStreamSynchronize(S));
+  return BMS_OK;
 }

@@ -53,6 +53,14 @@ hipError_t launch_spline_backward_eval(hipStream_t stream, const double* Y, cons
 hipError_t launch_psi_mix(hipStream_t stream, double* Y, const double* Yaux, long long ld, int n_pix, long long n_rows,
                           const double* x /* times of the rows */, const double* alpha, const double* xa /* c16[n_pix] */,
                           const double* xb /* c16[n_pix] */, double coeff, int power);
+// Horner mixing of the six ABD grids in place (transformations.py:340-385)
+struct AbdGrids {
+  double* y[6];
+};
+hipError_t launch_abd_mix(hipStream_t stream, const AbdGrids& g, long long ld, int n_pix, long long n_rows, const double* u,
+                          const double* alpha, const double* ethk_over_k /* c16[n_pix] */,
+                          const double* eth_alpha /* c16 */, const double* etheth_alpha /* c16 */, const double* inv_k,
+                          const double* inv_k3);
 // y[t][col] = (y[t][col] - off[col]) * scale[col]
 hipError_t launch_affine_cols(hipStream_t stream, double* Y, long long ld, int n_cols, long long n_rows,
                               const double* off, const double* scale);

@@ -128,6 +128,70 @@ hipError_t launch_psi_mix(hipStream_t stream, double* Y, const double* Yaux, lon
   return hipGetLastError();
 }
 
+// Horner mixing of the six ABD fields on the distorted grid, in place
+// (scri/asymptotic_bondi_data/transformations.py:340-385; Moreschi-Boyle signs):
+//   X     = (eth k / k)_p (u_t - alpha_p) - (eth alpha)_p
+//   psi0' = ((((psi4 X - 4 psi3) X + 6 psi2) X - 4 psi1) X + psi0) / k^3
+//   psi1' = (((-psi4 X + 3 psi3) X - 3 psi2) X + psi1) / k^3
+//   psi2' = ((psi4 X - 2 psi3) X + psi2) / k^3,   psi3' = (-psi4 X + psi3) / k^3,   psi4' = psi4 / k^3
+//   sigma' = (sigma - eth^2 alpha) / k
+__global__ __launch_bounds__(256) void abd_mix_kernel(AbdGrids g, long long ld, int n_pix, long long n_rows,
+                                                      const double* __restrict__ u, const double* __restrict__ alpha,
+                                                      const double* __restrict__ ethk_over_k,
+                                                      const double* __restrict__ eth_alpha,
+                                                      const double* __restrict__ etheth_alpha,
+                                                      const double* __restrict__ inv_k, const double* __restrict__ inv_k3) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n_pix) return;
+  const double al = alpha[p], ik = inv_k[p], ik3 = inv_k3[p];
+  const cplx A = {ethk_over_k[2 * p], ethk_over_k[2 * p + 1]}, B = {eth_alpha[2 * p], eth_alpha[2 * p + 1]};
+  const cplx EE = {etheth_alpha[2 * p], etheth_alpha[2 * p + 1]};
+  for (long long r = blockIdx.y; r < n_rows; r += gridDim.y) {
+    const double dt = u[r] - al;
+    const cplx X = {A.re * dt - B.re, A.im * dt - B.im};
+    const long long o = r * ld + 2LL * p;
+    cplx f[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      const double2 v = *reinterpret_cast<const double2*>(g.y[i] + o);
+      f[i] = {v.x, v.y};
+    }
+    auto axpy = [](cplx t, cplx X, double c, cplx f) {  // t*X + c*f
+      cplx r = cmul(t, X);
+      return cplx{r.re + c * f.re, r.im + c * f.im};
+    };
+    cplx t0 = f[4];
+    t0 = axpy(t0, X, -4.0, f[3]);
+    t0 = axpy(t0, X, 6.0, f[2]);
+    t0 = axpy(t0, X, -4.0, f[1]);
+    t0 = axpy(t0, X, 1.0, f[0]);
+    cplx t1 = {-f[4].re, -f[4].im};
+    t1 = axpy(t1, X, 3.0, f[3]);
+    t1 = axpy(t1, X, -3.0, f[2]);
+    t1 = axpy(t1, X, 1.0, f[1]);
+    cplx t2 = f[4];
+    t2 = axpy(t2, X, -2.0, f[3]);
+    t2 = axpy(t2, X, 1.0, f[2]);
+    cplx t3 = {-f[4].re, -f[4].im};
+    t3 = axpy(t3, X, 1.0, f[3]);
+    const cplx out[6] = {{t0.re * ik3, t0.im * ik3}, {t1.re * ik3, t1.im * ik3}, {t2.re * ik3, t2.im * ik3},
+                         {t3.re * ik3, t3.im * ik3}, {f[4].re * ik3, f[4].im * ik3},
+                         {(f[5].re - EE.re) * ik, (f[5].im - EE.im) * ik}};
+#pragma unroll
+    for (int i = 0; i < 6; ++i) *reinterpret_cast<double2*>(g.y[i] + o) = double2{out[i].re, out[i].im};
+  }
+}
+
+hipError_t launch_abd_mix(hipStream_t stream, const AbdGrids& g, long long ld, int n_pix, long long n_rows, const double* u,
+                          const double* alpha, const double* ethk_over_k, const double* eth_alpha,
+                          const double* etheth_alpha, const double* inv_k, const double* inv_k3) {
+  if (n_rows <= 0 || n_pix <= 0) return hipSuccess;
+  dim3 grid((n_pix + 255) / 256, (unsigned)(n_rows < 2048 ? n_rows : 2048));
+  hipLaunchKernelGGL(abd_mix_kernel, grid, dim3(256), 0, stream, g, ld, n_pix, n_rows, u, alpha, ethk_over_k, eth_alpha,
+                     etheth_alpha, inv_k, inv_k3);
+  return hipGetLastError();
+}
+
 __global__ __launch_bounds__(256) void affine_cols_kernel(double* __restrict__ Y, long long ld, int n_cols,
                                                           long long n_rows, const double* __restrict__ off,
                                                           const double* __restrict__ scale) {
