@@ -1,0 +1,180 @@
+"""The reference's own hot-path tests, run against the GPU engine through the scri-compatible
+classes.  Each test names the reference test it mirrors; analytic answers come from the oracle's generators."""
+import math
+
+import numpy as np
+import pytest
+
+import scri_amd
+from oracle import quat, wigner, rotations_ref
+from oracle import sample_waveforms_ref as samples
+from oracle import waveform_grid_ref as grid_ref
+
+pytestmark = pytest.mark.gpu
+
+
+def to_gpu(w, ctx):
+    return scri_amd.WaveformModes(
+        t=w.t, data=w.data, ell_min=w.ell_min, ell_max=w.ell_max, dataType=w.dataType, frameType=w.frameType,
+        r_is_scaled_out=w.r_is_scaled_out, m_is_scaled_out=w.m_is_scaled_out, frame=w.frame, ctx=ctx,
+    )
+
+
+def test_time_translation(ctx):
+    """tests/test_waveform_grid.py:17-27."""
+    dt = 1.469
+    w1 = to_gpu(samples.constant_waveform(), ctx)
+    w2 = w1.transform(time_translation=dt)
+    w3 = w1.transform(supertranslation=[math.sqrt(4 * math.pi) * dt])
+    assert np.allclose(w1.t, w2.t + dt, rtol=0.0, atol=2e-15)
+    assert np.allclose(w1.data, w2.data, rtol=0.0, atol=6e-14)
+    assert np.allclose(w2.t, w3.t, rtol=0.0, atol=0.0)
+    assert np.allclose(w2.data, w3.data, rtol=0.0, atol=0.0)
+
+
+def test_BMS_rotation(ctx):
+    """tests/test_waveform_grid.py:30-38: the grid path with frame_rotation equals the Wigner-D path."""
+    base = samples.constant_waveform(t=np.linspace(-10.0, 100.0, num=40))
+    for R in samples.Rs():
+        w2 = to_gpu(base, ctx)
+        w2.rotate_decomposition_basis(R)
+        w3 = to_gpu(base, ctx).transform(frame_rotation=R)
+        assert np.allclose(w2.data, w3.data, rtol=1e-15, atol=4e-13)
+
+
+@pytest.mark.parametrize("s", [-2, -1, 0, 1, 2])
+def test_space_translation_analytic(ctx, s):
+    """tests/test_waveform_grid.py:41-92 (subset of (l, m) per spin): psi_n types, auxiliary psi's zeroed, so the
+    BMS_TERM_PSI mixing path of the engine is exercised; answer = analytic Wigner-3j formula."""
+    for ell, m in [(max(abs(s), 1), -1), (5, 3), (8, -8)]:
+        if ell < abs(s):
+            continue
+        for st in ([1.0, 0.0, 0.0], [0.0, 1.0, 0.0], [0.0, 0.0, 1.0]):
+            aux = {}
+            for i in range(s + 2):
+                a = samples.single_mode_proportional_to_time(s=i - 2)
+                a.data *= 0
+                aux[f"psi{4-i}_modes"] = to_gpu(a, ctx)
+            w1 = to_gpu(samples.single_mode_proportional_to_time(s=s, ell=ell, m=m), ctx).transform(space_translation=st, **aux)
+            w2 = samples.single_mode_proportional_to_time_supertranslated(s=s, ell=ell, m=m, space_translation=np.array(st))
+            i1A = np.argmin(abs(w1.t - (w1.t[0] + 2)))
+            i1B = np.argmin(abs(w1.t - (w1.t[-1] - 2)))
+            i2A = np.argmin(abs(w2.t - w1.t[i1A]))
+            i2B = np.argmin(abs(w2.t - w1.t[i1B]))
+            assert np.allclose(w1.t[i1A : i1B + 1], w2.t[i2A : i2B + 1], rtol=0.0, atol=1e-16)
+            # 5e-14 in the reference (its FFT-based analysis sums ~40 terms per output); the dense-quadrature
+            # analysis GEMM accumulates 2 n_pix = 722 products per output in one fp64 chain: ~sqrt(722) eps |f| = 6e-14
+            assert np.allclose(w1.data[i1A : i1B + 1], w2.data[i2A : i2B + 1], rtol=0.0, atol=1.5e-13), (s, ell, m, st)
+
+
+@pytest.mark.parametrize("dataType", [scri_amd.psi0, scri_amd.psi1, scri_amd.psi2, scri_amd.psi3])
+def test_psi_mixing_matches_oracle(ctx, dataType):
+    """scri/waveform_grid.py:504-550 with non-trivial higher Weyl scalars, supertranslation and boost."""
+    from tests.test_gpu_transform_modes import smooth_waveform, real_supertranslation
+
+    w = smooth_waveform(300, 5, 300 + dataType, dataType)
+    kw = dict(supertranslation=real_supertranslation(2, 5, 0.05), boost_velocity=np.array([0.01, 0.02, -0.01]),
+              frame_rotation=np.array([1.0, 0.5, -0.2, 0.1]))
+    aux_o, aux_g = {}, {}
+    for DT in range(dataType + 1, scri_amd.psi4 + 1):
+        a = smooth_waveform(300, 4 + (DT % 2), 400 + DT, DT)
+        aux_o[f"psi{DT-1}_modes"] = a
+        aux_g[f"psi{DT-1}_modes"] = to_gpu(a, ctx)
+    expect = grid_ref.transform(w, **kw, **aux_o)
+    got = to_gpu(w, ctx).transform(**kw, **aux_g)
+    assert got.t.shape == expect.t.shape
+    assert np.abs(got.data - expect.data).max() < 1e-12 * max(1.0, np.abs(expect.data).max())
+
+
+def test_supertranslation_inverses(ctx):
+    """tests/test_waveform_grid.py:161-185."""
+    w1 = to_gpu(samples.random_waveform_proportional_to_time(n_times=601), ctx)
+    for ellpp, mpp in [(0, 0), (1, -1), (2, 0), (2, 2), (3, -2)]:
+        st = np.zeros(16, dtype=complex)
+        if mpp == 0:
+            st[wigner.LM_index(ellpp, 0, 0)] = 1.0
+        elif mpp < 0:
+            st[wigner.LM_index(ellpp, mpp, 0)] = 1.0
+            st[wigner.LM_index(ellpp, -mpp, 0)] = (-1.0) ** mpp
+        else:
+            st[wigner.LM_index(ellpp, mpp, 0)] = 1.0j
+            st[wigner.LM_index(ellpp, -mpp, 0)] = (-1.0) ** mpp * -1.0j
+        w2 = w1.transform(supertranslation=st).transform(supertranslation=-st)
+        w1i = w1.interpolate(w2.t)
+        assert w1i._allclose(w2, rtol=5e-10, atol=5e-14)
+
+
+def test_boost_inverses(ctx):
+    """tests/test_waveform_grid.py:188-214, both legs (beta = 1e-2 at l = 8, beta = 1e-1 at l = 14)."""
+    for beta, ell_max in [(1e-2, 8), (1e-1, 14)]:
+        for v in [np.array([0.0, 0.0, beta]), np.array([0.0, beta, 0.0]), np.array([beta, 0.0, 0.0])]:
+            w1 = to_gpu(samples.single_mode_constant_rotation(s=-2, ell=2, m=2, omega=0.3, t_0=-10.0, t_1=10.0, dt=1.0 / 200.0), ctx)
+            w1 = w1.transform(space_translation=np.array([0.1, 0.0, 0.0]))
+            w1.m_is_scaled_out = False
+            w2 = w1.transform(boost_velocity=v, n_theta=2 * (ell_max + 1) + 1, n_phi=2 * (ell_max + 1) + 1, ell_max=ell_max)
+            w2 = w2.transform(boost_velocity=-v, ell_max=w1.ell_max)
+            w1i = w1.interpolate(w2.t)
+            assert w1i._allclose(w2, atol=1e-12, rtol=0)
+
+
+# ---------------------------------------------------------------------------- tests/test_rotations.py
+
+
+def test_rotation_bookkeeping_and_inversion(ctx):
+    """tests/test_rotations.py:14-129: identity is exact; frame is right-multiplied; R then ~R restores."""
+    rng = np.random.default_rng(3)
+    for w0 in (samples.linear_waveform(n_times=200), samples.random_waveform(n_times=200)):
+        w = to_gpu(w0, ctx)
+        w.rotate_decomposition_basis([1.0, 0.0, 0.0, 0.0])
+        assert np.array_equal(w.data, w0.data) and np.array_equal(w.frame, w0.frame)
+        for R in (rng.uniform(-1, 1, 4), rng.uniform(-1, 1, (200, 4))):
+            R = R / np.linalg.norm(R, axis=-1, keepdims=True)
+            w = to_gpu(w0, ctx)
+            w.rotate_decomposition_basis(R)
+            assert np.allclose(w.frame, quat.qmul(w0.frame, R), atol=1e-15)
+            assert not np.array_equal(w.data, w0.data)
+            w.rotate_decomposition_basis(quat.qconj(R))
+            assert np.max(np.abs(w.frame - w0.frame)) < 1e-15
+            assert np.allclose(w.data, w0.data, atol=1e-12, rtol=w.ell_max**4 * 4e-14)
+    with pytest.raises(ValueError, match="Input dimension mismatch"):
+        to_gpu(samples.linear_waveform(n_times=20), ctx).rotate_decomposition_basis(np.ones((7, 4)))
+
+
+def test_rotations_of_0_0_mode_and_each_mode(ctx):
+    """tests/test_rotations.py:132-198: (0,0) exactly invariant; a delta in (l, m') gives row m' of D^l, with exact
+    zeros in every other l block."""
+    Rs = samples.Rs()
+    w = to_gpu(samples.delta_waveform(0, 0, n_times=len(Rs), ell_min=0, ell_max=8), ctx)
+    before = w.data.copy()
+    w.rotate_decomposition_basis(Rs)
+    assert np.array_equal(w.data, before)
+    assert np.max(np.abs(w.frame - Rs)) == 0.0
+    ell_min, ell_max = 0, 8
+    Ds = np.array([scri_amd.engine.wigner_D(R, ell_min, ell_max, ctx=ctx) for R in Rs])
+    sp = quat.as_spinor_array(Rs)
+    assert np.abs(Ds - wigner.wigner_D_matrices(sp[:, 0], sp[:, 1], ell_min, ell_max)).max() < 2e-14
+    for ell in (0, 1, 3, 8):
+        for Mp in (-ell, 0, ell):
+            w = to_gpu(samples.delta_waveform(ell, Mp, n_times=len(Rs), ell_min=ell_min, ell_max=ell_max), ctx)
+            w.rotate_decomposition_basis(Rs)
+            lo, hi = wigner.LM_total_size(ell_min, ell - 1), wigner.LM_total_size(ell_min, ell)
+            i0 = wigner.LMpM_index(ell, Mp, -ell, ell_min)
+            assert np.array_equal(w.data[:, :lo], np.zeros((len(Rs), lo)))
+            assert np.array_equal(w.data[:, hi:], np.zeros((len(Rs), w.data.shape[1] - hi)))
+            assert np.abs(w.data[:, lo:hi] - Ds[:, i0 : i0 + 2 * ell + 1]).max() < 1e-15
+
+
+def test_rotate_physical_system_and_to_inertial_frame(ctx):
+    w0 = samples.linear_waveform(n_times=100)
+    w = to_gpu(w0, ctx)
+    w.to_inertial_frame()
+    assert w.frameType == scri_amd.Inertial
+    expect = rotations_ref.rotate_by_series(w0.data, quat.as_spinor_array(quat.qconj(w0.frame)), w0.ell_min, w0.ell_max)
+    assert np.allclose(w.data, expect, rtol=1e-13, atol=1e-12)
+    assert np.allclose(w.frame, np.tile([1.0, 0, 0, 0], (100, 1)), atol=1e-15)
+    q = np.array([0.5, -0.5, 0.5, 0.5])
+    a = to_gpu(w0, ctx)
+    a.rotate_physical_system(q)
+    b = to_gpu(w0, ctx)
+    b.rotate_decomposition_basis(quat.qconj(q))
+    assert np.array_equal(a.data, b.data)
