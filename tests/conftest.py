@@ -13,6 +13,19 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "slow: exhaustive analytic tests of the oracle (minutes)")
 
 
+def pytest_addoption(parser):
+    parser.addoption("--run-slow", action="store_true", help="run the exhaustive (slow) analytic tests too")
+
+
+def pytest_collection_modifyitems(config, items):
+    if config.getoption("--run-slow") or "slow" in (config.getoption("-m") or ""):
+        return
+    skip = pytest.mark.skip(reason="exhaustive variant: needs --run-slow")
+    for item in items:
+        if "slow" in item.keywords:
+            item.add_marker(skip)
+
+
 @pytest.fixture(scope="session")
 def ctx():
     """One engine context on GPU 0 for the whole session (GPU tests only)."""
