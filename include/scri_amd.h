@@ -72,9 +72,10 @@ enum bms_kernel_tag {
   BMS_TAG_GEMM_SYNTHESIS = 2,  /* dgemm_mfma_kernel, modes -> grid */
   BMS_TAG_SPLINE_FORWARD = 3,  /* spline_forward_kernel */
   BMS_TAG_SPLINE_BACKWARD = 4, /* spline_backward_eval_kernel */
-  BMS_TAG_GEMM_ANALYSIS = 5,   /* dgemm_mfma_kernel, grid -> modes */
+  BMS_TAG_GEMM_ANALYSIS = 5,   /* dgemm_mfma_kernel, grid -> modes: phi-DFT (or dense quadrature) */
   BMS_TAG_POINTWISE = 6,       /* psi mixing / affine / Horner kernels */
-  BMS_TAG_COUNT = 7
+  BMS_TAG_THETA_QUADRATURE = 7, /* theta_quadrature_kernel (second step of the separable analysis) */
+  BMS_TAG_COUNT = 8
 };
 int bms_ctx_enable_timing(bms_ctx* ctx, int on);
 int bms_ctx_get_timing(bms_ctx* ctx, double ms[BMS_TAG_COUNT], int64_t calls[BMS_TAG_COUNT], int reset);

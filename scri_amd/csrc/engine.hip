@@ -611,6 +611,117 @@ struct FieldPlan {  // one field to synthesise: input modes, its SWSH matrix
 
 }  // namespace
 
+
+// ---------------------------------------------------------------------------------------------- analysis plan
+// Separable analysis (kernels_analysis.hip) when n_theta <= MAX_THETA_SEPARABLE, dense quadrature GEMM otherwise.
+struct AnalysisPlan {
+  bool separable = true;
+  int n_theta = 0, n_phi = 0, n_pix = 0, n_out = 0, L = 0, nm = 0;
+  // separable
+  double* d_dft = nullptr;
+  long long ld_dft = 0;
+  double* d_T = nullptr;
+  int* d_mindex = nullptr;
+  // dense
+  double* d_W = nullptr;
+  long long ldw = 0;
+};
+
+static int upload(bms_ctx* c, const char* name, const void* host, size_t bytes, void** dev);
+
+static int build_analysis(bms_ctx* c, const char* tag, int n_theta, int n_phi, int spin, int ell_min_out, int ell_max_out,
+                          AnalysisPlan& A) {
+  hipStream_t S = c->stream;
+  A.n_theta = n_theta;
+  A.n_phi = n_phi;
+  A.n_pix = n_theta * n_phi;
+  A.n_out = LM_total_size(ell_min_out, ell_max_out);
+  A.L = ell_max_out;
+  A.nm = 2 * ell_max_out + 1;
+  A.separable = n_theta <= MAX_THETA_SEPARABLE;
+  std::vector<double> qth;
+  theta_quadrature_weights(n_theta, qth);
+  int rc;
+  void* vp;
+  char nm_[64];
+  if (A.separable) {
+    // phi-DFT matrix [2 n_phi -> 16] x [2 (2L+1) -> 128]
+    A.ld_dft = round_up(2LL * A.nm, 128);
+    const long long rows = round_up(2LL * n_phi, 16);
+    snprintf(nm_, sizeof nm_, "dft_%d_%d", n_phi, A.L);
+    if ((rc = dev_buf_t(c, nm_, (size_t)rows * A.ld_dft, &A.d_dft))) return rc;
+    HIP_TRY(c, hipMemsetAsync(A.d_dft, 0, sizeof(double) * rows * A.ld_dft, S));
+    TIMED(c, BMS_TAG_SETUP, launch_dft_matrix(S, n_phi, A.L, A.d_dft, A.ld_dft));
+    // theta table from sLambda_lm(theta_j) = sYlm(R(theta_j, 0))
+    std::vector<double> rot(4 * (size_t)n_theta), wth(n_theta);
+    std::vector<int> mindex(A.n_out);
+    for (int j = 0; j < n_theta; ++j) {
+      const Quat q = from_spherical_coords(M_PI * j / (n_theta - 1), 0.0);
+      rot[4 * j] = q.w, rot[4 * j + 1] = q.x, rot[4 * j + 2] = q.y, rot[4 * j + 3] = q.z;
+      wth[j] = qth[j] / n_phi;
+    }
+    for (int l = ell_min_out; l <= ell_max_out; ++l)
+      for (int m = -l; m <= l; ++m) mindex[LM_index(l, m, ell_min_out)] = m + A.L;
+    snprintf(nm_, sizeof nm_, "ana_rot_%s", tag);
+    if ((rc = upload(c, nm_, rot.data(), 8 * rot.size(), &vp))) return rc;
+    const double* d_rot = (const double*)vp;
+    snprintf(nm_, sizeof nm_, "ana_wth_%s", tag);
+    if ((rc = upload(c, nm_, wth.data(), 8 * wth.size(), &vp))) return rc;
+    const double* d_wth = (const double*)vp;
+    snprintf(nm_, sizeof nm_, "ana_mi_%s", tag);
+    if ((rc = upload(c, nm_, mindex.data(), sizeof(int) * mindex.size(), &vp))) return rc;
+    A.d_mindex = (int*)vp;
+    double* d_Y;
+    snprintf(nm_, sizeof nm_, "ana_Y_%s", tag);
+    if ((rc = dev_buf_t(c, nm_, (size_t)n_theta * A.n_out * 2, &d_Y))) return rc;
+    HIP_TRY(c, hipMemsetAsync(d_Y, 0, 16 * (size_t)n_theta * A.n_out, S));
+    TIMED(c, BMS_TAG_SETUP, launch_swsh_values(S, d_rot, n_theta, spin, ell_min_out, ell_max_out, d_Y));
+    snprintf(nm_, sizeof nm_, "ana_T_%s", tag);
+    if ((rc = dev_buf_t(c, nm_, (size_t)n_theta * A.n_out, &A.d_T))) return rc;
+    TIMED(c, BMS_TAG_SETUP, launch_theta_table(S, d_Y, d_wth, n_theta, A.n_out, A.d_T));
+    HIP_TRY(c, hipStreamSynchronize(S));  // host vectors above go out of scope
+  } else {
+    std::vector<double> wpix((size_t)A.n_pix), grid_rot(4 * (size_t)A.n_pix);
+    for (int j = 0; j < n_theta; ++j)
+      for (int k = 0; k < n_phi; ++k) {
+        const int p = j * n_phi + k;
+        wpix[p] = qth[j] / n_phi;
+        const Quat q = from_spherical_coords(M_PI * j / (n_theta - 1), (2 * M_PI) * k / n_phi);
+        grid_rot[4 * p] = q.w, grid_rot[4 * p + 1] = q.x, grid_rot[4 * p + 2] = q.y, grid_rot[4 * p + 3] = q.z;
+      }
+    if ((rc = upload(c, "grid_rotors", grid_rot.data(), 8 * grid_rot.size(), &vp))) return rc;
+    const double* d_grot = (const double*)vp;
+    if ((rc = upload(c, "wpix", wpix.data(), 8 * wpix.size(), &vp))) return rc;
+    const double* d_wpix = (const double*)vp;
+    A.ldw = round_up(2LL * A.n_out, 128);
+    const long long wrows = round_up(2LL * A.n_pix, 16);
+    snprintf(nm_, sizeof nm_, "Wana_%s", tag);
+    if ((rc = dev_buf_t(c, nm_, (size_t)wrows * A.ldw, &A.d_W))) return rc;
+    HIP_TRY(c, hipMemsetAsync(A.d_W, 0, sizeof(double) * wrows * A.ldw, S));
+    TIMED(c, BMS_TAG_SETUP, launch_quadrature_matrix(S, d_grot, d_wpix, A.n_pix, spin, ell_min_out, ell_max_out, A.d_W, A.ldw));
+    HIP_TRY(c, hipStreamSynchronize(S));
+  }
+  return BMS_OK;
+}
+
+// G: [rows][2 n_pix] (row stride exactly 2 n_pix doubles) -> out[rows][ldo] complex modes
+static int run_analysis(bms_ctx* c, const AnalysisPlan& A, const double* d_G, long long rows, double* d_out, long long ldo) {
+  hipStream_t S = c->stream;
+  const long long P2 = 2LL * A.n_pix;
+  if (A.separable) {
+    double* d_F;
+    int rc = dev_buf_t(c, "Fphi", (size_t)rows * A.n_theta * 2 * A.nm, &d_F);
+    if (rc) return rc;
+    TIMED(c, BMS_TAG_GEMM_ANALYSIS, launch_dgemm(S, d_G, 2LL * A.n_phi, A.d_dft, A.ld_dft, d_F, 2LL * A.nm, rows * A.n_theta,
+                                                 2 * A.nm, 2 * A.n_phi, nullptr, nullptr));
+    TIMED(c, BMS_TAG_THETA_QUADRATURE,
+          launch_theta_quadrature(S, d_F, rows, A.n_theta, A.nm, A.n_out, A.d_mindex, A.d_T, d_out, ldo));
+  } else {
+    TIMED(c, BMS_TAG_GEMM_ANALYSIS, launch_dgemm(S, d_G, P2, A.d_W, A.ldw, d_out, ldo, rows, 2 * A.n_out, (int)P2, nullptr, nullptr));
+  }
+  return BMS_OK;
+}
+
 static int upload(bms_ctx* c, const char* name, const void* host, size_t bytes, void** dev) {
   int rc = dev_buf(c, name, bytes, dev);
   if (rc) return rc;
@@ -777,30 +888,12 @@ extern "C" int bms_transform_modes_shard(bms_ctx* c, const bms_wm_input* in, con
       xb[2 * p + 1] = A.im;
     }
   }
-  // quadrature: undistorted grid rotors and pixel weights q_j / n_phi
-  std::vector<double> qth, wpix((size_t)n_pix), grid_rot(4 * (size_t)n_pix);
-  theta_quadrature_weights(T.n_theta, qth);
-  for (int j = 0; j < T.n_theta; ++j)
-    for (int k = 0; k < T.n_phi; ++k) {
-      const int p = j * T.n_phi + k;
-      wpix[p] = qth[j] / T.n_phi;
-      const Quat q = from_spherical_coords(M_PI * j / (T.n_theta - 1), (2 * M_PI) * k / T.n_phi);
-      grid_rot[4 * p] = q.w;
-      grid_rot[4 * p + 1] = q.x;
-      grid_rot[4 * p + 2] = q.y;
-      grid_rot[4 * p + 3] = q.z;
-    }
-
   // ---------------------------------------------------------------- device tables
   hipStream_t S = c->stream;
   void* vp;
-  double *d_rot, *d_grot, *d_wpix, *d_off, *d_scale, *d_skewa, *d_skewb, *d_x, *d_alpha = nullptr, *d_xa = nullptr, *d_xb = nullptr;
+  double *d_rot, *d_off, *d_scale, *d_skewa, *d_skewb, *d_x, *d_alpha = nullptr, *d_xa = nullptr, *d_xb = nullptr;
   if ((rc = upload(c, "rotors", T.R.data(), sizeof(Quat) * n_pix, &vp))) return rc;
   d_rot = (double*)vp;
-  if ((rc = upload(c, "grid_rotors", grid_rot.data(), 32 * (size_t)n_pix, &vp))) return rc;
-  d_grot = (double*)vp;
-  if ((rc = upload(c, "wpix", wpix.data(), 8 * (size_t)n_pix, &vp))) return rc;
-  d_wpix = (double*)vp;
   if ((rc = upload(c, "col_off", col_off.data(), 16 * (size_t)n_pix, &vp))) return rc;
   d_off = (double*)vp;
   if ((rc = upload(c, "col_scale", col_scale.data(), 16 * (size_t)n_pix, &vp))) return rc;
@@ -853,13 +946,8 @@ extern "C" int bms_transform_modes_shard(bms_ctx* c, const bms_wm_input* in, con
     HIP_TRY(c, hipMemsetAsync(f.d_B, 0, sizeof(double) * rows * ldb, S));
     TIMED(c, BMS_TAG_SETUP, launch_swsh_matrix(S, d_rot, n_pix, f.spin, f.ell_min, f.ell_max, f.d_B, ldb));
   }
-  // analysis matrix [2 n_pix (rounded to 16)] x [2 n_out (rounded to 128)]
-  const long long ldw = round_up(2LL * n_out, 128);
-  const long long wrows = round_up(P2, 16);
-  double* d_W;
-  if ((rc = dev_buf_t(c, "Wana", (size_t)wrows * ldw, &d_W))) return rc;
-  HIP_TRY(c, hipMemsetAsync(d_W, 0, sizeof(double) * wrows * ldw, S));
-  TIMED(c, BMS_TAG_SETUP, launch_quadrature_matrix(S, d_grot, d_wpix, n_pix, s, ell_min_out, tr->ell_max_out, d_W, ldw));
+  AnalysisPlan ana;
+  if ((rc = build_analysis(c, "wm", T.n_theta, T.n_phi, s, ell_min_out, tr->ell_max_out, ana))) return rc;
   // spline factors
   SplineTable* d_tab;
   if ((rc = dev_buf_t(c, "spline_table", (size_t)n, &d_tab))) return rc;
@@ -873,7 +961,7 @@ extern "C" int bms_transform_modes_shard(bms_ctx* c, const bms_wm_input* in, con
   // ---------------------------------------------------------------- chunk loop over output samples
   const int margin = SPLINE_HALO + 2;
   // bytes per output row ~ (Y + R + G [+ Yaux]) * ldg * 8
-  const double bytes_per_row = (3.0 + (psi ? 1.0 : 0.0)) * ldg * 8.0;
+  const double bytes_per_row = (4.0 + (psi ? 1.0 : 0.0)) * ldg * 8.0;  // Y, R, G, F (+ Yaux)
   int64_t chunk = (int64_t)std::max(1024.0, (double)c->ws_limit / bytes_per_row - 4.0 * margin);
   chunk = std::min<int64_t>(chunk, n_new);
   for (int64_t c0 = i_lo; c0 < i_hi; c0 += chunk) {
@@ -890,7 +978,7 @@ extern "C" int bms_transform_modes_shard(bms_ctx* c, const bms_wm_input* in, con
     double *d_Y, *d_R, *d_G, *d_Yaux = nullptr;
     if ((rc = dev_buf_t(c, "Y", (size_t)rows_in * ldg, &d_Y))) return rc;
     if ((rc = dev_buf_t(c, "R", (size_t)rows_in * ldg, &d_R))) return rc;
-    if ((rc = dev_buf_t(c, "G", (size_t)rows_out * ldg, &d_G))) return rc;
+    if ((rc = dev_buf_t(c, "G", (size_t)rows_out * P2, &d_G))) return rc;
     if (psi)
       if ((rc = dev_buf_t(c, "Yaux", (size_t)rows_in * ldg, &d_Yaux))) return rc;
     // synthesis (+ fused affine map when there is no psi mixing)
@@ -909,10 +997,9 @@ extern "C" int bms_transform_modes_shard(bms_ctx* c, const bms_wm_input* in, con
     // spline along time on the shared knots, evaluated on the distorted slices
     TIMED(c, BMS_TAG_SPLINE_FORWARD, launch_spline_forward(S, d_Y, d_R, ldg, n_pix, g0, rows_in, n, d_x, d_tab, SPLINE_TILE, SPLINE_HALO));
     TIMED(c, BMS_TAG_SPLINE_BACKWARD, launch_spline_backward_eval(S, d_Y, d_R, ldg, n_pix, g0, rows_in, n, d_x, d_tab, SPLINE_TILE, SPLINE_HALO,
-                                           d_x, d_skewa, d_skewb, T.tt, c0, c1, d_G, ldg));
+                                           d_x, d_skewa, d_skewb, T.tt, c0, c1, d_G, P2));
     // analysis
-    TIMED(c, BMS_TAG_GEMM_ANALYSIS, launch_dgemm(S, d_G, ldg, d_W, ldw, d_out + (c0 - i_lo) * n_out * 2, 2LL * n_out, rows_out, 2 * n_out,
-                            (int)P2, nullptr, nullptr));
+    if ((rc = run_analysis(c, ana, d_G, rows_out, d_out + (c0 - i_lo) * n_out * 2, 2LL * n_out))) return rc;
   }
   if (in->mem == BMS_HOST)
     HIP_TRY(c, hipMemcpyAsync(data_out, d_out, (size_t)n_new * n_out * 16, hipMemcpyDeviceToHost, S));
@@ -957,30 +1044,15 @@ extern "C" int bms_map2salm(bms_ctx* c, const void* grid, int mem, int64_t n_map
   if (n_theta < 2 || n_phi < 1 || ell_min < 0 || ell_max < ell_min) return fail(c, BMS_ERR_INVALID, "bad sizes");
   if (n_maps <= 0) return BMS_OK;
   const int n_pix = n_theta * n_phi, n_out = LM_total_size(ell_min, ell_max);
-  std::vector<double> qth, wpix((size_t)n_pix), rot(4 * (size_t)n_pix);
-  theta_quadrature_weights(n_theta, qth);
-  for (int j = 0; j < n_theta; ++j)
-    for (int k = 0; k < n_phi; ++k) {
-      const int p = j * n_phi + k;
-      wpix[p] = qth[j] / n_phi;
-      const Quat q = from_spherical_coords(M_PI * j / (n_theta - 1), (2 * M_PI) * k / n_phi);
-      rot[4 * p] = q.w, rot[4 * p + 1] = q.x, rot[4 * p + 2] = q.y, rot[4 * p + 3] = q.z;
-    }
-  void *d_rot, *d_w;
   int rc;
-  if ((rc = upload(c, "grid_rotors", rot.data(), 32 * (size_t)n_pix, &d_rot))) return rc;
-  if ((rc = upload(c, "wpix", wpix.data(), 8 * (size_t)n_pix, &d_w))) return rc;
-  const long long P2 = 2LL * n_pix, ldw = round_up(2LL * n_out, 128), wrows = round_up(P2, 16);
-  double* d_W;
-  if ((rc = dev_buf_t(c, "Wana", (size_t)wrows * ldw, &d_W))) return rc;
-  HIP_TRY(c, hipMemsetAsync(d_W, 0, sizeof(double) * wrows * ldw, c->stream));
-  TIMED(c, BMS_TAG_SETUP, launch_quadrature_matrix(c->stream, (const double*)d_rot, (const double*)d_w, n_pix, spin, ell_min, ell_max, d_W, ldw));
+  AnalysisPlan ana;
+  if ((rc = build_analysis(c, "m2s", n_theta, n_phi, spin, ell_min, ell_max, ana))) return rc;
   const double* d_in;
   if ((rc = stage_in(c, "in_data", grid, mem, (size_t)n_maps * n_pix * 16, &d_in))) return rc;
   double* d_out = (double*)modes_out;
   if (mem == BMS_HOST)
     if ((rc = dev_buf_t(c, "out_data", (size_t)n_maps * n_out * 2, &d_out))) return rc;
-  TIMED(c, BMS_TAG_GEMM_ANALYSIS, launch_dgemm(c->stream, d_in, P2, d_W, ldw, d_out, 2LL * n_out, n_maps, 2 * n_out, (int)P2, nullptr, nullptr));
+  if ((rc = run_analysis(c, ana, d_in, n_maps, d_out, 2LL * n_out))) return rc;
   if (mem == BMS_HOST) HIP_TRY(c, hipMemcpyAsync(modes_out, d_out, (size_t)n_maps * n_out * 16, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   return BMS_OK;
@@ -1083,16 +1155,6 @@ extern "C" int bms_transform_abd(bms_ctx* c, const double* u, const void* raw, i
     ik[p] = one_over_k;
     ik3[p] = one_over_k * one_over_k * one_over_k;
   }
-  std::vector<double> qth, wpix((size_t)n_pix), grid_rot(4 * (size_t)n_pix);
-  theta_quadrature_weights(T.n_theta, qth);
-  for (int j = 0; j < T.n_theta; ++j)
-    for (int k = 0; k < T.n_phi; ++k) {
-      const int p = j * T.n_phi + k;
-      wpix[p] = qth[j] / T.n_phi;
-      const Quat q = from_spherical_coords(M_PI * j / (T.n_theta - 1), (2 * M_PI) * k / T.n_phi);
-      grid_rot[4 * p] = q.w, grid_rot[4 * p + 1] = q.x, grid_rot[4 * p + 2] = q.y, grid_rot[4 * p + 3] = q.z;
-    }
-
   // ---- device tables
   hipStream_t S = c->stream;
   void* vp;
@@ -1101,8 +1163,6 @@ extern "C" int bms_transform_abd(bms_ctx* c, const double* u, const void* raw, i
   double* dst = (double*)vp;
   if ((rc = upload(c, "rotors", T.R.data(), sizeof(Quat) * n_pix, &vp))) return rc;
   double* d_rot = (double*)vp;
-  UP("grid_rotors", grid_rot, d_grot)
-  UP("wpix", wpix, d_wpix)
   UP("skew_a", T.skew_a, d_skewa)
   UP("skew_b", T.skew_b, d_skewb)
   UP("alpha", T.alpha, d_alpha)
@@ -1118,19 +1178,17 @@ extern "C" int bms_transform_abd(bms_ctx* c, const double* u, const void* raw, i
   const long long P2 = 2LL * n_pix, ldg = round_up(P2, 16), ldb = round_up(P2, 128);
   const int K = 2 * nm;
   const long long brows = round_up(K, 16);
-  const long long ldw = round_up(2LL * n_out, 128), wrows = round_up(P2, 16);
-  // five distinct spins: matrices indexed by spin + 2
-  double *d_B[5], *d_W[5];
+  // five distinct spins: matrices / analysis plans indexed by spin + 2
+  double* d_B[5];
+  AnalysisPlan ana[5];
   for (int si = 0; si < 5; ++si) {
-    char nm1[32], nm2[32];
+    char nm1[32], tag[16];
     snprintf(nm1, sizeof nm1, "abd_B%d", si);
-    snprintf(nm2, sizeof nm2, "abd_W%d", si);
+    snprintf(tag, sizeof tag, "abd%d", si);
     if ((rc = dev_buf_t(c, nm1, (size_t)brows * ldb, &d_B[si]))) return rc;
-    if ((rc = dev_buf_t(c, nm2, (size_t)wrows * ldw, &d_W[si]))) return rc;
     HIP_TRY(c, hipMemsetAsync(d_B[si], 0, sizeof(double) * brows * ldb, S));
-    HIP_TRY(c, hipMemsetAsync(d_W[si], 0, sizeof(double) * wrows * ldw, S));
     TIMED(c, BMS_TAG_SETUP, launch_swsh_matrix(S, d_rot, n_pix, si - 2, 0, ell_max, d_B[si], ldb));
-    TIMED(c, BMS_TAG_SETUP, launch_quadrature_matrix(S, d_grot, d_wpix, n_pix, si - 2, 0, tr->ell_max_out, d_W[si], ldw));
+    if ((rc = build_analysis(c, tag, T.n_theta, T.n_phi, si - 2, 0, tr->ell_max_out, ana[si]))) return rc;
   }
   SplineTable* d_tab;
   if ((rc = dev_buf_t(c, "spline_table", (size_t)n, &d_tab))) return rc;
@@ -1144,7 +1202,7 @@ extern "C" int bms_transform_abd(bms_ctx* c, const double* u, const void* raw, i
 
   // ---- chunk loop: 6 fields x (Y, R, G)
   const int margin = SPLINE_HALO + 2;
-  const double bytes_per_row = 18.0 * ldg * 8.0;
+  const double bytes_per_row = 19.0 * ldg * 8.0;  // 6 x (Y, R, G) + F
   int64_t chunk = (int64_t)std::max(256.0, (double)c->ws_limit / bytes_per_row - 4.0 * margin);
   chunk = std::min<int64_t>(chunk, n_new);
   for (int64_t c0 = i_lo; c0 < i_hi; c0 += chunk) {
@@ -1156,7 +1214,7 @@ extern "C" int bms_transform_abd(bms_ctx* c, const double* u, const void* raw, i
     double *d_Y, *d_R, *d_G;
     if ((rc = dev_buf_t(c, "Y", (size_t)6 * rows_in * ldg, &d_Y))) return rc;
     if ((rc = dev_buf_t(c, "R", (size_t)6 * rows_in * ldg, &d_R))) return rc;
-    if ((rc = dev_buf_t(c, "G", (size_t)6 * rows_out * ldg, &d_G))) return rc;
+    if ((rc = dev_buf_t(c, "G", (size_t)6 * rows_out * P2, &d_G))) return rc;
     AbdGrids grids;
     for (int f = 0; f < 6; ++f) {
       grids.y[f] = d_Y + (size_t)f * rows_in * ldg;
@@ -1168,15 +1226,14 @@ extern "C" int bms_transform_abd(bms_ctx* c, const double* u, const void* raw, i
           launch_abd_mix(S, grids, ldg, n_pix, rows_in, d_x + g0, d_alpha, d_ethk, d_etha, d_ethetha, d_ik, d_ik3));
     for (int f = 0; f < 6; ++f) {
       double* Rf = d_R + (size_t)f * rows_in * ldg;
-      double* Gf = d_G + (size_t)f * rows_out * ldg;
+      double* Gf = d_G + (size_t)f * rows_out * P2;
       TIMED(c, BMS_TAG_SPLINE_FORWARD,
             launch_spline_forward(S, grids.y[f], Rf, ldg, n_pix, g0, rows_in, n, d_x, d_tab, SPLINE_TILE, SPLINE_HALO));
       TIMED(c, BMS_TAG_SPLINE_BACKWARD,
             launch_spline_backward_eval(S, grids.y[f], Rf, ldg, n_pix, g0, rows_in, n, d_x, d_tab, SPLINE_TILE, SPLINE_HALO,
-                                        d_x, d_skewa, d_skewb, T.tt, c0, c1_, Gf, ldg));
-      TIMED(c, BMS_TAG_GEMM_ANALYSIS,
-            launch_dgemm(S, Gf, ldg, d_W[spins[f] + 2], ldw, d_out + ((size_t)f * n + (c0 - i_lo)) * n_out * 2, 2LL * n_out,
-                         rows_out, 2 * n_out, (int)P2, nullptr, nullptr));
+                                        d_x, d_skewa, d_skewb, T.tt, c0, c1_, Gf, P2));
+      if ((rc = run_analysis(c, ana[spins[f] + 2], Gf, rows_out, d_out + ((size_t)f * n + (c0 - i_lo)) * n_out * 2, 2LL * n_out)))
+        return rc;
     }
   }
   if (mem == BMS_HOST) {

@@ -25,6 +25,13 @@ hipError_t launch_quadrature_matrix(hipStream_t stream, const double* rotors, co
 hipError_t launch_swsh_values(hipStream_t stream, const double* rotors, int n_pix, int spin, int ell_min, int ell_max,
                               double* Y /* c16[n_pix][n_modes] */);
 
+// ---- separable analysis (kernels_analysis.hip): phi-DFT matrix for the GEMM, theta table, theta quadrature
+hipError_t launch_dft_matrix(hipStream_t stream, int n_phi, int L, double* B, long long ldb);
+hipError_t launch_theta_table(hipStream_t stream, const double* Y, const double* w_theta, int n_theta, int n_out, double* T);
+hipError_t launch_theta_quadrature(hipStream_t stream, const double* F, long long n_rows, int n_theta, int nm, int n_out,
+                                   const int* m_index, const double* T, double* out, long long ldo);
+constexpr int MAX_THETA_SEPARABLE = 104;
+
 // ---- dense fp64 GEMM on MFMA: C[M x N] = (A[M x K] * B[K x N] - col_off[N]) * col_scale[N]
 // A row-major (lda), B row-major (ldb, zero padded to a multiple of 128 columns and 16 rows), C row-major (ldc).
 hipError_t launch_dgemm(hipStream_t stream, const double* A, long long lda, const double* B, long long ldb, double* C,
