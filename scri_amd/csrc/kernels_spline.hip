@@ -126,10 +126,12 @@ __global__ __launch_bounds__(64) void spline_forward_kernel(const double* __rest
     y0 = ld2(j);
     y1 = (j + 1 < jend) ? ld2(j + 1) : y0;
   }
-  for (; j < jB; ++j) {
-    const SplineTable e = table[j];
+  // main loop, 4 knots per trip: the 4 next rows are requested together (4 x 16 B per lane in flight) before
+  // the dependent recurrence consumes them -- the loop is a latency-bound HBM stream otherwise.
+  auto step = [&](long long jj, double2 ynext, bool have_next) {
+    const SplineTable e = table[jj];
     double2 dlo, dhi;
-    if (j == n - 1) {  // true last row: D_{n-3} and D_{n-2}
+    if (jj == n - 1) {  // true last row: D_{n-3} and D_{n-2}
       const double2 a = ld2(n - 3), b = ld2(n - 2), c = ld2(n - 1);
       dlo = {b.x - a.x, b.y - a.y};
       dhi = {c.x - b.x, c.y - b.y};
@@ -140,11 +142,23 @@ __global__ __launch_bounds__(64) void spline_forward_kernel(const double* __rest
     double2 rj;
     rj.x = e.P * dlo.x + e.Q * dhi.x - e.A * rprev.x;
     rj.y = e.P * dlo.y + e.Q * dhi.y - e.A * rprev.y;
-    if (j >= jA) *reinterpret_cast<double2*>(rp + j * ld) = rj;
+    if (jj >= jA) *reinterpret_cast<double2*>(rp + jj * ld) = rj;
     rprev = rj;
     ym = y0;
     y0 = y1;
-    if (j + 2 < jend) y1 = ld2(j + 2);
+    if (have_next) y1 = ynext;
+  };
+  for (; j + 4 <= jB && j + 5 < jend; j += 4) {
+    const double2 n0 = ld2(j + 2), n1 = ld2(j + 3), n2 = ld2(j + 4), n3 = ld2(j + 5);
+    step(j, n0, true);
+    step(j + 1, n1, true);
+    step(j + 2, n2, true);
+    step(j + 3, n3, true);
+  }
+  for (; j < jB; ++j) {
+    const bool have = j + 2 < jend;
+    const double2 nx = have ? ld2(j + 2) : y1;
+    step(j, nx, have);
   }
 }
 
@@ -214,26 +228,36 @@ __global__ __launch_bounds__(64) void spline_backward_eval_kernel(
   if (jE > jend - 1) jE = jend - 1;
   // s at jE: exact at the true last knot, otherwise the truncated start (decays as 0.268^halo)
   double2 s1 = ld2(rp, jE);
-  for (long long j = jE - 1; j >= jI; --j) {
-    const double C = table[j].C;
-    const double2 r = ld2(rp, j);
-    s1.x = r.x - C * s1.x;
-    s1.y = r.y - C * s1.y;
+  {
+    long long j = jE - 1;
+    for (; j - 3 >= jI; j -= 4) {
+      const double2 r0 = ld2(rp, j), r1 = ld2(rp, j - 1), r2 = ld2(rp, j - 2), r3 = ld2(rp, j - 3);
+      const double C0 = table[j].C, C1 = table[j - 1].C, C2 = table[j - 2].C, C3 = table[j - 3].C;
+      s1.x = r0.x - C0 * s1.x, s1.y = r0.y - C0 * s1.y;
+      s1.x = r1.x - C1 * s1.x, s1.y = r1.y - C1 * s1.y;
+      s1.x = r2.x - C2 * s1.x, s1.y = r2.y - C2 * s1.y;
+      s1.x = r3.x - C3 * s1.x, s1.y = r3.y - C3 * s1.y;
+    }
+    for (; j >= jI; --j) {
+      const double C = table[j].C;
+      const double2 r = ld2(rp, j);
+      s1.x = r.x - C * s1.x;
+      s1.y = r.y - C * s1.y;
+    }
   }
   // now s1 = s_{jI}
   double2 y1 = ld2(yp, jI);
   double ue = ueval(i);
-  for (long long j = jI - 1; j >= jA; --j) {
-    const double C = table[j].C;
-    const double2 r = ld2(rp, j);
-    const double2 y0 = ld2(yp, j);
+  // one interval: s_j from the recurrence, then every output sample that lands in [x_j, x_{j+1})
+  auto interval = [&](long long jj, double2 r, double2 y0) -> bool {
+    const double C = table[jj].C;
     double2 s0;
     s0.x = r.x - C * s1.x;
     s0.y = r.y - C * s1.y;
-    const double xj = x[j];
-    const bool last_interval = (j == jA) && open_bottom;
+    const double xj = x[jj];
+    const bool last_interval = (jj == jA) && open_bottom;
     if (ue >= xj || last_interval) {
-      const double h = x[j + 1] - xj;
+      const double h = x[jj + 1] - xj;
       const double ih = 1.0 / h;
       // scipy: slope = dy/h; t = (s0 + s1 - 2 slope)/h; c3 = t/h; c2 = (slope - s0)/h - t; c1 = s0; c0 = y0
       const double slx = (y1.x - y0.x) * ih, sly = (y1.y - y0.y) * ih;
@@ -252,9 +276,22 @@ __global__ __launch_bounds__(64) void spline_backward_eval_kernel(
         if (i >= i_lo) ue = ueval(i);
       }
     }
-    if (i < i_lo) return;
     s1 = s0;
     y1 = y0;
+    return i >= i_lo;
+  };
+  long long j = jI - 1;
+  for (; j - 3 >= jA; j -= 4) {
+    // 8 x 16 B per lane in flight before the dependent chain starts
+    const double2 r0 = ld2(rp, j), r1 = ld2(rp, j - 1), r2 = ld2(rp, j - 2), r3 = ld2(rp, j - 3);
+    const double2 q0 = ld2(yp, j), q1 = ld2(yp, j - 1), q2 = ld2(yp, j - 2), q3 = ld2(yp, j - 3);
+    if (!interval(j, r0, q0)) return;
+    if (!interval(j - 1, r1, q1)) return;
+    if (!interval(j - 2, r2, q2)) return;
+    if (!interval(j - 3, r3, q3)) return;
+  }
+  for (; j >= jA; --j) {
+    if (!interval(j, ld2(rp, j), ld2(yp, j))) return;
   }
 }
 
