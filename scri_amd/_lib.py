@@ -61,7 +61,7 @@ class bms_shard(ctypes.Structure):
     _fields_ = [("data_row0", c_i64), ("data_rows", c_i64), ("out_i0", c_i64), ("out_i1", c_i64)]
 
 
-KERNEL_TAGS = ("rotate", "setup", "gemm_synthesis", "spline_forward", "spline_backward", "gemm_analysis", "pointwise", "theta_quadrature")
+KERNEL_TAGS = ("rotate", "setup", "gemm_synthesis", "spline_forward", "spline_backward", "gemm_analysis", "pointwise", "theta_quadrature", "analysis_fused")
 
 # every symbol include/scri_amd.h declares: (restype, argtypes)
 SIGNATURES = {

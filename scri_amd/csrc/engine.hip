@@ -11,6 +11,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
@@ -616,6 +617,8 @@ struct FieldPlan {  // one field to synthesise: input modes, its SWSH matrix
 // Separable analysis (kernels_analysis.hip) when n_theta <= MAX_THETA_SEPARABLE, dense quadrature GEMM otherwise.
 struct AnalysisPlan {
   bool separable = true;
+  bool fused = false;  // single-kernel analysis (kernels_analysis.hip, analysis_fused_kernel)
+  double* d_dcs = nullptr;
   int n_theta = 0, n_phi = 0, n_pix = 0, n_out = 0, L = 0, nm = 0;
   // separable
   double* d_dft = nullptr;
@@ -644,14 +647,24 @@ static int build_analysis(bms_ctx* c, const char* tag, int n_theta, int n_phi, i
   int rc;
   void* vp;
   char nm_[64];
+  A.fused = A.separable && fused_analysis_supported(n_theta, n_phi, A.L, A.n_out) && !getenv("SCRI_AMD_NO_FUSED_ANALYSIS");
   if (A.separable) {
-    // phi-DFT matrix [2 n_phi -> 16] x [2 (2L+1) -> 128]
-    A.ld_dft = round_up(2LL * A.nm, 128);
-    const long long rows = round_up(2LL * n_phi, 16);
-    snprintf(nm_, sizeof nm_, "dft_%d_%d", n_phi, A.L);
-    if ((rc = dev_buf_t(c, nm_, (size_t)rows * A.ld_dft, &A.d_dft))) return rc;
-    HIP_TRY(c, hipMemsetAsync(A.d_dft, 0, sizeof(double) * rows * A.ld_dft, S));
-    TIMED(c, BMS_TAG_SETUP, launch_dft_matrix(S, n_phi, A.L, A.d_dft, A.ld_dft));
+    if (A.fused) {
+      int ks, pd;
+      fused_pitches(n_theta, n_phi, A.L, &ks, &pd);
+      snprintf(nm_, sizeof nm_, "dcs_%d_%d", n_phi, A.L);
+      if ((rc = dev_buf_t(c, nm_, (size_t)4 * ks * pd, &A.d_dcs))) return rc;
+      HIP_TRY(c, hipMemsetAsync(A.d_dcs, 0, sizeof(double) * 4 * ks * pd, S));
+      TIMED(c, BMS_TAG_SETUP, launch_dft_cs_matrix(S, n_phi, A.L, A.d_dcs, pd));
+    } else {
+      // phi-DFT matrix [2 n_phi -> 16] x [2 (2L+1) -> 128]
+      A.ld_dft = round_up(2LL * A.nm, 128);
+      const long long rows = round_up(2LL * n_phi, 16);
+      snprintf(nm_, sizeof nm_, "dft_%d_%d", n_phi, A.L);
+      if ((rc = dev_buf_t(c, nm_, (size_t)rows * A.ld_dft, &A.d_dft))) return rc;
+      HIP_TRY(c, hipMemsetAsync(A.d_dft, 0, sizeof(double) * rows * A.ld_dft, S));
+      TIMED(c, BMS_TAG_SETUP, launch_dft_matrix(S, n_phi, A.L, A.d_dft, A.ld_dft));
+    }
     // theta table from sLambda_lm(theta_j) = sYlm(R(theta_j, 0))
     std::vector<double> rot(4 * (size_t)n_theta), wth(n_theta);
     std::vector<int> mindex(A.n_out);
@@ -708,7 +721,10 @@ static int build_analysis(bms_ctx* c, const char* tag, int n_theta, int n_phi, i
 static int run_analysis(bms_ctx* c, const AnalysisPlan& A, const double* d_G, long long rows, double* d_out, long long ldo) {
   hipStream_t S = c->stream;
   const long long P2 = 2LL * A.n_pix;
-  if (A.separable) {
+  if (A.fused) {
+    TIMED(c, BMS_TAG_ANALYSIS_FUSED, launch_analysis_fused(S, d_G, P2, rows, A.n_theta, A.n_phi, A.L, A.n_out, A.d_mindex, A.d_T,
+                                                           A.d_dcs, d_out, ldo));
+  } else if (A.separable) {
     double* d_F;
     int rc = dev_buf_t(c, "Fphi", (size_t)rows * A.n_theta * 2 * A.nm, &d_F);
     if (rc) return rc;

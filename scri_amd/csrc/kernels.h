@@ -31,6 +31,14 @@ hipError_t launch_theta_table(hipStream_t stream, const double* Y, const double*
 hipError_t launch_theta_quadrature(hipStream_t stream, const double* F, long long n_rows, int n_theta, int nm, int n_out,
                                    const int* m_index, const double* T, double* out, long long ldo);
 constexpr int MAX_THETA_SEPARABLE = 104;
+// fused single-kernel analysis (n_theta <= 40, n_out <= 1024): D = cos|sin DFT matrix [4 ks][pd] from launch_dft_cs_matrix
+struct FusedGeom;
+int fused_analysis_supported(int n_theta, int n_phi, int L, int n_out);
+void fused_pitches(int n_theta, int n_phi, int L, int* ks, int* pd);
+hipError_t launch_dft_cs_matrix(hipStream_t stream, int n_phi, int L, double* D, int pd);
+hipError_t launch_analysis_fused(hipStream_t stream, const double* G, long long ldg, long long n_rows, int n_theta, int n_phi,
+                                 int L, int n_out, const int* m_index, const double* T, const double* D, double* out,
+                                 long long ldo);
 
 // ---- dense fp64 GEMM on MFMA: C[M x N] = (A[M x K] * B[K x N] - col_off[N]) * col_scale[N]
 // A row-major (lda), B row-major (ldb, zero padded to a multiple of 128 columns and 16 rows), C row-major (ldc).
