@@ -9,6 +9,7 @@
 // Nothing in this file falls back to the CPU for the data path; the host only prepares O(n_pix) tables.
 #include <algorithm>
 #include <cmath>
+#include <chrono>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -38,6 +39,7 @@ struct bms_ctx {
   uint64_t ws_limit = 32ull << 30;
   std::map<std::string, DevBuf> bufs;  // grow-only named work space
   int delta_lmax = -1;                 // Delta tables cached up to this l
+  int delta_mfma_lmax = -1;            // ... in the MFMA B-image packing
   // optional per-kernel timing with HIP events on the context's stream (bms_ctx_enable_timing)
   bool timing = false;
   struct Timed {
@@ -85,6 +87,19 @@ struct ScopedTimer {  // brackets one kernel launch with two events when timing 
   } while (0)
 
 static thread_local std::string g_create_error;
+
+// host-side phase timing of a call, printed when SCRI_AMD_TRACE is set (debugging aid)
+struct HostTrace {
+  bool on;
+  std::chrono::steady_clock::time_point t0;
+  HostTrace() : on(getenv("SCRI_AMD_TRACE") != nullptr), t0(std::chrono::steady_clock::now()) {}
+  void mark(const char* what) {
+    if (!on) return;
+    auto t1 = std::chrono::steady_clock::now();
+    fprintf(stderr, "[scri_amd] %-28s %8.1f us\n", what, std::chrono::duration<double, std::micro>(t1 - t0).count());
+    t0 = t1;
+  }
+};
 
 static int fail(bms_ctx* c, int code, const char* fmt, ...) {
   char buf[1024];
@@ -443,6 +458,51 @@ static int ensure_delta(bms_ctx* c, int lmax, const double** d_delta, const long
   return BMS_OK;
 }
 
+// B images for rotate_modes_mfma_kernel: per l, B1[k = m'][mu] = Delta[mu][m'] then B2[k = mu][m] = Delta[mu][m],
+// each [kpad][pd] zero padded
+static int ensure_delta_mfma(bms_ctx* c, int lmax, const double** d_tab, const long long** d_off) {
+  if (c->delta_mfma_lmax >= lmax) {
+    *d_tab = (const double*)c->bufs["delta_mfma"].p;
+    *d_off = (const long long*)c->bufs["delta_mfma_off"].p;
+    return BMS_OK;
+  }
+  std::vector<long long> off(lmax + 1);
+  long long total = 0;
+  for (int l = 0; l <= lmax; ++l) {
+    int kpad, pd;
+    rotate_mfma_table_shape(l, &kpad, &pd);
+    off[l] = total;
+    total += 2LL * kpad * pd;
+  }
+  std::vector<double> packed((size_t)total, 0.0), D;
+  for (int l = 0; l <= lmax; ++l) {
+    int kpad, pd;
+    rotate_mfma_table_shape(l, &kpad, &pd);
+    delta_matrix<long double>(l, D);
+    const int n = 2 * l + 1;
+    double* B1 = packed.data() + off[l];
+    double* B2 = B1 + (size_t)kpad * pd;
+    for (int a = 0; a < n; ++a)
+      for (int b = 0; b < n; ++b) {
+        B1[(size_t)a * pd + b] = D[(size_t)b * n + a];  // k = m' = a, column mu = b
+        B2[(size_t)a * pd + b] = D[(size_t)a * n + b];  // k = mu = a, column m = b
+      }
+  }
+  double* dd = nullptr;
+  long long* doff = nullptr;
+  int rc = dev_buf_t(c, "delta_mfma", (size_t)total, &dd);
+  if (rc) return rc;
+  rc = dev_buf_t(c, "delta_mfma_off", (size_t)lmax + 1, &doff);
+  if (rc) return rc;
+  HIP_TRY(c, hipMemcpyAsync(dd, packed.data(), sizeof(double) * total, hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(c, hipMemcpyAsync(doff, off.data(), sizeof(long long) * (lmax + 1), hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  c->delta_mfma_lmax = lmax;
+  *d_tab = dd;
+  *d_off = doff;
+  return BMS_OK;
+}
+
 // ====================================================================================================== rotation
 
 static int rotate_impl(bms_ctx* c, void* data, int mem, int64_t n_times, int64_t ld, int ell_min, int ell_max,
@@ -453,10 +513,12 @@ static int rotate_impl(bms_ctx* c, void* data, int mem, int64_t n_times, int64_t
   const int64_t n_modes = LM_total_size(ell_min, ell_max);
   if (ld < n_modes) return fail(c, BMS_ERR_INVALID, "row stride %lld smaller than %lld modes", (long long)ld, (long long)n_modes);
   if (n_times == 0) return BMS_OK;
-  if (rotate_waves_per_block(ell_max) < 1) return fail(c, BMS_ERR_UNSUPPORTED, "ell_max=%d too large for the rotation kernel", ell_max);
+  const bool use_mfma = rotate_mfma_supported(ell_max) && !getenv("SCRI_AMD_ROTATE_VALU");
+  if (!use_mfma && rotate_waves_per_block(ell_max) < 1)
+    return fail(c, BMS_ERR_UNSUPPORTED, "ell_max=%d too large for the rotation kernels", ell_max);
   const double* d_delta;
   const long long* d_off;
-  int rc = ensure_delta(c, ell_max, &d_delta, &d_off);
+  int rc = use_mfma ? ensure_delta_mfma(c, ell_max, &d_delta, &d_off) : ensure_delta(c, ell_max, &d_delta, &d_off);
   if (rc) return rc;
   double* d_data = (double*)data;
   const double* d_rot = (const double*)spinors;
@@ -474,7 +536,10 @@ static int rotate_impl(bms_ctx* c, void* data, int mem, int64_t n_times, int64_t
     if (rc) return rc;
     HIP_TRY(c, hipMemcpyAsync(d_data, data, data_bytes, hipMemcpyHostToDevice, c->stream));
   }
-  TIMED(c, BMS_TAG_ROTATE, launch_rotate_modes(c->stream, d_data, n_times, ld, ell_min, ell_max, d_rot, series ? 4 : 0, d_delta, d_off));
+  if (use_mfma)
+    TIMED(c, BMS_TAG_ROTATE, launch_rotate_modes_mfma(c->stream, d_data, n_times, ld, ell_min, ell_max, d_rot, series ? 4 : 0, d_delta, d_off));
+  else
+    TIMED(c, BMS_TAG_ROTATE, launch_rotate_modes(c->stream, d_data, n_times, ld, ell_min, ell_max, d_rot, series ? 4 : 0, d_delta, d_off));
   if (mem == BMS_HOST) {
     HIP_TRY(c, hipMemcpyAsync(data, d_data, data_bytes, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -829,8 +894,10 @@ extern "C" int bms_transform_modes_shard(bms_ctx* c, const bms_wm_input* in, con
   const cplx* st = (const cplx*)tr->supertranslation;
 
   // ---------------------------------------------------------------- host tables
+  HostTrace trace;
   PixelTables T;
   build_pixel_tables(tr, T);
+  trace.mark("pixel tables (host)");
   const int n_pix = T.n_pix;
   int64_t i_lo, i_hi;
   output_window(T, in->t, n, i_lo, i_hi);
@@ -904,6 +971,7 @@ extern "C" int bms_transform_modes_shard(bms_ctx* c, const bms_wm_input* in, con
       xb[2 * p + 1] = A.im;
     }
   }
+  trace.mark("window + type tables (host)");
   // ---------------------------------------------------------------- device tables
   hipStream_t S = c->stream;
   void* vp;
@@ -962,8 +1030,10 @@ extern "C" int bms_transform_modes_shard(bms_ctx* c, const bms_wm_input* in, con
     HIP_TRY(c, hipMemsetAsync(f.d_B, 0, sizeof(double) * rows * ldb, S));
     TIMED(c, BMS_TAG_SETUP, launch_swsh_matrix(S, d_rot, n_pix, f.spin, f.ell_min, f.ell_max, f.d_B, ldb));
   }
+  trace.mark("uploads + synthesis matrices");
   AnalysisPlan ana;
   if ((rc = build_analysis(c, "wm", T.n_theta, T.n_phi, s, ell_min_out, tr->ell_max_out, ana))) return rc;
+  trace.mark("analysis plan");
   // spline factors
   SplineTable* d_tab;
   if ((rc = dev_buf_t(c, "spline_table", (size_t)n, &d_tab))) return rc;
@@ -1017,10 +1087,12 @@ extern "C" int bms_transform_modes_shard(bms_ctx* c, const bms_wm_input* in, con
     // analysis
     if ((rc = run_analysis(c, ana, d_G, rows_out, d_out + (c0 - i_lo) * n_out * 2, 2LL * n_out))) return rc;
   }
+  trace.mark("chunk loop (enqueue)");
   if (in->mem == BMS_HOST)
     HIP_TRY(c, hipMemcpyAsync(data_out, d_out, (size_t)n_new * n_out * 16, hipMemcpyDeviceToHost, S));
   // host tables above are stack/vector memory: wait for the uploads (and results) before returning
   HIP_TRY(c, hipStreamSynchronize(S));
+  trace.mark("final synchronize");
   return BMS_OK;
 }
 

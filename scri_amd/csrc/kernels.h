@@ -13,6 +13,14 @@ hipError_t launch_rotate_modes(hipStream_t stream, double* data, long long n_tim
                                const double* RaRb, long long rotor_stride, const double* delta,
                                const long long* delta_off);
 
+// MFMA formulation (kernels_rotate_mfma.hip), ell_max <= ~32: btab = per-l packed B images, boff = offsets (doubles)
+struct RotGeom;
+void rotate_mfma_table_shape(int ell, int* kpad, int* pd);
+int rotate_mfma_supported(int ell_max);
+hipError_t launch_rotate_modes_mfma(hipStream_t stream, double* data, long long n_times, long long ld, int ell_min,
+                                    int ell_max, const double* RaRb, long long rotor_stride, const double* btab,
+                                    const long long* boff);
+
 // ---- SWSH matrices (sf.SWSH_grid, waveform_grid.py:470-484)
 // Bmat[2k][2p] = Re Y_k(R_p), [2k][2p+1] = Im, [2k+1][2p] = -Im, [2k+1][2p+1] = Re;  k = LM_index(l,m,ell_min)
 hipError_t launch_swsh_matrix(hipStream_t stream, const double* rotors /* f8[n_pix][4] */, int n_pix, int spin,
