@@ -12,8 +12,8 @@
 // Workgroup tile 128 x 128 x 16, 4 wavefronts (2 x 2), 64 x 64 per wavefront = 16 independent accumulator tiles;
 // operands are staged global -> registers -> LDS with a two-deep LDS ring (one barrier per K-step); the LDS
 // pitches (A rows 18 doubles, B rows 144 doubles) make every ds_read_b64 fragment read conflict free.
-// Blocks are dealt so that all column-blocks of one 128-row slab of A run on one XCD (its L2 then serves
-// the 20-fold re-read of the slab); B (<= a few tens of MB) lives in L2 / Infinity Cache.
+// Blocks are dealt in 8 x 8 super-tiles per XCD so that A slabs and B panels are re-used out of that XCD's L2.
+#include <cstdlib>
 #include "kernels.h"
 
 namespace bms {
@@ -29,20 +29,27 @@ constexpr int G_BSZ = G_BK * G_LDB;
 __global__ __launch_bounds__(256, 2) void dgemm_mfma_kernel(const double* __restrict__ A, long long lda,
                                                             const double* __restrict__ B, long long ldb,
                                                             double* __restrict__ C, long long ldc, long long M, int N,
-                                                            int K, int nbm, int nbn,
+                                                            int K, int nbm, int nbn, int st_rows_log2,
                                                             const double* __restrict__ col_off,
                                                             const double* __restrict__ col_scale) {
   __shared__ __attribute__((aligned(16))) double lds[2 * G_ASZ + 2 * G_BSZ];
   double* As = lds;
   double* Bs = lds + 2 * G_ASZ;
 
-  // XCD-aware block -> tile map: blocks b and b+8 share an XCD; give each XCD whole row slabs.
+  // XCD-aware block -> tile map.  Blocks b and b+8 share an XCD (round-robin dispatch), and an XCD holds 64 resident
+  // workgroups (2 per CU): give each XCD whole super-tiles of 2^r row slabs x 2^(6-r) column panels.  The 64 workgroups of
+  // a super-tile walk K together, so every 16-deep slice of its A slabs and B panels is fetched into that XCD's L2 once and
+  // re-used from there.  Measured on cfg3 (r = 0..6): 6.13, 6.06, 8.73, 6.11, 6.25, 5.76, 5.85 ms -> r = 5 (32 x 2).
   const int b = blockIdx.x;
   const int xcd = b & 7;
   const int q = b >> 3;
-  const int bm = (q / nbn) * 8 + xcd;
-  const int bn = q % nbn;
-  if (bm >= nbm) return;
+  const int st_cols_log2 = 6 - st_rows_log2;
+  const int nsn = (nbn + (1 << st_cols_log2) - 1) >> st_cols_log2;  // super-tile columns
+  const int S = (q >> 6) * 8 + xcd;
+  const int r = q & 63;
+  const int bm = ((S / nsn) << st_rows_log2) + (r >> st_cols_log2);
+  const int bn = ((S % nsn) << st_cols_log2) + (r & ((1 << st_cols_log2) - 1));
+  if (bm >= nbm || bn >= nbn) return;
   const long long m0 = (long long)bm * G_BM;
   const int n0 = bn * G_BN;
 
@@ -149,9 +156,12 @@ hipError_t launch_dgemm(hipStream_t stream, const double* A, long long lda, cons
   if (M <= 0 || N <= 0) return hipSuccess;
   const int nbm = (int)((M + G_BM - 1) / G_BM);
   const int nbn = (N + G_BN - 1) / G_BN;
-  const long long grid = (long long)((nbm + 7) / 8) * 8 * nbn;
+  static const int st_rows_log2 = getenv("SCRI_AMD_GEMM_ST_ROWS_LOG2") ? atoi(getenv("SCRI_AMD_GEMM_ST_ROWS_LOG2")) : 5;
+  const int sr = 1 << st_rows_log2, sc = 64 >> st_rows_log2;
+  const long long n_super = (long long)((nbm + sr - 1) / sr) * ((nbn + sc - 1) / sc);
+  const long long grid = ((n_super + 7) / 8) * 8 * 64;
   hipLaunchKernelGGL(dgemm_mfma_kernel, dim3((unsigned)grid), dim3(256), 0, stream, A, lda, B, ldb, C, ldc, M, N, K, nbm,
-                     nbn, col_off, col_scale);
+                     nbn, st_rows_log2, col_off, col_scale);
   return hipGetLastError();
 }
 
