@@ -65,13 +65,24 @@ def from_spherical_coords(theta, phi):
     return np.stack([cp * ct, -sp * st, cp * st, sp * ct], axis=-1)
 
 
+# numpy-quaternion extracts theta = 2 arccos(sqrt((w^2+z^2)/|q|^2)); near the poles that formula turns the 1-ulp
+# rounding of w^2 + z^2 into +-3e-8 rad (arccos near 1), i.e. the reference's own boosted rotor grid is only defined
+# to ~|v| 3e-8 at pole pixels.  ROBUST_POLES = True switches to the well-conditioned 2 arctan2(|(x,y)|, |(w,z)|) (the
+# same angle), which is what the product uses; the GPU parity tests of boosted transforms run with it so that they can
+# keep a 1e-12 bar, the known-answer tests run with the literal formula.
+ROBUST_POLES = False
+
+
 def as_spherical_coords(q):
     """(theta, phi) of q = (beta, alpha) of its z-y-z Euler angles
     (quaternion.as_spherical_coords = as_euler_angles(q)[..., 1::-1])."""
     q = np.asarray(q, dtype=float)
     n = np.sum(q * q, axis=-1)
     alpha = np.arctan2(q[..., 3], q[..., 0]) + np.arctan2(-q[..., 1], q[..., 2])
-    beta = 2 * np.arccos(np.sqrt(np.clip((q[..., 0] ** 2 + q[..., 3] ** 2) / n, 0.0, 1.0)))
+    if ROBUST_POLES:
+        beta = 2 * np.arctan2(np.sqrt(q[..., 1] ** 2 + q[..., 2] ** 2), np.sqrt(q[..., 0] ** 2 + q[..., 3] ** 2))
+    else:
+        beta = 2 * np.arccos(np.sqrt(np.clip((q[..., 0] ** 2 + q[..., 3] ** 2) / n, 0.0, 1.0)))
     return beta, alpha
 
 

@@ -20,6 +20,7 @@
 
 #include "../../include/scri_amd.h"
 #include "kernels.h"
+#include "pixel_math.h"
 #include "wigner.h"
 
 using namespace bms;
@@ -259,98 +260,13 @@ extern "C" int bms_ctx_synchronize(bms_ctx* c) {
 
 namespace {
 
-struct Quat {
-  double w, x, y, z;
-};
-inline Quat qmul(const Quat& a, const Quat& b) {
-  return {a.w * b.w - a.x * b.x - a.y * b.y - a.z * b.z, a.w * b.x + a.x * b.w + a.y * b.z - a.z * b.y,
-          a.w * b.y - a.x * b.z + a.y * b.w + a.z * b.x, a.w * b.z + a.x * b.y - a.y * b.x + a.z * b.w};
-}
-inline Quat from_spherical_coords(double theta, double phi) {
-  const double ct = std::cos(theta / 2), st = std::sin(theta / 2), cp = std::cos(phi / 2), sp = std::sin(phi / 2);
-  return {cp * ct, -sp * st, cp * st, sp * ct};
-}
-// (theta, phi) of a rotor = (beta, alpha) of its Euler angles (numpy-quaternion as_spherical_coords)
-inline void as_spherical_coords(const Quat& q, double& theta, double& phi) {
-  const double n = q.w * q.w + q.x * q.x + q.y * q.y + q.z * q.z;
-  phi = std::atan2(q.z, q.w) + std::atan2(-q.x, q.y);
-  double c = std::sqrt((q.w * q.w + q.z * q.z) / n);
-  if (c > 1.0) c = 1.0;
-  theta = 2 * std::acos(c);
-}
-// q z q^-1
-inline void rotate_z(const Quat& q, double r[3]) {
-  const double n = q.w * q.w + q.x * q.x + q.y * q.y + q.z * q.z;
-  r[0] = 2 * (q.x * q.z + q.w * q.y) / n;
-  r[1] = 2 * (q.y * q.z - q.w * q.x) / n;
-  r[2] = (q.w * q.w - q.x * q.x - q.y * q.y + q.z * q.z) / n;
-}
-
-// R_jk of scri/waveform_grid.py:130-174 == boosted_grid, transformations.py:100-148
+// R_jk of scri/waveform_grid.py:130-174 == boosted_grid, transformations.py:100-148 (host loop over pixel_rotor)
 void build_rotor_grid(const double fr[4], const double v[3], int n_theta, int n_phi, std::vector<Quat>& R) {
   R.resize((size_t)n_theta * n_phi);
-  const double beta = std::sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
-  const double rapidity = std::atanh(beta);
-  const bool boosted = beta > 3e-14;
-  double vhat[3] = {0, 0, 0};
-  if (boosted)
-    for (int i = 0; i < 3; ++i) vhat[i] = v[i] / beta;
   const Quat frq = {fr[0], fr[1], fr[2], fr[3]};
-  for (int j = 0; j < n_theta; ++j) {
-    const double th = M_PI * j / (n_theta - 1);  // np.linspace(0, pi, n_theta)
-    for (int k = 0; k < n_phi; ++k) {
-      const double ph = (2 * M_PI) * k / n_phi;  // np.linspace(0, 2 pi, n_phi, endpoint=False)
-      const Quat rq = qmul(frq, from_spherical_coords(th, ph));
-      Quat out = rq;
-      if (boosted) {
-        double tp, pp;
-        as_spherical_coords(rq, tp, pp);
-        const double rp[3] = {std::cos(pp) * std::sin(tp), std::sin(pp) * std::sin(tp), std::cos(tp)};
-        double dot = vhat[0] * rp[0] + vhat[1] * rp[1] + vhat[2] * rp[2];
-        if (dot > 1.0) dot = 1.0;
-        if (dot < -1.0) dot = -1.0;
-        const double Thetaprm = std::acos(dot);
-        const double Theta = 2 * std::atan(std::exp(-rapidity) * std::tan(Thetaprm / 2.0));
-        const double c[3] = {rp[1] * vhat[2] - rp[2] * vhat[1], rp[2] * vhat[0] - rp[0] * vhat[2],
-                             rp[0] * vhat[1] - rp[1] * vhat[0]};
-        const double cn = std::sqrt(c[0] * c[0] + c[1] * c[1] + c[2] * c[2]);
-        if (cn > 1e-200) {
-          const double ang = (Thetaprm - Theta) / 2;
-          const double s = std::sin(ang), co = std::cos(ang);
-          const Quat B = {co, s * c[0] / cn, s * c[1] / cn, s * c[2] / cn};
-          out = qmul(B, rq);
-        }
-      }
-      R[(size_t)j * n_phi + k] = out;
-    }
-  }
-}
-
-// sum_k coef[k] sYlm_k(R) for modes l = 0..lmax (host; small lmax)
-cplx eval_modes_host(const cplx* coef, int lmax, int spin, const Quat& q) {
-  cplx Ra = {q.w, q.z}, Rb = {q.y, q.x};
-  double ra, rb;
-  cplx ea, eb;
-  spinor_polar(Ra, Rb, ra, rb, ea, eb);
-  const double sgn = (spin & 1) ? -1.0 : 1.0;
-  cplx sum = {0.0, 0.0};
-  for (int m = -lmax; m <= lmax; ++m) {
-    const cplx phase = cmul(cpow_unit(ea, m - spin), cpow_unit(eb, -spin - m));
-    DChain ch;
-    ch.init(m, -spin, ra, rb);
-    for (int ell = ch.ell; ell <= lmax; ++ell) {
-      const cplx c = coef[LM_index(ell, m, 0)];
-      if (c.re != 0.0 || c.im != 0.0) {
-        const double a = sgn * std::sqrt((2.0 * ell + 1.0) / (4.0 * M_PI)) * ch.value();
-        const cplx y = {a * phase.re, a * phase.im};
-        const cplx t = cmul(c, y);
-        sum.re += t.re;
-        sum.im += t.im;
-      }
-      if (ell < lmax) ch.next();
-    }
-  }
-  return sum;
+  const BoostSpec bs = make_boost_spec(v);
+  for (int j = 0; j < n_theta; ++j)
+    for (int k = 0; k < n_phi; ++k) R[(size_t)j * n_phi + k] = pixel_rotor(frq, bs, j, k, n_theta, n_phi);
 }
 
 // theta quadrature weights of the equiangular analysis (spinsfast.map2salm; H&W 2010): with M = 2 n_theta - 2,
@@ -608,12 +524,11 @@ struct PixelTables {
   double uprm_scale_min = 0, uprm_scale_max = 0;
 };
 
-// per-pixel scalars common to both flavours (waveform_grid.py:470-474; transformations.py:306-321)
-void build_pixel_tables(const bms_transformation* tr, PixelTables& T) {
+// scalars of the transformation + allocation of the host-side per-pixel arrays
+void init_pixel_tables(const bms_transformation* tr, PixelTables& T) {
   T.n_theta = tr->n_theta;
   T.n_phi = tr->n_phi;
   T.n_pix = tr->n_theta * tr->n_phi;
-  build_rotor_grid(tr->frame_rotation, tr->boost_velocity, tr->n_theta, tr->n_phi, T.R);
   const double* v = tr->boost_velocity;
   T.beta = std::sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
   T.gamma = 1 / std::sqrt(1 - T.beta * T.beta);
@@ -627,15 +542,35 @@ void build_pixel_tables(const bms_transformation* tr, PixelTables& T) {
   T.alpha.resize(T.n_pix);
   T.skew_a.resize(T.n_pix);
   T.skew_b.resize(T.n_pix);
-  for (int p = 0; p < T.n_pix; ++p) {
-    double r[3];
-    rotate_z(T.R[p], r);
-    const double vr = v[0] * r[0] + v[1] * r[1] + v[2] * r[2];
-    T.k[p] = 1.0 / (T.gamma * (1 - vr));
-    T.alpha[p] = eval_modes_host(st, tr->ell_max_supertranslation, 0, T.R[p]).re;
-    T.skew_a[p] = -vr;  // 1/(gamma k) - 1
-    T.skew_b[p] = T.alpha[p] - T.tt;
-  }
+}
+
+PixelSpec base_pixel_spec(const bms_transformation* tr, const PixelTables& T) {
+  PixelSpec P{};
+  P.frq = {tr->frame_rotation[0], tr->frame_rotation[1], tr->frame_rotation[2], tr->frame_rotation[3]};
+  for (int i = 0; i < 3; ++i) P.v[i] = tr->boost_velocity[i];
+  P.bs = make_boost_spec(tr->boost_velocity);
+  P.gamma = T.gamma;
+  P.tt = T.tt;
+  P.n_theta = tr->n_theta;
+  P.n_phi = tr->n_phi;
+  P.lst = tr->ell_max_supertranslation;
+  P.mode = -1;
+  return P;
+}
+
+// host-only evaluation of the per-pixel scalars (bms_shard_plan: no GPU needed); same code as pixel_tables_kernel
+void build_pixel_tables(const bms_transformation* tr, PixelTables& T) {
+  init_pixel_tables(tr, T);
+  PixelSpec P = base_pixel_spec(tr, T);
+  P.st = (const cplx*)tr->supertranslation;
+  T.R.resize(T.n_pix);
+  PixelOut O{};
+  O.rotors = (double*)T.R.data();
+  O.k = T.k.data();
+  O.alpha = T.alpha.data();
+  O.skew_a = T.skew_a.data();
+  O.skew_b = T.skew_b.data();
+  for (int p = 0; p < T.n_pix; ++p) pixel_tables_one(P, O, p);
 }
 
 // output time window (waveform_grid.py:564-568 == transformations.py:391-396)
@@ -832,6 +767,67 @@ static int validate_common(bms_ctx* c, int64_t n, const double* t, const bms_tra
   return BMS_OK;
 }
 
+
+// Per-pixel tables on the GPU.  `coef0/coef1` (host, (lst+1)^2 complex each, may be null) are uploaded next to the
+// supertranslation modes; the four scalars the host needs for the output window and the chunk plan come back in T.
+struct DevPixel {
+  double *rotors, *k, *alpha, *skew_a, *skew_b, *col_off, *col_scale, *xa, *xb, *ethk, *etha, *ethetha, *ik, *ik3;
+};
+static int device_pixel_tables(bms_ctx* c, const bms_transformation* tr, PixelTables& T, int mode, int spin, int cw,
+                               const std::vector<cplx>* coef0, const std::vector<cplx>* coef1, const cplx cv[4], DevPixel& D) {
+  init_pixel_tables(tr, T);
+  const int n_pix = T.n_pix, lst = tr->ell_max_supertranslation, nst = (lst + 1) * (lst + 1);
+  PixelSpec P = base_pixel_spec(tr, T);
+  P.mode = mode;
+  P.spin = spin;
+  P.conformal_weight = cw;
+  if (cv)
+    for (int i = 0; i < 4; ++i) P.cv[i] = cv[i];
+  // one upload for the (up to three) coefficient sets
+  std::vector<cplx> coefs((size_t)3 * nst, cplx{0.0, 0.0});
+  std::memcpy(coefs.data(), tr->supertranslation, sizeof(cplx) * nst);
+  if (coef0) std::memcpy(coefs.data() + nst, coef0->data(), sizeof(cplx) * nst);
+  if (coef1) std::memcpy(coefs.data() + 2 * nst, coef1->data(), sizeof(cplx) * nst);
+  cplx* d_coefs;
+  int rc = dev_buf_t(c, "pix_coefs", (size_t)3 * nst, &d_coefs);
+  if (rc) return rc;
+  HIP_TRY(c, hipMemcpyAsync(d_coefs, coefs.data(), sizeof(cplx) * 3 * nst, hipMemcpyHostToDevice, c->stream));
+  P.st = d_coefs;
+  P.c0 = coef0 ? d_coefs + nst : nullptr;
+  P.c1 = coef1 ? d_coefs + 2 * nst : nullptr;
+  // one device block for all per-pixel outputs: 4 (rotor) + 4 scalars + 4 (off, scale) + 4 (xa, xb) + 6 + 2 doubles per pixel
+  double* blk;
+  if ((rc = dev_buf_t(c, "pix_block", (size_t)24 * n_pix, &blk))) return rc;
+  D.rotors = blk;
+  D.k = blk + 4 * (size_t)n_pix;
+  D.alpha = D.k + n_pix;
+  D.skew_a = D.alpha + n_pix;
+  D.skew_b = D.skew_a + n_pix;
+  D.col_off = D.skew_b + n_pix;
+  D.col_scale = D.col_off + 2 * (size_t)n_pix;
+  D.xa = D.col_scale + 2 * (size_t)n_pix;
+  D.xb = D.xa + 2 * (size_t)n_pix;
+  D.ethk = D.xb + 2 * (size_t)n_pix;  // ABD block aliases nothing: 16 + 2 + 2 + 2 + 1 + 1 = 24
+  D.etha = D.col_off;                 // ABD never uses the WM arrays: reuse them
+  D.ethetha = D.xa;
+  D.ik = D.ethk + 2 * (size_t)n_pix;
+  D.ik3 = D.ik + n_pix;
+  PixelOut O{};
+  O.rotors = D.rotors, O.k = D.k, O.alpha = D.alpha, O.skew_a = D.skew_a, O.skew_b = D.skew_b;
+  O.col_off = D.col_off, O.col_scale = D.col_scale, O.xa = D.xa, O.xb = D.xb;
+  O.ethk = D.ethk, O.etha = D.etha, O.ethetha = D.ethetha, O.ik = D.ik, O.ik3 = D.ik3;
+  TIMED(c, BMS_TAG_SETUP, launch_pixel_tables(c->stream, P, O, n_pix));
+  // k, alpha, skew_a, skew_b are contiguous: one copy back
+  std::vector<double> back((size_t)4 * n_pix);
+  HIP_TRY(c, hipMemcpyAsync(back.data(), D.k, sizeof(double) * 4 * n_pix, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  std::memcpy(T.k.data(), back.data(), sizeof(double) * n_pix);
+  std::memcpy(T.alpha.data(), back.data() + n_pix, sizeof(double) * n_pix);
+  std::memcpy(T.skew_a.data(), back.data() + 2 * (size_t)n_pix, sizeof(double) * n_pix);
+  std::memcpy(T.skew_b.data(), back.data() + 3 * (size_t)n_pix, sizeof(double) * n_pix);
+  return BMS_OK;
+}
+
 // The shared pipeline: `nf` synthesised fields -> pointwise stage -> spline -> analysis, chunked over time.
 struct PointwiseWM {
   // WM flavour: y = (f0 + sum_i coeff_i f_i X^power_i - off) * scale, see bms_transform_modes
@@ -893,11 +889,56 @@ extern "C" int bms_transform_modes_shard(bms_ctx* c, const bms_wm_input* in, con
   const int lst = tr->ell_max_supertranslation;
   const cplx* st = (const cplx*)tr->supertranslation;
 
-  // ---------------------------------------------------------------- host tables
+  // ---------------------------------------------------------------- per-pixel tables (GPU) and output window (host)
   HostTrace trace;
+  hipStream_t S = c->stream;
+  void* vp;
+  const bool nontrivial = [&] {
+    const double* v = tr->boost_velocity;
+    if (v[0] != 0 || v[1] != 0 || v[2] != 0) return true;
+    for (int i = 1; i < (lst + 1) * (lst + 1); ++i)
+      if (st[i].re != 0 || st[i].im != 0) return true;
+    return false;
+  }();
+  const bool apply_term = nontrivial;
+  const bool psi = apply_term && in->type_term == BMS_TERM_PSI;
+  std::vector<cplx> coef0;
+  cplx cv[4] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}};
+  if (apply_term && (in->type_term == BMS_TERM_H || in->type_term == BMS_TERM_SIGMA)) {
+    // h:     2 ethbar_GHP(ethbar_GHP(alpha, 0), -1) = +sqrt((l-1) l (l+1) (l+2)) alpha_lm, evaluated with s = -2
+    // sigma: eth_GHP(eth_GHP(alpha, 0), 1) = (1/2) sqrt(l (l+1)) sqrt((l-1)(l+2)) alpha_lm, evaluated with s = +2
+    coef0.resize((size_t)(lst + 1) * (lst + 1));
+    for (int l = 0; l <= lst; ++l)
+      for (int m = -l; m <= l; ++m) {
+        const cplx a = st[LM_index(l, m, 0)];
+        double f;
+        if (in->type_term == BMS_TERM_H)
+          f = 2 * ((-std::sqrt((double)l * (l + 1.0))) / std::sqrt(2.0)) * ((l >= 1 ? -std::sqrt((l - 1.0) * (l + 2.0)) : 0.0) / std::sqrt(2.0));
+        else
+          f = (std::sqrt((double)l * (l + 1.0)) / std::sqrt(2.0)) * ((l >= 1 ? std::sqrt((l - 1.0) * (l + 2.0)) : 0.0) / std::sqrt(2.0));
+        if (l < 2) f = 0.0;
+        coef0[LM_index(l, m, 0)] = {f * a.re, f * a.im};
+      }
+  } else if (psi) {
+    // eth u'/k = (t - alpha) gamma k eth(v.r)/sqrt2 - eth alpha/sqrt2, exactly as waveform_grid.py:508-523
+    coef0.resize((size_t)(lst + 1) * (lst + 1));
+    for (int l = 0; l <= lst; ++l)
+      for (int m = -l; m <= l; ++m) {
+        const cplx a = st[LM_index(l, m, 0)];
+        const double f = (1 / std::sqrt(2.0)) * (std::sqrt((double)l * (l + 1.0)) / std::sqrt(2.0));
+        coef0[LM_index(l, m, 0)] = {f * a.re, f * a.im};
+      }
+    const double* v = tr->boost_velocity;
+    const double is2 = 1 / std::sqrt(2.0);
+    cv[1] = {is2 * v[0] * std::sqrt(2 * M_PI / 3), is2 * v[1] * std::sqrt(2 * M_PI / 3)};
+    cv[2] = {is2 * v[2] * std::sqrt(4 * M_PI / 3), 0};
+    cv[3] = {-is2 * v[0] * std::sqrt(2 * M_PI / 3), is2 * v[1] * std::sqrt(2 * M_PI / 3)};
+  }
   PixelTables T;
-  build_pixel_tables(tr, T);
-  trace.mark("pixel tables (host)");
+  DevPixel DP;
+  if ((rc = device_pixel_tables(c, tr, T, psi ? 1 : 0, s, in->conformal_weight, coef0.empty() ? nullptr : &coef0, nullptr, cv, DP)))
+    return rc;
+  trace.mark("pixel tables (GPU) + copy back");
   const int n_pix = T.n_pix;
   int64_t i_lo, i_hi;
   output_window(T, in->t, n, i_lo, i_hi);
@@ -914,88 +955,11 @@ extern "C" int bms_transform_modes_shard(bms_ctx* c, const bms_wm_input* in, con
   *n_times_out = n_new;
   for (int64_t i = 0; i < n_new; ++i) t_out[i] = (1 / T.gamma) * (in->t[i_lo + i] - T.tt);
   if (n_new == 0) return BMS_OK;
-
-  std::vector<double> col_off(2 * (size_t)n_pix, 0.0), col_scale(2 * (size_t)n_pix, 1.0);
-  const bool apply_term = T.nontrivial;
-  if (apply_term && (in->type_term == BMS_TERM_H || in->type_term == BMS_TERM_SIGMA)) {
-    // h:     2 ethbar_GHP(ethbar_GHP(alpha, 0), -1) = +sqrt((l-1) l (l+1) (l+2)) alpha_lm, evaluated with s = -2
-    // sigma: eth_GHP(eth_GHP(alpha, 0), 1) = (1/2) sqrt(l (l+1)) sqrt((l-1)(l+2)) alpha_lm, evaluated with s = +2
-    std::vector<cplx> d((size_t)(lst + 1) * (lst + 1));
-    for (int l = 0; l <= lst; ++l)
-      for (int m = -l; m <= l; ++m) {
-        const cplx a = st[LM_index(l, m, 0)];
-        double f;
-        if (in->type_term == BMS_TERM_H)
-          f = 2 * ((-std::sqrt((double)l * (l + 1.0))) / std::sqrt(2.0)) * ((l >= 1 ? -std::sqrt((l - 1.0) * (l + 2.0)) : 0.0) / std::sqrt(2.0));
-        else
-          f = (std::sqrt((double)l * (l + 1.0)) / std::sqrt(2.0)) * ((l >= 1 ? std::sqrt((l - 1.0) * (l + 2.0)) : 0.0) / std::sqrt(2.0));
-        if (l < 2) f = 0.0;
-        d[LM_index(l, m, 0)] = {f * a.re, f * a.im};
-      }
-    for (int p = 0; p < n_pix; ++p) {
-      const cplx v = eval_modes_host(d.data(), lst, s, T.R[p]);
-      col_off[2 * p] = v.re;
-      col_off[2 * p + 1] = v.im;
-    }
-  }
-  for (int p = 0; p < n_pix; ++p) {
-    const double kw = std::pow(T.k[p], (double)in->conformal_weight);
-    col_scale[2 * p] = kw;
-    col_scale[2 * p + 1] = kw;
-  }
-  const bool psi = apply_term && in->type_term == BMS_TERM_PSI;
-  std::vector<double> xa, xb;
-  if (psi) {
-    // eth u'/k = (t - alpha) gamma k eth(v.r)/sqrt2... exactly as waveform_grid.py:508-523
-    std::vector<cplx> ea((size_t)(lst + 1) * (lst + 1)), ev(4);
-    for (int l = 0; l <= lst; ++l)
-      for (int m = -l; m <= l; ++m) {
-        const cplx a = st[LM_index(l, m, 0)];
-        const double f = (1 / std::sqrt(2.0)) * (std::sqrt((double)l * (l + 1.0)) / std::sqrt(2.0));
-        ea[LM_index(l, m, 0)] = {f * a.re, f * a.im};
-      }
-    const double* v = tr->boost_velocity;
-    const double is2 = 1 / std::sqrt(2.0);
-    ev[0] = {0, 0};
-    ev[1] = {is2 * v[0] * std::sqrt(2 * M_PI / 3), is2 * v[1] * std::sqrt(2 * M_PI / 3)};
-    ev[2] = {is2 * v[2] * std::sqrt(4 * M_PI / 3), 0};
-    ev[3] = {-is2 * v[0] * std::sqrt(2 * M_PI / 3), is2 * v[1] * std::sqrt(2 * M_PI / 3)};
-    xa.resize(2 * (size_t)n_pix);
-    xb.resize(2 * (size_t)n_pix);
-    for (int p = 0; p < n_pix; ++p) {
-      const cplx A = eval_modes_host(ea.data(), lst, 1, T.R[p]);
-      const cplx V = eval_modes_host(ev.data(), 1, 1, T.R[p]);
-      xa[2 * p] = T.gamma * T.k[p] * V.re;
-      xa[2 * p + 1] = T.gamma * T.k[p] * V.im;
-      xb[2 * p] = A.re;
-      xb[2 * p + 1] = A.im;
-    }
-  }
-  trace.mark("window + type tables (host)");
-  // ---------------------------------------------------------------- device tables
-  hipStream_t S = c->stream;
-  void* vp;
-  double *d_rot, *d_off, *d_scale, *d_skewa, *d_skewb, *d_x, *d_alpha = nullptr, *d_xa = nullptr, *d_xb = nullptr;
-  if ((rc = upload(c, "rotors", T.R.data(), sizeof(Quat) * n_pix, &vp))) return rc;
-  d_rot = (double*)vp;
-  if ((rc = upload(c, "col_off", col_off.data(), 16 * (size_t)n_pix, &vp))) return rc;
-  d_off = (double*)vp;
-  if ((rc = upload(c, "col_scale", col_scale.data(), 16 * (size_t)n_pix, &vp))) return rc;
-  d_scale = (double*)vp;
-  if ((rc = upload(c, "skew_a", T.skew_a.data(), 8 * (size_t)n_pix, &vp))) return rc;
-  d_skewa = (double*)vp;
-  if ((rc = upload(c, "skew_b", T.skew_b.data(), 8 * (size_t)n_pix, &vp))) return rc;
-  d_skewb = (double*)vp;
+  double *d_rot = DP.rotors, *d_off = DP.col_off, *d_scale = DP.col_scale, *d_skewa = DP.skew_a, *d_skewb = DP.skew_b;
+  double *d_alpha = DP.alpha, *d_xa = DP.xa, *d_xb = DP.xb, *d_x;
   if ((rc = upload(c, "times", in->t, 8 * (size_t)n, &vp))) return rc;
   d_x = (double*)vp;
-  if (psi) {
-    if ((rc = upload(c, "alpha", T.alpha.data(), 8 * (size_t)n_pix, &vp))) return rc;
-    d_alpha = (double*)vp;
-    if ((rc = upload(c, "xa", xa.data(), 16 * (size_t)n_pix, &vp))) return rc;
-    d_xa = (double*)vp;
-    if ((rc = upload(c, "xb", xb.data(), 16 * (size_t)n_pix, &vp))) return rc;
-    d_xb = (double*)vp;
-  }
+  trace.mark("window (host) + time upload");
 
   const long long P2 = 2LL * n_pix;
   const long long ldg = round_up(P2, 16);
@@ -1099,12 +1063,30 @@ extern "C" int bms_transform_modes_shard(bms_ctx* c, const bms_wm_input* in, con
 // ====================================================================================================== building blocks
 
 extern "C" int bms_rotor_grid(bms_ctx* c, const double fr[4], const double v[3], int n_theta, int n_phi, double* out) {
-  // pure host set-up: ctx may be NULL
+  // ctx == NULL: pure host evaluation; otherwise the GPU kernel the transforms use (same pixel_math.h code)
   if (!fr || !v || !out) return fail(c, BMS_ERR_INVALID, "NULL argument");
   if (n_theta < 2 || n_phi < 1) return fail(c, BMS_ERR_INVALID, "bad grid size");
-  std::vector<Quat> R;
-  build_rotor_grid(fr, v, n_theta, n_phi, R);
-  std::memcpy(out, R.data(), sizeof(Quat) * R.size());
+  if (!c) {
+    std::vector<Quat> R;
+    build_rotor_grid(fr, v, n_theta, n_phi, R);
+    std::memcpy(out, R.data(), sizeof(Quat) * R.size());
+    return BMS_OK;
+  }
+  HIP_TRY(c, hipSetDevice(c->device));
+  const cplx zero4[4] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}};
+  bms_transformation tr{};
+  tr.supertranslation = zero4;
+  tr.ell_max_supertranslation = 1;
+  for (int i = 0; i < 4; ++i) tr.frame_rotation[i] = fr[i];
+  for (int i = 0; i < 3; ++i) tr.boost_velocity[i] = v[i];
+  tr.n_theta = n_theta;
+  tr.n_phi = n_phi;
+  PixelTables T;
+  DevPixel DP;
+  int rc = device_pixel_tables(c, &tr, T, -1, 0, 0, nullptr, nullptr, nullptr, DP);
+  if (rc) return rc;
+  HIP_TRY(c, hipMemcpyAsync(out, DP.rotors, sizeof(double) * 4 * T.n_pix, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
   return BMS_OK;
 }
 
@@ -1195,9 +1177,26 @@ extern "C" int bms_transform_abd(bms_ctx* c, const double* u, const void* raw, i
   const int lst = tr->ell_max_supertranslation;
   const cplx* st = (const cplx*)tr->supertranslation;
 
-  // ---- host tables (transformations.py:306-321, 391-396)
+  // ---- per-pixel tables on the GPU (transformations.py:306-321), output window on the host (:391-396)
+  hipStream_t S = c->stream;
+  void* vp;
+  std::vector<cplx> c1((size_t)(lst + 1) * (lst + 1)), c2((size_t)(lst + 1) * (lst + 1));
+  for (int l = 0; l <= lst; ++l)
+    for (int m = -l; m <= l; ++m) {
+      const cplx a = st[LM_index(l, m, 0)];
+      const double f1 = std::sqrt((double)l * (l + 1.0)) / std::sqrt(2.0);                                          // eth alpha / sqrt2
+      const double f2 = 0.5 * (std::sqrt((double)l * (l + 1.0)) * (l >= 1 ? std::sqrt((l - 1.0) * (l + 2.0)) : 0.0));  // eth eth alpha / 2
+      c1[LM_index(l, m, 0)] = {f1 * a.re, f1 * a.im};
+      c2[LM_index(l, m, 0)] = {f2 * a.re, f2 * a.im};
+    }
+  const double* v = tr->boost_velocity;
+  const cplx cv[4] = {{0, 0},
+                      {v[0] * std::sqrt(2 * M_PI / 3), v[1] * std::sqrt(2 * M_PI / 3)},
+                      {v[2] * std::sqrt(4 * M_PI / 3), 0},
+                      {-v[0] * std::sqrt(2 * M_PI / 3), v[1] * std::sqrt(2 * M_PI / 3)}};
   PixelTables T;
-  build_pixel_tables(tr, T);
+  DevPixel DP;
+  if ((rc = device_pixel_tables(c, tr, T, 2, 0, 0, &c1, &c2, cv, DP))) return rc;
   const int n_pix = T.n_pix;
   // window: timeprime = (u - tt) / gamma  (division, unlike the WaveformModes flavour)
   double umin = -INFINITY, umax = INFINITY;
@@ -1212,54 +1211,8 @@ extern "C" int bms_transform_abd(bms_ctx* c, const double* u, const void* raw, i
   *n_times_out = n_new;
   for (int64_t i = 0; i < n_new; ++i) u_out[i] = (u[i_lo + i] - T.tt) / T.gamma;
   if (n_new == 0) return BMS_OK;
-
-  std::vector<cplx> c1((size_t)(lst + 1) * (lst + 1)), c2((size_t)(lst + 1) * (lst + 1)), cv(4);
-  for (int l = 0; l <= lst; ++l)
-    for (int m = -l; m <= l; ++m) {
-      const cplx a = st[LM_index(l, m, 0)];
-      const double f1 = std::sqrt((double)l * (l + 1.0)) / std::sqrt(2.0);                                          // eth alpha / sqrt2
-      const double f2 = 0.5 * (std::sqrt((double)l * (l + 1.0)) * (l >= 1 ? std::sqrt((l - 1.0) * (l + 2.0)) : 0.0));  // eth eth alpha / 2
-      c1[LM_index(l, m, 0)] = {f1 * a.re, f1 * a.im};
-      c2[LM_index(l, m, 0)] = {f2 * a.re, f2 * a.im};
-    }
-  const double* v = tr->boost_velocity;
-  cv[0] = {0, 0};
-  cv[1] = {v[0] * std::sqrt(2 * M_PI / 3), v[1] * std::sqrt(2 * M_PI / 3)};
-  cv[2] = {v[2] * std::sqrt(4 * M_PI / 3), 0};
-  cv[3] = {-v[0] * std::sqrt(2 * M_PI / 3), v[1] * std::sqrt(2 * M_PI / 3)};
-  std::vector<double> ethk(2 * (size_t)n_pix), etha(2 * (size_t)n_pix), ethetha(2 * (size_t)n_pix), ik(n_pix), ik3(n_pix);
-  for (int p = 0; p < n_pix; ++p) {
-    double r[3];
-    rotate_z(T.R[p], r);
-    const double vr = v[0] * r[0] + v[1] * r[1] + v[2] * r[2];
-    const cplx ev = eval_modes_host(cv.data(), 1, 1, T.R[p]);
-    ethk[2 * p] = ev.re / (1 - vr);
-    ethk[2 * p + 1] = ev.im / (1 - vr);
-    const cplx e1 = eval_modes_host(c1.data(), lst, 1, T.R[p]);
-    const cplx e2 = eval_modes_host(c2.data(), lst, 2, T.R[p]);
-    etha[2 * p] = e1.re, etha[2 * p + 1] = e1.im;
-    ethetha[2 * p] = e2.re, ethetha[2 * p + 1] = e2.im;
-    const double one_over_k = T.gamma * (1 - vr);
-    ik[p] = one_over_k;
-    ik3[p] = one_over_k * one_over_k * one_over_k;
-  }
-  // ---- device tables
-  hipStream_t S = c->stream;
-  void* vp;
-#define UP(name, vec, dst)                                                            \
-  if ((rc = upload(c, name, (vec).data(), sizeof((vec)[0]) * (vec).size(), &vp))) return rc; \
-  double* dst = (double*)vp;
-  if ((rc = upload(c, "rotors", T.R.data(), sizeof(Quat) * n_pix, &vp))) return rc;
-  double* d_rot = (double*)vp;
-  UP("skew_a", T.skew_a, d_skewa)
-  UP("skew_b", T.skew_b, d_skewb)
-  UP("alpha", T.alpha, d_alpha)
-  UP("abd_ethk", ethk, d_ethk)
-  UP("abd_etha", etha, d_etha)
-  UP("abd_ethetha", ethetha, d_ethetha)
-  UP("abd_ik", ik, d_ik)
-  UP("abd_ik3", ik3, d_ik3)
-#undef UP
+  double *d_rot = DP.rotors, *d_skewa = DP.skew_a, *d_skewb = DP.skew_b, *d_alpha = DP.alpha, *d_ethk = DP.ethk,
+         *d_etha = DP.etha, *d_ethetha = DP.ethetha, *d_ik = DP.ik, *d_ik3 = DP.ik3;
   if ((rc = upload(c, "times", u, 8 * (size_t)n, &vp))) return rc;
   double* d_x = (double*)vp;
 

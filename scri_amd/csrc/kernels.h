@@ -33,6 +33,11 @@ hipError_t launch_quadrature_matrix(hipStream_t stream, const double* rotors, co
 hipError_t launch_swsh_values(hipStream_t stream, const double* rotors, int n_pix, int spin, int ell_min, int ell_max,
                               double* Y /* c16[n_pix][n_modes] */);
 
+// ---- per-pixel set-up tables on the device (pixel_math.h)
+struct PixelSpec;
+struct PixelOut;
+hipError_t launch_pixel_tables(hipStream_t stream, const PixelSpec& P, const PixelOut& O, int n_pix);
+
 // ---- separable analysis (kernels_analysis.hip): phi-DFT matrix for the GEMM, theta table, theta quadrature
 hipError_t launch_dft_matrix(hipStream_t stream, int n_phi, int L, double* B, long long ldb);
 hipError_t launch_theta_table(hipStream_t stream, const double* Y, const double* w_theta, int n_theta, int n_out, double* T);

@@ -10,6 +10,7 @@
 //   |-yi  yr |
 // so row 2k holds (yr, yi) and row 2k+1 holds (-yi, yr) at columns (2p, 2p+1).
 #include "wigner.h"
+#include "pixel_math.h"
 #include "kernels.h"
 
 namespace bms {
@@ -89,6 +90,19 @@ hipError_t launch_swsh_values(hipStream_t stream, const double* rotors, int n_pi
   if (n <= 0) return hipSuccess;
   hipLaunchKernelGGL(swsh_kernel<0>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, rotors,
                      (const double*)nullptr, n_pix, spin, ell_min, ell_max, Y, 0);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------- per-pixel tables
+// rotor grid, conformal factor k, supertranslation alpha, time-skew coefficients and the flavour-specific per-pixel
+// terms (pixel_math.h: the same code the host runs for bms_shard_plan), one thread per pixel
+__global__ __launch_bounds__(128) void pixel_tables_kernel(PixelSpec P, PixelOut O, int n_pix) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p < n_pix) pixel_tables_one(P, O, p);
+}
+
+hipError_t launch_pixel_tables(hipStream_t stream, const PixelSpec& P, const PixelOut& O, int n_pix) {
+  hipLaunchKernelGGL(pixel_tables_kernel, dim3((n_pix + 127) / 128), dim3(128), 0, stream, P, O, n_pix);
   return hipGetLastError();
 }
 

@@ -237,14 +237,16 @@ def transform_abd(u, raw, ell_max, transformation, ctx=None):
 # ---------------------------------------------------------------------------------- building blocks
 
 
-def rotor_grid(frame_rotation, boost_velocity, n_theta, n_phi, ctx=None):
-    """boosted_grid / R_j_k (host-only set-up: works without a GPU context)."""
+def rotor_grid(frame_rotation, boost_velocity, n_theta, n_phi, ctx=None, device=False):
+    """boosted_grid / R_j_k.  Default: host-only evaluation (works without a GPU); device=True runs the GPU kernel the
+    transforms use (same code, pixel_math.h) on `ctx`."""
     fr = np.ascontiguousarray(frame_rotation, dtype=float)
     v = np.ascontiguousarray(boost_velocity, dtype=float)
     out = np.empty((n_theta, n_phi, 4))
-    rc = _lib.load().bms_rotor_grid(None, dptr(fr), dptr(v), n_theta, n_phi, dptr(out))
+    h = _ctx(ctx).handle if device else None
+    rc = _lib.load().bms_rotor_grid(h, dptr(fr), dptr(v), n_theta, n_phi, dptr(out))
     if rc != 0:
-        _lib._raise(rc, None, "bms_rotor_grid")
+        _lib._raise(rc, h, "bms_rotor_grid")
     return out
 
 
