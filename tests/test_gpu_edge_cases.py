@@ -1,0 +1,137 @@
+"""Edge cases of the GPU paths: non-uniform time grids, tiny series, user grid sizes, every analysis variant
+(fused kernel / phi-DFT GEMM + theta quadrature / dense quadrature GEMM), large boosts (wide time skew), large l in the
+rotation (MFMA and VALU kernels), strided inputs."""
+import numpy as np
+import pytest
+from scipy.interpolate import CubicSpline
+
+from oracle import quat, wigner, rotations_ref, spinsfast_ref, abd_ref
+from oracle import waveform_grid_ref as grid_ref
+from oracle.containers import WM, ABD, h, psi4
+
+pytestmark = pytest.mark.gpu
+
+
+def _wm(t, ell_max, seed, dataType=h):
+    rng = np.random.default_rng(seed)
+    LM = wigner.LM_range(2, ell_max)
+    a = (rng.normal(size=LM.shape[0]) + 1j * rng.normal(size=LM.shape[0])) * 10.0 ** (-LM[:, 0] / 4.0)
+    ph = 0.05 * t + 1e-4 * t**2
+    return WM(t=t, data=a[None, :] * np.exp(1j * LM[None, :, 1] * ph[:, None]), ell_min=2, ell_max=ell_max, dataType=dataType)
+
+
+def _gpu(w, ctx):
+    import scri_amd
+
+    return scri_amd.WaveformModes(t=w.t, data=w.data, ell_min=w.ell_min, ell_max=w.ell_max, dataType=w.dataType, frameType=1,
+                                  r_is_scaled_out=True, m_is_scaled_out=True, ctx=ctx)
+
+
+def _check(w, ctx, tol=1e-12, **kw):
+    e = grid_ref.transform(w, **kw)
+    g = _gpu(w, ctx).transform(**kw)
+    assert g.t.shape == e.t.shape and np.abs(g.t - e.t).max() < 1e-12
+    assert np.abs(g.data - e.data).max() < tol * max(1.0, np.abs(e.data).max())
+
+
+def test_nonuniform_time_grid(ctx):
+    rng = np.random.default_rng(1)
+    t = np.cumsum(rng.uniform(0.02, 0.3, size=700)) - 30.0  # step ratio up to 15
+    _check(_wm(t, 5, 2), ctx, space_translation=np.array([0.2, -0.3, 0.1]), boost_velocity=np.array([0.002, 0.001, -0.003]))
+
+
+@pytest.mark.parametrize("n", [4, 5, 7, 33])
+def test_tiny_series(ctx, n):
+    t = np.linspace(0.0, 1.0, n)
+    _check(_wm(t, 3, 3), ctx, time_translation=0.0)
+    _check(_wm(t, 3, 3), ctx, frame_rotation=np.array([1.0, 0.3, -0.2, 0.5]))
+
+
+def test_series_shorter_than_4_is_rejected(ctx):
+    with pytest.raises(ValueError, match="at least 4 time steps"):
+        _gpu(_wm(np.linspace(0, 1, 3), 3, 3), ctx).transform(time_translation=0.1)
+
+
+@pytest.mark.parametrize("n_theta,n_phi", [(15, 15), (21, 17), (15, 33), (45, 47)])
+def test_user_grid_sizes_and_analysis_variants(ctx, n_theta, n_phi):
+    """(45, 47) exceeds the fused kernel's limits -> phi-DFT GEMM + theta_quadrature_kernel."""
+    t = np.linspace(-5, 25, 200)
+    _check(_wm(t, 6, 4), ctx, supertranslation=np.array([0.0, 0.01 - 0.02j, 0.03, -0.01 - 0.02j]), n_theta=n_theta, n_phi=n_phi, ell_max=5)
+
+
+def test_dense_quadrature_path_for_very_fine_grids(ctx):
+    """n_theta > 104 uses the dense quadrature GEMM (engine build_analysis)."""
+    from scri_amd import engine
+
+    rng = np.random.default_rng(5)
+    f = rng.normal(size=(3, 107, 9)) + 1j * rng.normal(size=(3, 107, 9))
+    assert np.abs(engine.map2salm(f, -1, 4, ctx=ctx) - spinsfast_ref.map2salm(f, -1, 4)).max() < 1e-12
+
+
+def test_large_boost_wide_skew_and_chunks(ctx):
+    import scri_amd
+
+    t = np.arange(3000) * 0.1 - 100.0
+    w = _wm(t, 4, 6, psi4)
+    kw = dict(boost_velocity=np.array([0.05, -0.08, 0.06]), n_theta=15, n_phi=15)  # skew of ~ +-150 samples
+    e = grid_ref.transform(w, **kw)
+    for limit in (None, 6 << 20):
+        c2 = scri_amd.Context(0, workspace_limit=limit) if limit else ctx
+        g = _gpu(w, c2).transform(**kw)
+        assert g.t.shape == e.t.shape
+        assert np.abs(g.data - e.data).max() < 1e-11 * max(1.0, np.abs(e.data).max())
+
+
+def test_abd_large_working_grid_uses_two_kernel_analysis(ctx):
+    import scri_amd
+
+    rng = np.random.default_rng(7)
+    L, n = 12, 40
+    u = np.linspace(0, 10, n)
+    raw = np.zeros((6, n, (L + 1) ** 2), dtype=complex)
+    LM = wigner.LM_range(0, L)
+    for i, s in enumerate(ABD.spins):
+        a = (rng.normal(size=LM.shape[0]) + 1j * rng.normal(size=LM.shape[0])) * 10.0 ** (-LM[:, 0] / 3.0)
+        a[: s * s] = 0
+        raw[i] = a[None, :] * (1 + 0.02 * u[:, None])
+    kw = dict(boost_velocity=np.array([0.01, 0.0, 0.02]), space_translation=np.array([0.1, 0.0, -0.1]))  # grid 51 x 51
+    e = abd_ref.transform(ABD(u, raw, L), **kw)
+    g = scri_amd.AsymptoticBondiData(u, L, ctx=ctx)
+    g._raw_data[:] = raw
+    o = g.transform(**kw)
+    assert o.n_times == e.n_times
+    assert np.abs(o._raw_data - e.raw).max() < 1e-12 * max(1.0, np.abs(e.raw).max())
+
+
+@pytest.mark.parametrize("ell_max", [24, 33, 40])
+def test_rotation_large_ell(ctx, ell_max):
+    """l <= 33 runs the MFMA kernel, above that the VALU kernel."""
+    from scri_amd import engine
+
+    rng = np.random.default_rng(8)
+    n, nm = 70, (ell_max + 1) ** 2
+    data = rng.normal(size=(n, nm)) + 1j * rng.normal(size=(n, nm))
+    R = rng.normal(size=(n, 4))
+    R /= np.linalg.norm(R, axis=1)[:, None]
+    sp = quat.as_spinor_array(R)
+    got = engine.rotate_series(data.copy(), 0, ell_max, sp, ctx=ctx)
+    expect = rotations_ref.rotate_by_series(data, sp, 0, ell_max)
+    assert np.abs(got - expect).max() < 1e-13 * ell_max
+
+
+def test_strided_rows_and_interpolate(ctx):
+    from scri_amd import engine
+
+    rng = np.random.default_rng(9)
+    big = rng.normal(size=(50, 40)) + 1j * rng.normal(size=(50, 40))
+    view = big[:, :21]  # row stride 40 complex, 21 modes of l = 2..4
+    q = np.array([0.3, 0.1, -0.7, 0.2])
+    q /= np.linalg.norm(q)
+    Ra, Rb = quat.as_spinor_array(q)
+    expect = rotations_ref.rotate_by_constant(view.copy(), 2, 4, wigner.wigner_D_matrices(Ra, Rb, 2, 4))
+    keep = big[:, 21:].copy()
+    engine.rotate_const(view, 2, 4, q, ctx=ctx)
+    assert np.abs(view - expect).max() < 1e-13 and np.array_equal(big[:, 21:], keep)
+    x = np.linspace(0, 1, 50)
+    xn = np.array([0.0, 0.013, 0.5, 0.99, 1.0])
+    assert np.abs(engine.cubic_spline(x, big, xn, ctx=ctx) - CubicSpline(x, big)(xn)).max() < 1e-12
