@@ -179,13 +179,32 @@ hipError_t launch_spline_forward(hipStream_t stream, const double* Y, double* R,
 // intervals [x_j, x_{j+1}) of the tile, evaluate every output sample whose abscissa
 //     u_eval(i) = b_i + (skew_a[p] (b_i - tt) + skew_b[p])          (= u'_i / k_p + alpha_p for b = x)
 // falls inside, with the polynomial form scipy uses (c3 t^3 + c2 t^2 + c1 t + c0, t = u_eval - x_j).
+constexpr int RING_ROWS = 16;  // power of two; output rows a lane may hold back before they are written
+
+__device__ __forceinline__ int wave_max_i32(int v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    const int o = __shfl_xor(v, off, 64);
+    v = o > v ? o : v;
+  }
+  return v;
+}
+
+// One wave = 64 adjacent pixels marching backward over the knots of one time tile.  The lanes cross from one output
+// row to the next at different knots (each pixel has its own time offset), so storing a sample the moment it is
+// produced tears every 1 KB output row into pieces written at different times (measured: 1.75x the ideal HBM write
+// bytes).  Instead each lane parks its samples in its own column of an LDS ring and the wave writes a row once every
+// lane is past it: whole rows, one store instruction each.  Row indices are kept relative to i_lo.
 __global__ __launch_bounds__(64) void spline_backward_eval_kernel(
     const double* __restrict__ Y, const double* __restrict__ R, long long ld, int n_cols, long long g0, long long n_rows,
     long long n, const double* __restrict__ x, const SplineTable* __restrict__ table, int tile, int halo,
     const double* __restrict__ base, const double* __restrict__ skew_a, const double* __restrict__ skew_b, double tt,
     long long i_lo, long long i_hi, double* __restrict__ out, long long ldo) {
-  const int p = blockIdx.x * blockDim.x + threadIdx.x;
-  if (p >= n_cols) return;
+  __shared__ double2 ring[RING_ROWS][64];
+  const int lane = threadIdx.x;
+  int p = blockIdx.x * blockDim.x + lane;
+  bool alive = p < n_cols;
+  if (!alive) p = n_cols - 1;
   const long long jend = g0 + n_rows;
   const long long jA = g0 + (long long)blockIdx.y * tile;
   long long jB = jA + tile;
@@ -196,19 +215,21 @@ __global__ __launch_bounds__(64) void spline_backward_eval_kernel(
   const bool open_top = (jI == n - 1);  // claims everything above
   const bool open_bottom = (jA == 0);   // claims everything below
   const double sa = skew_a ? skew_a[p] : 0.0, sb = skew_b ? skew_b[p] : 0.0;
-  auto ueval = [&](long long i) {
-    const double xi = base[i];
+  const double* bp = base + i_lo;
+  const int n_i = (int)(i_hi - i_lo);
+  auto ueval = [&](int i) {
+    const double xi = bp[i];
     return xi + (sa * (xi - tt) + sb);
   };
-  // largest i in [i_lo, i_hi) with u_eval(i) < x[jI] (all of them if open_top)
-  long long i;
+  // largest i in [0, n_i) with u_eval(i) < x[jI] (all of them if open_top)
+  int i;
   if (open_top) {
-    i = i_hi - 1;
+    i = n_i - 1;
   } else {
     const double xt = x[jI];
-    long long lo = i_lo, hi = i_hi;  // first index with ueval >= xt
+    int lo = 0, hi = n_i;  // first index with ueval >= xt
     while (lo < hi) {
-      const long long mid = (lo + hi) >> 1;
+      const int mid = (lo + hi) >> 1;
       if (ueval(mid) < xt)
         lo = mid + 1;
       else
@@ -216,12 +237,14 @@ __global__ __launch_bounds__(64) void spline_backward_eval_kernel(
     }
     i = lo - 1;
   }
-  if (i < i_lo) return;
-  if (!open_bottom && ueval(i) < x[jA]) return;  // nothing lands in this tile
+  if (i < 0) alive = false;
+  if (alive && !open_bottom && ueval(i) < x[jA]) alive = false;  // nothing lands in this tile
+  if (!__any(alive)) return;
+  if (!alive) i = -1;
 
   const double* yp = Y + 2LL * p - g0 * ld;
   const double* rp = R + 2LL * p - g0 * ld;
-  double* op = out + 2LL * p - i_lo * ldo;
+  double* op = out + 2LL * p;
   auto ld2 = [&](const double* base, long long j) { return *reinterpret_cast<const double2*>(base + j * ld); };
 
   long long jE = jI + halo;
@@ -247,16 +270,34 @@ __global__ __launch_bounds__(64) void spline_backward_eval_kernel(
   }
   // now s1 = s_{jI}
   double2 y1 = ld2(yp, jI);
-  double ue = ueval(i);
+  double ue = alive ? ueval(i) : 0.0;
+  // this lane's samples of rows (i, fl] sit in the ring; every row above `ftop` (wave-uniform) is already in memory
+  int fl = i;
+  int ftop = wave_max_i32(i);
+  auto park = [&](double2 v) {
+    if (fl - i >= RING_ROWS) {  // ring full (output much denser than the knots): let the oldest row go
+      *reinterpret_cast<double2*>(op + fl * ldo) = ring[fl & (RING_ROWS - 1)][lane];
+      --fl;
+    }
+    ring[i & (RING_ROWS - 1)][lane] = v;
+  };
+  // write rows (bot, ftop]: each lane contributes the rows it has parked
+  auto flush = [&](int bot) {
+    for (int row = ftop; row > bot; --row)
+      if (row <= fl && row > i) *reinterpret_cast<double2*>(op + row * ldo) = ring[row & (RING_ROWS - 1)][lane];
+    const int keep = bot > i ? bot : i;
+    if (fl > keep) fl = keep;
+    if (ftop > bot) ftop = bot;
+  };
   // one interval: s_j from the recurrence, then every output sample that lands in [x_j, x_{j+1})
-  auto interval = [&](long long jj, double2 r, double2 y0) -> bool {
+  auto interval = [&](long long jj, double2 r, double2 y0) {
     const double C = table[jj].C;
     double2 s0;
     s0.x = r.x - C * s1.x;
     s0.y = r.y - C * s1.y;
     const double xj = x[jj];
     const bool last_interval = (jj == jA) && open_bottom;
-    if (ue >= xj || last_interval) {
+    if (i >= 0 && (ue >= xj || last_interval)) {
       const double h = x[jj + 1] - xj;
       const double ih = 1.0 / h;
       // scipy: slope = dy/h; t = (s0 + s1 - 2 slope)/h; c3 = t/h; c2 = (slope - s0)/h - t; c1 = s0; c0 = y0
@@ -264,35 +305,39 @@ __global__ __launch_bounds__(64) void spline_backward_eval_kernel(
       const double tx = (s0.x + s1.x - 2.0 * slx) * ih, ty = (s0.y + s1.y - 2.0 * sly) * ih;
       const double c3x = tx * ih, c3y = ty * ih;
       const double c2x = (slx - s0.x) * ih - tx, c2y = (sly - s0.y) * ih - ty;
-      while (i >= i_lo && (ue >= xj || last_interval)) {
+      while (i >= 0 && (ue >= xj || last_interval)) {
         // t = u_eval - x_j, formed as (x_i - x_j) + skew to keep the small difference exact
-        const double xi = base[i];
+        const double xi = bp[i];
         const double t = (xi - xj) + (sa * (xi - tt) + sb);
         double2 v;
         v.x = ((c3x * t + c2x) * t + s0.x) * t + y0.x;
         v.y = ((c3y * t + c2y) * t + s0.y) * t + y0.y;
-        *reinterpret_cast<double2*>(op + i * ldo) = v;
+        park(v);
         --i;
-        if (i >= i_lo) ue = ueval(i);
+        if (i >= 0) ue = ueval(i);
       }
     }
     s1 = s0;
     y1 = y0;
-    return i >= i_lo;
   };
   long long j = jI - 1;
   for (; j - 3 >= jA; j -= 4) {
     // 8 x 16 B per lane in flight before the dependent chain starts
     const double2 r0 = ld2(rp, j), r1 = ld2(rp, j - 1), r2 = ld2(rp, j - 2), r3 = ld2(rp, j - 3);
     const double2 q0 = ld2(yp, j), q1 = ld2(yp, j - 1), q2 = ld2(yp, j - 2), q3 = ld2(yp, j - 3);
-    if (!interval(j, r0, q0)) return;
-    if (!interval(j - 1, r1, q1)) return;
-    if (!interval(j - 2, r2, q2)) return;
-    if (!interval(j - 3, r3, q3)) return;
+    interval(j, r0, q0);
+    interval(j - 1, r1, q1);
+    interval(j - 2, r2, q2);
+    interval(j - 3, r3, q3);
+    // rows every lane has left behind (a finished lane, i = -1, holds nobody back)
+    flush(wave_max_i32(i));
+    if (!__any(i >= 0)) break;
   }
-  for (; j >= jA; --j) {
-    if (!interval(j, ld2(rp, j), ld2(yp, j))) return;
-  }
+  if (__any(i >= 0))
+    for (; j >= jA; --j) interval(j, ld2(rp, j), ld2(yp, j));
+  // lanes stop at different rows at the bottom of the tile: whatever is still parked goes out now
+  const int low = -wave_max_i32(fl > i ? -i : -0x7fffffff);
+  flush(low);
 }
 
 hipError_t launch_spline_backward_eval(hipStream_t stream, const double* Y, const double* R, long long ld, int n_cols,
