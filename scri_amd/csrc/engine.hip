@@ -992,7 +992,7 @@ extern "C" int bms_transform_modes_shard(bms_ctx* c, const bms_wm_input* in, con
     snprintf(nm, sizeof nm, "Bsyn%d", fi);
     if ((rc = dev_buf_t(c, nm, (size_t)rows * ldb, &f.d_B))) return rc;
     HIP_TRY(c, hipMemsetAsync(f.d_B, 0, sizeof(double) * rows * ldb, S));
-    TIMED(c, BMS_TAG_SETUP, launch_swsh_matrix(S, d_rot, n_pix, f.spin, f.ell_min, f.ell_max, f.d_B, ldb));
+    TIMED(c, BMS_TAG_SETUP, launch_swsh_matrix_complex(S, d_rot, n_pix, f.spin, f.ell_min, f.ell_max, f.d_B, ldb));
   }
   trace.mark("uploads + synthesis matrices");
   AnalysisPlan ana;
@@ -1032,12 +1032,12 @@ extern "C" int bms_transform_modes_shard(bms_ctx* c, const bms_wm_input* in, con
     if (psi)
       if ((rc = dev_buf_t(c, "Yaux", (size_t)rows_in * ldg, &d_Yaux))) return rc;
     // synthesis (+ fused affine map when there is no psi mixing)
-    TIMED(c, BMS_TAG_GEMM_SYNTHESIS, launch_dgemm(S, F[0].d_data + (g0 - row0) * F[0].ld * 2, F[0].ld * 2, F[0].d_B, ldb, d_Y, ldg, rows_in, (int)P2,
-                            F[0].K, psi ? nullptr : d_off, psi ? nullptr : d_scale));
+    TIMED(c, BMS_TAG_GEMM_SYNTHESIS, launch_zgemm3m(S, F[0].d_data + (g0 - row0) * F[0].ld * 2, F[0].ld * 2, F[0].d_B, ldb, d_Y, ldg, rows_in, n_pix,
+                            F[0].K / 2, psi ? nullptr : d_off, psi ? nullptr : d_scale));
     if (psi) {
       for (int a = 0; a < in->n_aux; ++a) {
         const FieldPlan& f = F[1 + a];
-        TIMED(c, BMS_TAG_GEMM_SYNTHESIS, launch_dgemm(S, f.d_data + (g0 - row0) * f.ld * 2, f.ld * 2, f.d_B, ldb, d_Yaux, ldg, rows_in, (int)P2, f.K,
+        TIMED(c, BMS_TAG_GEMM_SYNTHESIS, launch_zgemm3m(S, f.d_data + (g0 - row0) * f.ld * 2, f.ld * 2, f.d_B, ldb, d_Yaux, ldg, rows_in, n_pix, f.K / 2,
                                 nullptr, nullptr));
         TIMED(c, BMS_TAG_POINTWISE, launch_psi_mix(S, d_Y, d_Yaux, ldg, n_pix, rows_in, d_x + g0, d_alpha, d_xa, d_xb, in->aux_coeff[a],
                                   in->aux_power[a]));
@@ -1228,7 +1228,7 @@ extern "C" int bms_transform_abd(bms_ctx* c, const double* u, const void* raw, i
     snprintf(tag, sizeof tag, "abd%d", si);
     if ((rc = dev_buf_t(c, nm1, (size_t)brows * ldb, &d_B[si]))) return rc;
     HIP_TRY(c, hipMemsetAsync(d_B[si], 0, sizeof(double) * brows * ldb, S));
-    TIMED(c, BMS_TAG_SETUP, launch_swsh_matrix(S, d_rot, n_pix, si - 2, 0, ell_max, d_B[si], ldb));
+    TIMED(c, BMS_TAG_SETUP, launch_swsh_matrix_complex(S, d_rot, n_pix, si - 2, 0, ell_max, d_B[si], ldb));
     if ((rc = build_analysis(c, tag, T.n_theta, T.n_phi, si - 2, 0, tr->ell_max_out, ana[si]))) return rc;
   }
   SplineTable* d_tab;
@@ -1260,8 +1260,8 @@ extern "C" int bms_transform_abd(bms_ctx* c, const double* u, const void* raw, i
     for (int f = 0; f < 6; ++f) {
       grids.y[f] = d_Y + (size_t)f * rows_in * ldg;
       TIMED(c, BMS_TAG_GEMM_SYNTHESIS,
-            launch_dgemm(S, d_raw + ((size_t)f * n + g0) * nm * 2, 2LL * nm, d_B[spins[f] + 2], ldb, grids.y[f], ldg, rows_in,
-                         (int)P2, K, nullptr, nullptr));
+            launch_zgemm3m(S, d_raw + ((size_t)f * n + g0) * nm * 2, 2LL * nm, d_B[spins[f] + 2], ldb, grids.y[f], ldg, rows_in,
+                           n_pix, K / 2, nullptr, nullptr));
     }
     TIMED(c, BMS_TAG_POINTWISE,
           launch_abd_mix(S, grids, ldg, n_pix, rows_in, d_x + g0, d_alpha, d_ethk, d_etha, d_ethetha, d_ik, d_ik3));

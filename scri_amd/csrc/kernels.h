@@ -25,6 +25,9 @@ hipError_t launch_rotate_modes_mfma(hipStream_t stream, double* data, long long 
 // Bmat[2k][2p] = Re Y_k(R_p), [2k][2p+1] = Im, [2k+1][2p] = -Im, [2k+1][2p+1] = Re;  k = LM_index(l,m,ell_min)
 hipError_t launch_swsh_matrix(hipStream_t stream, const double* rotors /* f8[n_pix][4] */, int n_pix, int spin,
                               int ell_min, int ell_max, double* Bmat, long long ldb);
+// the same harmonics as a plain complex matrix Y[k][p] (row pitch ldb doubles), the B operand of launch_zgemm3m
+hipError_t launch_swsh_matrix_complex(hipStream_t stream, const double* rotors, int n_pix, int spin, int ell_min,
+                                      int ell_max, double* Bmat, long long ldb);
 // analysis (quadrature) matrix: W[p][k] = w_pix[p] conj(Y_k(R_p)) in the real layout with pixels as rows:
 // Wmat[2p][2k] = Re W, [2p][2k+1] = Im W, [2p+1][2k] = -Im W, [2p+1][2k+1] = Re W
 hipError_t launch_quadrature_matrix(hipStream_t stream, const double* rotors, const double* w_pix, int n_pix, int spin,
@@ -57,6 +60,12 @@ hipError_t launch_analysis_fused(hipStream_t stream, const double* G, long long 
 // A row-major (lda), B row-major (ldb, zero padded to a multiple of 128 columns and 16 rows), C row-major (ldc).
 hipError_t launch_dgemm(hipStream_t stream, const double* A, long long lda, const double* B, long long ldb, double* C,
                         long long ldc, long long M, int N, int K, const double* col_off, const double* col_scale);
+
+// ---- complex128 GEMM on MFMA with 3 real products per complex one: C = (A . B - col_off) * col_scale
+// A[M x K], B[K x N], C[M x N] complex interleaved, row-major, pitches lda/ldb/ldc in DOUBLES; B zero padded to a multiple
+// of 64 complex columns and 8 rows; col_off/col_scale per real column (2N entries) or null.
+hipError_t launch_zgemm3m(hipStream_t stream, const double* A, long long lda, const double* B, long long ldb, double* C,
+                          long long ldc, long long M, int N, int K, const double* col_off, const double* col_scale);
 
 // ---- shared-matrix not-a-knot cubic spline along time (waveform_grid.py:574-588)
 struct SplineTable {  // per knot j

@@ -151,6 +151,162 @@ __global__ __launch_bounds__(256, 2) void dgemm_mfma_kernel(const double* __rest
 #undef G_LOAD_GLOBAL
 #undef G_STORE_LDS
 
+// ------------------------------------------------------------------------------------------------ complex, 3 products
+// The synthesis contraction is complex x complex.  Written as the real GEMM above it costs 4 real MFMA products per
+// complex multiply-add; the matrix pipe is the bound (60 TFLOP/s sustained), so the complex kernel below spends 3:
+//     P1 = Ar.Br,  P2 = Ai.Bi,  P3 = (Ar + Ai).(Br + Bi)   =>   Re = P1 - P2,  Im = P3 - P1 - P2
+// (the "3M" scheme; the error bound stays normwise O(K eps |A||B|), the imaginary part just loses the componentwise
+// bound, which the parity tolerances never relied on).  The operand sums cost one v_add_f64 per fragment in registers.
+//     C[M x N] = (A[M x K] . B[K x N] - col_off) * col_scale      (complex128 interleaved; off/scale per real column)
+// Workgroup tile 64 rows x 64 complex columns x 8 complex k, 4 wavefronts (2 x 2), 32 x 32 per wavefront =
+// 3 x 4 accumulator tiles (96 VGPRs), three workgroups per CU.  Fragments are (re, im) pairs read with ds_read_b128:
+// A rows at a pitch of 10 complex and B rows at 64 complex make every 16-lane group of a read hit 16 distinct slots.
+constexpr int Z_BM = 64, Z_BN = 64, Z_KC = 8;
+constexpr int Z_PA = 10;  // LDS pitch of an A row (complex)
+constexpr int Z_PB = 64;  // LDS pitch of a B row (complex)
+constexpr int Z_ASZ = Z_BM * Z_PA;
+constexpr int Z_BSZ = Z_KC * Z_PB;
+
+__global__ __launch_bounds__(256, 3) void zgemm3m_mfma_kernel(const double* __restrict__ A, long long lda,
+                                                              const double* __restrict__ B, long long ldb,
+                                                              double* __restrict__ C, long long ldc, long long M, int N,
+                                                              int K, int nbm, int nbn, int st_rows_log2,
+                                                              const double* __restrict__ col_off,
+                                                              const double* __restrict__ col_scale) {
+  __shared__ __attribute__((aligned(16))) double2 lds[2 * Z_ASZ + 2 * Z_BSZ];
+  double2* As = lds;
+  double2* Bs = lds + 2 * Z_ASZ;
+
+  // same XCD-aware super-tile map as dgemm_mfma_kernel
+  const int b = blockIdx.x;
+  const int xcd = b & 7;
+  const int q = b >> 3;
+  const int st_cols_log2 = 6 - st_rows_log2;
+  const int nsn = (nbn + (1 << st_cols_log2) - 1) >> st_cols_log2;
+  const int S = (q >> 6) * 8 + xcd;
+  const int r = q & 63;
+  const int bm = ((S / nsn) << st_rows_log2) + (r >> st_cols_log2);
+  const int bn = ((S % nsn) << st_cols_log2) + (r & ((1 << st_cols_log2) - 1));
+  if (bm >= nbm || bn >= nbn) return;
+  const long long m0 = (long long)bm * Z_BM;
+  const int n0 = bn * Z_BN;
+
+  const int tid = threadIdx.x;
+  const int wave = tid >> 6, lane = tid & 63;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int fi = lane & 15, fk = lane >> 4;
+
+  v4d p1[2][2], p2[2][2], p3[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) p1[i][j] = p2[i][j] = p3[i][j] = v4d{0.0, 0.0, 0.0, 0.0};
+
+  // staging maps: A tile 64 rows x 8 complex (thread -> row = tid>>3 (+32), k = tid&7);
+  //               B tile 8 rows x 64 complex (thread -> row = tid>>6 (+4), column = tid&63)
+  const int a_row = tid >> 3, a_k = tid & 7;
+  const int b_row = tid >> 6, b_col = tid & 63;
+  const double* a_ptr = A + (m0 + a_row) * lda + 2 * a_k;
+  const double* b_ptr = B + (long long)b_row * ldb + 2 * (n0 + b_col);
+  const bool a_ok0 = (m0 + a_row) < M, a_ok1 = (m0 + a_row + 32) < M;
+  const double2 zero2 = {0.0, 0.0};
+  double2 ra0, ra1, rb0, rb1;
+  const int nk = (K + Z_KC - 1) / Z_KC;
+
+#define Z_LOAD_GLOBAL(kt)                                                                      \
+  {                                                                                            \
+    const int k0 = (kt)*Z_KC;                                                                  \
+    const bool kok = (k0 + a_k) < K;                                                           \
+    ra0 = (a_ok0 && kok) ? *reinterpret_cast<const double2*>(a_ptr + 2 * k0) : zero2;          \
+    ra1 = (a_ok1 && kok) ? *reinterpret_cast<const double2*>(a_ptr + 32 * lda + 2 * k0) : zero2; \
+    const double* bp = b_ptr + (long long)k0 * ldb;                                            \
+    rb0 = *reinterpret_cast<const double2*>(bp);                                               \
+    rb1 = *reinterpret_cast<const double2*>(bp + 4 * ldb);                                     \
+  }
+#define Z_STORE_LDS(buf)                                        \
+  {                                                             \
+    double2* as_w = As + (buf)*Z_ASZ + a_row * Z_PA + a_k;      \
+    as_w[0] = ra0;                                              \
+    as_w[32 * Z_PA] = ra1;                                      \
+    double2* bs_w = Bs + (buf)*Z_BSZ + b_row * Z_PB + b_col;    \
+    bs_w[0] = rb0;                                              \
+    bs_w[4 * Z_PB] = rb1;                                       \
+  }
+
+  Z_LOAD_GLOBAL(0);
+  Z_STORE_LDS(0);
+  __syncthreads();
+
+  for (int kt = 0; kt < nk; ++kt) {
+    const int buf = kt & 1;
+    if (kt + 1 < nk) Z_LOAD_GLOBAL(kt + 1);
+    const double2* as = As + buf * Z_ASZ + (wm * 32 + fi) * Z_PA + fk;
+    const double2* bs = Bs + buf * Z_BSZ + fk * Z_PB + wn * 32 + fi;
+#pragma unroll
+    for (int kk = 0; kk < Z_KC / 4; ++kk) {
+      const double2 a0 = as[kk * 4], a1 = as[16 * Z_PA + kk * 4];
+      const double2 b0 = bs[kk * 4 * Z_PB], b1 = bs[kk * 4 * Z_PB + 16];
+      const double sa0 = a0.x + a0.y, sa1 = a1.x + a1.y, sb0 = b0.x + b0.y, sb1 = b1.x + b1.y;
+      p1[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0.x, b0.x, p1[0][0], 0, 0, 0);
+      p1[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0.x, b1.x, p1[0][1], 0, 0, 0);
+      p1[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1.x, b0.x, p1[1][0], 0, 0, 0);
+      p1[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1.x, b1.x, p1[1][1], 0, 0, 0);
+      p2[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0.y, b0.y, p2[0][0], 0, 0, 0);
+      p2[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0.y, b1.y, p2[0][1], 0, 0, 0);
+      p2[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1.y, b0.y, p2[1][0], 0, 0, 0);
+      p2[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1.y, b1.y, p2[1][1], 0, 0, 0);
+      p3[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(sa0, sb0, p3[0][0], 0, 0, 0);
+      p3[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(sa0, sb1, p3[0][1], 0, 0, 0);
+      p3[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(sa1, sb0, p3[1][0], 0, 0, 0);
+      p3[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(sa1, sb1, p3[1][1], 0, 0, 0);
+    }
+    if (kt + 1 < nk) Z_STORE_LDS(buf ^ 1);
+    __syncthreads();
+  }
+
+  // epilogue: recombine, then the affine per-column map (type-specific inhomogeneous term and conformal factor,
+  // scri/waveform_grid.py:485-503,559) fused into the 16-byte store
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int col = n0 + wn * 32 + j * 16 + fi;
+    if (col >= N) continue;
+    const double off_r = col_off ? col_off[2 * col] : 0.0, off_i = col_off ? col_off[2 * col + 1] : 0.0;
+    const double sc_r = col_scale ? col_scale[2 * col] : 1.0, sc_i = col_scale ? col_scale[2 * col + 1] : 1.0;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) {
+        const long long row = m0 + wm * 32 + i * 16 + fk + 4 * rr;
+        if (row < M) {
+          const double re = p1[i][j][rr] - p2[i][j][rr];
+          const double im = (p3[i][j][rr] - p1[i][j][rr]) - p2[i][j][rr];
+          double2 v;
+          v.x = (re - off_r) * sc_r;
+          v.y = (im - off_i) * sc_i;
+          *reinterpret_cast<double2*>(C + row * ldc + 2LL * col) = v;
+        }
+      }
+    }
+  }
+}
+
+#undef Z_LOAD_GLOBAL
+#undef Z_STORE_LDS
+
+hipError_t launch_zgemm3m(hipStream_t stream, const double* A, long long lda, const double* B, long long ldb, double* C,
+                          long long ldc, long long M, int N, int K, const double* col_off, const double* col_scale) {
+  if (M <= 0 || N <= 0) return hipSuccess;
+  const int nbm = (int)((M + Z_BM - 1) / Z_BM);
+  const int nbn = (N + Z_BN - 1) / Z_BN;
+  static const int st_rows_log2 = getenv("SCRI_AMD_ZGEMM_ST_ROWS_LOG2") ? atoi(getenv("SCRI_AMD_ZGEMM_ST_ROWS_LOG2")) : 5;
+  const int sr = 1 << st_rows_log2, sc = 64 >> st_rows_log2;
+  const long long n_super = (long long)((nbm + sr - 1) / sr) * ((nbn + sc - 1) / sc);
+  const long long grid = ((n_super + 7) / 8) * 8 * 64;
+  hipLaunchKernelGGL(zgemm3m_mfma_kernel, dim3((unsigned)grid), dim3(256), 0, stream, A, lda, B, ldb, C, ldc, M, N, K,
+                     nbm, nbn, st_rows_log2, col_off, col_scale);
+  return hipGetLastError();
+}
+
 hipError_t launch_dgemm(hipStream_t stream, const double* A, long long lda, const double* B, long long ldb, double* C,
                         long long ldc, long long M, int N, int K, const double* col_off, const double* col_scale) {
   if (M <= 0 || N <= 0) return hipSuccess;

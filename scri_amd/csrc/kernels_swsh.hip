@@ -15,7 +15,8 @@
 
 namespace bms {
 
-// MODE 0: complex values Y[p][k]; MODE 1: synthesis matrix (modes as rows); MODE 2: quadrature matrix (pixels as rows)
+// MODE 0: complex values Y[p][k]; MODE 1: synthesis matrix (modes as rows), real 2K x 2N layout; MODE 2: quadrature
+// matrix (pixels as rows), real layout; MODE 3: synthesis matrix as plain complex Y[k][p] (row pitch ldb doubles)
 template <int MODE>
 __global__ __launch_bounds__(256) void swsh_kernel(const double* __restrict__ rotors, const double* __restrict__ w_pix,
                                                    int n_pix, int spin, int ell_min, int ell_max,
@@ -48,6 +49,10 @@ __global__ __launch_bounds__(256) void swsh_kernel(const double* __restrict__ ro
         r0[1] = yi;
         r1[0] = -yi;
         r1[1] = yr;
+      } else if (MODE == 3) {
+        double* r0 = out + k * ldb + 2LL * p;
+        r0[0] = yr;
+        r0[1] = yi;
       } else if (MODE == 2) {
         const double w = w_pix[p];
         const double wr = w * yr, wi = -w * yi;  // w conj(Y)
@@ -71,6 +76,15 @@ hipError_t launch_swsh_matrix(hipStream_t stream, const double* rotors, int n_pi
   const long long n = (long long)n_pix * (2 * ell_max + 1);
   if (n <= 0) return hipSuccess;
   hipLaunchKernelGGL(swsh_kernel<1>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, rotors,
+                     (const double*)nullptr, n_pix, spin, ell_min, ell_max, Bmat, ldb);
+  return hipGetLastError();
+}
+
+hipError_t launch_swsh_matrix_complex(hipStream_t stream, const double* rotors, int n_pix, int spin, int ell_min,
+                                      int ell_max, double* Bmat, long long ldb) {
+  const long long n = (long long)n_pix * (2 * ell_max + 1);
+  if (n <= 0) return hipSuccess;
+  hipLaunchKernelGGL(swsh_kernel<3>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, rotors,
                      (const double*)nullptr, n_pix, spin, ell_min, ell_max, Bmat, ldb);
   return hipGetLastError();
 }
