@@ -160,6 +160,16 @@ int bms_transform_modes_shard(bms_ctx* ctx, const bms_wm_input* in, const bms_tr
 int bms_transform_abd(bms_ctx* ctx, const double* u, const void* raw, int mem, int64_t n_times, int ell_max,
                       const bms_transformation* tr, double* u_out, void* raw_out, int64_t* n_times_out);
 
+/* Time-axis shard of the same transformation (cfg5 of BASELINE.json: one shard per GPU).  u and n_times stay GLOBAL;
+ * raw holds rows [shard->data_row0, +data_rows) of every field, c16[6][data_rows][(ell_max+1)^2]; the call produces the
+ * output samples whose global input index lies in [out_i0, out_i1) (intersected with the valid window,
+ * transformations.py:391-396): u_out[*n_times_out], raw_out c16[6][out_i1 - out_i0][(ell_max_out+1)^2] (only the first
+ * *n_times_out rows of each field are written), *first_index_out = global input index of output row 0.
+ * bms_shard_plan gives the rows a shard must hold.  shard == NULL: whole series (== bms_transform_abd). */
+int bms_transform_abd_shard(bms_ctx* ctx, const double* u, const void* raw, int mem, int64_t n_times, int ell_max,
+                            const bms_transformation* tr, const bms_shard* shard, double* u_out, void* raw_out,
+                            int64_t* n_times_out, int64_t* first_index_out);
+
 /* ---- building blocks (exported for the parity tests and for the "next" rows of the scope table) --------- */
 /* boosted_grid / R_j_k (transformations.py:100-148, waveform_grid.py:130-174): host f8[n_theta][n_phi][4] */
 int bms_rotor_grid(bms_ctx* ctx, const double frame_rotation[4], const double boost_velocity[3], int n_theta,

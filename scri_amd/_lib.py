@@ -94,6 +94,11 @@ SIGNATURES = {
         c_int,
         [c_vp, c_dp, c_vp, c_int, c_i64, c_int, ctypes.POINTER(bms_transformation), c_dp, c_vp, ctypes.POINTER(c_i64)],
     ),
+    "bms_transform_abd_shard": (
+        c_int,
+        [c_vp, c_dp, c_vp, c_int, c_i64, c_int, ctypes.POINTER(bms_transformation), ctypes.POINTER(bms_shard), c_dp, c_vp,
+         ctypes.POINTER(c_i64), ctypes.POINTER(c_i64)],
+    ),
     "bms_rotor_grid": (c_int, [c_vp, c_dp, c_dp, c_int, c_int, c_dp]),
     "bms_swsh_grid": (c_int, [c_vp, c_dp, c_i64, c_int, c_int, c_int, c_vp]),
     "bms_map2salm": (c_int, [c_vp, c_vp, c_int, c_i64, c_int, c_int, c_int, c_int, c_int, c_vp]),

@@ -1162,8 +1162,9 @@ extern "C" int bms_cubic_spline(bms_ctx* c, const double* x, int64_t n, const vo
 }
 
 // ====================================================================================================== ABD flavour
-extern "C" int bms_transform_abd(bms_ctx* c, const double* u, const void* raw, int mem, int64_t n_times, int ell_max,
-                                 const bms_transformation* tr, double* u_out, void* raw_out, int64_t* n_times_out) {
+extern "C" int bms_transform_abd_shard(bms_ctx* c, const double* u, const void* raw, int mem, int64_t n_times, int ell_max,
+                                       const bms_transformation* tr, const bms_shard* sh, double* u_out, void* raw_out,
+                                       int64_t* n_times_out, int64_t* first_index_out) {
   if (!c) return BMS_ERR_INVALID;
   if (!u || !raw || !tr || !u_out || !raw_out || !n_times_out) return fail(c, BMS_ERR_INVALID, "NULL argument");
   HIP_TRY(c, hipSetDevice(c->device));
@@ -1204,11 +1205,22 @@ extern "C" int bms_transform_abd(bms_ctx* c, const double* u, const void* raw, i
     umin = std::max(umin, T.k[p] * (u[0] - T.alpha[p]));
     umax = std::min(umax, T.k[p] * (u[n - 1] - T.alpha[p]));
   }
-  const int64_t i_lo = std::partition_point(u, u + n, [&](double ui) { return (ui - T.tt) / T.gamma < umin; }) - u;
+  int64_t i_lo = std::partition_point(u, u + n, [&](double ui) { return (ui - T.tt) / T.gamma < umin; }) - u;
   int64_t i_hi = std::partition_point(u, u + n, [&](double ui) { return (ui - T.tt) / T.gamma <= umax; }) - u;
   if (i_hi < i_lo) i_hi = i_lo;
+  // the shard's share of the window, and the rows of the global series it was given
+  int64_t row0 = 0, rows_avail = n, fs_out = n;
+  if (sh) {
+    row0 = sh->data_row0;
+    rows_avail = sh->data_rows;
+    if (row0 < 0 || rows_avail < 0 || row0 + rows_avail > n || sh->out_i1 < sh->out_i0) return fail(c, BMS_ERR_INVALID, "bad shard description");
+    i_lo = std::max(i_lo, sh->out_i0);
+    i_hi = std::max(i_lo, std::min(i_hi, sh->out_i1));
+    fs_out = sh->out_i1 - sh->out_i0;
+  }
   const int64_t n_new = i_hi - i_lo;
   *n_times_out = n_new;
+  if (first_index_out) *first_index_out = i_lo;
   for (int64_t i = 0; i < n_new; ++i) u_out[i] = (u[i_lo + i] - T.tt) / T.gamma;
   if (n_new == 0) return BMS_OK;
   double *d_rot = DP.rotors, *d_skewa = DP.skew_a, *d_skewb = DP.skew_b, *d_alpha = DP.alpha, *d_ethk = DP.ethk,
@@ -1236,10 +1248,10 @@ extern "C" int bms_transform_abd(bms_ctx* c, const double* u, const void* raw, i
   TIMED(c, BMS_TAG_SETUP, launch_spline_table(S, d_x, n, d_tab));
 
   const double* d_raw;
-  if ((rc = stage_in(c, "in_data", raw, mem, (size_t)6 * n * nm * 16, &d_raw))) return rc;
+  if ((rc = stage_in(c, "in_data", raw, mem, (size_t)6 * rows_avail * nm * 16, &d_raw))) return rc;
   double* d_out = (double*)raw_out;
   if (mem == BMS_HOST)
-    if ((rc = dev_buf_t(c, "out_data", (size_t)6 * n * n_out * 2, &d_out))) return rc;
+    if ((rc = dev_buf_t(c, "out_data", (size_t)6 * fs_out * n_out * 2, &d_out))) return rc;
 
   // ---- chunk loop: 6 fields x (Y, R, G)
   const int margin = SPLINE_HALO + 2;
@@ -1252,6 +1264,11 @@ extern "C" int bms_transform_abd(bms_ctx* c, const double* u, const void* raw, i
     needed_knots(T, u, n, c0, c1_, ja, jb);
     const int64_t g0 = std::max<int64_t>(0, ja - margin), g1 = std::min<int64_t>(n, jb + margin + 1);
     const int64_t rows_in = g1 - g0, rows_out = c1_ - c0;
+    if (g0 < row0 || g1 > row0 + rows_avail)
+      return fail(c, BMS_ERR_INVALID,
+                  "shard holds rows [%lld, %lld) but outputs [%lld, %lld) need rows [%lld, %lld): halo too small "
+                  "(use bms_shard_plan)",
+                  (long long)row0, (long long)(row0 + rows_avail), (long long)c0, (long long)c1_, (long long)g0, (long long)g1);
     double *d_Y, *d_R, *d_G;
     if ((rc = dev_buf_t(c, "Y", (size_t)6 * rows_in * ldg, &d_Y))) return rc;
     if ((rc = dev_buf_t(c, "R", (size_t)6 * rows_in * ldg, &d_R))) return rc;
@@ -1260,7 +1277,7 @@ extern "C" int bms_transform_abd(bms_ctx* c, const double* u, const void* raw, i
     for (int f = 0; f < 6; ++f) {
       grids.y[f] = d_Y + (size_t)f * rows_in * ldg;
       TIMED(c, BMS_TAG_GEMM_SYNTHESIS,
-            launch_zgemm3m(S, d_raw + ((size_t)f * n + g0) * nm * 2, 2LL * nm, d_B[spins[f] + 2], ldb, grids.y[f], ldg, rows_in,
+            launch_zgemm3m(S, d_raw + ((size_t)f * rows_avail + (g0 - row0)) * nm * 2, 2LL * nm, d_B[spins[f] + 2], ldb, grids.y[f], ldg, rows_in,
                            n_pix, K / 2, nullptr, nullptr));
     }
     TIMED(c, BMS_TAG_POINTWISE,
@@ -1273,15 +1290,20 @@ extern "C" int bms_transform_abd(bms_ctx* c, const double* u, const void* raw, i
       TIMED(c, BMS_TAG_SPLINE_BACKWARD,
             launch_spline_backward_eval(S, grids.y[f], Rf, ldg, n_pix, g0, rows_in, n, d_x, d_tab, SPLINE_TILE, SPLINE_HALO,
                                         d_x, d_skewa, d_skewb, T.tt, c0, c1_, Gf, P2));
-      if ((rc = run_analysis(c, ana[spins[f] + 2], Gf, rows_out, d_out + ((size_t)f * n + (c0 - i_lo)) * n_out * 2, 2LL * n_out)))
+      if ((rc = run_analysis(c, ana[spins[f] + 2], Gf, rows_out, d_out + ((size_t)f * fs_out + (c0 - i_lo)) * n_out * 2, 2LL * n_out)))
         return rc;
     }
   }
   if (mem == BMS_HOST) {
     for (int f = 0; f < 6; ++f)
-      HIP_TRY(c, hipMemcpyAsync((char*)raw_out + (size_t)f * n * n_out * 16, d_out + (size_t)f * n * n_out * 2,
+      HIP_TRY(c, hipMemcpyAsync((char*)raw_out + (size_t)f * fs_out * n_out * 16, d_out + (size_t)f * fs_out * n_out * 2,
                                 (size_t)n_new * n_out * 16, hipMemcpyDeviceToHost, S));
   }
   HIP_TRY(c, hipStreamSynchronize(S));
   return BMS_OK;
+}
+
+extern "C" int bms_transform_abd(bms_ctx* c, const double* u, const void* raw, int mem, int64_t n_times, int ell_max,
+                                 const bms_transformation* tr, double* u_out, void* raw_out, int64_t* n_times_out) {
+  return bms_transform_abd_shard(c, u, raw, mem, n_times, ell_max, tr, nullptr, u_out, raw_out, n_times_out, nullptr);
 }

@@ -215,23 +215,46 @@ def shard_plan(t, transformation, out_i0, out_i1, ctx=None):
     return (need[0], need[1]), (win[0], win[1])
 
 
-def transform_abd(u, raw, ell_max, transformation, ctx=None):
-    """bms_transform_abd (host arrays): raw complex128 [6, N, (ell_max+1)^2] -> (u_out[N'], raw_out[6, N', n_out])."""
+def transform_abd(u, raw, ell_max, transformation, ctx=None, shard=None, device=False, out_ptr=None):
+    """bms_transform_abd[_shard]: raw complex128 [6, N, (ell_max+1)^2] -> (u_out[N'], raw_out[6, N', n_out]).
+
+    shard = (data_row0, data_rows, out_i0, out_i1): `u` stays the GLOBAL time axis, `raw` holds rows
+    [data_row0, data_row0 + data_rows) of every field, and the result carries a third element, the global input
+    index of output row 0.  device=True: `raw` and `out_ptr` are device pointers (c16[6][data_rows][n_modes] and
+    c16[6][out_i1 - out_i0][n_out]); returns (u_out, n_new[, first])."""
     ctx = _ctx(ctx)
     u = np.ascontiguousarray(u, dtype=float)
-    raw = _lib.as_c16(raw)
     n = u.shape[0]
-    if raw.shape != (6, n, (ell_max + 1) ** 2):
-        raise ValueError(f"raw shape {raw.shape} inconsistent")
+    n_rows = n if shard is None else int(shard[1])
     n_out = (transformation.ell_max_out + 1) ** 2
-    out = np.empty((6, n, n_out), dtype=np.complex128)
-    u_out = np.empty(n, dtype=float)
+    sh = None
+    fs_out = n
+    if shard is not None:
+        sh = bms_shard(int(shard[0]), int(shard[1]), int(shard[2]), int(shard[3]))
+        fs_out = int(shard[3]) - int(shard[2])
+    shp = ctypes.byref(sh) if sh is not None else None
+    u_out = np.empty(max(fs_out, 1), dtype=float)
     n_new = c_i64(0)
-    rc = _lib.load().bms_transform_abd(
-        ctx.handle, dptr(u), vptr(raw), BMS_HOST, n, int(ell_max), ctypes.byref(transformation), dptr(u_out), vptr(out), ctypes.byref(n_new)
+    first = c_i64(0)
+    if device:
+        rc = _lib.load().bms_transform_abd_shard(
+            ctx.handle, dptr(u), c_vp(int(raw)), BMS_DEVICE, n, int(ell_max), ctypes.byref(transformation), shp, dptr(u_out),
+            c_vp(int(out_ptr)), ctypes.byref(n_new), ctypes.byref(first),
+        )
+        ctx.check(rc, "bms_transform_abd")
+        res = (u_out[: n_new.value], n_new.value)
+        return res + (first.value,) if shard is not None else res
+    raw = _lib.as_c16(raw)
+    if raw.shape != (6, n_rows, (ell_max + 1) ** 2):
+        raise ValueError(f"raw shape {raw.shape} inconsistent")
+    out = np.empty((6, max(fs_out, 1), n_out), dtype=np.complex128)
+    rc = _lib.load().bms_transform_abd_shard(
+        ctx.handle, dptr(u), vptr(raw), BMS_HOST, n, int(ell_max), ctypes.byref(transformation), shp, dptr(u_out), vptr(out),
+        ctypes.byref(n_new), ctypes.byref(first),
     )
     ctx.check(rc, "bms_transform_abd")
-    return u_out[: n_new.value].copy(), out[:, : n_new.value].copy()
+    res = (u_out[: n_new.value].copy(), out[:, : n_new.value].copy())
+    return res + (first.value,) if shard is not None else res
 
 
 # ---------------------------------------------------------------------------------- building blocks

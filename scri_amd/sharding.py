@@ -17,10 +17,11 @@ def shard_bounds(n_times, world_size, rank):
     return i0, i0 + base + (1 if rank < rem else 0)
 
 
-def exchange_halos(local, have, need, all_have, all_need, group=None):
+def exchange_halos(local, have, need, all_have, all_need, group=None, dim=0):
     """Return rows [need[0], need[1]) of the global array, given this rank's rows `local` = [have[0], have[1]).
 
-    local: torch tensor [rows, cols] float64/complex128 (CPU for gloo, GPU for nccl).
+    local: torch tensor [rows, cols] float64/complex128 (CPU for gloo, GPU for nccl); `dim` names the time axis
+    when it is not the first one (AsymptoticBondiData storage is [6, rows, modes]: dim=1).
     all_have / all_need: per-rank (start, stop) lists known to every rank (static plan, no communication).
     Rows outside every rank's range are never requested."""
     import torch
@@ -29,6 +30,8 @@ def exchange_halos(local, have, need, all_have, all_need, group=None):
     rank = dist.get_rank(group)
     world = dist.get_world_size(group)
     is_complex = local.is_complex()
+    if dim != 0:
+        local = local.movedim(dim, 0)
     loc = torch.view_as_real(local) if is_complex else local
     out_shape = (need[1] - need[0],) + tuple(loc.shape[1:])
     out = torch.empty(out_shape, dtype=loc.dtype, device=loc.device)
@@ -55,7 +58,8 @@ def exchange_halos(local, have, need, all_have, all_need, group=None):
             req.wait()
     for a, b, buf in recv_bufs:
         out[a - need[0] : b - need[0]] = buf
-    return torch.view_as_complex(out) if is_complex else out
+    out = torch.view_as_complex(out) if is_complex else out
+    return out.movedim(0, dim).contiguous() if dim != 0 else out
 
 
 def plan(t_global, transformation, world_size):

@@ -60,3 +60,68 @@ def test_chunked_workspace_equals_single_chunk():
     assert np.array_equal(t1, t2)
     assert np.abs(d1 - d2).max() < 1e-14 * max(1.0, np.abs(d1).max())
     big.close(), small.close()
+
+
+# ------------------------------------------------------------------------------------------------- ABD flavour (cfg5)
+def _abd_case(n=3000, ell_max=4):
+    from scri_amd import engine
+
+    rng = np.random.default_rng(77)
+    u = np.arange(n) * 0.1
+    nm = (ell_max + 1) ** 2
+    spins = (2, 1, 0, -1, -2, 2)
+    raw = np.zeros((6, n, nm), dtype=complex)
+    ph = 0.05 * u + 2e-5 * u**2
+    for f, s in enumerate(spins):
+        a = rng.normal(size=nm) + 1j * rng.normal(size=nm)
+        a[: s * s] = 0
+        m = np.concatenate([np.arange(-l, l + 1) for l in range(ell_max + 1)])
+        raw[f] = a[None, :] * np.exp(1j * m[None, :] * ph[:, None])
+    st = np.zeros(9, dtype=complex)
+    st[0], st[2], st[6] = 0.3, 0.05, 0.02  # real supertranslation (m = 0 components)
+    n_theta = 2 * (2 * ell_max + 2) + 1
+    tr = engine.make_transformation(st, [0.9, 0.1, -0.3, 0.2], [2e-3, -1e-3, 3e-3], n_theta, n_theta, ell_max)
+    return u, raw, tr, ell_max
+
+
+def test_abd_shards_reassemble_to_unsharded(ctx):
+    from scri_amd import engine, sharding
+
+    u, raw, tr, ell_max = _abd_case()
+    u_ref, r_ref = engine.transform_abd(u, raw, ell_max, tr, ctx=ctx)
+    for world in (2, 3):
+        have, need, window = sharding.plan(u, tr, world)
+        us, rs, firsts = [], [], []
+        for r in range(world):
+            ext = np.ascontiguousarray(raw[:, need[r][0] : need[r][1]])
+            uo, ro, first = engine.transform_abd(u, ext, ell_max, tr, ctx=ctx, shard=(need[r][0], ext.shape[1], have[r][0], have[r][1]))
+            us.append(uo), rs.append(ro), firsts.append(first)
+        assert firsts[0] == window[0]
+        assert np.array_equal(np.concatenate(us), u_ref)
+        assert np.abs(np.concatenate(rs, axis=1) - r_ref).max() < 1e-14 * max(1.0, np.abs(r_ref).max())
+
+
+def test_abd_shard_with_insufficient_halo_is_rejected(ctx):
+    from scri_amd import engine, sharding
+
+    u, raw, tr, ell_max = _abd_case()
+    have, need, _ = sharding.plan(u, tr, 2)
+    own = np.ascontiguousarray(raw[:, have[1][0] : have[1][1]])
+    with pytest.raises(ValueError, match="halo too small"):
+        engine.transform_abd(u, own, ell_max, tr, ctx=ctx, shard=(have[1][0], own.shape[1], have[1][0], have[1][1]))
+
+
+def test_abd_device_resident_equals_host(ctx):
+    import torch
+
+    from scri_amd import engine
+
+    u, raw, tr, ell_max = _abd_case(n=1200)
+    u_ref, r_ref = engine.transform_abd(u, raw, ell_max, tr, ctx=ctx)
+    d_in = torch.from_numpy(raw).cuda()
+    n_out = (ell_max + 1) ** 2
+    d_out = torch.zeros((6, u.size, n_out), dtype=torch.complex128, device="cuda")
+    torch.cuda.synchronize()
+    u_out, n_new = engine.transform_abd(u, d_in.data_ptr(), ell_max, tr, ctx=ctx, device=True, out_ptr=d_out.data_ptr())
+    assert n_new == u_ref.size and np.array_equal(u_out, u_ref)
+    assert np.array_equal(d_out[:, :n_new].cpu().numpy(), r_ref)

@@ -94,3 +94,76 @@ def test_two_rank_sharded_transform_equals_global(tmp_path):
     assert np.array_equal(idx, np.arange(window[0], window[1]))  # every output produced exactly once, in order
     assert np.abs(t_sh - ref.t).max() < 1e-13
     assert np.abs(d_sh - ref.data).max() < 1e-13 * max(1.0, np.abs(ref.data).max())
+
+
+# ------------------------------------------------------------------------------------------------- ABD flavour
+def _abd_inputs(n_times, ell_max):
+    from oracle.containers import ABD
+
+    rng = np.random.default_rng(21)
+    u = np.arange(n_times) * 0.1
+    nm = (ell_max + 1) ** 2
+    m = np.concatenate([np.arange(-l, l + 1) for l in range(ell_max + 1)])
+    raw = np.zeros((6, n_times, nm), dtype=complex)
+    ph = 0.05 * u + 2e-4 * u**2
+    for f, s in enumerate(ABD.spins):
+        a = rng.normal(size=nm) + 1j * rng.normal(size=nm)
+        a[: s * s] = 0
+        raw[f] = a[None, :] * np.exp(1j * m[None, :] * ph[:, None])
+    kw = dict(supertranslation=np.array([0.3, 0, 0.05, 0], dtype=complex), boost_velocity=np.array([2e-3, -1e-3, 3e-3]))
+    return u, raw, kw
+
+
+def _abd_worker(rank, world, port, n_times, ell_max, tmpdir):
+    import torch
+    import torch.distributed as dist
+
+    from oracle import abd_ref
+    from oracle.containers import ABD
+    from scri_amd import engine, sharding
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        u, raw, kw = _abd_inputs(n_times, ell_max)
+        n_theta = 2 * (2 * ell_max + 1) + 1
+        tr = engine.make_transformation(kw["supertranslation"], [1, 0, 0, 0], kw["boost_velocity"], n_theta, n_theta, ell_max)
+        have, need, window = sharding.plan(u, tr, world)
+        local = torch.from_numpy(np.ascontiguousarray(raw[:, have[rank][0] : have[rank][1]]))
+        ext = sharding.exchange_halos(local, have[rank], need[rank], have, need, dim=1)
+        assert ext.shape == (6, need[rank][1] - need[rank][0], raw.shape[2])
+        assert np.array_equal(ext.numpy(), raw[:, need[rank][0] : need[rank][1]])
+        # this shard's outputs from its rows + halo only (the oracle as the per-shard arithmetic)
+        sub = abd_ref.transform(ABD(u[need[rank][0] : need[rank][1]], ext.numpy(), ell_max), **kw)
+        tt = kw["supertranslation"][0].real / np.sqrt(4 * np.pi)
+        gamma = 1 / np.sqrt(1 - np.dot(kw["boost_velocity"], kw["boost_velocity"]))
+        uprm = (u - tt) / gamma
+        idx = np.searchsorted(uprm, sub.u - 1e-9)
+        assert np.abs(uprm[idx] - sub.u).max() < 1e-12
+        keep = (idx >= have[rank][0]) & (idx < have[rank][1])
+        np.savez(os.path.join(tmpdir, f"abd{rank}.npz"), idx=idx[keep], u=sub.u[keep], raw=sub.raw[:, keep], window=np.array(window))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_two_rank_sharded_abd_transform_equals_global(tmp_path):
+    import torch.multiprocessing as mp
+
+    from oracle import abd_ref
+    from oracle.containers import ABD
+
+    n_times, ell_max, world = 400, 2, 2
+    port = _free_port()
+    mp.spawn(_abd_worker, args=(world, port, n_times, ell_max, str(tmp_path)), nprocs=world, join=True)
+    parts = [np.load(tmp_path / f"abd{r}.npz") for r in range(world)]
+    u, raw, kw = _abd_inputs(n_times, ell_max)
+    ref = abd_ref.transform(ABD(u, raw, ell_max), **kw)
+    window = parts[0]["window"]
+    idx = np.concatenate([p["idx"] for p in parts])
+    assert ref.u.size == window[1] - window[0]
+    assert np.array_equal(idx, np.arange(window[0], window[1]))
+    assert np.abs(np.concatenate([p["u"] for p in parts]) - ref.u).max() < 1e-13
+    got = np.concatenate([p["raw"] for p in parts], axis=1)
+    assert np.abs(got - ref.raw).max() < 1e-12 * max(1.0, np.abs(ref.raw).max())
