@@ -21,6 +21,19 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 FP64_MATRIX_PEAK_TFLOPS = 78.6  # MI355X fp64 matrix (= vector) peak, AMD public spec
+# HBM traffic of the dominant kernel comes from separate rocprofv3 --pmc passes of this same command
+# (tools/run_profiles.sh -> tools/pmc_summary.py; 2 x FETCH_SIZE + WRITE_SIZE as MI355X_MICROARCH.md prescribes for
+# gfx950); the committed summary is read back here so the bench line carries it.
+PMC_SUMMARY = os.path.join(ROOT, "profiles", "r01_d_pmc_cfg3.json")
+DOMINANT_KERNEL = "bms::zgemm3m_mfma_kernel"
+
+
+def pmc_traffic(workload, world, per_gpu):
+    """HBM bytes per launch of the dominant kernel from the committed PMC summary (cfg3, 1 GPU, 1e5 steps only)."""
+    if workload != "cfg3" or world != 1 or per_gpu != 100_000 or not os.path.exists(PMC_SUMMARY):
+        return None
+    with open(PMC_SUMMARY) as f:
+        return json.load(f).get(DOMINANT_KERNEL, {}).get("traffic_bytes")
 
 
 def cpu_baseline(spec, n_sample):
@@ -51,9 +64,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="cfg3", choices=["cfg2", "cfg3"])
-    ap.add_argument("--n-times", type=int, default=None, help="time steps PER GPU (default: the workload's 1e5)")
-    ap.add_argument("--cpu-sample", type=int, default=4000, help="time steps of the CPU-baseline sample (0: skip)")
+    ap.add_argument("--workload", default="cfg3", choices=["cfg2", "cfg3", "cfg5"])
+    ap.add_argument("--n-times", type=int, default=None, help="time steps PER GPU (default: 1e5; cfg5: 2e5 / 8)")
+    ap.add_argument("--working-ell-max", type=int, default=None, help="cfg5 only (default 2 ell_max + 1 = 49 -> 99 x 99 grid)")
+    ap.add_argument("--cpu-sample", type=int, default=30000, help="time steps of the CPU-baseline sample (0: skip)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -80,33 +94,48 @@ def main():
 
     spec = dict(synthetic.CONFIGS[args.workload])
     spec["name"] = args.workload
-    per_gpu = int(args.n_times or spec["n_times"])
+    abd = args.workload == "cfg5"
+    per_gpu = int(args.n_times or (spec["n_times"] // 8 if abd else spec["n_times"]))
     n_global = per_gpu * world
     kw = spec["kwargs"]
     ell_max = spec["ell_max"]
     lst = int(round(np.sqrt(len(kw["supertranslation"])))) - 1
-    n_theta = 2 * (ell_max + lst) + 1
+    if abd:
+        n_theta = 2 * int(args.working_ell_max or 2 * ell_max + 1) + 1
+        n_modes = (ell_max + 1) ** 2
+    else:
+        n_theta = 2 * (ell_max + lst) + 1
+        n_modes = (ell_max + 1) ** 2 - 4
     tr = engine.make_transformation(
         kw["supertranslation"], kw.get("frame_rotation", [1, 0, 0, 0]), kw.get("boost_velocity", [0, 0, 0]), n_theta, n_theta, ell_max
     )
-    n_modes = (ell_max + 1) ** 2 - 4
     n_pix = n_theta * n_theta
+    n_fields = 6 if abd else 1
 
     # this rank's rows of the global series, resident in HBM before the timed region
     have, need, window = sharding.plan(np.arange(n_global) * spec["dt"], tr, world)
-    t_global, local_host, _ = synthetic.workload(args.workload, n_times=n_global, rows=have[rank])
+    own = have[rank][1] - have[rank][0]
+    if abd:
+        t_global, local_host, _ = synthetic.abd_workload(args.workload, n_times=n_global, rows=have[rank])
+        out = torch.empty((6, own, n_modes), dtype=torch.complex128, device=dev)
+    else:
+        t_global, local_host, _ = synthetic.workload(args.workload, n_times=n_global, rows=have[rank])
+        out = torch.empty((own, n_modes), dtype=torch.complex128, device=dev)
     local = torch.from_numpy(local_host).to(dev)
-    out = torch.empty((have[rank][1] - have[rank][0], n_modes), dtype=torch.complex128, device=dev)
+    del local_host
     ctx = _lib.Context(local_rank)
     ctx.enable_timing(True)
 
     def step():
         if world > 1:
-            ext = sharding.exchange_halos(local, have[rank], need[rank], have, need)
+            ext = sharding.exchange_halos(local, have[rank], need[rank], have, need, dim=1 if abd else 0)
             torch.cuda.synchronize()
         else:
             ext = local
         row0 = need[rank][0] if world > 1 else 0
+        if abd:
+            shard = (row0, ext.shape[1], have[rank][0], have[rank][1])
+            return engine.transform_abd(t_global, ext.data_ptr(), ell_max, tr, ctx=ctx, shard=shard, device=True, out_ptr=out.data_ptr())[1]
         t_out, n_new, first = engine.transform_modes(
             t_global, ext.data_ptr(), 2, ell_max, -2, -1, engine.BMS_TERM_H, tr, ctx=ctx, device=True, ld=n_modes,
             out_ptr=out.data_ptr(), shard=(row0, ext.shape[0], have[rank][0], have[rank][1]),
@@ -143,11 +172,18 @@ def main():
         # 8 * n_modes * n_pix per time row x rows per launch / HIP-event duration per launch
         rows_in = (need[0][1] - need[0][0]) if world > 1 else n_global
         g_ms, g_calls = timing["gemm_synthesis"]
-        flops_per_launch = 8.0 * n_modes * n_pix * rows_in
+        # (cfg5: the work space is walked in chunks, 6 launches each; per-launch figures are averages over them and
+        # ignore the few halo rows that neighbouring chunks both synthesise)
+        launches_per_step = max(g_calls, 1) / args.steps
+        flops_per_launch = 8.0 * n_modes * n_pix * rows_in * n_fields / launches_per_step
         achieved = flops_per_launch / (g_ms / max(g_calls, 1) * 1e-3) / 1e12 if g_ms > 0 else None
         kernels = {k: {"ms_per_step": v[0] / args.steps, "launches_per_step": v[1] / args.steps} for k, v in timing.items() if v[1]}
         line = {
-            "metric": "timesteps/sec for full BMS transform, l_max=16, 1e5 steps; fp64" if args.workload == "cfg3" else "timesteps/sec for BMS transform (cfg2)",
+            "metric": {
+                "cfg3": "timesteps/sec for full BMS transform, l_max=16, 1e5 steps; fp64",
+                "cfg2": "timesteps/sec for BMS transform (cfg2)",
+                "cfg5": "timesteps/sec for AsymptoticBondiData BMS transform (cfg5: psi0..psi4 + sigma, l_max=24)",
+            }[args.workload],
             "value": value,
             "unit": "timesteps/s",
             "n_gpus": world,
@@ -160,9 +196,12 @@ def main():
             "dtype": "f64",
             "data": "synthetic",
             "config": {
-                "workload": f"{args.workload}: WaveformModes h, ell 2..{ell_max} ({n_modes} modes), {per_gpu} time steps per GPU "
-                f"({n_global} total), supertranslation(l<=2) + frame_rotation + boost |v|=3.7e-4, {n_theta}x{n_theta} grid, "
-                f"{n_out} output steps on rank 0",
+                "workload": (
+                    f"{args.workload}: AsymptoticBondiData psi0..psi4 + sigma, ell 0..{ell_max} (6 x {n_modes} modes), " if abd
+                    else f"{args.workload}: WaveformModes h, ell 2..{ell_max} ({n_modes} modes), "
+                )
+                + f"{per_gpu} time steps per GPU ({n_global} total), supertranslation(l<=2) + frame_rotation + boost |v|=3.7e-4, "
+                f"{n_theta}x{n_theta} grid, {n_out} output steps on rank 0",
                 "sharding": f"time axis x{world}, RCCL point-to-point halo exchange of input modes" if world > 1 else "none",
             },
             "roofline": {
@@ -172,7 +211,8 @@ def main():
                 "peak": FP64_MATRIX_PEAK_TFLOPS,
                 "unit": "TFLOP/s",
                 "frac": (achieved / FP64_MATRIX_PEAK_TFLOPS) if achieved else None,
-                "traffic": None,
+                "traffic": pmc_traffic(args.workload, world, per_gpu),
+                "traffic_unit": "bytes of HBM per launch (profiles/r01_d_pmc_cfg3.json)",
                 "flops_per_launch": flops_per_launch,
                 "ms_per_launch": g_ms / max(g_calls, 1),
                 # the kernel forms each complex product from 3 real MFMA products (not 4): flops it actually executes
@@ -180,7 +220,7 @@ def main():
             },
             "kernels": kernels,
         }
-        if world == 1 and args.cpu_sample > 0:
+        if world == 1 and args.cpu_sample > 0 and not abd:
             line["cpu_baseline"] = cpu_baseline(spec, args.cpu_sample)
         print(json.dumps(line))
     if world > 1:

@@ -41,7 +41,31 @@ CONFIGS = {
         ell_max=16, n_times=1_000_000, dt=0.1, seed=6,
         kwargs=dict(supertranslation=S9, frame_rotation=np.array([1.0, 2, 3, 4]) / np.sqrt(30), boost_velocity=np.array([1.0, 2, 3]) * 1e-4),
     ),
+    # AsymptoticBondiData, psi0..psi4 + sigma; the grid follows working_ell_max (default 2 ell_max + 1 -> 99 x 99)
+    "cfg5": dict(
+        ell_max=24, n_times=200_000, dt=0.1, seed=7,
+        kwargs=dict(supertranslation=S9, frame_rotation=np.array([1.0, 2, 3, 4]) / np.sqrt(30), boost_velocity=np.array([1.0, 2, 3]) * 1e-4),
+    ),
 }
+
+ABD_SPINS = (2, 1, 0, -1, -2, 2)
+
+
+def abd_workload(name="cfg5", n_times=None, rows=None, ell_max=None):
+    """(u_global, raw[6, rows, (ell_max+1)^2], spec): every field as `chirp_modes` (its own seed), zeros below |s|."""
+    spec = dict(CONFIGS[name])
+    n = int(n_times or spec["n_times"])
+    spec["n_times"] = n
+    if ell_max is not None:
+        spec["ell_max"] = int(ell_max)
+    u = np.arange(n) * spec["dt"]
+    r0, r1 = rows if rows is not None else (0, n)
+    nm = (spec["ell_max"] + 1) ** 2
+    raw = np.zeros((6, r1 - r0, nm), dtype=complex)
+    for f, s in enumerate(ABD_SPINS):
+        raw[f] = chirp_modes(u[r0:r1], 0, spec["ell_max"], spec["seed"] + 10 * f)
+        raw[f, :, : s * s] = 0
+    return u, raw, spec
 
 
 def workload(name, n_times=None, rows=None):
