@@ -650,12 +650,11 @@ static int build_analysis(bms_ctx* c, const char* tag, int n_theta, int n_phi, i
   A.fused = A.separable && fused_analysis_supported(n_theta, n_phi, A.L, A.n_out) && !getenv("SCRI_AMD_NO_FUSED_ANALYSIS");
   if (A.separable) {
     if (A.fused) {
-      int ks, pd;
-      fused_pitches(n_theta, n_phi, A.L, &ks, &pd);
+      const size_t nd = fused_dft_table_size(n_phi, A.L);
       snprintf(nm_, sizeof nm_, "dcs_%d_%d", n_phi, A.L);
-      if ((rc = dev_buf_t(c, nm_, (size_t)4 * ks * pd, &A.d_dcs))) return rc;
-      HIP_TRY(c, hipMemsetAsync(A.d_dcs, 0, sizeof(double) * 4 * ks * pd, S));
-      TIMED(c, BMS_TAG_SETUP, launch_dft_cs_matrix(S, n_phi, A.L, A.d_dcs, pd));
+      if ((rc = dev_buf_t(c, nm_, nd, &A.d_dcs))) return rc;
+      HIP_TRY(c, hipMemsetAsync(A.d_dcs, 0, sizeof(double) * nd, S));
+      TIMED(c, BMS_TAG_SETUP, launch_dft_cs_matrix(S, n_phi, A.L, A.d_dcs));
     } else {
       // phi-DFT matrix [2 n_phi -> 16] x [2 (2L+1) -> 128]
       A.ld_dft = round_up(2LL * A.nm, 128);

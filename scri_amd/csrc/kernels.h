@@ -50,8 +50,8 @@ constexpr int MAX_THETA_SEPARABLE = 104;
 // fused single-kernel analysis (n_theta <= 40, n_out <= 1024): D = cos|sin DFT matrix [4 ks][pd] from launch_dft_cs_matrix
 struct FusedGeom;
 int fused_analysis_supported(int n_theta, int n_phi, int L, int n_out);
-void fused_pitches(int n_theta, int n_phi, int L, int* ks, int* pd);
-hipError_t launch_dft_cs_matrix(hipStream_t stream, int n_phi, int L, double* D, int pd);
+size_t fused_dft_table_size(int n_phi, int L);  // doubles
+hipError_t launch_dft_cs_matrix(hipStream_t stream, int n_phi, int L, double* D);
 hipError_t launch_analysis_fused(hipStream_t stream, const double* G, long long ldg, long long n_rows, int n_theta, int n_phi,
                                  int L, int n_out, const int* m_index, const double* T, const double* D, double* out,
                                  long long ldo);

@@ -8,6 +8,7 @@
 // theta_quadrature_kernel below.  Compared with the dense quadrature GEMM this is ~10x less arithmetic and sums
 // n_phi and n_theta terms per output instead of 2 n_pix (shorter fp64 chains => smaller rounding error).
 #include "wigner.h"
+#include <cstdlib>
 #include "kernels.h"
 
 namespace bms {
@@ -123,181 +124,267 @@ hipError_t launch_theta_quadrature(hipStream_t stream, const double* F, long lon
 // =====================================================================================================================
 // Fused analysis: one workgroup per time step, the grid row never leaves the chip between the two steps.
 //
-//   step 1 (MFMA):  the phi-DFT with the cos/sin split.  The grid is de-interleaved into real rows (2j = Re ring j,
-//                   2j+1 = Im ring j; A operand [2 n_theta x n_phi]) and multiplied by the real matrix
-//                   D[k][m] = cos(m phi_k) (m = 0..L), D[k][L+m] = sin(m phi_k) (m = 1..L)  ([n_phi x (2L+1)]):
-//                   C_m[r] = sum_k G[r][k] cos(m phi_k),  S_m[r] = sum_k G[r][k] sin(m phi_k).
-//                   Both signs of m come from one product:  F_{+-m}(j) = (C[2j] +- S[2j+1]) + i (C[2j+1] -+ S[2j]).
-//                   This is 2.7x less MFMA work than the interleaved complex form (no 66 -> 128 column padding, real
-//                   twiddles) and sums n_phi terms per output.
-//   step 2 (VALU):  a_o = sum_j T[o][j] F_{m(o)}(j) with the T row of thread o in registers (as theta_quadrature_kernel).
+//   step 0 (fold):  the ring samples are folded about phi = 0:  e_k = x_k + x_{n-k},  o_k = x_k - x_{n-k}  (k = 1..n/2;
+//                   e_0 = x_0, o_0 = 0; the Nyquist sample of an even ring is its own partner), because
+//                   C_m = sum_k x_k cos(m phi_k) = sum_{k <= n/2} e_k cos(m phi_k),  S_m = sum_k x_k sin(m phi_k) =
+//                   sum_{k <= n/2} o_k sin(m phi_k):  half the terms.  Real and imaginary parts are separate real rows.
+//   step 1 (MFMA):  C = E . cos, S = O . sin for m = 1..L as two real products [2 n_theta x n/2+1] x [n/2+1 x L]
+//                   (L = 16: exactly one 16-column tile each; 2.9x fewer MFMAs than the unfolded cos|sin form, 8x
+//                   fewer than the interleaved complex form).  The operand rows are ordered so that the four results
+//                   a lane holds are (Re, Im) of two rings, and both signs of m come out of registers:
+//                   F_{+-m}(j) = (C_re +- S_im) + i (C_im -+ S_re).   m = 0 is a plain sum of e_k.
+//   step 2 (VALU):  a_o = sum_j T[o][j] F_{m(o)}(j): one thread per output mode, its T row in registers, F read as
+//                   16-byte (re, im) pairs.
 // HBM traffic = the algorithmic minimum: read the grid row once (16 n_pix B), write the modes once (16 n_out B).
 // =====================================================================================================================
 typedef double v4d_t __attribute__((ext_vector_type(4)));
 
-// D[k][c]: c in [0, L] -> cos(c phi_k); c in [L+1, 2L] -> sin((c-L) phi_k); zero padded to [kpad][pd]
-__global__ __launch_bounds__(256) void dft_cs_matrix_kernel(int n_phi, int L, double* __restrict__ D, int pd) {
-  const int id = blockIdx.x * blockDim.x + threadIdx.x;
-  const int nc = 2 * L + 1;
-  if (id >= n_phi * nc) return;
-  const int k = id / nc, c = id % nc;
-  const int m = c <= L ? c : c - L;
-  const long long r = ((long long)m * k) % n_phi;
-  double s, co;
-  sincospi(2.0 * (double)r / (double)n_phi, &s, &co);
-  D[(long long)k * pd + c] = c <= L ? co : s;
-}
+constexpr int F_PA = 26;    // LDS pitch (doubles) of the folded operand rows: 2 x odd >= 24 -> conflict-free fragment reads
+constexpr int F_KSMAX = 6;  // k-steps of 4 along the folded ring: n_phi / 2 + 1 <= 24 (kernels are built for 3, 5 and 6)
+constexpr int F_EPT = 4;    // (ring, sample pair) items per thread: n_theta (n_phi/2 + 1) <= 40 x 21 <= 4 x 256 threads
 
 struct FusedGeom {
   int n_theta, n_phi, L, n_out;
-  int mt, ks;  // 16-row tiles along the 2 n_theta rows; k-steps of 4 along n_phi
-  int pd;      // LDS pitch (doubles) of the DFT matrix rows
+  int mt;  // 16-row operand tiles (8 rings x {re, im} each)
+  int nk;  // folded ring length n_phi / 2 + 1
+  int ks;  // k-steps of 4 covering nk, rounded up to a built kernel: 3, 5 or 6 (tables are zero padded to it)
+  int n_sec;  // output modes beyond one per thread (<= 64): handled by the first threads with their T rows in LDS
 };
 
-// NT: max n_theta (T row length held in registers); PA: LDS pitch of the A rows (2 x odd, >= 4 ks);
-// NTN: 16-column tiles of the 2L+1 cos|sin columns; EPT: grid pixels per thread.
-template <int NT, int PA, int NTN, int EPT>
-__global__ __launch_bounds__(512) void analysis_fused_kernel(const double* __restrict__ G, long long ldg, long long n_rows,
-                                                             FusedGeom g, const int* __restrict__ m_index,
-                                                             const double* __restrict__ T, const double* __restrict__ Dg,
-                                                             double* __restrict__ out, long long ldo) {
-  constexpr int PC = 16 * NTN + 2;  // LDS pitch of the C|S rows: compile-time so that step-2 reads use immediate offsets
+__host__ __device__ inline int fused_pd(int L) { return L <= 16 ? 16 : 48; }  // = 16 mod 32: B fragment halves on different banks
+
+// Dc[k][c] = cos((c+1) phi_k), Ds[k][c] = sin((c+1) phi_k) for k < n_phi/2 + 1, c < L; both [4 ks][pd], zero padded
+__global__ __launch_bounds__(256) void dft_cs_matrix_kernel(int n_phi, int L, int ks, int pd, double* __restrict__ D) {
+  const int id = blockIdx.x * blockDim.x + threadIdx.x;
+  const int nk = n_phi / 2 + 1;
+  if (id >= nk * L) return;
+  const int k = id / L, c = id % L;
+  const long long r = ((long long)(c + 1) * k) % n_phi;
+  double sn, co;
+  sincospi(2.0 * (double)r / (double)n_phi, &sn, &co);
+  D[(long long)k * pd + c] = co;
+  D[(long long)(4 * ks + k) * pd + c] = sn;
+}
+
+// operand row of ring j, real part (imaginary part: + 4): rows g + 4 r of a 16-row MFMA tile sit in the lanes with
+// lane >> 4 = g, so (re, im) of rings g and g + 4 of the tile are the four results one lane holds
+__device__ __forceinline__ int fused_row(int j) { return (j >> 3) * 16 + (j & 3) + 8 * ((j >> 2) & 1); }
+
+// NT: max n_theta (T row length held in registers); NTC: 16-column tiles covering m = 1..L; KS: k-steps.
+// Everything inside the row loop is branch-free on purpose (zero padding instead of bounds tests): a uniform branch
+// around an LDS read makes the compiler wait for each read before issuing the next.
+template <int NT, int NTC, int KS>
+__device__ __forceinline__ void analysis_fused_body(const double* __restrict__ G, long long ldg, long long n_rows,
+                                                    const FusedGeom& g, const int* __restrict__ m_index,
+                                                    const double* __restrict__ T, const double* __restrict__ Dg,
+                                                    double* __restrict__ out, long long ldo) {
+  constexpr int PD = NTC == 1 ? 16 : 48;
+  constexpr int PJ = NT + 1;  // odd pitch (complex) of an F_m row: consecutive m on distinct 16-byte slots
   extern __shared__ double lds[];
-  double* Gs = lds;                    // [16 mt][PA]
-  double* Cs = Gs + 16 * g.mt * PA;    // [16 mt][PC]
-  double* Ds = Cs + 16 * g.mt * PC;    // [4 ks][pd]
+  double* Es = lds;                       // [16 mt][F_PA]
+  double* Os = Es + 16 * g.mt * F_PA;     // [16 mt][F_PA]
+  double* Dc = Os + 16 * g.mt * F_PA;     // [4 ks][PD]
+  double* Dn = Dc + 4 * g.ks * PD;        // [4 ks][PD]
+  double2* Fs = reinterpret_cast<double2*>(Dn + 4 * g.ks * PD);  // [2L+1][PJ]
+  double* T2 = reinterpret_cast<double*>(Fs + (2 * g.L + 1) * PJ);  // [n_sec][PJ]
   const int tid = threadIdx.x, nthreads = blockDim.x;
   const int wave = tid >> 6, lane = tid & 63, nwaves = nthreads >> 6;
-  const int n_pix = g.n_theta * g.n_phi;
+  const int fi = lane & 15, fk = lane >> 4;
 
-  // one-time set-up: zero the A operand (its padding stays zero), copy the DFT matrix, T row to registers
-  for (int e = tid; e < 16 * g.mt * PA; e += nthreads) Gs[e] = 0.0;
-  for (int e = tid; e < 4 * g.ks * g.pd; e += nthreads) Ds[e] = Dg[e];
+  // one-time set-up: zero the operands (their padding stays zero), copy the DFT matrices, T row to registers
+  for (int e = tid; e < 2 * 16 * g.mt * F_PA; e += nthreads) Es[e] = 0.0;
+  for (int e = tid; e < 2 * 4 * g.ks * PD; e += nthreads) Dc[e] = Dg[e];
+  for (int e = tid; e < (2 * g.L + 1) * PJ; e += nthreads) Fs[e] = double2{0.0, 0.0};
   const int o = tid;
   const bool live = o < g.n_out;
   double tj[NT];
 #pragma unroll
   for (int j = 0; j < NT; ++j) tj[j] = (live && j < g.n_theta) ? T[(long long)o * g.n_theta + j] : 0.0;
-  const int m = live ? m_index[o] - g.L : 0;
-  const int am = m < 0 ? -m : m;
-  const double s_on = m == 0 ? 0.0 : (m < 0 ? -1.0 : 1.0);
-  const double* rc = Cs + am;          // C_|m| column
-  const double* rs = Cs + g.L + am;    // S_|m| column (multiplied by 0 for m = 0)
+  const double2* fp = Fs + (live ? m_index[o] : 0) * PJ;
+  // a second output mode for the first n_sec threads (keeps the workgroup at 4 waves = one per SIMD, so that two
+  // workgroups share a CU and one's MFMA step runs under the other's loads and quadrature)
+  const bool sec = tid < g.n_sec;
+  const int o2 = nthreads + tid;
+  for (int e = tid; e < g.n_sec * PJ; e += nthreads) {
+    const int r = e / PJ, j = e - r * PJ;
+    T2[e] = j < g.n_theta ? T[(long long)(nthreads + r) * g.n_theta + j] : 0.0;
+  }
+  const double2* fp2 = Fs + (sec ? m_index[o2] : 0) * PJ;
+  const double* t2 = T2 + (sec ? tid : 0) * PJ;
 
-  // LDS slots of this thread's pixels in the de-interleaved A operand, and the prefetch registers
-  int slot[EPT];
-  double2 pre[EPT];
+  // this thread's (ring, sample pair) items: global offsets of the two samples, LDS slot of the folded pair.
+  // A sample that is its own partner (k = 0, Nyquist) is loaded twice and its partner weighted by 0.
+  int slot[F_EPT], off1[F_EPT], off2[F_EPT];
+  double wb[F_EPT];
+  double2 pa[F_EPT], pb[F_EPT];
 #pragma unroll
-  for (int q = 0; q < EPT; ++q) {
+  for (int q = 0; q < F_EPT; ++q) {
     const int e = tid + q * nthreads;
-    const int j = e / g.n_phi, k = e - j * g.n_phi;
-    slot[q] = e < n_pix ? (2 * j) * PA + k : -1;
+    const bool ok = e < g.n_theta * g.nk;
+    const int j = ok ? e / g.nk : 0, kk = ok ? e - j * g.nk : 0;
+    const int k2 = kk == 0 ? 0 : g.n_phi - kk;
+    slot[q] = ok ? fused_row(j) * F_PA + kk : -1;
+    off1[q] = 2 * (j * g.n_phi + kk);
+    off2[q] = 2 * (j * g.n_phi + k2);
+    wb[q] = k2 == kk ? 0.0 : 1.0;
   }
-  long long t = blockIdx.x;
-  if (t < n_rows) {
+  auto fetch = [&](long long t) {
 #pragma unroll
-    for (int q = 0; q < EPT; ++q)
-      if (slot[q] >= 0) pre[q] = *reinterpret_cast<const double2*>(G + t * ldg + 2LL * (tid + q * nthreads));
-  }
+    for (int q = 0; q < F_EPT; ++q) {
+      pa[q] = *reinterpret_cast<const double2*>(G + t * ldg + off1[q]);
+      pb[q] = *reinterpret_cast<const double2*>(G + t * ldg + off2[q]);
+    }
+  };
+  long long t = blockIdx.x;
+  if (t < n_rows) fetch(t);
   __syncthreads();
   for (; t < n_rows; t += gridDim.x) {
-    // ---- de-interleave the row into the A operand (row 2j = Re, row 2j+1 = Im of ring j)
+    // ---- step 0: fold into the operands
 #pragma unroll
-    for (int q = 0; q < EPT; ++q)
+    for (int q = 0; q < F_EPT; ++q) {
+      const double bx = wb[q] * pb[q].x, by = wb[q] * pb[q].y;
       if (slot[q] >= 0) {
-        Gs[slot[q]] = pre[q].x;
-        Gs[slot[q] + PA] = pre[q].y;
+        Es[slot[q]] = pa[q].x + bx;
+        Es[slot[q] + 4 * F_PA] = pa[q].y + by;
+        Os[slot[q]] = wb[q] * pa[q].x - bx;
+        Os[slot[q] + 4 * F_PA] = wb[q] * pa[q].y - by;
       }
-    __syncthreads();  // A operand complete; every thread has finished step 2 of the previous row
+    }
+    __syncthreads();  // operands complete; every thread has finished step 2 of the previous row
     const long long tn = t + gridDim.x;
-    if (tn < n_rows) {
-#pragma unroll
-      for (int q = 0; q < EPT; ++q)
-        if (slot[q] >= 0) pre[q] = *reinterpret_cast<const double2*>(G + tn * ldg + 2LL * (tid + q * nthreads));
-    }
-    // ---- step 1: one 16-row tile x all NTN column tiles per wave trip: one A fragment feeds NTN independent MFMA chains
+    if (tn < n_rows) fetch(tn);
+    // ---- step 1: one 16-row tile (8 rings) per wave trip
     for (int tm = wave; tm < g.mt; tm += nwaves) {
-      const double* ap = Gs + (tm * 16 + (lane & 15)) * PA + (lane >> 4);
-      const double* bp = Ds + (lane >> 4) * g.pd + (lane & 15);
-      v4d_t acc[NTN];
+      const double* ep = Es + (tm * 16 + fi) * F_PA + fk;
+      const double* op = Os + (tm * 16 + fi) * F_PA + fk;
+      const double* cp = Dc + fk * PD + fi;
+      const double* sp = Dn + fk * PD + fi;
+      v4d_t ac[NTC], as[NTC];
 #pragma unroll
-      for (int n = 0; n < NTN; ++n) acc[n] = v4d_t{0.0, 0.0, 0.0, 0.0};
-#pragma unroll 2
-      for (int s = 0; s < g.ks; ++s) {
-        const double a = ap[4 * s];
+      for (int n = 0; n < NTC; ++n) ac[n] = as[n] = v4d_t{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-        for (int n = 0; n < NTN; ++n) acc[n] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bp[4 * s * g.pd + 16 * n], acc[n], 0, 0, 0);
-      }
-      double* cp = Cs + (tm * 16 + (lane >> 4)) * PC + (lane & 15);
+      for (int s = 0; s < KS; ++s) {
+        const double ae = ep[4 * s], ao = op[4 * s];
 #pragma unroll
-      for (int n = 0; n < NTN; ++n)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) cp[4 * r * PC + 16 * n] = acc[n][r];
-    }
-    __syncthreads();  // C|S complete
-    // ---- step 2: theta quadrature; F_{+-m}(j) = (C[2j] +- S[2j+1]) + i (C[2j+1] -+ S[2j])
-    if (live) {
-      double p1 = 0.0, p2 = 0.0, p3 = 0.0, p4 = 0.0;
-#pragma unroll
-      for (int j = 0; j < NT; ++j) {
-        if (j < g.n_theta) {
-          p1 = fma(tj[j], rc[2 * j * PC], p1);       // T C[Re]
-          p3 = fma(tj[j], rc[(2 * j + 1) * PC], p3);  // T C[Im]
-          p4 = fma(tj[j], rs[2 * j * PC], p4);       // T S[Re]
-          p2 = fma(tj[j], rs[(2 * j + 1) * PC], p2);  // T S[Im]
+        for (int n = 0; n < NTC; ++n) {
+          ac[n] = __builtin_amdgcn_mfma_f64_16x16x4f64(ae, cp[4 * s * PD + 16 * n], ac[n], 0, 0, 0);
+          as[n] = __builtin_amdgcn_mfma_f64_16x16x4f64(ao, sp[4 * s * PD + 16 * n], as[n], 0, 0, 0);
         }
       }
-      *reinterpret_cast<double2*>(out + t * ldo + 2LL * o) = double2{p1 + s_on * p2, p3 - s_on * p4};
+      // m = 0: plain sums of the folded rows (16 lanes, one operand row each)
+      if (fk == 0) {
+        const double* rp = Es + (tm * 16 + fi) * F_PA;
+        double c0 = 0.0, c1 = 0.0;
+#pragma unroll
+        for (int k = 0; k < 4 * KS; k += 2) {
+          c0 += rp[k];
+          c1 += rp[k + 1];
+        }
+        const int ring = tm * 8 + (fi & 3) + 4 * (fi >> 3), part = (fi >> 2) & 1;
+        reinterpret_cast<double*>(Fs + g.L * PJ + ring)[part] = c0 + c1;
+      }
+      // both signs of m from registers: results r = 2h (re), 2h+1 (im) of ring 8 tm + fk + 4h, column m = 16 n + fi + 1
+#pragma unroll
+      for (int n = 0; n < NTC; ++n) {
+        const int m = 16 * n + fi + 1;
+        if (m <= g.L) {
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            const int ring = tm * 8 + fk + 4 * h;
+            const double cre = ac[n][2 * h], cim = ac[n][2 * h + 1], sre = as[n][2 * h], sim = as[n][2 * h + 1];
+            Fs[(g.L + m) * PJ + ring] = double2{cre + sim, cim - sre};
+            Fs[(g.L - m) * PJ + ring] = double2{cre - sim, cim + sre};
+          }
+        }
+      }
+    }
+    __syncthreads();  // F complete
+    // ---- step 2: theta quadrature
+    if (live) {
+      // rings beyond n_theta carry zero weights and zero F: no bounds tests
+      double pr0 = 0.0, pi0 = 0.0, pr1 = 0.0, pi1 = 0.0;
+#pragma unroll
+      for (int j = 0; j + 1 < NT; j += 2) {
+        const double2 v0 = fp[j], v1 = fp[j + 1];
+        pr0 = fma(tj[j], v0.x, pr0);
+        pi0 = fma(tj[j], v0.y, pi0);
+        pr1 = fma(tj[j + 1], v1.x, pr1);
+        pi1 = fma(tj[j + 1], v1.y, pi1);
+      }
+      *reinterpret_cast<double2*>(out + t * ldo + 2LL * o) = double2{pr0 + pr1, pi0 + pi1};
+    }
+    if (sec) {
+      double pr0 = 0.0, pi0 = 0.0, pr1 = 0.0, pi1 = 0.0;
+#pragma unroll
+      for (int j = 0; j + 1 < NT; j += 2) {
+        const double2 v0 = fp2[j], v1 = fp2[j + 1];
+        const double w0 = t2[j], w1 = t2[j + 1];
+        pr0 = fma(w0, v0.x, pr0);
+        pi0 = fma(w0, v0.y, pi0);
+        pr1 = fma(w1, v1.x, pr1);
+        pi1 = fma(w1, v1.y, pi1);
+      }
+      *reinterpret_cast<double2*>(out + t * ldo + 2LL * o2) = double2{pr0 + pr1, pi0 + pi1};
     }
   }
 }
 
-static void fused_geometry(int n_theta, int n_phi, int L, int n_out, FusedGeom& g, int& pa, int& ntn, size_t& lds_bytes) {
+template <int NT, int KS>
+__global__ __launch_bounds__(512) void analysis_fused_kernel(
+    const double* __restrict__ G, long long ldg, long long n_rows, FusedGeom g, const int* __restrict__ m_index,
+    const double* __restrict__ T, const double* __restrict__ Dg, double* __restrict__ out, long long ldo) {
+  analysis_fused_body<NT, 1, KS>(G, ldg, n_rows, g, m_index, T, Dg, out, ldo);
+}
+// 16 < L <= 32: two column tiles per product
+template <int NT, int KS>
+__global__ __launch_bounds__(512) void analysis_fused_wide_kernel(
+    const double* __restrict__ G, long long ldg, long long n_rows, FusedGeom g, const int* __restrict__ m_index,
+    const double* __restrict__ T, const double* __restrict__ Dg, double* __restrict__ out, long long ldo) {
+  analysis_fused_body<NT, 2, KS>(G, ldg, n_rows, g, m_index, T, Dg, out, ldo);
+}
+
+static int fused_ks(int n_phi) {
+  const int ks = (n_phi / 2 + 1 + 3) / 4;
+  return ks <= 3 ? 3 : ks <= 5 ? 5 : 6;
+}
+
+static void fused_geometry(int n_theta, int n_phi, int L, int n_out, FusedGeom& g, size_t& lds_bytes, int& pj) {
   g.n_theta = n_theta;
   g.n_phi = n_phi;
   g.L = L;
   g.n_out = n_out;
-  g.mt = (2 * n_theta + 15) / 16;
-  g.ks = (n_phi + 3) / 4;
-  ntn = (2 * L + 1 + 15) / 16;
-  pa = n_phi <= 24 ? 26 : 42;  // 2 x odd: conflict-free ds_read_b64 of the A fragment
-  int pd = 16 * ntn;
-  while ((pd & 31) != 16) ++pd;  // = 16 mod 32: the two 16-lane halves of a B fragment read hit different banks
-  g.pd = pd;
-  const int pc = 16 * ntn + 2;
-  lds_bytes = sizeof(double) * ((size_t)16 * g.mt * pa + (size_t)16 * g.mt * pc + (size_t)4 * g.ks * g.pd);
+  g.mt = (n_theta + 7) / 8;
+  g.nk = n_phi / 2 + 1;
+  g.ks = fused_ks(n_phi);
+  g.n_sec = (n_out > 256 && n_out <= 320) ? n_out - 256 : 0;
+  pj = (n_theta <= 24 ? 24 : 40) + 1;
+  lds_bytes = sizeof(double) * ((size_t)2 * 16 * g.mt * F_PA + (size_t)2 * 4 * g.ks * fused_pd(L) + (size_t)2 * (2 * L + 1) * pj + (size_t)g.n_sec * pj);
 }
 
 int fused_analysis_supported(int n_theta, int n_phi, int L, int n_out) {
-  if (n_theta > 40 || n_phi > 40 || n_out > 512 || 2 * L + 1 > 64) return 0;
-  if ((long long)n_theta * n_phi > 4LL * 512) return 0;
+  if (n_theta > 40 || n_phi < 2 || n_phi / 2 + 1 > 4 * F_KSMAX || n_out > 512 || L < 1 || L > 32) return 0;
   return 1;
 }
 
-void fused_pitches(int n_theta, int n_phi, int L, int* ks, int* pd) {
-  FusedGeom g;
-  int pa, ntn;
-  size_t lds;
-  fused_geometry(n_theta, n_phi, L, 1, g, pa, ntn, lds);
-  *ks = g.ks;
-  *pd = g.pd;
+// doubles in the cos|sin table of launch_dft_cs_matrix
+size_t fused_dft_table_size(int n_phi, int L) {
+  return (size_t)2 * 4 * fused_ks(n_phi) * fused_pd(L);
 }
 
-hipError_t launch_dft_cs_matrix(hipStream_t stream, int n_phi, int L, double* D, int pd) {
-  const int n = n_phi * (2 * L + 1);
-  hipLaunchKernelGGL(dft_cs_matrix_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, n_phi, L, D, pd);
+hipError_t launch_dft_cs_matrix(hipStream_t stream, int n_phi, int L, double* D) {
+  const int nk = n_phi / 2 + 1, ks = fused_ks(n_phi);
+  const int n = nk * L;
+  hipLaunchKernelGGL(dft_cs_matrix_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, n_phi, L, ks, fused_pd(L), D);
   return hipGetLastError();
 }
 
-template <int NT, int PA, int NTN>
-static hipError_t launch_fused_t(hipStream_t stream, dim3 grid, dim3 block, size_t lds, const double* G, long long ldg,
+template <typename K>
+static hipError_t launch_fused_t(K kernel, hipStream_t stream, dim3 grid, dim3 block, size_t lds, const double* G, long long ldg,
                                  long long n_rows, const FusedGeom& g, const int* m_index, const double* T, const double* D,
                                  double* out, long long ldo) {
-  hipError_t e = hipFuncSetAttribute((const void*)analysis_fused_kernel<NT, PA, NTN, 4>,
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipError_t e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL((analysis_fused_kernel<NT, PA, NTN, 4>), grid, block, lds, stream, G, ldg, n_rows, g, m_index, T, D, out,
-                     ldo);
+  hipLaunchKernelGGL(kernel, grid, block, lds, stream, G, ldg, n_rows, g, m_index, T, D, out, ldo);
   return hipGetLastError();
 }
 
@@ -306,29 +393,38 @@ hipError_t launch_analysis_fused(hipStream_t stream, const double* G, long long 
                                  long long ldo) {
   if (n_rows <= 0) return hipSuccess;
   FusedGeom g;
-  int pa, ntn;
   size_t lds;
-  fused_geometry(n_theta, n_phi, L, n_out, g, pa, ntn, lds);
-  // enough threads for one output mode each and for at most 4 grid pixels each
-  int threads = ((n_out + 63) / 64) * 64;
-  const int t_pix = (((n_theta * n_phi + 3) / 4 + 63) / 64) * 64;
-  if (t_pix > threads) threads = t_pix;
-  const long long blocks = n_rows < 512 ? n_rows : 512;
+  int pj;
+  fused_geometry(n_theta, n_phi, L, n_out, g, lds, pj);
+  // one thread per output mode (up to 64 modes beyond 256 ride along as second modes), never fewer than 4 waves
+  int threads = g.n_sec ? 256 : ((n_out + 63) / 64) * 64;
+  if (threads < 256) threads = 256;
+  // persistent workgroups, two per CU (what registers and LDS allow): measured 0.76 ms at 2 x CUs vs 1.00 ms at 3 x
+  // (tail) and 1.16 ms at 1 x on cfg3
+  static const long long max_blocks = [] {
+    if (getenv("SCRI_AMD_FUSED_BLOCKS")) return atoll(getenv("SCRI_AMD_FUSED_BLOCKS"));
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    return 2LL * cus;
+  }();
+  const long long blocks = n_rows < max_blocks ? n_rows : max_blocks;
   const dim3 grid((unsigned)blocks), block(threads);
-#define FUSED_CASE(NT, PA)                                                                                     \
-  switch (ntn) {                                                                                               \
-    case 1: return launch_fused_t<NT, PA, 1>(stream, grid, block, lds, G, ldg, n_rows, g, m_index, T, D, out, ldo); \
-    case 2: return launch_fused_t<NT, PA, 2>(stream, grid, block, lds, G, ldg, n_rows, g, m_index, T, D, out, ldo); \
-    case 3: return launch_fused_t<NT, PA, 3>(stream, grid, block, lds, G, ldg, n_rows, g, m_index, T, D, out, ldo); \
-    case 4: return launch_fused_t<NT, PA, 4>(stream, grid, block, lds, G, ldg, n_rows, g, m_index, T, D, out, ldo); \
-    default: return hipErrorInvalidValue;                                                                      \
+#define FUSED_GO(K) return launch_fused_t(K, stream, grid, block, lds, G, ldg, n_rows, g, m_index, T, D, out, ldo)
+#define FUSED_KS(NT)                                       \
+  if (L <= 16) {                                           \
+    if (g.ks == 3) FUSED_GO((analysis_fused_kernel<NT, 3>)); \
+    if (g.ks == 5) FUSED_GO((analysis_fused_kernel<NT, 5>)); \
+    FUSED_GO((analysis_fused_kernel<NT, 6>));                \
+  }                                                        \
+  if (g.ks == 3) FUSED_GO((analysis_fused_wide_kernel<NT, 3>)); \
+  if (g.ks == 5) FUSED_GO((analysis_fused_wide_kernel<NT, 5>)); \
+  FUSED_GO((analysis_fused_wide_kernel<NT, 6>));
+  if (n_theta <= 24) {
+    FUSED_KS(24)
   }
-  if (n_theta <= 24 && n_phi <= 24) {
-    FUSED_CASE(24, 26)
-  } else {
-    FUSED_CASE(40, 42)
-  }
-#undef FUSED_CASE
+  FUSED_KS(40)
+#undef FUSED_KS
+#undef FUSED_GO
 }
 
 }  // namespace bms
