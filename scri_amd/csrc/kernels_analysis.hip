@@ -69,29 +69,34 @@ __global__ __launch_bounds__(MAXT) void theta_quadrature_kernel(const double* __
   for (int j = 0; j < NT; ++j) tj[j] = (live && j < n_theta) ? T[(long long)o * n_theta + j] : 0.0;
   const int mi = live ? m_index[o] : 0;
   const int tile = n_theta * 2 * nm;  // doubles
+  // rows n_theta..NT-1 of the LDS tile stay zero (and carry zero weights): the sum below needs no bounds test, and a
+  // branch around an LDS read would make the compiler wait for every read before issuing the next
+  for (int e = tile + threadIdx.x; e < NT * 2 * nm; e += blockDim.x) Fs[e] = 0.0;
   for (long long t = blockIdx.y; t < n_rows; t += gridDim.y) {
     const double* src = F + t * tile;
     __syncthreads();  // previous tile fully consumed
     for (int e = threadIdx.x * 2; e < tile; e += blockDim.x * 2)
       *reinterpret_cast<double2*>(Fs + e) = *reinterpret_cast<const double2*>(src + e);
     __syncthreads();
-    double ar = 0.0, ai = 0.0;
+    double ar = 0.0, ai = 0.0, br = 0.0, bi = 0.0;
 #pragma unroll
-    for (int j = 0; j < NT; ++j) {
-      if (j < n_theta) {
-        const double2 f = *reinterpret_cast<const double2*>(Fs + (j * nm + mi) * 2);
-        ar = fma(tj[j], f.x, ar);
-        ai = fma(tj[j], f.y, ai);
-      }
+    for (int j = 0; j + 1 < NT; j += 2) {
+      const double2 f0 = *reinterpret_cast<const double2*>(Fs + (j * nm + mi) * 2);
+      const double2 f1 = *reinterpret_cast<const double2*>(Fs + ((j + 1) * nm + mi) * 2);
+      ar = fma(tj[j], f0.x, ar);
+      ai = fma(tj[j], f0.y, ai);
+      br = fma(tj[j + 1], f1.x, br);
+      bi = fma(tj[j + 1], f1.y, bi);
     }
-    if (live) *reinterpret_cast<double2*>(out + t * ldo + 2LL * o) = double2{ar, ai};
+    if (live) *reinterpret_cast<double2*>(out + t * ldo + 2LL * o) = double2{ar + br, ai + bi};
   }
 }
 
 hipError_t launch_theta_quadrature(hipStream_t stream, const double* F, long long n_rows, int n_theta, int nm, int n_out,
                                    const int* m_index, const double* T, double* out, long long ldo) {
   if (n_rows <= 0 || n_out <= 0) return hipSuccess;
-  const size_t lds = sizeof(double) * (size_t)n_theta * 2 * nm;
+  const int nt_pad = n_theta <= 24 ? 24 : n_theta <= 40 ? 40 : n_theta <= 72 ? 72 : 104;
+  const size_t lds = sizeof(double) * (size_t)nt_pad * 2 * nm;
   const long long by = n_rows < 2048 ? n_rows : 2048;
   // the T row lives in registers: NT doubles per thread, so larger grids get smaller workgroups
 #define LAUNCH_TQ(NT, MAXT)                                                                                              \

@@ -13,6 +13,7 @@
 // outside the tile (0.268^32 = 5e-19: below fp64 rounding of the global solve).  That gives
 // n_pix x n_tiles independent threads, lanes across adjacent pixels (16 B coalesced complex accesses),
 // marching in time.  Both kernels are HBM-bound streaming passes.
+#include <cstdlib>
 #include "wigner.h"
 #include "kernels.h"
 
@@ -165,6 +166,8 @@ __global__ __launch_bounds__(64) void spline_forward_kernel(const double* __rest
 hipError_t launch_spline_forward(hipStream_t stream, const double* Y, double* R, long long ld, int n_cols,
                                  long long g0, long long n_rows, long long n_knots, const double* x,
                                  const SplineTable* table, int tile, int halo) {
+  static const int tile_env = getenv("SCRI_AMD_SPLINE_TILE_FWD") ? atoi(getenv("SCRI_AMD_SPLINE_TILE_FWD")) : 0;
+  if (tile_env > 0) tile = tile_env;
   (void)x;
   if (n_rows <= 0 || n_cols <= 0) return hipSuccess;
   const long long n_tiles = (n_rows + tile - 1) / tile;
@@ -345,6 +348,8 @@ hipError_t launch_spline_backward_eval(hipStream_t stream, const double* Y, cons
                                        const SplineTable* table, int tile, int halo, const double* base,
                                        const double* skew_a, const double* skew_b, double tt, long long i_lo,
                                        long long i_hi, double* out, long long ldo) {
+  static const int tile_env = getenv("SCRI_AMD_SPLINE_TILE_BWD") ? atoi(getenv("SCRI_AMD_SPLINE_TILE_BWD")) : 0;
+  if (tile_env > 0) tile = tile_env;
   if (n_rows <= 0 || n_cols <= 0 || i_hi <= i_lo) return hipSuccess;
   const long long n_tiles = (n_rows + tile - 1) / tile;
   dim3 grid((n_cols + 63) / 64, (unsigned)n_tiles);
