@@ -570,7 +570,7 @@ void build_pixel_tables(const bms_transformation* tr, PixelTables& T) {
   O.alpha = T.alpha.data();
   O.skew_a = T.skew_a.data();
   O.skew_b = T.skew_b.data();
-  for (int p = 0; p < T.n_pix; ++p) pixel_tables_one(P, O, p);
+  for (int p = 0; p < T.n_pix; ++p) pixel_tables_one(P, O, p, p);
 }
 
 // output time window (waveform_grid.py:564-568 == transformations.py:391-396)
@@ -717,13 +717,15 @@ static int build_analysis(bms_ctx* c, const char* tag, int n_theta, int n_phi, i
 }
 
 // G: [rows][2 n_pix] (row stride exactly 2 n_pix doubles) -> out[rows][ldo] complex modes
-static int run_analysis(bms_ctx* c, const AnalysisPlan& A, const double* d_G, long long rows, double* d_out, long long ldo) {
+static int run_analysis(bms_ctx* c, const AnalysisPlan& A, const double* d_G, long long rows, double* d_out, long long ldo,
+                        const int* col_of_pixel = nullptr) {
   hipStream_t S = c->stream;
   const long long P2 = 2LL * A.n_pix;
   if (A.fused) {
     TIMED(c, BMS_TAG_ANALYSIS_FUSED, launch_analysis_fused(S, d_G, P2, rows, A.n_theta, A.n_phi, A.L, A.n_out, A.d_mindex, A.d_T,
-                                                           A.d_dcs, d_out, ldo));
+                                                           A.d_dcs, d_out, ldo, col_of_pixel));
   } else if (A.separable) {
+    if (col_of_pixel) return fail(c, BMS_ERR_UNSUPPORTED, "internal: sorted columns need the fused analysis");
     double* d_F;
     int rc = dev_buf_t(c, "Fphi", (size_t)rows * A.n_theta * 2 * A.nm, &d_F);
     if (rc) return rc;
@@ -744,6 +746,20 @@ static int upload(bms_ctx* c, const char* name, const void* host, size_t bytes, 
   return BMS_OK;
 }
 
+// times [lo, hi) and the spline table of knots [j0, j1) on the device; both pointers are indexed by GLOBAL knot number
+static int upload_times(bms_ctx* c, const double* t, int64_t n, int64_t lo, int64_t hi, int64_t j0, int64_t j1, double** d_x,
+                        SplineTable** d_tab) {
+  void* vp;
+  int rc = upload(c, "times", t + lo, 8 * (size_t)(hi - lo), &vp);
+  if (rc) return rc;
+  *d_x = (double*)vp - lo;
+  SplineTable* tab;
+  if ((rc = dev_buf_t(c, "spline_table", (size_t)(hi - lo), &tab))) return rc;
+  *d_tab = tab - lo;
+  TIMED(c, BMS_TAG_SETUP, launch_spline_table(c->stream, *d_x, n, *d_tab, std::max(j0, lo), std::min(j1, hi)));
+  return BMS_OK;
+}
+
 static int stage_in(bms_ctx* c, const char* name, const void* src, int mem, size_t bytes, const double** dev) {
   if (mem == BMS_DEVICE) {
     *dev = (const double*)src;
@@ -755,9 +771,23 @@ static int stage_in(bms_ctx* c, const char* name, const void* src, int mem, size
   return rc;
 }
 
-static int validate_common(bms_ctx* c, int64_t n, const double* t, const bms_transformation* tr) {
+// Time samples a call touches on the device: the rows it holds plus the spline-table warm-up margin.  A shard of an
+// 8 x 1e5-step series uploads and checks 1e5 + 128 samples, not 8e5 (the host still sees the global array: window
+// search and chunk planning are binary searches on it).
+constexpr int64_t TIME_MARGIN = 64;
+static void time_window(int64_t n, const bms_shard* sh, int64_t& lo, int64_t& hi) {
+  lo = 0, hi = n;
+  if (sh && sh->data_row0 >= 0 && sh->data_rows >= 0 && sh->data_row0 + sh->data_rows <= n) {
+    lo = std::max<int64_t>(0, sh->data_row0 - TIME_MARGIN);
+    hi = std::min<int64_t>(n, sh->data_row0 + sh->data_rows + TIME_MARGIN);
+  }
+}
+
+static int validate_common(bms_ctx* c, int64_t n, const double* t, const bms_transformation* tr, int64_t lo = 0, int64_t hi = -1) {
   if (n < 4) return fail(c, BMS_ERR_INVALID, "need at least 4 time steps for the cubic spline, got %lld", (long long)n);
-  for (int64_t i = 1; i < n; ++i)
+  if (hi < 0) hi = n;
+  if (!(t[n - 1] > t[0])) return fail(c, BMS_ERR_INVALID, "time array must be strictly increasing (first/last)");
+  for (int64_t i = std::max<int64_t>(lo, 0) + 1; i < hi; ++i)
     if (!(t[i] > t[i - 1])) return fail(c, BMS_ERR_INVALID, "time array must be strictly increasing (index %lld)", (long long)i);
   if (tr->n_theta < 2 || tr->n_phi < 1) return fail(c, BMS_ERR_INVALID, "bad grid size %d x %d", tr->n_theta, tr->n_phi);
   if (tr->ell_max_supertranslation < 1 || !tr->supertranslation) return fail(c, BMS_ERR_INVALID, "supertranslation must hold at least l <= 1");
@@ -771,9 +801,20 @@ static int validate_common(bms_ctx* c, int64_t n, const double* t, const bms_tra
 // supertranslation modes; the four scalars the host needs for the output window and the chunk plan come back in T.
 struct DevPixel {
   double *rotors, *k, *alpha, *skew_a, *skew_b, *col_off, *col_scale, *xa, *xb, *ethk, *etha, *ethetha, *ik, *ik3;
+  const int* col_of_pixel = nullptr;  // set when the columns are stored sorted by time skew (kernels_swsh.hip)
 };
+// the columns are sorted when there is a boost (time skew that grows with |u|) and the analysis can read them in any
+// order, i.e. runs as the fused kernel
+static bool sort_columns(const bms_transformation* tr, int n_out) {
+  const double* v = tr->boost_velocity;
+  if (v[0] == 0 && v[1] == 0 && v[2] == 0) return false;
+  if (getenv("SCRI_AMD_NO_COLUMN_SORT") || getenv("SCRI_AMD_NO_FUSED_ANALYSIS")) return false;
+  return tr->n_theta * tr->n_phi <= pixel_sort_max() && tr->n_theta <= MAX_THETA_SEPARABLE &&
+         fused_analysis_supported(tr->n_theta, tr->n_phi, tr->ell_max_out, n_out);
+}
 static int device_pixel_tables(bms_ctx* c, const bms_transformation* tr, PixelTables& T, int mode, int spin, int cw,
-                               const std::vector<cplx>* coef0, const std::vector<cplx>* coef1, const cplx cv[4], DevPixel& D) {
+                               const std::vector<cplx>* coef0, const std::vector<cplx>* coef1, const cplx cv[4], DevPixel& D,
+                               bool sorted) {
   init_pixel_tables(tr, T);
   const int n_pix = T.n_pix, lst = tr->ell_max_supertranslation, nst = (lst + 1) * (lst + 1);
   PixelSpec P = base_pixel_spec(tr, T);
@@ -815,7 +856,15 @@ static int device_pixel_tables(bms_ctx* c, const bms_transformation* tr, PixelTa
   O.rotors = D.rotors, O.k = D.k, O.alpha = D.alpha, O.skew_a = D.skew_a, O.skew_b = D.skew_b;
   O.col_off = D.col_off, O.col_scale = D.col_scale, O.xa = D.xa, O.xb = D.xb;
   O.ethk = D.ethk, O.etha = D.etha, O.ethetha = D.ethetha, O.ik = D.ik, O.ik3 = D.ik3;
-  TIMED(c, BMS_TAG_SETUP, launch_pixel_tables(c->stream, P, O, n_pix));
+  TIMED(c, BMS_TAG_SETUP, launch_pixel_tables(c->stream, P, O, n_pix, nullptr));
+  if (sorted) {
+    // sort on the skew rate just computed, then rebuild every table in that column order
+    int* d_perm;
+    if ((rc = dev_buf_t(c, "pix_perm", (size_t)2 * n_pix, &d_perm))) return rc;
+    TIMED(c, BMS_TAG_SETUP, launch_pixel_sort(c->stream, D.skew_a, n_pix, d_perm, d_perm + n_pix));
+    TIMED(c, BMS_TAG_SETUP, launch_pixel_tables(c->stream, P, O, n_pix, d_perm));
+    D.col_of_pixel = d_perm + n_pix;
+  }
   // k, alpha, skew_a, skew_b are contiguous: one copy back
   std::vector<double> back((size_t)4 * n_pix);
   HIP_TRY(c, hipMemcpyAsync(back.data(), D.k, sizeof(double) * 4 * n_pix, hipMemcpyDeviceToHost, c->stream));
@@ -875,7 +924,9 @@ extern "C" int bms_transform_modes_shard(bms_ctx* c, const bms_wm_input* in, con
   if (!in || !tr || !t_out || !data_out || !n_times_out) return fail(c, BMS_ERR_INVALID, "NULL argument");
   HIP_TRY(c, hipSetDevice(c->device));
   const int64_t n = in->n_times;
-  int rc = validate_common(c, n, in->t, tr);
+  int64_t t_lo, t_hi;
+  time_window(n, sh, t_lo, t_hi);
+  int rc = validate_common(c, n, in->t, tr, t_lo, t_hi);
   if (rc) return rc;
   const int s = in->spin_weight;
   if (in->ell_min < 0 || in->ell_max < in->ell_min) return fail(c, BMS_ERR_INVALID, "bad ell range");
@@ -891,7 +942,6 @@ extern "C" int bms_transform_modes_shard(bms_ctx* c, const bms_wm_input* in, con
   // ---------------------------------------------------------------- per-pixel tables (GPU) and output window (host)
   HostTrace trace;
   hipStream_t S = c->stream;
-  void* vp;
   const bool nontrivial = [&] {
     const double* v = tr->boost_velocity;
     if (v[0] != 0 || v[1] != 0 || v[2] != 0) return true;
@@ -935,7 +985,7 @@ extern "C" int bms_transform_modes_shard(bms_ctx* c, const bms_wm_input* in, con
   }
   PixelTables T;
   DevPixel DP;
-  if ((rc = device_pixel_tables(c, tr, T, psi ? 1 : 0, s, in->conformal_weight, coef0.empty() ? nullptr : &coef0, nullptr, cv, DP)))
+  if ((rc = device_pixel_tables(c, tr, T, psi ? 1 : 0, s, in->conformal_weight, coef0.empty() ? nullptr : &coef0, nullptr, cv, DP, sort_columns(tr, n_out))))
     return rc;
   trace.mark("pixel tables (GPU) + copy back");
   const int n_pix = T.n_pix;
@@ -956,9 +1006,9 @@ extern "C" int bms_transform_modes_shard(bms_ctx* c, const bms_wm_input* in, con
   if (n_new == 0) return BMS_OK;
   double *d_rot = DP.rotors, *d_off = DP.col_off, *d_scale = DP.col_scale, *d_skewa = DP.skew_a, *d_skewb = DP.skew_b;
   double *d_alpha = DP.alpha, *d_xa = DP.xa, *d_xb = DP.xb, *d_x;
-  if ((rc = upload(c, "times", in->t, 8 * (size_t)n, &vp))) return rc;
-  d_x = (double*)vp;
-  trace.mark("window (host) + time upload");
+  SplineTable* d_tab;
+  if ((rc = upload_times(c, in->t, n, t_lo, t_hi, row0, row0 + rows_avail, &d_x, &d_tab))) return rc;
+  trace.mark("window (host) + time upload + spline factors");
 
   const long long P2 = 2LL * n_pix;
   const long long ldg = round_up(P2, 16);
@@ -998,9 +1048,6 @@ extern "C" int bms_transform_modes_shard(bms_ctx* c, const bms_wm_input* in, con
   if ((rc = build_analysis(c, "wm", T.n_theta, T.n_phi, s, ell_min_out, tr->ell_max_out, ana))) return rc;
   trace.mark("analysis plan");
   // spline factors
-  SplineTable* d_tab;
-  if ((rc = dev_buf_t(c, "spline_table", (size_t)n, &d_tab))) return rc;
-  TIMED(c, BMS_TAG_SETUP, launch_spline_table(S, d_x, n, d_tab));
 
   // output staging
   double* d_out = (double*)data_out;
@@ -1048,7 +1095,7 @@ extern "C" int bms_transform_modes_shard(bms_ctx* c, const bms_wm_input* in, con
     TIMED(c, BMS_TAG_SPLINE_BACKWARD, launch_spline_backward_eval(S, d_Y, d_R, ldg, n_pix, g0, rows_in, n, d_x, d_tab, SPLINE_TILE, SPLINE_HALO,
                                            d_x, d_skewa, d_skewb, T.tt, c0, c1, d_G, P2));
     // analysis
-    if ((rc = run_analysis(c, ana, d_G, rows_out, d_out + (c0 - i_lo) * n_out * 2, 2LL * n_out))) return rc;
+    if ((rc = run_analysis(c, ana, d_G, rows_out, d_out + (c0 - i_lo) * n_out * 2, 2LL * n_out, DP.col_of_pixel))) return rc;
   }
   trace.mark("chunk loop (enqueue)");
   if (in->mem == BMS_HOST)
@@ -1082,7 +1129,7 @@ extern "C" int bms_rotor_grid(bms_ctx* c, const double fr[4], const double v[3],
   tr.n_phi = n_phi;
   PixelTables T;
   DevPixel DP;
-  int rc = device_pixel_tables(c, &tr, T, -1, 0, 0, nullptr, nullptr, nullptr, DP);
+  int rc = device_pixel_tables(c, &tr, T, -1, 0, 0, nullptr, nullptr, nullptr, DP, false);
   if (rc) return rc;
   HIP_TRY(c, hipMemcpyAsync(out, DP.rotors, sizeof(double) * 4 * T.n_pix, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -1139,14 +1186,13 @@ extern "C" int bms_cubic_spline(bms_ctx* c, const double* x, int64_t n, const vo
     if (!(x_new[i] >= x_new[i - 1])) return fail(c, BMS_ERR_INVALID, "evaluation points must be non-decreasing");
   if (n_new <= 0) return BMS_OK;
   int rc;
-  void *d_x, *d_xn;
-  if ((rc = upload(c, "times", x, 8 * (size_t)n, &d_x))) return rc;
+  double* d_x;
+  void* d_xn;
+  SplineTable* d_tab;
+  if ((rc = upload_times(c, x, n, 0, n, 0, n, &d_x, &d_tab))) return rc;
   if ((rc = upload(c, "times_new", x_new, 8 * (size_t)n_new, &d_xn))) return rc;
   const double* d_y;
   if ((rc = stage_in(c, "in_data", y, mem, (size_t)n * ld * 16, &d_y))) return rc;
-  SplineTable* d_tab;
-  if ((rc = dev_buf_t(c, "spline_table", (size_t)n, &d_tab))) return rc;
-  TIMED(c, BMS_TAG_SETUP, launch_spline_table(c->stream, (const double*)d_x, n, d_tab));
   double* d_R;
   if ((rc = dev_buf_t(c, "R", (size_t)n * ld * 2, &d_R))) return rc;
   double* d_out = (double*)out;
@@ -1168,7 +1214,9 @@ extern "C" int bms_transform_abd_shard(bms_ctx* c, const double* u, const void* 
   if (!u || !raw || !tr || !u_out || !raw_out || !n_times_out) return fail(c, BMS_ERR_INVALID, "NULL argument");
   HIP_TRY(c, hipSetDevice(c->device));
   const int64_t n = n_times;
-  int rc = validate_common(c, n, u, tr);
+  int64_t t_lo, t_hi;
+  time_window(n, sh, t_lo, t_hi);
+  int rc = validate_common(c, n, u, tr, t_lo, t_hi);
   if (rc) return rc;
   if (ell_max < 0 || tr->ell_max_out < 0) return fail(c, BMS_ERR_INVALID, "bad ell_max");
   static const int spins[6] = {2, 1, 0, -1, -2, 2};  // psi0..psi4, sigma
@@ -1179,7 +1227,6 @@ extern "C" int bms_transform_abd_shard(bms_ctx* c, const double* u, const void* 
 
   // ---- per-pixel tables on the GPU (transformations.py:306-321), output window on the host (:391-396)
   hipStream_t S = c->stream;
-  void* vp;
   std::vector<cplx> c1((size_t)(lst + 1) * (lst + 1)), c2((size_t)(lst + 1) * (lst + 1));
   for (int l = 0; l <= lst; ++l)
     for (int m = -l; m <= l; ++m) {
@@ -1196,7 +1243,7 @@ extern "C" int bms_transform_abd_shard(bms_ctx* c, const double* u, const void* 
                       {-v[0] * std::sqrt(2 * M_PI / 3), v[1] * std::sqrt(2 * M_PI / 3)}};
   PixelTables T;
   DevPixel DP;
-  if ((rc = device_pixel_tables(c, tr, T, 2, 0, 0, &c1, &c2, cv, DP))) return rc;
+  if ((rc = device_pixel_tables(c, tr, T, 2, 0, 0, &c1, &c2, cv, DP, sort_columns(tr, n_out)))) return rc;
   const int n_pix = T.n_pix;
   // window: timeprime = (u - tt) / gamma  (division, unlike the WaveformModes flavour)
   double umin = -INFINITY, umax = INFINITY;
@@ -1224,8 +1271,9 @@ extern "C" int bms_transform_abd_shard(bms_ctx* c, const double* u, const void* 
   if (n_new == 0) return BMS_OK;
   double *d_rot = DP.rotors, *d_skewa = DP.skew_a, *d_skewb = DP.skew_b, *d_alpha = DP.alpha, *d_ethk = DP.ethk,
          *d_etha = DP.etha, *d_ethetha = DP.ethetha, *d_ik = DP.ik, *d_ik3 = DP.ik3;
-  if ((rc = upload(c, "times", u, 8 * (size_t)n, &vp))) return rc;
-  double* d_x = (double*)vp;
+  double* d_x;
+  SplineTable* d_tab;
+  if ((rc = upload_times(c, u, n, t_lo, t_hi, row0, row0 + rows_avail, &d_x, &d_tab))) return rc;
 
   const long long P2 = 2LL * n_pix, ldg = round_up(P2, 16), ldb = round_up(P2, 128);
   const int K = 2 * nm;
@@ -1242,9 +1290,6 @@ extern "C" int bms_transform_abd_shard(bms_ctx* c, const double* u, const void* 
     TIMED(c, BMS_TAG_SETUP, launch_swsh_matrix_complex(S, d_rot, n_pix, si - 2, 0, ell_max, d_B[si], ldb));
     if ((rc = build_analysis(c, tag, T.n_theta, T.n_phi, si - 2, 0, tr->ell_max_out, ana[si]))) return rc;
   }
-  SplineTable* d_tab;
-  if ((rc = dev_buf_t(c, "spline_table", (size_t)n, &d_tab))) return rc;
-  TIMED(c, BMS_TAG_SETUP, launch_spline_table(S, d_x, n, d_tab));
 
   const double* d_raw;
   if ((rc = stage_in(c, "in_data", raw, mem, (size_t)6 * rows_avail * nm * 16, &d_raw))) return rc;
@@ -1289,7 +1334,7 @@ extern "C" int bms_transform_abd_shard(bms_ctx* c, const double* u, const void* 
       TIMED(c, BMS_TAG_SPLINE_BACKWARD,
             launch_spline_backward_eval(S, grids.y[f], Rf, ldg, n_pix, g0, rows_in, n, d_x, d_tab, SPLINE_TILE, SPLINE_HALO,
                                         d_x, d_skewa, d_skewb, T.tt, c0, c1_, Gf, P2));
-      if ((rc = run_analysis(c, ana[spins[f] + 2], Gf, rows_out, d_out + ((size_t)f * fs_out + (c0 - i_lo)) * n_out * 2, 2LL * n_out)))
+      if ((rc = run_analysis(c, ana[spins[f] + 2], Gf, rows_out, d_out + ((size_t)f * fs_out + (c0 - i_lo)) * n_out * 2, 2LL * n_out, DP.col_of_pixel)))
         return rc;
     }
   }

@@ -39,7 +39,11 @@ hipError_t launch_swsh_values(hipStream_t stream, const double* rotors, int n_pi
 // ---- per-pixel set-up tables on the device (pixel_math.h)
 struct PixelSpec;
 struct PixelOut;
-hipError_t launch_pixel_tables(hipStream_t stream, const PixelSpec& P, const PixelOut& O, int n_pix);
+// perm (device, may be null): column p holds grid pixel perm[p]
+hipError_t launch_pixel_tables(hipStream_t stream, const PixelSpec& P, const PixelOut& O, int n_pix, const int* perm);
+// perm = argsort(key) (ties by index), inv = its inverse; n <= pixel_sort_max()
+int pixel_sort_max();
+hipError_t launch_pixel_sort(hipStream_t stream, const double* key, int n, int* perm, int* inv);
 
 // ---- separable analysis (kernels_analysis.hip): phi-DFT matrix for the GEMM, theta table, theta quadrature
 hipError_t launch_dft_matrix(hipStream_t stream, int n_phi, int L, double* B, long long ldb);
@@ -52,9 +56,10 @@ struct FusedGeom;
 int fused_analysis_supported(int n_theta, int n_phi, int L, int n_out);
 size_t fused_dft_table_size(int n_phi, int L);  // doubles
 hipError_t launch_dft_cs_matrix(hipStream_t stream, int n_phi, int L, double* D);
+// col_of_pixel (device, may be null): grid pixel g is column col_of_pixel[g] of G
 hipError_t launch_analysis_fused(hipStream_t stream, const double* G, long long ldg, long long n_rows, int n_theta, int n_phi,
                                  int L, int n_out, const int* m_index, const double* T, const double* D, double* out,
-                                 long long ldo);
+                                 long long ldo, const int* col_of_pixel);
 
 // ---- dense fp64 GEMM on MFMA: C[M x N] = (A[M x K] * B[K x N] - col_off[N]) * col_scale[N]
 // A row-major (lda), B row-major (ldb, zero padded to a multiple of 128 columns and 16 rows), C row-major (ldc).
@@ -71,7 +76,9 @@ hipError_t launch_zgemm3m(hipStream_t stream, const double* A, long long lda, co
 struct SplineTable {  // per knot j
   double P, Q, A, C;  // r'_j = P (y_j - y_{j-1}) + Q (y_{j+1} - y_j) - A r'_{j-1};  s_j = r'_j - C s_{j+1}
 };
-hipError_t launch_spline_table(hipStream_t stream, const double* x, long long n, SplineTable* table);
+// entries [j0, j1) of the table; x / table are indexed by global knot number and touched on [j0 - 41, j1] only
+hipError_t launch_spline_table(hipStream_t stream, const double* x, long long n, SplineTable* table, long long j0,
+                               long long j1);
 // forward elimination over rows [row_lo, row_hi) of the knot axis; Y, R are [rows][ld] doubles holding
 // global rows g0.. (row index r maps to knot g0 + r)
 hipError_t launch_spline_forward(hipStream_t stream, const double* Y, double* R, long long ld, int n_cols /* complex */,

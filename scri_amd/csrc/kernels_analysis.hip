@@ -182,7 +182,8 @@ template <int NT, int NTC, int KS>
 __device__ __forceinline__ void analysis_fused_body(const double* __restrict__ G, long long ldg, long long n_rows,
                                                     const FusedGeom& g, const int* __restrict__ m_index,
                                                     const double* __restrict__ T, const double* __restrict__ Dg,
-                                                    double* __restrict__ out, long long ldo) {
+                                                    double* __restrict__ out, long long ldo,
+                                                    const int* __restrict__ col_of_pixel) {
   constexpr int PD = NTC == 1 ? 16 : 48;
   constexpr int PJ = NT + 1;  // odd pitch (complex) of an F_m row: consecutive m on distinct 16-byte slots
   extern __shared__ double lds[];
@@ -229,8 +230,9 @@ __device__ __forceinline__ void analysis_fused_body(const double* __restrict__ G
     const int j = ok ? e / g.nk : 0, kk = ok ? e - j * g.nk : 0;
     const int k2 = kk == 0 ? 0 : g.n_phi - kk;
     slot[q] = ok ? fused_row(j) * F_PA + kk : -1;
-    off1[q] = 2 * (j * g.n_phi + kk);
-    off2[q] = 2 * (j * g.n_phi + k2);
+    const int g1 = j * g.n_phi + kk, g2 = j * g.n_phi + k2;
+    off1[q] = 2 * (col_of_pixel ? col_of_pixel[g1] : g1);
+    off2[q] = 2 * (col_of_pixel ? col_of_pixel[g2] : g2);
     wb[q] = k2 == kk ? 0.0 : 1.0;
   }
   auto fetch = [&](long long t) {
@@ -337,15 +339,17 @@ __device__ __forceinline__ void analysis_fused_body(const double* __restrict__ G
 template <int NT, int KS>
 __global__ __launch_bounds__(512) void analysis_fused_kernel(
     const double* __restrict__ G, long long ldg, long long n_rows, FusedGeom g, const int* __restrict__ m_index,
-    const double* __restrict__ T, const double* __restrict__ Dg, double* __restrict__ out, long long ldo) {
-  analysis_fused_body<NT, 1, KS>(G, ldg, n_rows, g, m_index, T, Dg, out, ldo);
+    const double* __restrict__ T, const double* __restrict__ Dg, double* __restrict__ out, long long ldo,
+    const int* __restrict__ col_of_pixel) {
+  analysis_fused_body<NT, 1, KS>(G, ldg, n_rows, g, m_index, T, Dg, out, ldo, col_of_pixel);
 }
 // 16 < L <= 32: two column tiles per product
 template <int NT, int KS>
 __global__ __launch_bounds__(512) void analysis_fused_wide_kernel(
     const double* __restrict__ G, long long ldg, long long n_rows, FusedGeom g, const int* __restrict__ m_index,
-    const double* __restrict__ T, const double* __restrict__ Dg, double* __restrict__ out, long long ldo) {
-  analysis_fused_body<NT, 2, KS>(G, ldg, n_rows, g, m_index, T, Dg, out, ldo);
+    const double* __restrict__ T, const double* __restrict__ Dg, double* __restrict__ out, long long ldo,
+    const int* __restrict__ col_of_pixel) {
+  analysis_fused_body<NT, 2, KS>(G, ldg, n_rows, g, m_index, T, Dg, out, ldo, col_of_pixel);
 }
 
 static int fused_ks(int n_phi) {
@@ -386,16 +390,16 @@ hipError_t launch_dft_cs_matrix(hipStream_t stream, int n_phi, int L, double* D)
 template <typename K>
 static hipError_t launch_fused_t(K kernel, hipStream_t stream, dim3 grid, dim3 block, size_t lds, const double* G, long long ldg,
                                  long long n_rows, const FusedGeom& g, const int* m_index, const double* T, const double* D,
-                                 double* out, long long ldo) {
+                                 double* out, long long ldo, const int* col_of_pixel) {
   hipError_t e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(kernel, grid, block, lds, stream, G, ldg, n_rows, g, m_index, T, D, out, ldo);
+  hipLaunchKernelGGL(kernel, grid, block, lds, stream, G, ldg, n_rows, g, m_index, T, D, out, ldo, col_of_pixel);
   return hipGetLastError();
 }
 
 hipError_t launch_analysis_fused(hipStream_t stream, const double* G, long long ldg, long long n_rows, int n_theta, int n_phi,
                                  int L, int n_out, const int* m_index, const double* T, const double* D, double* out,
-                                 long long ldo) {
+                                 long long ldo, const int* col_of_pixel) {
   if (n_rows <= 0) return hipSuccess;
   FusedGeom g;
   size_t lds;
@@ -409,12 +413,13 @@ hipError_t launch_analysis_fused(hipStream_t stream, const double* G, long long 
   static const long long max_blocks = [] {
     if (getenv("SCRI_AMD_FUSED_BLOCKS")) return atoll(getenv("SCRI_AMD_FUSED_BLOCKS"));
     int dev = 0, cus = 256;
-    if (hipGetDevice(&dev) == hipSuccess) hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
+      cus = 256;
     return 2LL * cus;
   }();
   const long long blocks = n_rows < max_blocks ? n_rows : max_blocks;
   const dim3 grid((unsigned)blocks), block(threads);
-#define FUSED_GO(K) return launch_fused_t(K, stream, grid, block, lds, G, ldg, n_rows, g, m_index, T, D, out, ldo)
+#define FUSED_GO(K) return launch_fused_t(K, stream, grid, block, lds, G, ldg, n_rows, g, m_index, T, D, out, ldo, col_of_pixel)
 #define FUSED_KS(NT)                                       \
   if (L <= 16) {                                           \
     if (g.ks == 3) FUSED_GO((analysis_fused_kernel<NT, 3>)); \

@@ -59,10 +59,12 @@ __device__ __forceinline__ RowCoef spline_row(const double* __restrict__ x, long
 
 constexpr int TABLE_WARMUP = 40;  // |dC_j/dC_{j-1}| <= 1/9 for any spacing: 9^-40 ~ 1e-38
 
+// x and table are indexed by global knot number; entries [j0, j1) are produced and x is read on [j0 - 41, j1]
+// (clipped to [0, n)) only, so a shard can pass pointers that are backed by memory just around its own rows.
 __global__ __launch_bounds__(256) void spline_table_kernel(const double* __restrict__ x, long long n,
-                                                           SplineTable* __restrict__ table) {
-  const long long j = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= n) return;
+                                                           SplineTable* __restrict__ table, long long j0, long long j1) {
+  const long long j = j0 + (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= j1) return;
   long long js = j - TABLE_WARMUP;
   double C = 0.25;  // any start in [0, 1/2]
   if (js <= 0) {
@@ -83,9 +85,11 @@ __global__ __launch_bounds__(256) void spline_table_kernel(const double* __restr
   table[j] = e;
 }
 
-hipError_t launch_spline_table(hipStream_t stream, const double* x, long long n, SplineTable* table) {
-  if (n < 4) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(spline_table_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, x, n, table);
+hipError_t launch_spline_table(hipStream_t stream, const double* x, long long n, SplineTable* table, long long j0,
+                               long long j1) {
+  if (n < 4 || j0 < 0 || j1 > n) return hipErrorInvalidValue;
+  if (j1 <= j0) return hipSuccess;
+  hipLaunchKernelGGL(spline_table_kernel, dim3((unsigned)((j1 - j0 + 255) / 256)), dim3(256), 0, stream, x, n, table, j0, j1);
   return hipGetLastError();
 }
 

@@ -110,13 +110,60 @@ hipError_t launch_swsh_values(hipStream_t stream, const double* rotors, int n_pi
 // ---------------------------------------------------------------------------------------------- per-pixel tables
 // rotor grid, conformal factor k, supertranslation alpha, time-skew coefficients and the flavour-specific per-pixel
 // terms (pixel_math.h: the same code the host runs for bms_shard_plan), one thread per pixel
-__global__ __launch_bounds__(128) void pixel_tables_kernel(PixelSpec P, PixelOut O, int n_pix) {
+__global__ __launch_bounds__(128) void pixel_tables_kernel(PixelSpec P, PixelOut O, int n_pix, const int* __restrict__ perm) {
   const int p = blockIdx.x * blockDim.x + threadIdx.x;
-  if (p < n_pix) pixel_tables_one(P, O, p);
+  if (p < n_pix) pixel_tables_one(P, O, p, perm ? perm[p] : p);
 }
 
-hipError_t launch_pixel_tables(hipStream_t stream, const PixelSpec& P, const PixelOut& O, int n_pix) {
-  hipLaunchKernelGGL(pixel_tables_kernel, dim3((n_pix + 127) / 128), dim3(128), 0, stream, P, O, n_pix);
+hipError_t launch_pixel_tables(hipStream_t stream, const PixelSpec& P, const PixelOut& O, int n_pix, const int* perm) {
+  hipLaunchKernelGGL(pixel_tables_kernel, dim3((n_pix + 127) / 128), dim3(128), 0, stream, P, O, n_pix, perm);
+  return hipGetLastError();
+}
+
+// Column order of the grids.  A boost makes the time skew of a pixel grow like -(v.r_p)(u - tt): at late times pixels
+// that are neighbours on the grid sit tens to hundreds of output rows apart, and the spline evaluation, whose lanes are
+// adjacent columns marching over the knots together, would write every output row in 16-byte pieces.  Storing the
+// columns sorted by the skew rate keeps the lanes of a wave within a few rows of each other at any time.  Nothing else
+// cares about the order (the synthesis matrix and every per-pixel table are simply built in it); the analysis reads
+// grid pixel g from column inv[g].  One workgroup, bitonic sort of (key, index) pairs in LDS; n <= 2048.
+constexpr int SORT_N = 2048;
+__global__ __launch_bounds__(1024) void pixel_sort_kernel(const double* __restrict__ key, int n, int* __restrict__ perm,
+                                                          int* __restrict__ inv) {
+  __shared__ double k[SORT_N];
+  __shared__ int id[SORT_N];
+  const int tid = threadIdx.x;
+  for (int i = tid; i < SORT_N; i += blockDim.x) {
+    k[i] = i < n ? key[i] : INFINITY;
+    id[i] = i;
+  }
+  for (int size = 2; size <= SORT_N; size <<= 1) {
+    for (int stride = size >> 1; stride > 0; stride >>= 1) {
+      __syncthreads();
+      for (int t = tid; t < SORT_N / 2; t += blockDim.x) {
+        const int a = 2 * t - (t & (stride - 1)), b = a + stride;
+        const bool up = (a & size) == 0;
+        const double ka = k[a], kb = k[b];
+        const int ia = id[a], ib = id[b];
+        const bool a_gt_b = ka > kb || (ka == kb && ia > ib);
+        if (a_gt_b == up) {
+          k[a] = kb, k[b] = ka;
+          id[a] = ib, id[b] = ia;
+        }
+      }
+    }
+  }
+  __syncthreads();
+  for (int i = tid; i < n; i += blockDim.x) {
+    perm[i] = id[i];
+    inv[id[i]] = i;
+  }
+}
+
+int pixel_sort_max() { return SORT_N; }
+
+hipError_t launch_pixel_sort(hipStream_t stream, const double* key, int n, int* perm, int* inv) {
+  if (n > SORT_N) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(pixel_sort_kernel, dim3(1), dim3(1024), 0, stream, key, n, perm, inv);
   return hipGetLastError();
 }
 

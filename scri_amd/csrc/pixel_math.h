@@ -125,8 +125,10 @@ struct PixelOut {
   double *ethk, *etha, *ethetha, *ik, *ik3;      // ABD
 };
 
-BMS_HD void pixel_tables_one(const PixelSpec& P, const PixelOut& O, int p) {
-  const int j = p / P.n_phi, kk = p - j * P.n_phi;
+// `p`: column (slot) the results are stored at; `p_grid`: the grid pixel they belong to (the two differ when the columns
+// are stored sorted by time skew, see pixel_sort_kernel)
+BMS_HD void pixel_tables_one(const PixelSpec& P, const PixelOut& O, int p, int p_grid) {
+  const int j = p_grid / P.n_phi, kk = p_grid - j * P.n_phi;
   const Quat R = pixel_rotor(P.frq, P.bs, j, kk, P.n_theta, P.n_phi);
   O.rotors[4 * p] = R.w, O.rotors[4 * p + 1] = R.x, O.rotors[4 * p + 2] = R.y, O.rotors[4 * p + 3] = R.z;
   double r[3];
