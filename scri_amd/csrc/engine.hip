@@ -8,6 +8,7 @@
 //            -> spline backward + evaluation on the distorted time slices  ->  analysis GEMM
 // Nothing in this file falls back to the CPU for the data path; the host only prepares O(n_pix) tables.
 #include <algorithm>
+#include <array>
 #include <cmath>
 #include <chrono>
 #include <cstdarg>
@@ -32,6 +33,23 @@ struct DevBuf {
   size_t cap = 0;
 };
 
+// ---------------------------------------------------------------------------------------------- analysis plan
+// Separable analysis (kernels_analysis.hip) when n_theta <= MAX_THETA_SEPARABLE, dense quadrature GEMM otherwise.
+struct AnalysisPlan {
+  bool separable = true;
+  bool fused = false;  // single-kernel analysis (kernels_analysis.hip, analysis_fused_kernel)
+  double* d_dcs = nullptr;
+  int n_theta = 0, n_phi = 0, n_pix = 0, n_out = 0, L = 0, nm = 0;
+  // separable
+  double* d_dft = nullptr;
+  long long ld_dft = 0;
+  double* d_T = nullptr;
+  int* d_mindex = nullptr;
+  // dense
+  double* d_W = nullptr;
+  long long ldw = 0;
+};
+
 struct bms_ctx {
   int device = 0;
   hipStream_t own_stream = nullptr;
@@ -41,6 +59,8 @@ struct bms_ctx {
   std::map<std::string, DevBuf> bufs;  // grow-only named work space
   int delta_lmax = -1;                 // Delta tables cached up to this l
   int delta_mfma_lmax = -1;            // ... in the MFMA B-image packing
+  // analysis tables depend on the grid, the spin and the l range only: kept per tag until a call asks for other ones
+  std::map<std::string, std::pair<std::array<int, 6>, AnalysisPlan>> plans;
   // optional per-kernel timing with HIP events on the context's stream (bms_ctx_enable_timing)
   bool timing = false;
   struct Timed {
@@ -613,28 +633,20 @@ struct FieldPlan {  // one field to synthesise: input modes, its SWSH matrix
 }  // namespace
 
 
-// ---------------------------------------------------------------------------------------------- analysis plan
-// Separable analysis (kernels_analysis.hip) when n_theta <= MAX_THETA_SEPARABLE, dense quadrature GEMM otherwise.
-struct AnalysisPlan {
-  bool separable = true;
-  bool fused = false;  // single-kernel analysis (kernels_analysis.hip, analysis_fused_kernel)
-  double* d_dcs = nullptr;
-  int n_theta = 0, n_phi = 0, n_pix = 0, n_out = 0, L = 0, nm = 0;
-  // separable
-  double* d_dft = nullptr;
-  long long ld_dft = 0;
-  double* d_T = nullptr;
-  int* d_mindex = nullptr;
-  // dense
-  double* d_W = nullptr;
-  long long ldw = 0;
-};
-
 static int upload(bms_ctx* c, const char* name, const void* host, size_t bytes, void** dev);
 
 static int build_analysis(bms_ctx* c, const char* tag, int n_theta, int n_phi, int spin, int ell_min_out, int ell_max_out,
                           AnalysisPlan& A) {
   hipStream_t S = c->stream;
+  const std::array<int, 6> key = {n_theta, n_phi, spin, ell_min_out, ell_max_out, getenv("SCRI_AMD_NO_FUSED_ANALYSIS") ? 1 : 0};
+  {
+    auto it = c->plans.find(tag);
+    if (it != c->plans.end() && it->second.first == key && !getenv("SCRI_AMD_NO_PLAN_CACHE")) {
+      A = it->second.second;
+      return BMS_OK;
+    }
+    c->plans.erase(tag);
+  }
   A.n_theta = n_theta;
   A.n_phi = n_phi;
   A.n_pix = n_theta * n_phi;
@@ -713,6 +725,7 @@ static int build_analysis(bms_ctx* c, const char* tag, int n_theta, int n_phi, i
     TIMED(c, BMS_TAG_SETUP, launch_quadrature_matrix(S, d_grot, d_wpix, A.n_pix, spin, ell_min_out, ell_max_out, A.d_W, A.ldw));
     HIP_TRY(c, hipStreamSynchronize(S));
   }
+  c->plans[tag] = {key, A};
   return BMS_OK;
 }
 
