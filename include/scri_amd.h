@@ -185,6 +185,19 @@ int bms_map2salm(bms_ctx* ctx, const void* grid, int mem, int64_t n_maps, int n_
 int bms_cubic_spline(bms_ctx* ctx, const double* x, int64_t n, const void* y, int64_t ld, int64_t n_cols, int mem,
                      const double* x_new, int64_t n_new, void* out);
 
+/* ---- "next" rows of the scope table: time-series calculus and grid products ------------- */
+/* scipy CubicSpline(x, y).derivative(order) (order 1..3), the spline itself (0) or .antiderivative(-order) (order -1, -2;
+ * zero at x[0]) evaluated at x_new (any order of samples): ModesTimeSeries.interpolate(new_time, derivative_order) and
+ * .dot / .ddot / .int / .iint (scri/modes_time_series.py:72-126).  y: c16[n][ld], out: c16[n_new][n_cols], both in `mem`. */
+int bms_spline_derivative(bms_ctx* ctx, const double* x, int64_t n, const void* y, int64_t ld, int64_t n_cols, int mem,
+                          const double* x_new, int64_t n_new, int order, void* out);
+/* ModesTimeSeries.grid_multiply (scri/modes_time_series.py:142-202): modes a (spin_a, l = 0..ell_max_a,
+ * c16[n_times][(ell_max_a+1)^2]) and b likewise are evaluated on the (2 working_ell_max + 1)^2 equiangular grid
+ * (spinsfast.salm2map), multiplied there, and the product is analysed (map2salm, spin spin_a + spin_b) into
+ * out c16[n_times][(output_ell_max+1)^2]. */
+int bms_grid_multiply(bms_ctx* ctx, const void* a, int spin_a, int ell_max_a, const void* b, int spin_b, int ell_max_b, int mem,
+                      int64_t n_times, int working_ell_max, int output_ell_max, void* out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -6,6 +6,7 @@ BMS-transformation path:
     WaveformModes.transform / rotate_decomposition_basis / rotate_physical_system / to_inertial_frame
     AsymptoticBondiData.transform
     bms_transformations.LorentzTransformation / BMSTransformation / transform_supertranslation
+    ModesTimeSeries.interpolate / derivative / antiderivative / grid_multiply   (next row of the scope table)
 
 All arithmetic on the data runs in hand-written HIP kernels for gfx950 behind the C ABI in
 ``include/scri_amd.h`` (``scri_amd/libscri_amd.so``).  There is no CPU fallback.
@@ -29,6 +30,7 @@ from .waveform_modes import WaveformModes  # noqa: E402,F401
 from .rotations import rotate_decomposition_basis, rotate_physical_system, to_inertial_frame  # noqa: E402,F401
 from .asymptotic_bondi_data import AsymptoticBondiData  # noqa: E402,F401
 from . import bms_transformations  # noqa: E402,F401
+from .modes_time_series import ModesTimeSeries  # noqa: E402,F401
 from .bms_transformations import LorentzTransformation, BMSTransformation  # noqa: E402,F401
 
 # Same grafting the reference performs at import (scri/__init__.py:140-142)

@@ -103,6 +103,8 @@ SIGNATURES = {
     "bms_swsh_grid": (c_int, [c_vp, c_dp, c_i64, c_int, c_int, c_int, c_vp]),
     "bms_map2salm": (c_int, [c_vp, c_vp, c_int, c_i64, c_int, c_int, c_int, c_int, c_int, c_vp]),
     "bms_cubic_spline": (c_int, [c_vp, c_dp, c_i64, c_vp, c_i64, c_i64, c_int, c_dp, c_i64, c_vp]),
+    "bms_spline_derivative": (c_int, [c_vp, c_dp, c_i64, c_vp, c_i64, c_i64, c_int, c_dp, c_i64, c_int, c_vp]),
+    "bms_grid_multiply": (c_int, [c_vp, c_vp, c_int, c_int, c_vp, c_int, c_int, c_int, c_i64, c_int, c_int, c_vp]),
 }
 
 _lib = None

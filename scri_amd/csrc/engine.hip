@@ -1219,6 +1219,110 @@ extern "C" int bms_cubic_spline(bms_ctx* c, const double* x, int64_t n, const vo
   return BMS_OK;
 }
 
+// scipy CubicSpline(x, y).derivative(k) / .antiderivative(-k) evaluated at x_new (ModesTimeSeries.interpolate with
+// derivative_order, .dot / .ddot / .int / .iint: scri/modes_time_series.py:72-126)
+extern "C" int bms_spline_derivative(bms_ctx* c, const double* x, int64_t n, const void* y, int64_t ld, int64_t n_cols, int mem,
+                                     const double* x_new, int64_t n_new, int order, void* out) {
+  if (!c || !x || !y || !x_new || !out) return BMS_ERR_INVALID;
+  HIP_TRY(c, hipSetDevice(c->device));
+  if (n < 4) return fail(c, BMS_ERR_UNSUPPORTED, "cubic spline needs at least 4 knots, got %lld", (long long)n);
+  if (ld < n_cols || n_cols <= 0) return fail(c, BMS_ERR_INVALID, "bad column count / stride");
+  if (order < -2 || order > 3) return fail(c, BMS_ERR_INVALID, "derivative order %d outside [-2, 3]", order);
+  for (int64_t i = 1; i < n; ++i)
+    if (!(x[i] > x[i - 1])) return fail(c, BMS_ERR_INVALID, "knots must be strictly increasing");
+  if (n_new <= 0) return BMS_OK;
+  int rc;
+  double* d_x;
+  void* d_xn;
+  SplineTable* d_tab;
+  if ((rc = upload_times(c, x, n, 0, n, 0, n, &d_x, &d_tab))) return rc;
+  if ((rc = upload(c, "times_new", x_new, 8 * (size_t)n_new, &d_xn))) return rc;
+  const double* d_y;
+  if ((rc = stage_in(c, "in_data", y, mem, (size_t)n * ld * 16, &d_y))) return rc;
+  double *d_R, *d_S, *d_P1 = nullptr, *d_P2 = nullptr, *d_carry = nullptr;
+  if ((rc = dev_buf_t(c, "R", (size_t)n * ld * 2, &d_R))) return rc;
+  if ((rc = dev_buf_t(c, "S", (size_t)n * ld * 2, &d_S))) return rc;
+  hipStream_t S = c->stream;
+  TIMED(c, BMS_TAG_SPLINE_FORWARD, launch_spline_forward(S, d_y, d_R, 2 * ld, (int)n_cols, 0, n, n, d_x, d_tab, SPLINE_TILE, SPLINE_HALO));
+  TIMED(c, BMS_TAG_SPLINE_BACKWARD, launch_spline_slopes(S, d_R, d_S, 2 * ld, (int)n_cols, n, d_tab, SPLINE_TILE, SPLINE_HALO));
+  if (order < 0) {
+    if ((rc = dev_buf_t(c, "P1", (size_t)n * ld * 2, &d_P1))) return rc;
+    if (order < -1)
+      if ((rc = dev_buf_t(c, "P2", (size_t)n * ld * 2, &d_P2))) return rc;
+    if ((rc = dev_buf_t(c, "P_carry", (size_t)spline_prefix_carry_size(n, (int)n_cols), &d_carry))) return rc;
+    TIMED(c, BMS_TAG_POINTWISE, launch_spline_prefix(S, d_y, d_S, 2 * ld, (int)n_cols, n, d_x, d_P1, d_P2, d_carry, -order));
+  }
+  double* d_out = (double*)out;
+  if (mem == BMS_HOST)
+    if ((rc = dev_buf_t(c, "out_data", (size_t)n_new * n_cols * 2, &d_out))) return rc;
+  TIMED(c, BMS_TAG_POINTWISE, launch_spline_hermite_eval(S, d_y, d_S, d_P1, d_P2, 2 * ld, (int)n_cols, n, d_x, (const double*)d_xn,
+                                                         n_new, order, d_out, 2 * n_cols));
+  if (mem == BMS_HOST) HIP_TRY(c, hipMemcpyAsync(out, d_out, (size_t)n_new * n_cols * 16, hipMemcpyDeviceToHost, S));
+  HIP_TRY(c, hipStreamSynchronize(S));
+  return BMS_OK;
+}
+
+// ModesTimeSeries.grid_multiply (scri/modes_time_series.py:142-202): both mode sets (l_min = 0) are synthesised on the
+// (2W+1) x (2W+1) equiangular grid, multiplied there, and the product (spin s_a + s_b) is analysed up to output_ell_max.
+extern "C" int bms_grid_multiply(bms_ctx* c, const void* a, int spin_a, int ell_max_a, const void* b, int spin_b, int ell_max_b,
+                                 int mem, int64_t n_times, int working_ell_max, int output_ell_max, void* out) {
+  if (!c || !a || !b || !out) return BMS_ERR_INVALID;
+  HIP_TRY(c, hipSetDevice(c->device));
+  if (ell_max_a < 0 || ell_max_b < 0 || working_ell_max < 1 || output_ell_max < 0 || output_ell_max > working_ell_max)
+    return fail(c, BMS_ERR_INVALID, "bad l ranges (need 0 <= output_ell_max <= working_ell_max)");
+  if (std::abs(spin_a) > 2 || std::abs(spin_b) > 2 || std::abs(spin_a + spin_b) > 4)
+    return fail(c, BMS_ERR_UNSUPPORTED, "spin weights beyond +-2 are not supported");
+  if (n_times <= 0) return BMS_OK;
+  const int n_theta = 2 * working_ell_max + 1, n_phi = n_theta, n_pix = n_theta * n_phi;
+  const int nma = (ell_max_a + 1) * (ell_max_a + 1), nmb = (ell_max_b + 1) * (ell_max_b + 1);
+  const int n_out = (output_ell_max + 1) * (output_ell_max + 1);
+  hipStream_t S = c->stream;
+  int rc;
+  // grid rotors R(theta_j, phi_k) in the natural order the analysis expects
+  std::vector<double> rot(4 * (size_t)n_pix);
+  for (int j = 0; j < n_theta; ++j)
+    for (int k = 0; k < n_phi; ++k) {
+      const Quat q = from_spherical_coords(M_PI * j / (n_theta - 1), (2 * M_PI) * k / n_phi);
+      double* r = &rot[4 * ((size_t)j * n_phi + k)];
+      r[0] = q.w, r[1] = q.x, r[2] = q.y, r[3] = q.z;
+    }
+  void* vp;
+  if ((rc = upload(c, "gm_rotors", rot.data(), 8 * rot.size(), &vp))) return rc;
+  const double* d_rot = (const double*)vp;
+  const long long P2 = 2LL * n_pix, ldb = round_up(P2, 128);
+  double *d_Ba, *d_Bb;
+  if ((rc = dev_buf_t(c, "gm_Ba", (size_t)round_up(nma, 8) * ldb, &d_Ba))) return rc;
+  if ((rc = dev_buf_t(c, "gm_Bb", (size_t)round_up(nmb, 8) * ldb, &d_Bb))) return rc;
+  HIP_TRY(c, hipMemsetAsync(d_Ba, 0, sizeof(double) * round_up(nma, 8) * ldb, S));
+  HIP_TRY(c, hipMemsetAsync(d_Bb, 0, sizeof(double) * round_up(nmb, 8) * ldb, S));
+  TIMED(c, BMS_TAG_SETUP, launch_swsh_matrix_complex(S, d_rot, n_pix, spin_a, 0, ell_max_a, d_Ba, ldb));
+  TIMED(c, BMS_TAG_SETUP, launch_swsh_matrix_complex(S, d_rot, n_pix, spin_b, 0, ell_max_b, d_Bb, ldb));
+  AnalysisPlan ana;
+  if ((rc = build_analysis(c, "gm", n_theta, n_phi, spin_a + spin_b, 0, output_ell_max, ana))) return rc;
+  const double *d_a, *d_b;
+  if ((rc = stage_in(c, "in_data", a, mem, (size_t)n_times * nma * 16, &d_a))) return rc;
+  if ((rc = stage_in(c, "in_aux0", b, mem, (size_t)n_times * nmb * 16, &d_b))) return rc;
+  double* d_out = (double*)out;
+  if (mem == BMS_HOST)
+    if ((rc = dev_buf_t(c, "out_data", (size_t)n_times * n_out * 2, &d_out))) return rc;
+  // chunks of time rows: two grids of 16 n_pix bytes per row
+  int64_t chunk = (int64_t)std::max(64.0, (double)c->ws_limit / (2.0 * P2 * 8.0));
+  chunk = std::min<int64_t>(chunk, n_times);
+  for (int64_t r0 = 0; r0 < n_times; r0 += chunk) {
+    const int64_t rows = std::min<int64_t>(chunk, n_times - r0);
+    double *d_Ga, *d_Gb;
+    if ((rc = dev_buf_t(c, "Y", (size_t)rows * P2, &d_Ga))) return rc;
+    if ((rc = dev_buf_t(c, "R", (size_t)rows * P2, &d_Gb))) return rc;
+    TIMED(c, BMS_TAG_GEMM_SYNTHESIS, launch_zgemm3m(S, d_a + r0 * nma * 2, 2LL * nma, d_Ba, ldb, d_Ga, P2, rows, n_pix, nma, nullptr, nullptr));
+    TIMED(c, BMS_TAG_GEMM_SYNTHESIS, launch_zgemm3m(S, d_b + r0 * nmb * 2, 2LL * nmb, d_Bb, ldb, d_Gb, P2, rows, n_pix, nmb, nullptr, nullptr));
+    TIMED(c, BMS_TAG_POINTWISE, launch_cmul(S, d_Ga, d_Gb, d_Ga, rows * (long long)n_pix));
+    if ((rc = run_analysis(c, ana, d_Ga, rows, d_out + r0 * n_out * 2, 2LL * n_out))) return rc;
+  }
+  if (mem == BMS_HOST) HIP_TRY(c, hipMemcpyAsync(out, d_out, (size_t)n_times * n_out * 16, hipMemcpyDeviceToHost, S));
+  HIP_TRY(c, hipStreamSynchronize(S));
+  return BMS_OK;
+}
+
 // ====================================================================================================== ABD flavour
 extern "C" int bms_transform_abd_shard(bms_ctx* c, const double* u, const void* raw, int mem, int64_t n_times, int ell_max,
                                        const bms_transformation* tr, const bms_shard* sh, double* u_out, void* raw_out,

@@ -92,6 +92,21 @@ hipError_t launch_spline_backward_eval(hipStream_t stream, const double* Y, cons
                                        const double* skew_a, const double* skew_b, double tt, long long i_lo,
                                        long long i_hi, double* out, long long ldo);
 
+// ---- time-series calculus and grid products (kernels_series.hip; scri/modes_time_series.py:72-202)
+// spline slopes s_j at all knots from the forward-pass result R (S != R)
+hipError_t launch_spline_slopes(hipStream_t stream, const double* R, double* S, long long ld, int n_cols, long long n,
+                                const SplineTable* table, int tile, int halo);
+// running integrals at the knots: P1 = int f (order >= 1), P2 = int P1 (order 2); carry: spline_prefix_carry_size doubles
+long long spline_prefix_carry_size(long long n, int n_cols);
+hipError_t launch_spline_prefix(hipStream_t stream, const double* Y, const double* S, long long ld, int n_cols, long long n,
+                                const double* x, double* P1, double* P2, double* carry, int order);
+// out[i][c] = (d/du)^order spline_c(x_new[i]), order in [-2, 3] (negative: antiderivatives vanishing at x[0])
+hipError_t launch_spline_hermite_eval(hipStream_t stream, const double* Y, const double* S, const double* P1, const double* P2,
+                                      long long ld, int n_cols, long long n, const double* x, const double* x_new,
+                                      long long n_new, int order, double* out, long long ldo);
+// c = a * b, n complex numbers
+hipError_t launch_cmul(hipStream_t stream, const double* a, const double* b, double* c, long long n);
+
 // ---- pointwise helpers
 // Y[t][p] += coeff * Yaux[t][p] * X[t][p]^power,  X = (x_t - alpha_p) * xa_p - xb_p   (waveform_grid.py:516-550)
 hipError_t launch_psi_mix(hipStream_t stream, double* Y, const double* Yaux, long long ld, int n_pix, long long n_rows,

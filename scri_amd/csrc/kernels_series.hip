@@ -1,0 +1,229 @@
+// Time-series calculus on mode data and products on the sphere: the kernels behind ModesTimeSeries
+// (scri/modes_time_series.py:72-126 interpolate / derivative / antiderivative, :142-202 grid_multiply) and
+// WaveformBase / AsymptoticBondiData.interpolate.
+//
+// scipy's CubicSpline(u, y).derivative(k) / .antiderivative(k) are evaluated from knot data instead of per-interval
+// coefficient tables: the spline slopes s_j at the knots (shared-matrix solve of kernels_spline.hip: forward pass,
+// then spline_slopes_kernel) and, for the antiderivatives, running integrals P1_j = int_{u_0}^{u_j} f and
+// P2_j = int_{u_0}^{u_j} P1 (spline_prefix_kernel).  Any sample is then a local Hermite evaluation
+// (spline_hermite_eval_kernel), lanes across columns (16-byte coalesced), one output time per block row.
+#include <cstdlib>
+#include "kernels.h"
+
+namespace bms {
+
+// ------------------------------------------------------------------------------------------------ slopes at the knots
+// Thread (column, tile): s_j = r'_j - C_j s_{j+1}, started `halo` knots above the tile (0.268^halo decay), written for
+// the knots of the tile.  R and S must be different buffers (a tile's start-up reads r' of its neighbour).
+__global__ __launch_bounds__(64) void spline_slopes_kernel(const double* __restrict__ R, double* __restrict__ S, long long ld,
+                                                           int n_cols, long long n, const SplineTable* __restrict__ table,
+                                                           int tile, int halo) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n_cols) return;
+  const long long jA = (long long)blockIdx.y * tile;
+  long long jB = jA + tile;
+  if (jB > n) jB = n;
+  long long jE = jB - 1 + halo;
+  if (jE > n - 1) jE = n - 1;
+  const double* rp = R + 2LL * p;
+  double* sp = S + 2LL * p;
+  double2 s = *reinterpret_cast<const double2*>(rp + jE * ld);  // exact at the last knot, truncated start otherwise
+  if (jE < jB) *reinterpret_cast<double2*>(sp + jE * ld) = s;
+  for (long long j = jE - 1; j >= jA; --j) {
+    const double C = table[j].C;
+    const double2 r = *reinterpret_cast<const double2*>(rp + j * ld);
+    s.x = r.x - C * s.x;
+    s.y = r.y - C * s.y;
+    if (j < jB) *reinterpret_cast<double2*>(sp + j * ld) = s;
+  }
+}
+
+hipError_t launch_spline_slopes(hipStream_t stream, const double* R, double* S, long long ld, int n_cols, long long n,
+                                const SplineTable* table, int tile, int halo) {
+  if (n <= 0 || n_cols <= 0) return hipSuccess;
+  dim3 grid((n_cols + 63) / 64, (unsigned)((n + tile - 1) / tile));
+  hipLaunchKernelGGL(spline_slopes_kernel, grid, dim3(64), 0, stream, R, S, ld, n_cols, n, table, tile, halo);
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------ running integrals
+// Interval j of the spline in Hermite form: f(t) = y0 + s0 t + c2 t^2 + c3 t^3, t = u - u_j, h = u_{j+1} - u_j,
+//   c3 = (s0 + s1 - 2 D) / h^2,  c2 = (D - s0) / h - c3 h,  D = (y1 - y0) / h.
+struct Hermite {
+  double c2x, c2y, c3x, c3y;
+};
+__device__ __forceinline__ Hermite hermite(double2 y0, double2 y1, double2 s0, double2 s1, double h) {
+  const double ih = 1.0 / h;
+  const double dx = (y1.x - y0.x) * ih, dy = (y1.y - y0.y) * ih;
+  const double tx = (s0.x + s1.x - 2.0 * dx) * ih, ty = (s0.y + s1.y - 2.0 * dy) * ih;
+  Hermite H;
+  H.c3x = tx * ih, H.c3y = ty * ih;
+  H.c2x = (dx - s0.x) * ih - tx, H.c2y = (dy - s0.y) * ih - ty;
+  return H;
+}
+
+// P1[j], P2[j] for all knots (P[0] = 0: scipy's antiderivative vanishes at the first knot).  The sum over intervals is
+// sequential per column; columns are independent.  Phase 1: per (column, tile) totals; phase 2: running sum over tiles;
+// phase 3: per (column, tile) prefix from the tile's start value.  P2 needs P1 at the tile starts, so P1's three phases
+// run before P2's (same kernel, `second` selects the integrand).
+__global__ __launch_bounds__(64) void spline_prefix_kernel(const double* __restrict__ Y, const double* __restrict__ S,
+                                                           long long ld, int n_cols, long long n, const double* __restrict__ x,
+                                                           int tile, double* __restrict__ P1, double* __restrict__ P2,
+                                                           double* __restrict__ carry /* [n_tiles][2 n_cols] */, int phase,
+                                                           int second) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n_cols) return;
+  const long long n_tiles = (n + tile - 1) / tile;
+  if (phase == 2) {
+    // exclusive running sum of the tile totals, one thread per column
+    if (blockIdx.y != 0) return;
+    double2 run = {0.0, 0.0};
+    for (long long t = 0; t < n_tiles; ++t) {
+      double2* cp = reinterpret_cast<double2*>(carry + t * 2LL * n_cols + 2LL * p);
+      const double2 v = *cp;
+      *cp = run;
+      run.x += v.x, run.y += v.y;
+    }
+    return;
+  }
+  const long long jA = (long long)blockIdx.y * tile;
+  long long jB = jA + tile;
+  if (jB > n) jB = n;
+  if (jA >= n) return;
+  const double* yp = Y + 2LL * p;
+  const double* sp = S + 2LL * p;
+  double* out = (second ? P2 : P1) + 2LL * p;
+  double2* cp = reinterpret_cast<double2*>(carry + (long long)blockIdx.y * 2LL * n_cols + 2LL * p);
+  double2 run = phase == 3 ? *cp : double2{0.0, 0.0};
+  double2 y0 = *reinterpret_cast<const double2*>(yp + jA * ld), s0 = *reinterpret_cast<const double2*>(sp + jA * ld);
+  for (long long j = jA; j < jB; ++j) {
+    if (phase == 3) *reinterpret_cast<double2*>(out + j * ld) = run;
+    if (j + 1 >= n) break;
+    const double2 y1 = *reinterpret_cast<const double2*>(yp + (j + 1) * ld);
+    const double2 s1 = *reinterpret_cast<const double2*>(sp + (j + 1) * ld);
+    const double h = x[j + 1] - x[j];
+    const Hermite H = hermite(y0, y1, s0, s1, h);
+    if (!second) {
+      // int_0^h f = h (y0 + h (s0/2 + h (c2/3 + h c3/4)))
+      run.x += h * (y0.x + h * (0.5 * s0.x + h * (H.c2x * (1.0 / 3.0) + h * H.c3x * 0.25)));
+      run.y += h * (y0.y + h * (0.5 * s0.y + h * (H.c2y * (1.0 / 3.0) + h * H.c3y * 0.25)));
+    } else {
+      // int_0^h (P1_j + int_0^t f) = h (P1_j + h (y0/2 + h (s0/6 + h (c2/12 + h c3/20))))
+      const double2 q = *reinterpret_cast<const double2*>(P1 + 2LL * p + j * ld);
+      run.x += h * (q.x + h * (0.5 * y0.x + h * (s0.x * (1.0 / 6.0) + h * (H.c2x * (1.0 / 12.0) + h * H.c3x * 0.05))));
+      run.y += h * (q.y + h * (0.5 * y0.y + h * (s0.y * (1.0 / 6.0) + h * (H.c2y * (1.0 / 12.0) + h * H.c3y * 0.05))));
+    }
+    y0 = y1, s0 = s1;
+  }
+  if (phase == 1) *cp = run;
+}
+
+hipError_t launch_spline_prefix(hipStream_t stream, const double* Y, const double* S, long long ld, int n_cols, long long n,
+                                const double* x, double* P1, double* P2, double* carry, int order) {
+  if (n <= 0 || n_cols <= 0) return hipSuccess;
+  const int tile = 512;
+  const long long n_tiles = (n + tile - 1) / tile;
+  dim3 grid((n_cols + 63) / 64, (unsigned)n_tiles), one((n_cols + 63) / 64, 1);
+  for (int second = 0; second < order; ++second)
+    for (int phase = 1; phase <= 3; ++phase) {
+      hipLaunchKernelGGL(spline_prefix_kernel, phase == 2 ? one : grid, dim3(64), 0, stream, Y, S, ld, n_cols, n, x, tile, P1, P2,
+                         carry, phase, second);
+    }
+  return hipGetLastError();
+}
+long long spline_prefix_carry_size(long long n, int n_cols) { return ((n + 511) / 512) * 2LL * n_cols; }
+
+// ------------------------------------------------------------------------------------------------ evaluation
+// out[i][c] = d^k/du^k spline_c (x_new[i]), k = order in [-2, 3]; interval found by binary search (the same for every
+// column of a block row), end intervals extrapolate (scipy's default).  Lanes across columns.
+__global__ __launch_bounds__(256) void spline_hermite_eval_kernel(const double* __restrict__ Y, const double* __restrict__ S,
+                                                                  const double* __restrict__ P1, const double* __restrict__ P2,
+                                                                  long long ld, int n_cols, long long n,
+                                                                  const double* __restrict__ x, const double* __restrict__ x_new,
+                                                                  long long n_new, int order, double* __restrict__ out,
+                                                                  long long ldo) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  for (long long i = blockIdx.y; i < n_new; i += gridDim.y) {
+    const double u = x_new[i];
+    // last knot <= u, clamped to [0, n-2]
+    long long lo = 0, hi = n - 1;
+    while (hi - lo > 1) {
+      const long long mid = (lo + hi) >> 1;
+      if (x[mid] <= u)
+        lo = mid;
+      else
+        hi = mid;
+    }
+    const long long j = lo;
+    if (p >= n_cols) continue;
+    const double xj = x[j], h = x[j + 1] - xj, t = u - xj;
+    const double2 y0 = *reinterpret_cast<const double2*>(Y + 2LL * p + j * ld);
+    const double2 y1 = *reinterpret_cast<const double2*>(Y + 2LL * p + (j + 1) * ld);
+    const double2 s0 = *reinterpret_cast<const double2*>(S + 2LL * p + j * ld);
+    const double2 s1 = *reinterpret_cast<const double2*>(S + 2LL * p + (j + 1) * ld);
+    const Hermite H = hermite(y0, y1, s0, s1, h);
+    double2 v;
+    switch (order) {
+      case 0:
+        v.x = y0.x + t * (s0.x + t * (H.c2x + t * H.c3x));
+        v.y = y0.y + t * (s0.y + t * (H.c2y + t * H.c3y));
+        break;
+      case 1:
+        v.x = s0.x + t * (2.0 * H.c2x + 3.0 * t * H.c3x);
+        v.y = s0.y + t * (2.0 * H.c2y + 3.0 * t * H.c3y);
+        break;
+      case 2:
+        v.x = 2.0 * H.c2x + 6.0 * t * H.c3x;
+        v.y = 2.0 * H.c2y + 6.0 * t * H.c3y;
+        break;
+      case 3:
+        v.x = 6.0 * H.c3x;
+        v.y = 6.0 * H.c3y;
+        break;
+      case -1: {
+        const double2 q1 = *reinterpret_cast<const double2*>(P1 + 2LL * p + j * ld);
+        v.x = q1.x + t * (y0.x + t * (0.5 * s0.x + t * (H.c2x * (1.0 / 3.0) + t * H.c3x * 0.25)));
+        v.y = q1.y + t * (y0.y + t * (0.5 * s0.y + t * (H.c2y * (1.0 / 3.0) + t * H.c3y * 0.25)));
+        break;
+      }
+      default: {
+        const double2 q1 = *reinterpret_cast<const double2*>(P1 + 2LL * p + j * ld);
+        const double2 q2 = *reinterpret_cast<const double2*>(P2 + 2LL * p + j * ld);
+        v.x = q2.x + t * (q1.x + t * (0.5 * y0.x + t * (s0.x * (1.0 / 6.0) + t * (H.c2x * (1.0 / 12.0) + t * H.c3x * 0.05))));
+        v.y = q2.y + t * (q1.y + t * (0.5 * y0.y + t * (s0.y * (1.0 / 6.0) + t * (H.c2y * (1.0 / 12.0) + t * H.c3y * 0.05))));
+      }
+    }
+    *reinterpret_cast<double2*>(out + 2LL * p + i * ldo) = v;
+  }
+}
+
+hipError_t launch_spline_hermite_eval(hipStream_t stream, const double* Y, const double* S, const double* P1, const double* P2,
+                                      long long ld, int n_cols, long long n, const double* x, const double* x_new,
+                                      long long n_new, int order, double* out, long long ldo) {
+  if (n_new <= 0 || n_cols <= 0) return hipSuccess;
+  const int threads = n_cols >= 256 ? 256 : ((n_cols + 63) / 64) * 64;
+  dim3 grid((n_cols + threads - 1) / threads, (unsigned)(n_new < 32768 ? n_new : 32768));
+  hipLaunchKernelGGL(spline_hermite_eval_kernel, grid, dim3(threads), 0, stream, Y, S, P1, P2, ld, n_cols, n, x, x_new, n_new,
+                     order, out, ldo);
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------ pointwise product
+// c[i] = a[i] * b[i] (complex), the grid-space product of ModesTimeSeries.grid_multiply (modes_time_series.py:181)
+__global__ __launch_bounds__(256) void cmul_kernel(const double2* __restrict__ a, const double2* __restrict__ b,
+                                                   double2* __restrict__ c, long long n) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    const double2 u = a[i], v = b[i];
+    c[i] = double2{u.x * v.x - u.y * v.y, u.x * v.y + u.y * v.x};
+  }
+}
+
+hipError_t launch_cmul(hipStream_t stream, const double* a, const double* b, double* c, long long n) {
+  if (n <= 0) return hipSuccess;
+  const long long blocks = (n + 255) / 256;
+  hipLaunchKernelGGL(cmul_kernel, dim3((unsigned)(blocks < 65536 ? blocks : 65536)), dim3(256), 0, stream,
+                     reinterpret_cast<const double2*>(a), reinterpret_cast<const double2*>(b), reinterpret_cast<double2*>(c), n);
+  return hipGetLastError();
+}
+
+}  // namespace bms

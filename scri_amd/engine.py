@@ -310,3 +310,39 @@ def cubic_spline(x, y, x_new, ctx=None):
     )
     ctx.check(rc, "bms_cubic_spline")
     return out.reshape((xn.shape[0],) + tail)
+
+
+def spline_derivative(x, y, x_new, order=0, ctx=None):
+    """scipy CubicSpline(x, y, axis=0) differentiated (`order` 1..3) or integrated (`order` -1, -2; zero at x[0]) and
+    evaluated at x_new, for complex y[N, ...]."""
+    ctx = _ctx(ctx)
+    x = np.ascontiguousarray(x, dtype=float)
+    xn = np.ascontiguousarray(x_new, dtype=float)
+    y = _lib.as_c16(y)
+    tail = y.shape[1:]
+    y2 = y.reshape(y.shape[0], -1)
+    out = np.empty((xn.shape[0], y2.shape[1]), dtype=np.complex128)
+    rc = _lib.load().bms_spline_derivative(
+        ctx.handle, dptr(x), x.shape[0], vptr(y2), y2.shape[1], y2.shape[1], BMS_HOST, dptr(xn), xn.shape[0], int(order), vptr(out)
+    )
+    ctx.check(rc, "bms_spline_derivative")
+    return out.reshape((xn.shape[0],) + tail)
+
+
+def grid_multiply(a, spin_a, ell_max_a, b, spin_b, ell_max_b, working_ell_max, output_ell_max, ctx=None):
+    """Modes (l_min = 0) of the product of two spin-weighted functions given by their modes a[N, (la+1)^2], b[N, (lb+1)^2]:
+    synthesis on the (2W+1)^2 grid, pointwise product, analysis up to output_ell_max."""
+    ctx = _ctx(ctx)
+    a = _lib.as_c16(a)
+    b = _lib.as_c16(b)
+    if a.ndim != 2 or b.ndim != 2 or a.shape[0] != b.shape[0]:
+        raise ValueError("mode arrays must be [n_times, n_modes] with equal n_times")
+    if a.shape[1] != (ell_max_a + 1) ** 2 or b.shape[1] != (ell_max_b + 1) ** 2:
+        raise ValueError("mode arrays must start at l = 0 and end at their ell_max")
+    out = np.empty((a.shape[0], (output_ell_max + 1) ** 2), dtype=np.complex128)
+    rc = _lib.load().bms_grid_multiply(
+        ctx.handle, vptr(a), int(spin_a), int(ell_max_a), vptr(b), int(spin_b), int(ell_max_b), BMS_HOST, a.shape[0],
+        int(working_ell_max), int(output_ell_max), vptr(out),
+    )
+    ctx.check(rc, "bms_grid_multiply")
+    return out

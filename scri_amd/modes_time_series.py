@@ -1,0 +1,220 @@
+"""ModesTimeSeries: SWSH modes as functions of time, with the time calculus and the grid product that the BMS-charge
+and super-rest-frame code wraps around the transformation path (scri/modes_time_series.py:7-202; the container
+behaviour it inherits from spherical_functions.Modes: spin_weight / ell_min / ell_max metadata, eth, ethbar, bar).
+
+The arithmetic on the series runs on the GPU through the C ABI: interpolate / derivative / antiderivative ->
+bms_spline_derivative, grid_multiply -> bms_grid_multiply.  The mode-space operators (eth, ethbar, bar) are diagonal
+or permutation maps on the mode axis, applied here with numpy.
+"""
+import copy
+import math
+
+import numpy as np
+
+from . import engine
+from .mode_algebra import LM_index, LM_range, LM_total_size
+
+
+class ModesTimeSeries(np.ndarray):
+    """complex ndarray [..., n_times, n_modes] + {time, spin_weight, ell_min, ell_max}."""
+
+    def __new__(cls, input_array, *args, **kwargs):
+        if len(args) > 2:
+            raise ValueError("Only one positional argument may be passed")
+        if len(args) == 1:
+            kwargs["time"] = args[0]
+        metadata = copy.copy(getattr(input_array, "_metadata", {}))
+        metadata.update(**kwargs)
+        arr = np.asanyarray(input_array).astype(complex, copy=False)
+        time = metadata.get("time", None)
+        if time is None:
+            raise ValueError("Time data must be specified as part of input array or as constructor parameter")
+        time = np.asarray(time, dtype=float)
+        if time.ndim != 1:
+            raise ValueError(f"Input time array must have exactly 1 dimension; it has {time.ndim}.")
+        if arr.ndim == 0:
+            arr = arr[np.newaxis, np.newaxis]
+        elif arr.ndim == 1:
+            arr = arr[np.newaxis, :]
+        elif arr.shape[-2] != time.shape[0] and arr.shape[-2] != 1:
+            raise ValueError(
+                "Second-to-last axis of input array must have size 1 or same size as time array.\n            "
+                f"Their shapes are {arr.shape} and {time.shape}, respectively."
+            )
+        spin_weight = metadata.get("spin_weight", None)
+        if spin_weight is None:
+            raise ValueError("spin_weight must be given")
+        ell_min = int(metadata.get("ell_min", 0))
+        ell_max = metadata.get("ell_max", None)
+        if ell_max is None:
+            ell_max = int(round(math.sqrt(arr.shape[-1] + ell_min**2))) - 1
+        if arr.shape[-1] != LM_total_size(ell_min, int(ell_max)):
+            raise ValueError(f"Last axis has size {arr.shape[-1]}, inconsistent with ell range [{ell_min}, {ell_max}]")
+        obj = arr.view(cls)
+        obj._metadata = dict(metadata)
+        obj._metadata.update(time=time, spin_weight=int(spin_weight), ell_min=ell_min, ell_max=int(ell_max))
+        return obj
+
+    def __array_finalize__(self, obj):
+        if obj is None:
+            return
+        self._metadata = copy.copy(getattr(obj, "_metadata", {}))
+
+    # ------------------------------------------------------------------ metadata
+    @property
+    def time(self):
+        return self._metadata["time"]
+
+    u = time
+    t = time
+
+    @property
+    def n_times(self):
+        return self.time.size
+
+    @property
+    def spin_weight(self):
+        return self._metadata["spin_weight"]
+
+    s = spin_weight
+
+    @property
+    def ell_min(self):
+        return self._metadata["ell_min"]
+
+    @property
+    def ell_max(self):
+        return self._metadata["ell_max"]
+
+    @property
+    def ndarray(self):
+        return self.view(np.ndarray)
+
+    @property
+    def LM(self):
+        return LM_range(self.ell_min, self.ell_max)
+
+    def _like(self, data, **changes):
+        md = dict(self._metadata)
+        md.update(changes)
+        return type(self)(data, **md)
+
+    # ------------------------------------------------------------------ time calculus (modes_time_series.py:72-126)
+    def interpolate(self, new_time, derivative_order=0, out=None):
+        new_time = np.asarray(new_time, dtype=float)
+        if new_time.ndim != 1:
+            raise ValueError(f"New time array must have exactly 1 dimension; it has {new_time.ndim}.")
+        new_shape = self.shape[:-2] + (new_time.size, self.shape[-1])
+        if out is not None:
+            out = np.asarray(out)
+            if out.shape != new_shape:
+                raise ValueError(
+                    f"Output array should have shape {new_shape} for consistency with new time array and modes array"
+                )
+            if out.dtype != complex:
+                raise ValueError(f"Output array should have dtype `complex`; it has dtype {out.dtype}")
+        if derivative_order > 3:
+            raise ValueError(
+                f"{type(self)} interpolation uses CubicSpline, and cannot take a derivative of order {derivative_order}"
+            )
+        if derivative_order < -2:
+            raise NotImplementedError("antiderivatives beyond the second are not provided")
+        data = self.ndarray
+        if data.shape[-2] != self.n_times:
+            raise ValueError("cannot interpolate a time-independent series")
+        # time is the second-to-last axis: move it first for the spline, restore afterwards
+        moved = np.moveaxis(data, -2, 0)
+        res = engine.spline_derivative(self.time, np.ascontiguousarray(moved), new_time, derivative_order)
+        res = np.moveaxis(res, 0, -2)
+        if out is not None:
+            out[:] = res
+            res = out
+        return self._like(res, time=new_time)
+
+    def antiderivative(self, antiderivative_order=1):
+        """Integrate modes with respect to time"""
+        return self.interpolate(self.time, derivative_order=-antiderivative_order)
+
+    def derivative(self, derivative_order=1):
+        """Differentiate modes with respect to time"""
+        return self.interpolate(self.time, derivative_order=derivative_order)
+
+    @property
+    def dot(self):
+        return self.derivative()
+
+    @property
+    def ddot(self):
+        return self.derivative(2)
+
+    @property
+    def int(self):
+        return self.antiderivative()
+
+    @property
+    def iint(self):
+        return self.antiderivative(2)
+
+    # ------------------------------------------------------------------ mode-space operators (sf.Modes)
+    def _ell_factor(self, f):
+        LM = self.LM
+        return np.array([f(int(l)) for l in LM[:, 0]])
+
+    @property
+    def eth(self):
+        """Newman-Penrose eth: x sqrt((l-s)(l+s+1)), spin s -> s+1"""
+        s = self.spin_weight
+        fac = self._ell_factor(lambda l: math.sqrt((l - s) * (l + s + 1)) if l >= abs(s) and l >= abs(s + 1) else 0.0)
+        return self._like(self.ndarray * fac, spin_weight=s + 1)
+
+    @property
+    def ethbar(self):
+        """Newman-Penrose ethbar: x -sqrt((l+s)(l-s+1)), spin s -> s-1"""
+        s = self.spin_weight
+        fac = self._ell_factor(lambda l: -math.sqrt((l + s) * (l - s + 1)) if l >= abs(s) and l >= abs(s - 1) else 0.0)
+        return self._like(self.ndarray * fac, spin_weight=s - 1)
+
+    @property
+    def eth_GHP(self):
+        """Raise spin-weight with GHP convention"""
+        return self._like(self.eth.ndarray / math.sqrt(2), spin_weight=self.spin_weight + 1)
+
+    @property
+    def ethbar_GHP(self):
+        """Lower spin-weight with GHP convention"""
+        return self._like(self.ethbar.ndarray / math.sqrt(2), spin_weight=self.spin_weight - 1)
+
+    @property
+    def bar(self):
+        """Modes of the complex-conjugate function: (-1)^(s+m) conj(a_{l,-m}), spin -s"""
+        s = self.spin_weight
+        d = self.ndarray
+        res = np.empty_like(d)
+        for ell in range(self.ell_min, self.ell_max + 1):
+            for m in range(-ell, ell + 1):
+                res[..., LM_index(ell, m, self.ell_min)] = (-1.0) ** (s + m) * np.conj(d[..., LM_index(ell, -m, self.ell_min)])
+        return self._like(res, spin_weight=-s)
+
+    # ------------------------------------------------------------------ grid product (modes_time_series.py:142-202)
+    def grid_multiply(self, mts, **kwargs):
+        """Mode weights of the product of two functions, formed on a (2 working_ell_max + 1)^2 grid."""
+        output_ell_max = kwargs.pop("output_ell_max", self.ell_max)
+        working_ell_max = kwargs.pop("working_ell_max", self.ell_max + mts.ell_max)
+        if self.n_times != mts.n_times or not np.equal(self.t, mts.t).all():
+            raise ValueError("The time series of objects to be multiplied must be the same.")
+        a, b = self._from_ell_0(), mts._from_ell_0()
+        prod = engine.grid_multiply(
+            a, self.spin_weight, self.ell_max, b, mts.spin_weight, mts.ell_max, working_ell_max, output_ell_max
+        )
+        return type(self)(prod, time=self.t, spin_weight=self.spin_weight + mts.spin_weight, ell_min=0, ell_max=output_ell_max)
+
+    def _from_ell_0(self):
+        """[n_times, (ell_max+1)^2] copy with zeros below ell_min."""
+        d = self.ndarray
+        if d.ndim != 2 or d.shape[0] != self.n_times:
+            raise ValueError("grid_multiply needs a [n_times, n_modes] series")
+        if self.ell_min == 0:
+            return np.ascontiguousarray(d)
+        full = np.zeros((d.shape[0], (self.ell_max + 1) ** 2), dtype=complex)
+        full[:, self.ell_min**2 :] = d
+        return full

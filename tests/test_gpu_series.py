@@ -1,0 +1,107 @@
+"""GPU parity of the time-series calculus and the grid product (bms_spline_derivative, bms_grid_multiply and the
+ModesTimeSeries methods built on them) against the oracle (scipy CubicSpline calculus; oracle salm2map / map2salm)."""
+import numpy as np
+import pytest
+
+from oracle import modes_time_series_ref as mref
+
+pytestmark = pytest.mark.gpu
+
+
+def _series(n, ncols, seed, uniform=False):
+    rng = np.random.default_rng(seed)
+    t = np.linspace(-3.0, 9.0, n) if uniform else np.sort(rng.uniform(-3.0, 9.0, n))
+    if not uniform:
+        t = t + np.arange(n) * 1e-3  # strictly increasing
+    w = rng.uniform(0.3, 2.0, ncols)
+    a = rng.normal(size=ncols) + 1j * rng.normal(size=ncols)
+    y = a[None, :] * np.exp(1j * w[None, :] * t[:, None]) * (1 + 0.05 * t[:, None])
+    return t, y
+
+
+@pytest.mark.parametrize("order", [-2, -1, 0, 1, 2, 3])
+def test_spline_derivative_matches_scipy(ctx, order):
+    from scri_amd import engine
+
+    t, y = _series(700, 37, 11 + order)
+    rng = np.random.default_rng(2)
+    # samples inside, at knots, outside (extrapolation) and in no particular order
+    tn = np.concatenate([rng.uniform(t[0] - 0.05, t[-1] + 0.05, 300), t[::50], [t[0], t[-1]]])
+    rng.shuffle(tn)
+    got = engine.spline_derivative(t, y, tn, order, ctx=ctx)
+    ref = mref.interpolate(t, y, tn, order)
+    scale = max(1.0, np.abs(ref).max())
+    # third derivatives of a spline are piecewise constant and amplify rounding by 1/h^3
+    tol = {3: 2e-8, 2: 2e-10, 1: 5e-12}.get(order, 5e-13)
+    assert np.abs(got - ref).max() < tol * scale, (order, np.abs(got - ref).max() / scale)
+
+
+def test_spline_derivative_long_series_tiles(ctx):
+    # several spline tiles and prefix tiles; antiderivative carried across them
+    from scri_amd import engine
+
+    t, y = _series(5000, 21, 77, uniform=True)
+    tn = np.linspace(t[0], t[-1], 1111)
+    for order in (-2, -1, 1):
+        got = engine.spline_derivative(t, y, tn, order, ctx=ctx)
+        ref = mref.interpolate(t, y, tn, order)
+        assert np.abs(got - ref).max() < 1e-11 * max(1.0, np.abs(ref).max()), order
+
+
+def test_modes_time_series_calculus(ctx):
+    from scri_amd.modes_time_series import ModesTimeSeries
+
+    t, y = _series(400, 21, 5)
+    m = ModesTimeSeries(y, t, spin_weight=-2, ell_min=2, ell_max=4)
+    assert np.abs(m.dot.ndarray - mref.interpolate(t, y, t, 1)).max() < 1e-10
+    assert np.abs(m.ddot.ndarray - mref.interpolate(t, y, t, 2)).max() < 1e-8
+    assert np.abs(m.int.ndarray - mref.interpolate(t, y, t, -1)).max() < 1e-12
+    assert np.abs(m.iint.ndarray - mref.interpolate(t, y, t, -2)).max() < 1e-11
+    tn = np.linspace(t[3], t[-3], 55)
+    mi = m.interpolate(tn)
+    assert mi.n_times == 55 and mi.spin_weight == -2 and mi.ell_min == 2
+    assert np.abs(mi.ndarray - mref.interpolate(t, y, tn, 0)).max() < 1e-12
+    with pytest.raises(ValueError, match="cannot take a derivative of order 4"):
+        m.interpolate(tn, derivative_order=4)
+    # chained operations: derivative of the antiderivative, as the oracle computes it (each step re-fits a spline)
+    back = m.int.dot
+    ref = mref.interpolate(t, mref.interpolate(t, y, t, -1), t, 1)
+    assert np.abs(back.ndarray - ref).max() < 1e-9
+    assert np.abs(back.ndarray[5:-5] - y[5:-5]).max() < 5e-3  # and it undoes the integral up to the spline error
+
+
+@pytest.mark.parametrize("sa,sb,la,lb", [(0, 0, 3, 4), (2, -2, 4, 4), (-1, 2, 3, 5), (1, 1, 2, 2), (-2, 0, 6, 3)])
+def test_grid_multiply_matches_oracle(ctx, sa, sb, la, lb):
+    from scri_amd import engine
+
+    rng = np.random.default_rng(100 + 10 * sa + sb)
+    n = 23
+    a = rng.normal(size=(n, (la + 1) ** 2)) + 1j * rng.normal(size=(n, (la + 1) ** 2))
+    b = rng.normal(size=(n, (lb + 1) ** 2)) + 1j * rng.normal(size=(n, (lb + 1) ** 2))
+    a[:, : sa * sa] = 0
+    b[:, : sb * sb] = 0
+    for W, Lout in ((la + lb, la + lb), (la + lb, la), (max(la, lb), 2)):  # exact, truncated, aliased working grid
+        got = engine.grid_multiply(a, sa, la, b, sb, lb, W, Lout, ctx=ctx)
+        ref = mref.grid_multiply(a, sa, la, b, sb, lb, W, Lout)
+        assert got.shape == ref.shape
+        assert np.abs(got - ref).max() < 2e-13 * max(1.0, np.abs(ref).max()), (W, Lout)
+
+
+def test_modes_time_series_grid_multiply(ctx):
+    from scri_amd.modes_time_series import ModesTimeSeries
+
+    rng = np.random.default_rng(8)
+    t = np.linspace(0, 1, 9)
+    a = rng.normal(size=(9, 21)) + 1j * rng.normal(size=(9, 21))  # l = 2..4, spin -2
+    b = rng.normal(size=(9, 16)) + 1j * rng.normal(size=(9, 16))  # l = 0..3, spin 1
+    b[:, :1] = 0
+    A = ModesTimeSeries(a, t, spin_weight=-2, ell_min=2, ell_max=4)
+    B = ModesTimeSeries(b, t, spin_weight=1, ell_min=0, ell_max=3)
+    P = A.grid_multiply(B)
+    assert (P.spin_weight, P.ell_min, P.ell_max, P.shape) == (-1, 0, 4, (9, 25))
+    a0 = np.zeros((9, 25), dtype=complex)
+    a0[:, 4:] = a
+    ref = mref.grid_multiply(a0, -2, 4, b, 1, 3, 7, 4)
+    assert np.abs(P.ndarray - ref).max() < 2e-13 * np.abs(ref).max()
+    with pytest.raises(ValueError, match="must be the same"):
+        A.grid_multiply(ModesTimeSeries(b, t + 1, spin_weight=1, ell_min=0, ell_max=3))
