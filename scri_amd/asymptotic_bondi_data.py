@@ -96,9 +96,15 @@ class AsymptoticBondiData:
         return abdprime
 
 
+_SPINS = (2, 1, 0, -1, -2, 2)  # psi0..psi4, sigma
+
+
 def _field_property(i):
     def get(self):
-        return self._raw_data[i]
+        # a ModesTimeSeries VIEW of the field (scri/asymptotic_bondi_data/__init__.py:117-216): writes go to _raw_data
+        from .modes_time_series import ModesTimeSeries
+
+        return ModesTimeSeries(self._raw_data[i], self._time, spin_weight=_SPINS[i], ell_min=0, ell_max=self._ell_max)
 
     def set(self, value):
         self._raw_data[i] = value
@@ -108,3 +114,11 @@ def _field_property(i):
 
 for _i, _name in enumerate(_FIELDS):
     setattr(AsymptoticBondiData, _name, _field_property(_i))
+
+
+# BMS charges as methods (scri/asymptotic_bondi_data/__init__.py:235-263 imports them into the class body)
+from . import bms_charges as _bms_charges  # noqa: E402
+
+for _f in _bms_charges.METHODS:
+    setattr(AsymptoticBondiData, _f.__name__, _f)
+AsymptoticBondiData.charge_vector_from_aspect = staticmethod(_bms_charges.charge_vector_from_aspect)

@@ -195,6 +195,71 @@ class ModesTimeSeries(np.ndarray):
                 res[..., LM_index(ell, m, self.ell_min)] = (-1.0) ** (s + m) * np.conj(d[..., LM_index(ell, -m, self.ell_min)])
         return self._like(res, spin_weight=-s)
 
+    @property
+    def real(self):
+        """Modes of the real part of a spin-0 function: (a + bar(a)) / 2 (sf.Modes.real)"""
+        if self.spin_weight != 0:
+            raise ValueError("The real part of a function with non-zero spin weight is not a spin-weighted function")
+        return self._like(0.5 * (self.ndarray + self.bar.ndarray))
+
+    @property
+    def imag(self):
+        if self.spin_weight != 0:
+            raise ValueError("The imaginary part of a function with non-zero spin weight is not a spin-weighted function")
+        return self._like(-0.5j * (self.ndarray - self.bar.ndarray))
+
+    def truncate_ell(self, new_ell_max):
+        """Copy with modes above new_ell_max dropped (sf.Modes.truncate_ell)"""
+        if new_ell_max >= self.ell_max:
+            return self._like(self.ndarray.copy())
+        if new_ell_max < self.ell_min:
+            raise ValueError(f"new ell_max {new_ell_max} is below ell_min {self.ell_min}")
+        return self._like(self.ndarray[..., : LM_total_size(self.ell_min, new_ell_max)].copy(), ell_max=new_ell_max)
+
+    def _combine(self, other, op):
+        """a +- b for two series of the same spin on the same times; the l ranges may differ (missing modes are zero)."""
+        if not isinstance(other, ModesTimeSeries):
+            return self._like(op(self.ndarray, other))
+        if other.spin_weight != self.spin_weight:
+            raise ValueError(f"Cannot add modes with different spin weights ({self.spin_weight} and {other.spin_weight})")
+        lo, hi = min(self.ell_min, other.ell_min), max(self.ell_max, other.ell_max)
+        a = np.zeros(self.shape[:-1] + (LM_total_size(lo, hi),), dtype=complex)
+        b = np.zeros(other.shape[:-1] + (LM_total_size(lo, hi),), dtype=complex)
+        a[..., LM_index(self.ell_min, -self.ell_min, lo) : LM_index(self.ell_max, self.ell_max, lo) + 1] = self.ndarray
+        b[..., LM_index(other.ell_min, -other.ell_min, lo) : LM_index(other.ell_max, other.ell_max, lo) + 1] = other.ndarray
+        return self._like(op(a, b), ell_min=lo, ell_max=hi)
+
+    def __add__(self, other):
+        return self._combine(other, np.add)
+
+    def __sub__(self, other):
+        return self._combine(other, np.subtract)
+
+    def __neg__(self):
+        return self._like(-self.ndarray)
+
+    def __mul__(self, other):
+        if isinstance(other, ModesTimeSeries):
+            return self.multiply(other)
+        return self._like(self.ndarray * other)
+
+    def __rmul__(self, other):
+        return self._like(other * self.ndarray)
+
+    def __truediv__(self, other):
+        if isinstance(other, ModesTimeSeries):
+            raise ValueError("Cannot divide by a mode series")
+        return self._like(self.ndarray / other)
+
+    def multiply(self, other, truncator=None):
+        """Modes of the product (sf.Modes.multiply): exact, formed on a grid fine enough for l_a + l_b, truncated to
+        `truncator((l_a, l_b))` (default: the sum)."""
+        if truncator is None:
+            truncator = sum
+        return self.grid_multiply(
+            other, working_ell_max=self.ell_max + other.ell_max, output_ell_max=int(truncator((self.ell_max, other.ell_max)))
+        )
+
     # ------------------------------------------------------------------ grid product (modes_time_series.py:142-202)
     def grid_multiply(self, mts, **kwargs):
         """Mode weights of the product of two functions, formed on a (2 working_ell_max + 1)^2 grid."""
