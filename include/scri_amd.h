@@ -198,6 +198,13 @@ int bms_spline_derivative(bms_ctx* ctx, const double* x, int64_t n, const void* 
 int bms_grid_multiply(bms_ctx* ctx, const void* a, int spin_a, int ell_max_a, const void* b, int spin_b, int ell_max_b, int mem,
                       int64_t n_times, int working_ell_max, int output_ell_max, void* out);
 
+/* ---- what feeds the rotation path -------------------------------------------------------- */
+/* <Ldt> (f8[n][3]), <LL> (f8[n][3][3]) and the angular velocity omega = -<LL>^-1 <Ldt> (f8[n][3]) of a waveform from its
+ * modes data c16[n][ld] (l = ell_min..ell_max) and their cubic-spline time derivative: LdtVector / LLMatrix /
+ * angular_velocity of scri/mode_calculations.py:46-57, 298-313, 403-432.  Outputs are host arrays; any may be NULL. */
+int bms_angular_velocity(bms_ctx* ctx, const double* t, int64_t n_times, const void* data, int64_t ld, int ell_min, int ell_max,
+                         int mem, double* ldt_out, double* ll_out, double* omega_out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1262,6 +1262,40 @@ extern "C" int bms_spline_derivative(bms_ctx* c, const double* x, int64_t n, con
   return BMS_OK;
 }
 
+// Angular velocity of a waveform from its modes (scri/mode_calculations.py:403-432 with LdtVector :46-57 and LLMatrix
+// :298-313; data_dot = CubicSpline(t, data).derivative()(t), scri/waveform_base.py:690-691 = the spline's knot slopes).
+extern "C" int bms_angular_velocity(bms_ctx* c, const double* t, int64_t n, const void* data, int64_t ld, int ell_min, int ell_max,
+                                    int mem, double* ldt_out, double* ll_out, double* omega_out) {
+  if (!c || !t || !data) return BMS_ERR_INVALID;
+  HIP_TRY(c, hipSetDevice(c->device));
+  if (n < 4) return fail(c, BMS_ERR_UNSUPPORTED, "the time derivative needs at least 4 time steps, got %lld", (long long)n);
+  if (ell_min < 0 || ell_max < ell_min) return fail(c, BMS_ERR_INVALID, "bad ell range");
+  const int n_modes = LM_total_size(ell_min, ell_max);
+  if (ld < n_modes) return fail(c, BMS_ERR_INVALID, "row stride smaller than the number of modes");
+  for (int64_t i = 1; i < n; ++i)
+    if (!(t[i] > t[i - 1])) return fail(c, BMS_ERR_INVALID, "time array must be strictly increasing (index %lld)", (long long)i);
+  int rc;
+  double* d_x;
+  SplineTable* d_tab;
+  if ((rc = upload_times(c, t, n, 0, n, 0, n, &d_x, &d_tab))) return rc;
+  const double* d_y;
+  if ((rc = stage_in(c, "in_data", data, mem, (size_t)n * ld * 16, &d_y))) return rc;
+  double *d_R, *d_S, *d_res;
+  if ((rc = dev_buf_t(c, "R", (size_t)n * ld * 2, &d_R))) return rc;
+  if ((rc = dev_buf_t(c, "S", (size_t)n * ld * 2, &d_S))) return rc;
+  if ((rc = dev_buf_t(c, "av_out", (size_t)n * 15, &d_res))) return rc;
+  hipStream_t S = c->stream;
+  TIMED(c, BMS_TAG_SPLINE_FORWARD, launch_spline_forward(S, d_y, d_R, 2 * ld, n_modes, 0, n, n, d_x, d_tab, SPLINE_TILE, SPLINE_HALO));
+  TIMED(c, BMS_TAG_SPLINE_BACKWARD, launch_spline_slopes(S, d_R, d_S, 2 * ld, n_modes, n, d_tab, SPLINE_TILE, SPLINE_HALO));
+  double *d_ldt = d_res, *d_ll = d_res + 3 * n, *d_om = d_res + 12 * n;
+  TIMED(c, BMS_TAG_POINTWISE, launch_angular_velocity(S, d_y, d_S, 2 * ld, n, ell_min, n_modes, d_ldt, d_ll, d_om));
+  if (ldt_out) HIP_TRY(c, hipMemcpyAsync(ldt_out, d_ldt, sizeof(double) * 3 * n, hipMemcpyDeviceToHost, S));
+  if (ll_out) HIP_TRY(c, hipMemcpyAsync(ll_out, d_ll, sizeof(double) * 9 * n, hipMemcpyDeviceToHost, S));
+  if (omega_out) HIP_TRY(c, hipMemcpyAsync(omega_out, d_om, sizeof(double) * 3 * n, hipMemcpyDeviceToHost, S));
+  HIP_TRY(c, hipStreamSynchronize(S));
+  return BMS_OK;
+}
+
 // ModesTimeSeries.grid_multiply (scri/modes_time_series.py:142-202): both mode sets (l_min = 0) are synthesised on the
 // (2W+1) x (2W+1) equiangular grid, multiplied there, and the product (spin s_a + s_b) is analysed up to output_ell_max.
 extern "C" int bms_grid_multiply(bms_ctx* c, const void* a, int spin_a, int ell_max_a, const void* b, int spin_b, int ell_max_b,

@@ -107,6 +107,11 @@ hipError_t launch_spline_hermite_eval(hipStream_t stream, const double* Y, const
 // c = a * b, n complex numbers
 hipError_t launch_cmul(hipStream_t stream, const double* a, const double* b, double* c, long long n);
 
+// <Ldt> f8[n][3], <LL> f8[n][9], omega = -<LL>^-1 <Ldt> f8[n][3] (any may be null) from modes F and their time
+// derivative Fdot, both c16[n][ld/2] (scri/mode_calculations.py:14-57, 209-313, 403-432)
+hipError_t launch_angular_velocity(hipStream_t stream, const double* F, const double* Fdot, long long ld, long long n_times,
+                                   int ell_min, int n_modes, double* ldt_out, double* ll_out, double* omega_out);
+
 // ---- pointwise helpers
 // Y[t][p] += coeff * Yaux[t][p] * X[t][p]^power,  X = (x_t - alpha_p) * xa_p - xb_p   (waveform_grid.py:516-550)
 hipError_t launch_psi_mix(hipStream_t stream, double* Y, const double* Yaux, long long ld, int n_pix, long long n_rows,

@@ -226,4 +226,129 @@ hipError_t launch_cmul(hipStream_t stream, const double* a, const double* b, dou
   return hipGetLastError();
 }
 
+// ------------------------------------------------------------------------------------------------ angular velocity
+// <Ldt>^a = sum fbar^{l,m'} <l,m'|L_a|l,m> fdot^{l,m}  and  <LL>^{ab} = Re sum fbar^{l,m'} <l,m'|L_a L_b|l,m> f^{l,m}
+// (scri/mode_calculations.py:14-57, 209-313), then omega = -<LL>^{-1} <Ldt> (:403-432).  One wave per time step: the
+// row of modes and of their time derivatives goes to LDS (the ladder terms couple m with m +- 1, m +- 2), each lane sums
+// its modes, the 9 numbers are reduced across the wave and lane 0 solves the 3 x 3 system.
+__device__ __forceinline__ double ladder(int l, int m) { return sqrt((double)((l - m) * (l + m + 1))); }  // sf.ladder_operator_coefficient
+
+__global__ __launch_bounds__(256) void angular_velocity_kernel(const double* __restrict__ F, const double* __restrict__ Fdot,
+                                                               long long ld, long long n_times, int ell_min, int n_modes,
+                                                               double* __restrict__ ldt_out, double* __restrict__ ll_out,
+                                                               double* __restrict__ omega_out) {
+  extern __shared__ double2 rows[];  // [waves][2][n_modes]
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const long long t = (long long)blockIdx.x * (blockDim.x >> 6) + wave;
+  if (t >= n_times) return;
+  double2* f = rows + (size_t)wave * 2 * n_modes;
+  double2* fd = f + n_modes;
+  for (int i = lane; i < n_modes; i += 64) {
+    f[i] = *reinterpret_cast<const double2*>(F + t * ld + 2LL * i);
+    fd[i] = *reinterpret_cast<const double2*>(Fdot + t * ld + 2LL * i);
+  }
+  // (single wave: LDS writes above are visible to its own later reads)
+  double lx = 0, ly = 0, lz = 0, xx = 0, xy = 0, xz = 0, yy = 0, yz = 0, zz = 0;
+  auto cmulc = [](double2 a, double2 b) { return double2{a.x * b.x + a.y * b.y, a.x * b.y - a.y * b.x}; };  // conj(a) b
+  for (int i = lane; i < n_modes; i += 64) {
+    const int k = i + ell_min * ell_min;
+    int l = (int)sqrt((double)k);
+    while (l * l > k) --l;
+    while ((l + 1) * (l + 1) <= k) ++l;
+    const int m = k - l * (l + 1);
+    const double2 a = f[i], ad = fd[i];
+    const double2 zero = {0.0, 0.0};
+    // ---- <Ldt>
+    {
+      const double2 p = m + 1 <= l ? cmulc(f[i + 1], ad) : zero, q = m - 1 >= -l ? cmulc(f[i - 1], ad) : zero;
+      const double cp = m + 1 <= l ? ladder(l, m) : 0.0, cm = m - 1 >= -l ? ladder(l, -m) : 0.0;
+      const double2 Lp = {p.x * cp, p.y * cp}, Lm = {q.x * cm, q.y * cm};
+      const double2 Lz = cmulc(a, ad);
+      lx += 0.5 * (Lp.y + Lm.y);
+      ly += -0.5 * (Lp.x - Lm.x);
+      lz += Lz.y * m;
+    }
+    // ---- <LL>
+    {
+      auto term = [&](bool ok, int j, double c) {
+        if (!ok) return zero;
+        const double2 v = cmulc(f[j], a);
+        return double2{v.x * c, v.y * c};
+      };
+      const double2 LpLp = term(m + 2 <= l, i + 2, m + 2 <= l ? ladder(l, m + 1) * ladder(l, m) : 0.0);
+      const double2 LpLm = term(m - 1 >= -l, i, m - 1 >= -l ? ladder(l, m - 1) * ladder(l, -m) : 0.0);
+      const double2 LmLp = term(m + 1 <= l, i, m + 1 <= l ? ladder(l, -(m + 1)) * ladder(l, m) : 0.0);
+      const double2 LmLm = term(m - 2 >= -l, i - 2, m - 2 >= -l ? ladder(l, -(m - 1)) * ladder(l, -m) : 0.0);
+      const double2 LpLz = term(m + 1 <= l, i + 1, m + 1 <= l ? ladder(l, m) * m : 0.0);
+      const double2 LzLp = term(m + 1 <= l, i + 1, m + 1 <= l ? (m + 1) * ladder(l, m) : 0.0);
+      const double2 LmLz = term(m - 1 >= -l, i - 1, m - 1 >= -l ? ladder(l, -m) * m : 0.0);
+      const double2 LzLm = term(m - 1 >= -l, i - 1, m - 1 >= -l ? (m - 1) * ladder(l, -m) : 0.0);
+      const double LzLz = (a.x * a.x + a.y * a.y) * (double)(m * m);
+      // real parts of the symmetrised (x, y, z) components; -i z has real part Im z
+      const double LxLx = 0.25 * (LpLp.x + LmLm.x + LmLp.x + LpLm.x);
+      const double LyLy = -0.25 * (LpLp.x - LmLp.x - LpLm.x + LmLm.x);
+      const double LxLy_r = 0.25 * (LpLp.y - LmLm.y + LmLp.y - LpLm.y);   // Re(-i/4 (LpLp - LmLm + LmLp - LpLm))
+      const double LyLx_r = 0.25 * (LpLp.y - LmLp.y + LpLm.y - LmLm.y);   // Re(-i/4 (LpLp - LmLp + LpLm - LmLm))
+      const double LxLz_r = 0.5 * (LpLz.x + LmLz.x), LzLx_r = 0.5 * (LzLp.x + LzLm.x);
+      const double LyLz_r = 0.5 * (LpLz.y - LmLz.y), LzLy_r = 0.5 * (LzLp.y - LzLm.y);
+      xx += LxLx;
+      yy += LyLy;
+      zz += LzLz;
+      xy += 0.5 * (LxLy_r + LyLx_r);
+      xz += 0.5 * (LxLz_r + LzLx_r);
+      yz += 0.5 * (LyLz_r + LzLy_r);
+    }
+  }
+  double v[9] = {lx, ly, lz, xx, xy, xz, yy, yz, zz};
+#pragma unroll
+  for (int c = 0; c < 9; ++c)
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v[c] += __shfl_xor(v[c], off, 64);
+  if (lane != 0) return;
+  if (ldt_out) ldt_out[3 * t] = v[0], ldt_out[3 * t + 1] = v[1], ldt_out[3 * t + 2] = v[2];
+  const double A[3][3] = {{v[3], v[4], v[5]}, {v[4], v[6], v[7]}, {v[5], v[7], v[8]}};
+  if (ll_out)
+    for (int r = 0; r < 3; ++r)
+      for (int c = 0; c < 3; ++c) ll_out[9 * t + 3 * r + c] = A[r][c];
+  if (omega_out) {
+    // omega = -A^{-1} l by Gaussian elimination with partial pivoting (numpy.linalg.solve = LAPACK gesv)
+    double M[3][4] = {{A[0][0], A[0][1], A[0][2], -v[0]}, {A[1][0], A[1][1], A[1][2], -v[1]}, {A[2][0], A[2][1], A[2][2], -v[2]}};
+    for (int c = 0; c < 3; ++c) {
+      int piv = c;
+      for (int r = c + 1; r < 3; ++r)
+        if (fabs(M[r][c]) > fabs(M[piv][c])) piv = r;
+      for (int k = 0; k < 4; ++k) {
+        const double tmp = M[c][k];
+        M[c][k] = M[piv][k];
+        M[piv][k] = tmp;
+      }
+      for (int r = c + 1; r < 3; ++r) {
+        const double fct = M[r][c] / M[c][c];
+        for (int k = c; k < 4; ++k) M[r][k] -= fct * M[c][k];
+      }
+    }
+    double x[3];
+    for (int r = 2; r >= 0; --r) {
+      double sum = M[r][3];
+      for (int k = r + 1; k < 3; ++k) sum -= M[r][k] * x[k];
+      x[r] = sum / M[r][r];
+    }
+    omega_out[3 * t] = x[0], omega_out[3 * t + 1] = x[1], omega_out[3 * t + 2] = x[2];
+  }
+}
+
+hipError_t launch_angular_velocity(hipStream_t stream, const double* F, const double* Fdot, long long ld, long long n_times,
+                                   int ell_min, int n_modes, double* ldt_out, double* ll_out, double* omega_out) {
+  if (n_times <= 0) return hipSuccess;
+  const int waves = 4;
+  const size_t lds = (size_t)waves * 2 * n_modes * sizeof(double2);
+  if (lds > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute((const void*)angular_velocity_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+  }
+  hipLaunchKernelGGL(angular_velocity_kernel, dim3((unsigned)((n_times + waves - 1) / waves)), dim3(64 * waves), lds, stream, F,
+                     Fdot, ld, n_times, ell_min, n_modes, ldt_out, ll_out, omega_out);
+  return hipGetLastError();
+}
+
 }  // namespace bms

@@ -346,3 +346,21 @@ def grid_multiply(a, spin_a, ell_max_a, b, spin_b, ell_max_b, working_ell_max, o
     )
     ctx.check(rc, "bms_grid_multiply")
     return out
+
+
+def angular_velocity(t, data, ell_min, ell_max, ctx=None, parts=False):
+    """omega[N, 3] = -<LL>^-1 <Ldt> of modes data[N, n_modes]; parts=True returns (<Ldt>[N, 3], <LL>[N, 3, 3], omega)."""
+    ctx = _ctx(ctx)
+    t = np.ascontiguousarray(t, dtype=float)
+    data = _lib.as_c16(data)
+    n = t.shape[0]
+    if data.shape != (n, LM_total_size(ell_min, ell_max)):
+        raise ValueError(f"data shape {data.shape} inconsistent with {n} time steps and ell range [{ell_min}, {ell_max}]")
+    ldt = np.empty((n, 3))
+    ll = np.empty((n, 3, 3))
+    om = np.empty((n, 3))
+    rc = _lib.load().bms_angular_velocity(
+        ctx.handle, dptr(t), n, vptr(data), data.shape[1], int(ell_min), int(ell_max), BMS_HOST, dptr(ldt), dptr(ll), dptr(om)
+    )
+    ctx.check(rc, "bms_angular_velocity")
+    return (ldt, ll, om) if parts else om

@@ -142,6 +142,38 @@ class WaveformModes:
         W._append_history(f"{W} = {self}.interpolate({tprime})")
         return W
 
+    # time calculus of the mode data (scri/waveform_base.py:689-703): cubic-spline derivatives / antiderivatives on the GPU
+    @property
+    def data_dot(self):
+        return engine.spline_derivative(self.t, self.data, self.t, 1, ctx=self._ctx)
+
+    @property
+    def data_ddot(self):
+        return engine.spline_derivative(self.t, self.data, self.t, 2, ctx=self._ctx)
+
+    @property
+    def data_int(self):
+        return engine.spline_derivative(self.t, self.data, self.t, -1, ctx=self._ctx)
+
+    @property
+    def data_iint(self):
+        return engine.spline_derivative(self.t, self.data, self.t, -2, ctx=self._ctx)
+
+    def LdtVector(self):
+        from . import mode_calculations
+
+        return mode_calculations.LdtVector(self)
+
+    def LLMatrix(self):
+        from . import mode_calculations
+
+        return mode_calculations.LLMatrix(self)
+
+    def angular_velocity(self, include_frame_velocity=False):
+        from . import mode_calculations
+
+        return mode_calculations.angular_velocity(self, include_frame_velocity)
+
     def _allclose(self, other, rtol=1e-05, atol=1e-08):
         return (
             np.allclose(self.t, other.t, rtol=rtol, atol=atol)
