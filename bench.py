@@ -86,11 +86,18 @@ def main():
 
     from scri_amd import _lib, engine, synthetic, sharding
 
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # SCRI_AMD_BENCH_BACKEND=gloo: dry run of the multi-rank path on a box with fewer GPUs than ranks (ranks share
+    # devices, halos travel through the host); the measured configuration is nccl = RCCL, one rank per GPU
+    backend = os.environ.get("SCRI_AMD_BENCH_BACKEND", "nccl")
+    dev_index = local_rank if backend == "nccl" else local_rank % max(torch.cuda.device_count(), 1)
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     spec = dict(synthetic.CONFIGS[args.workload])
     spec["name"] = args.workload
@@ -123,7 +130,7 @@ def main():
         out = torch.empty((own, n_modes), dtype=torch.complex128, device=dev)
     local = torch.from_numpy(local_host).to(dev)
     del local_host
-    ctx = _lib.Context(local_rank)
+    ctx = _lib.Context(dev_index)
     ctx.enable_timing(True)
 
     def step():
@@ -160,7 +167,7 @@ def main():
     elapsed = time.perf_counter() - t0
     timing = ctx.get_timing(reset=True)
 
-    el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    el = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
     if world > 1:
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
     elapsed = float(el.item())

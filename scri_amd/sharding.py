@@ -32,6 +32,11 @@ def exchange_halos(local, have, need, all_have, all_need, group=None, dim=0):
     is_complex = local.is_complex()
     if dim != 0:
         local = local.movedim(dim, 0)
+    # gloo moves host memory only: device tensors take a round trip through the host (dry runs of the multi-rank
+    # path on a box without RCCL peers; the production backend is nccl = RCCL, device to device)
+    device = local.device
+    if device.type != "cpu" and dist.get_backend(group) == "gloo":
+        local = local.cpu()
     loc = torch.view_as_real(local) if is_complex else local
     out_shape = (need[1] - need[0],) + tuple(loc.shape[1:])
     out = torch.empty(out_shape, dtype=loc.dtype, device=loc.device)
@@ -59,6 +64,8 @@ def exchange_halos(local, have, need, all_have, all_need, group=None, dim=0):
     for a, b, buf in recv_bufs:
         out[a - need[0] : b - need[0]] = buf
     out = torch.view_as_complex(out) if is_complex else out
+    if out.device != device:
+        out = out.to(device)
     return out.movedim(0, dim).contiguous() if dim != 0 else out
 
 
