@@ -38,6 +38,8 @@ struct DevBuf {
 struct AnalysisPlan {
   bool separable = true;
   bool fused = false;  // single-kernel analysis (kernels_analysis.hip, analysis_fused_kernel)
+  bool large = false;  // folded phi-DFT + MFMA theta quadrature for grids too large for the fused kernel
+  int ell_min_out = 0;
   double* d_dcs = nullptr;
   int n_theta = 0, n_phi = 0, n_pix = 0, n_out = 0, L = 0, nm = 0;
   // separable
@@ -638,7 +640,7 @@ static int upload(bms_ctx* c, const char* name, const void* host, size_t bytes, 
 static int build_analysis(bms_ctx* c, const char* tag, int n_theta, int n_phi, int spin, int ell_min_out, int ell_max_out,
                           AnalysisPlan& A) {
   hipStream_t S = c->stream;
-  const std::array<int, 6> key = {n_theta, n_phi, spin, ell_min_out, ell_max_out, getenv("SCRI_AMD_NO_FUSED_ANALYSIS") ? 1 : 0};
+  const std::array<int, 6> key = {n_theta, n_phi, spin, ell_min_out, ell_max_out, (getenv("SCRI_AMD_NO_FUSED_ANALYSIS") ? 1 : 0) + (getenv("SCRI_AMD_NO_LARGE_ANALYSIS") ? 2 : 0)};
   {
     auto it = c->plans.find(tag);
     if (it != c->plans.end() && it->second.first == key && !getenv("SCRI_AMD_NO_PLAN_CACHE")) {
@@ -660,8 +662,13 @@ static int build_analysis(bms_ctx* c, const char* tag, int n_theta, int n_phi, i
   void* vp;
   char nm_[64];
   A.fused = A.separable && fused_analysis_supported(n_theta, n_phi, A.L, A.n_out) && !getenv("SCRI_AMD_NO_FUSED_ANALYSIS");
+  A.large = A.separable && !A.fused && large_analysis_supported(n_theta, n_phi, A.L) && !getenv("SCRI_AMD_NO_LARGE_ANALYSIS") &&
+            !getenv("SCRI_AMD_NO_FUSED_ANALYSIS");
+  A.ell_min_out = ell_min_out;
   if (A.separable) {
-    if (A.fused) {
+    if (A.large) {
+      // twiddles are computed in the kernel; only the theta table below is needed
+    } else if (A.fused) {
       const size_t nd = fused_dft_table_size(n_phi, A.L);
       snprintf(nm_, sizeof nm_, "dcs_%d_%d", n_phi, A.L);
       if ((rc = dev_buf_t(c, nm_, nd, &A.d_dcs))) return rc;
@@ -737,6 +744,12 @@ static int run_analysis(bms_ctx* c, const AnalysisPlan& A, const double* d_G, lo
   if (A.fused) {
     TIMED(c, BMS_TAG_ANALYSIS_FUSED, launch_analysis_fused(S, d_G, P2, rows, A.n_theta, A.n_phi, A.L, A.n_out, A.d_mindex, A.d_T,
                                                            A.d_dcs, d_out, ldo, col_of_pixel));
+  } else if (A.large) {
+    if (col_of_pixel) return fail(c, BMS_ERR_UNSUPPORTED, "internal: sorted columns need the fused analysis");
+    double* d_F;
+    int rc = dev_buf_t(c, "Fphi", (size_t)rows * A.nm * large_analysis_jp(A.n_theta) * 2, &d_F);
+    if (rc) return rc;
+    TIMED(c, BMS_TAG_GEMM_ANALYSIS, launch_analysis_large(S, d_G, P2, rows, A.n_theta, A.n_phi, A.L, A.ell_min_out, A.d_T, d_F, d_out, ldo));
   } else if (A.separable) {
     if (col_of_pixel) return fail(c, BMS_ERR_UNSUPPORTED, "internal: sorted columns need the fused analysis");
     double* d_F;

@@ -51,6 +51,12 @@ hipError_t launch_theta_table(hipStream_t stream, const double* Y, const double*
 hipError_t launch_theta_quadrature(hipStream_t stream, const double* F, long long n_rows, int n_theta, int nm, int n_out,
                                    const int* m_index, const double* T, double* out, long long ldo);
 constexpr int MAX_THETA_SEPARABLE = 104;
+// large grids (40 < n_theta <= 104): folded phi-DFT to F[t][m][jp] (jp = large_analysis_jp(n_theta) rings), then the theta
+// quadrature as MFMA products batched over time; T from launch_theta_table; F: n_rows * (2L+1) * jp complex of work space
+int large_analysis_supported(int n_theta, int n_phi, int L);
+int large_analysis_jp(int n_theta);
+hipError_t launch_analysis_large(hipStream_t stream, const double* G, long long ldg, long long n_rows, int n_theta, int n_phi,
+                                 int L, int ell_min_out, const double* T, double* F, double* out, long long ldo);
 // fused single-kernel analysis (n_theta <= 40, n_out <= 1024): D = cos|sin DFT matrix [4 ks][pd] from launch_dft_cs_matrix
 struct FusedGeom;
 int fused_analysis_supported(int n_theta, int n_phi, int L, int n_out);

@@ -437,4 +437,233 @@ hipError_t launch_analysis_fused(hipStream_t stream, const double* G, long long 
 #undef FUSED_GO
 }
 
+// =====================================================================================================================
+// Large grids (n_theta > 40: the ABD working grids, 99 x 99 at l_max = 24): the row of one time step no longer fits a
+// workgroup's LDS next to its Fourier coefficients, so the two steps are two kernels with F[t][m][ring] in HBM between
+// them -- but with the same arithmetic as the fused kernel: phi-folded cos/sin products on the MFMA pipe with the
+// twiddles held in REGISTERS for the whole kernel, +-m recombined in registers, and the theta quadrature as MFMA
+// products batched over time with the quadrature table of one m in registers.
+// =====================================================================================================================
+
+// ---- step 1: F[t][mi][ring] = sum_k G[t][ring][k] exp(-i m phi_k).  One wave per (time step, tile of 8 rings).
+template <int KS, int NTC>
+__global__ __launch_bounds__(64) void phi_dft_folded_kernel(const double* __restrict__ G, long long ldg, long long n_rows,
+                                                            int n_theta, int n_phi, int L, int jp, double* __restrict__ F) {
+  constexpr int PA = 4 * KS + 2;  // 2 x odd: conflict-free fragment reads
+  __shared__ double Es[16 * PA], Os[16 * PA];
+  extern __shared__ double2 Ft[];  // [2L+1][8] tile of F
+  const int lane = threadIdx.x, fi = lane & 15, fk = lane >> 4;
+  const int nk = n_phi / 2 + 1, mt = (n_theta + 7) / 8, nm = 2 * L + 1;
+  // twiddles of this lane's B fragments: cos / sin (m phi_k), k = 4 s + fk, m = 16 n + fi + 1
+  double bc[KS][NTC], bs[KS][NTC];
+#pragma unroll
+  for (int s = 0; s < KS; ++s)
+#pragma unroll
+    for (int n = 0; n < NTC; ++n) {
+      const int k = 4 * s + fk, m = 16 * n + fi + 1;
+      double sn = 0.0, co = 0.0;
+      if (k < nk && m <= L) sincospi(2.0 * (double)(((long long)m * k) % n_phi) / (double)n_phi, &sn, &co);
+      bc[s][n] = co, bs[s][n] = sn;
+    }
+  for (int e = lane; e < 16 * PA; e += 64) Es[e] = Os[e] = 0.0;
+  const long long n_items = n_rows * mt;
+  for (long long item = blockIdx.x; item < n_items; item += gridDim.x) {
+    const long long t = item / mt;
+    const int rt = (int)(item - t * mt);
+    const int rings = n_theta - 8 * rt < 8 ? n_theta - 8 * rt : 8;
+    const double* g = G + t * ldg + 2LL * (8 * rt) * n_phi;
+    // ---- fold 8 rings into the operands (row g + 8 h (+4 for Im) holds ring g + 4 h of the tile)
+    for (int e = lane; e < 8 * nk; e += 64) {
+      const int r = e / nk, kk = e - r * nk;
+      double2 a = {0.0, 0.0}, b = {0.0, 0.0};
+      double wb = 0.0;
+      if (r < rings) {
+        const int k2 = kk == 0 ? 0 : n_phi - kk;
+        a = *reinterpret_cast<const double2*>(g + 2LL * (r * n_phi + kk));
+        if (k2 != kk) {
+          b = *reinterpret_cast<const double2*>(g + 2LL * (r * n_phi + k2));
+          wb = 1.0;
+        }
+      }
+      const int row = (r & 3) + 8 * (r >> 2);
+      Es[row * PA + kk] = a.x + b.x;
+      Es[(row + 4) * PA + kk] = a.y + b.y;
+      Os[row * PA + kk] = wb * (a.x - b.x);
+      Os[(row + 4) * PA + kk] = wb * (a.y - b.y);
+    }
+    // (one wave: its LDS writes are visible to its own reads in program order)
+    v4d_t ac[NTC], as[NTC];
+#pragma unroll
+    for (int n = 0; n < NTC; ++n) ac[n] = as[n] = v4d_t{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      const double ae = Es[fi * PA + 4 * s + fk], ao = Os[fi * PA + 4 * s + fk];
+#pragma unroll
+      for (int n = 0; n < NTC; ++n) {
+        ac[n] = __builtin_amdgcn_mfma_f64_16x16x4f64(ae, bc[s][n], ac[n], 0, 0, 0);
+        as[n] = __builtin_amdgcn_mfma_f64_16x16x4f64(ao, bs[s][n], as[n], 0, 0, 0);
+      }
+    }
+    // m = 0: plain sums of the folded rows
+    if (fk == 0) {
+      double c0 = 0.0, c1 = 0.0;
+#pragma unroll
+      for (int k = 0; k < 4 * KS; k += 2) {
+        c0 += Es[fi * PA + k];
+        c1 += Es[fi * PA + k + 1];
+      }
+      const int ring = (fi & 3) + 4 * (fi >> 3), part = (fi >> 2) & 1;
+      reinterpret_cast<double*>(Ft + L * 8 + ring)[part] = c0 + c1;
+    }
+#pragma unroll
+    for (int n = 0; n < NTC; ++n) {
+      const int m = 16 * n + fi + 1;
+      if (m <= L) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int ring = fk + 4 * h;
+          const double cre = ac[n][2 * h], cim = ac[n][2 * h + 1], sre = as[n][2 * h], sim = as[n][2 * h + 1];
+          Ft[(L + m) * 8 + ring] = double2{cre + sim, cim - sre};
+          Ft[(L - m) * 8 + ring] = double2{cre - sim, cim + sre};
+        }
+      }
+    }
+    // ---- the tile goes out as 128-byte pieces: F[t][mi][8 rt .. 8 rt + 7]
+    double* f = F + ((t * nm) * (long long)jp + 8 * rt) * 2;
+    for (int e = lane; e < nm * 8; e += 64) {
+      const int mi = e >> 3, r = e & 7;
+      if (r < rings) *reinterpret_cast<double2*>(f + ((long long)mi * jp + r) * 2) = Ft[e];
+    }
+  }
+}
+
+// ---- step 2: out[t][(l, m)] = sum_j T[(l,m)][j] F[t][m][j].  Workgroup = (m, block of time steps); the quadrature
+// table of that m sits in registers as MFMA B fragments; a wave multiplies 8 time steps (16 real rows) per trip.
+template <int KQ, int NTQ>
+__global__ __launch_bounds__(256) void theta_quadrature_mfma_kernel(const double* __restrict__ F, long long n_rows, int n_theta,
+                                                                    int L, int jp, int ell_min_out, int rows_per_block,
+                                                                    const double* __restrict__ T, double* __restrict__ out,
+                                                                    long long ldo) {
+  constexpr int PQ = 4 * KQ + 2;  // 2 x odd
+  __shared__ double As[4][16 * PQ];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, fi = lane & 15, fk = lane >> 4;
+  const int mi = blockIdx.x, m = mi - L, nm = 2 * L + 1;
+  const int am = m < 0 ? -m : m;
+  const int l0 = am > ell_min_out ? am : ell_min_out;  // first l of this m
+  // B fragments: T[(l0 + 16 n + fi, m)][4 s + fk]
+  double bq[KQ][NTQ];
+#pragma unroll
+  for (int n = 0; n < NTQ; ++n) {
+    const int l = l0 + 16 * n + fi;
+    const long long o = (long long)l * (l + 1) - (long long)ell_min_out * ell_min_out + m;
+#pragma unroll
+    for (int s = 0; s < KQ; ++s) {
+      const int j = 4 * s + fk;
+      bq[s][n] = (l <= L && j < n_theta) ? T[o * n_theta + j] : 0.0;
+    }
+  }
+  double* A = As[wave];
+  for (int e = lane; e < 16 * PQ; e += 64) A[e] = 0.0;
+  const long long t_begin = (long long)blockIdx.y * rows_per_block;
+  long long t_end = t_begin + rows_per_block;
+  if (t_end > n_rows) t_end = n_rows;
+  for (long long t0 = t_begin + 8 * wave; t0 < t_end; t0 += 32) {
+    // ---- 8 time steps of F[.][mi][0 .. jp) into the operand: row g + 8 h (+4 for Im) holds time step t0 + g + 4 h
+    for (int e = lane; e < 8 * jp; e += 64) {
+      const int r = e / jp, j = e - r * jp;
+      double2 v = {0.0, 0.0};
+      if (t0 + r < t_end && j < n_theta) v = *reinterpret_cast<const double2*>(F + (((t0 + r) * nm + mi) * (long long)jp + j) * 2);
+      const int row = (r & 3) + 8 * (r >> 2);
+      if (j < 4 * KQ) {  // jp may exceed the operand width; those rings carry no weight
+        A[row * PQ + j] = v.x;
+        A[(row + 4) * PQ + j] = v.y;
+      }
+    }
+    v4d_t acc[NTQ];
+#pragma unroll
+    for (int n = 0; n < NTQ; ++n) acc[n] = v4d_t{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int s = 0; s < KQ; ++s) {
+      const double a = A[fi * PQ + 4 * s + fk];
+#pragma unroll
+      for (int n = 0; n < NTQ; ++n) acc[n] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bq[s][n], acc[n], 0, 0, 0);
+    }
+    // results r = 2h (re), 2h+1 (im) of time step t0 + fk + 4 h, column l = l0 + 16 n + fi
+#pragma unroll
+    for (int n = 0; n < NTQ; ++n) {
+      const int l = l0 + 16 * n + fi;
+      if (l <= L) {
+        const long long o = (long long)l * (l + 1) - (long long)ell_min_out * ell_min_out + m;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const long long t = t0 + fk + 4 * h;
+          if (t < t_end) *reinterpret_cast<double2*>(out + t * ldo + 2 * o) = double2{acc[n][2 * h], acc[n][2 * h + 1]};
+        }
+      }
+    }
+  }
+}
+
+int large_analysis_supported(int n_theta, int n_phi, int L) {
+  const int ks = (n_phi / 2 + 1 + 3) / 4;
+  return n_theta <= 104 && ks <= 16 && L >= 1 && L <= 32;
+}
+int large_analysis_jp(int n_theta) { return ((n_theta + 7) / 8) * 8; }
+
+hipError_t launch_analysis_large(hipStream_t stream, const double* G, long long ldg, long long n_rows, int n_theta, int n_phi,
+                                 int L, int ell_min_out, const double* T, double* F, double* out, long long ldo) {
+  if (n_rows <= 0) return hipSuccess;
+  const int jp = large_analysis_jp(n_theta), nm = 2 * L + 1;
+  const int ks = (n_phi / 2 + 1 + 3) / 4;
+  const int mt = (n_theta + 7) / 8;
+  const size_t lds1 = sizeof(double2) * (size_t)nm * 8;
+  const long long items = n_rows * mt;
+  const unsigned grid1 = (unsigned)(items < 256 * 16 ? items : 256 * 16);
+#define DFT_GO(KS, NTC)                                                                                              \
+  hipLaunchKernelGGL((phi_dft_folded_kernel<KS, NTC>), dim3(grid1), dim3(64), lds1, stream, G, ldg, n_rows, n_theta, n_phi, L, jp, F)
+#define DFT_KS(NTC)      \
+  if (ks <= 7)           \
+    DFT_GO(7, NTC);      \
+  else if (ks <= 10)     \
+    DFT_GO(10, NTC);     \
+  else if (ks <= 13)     \
+    DFT_GO(13, NTC);     \
+  else                   \
+    DFT_GO(16, NTC);
+  if (L <= 16) {
+    DFT_KS(1)
+  } else {
+    DFT_KS(2)
+  }
+#undef DFT_KS
+#undef DFT_GO
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return e;
+  const int kq = (n_theta + 3) / 4;
+  const int rows_per_block = 512;
+  const dim3 grid2(nm, (unsigned)((n_rows + rows_per_block - 1) / rows_per_block));
+  // columns of one m: l = max(|m|, ell_min_out) .. L, at most L + 1 - ell_min_out
+  const int ntq = (L + 1 - ell_min_out + 15) / 16;
+#define TQ_GO(KQ, NTQ)                                                                                                     \
+  hipLaunchKernelGGL((theta_quadrature_mfma_kernel<KQ, NTQ>), grid2, dim3(256), 0, stream, F, n_rows, n_theta, L, jp, ell_min_out, \
+                     rows_per_block, T, out, ldo)
+#define TQ_KQ(NTQ)   \
+  if (kq <= 11)      \
+    TQ_GO(11, NTQ);  \
+  else if (kq <= 18) \
+    TQ_GO(18, NTQ);  \
+  else               \
+    TQ_GO(26, NTQ);
+  if (ntq <= 1) {
+    TQ_KQ(1)
+  } else if (ntq == 2) {
+    TQ_KQ(2)
+  } else {
+    TQ_KQ(3)
+  }
+#undef TQ_KQ
+#undef TQ_GO
+  return hipGetLastError();
+}
+
 }  // namespace bms

@@ -68,6 +68,22 @@ def test_dense_quadrature_path_for_very_fine_grids(ctx):
     assert np.abs(engine.map2salm(f, -1, 4, ctx=ctx) - spinsfast_ref.map2salm(f, -1, 4)).max() < 1e-12
 
 
+@pytest.mark.parametrize("n_theta,n_phi,spin,ell_max,ell_min", [(45, 47, -2, 9, 2), (99, 99, 2, 24, 0), (64, 50, 0, 16, 0), (41, 96, -1, 20, 1), (104, 104, 1, 32, 0), (57, 60, -2, 3, 2)])
+def test_large_grid_analysis_variants(ctx, monkeypatch, n_theta, n_phi, spin, ell_max, ell_min):
+    """40 < n_theta <= 104: folded phi-DFT kernel + MFMA theta quadrature (odd and even rings, every template branch);
+    the older phi-DFT GEMM + theta_quadrature_kernel pair stays reachable and must agree."""
+    from scri_amd import engine
+
+    rng = np.random.default_rng(n_theta + n_phi)
+    f = rng.normal(size=(21, n_theta, n_phi)) + 1j * rng.normal(size=(21, n_theta, n_phi))
+    ref = spinsfast_ref.map2salm(f, spin, ell_max)[..., ell_min**2 :]
+    got = engine.map2salm(f, spin, ell_max, ell_min=ell_min, ctx=ctx)
+    assert np.abs(got - ref).max() < 2e-13 * max(1.0, np.abs(ref).max())
+    monkeypatch.setenv("SCRI_AMD_NO_LARGE_ANALYSIS", "1")
+    old = engine.map2salm(f, spin, ell_max, ell_min=ell_min, ctx=ctx)
+    assert np.abs(old - ref).max() < 2e-13 * max(1.0, np.abs(ref).max())
+
+
 def test_large_boost_wide_skew_and_chunks(ctx):
     import scri_amd
 
