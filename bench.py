@@ -59,6 +59,53 @@ def cpu_baseline(spec, n_sample):
     }
 
 
+def rotation_line(local, ell_max, ctx, cpu_steps):
+    """Secondary measurement (configs[0] of BASELINE.json at the cfg3 size): in-place time-series rotation of the resident
+    modes by one rotor per time step (scri/rotations.py:370-392), HIP-event kernel time against the HBM roofline
+    (read + write the modes once: 2 x 16 n_modes + 32 B per step), with the scalar C port of the numba kernel beside it."""
+    import torch
+
+    from scri_amd import engine
+
+    n, nm = local.shape
+    rng = np.random.default_rng(0)
+    R = rng.normal(size=(n, 4))
+    R /= np.linalg.norm(R, axis=1)[:, None]
+    sp_host = np.stack([R[:, 0] + 1j * R[:, 3], R[:, 2] + 1j * R[:, 1]], axis=1)
+    sp = torch.from_numpy(sp_host).to(local.device)
+    data = local.clone()
+    for _ in range(3):
+        engine.rotate_device(data.data_ptr(), n, nm, 2, ell_max, spinors_ptr=sp.data_ptr(), ctx=ctx)
+    ctx.synchronize()
+    ctx.get_timing(reset=True)
+    reps = 10
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        engine.rotate_device(data.data_ptr(), n, nm, 2, ell_max, spinors_ptr=sp.data_ptr(), ctx=ctx)
+    ctx.synchronize()
+    wall = (time.perf_counter() - t0) / reps
+    ms = ctx.get_timing(reset=True)["rotate"][0] / reps
+    bytes_per_step = 2 * 16 * nm + 32
+    out = {
+        "metric": "timesteps/s, time-series rotation of modes in HBM",
+        "value": n / wall,
+        "kernel_ms": ms,
+        "roofline": {"bound": "hbm", "achieved": n * bytes_per_step / (ms * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
+                     "frac": n * bytes_per_step / (ms * 1e-3) / 8e12, "bytes_per_step": bytes_per_step},
+    }
+    if cpu_steps > 0:
+        from oracle import rotate_port
+
+        ns = min(cpu_steps, n)
+        d = np.ascontiguousarray(local[:ns].cpu().numpy())
+        t0 = time.perf_counter()
+        rotate_port.rotate_by_series(d, np.ascontiguousarray(sp_host[:ns]), 2, ell_max)
+        dt = time.perf_counter() - t0
+        out["cpu_baseline"] = {"value": ns / dt, "unit": "timesteps/s", "cores": 1, "kind": "port",
+                               "sample": f"{ns} steps, oracle/rotate_port.c (scalar C port of the numba kernel incl. per-step Wigner-D), {dt:.1f} s"}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -229,6 +276,8 @@ def main():
         }
         if world == 1 and args.cpu_sample > 0 and not abd:
             line["cpu_baseline"] = cpu_baseline(spec, args.cpu_sample)
+        if world == 1 and not abd:
+            line["rotation"] = rotation_line(local, ell_max, ctx, 3000 if args.cpu_sample > 0 else 0)
         print(json.dumps(line))
     if world > 1:
         dist.barrier()
