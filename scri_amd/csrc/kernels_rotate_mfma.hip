@@ -33,7 +33,7 @@ struct RotGeom {
 };
 
 template <int MAXNT>
-__global__ __launch_bounds__(256) void rotate_modes_mfma_kernel(double* __restrict__ data, long long n_times, long long ld,
+__global__ __launch_bounds__(256, 2) void rotate_modes_mfma_kernel(double* __restrict__ data, long long n_times, long long ld,
                                                                 int ell_min, int ell_max, const double* __restrict__ RaRb,
                                                                 long long rotor_stride, const double* __restrict__ btab,
                                                                 const long long* __restrict__ boff, RotGeom geo) {
@@ -88,6 +88,21 @@ __global__ __launch_bounds__(256) void rotate_modes_mfma_kernel(double* __restri
     pN[r] = cpow_unit(p2, -ell_min);
   }
 
+  // rows of the next l are requested while the products of the current one run (PF: a quarter row fits the registers)
+  constexpr bool PF = MAXNT <= 3;
+  constexpr int PFN = PF ? 4 * MAXNT : 1;
+  double2 fpre[PFN];
+  auto prefetch = [&](int ell) {
+    const int n = 2 * ell + 1, kpad = 4 * ((n + 3) / 4), cq = (kpad + 3) / 4;
+    const double* src = data + (tg * ld + ((long long)ell * ell - (long long)ell_min * ell_min)) * 2;
+#pragma unroll
+    for (int u = 0; u < PFN; ++u) {
+      const int c = q * cq + u;
+      fpre[u] = (live && u < cq && c < n) ? *reinterpret_cast<const double2*>(src + 2 * c) : double2{0.0, 0.0};
+    }
+  };
+  if (PF) prefetch(ell_min);
+
   for (int ell = ell_min; ell <= ell_max; ++ell) {
     const int n = 2 * ell + 1;
     const int kpad = 4 * ((n + 3) / 4);
@@ -104,7 +119,19 @@ __global__ __launch_bounds__(256) void rotate_modes_mfma_kernel(double* __restri
     }
     // ---- stage rows: f_m' p1^m' -> A image (Re row tl, Im row 64 + tl); pad columns zeroed.
     // All loads of a thread are issued before the dependent phase products (one memory latency per l, not per element).
-    {
+    if (PF) {
+      const int cq = (kpad + 3) / 4;
+      cplx w = cpow_unit(p1, q * cq - ell);
+#pragma unroll
+      for (int u = 0; u < PFN; ++u) {
+        const int c = q * cq + u;
+        if (u < cq && c < kpad) {
+          As[tl * geo.pa + c] = fpre[u].x * w.re - fpre[u].y * w.im;
+          As[(64 + tl) * geo.pa + c] = fpre[u].x * w.im + fpre[u].y * w.re;
+        }
+        w = cmul(w, p1);
+      }
+    } else {
       const int cq = (kpad + 3) / 4;
       const int c_lo = q * cq, c_hi = (c_lo + cq < kpad) ? c_lo + cq : kpad;
       const double* src = data + (tg * ld + col0) * 2;
@@ -128,6 +155,7 @@ __global__ __launch_bounds__(256) void rotate_modes_mfma_kernel(double* __restri
       }
     }
     __syncthreads();
+    if (PF && ell < ell_max) prefetch(ell + 1);
     // ---- two wave-local products, in place in the A image
 #pragma unroll 1
     for (int stage = 0; stage < 2; ++stage) {
