@@ -1028,7 +1028,6 @@ extern "C" int bms_transform_modes_shard(bms_ctx* c, const bms_wm_input* in, con
   if (first_index_out) *first_index_out = i_lo;
   const int64_t n_new = i_hi - i_lo;
   *n_times_out = n_new;
-  for (int64_t i = 0; i < n_new; ++i) t_out[i] = (1 / T.gamma) * (in->t[i_lo + i] - T.tt);
   if (n_new == 0) return BMS_OK;
   double *d_rot = DP.rotors, *d_off = DP.col_off, *d_scale = DP.col_scale, *d_skewa = DP.skew_a, *d_skewb = DP.skew_b;
   double *d_alpha = DP.alpha, *d_xa = DP.xa, *d_xb = DP.xb, *d_x;
@@ -1126,6 +1125,8 @@ extern "C" int bms_transform_modes_shard(bms_ctx* c, const bms_wm_input* in, con
   trace.mark("chunk loop (enqueue)");
   if (in->mem == BMS_HOST)
     HIP_TRY(c, hipMemcpyAsync(data_out, d_out, (size_t)n_new * n_out * 16, hipMemcpyDeviceToHost, S));
+  // the new time axis is host work: done while the GPU runs
+  for (int64_t i = 0; i < n_new; ++i) t_out[i] = (1 / T.gamma) * (in->t[i_lo + i] - T.tt);
   // host tables above are stack/vector memory: wait for the uploads (and results) before returning
   HIP_TRY(c, hipStreamSynchronize(S));
   trace.mark("final synchronize");
