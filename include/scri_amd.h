@@ -205,6 +205,12 @@ int bms_grid_multiply(bms_ctx* ctx, const void* a, int spin_a, int ell_max_a, co
 int bms_angular_velocity(bms_ctx* ctx, const double* t, int64_t n_times, const void* data, int64_t ld, int ell_min, int ell_max,
                          int mem, double* ldt_out, double* ll_out, double* omega_out);
 
+/* Frame R[n][4] with R[0] = R0 and dR/dt = (1/2) Omega R, Omega(t) = not-a-knot cubic spline through omega[n][3]:
+ * quaternion.integrate_angular_velocity as used by corotating_frame (scri/mode_calculations.py:435-491).  Host routine
+ * (sequential in time); ctx may be NULL.  tolerance: absolute tolerance of the integration (<= 0: 1e-12). */
+int bms_integrate_angular_velocity(bms_ctx* ctx, const double* t, int64_t n_times, const double* omega, const double R0[4],
+                                   double tolerance, double* R_out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -77,3 +77,25 @@ def angular_velocity(t, data, ell_min, ell_max):
     l = LdtVector(data, data_dot(t, data), ell_min, ell_max)
     ll = LLMatrix(data, ell_min, ell_max)
     return -np.linalg.solve(ll, l[..., np.newaxis])[..., 0]
+
+
+def integrate_angular_velocity(t, omega, R0, rtol=1e-13, atol=1e-13):
+    """quaternion.integrate_angular_velocity as corotating_frame uses it (mode_calculations.py:470-471): the frame with
+    R(t0) = R0 and dR/dt = (1/2) Omega R, Omega the cubic spline through the samples; here with scipy's DOP853."""
+    from scipy.integrate import solve_ivp
+
+    from . import quat
+
+    sp = CubicSpline(t, omega)
+
+    def rhs(tt, y):
+        return 0.5 * quat.qmul(np.concatenate([[0.0], sp(tt)]), y)
+
+    sol = solve_ivp(rhs, (t[0], t[-1]), np.asarray(R0, dtype=float), method="DOP853", t_eval=t, rtol=rtol, atol=atol)
+    R = sol.y.T
+    return R / np.linalg.norm(R, axis=1)[:, None]
+
+
+def corotating_frame(t, data, ell_min, ell_max, R0):
+    """mode_calculations.py:435-491 without z alignment"""
+    return integrate_angular_velocity(t, angular_velocity(t, data, ell_min, ell_max), R0)

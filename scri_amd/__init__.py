@@ -27,9 +27,10 @@ from . import _lib  # noqa: E402  (raises ImportError if libscri_amd.so has not 
 from ._lib import Context, default_context, BMSError  # noqa: E402,F401
 from . import engine  # noqa: E402,F401
 from .waveform_modes import WaveformModes  # noqa: E402,F401
-from .rotations import rotate_decomposition_basis, rotate_physical_system, to_inertial_frame  # noqa: E402,F401
+from .rotations import rotate_decomposition_basis, rotate_physical_system, to_inertial_frame, to_corotating_frame  # noqa: E402,F401
 from .asymptotic_bondi_data import AsymptoticBondiData  # noqa: E402,F401
 from . import bms_transformations  # noqa: E402,F401
+from . import mode_calculations  # noqa: E402,F401
 from .modes_time_series import ModesTimeSeries  # noqa: E402,F401
 from .bms_transformations import LorentzTransformation, BMSTransformation  # noqa: E402,F401
 
@@ -37,6 +38,7 @@ from .bms_transformations import LorentzTransformation, BMSTransformation  # noq
 WaveformModes.rotate_decomposition_basis = rotate_decomposition_basis
 WaveformModes.rotate_physical_system = rotate_physical_system
 WaveformModes.to_inertial_frame = to_inertial_frame
+WaveformModes.to_corotating_frame = to_corotating_frame
 
 
 def patch_scri():

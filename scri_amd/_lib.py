@@ -105,6 +105,7 @@ SIGNATURES = {
     "bms_cubic_spline": (c_int, [c_vp, c_dp, c_i64, c_vp, c_i64, c_i64, c_int, c_dp, c_i64, c_vp]),
     "bms_spline_derivative": (c_int, [c_vp, c_dp, c_i64, c_vp, c_i64, c_i64, c_int, c_dp, c_i64, c_int, c_vp]),
     "bms_angular_velocity": (c_int, [c_vp, c_dp, c_i64, c_vp, c_i64, c_int, c_int, c_int, c_dp, c_dp, c_dp]),
+    "bms_integrate_angular_velocity": (c_int, [c_vp, c_dp, c_i64, c_dp, c_dp, ctypes.c_double, c_dp]),
     "bms_grid_multiply": (c_int, [c_vp, c_vp, c_int, c_int, c_vp, c_int, c_int, c_int, c_i64, c_int, c_int, c_vp]),
 }
 

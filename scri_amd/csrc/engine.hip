@@ -1310,6 +1310,95 @@ extern "C" int bms_angular_velocity(bms_ctx* c, const double* t, int64_t n, cons
   return BMS_OK;
 }
 
+// Frame from angular velocity: dR/dt = (1/2) Omega R with Omega(t) the not-a-knot cubic spline through omega[n][3]
+// (quaternion.integrate_angular_velocity as called by corotating_frame, scri/mode_calculations.py:470-471).  The state is
+// four numbers marching in time: host code.  Each sampling interval is cut into sub-steps of bounded rotation angle; a
+// sub-step is one fourth-order Magnus step (two Gauss points, one commutator), applied as an exact rotor exponential,
+// so |R| = 1 is preserved to rounding and a constant angular velocity is integrated exactly.
+namespace {
+void host_spline_slopes(const double* x, int64_t n, const double* y, int64_t stride, std::vector<double>& s) {
+  // scipy CubicSpline(bc_type='not-a-knot'): tridiagonal system for the knot slopes (same rows as kernels_spline.hip)
+  std::vector<double> a(n), b(n), c(n), r(n);
+  auto D = [&](int64_t j) { return y[(j + 1) * stride] - y[j * stride]; };
+  {
+    const double h0 = x[1] - x[0], h1 = x[2] - x[1], d = x[2] - x[0];
+    a[0] = 0, b[0] = h1, c[0] = d;
+    r[0] = ((h0 + 2 * d) * h1 / (d * h0)) * D(0) + (h0 * h0 / (d * h1)) * D(1);
+  }
+  for (int64_t j = 1; j < n - 1; ++j) {
+    const double hm = x[j] - x[j - 1], hp = x[j + 1] - x[j];
+    a[j] = hp, b[j] = 2 * (hm + hp), c[j] = hm;
+    r[j] = 3 * (hp / hm) * D(j - 1) + 3 * (hm / hp) * D(j);
+  }
+  {
+    const double hm = x[n - 2] - x[n - 3], hl = x[n - 1] - x[n - 2], d = x[n - 1] - x[n - 3];
+    a[n - 1] = d, b[n - 1] = hm, c[n - 1] = 0;
+    r[n - 1] = (hl * hl / (d * hm)) * D(n - 3) + ((2 * d + hl) * hm / (d * hl)) * D(n - 2);
+  }
+  for (int64_t j = 1; j < n; ++j) {
+    const double m = a[j] / b[j - 1];
+    b[j] -= m * c[j - 1];
+    r[j] -= m * r[j - 1];
+  }
+  s.resize(n);
+  s[n - 1] = r[n - 1] / b[n - 1];
+  for (int64_t j = n - 2; j >= 0; --j) s[j] = (r[j] - c[j] * s[j + 1]) / b[j];
+}
+}  // namespace
+
+extern "C" int bms_integrate_angular_velocity(bms_ctx* c, const double* t, int64_t n, const double* omega, const double R0[4],
+                                              double tolerance, double* R_out) {
+  // pure host routine: ctx may be NULL
+  if (!t || !omega || !R0 || !R_out) return fail(c, BMS_ERR_INVALID, "NULL argument");
+  if (n < 4) return fail(c, BMS_ERR_UNSUPPORTED, "the spline of the angular velocity needs at least 4 time steps, got %lld", (long long)n);
+  for (int64_t i = 1; i < n; ++i)
+    if (!(t[i] > t[i - 1])) return fail(c, BMS_ERR_INVALID, "time array must be strictly increasing (index %lld)", (long long)i);
+  if (!(tolerance > 0)) tolerance = 1e-12;
+  std::vector<double> sl[3];
+  for (int k = 0; k < 3; ++k) host_spline_slopes(t, n, omega + k, 3, sl[k]);
+  // rotation angle per sub-step: the Magnus-4 defect scales like angle^5 times the relative change of Omega
+  double amax = 2.0 * std::pow(tolerance, 0.2);
+  amax = std::min(0.2, std::max(1e-3, amax));
+  Quat R = {R0[0], R0[1], R0[2], R0[3]};
+  R_out[0] = R.w, R_out[1] = R.x, R_out[2] = R.y, R_out[3] = R.z;
+  const double g1 = 0.5 - std::sqrt(3.0) / 6.0, g2 = 0.5 + std::sqrt(3.0) / 6.0;
+  for (int64_t j = 0; j + 1 < n; ++j) {
+    const double h = t[j + 1] - t[j];
+    double y0[3], y1[3], s0[3], s1[3], c2[3], c3[3];
+    double wmax = 0;
+    for (int k = 0; k < 3; ++k) {
+      y0[k] = omega[3 * j + k], y1[k] = omega[3 * (j + 1) + k], s0[k] = sl[k][j], s1[k] = sl[k][j + 1];
+      const double dd = (y1[k] - y0[k]) / h, tt = (s0[k] + s1[k] - 2 * dd) / h;
+      c3[k] = tt / h, c2[k] = (dd - s0[k]) / h - tt;
+    }
+    wmax = std::max(std::sqrt(y0[0] * y0[0] + y0[1] * y0[1] + y0[2] * y0[2]), std::sqrt(y1[0] * y1[0] + y1[1] * y1[1] + y1[2] * y1[2]));
+    const int64_t m = std::max<int64_t>(1, (int64_t)std::ceil(wmax * h / amax));
+    const double hs = h / m;
+    auto om = [&](double tau, double* w) {
+      for (int k = 0; k < 3; ++k) w[k] = y0[k] + tau * (s0[k] + tau * (c2[k] + tau * c3[k]));
+    };
+    for (int64_t q = 0; q < m; ++q) {
+      double wa[3], wb[3];
+      om((q + g1) * hs, wa);
+      om((q + g2) * hs, wb);
+      // Magnus: Theta = h/2 (A1 + A2) + (sqrt3/12) h^2 [A2, A1], A = Omega/2 as a pure quaternion, [A2, A1] = 2 (a2 x a1)
+      // => rotation vector (for exp(Theta), Theta = theta/2 as a vector): theta/2 = h/4 (wa + wb) + (sqrt3/24) h^2 (wb x wa)
+      const double cx = wb[1] * wa[2] - wb[2] * wa[1], cy = wb[2] * wa[0] - wb[0] * wa[2], cz = wb[0] * wa[1] - wb[1] * wa[0];
+      const double k1 = hs / 4, k2 = std::sqrt(3.0) / 24 * hs * hs;
+      const double vx = k1 * (wa[0] + wb[0]) + k2 * cx, vy = k1 * (wa[1] + wb[1]) + k2 * cy, vz = k1 * (wa[2] + wb[2]) + k2 * cz;
+      const double vn = std::sqrt(vx * vx + vy * vy + vz * vz);
+      const double sc = vn > 1e-300 ? std::sin(vn) / vn : 1.0;
+      const Quat E = {std::cos(vn), sc * vx, sc * vy, sc * vz};
+      R = qmul(E, R);
+    }
+    const double nr = std::sqrt(R.w * R.w + R.x * R.x + R.y * R.y + R.z * R.z);
+    R = {R.w / nr, R.x / nr, R.y / nr, R.z / nr};
+    double* o = R_out + 4 * (j + 1);
+    o[0] = R.w, o[1] = R.x, o[2] = R.y, o[3] = R.z;
+  }
+  return BMS_OK;
+}
+
 // ModesTimeSeries.grid_multiply (scri/modes_time_series.py:142-202): both mode sets (l_min = 0) are synthesised on the
 // (2W+1) x (2W+1) equiangular grid, multiplied there, and the product (spin s_a + s_b) is analysed up to output_ell_max.
 extern "C" int bms_grid_multiply(bms_ctx* c, const void* a, int spin_a, int ell_max_a, const void* b, int spin_b, int ell_max_b,

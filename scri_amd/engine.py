@@ -364,3 +364,17 @@ def angular_velocity(t, data, ell_min, ell_max, ctx=None, parts=False):
     )
     ctx.check(rc, "bms_angular_velocity")
     return (ldt, ll, om) if parts else om
+
+
+def integrate_angular_velocity(t, omega, R0=(1.0, 0.0, 0.0, 0.0), tolerance=1e-12):
+    """R[N, 4] with R[0] = R0 and dR/dt = (1/2) Omega R for the cubic spline Omega through omega[N, 3] (host routine)."""
+    t = np.ascontiguousarray(t, dtype=float)
+    omega = np.ascontiguousarray(omega, dtype=float)
+    if omega.shape != (t.shape[0], 3):
+        raise ValueError(f"omega must have shape ({t.shape[0]}, 3); it has shape {omega.shape}")
+    R0 = np.ascontiguousarray(R0, dtype=float)
+    out = np.empty((t.shape[0], 4))
+    rc = _lib.load().bms_integrate_angular_velocity(None, dptr(t), t.shape[0], dptr(omega), dptr(R0), float(tolerance), dptr(out))
+    if rc != 0:
+        _lib._raise(rc, None, "bms_integrate_angular_velocity")
+    return out

@@ -2,10 +2,15 @@
 :298-313 LLMatrix, :403-432 angular_velocity), SURVEY 8(f) rank 3.  One GPU pass (bms_angular_velocity): the cubic-spline
 time derivative of the modes, the <Ldt> and <LL> sums over modes per time step, and the 3 x 3 solve.
 
-Not provided: the frame-velocity term (needs numpy-quaternion's `derivative`), corotating_frame (numpy-quaternion's
-adaptive integrate_angular_velocity) and the dominant-eigenvector routines.
+corotating_frame (:435-491) integrates that angular velocity with the library's host integrator
+(bms_integrate_angular_velocity: the frame is four numbers marching in time).
+
+Not provided: the frame-velocity term (needs numpy-quaternion's `derivative`), z_alignment_region (needs
+LLDominantEigenvector).
 """
-from . import engine
+import numpy as np
+
+from . import engine, quaternions
 
 
 def _parts(W):
@@ -27,3 +32,15 @@ def angular_velocity(W, include_frame_velocity=False):
     if include_frame_velocity and len(W.frame) == W.n_times:
         raise NotImplementedError("include_frame_velocity needs quaternion.derivative, which is outside this build")
     return _parts(W)[2]
+
+
+def corotating_frame(W, R0=(1.0, 0.0, 0.0, 0.0), tolerance=1e-12, z_alignment_region=None, return_omega=False):
+    """Rotor taking the current mode frame into the corotating frame: the integral of the waveform's angular velocity
+    starting from R0 (scri/mode_calculations.py:435-491)."""
+    if z_alignment_region is not None:
+        raise NotImplementedError("z_alignment_region needs LLDominantEigenvector, which is outside this build")
+    omega = angular_velocity(W)
+    R0 = np.asarray(getattr(R0, "components", R0), dtype=float)
+    frame = engine.integrate_angular_velocity(W.t, omega, R0=R0, tolerance=tolerance)
+    frame = frame / np.linalg.norm(frame, axis=1)[:, np.newaxis]
+    return (frame, omega) if return_omega else frame

@@ -67,3 +67,18 @@ def to_inertial_frame(W):
     W.frameType = Inertial
     W._append_history(f"{W}.to_inertial_frame()")
     return W
+
+
+def to_corotating_frame(W, R0=(1.0, 0.0, 0.0, 0.0), tolerance=1e-12, z_alignment_region=None, return_omega=False,
+                        truncate_log_frame=False):
+    """Transform the waveform (in place) to a corotating frame (scri/rotations.py:52-103)."""
+    from . import Corotating
+    from .mode_calculations import corotating_frame
+
+    if truncate_log_frame:
+        raise NotImplementedError("truncate_log_frame is outside this build")
+    frame, omega = corotating_frame(W, R0=R0, tolerance=tolerance, z_alignment_region=z_alignment_region, return_omega=True)
+    W.rotate_decomposition_basis(frame)
+    W._append_history(f"{W}.to_corotating_frame({R0}, {tolerance}, {z_alignment_region}, {return_omega}, {truncate_log_frame})")
+    W.frameType = Corotating
+    return (W, omega) if return_omega else W

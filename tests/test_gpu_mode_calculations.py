@@ -56,3 +56,23 @@ def test_reference_angular_velocity_cases(ctx):
 
     assert np.abs(wr.data_dot - mref.interpolate(wr.t, wr.data, wr.t, 1)).max() < 1e-9
     assert np.abs(wr.data_int - mref.interpolate(wr.t, wr.data, wr.t, -1)).max() < 1e-11
+
+
+def test_reference_corotating_frame_case(ctx):
+    """tests/test_mode_calculations.py:113-128: a constant waveform rotated by R_in(t) has corotating frame R_in, and
+    to_corotating_frame brings back the constant waveform."""
+    import scri_amd
+
+    w = _constant_waveform(100000, ctx)
+    omega = 2 * math.pi / 5.0
+    R0 = np.array([1.0, 2, 3, 4]) / math.sqrt(30)
+    half = np.zeros((w.n_times, 4))
+    half[:, 3] = omega / 2 * w.t
+    R_in = quat.qmul(R0[None, :], quat.qexp(half))
+    w_rot = _constant_waveform(100000, ctx)
+    w_rot.rotate_physical_system(R_in)
+    R_out = scri_amd.mode_calculations.corotating_frame(w_rot, R0=R_in[0], tolerance=1e-12)
+    assert np.allclose(R_in, R_out, atol=1e-10, rtol=0.0)
+    w_rot.to_corotating_frame(R0=R_in[0], tolerance=1e-12)
+    assert np.allclose(w_rot.data, w.data, atol=1e-8, rtol=1e-5)
+    assert w_rot.frameType == scri_amd.Corotating

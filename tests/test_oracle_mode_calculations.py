@@ -4,6 +4,7 @@ tilted axis, its angular velocity is the rotation's."""
 import math
 
 import numpy as np
+import pytest
 
 from oracle import mode_calculations_ref as mc
 from oracle import quat, rotations_ref
@@ -43,3 +44,29 @@ def test_rotated_angular_velocity():
     Om = quat.qmul(quat.qmul(R0, np.array([0, 0, 0, omega])), quat.qinverse(R0))
     om = mc.angular_velocity(t, w.data, w.ell_min, w.ell_max)
     assert np.allclose(om, Om[1:][None, :], atol=1e-12, rtol=2e-8)
+
+
+def test_host_integrator_matches_dop853_and_the_analytic_frame():
+    """bms_integrate_angular_velocity is host code behind the C ABI (no GPU): against the oracle's scipy DOP853
+    integration of a precessing angular velocity, and against exp(axis omega t / 2) for a constant one."""
+    from scri_amd import engine
+
+    t = np.linspace(-10.0, 10.0, 2001)
+    R0 = np.array([1.0, 2, 3, 4]) / math.sqrt(30)
+    om = np.stack([0.3 * np.sin(0.4 * t), 0.2 * np.cos(0.3 * t), 1.0 + 0.01 * t], axis=1)
+    R = engine.integrate_angular_velocity(t, om, R0)
+    assert np.abs(R - mc.integrate_angular_velocity(t, om, R0)).max() < 5e-12
+    assert np.abs(np.linalg.norm(R, axis=1) - 1).max() < 1e-15
+    omega = 2 * math.pi / 5.0
+    Om = quat.qmul(quat.qmul(R0, np.array([0, 0, 0, omega])), quat.qinverse(R0))[1:]
+    half = np.zeros((t.size, 4))
+    half[:, 3] = omega / 2 * (t - t[0])
+    R = engine.integrate_angular_velocity(t, np.repeat(Om[None, :], t.size, axis=0), R0)
+    assert np.abs(R - quat.qmul(R0[None, :], quat.qexp(half))).max() < 1e-13
+    # coarse sampling of a fast rotation: sub-stepping keeps the tolerance
+    tc = np.linspace(0.0, 40.0, 81)
+    omc = np.stack([0.5 * np.sin(0.2 * tc), 0.5 * np.cos(0.2 * tc), 3.0 + 0 * tc], axis=1)
+    Rc = engine.integrate_angular_velocity(tc, omc, [1.0, 0, 0, 0])
+    assert np.abs(Rc - mc.integrate_angular_velocity(tc, omc, [1.0, 0, 0, 0])).max() < 1e-10
+    with pytest.raises(ValueError, match="strictly increasing"):
+        engine.integrate_angular_velocity(tc[::-1], omc, [1.0, 0, 0, 0])
