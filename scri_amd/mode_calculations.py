@@ -5,8 +5,10 @@ time derivative of the modes, the <Ldt> and <LL> sums over modes per time step, 
 corotating_frame (:435-491) integrates that angular velocity with the library's host integrator
 (bms_integrate_angular_velocity: the frame is four numbers marching in time).
 
-Not provided: the frame-velocity term (needs numpy-quaternion's `derivative`), z_alignment_region (needs
-LLDominantEigenvector).
+LLDominantEigenvector (:316-399) takes the <LL> matrices from the GPU and finishes on the host (3 x 3 symmetric
+eigenproblems and the sequential sign choice that makes the axis continuous).
+
+Not provided: the frame-velocity term (needs numpy-quaternion's `derivative`).
 """
 import numpy as np
 
@@ -34,13 +36,62 @@ def angular_velocity(W, include_frame_velocity=False):
     return _parts(W)[2]
 
 
+def _make_continuous(dpa, rough, i_index):
+    """Sign choice of scri/mode_calculations.py:316-363: the axis at i_index points along `rough` rather than against
+    it, and going outwards from there a vector is flipped when it is further from its (already fixed) neighbour than its
+    own length; every vector is normalised."""
+    dpa = np.array(dpa, dtype=float)
+    if np.dot(rough, dpa[i_index]) < 0.0:
+        dpa[i_index] *= -1
+    for rng, d in ((range(i_index - 1, -1, -1), -1), (range(i_index + 1, dpa.shape[0]), 1)):
+        for i in rng:
+            diff = dpa[i] - dpa[i - d]
+            if diff @ diff > dpa[i] @ dpa[i]:
+                dpa[i] *= -1
+    norms = np.linalg.norm(dpa, axis=1)
+    ok = norms != 0.0
+    dpa[ok] /= norms[ok, np.newaxis]
+    return dpa
+
+
+def LLDominantEigenvector(W, RoughDirection=np.array([0.0, 0.0, 1.0]), RoughDirectionIndex=0):
+    """Principal axis of the <LL> matrix at every time step, made continuous in time (mode frame)."""
+    _, eigenvecs = np.linalg.eigh(LLMatrix(W))
+    return _make_continuous(eigenvecs[:, :, 2], np.asarray(RoughDirection, dtype=float), RoughDirectionIndex)  # largest eigenvalue last
+
+
+def _qsqrt(q):
+    """square root of a unit quaternion"""
+    p = np.array(q, dtype=float)
+    p[0] += 1.0
+    return p / np.linalg.norm(p)
+
+
 def corotating_frame(W, R0=(1.0, 0.0, 0.0, 0.0), tolerance=1e-12, z_alignment_region=None, return_omega=False):
     """Rotor taking the current mode frame into the corotating frame: the integral of the waveform's angular velocity
-    starting from R0 (scri/mode_calculations.py:435-491)."""
-    if z_alignment_region is not None:
-        raise NotImplementedError("z_alignment_region needs LLDominantEigenvector, which is outside this build")
+    starting from R0 (scri/mode_calculations.py:435-491).  z_alignment_region = (f1, f2): additionally align the dominant
+    eigenvector of <LL>, averaged over that fraction of the inspiral, with the z axis."""
     omega = angular_velocity(W)
     R0 = np.asarray(getattr(R0, "components", R0), dtype=float)
     frame = engine.integrate_angular_velocity(W.t, omega, R0=R0, tolerance=tolerance)
+    if z_alignment_region is not None:
+        initial_time = W.t[0]
+        n4 = W.n_times // 4  # WaveformBase.max_norm_time: skips the first quarter (scri/waveform_base.py:553-575)
+        inspiral_time = W.t[n4 + int(np.argmax((np.abs(W.data[n4:]) ** 2).sum(axis=1)))] - initial_time
+        t1 = initial_time + z_alignment_region[0] * inspiral_time
+        t2 = initial_time + z_alignment_region[1] * inspiral_time
+        i1 = int(np.argmin(np.abs(W.t - t1)))
+        i2 = int(np.argmin(np.abs(W.t - t2)))
+        R = frame[i1:i2]
+        i1m = max(0, i1 - 10)
+        rough = omega[i1m + 10]
+        _, vecs = np.linalg.eigh(LLMatrix(W)[i1:i2])
+        Vhat = _make_continuous(vecs[:, :, 2], rough, 0)
+        V = np.concatenate([np.zeros((Vhat.shape[0], 1)), Vhat], axis=1)
+        Vhat_corot = quaternions.multiply(quaternions.multiply(quaternions.conjugate(R), V), R)[:, 1:]
+        mean = np.concatenate([[0.0], np.mean(Vhat_corot, axis=0)])
+        mean /= np.linalg.norm(mean)
+        correction = quaternions.conjugate(_qsqrt(quaternions.multiply(np.array([0.0, 0.0, 0.0, -1.0]), mean)))  # sqrt(-z V)^-1
+        frame = quaternions.multiply(frame, correction)
     frame = frame / np.linalg.norm(frame, axis=1)[:, np.newaxis]
     return (frame, omega) if return_omega else frame

@@ -169,6 +169,11 @@ class WaveformModes:
 
         return mode_calculations.LLMatrix(self)
 
+    def LLDominantEigenvector(self, RoughDirection=np.array([0.0, 0.0, 1.0]), RoughDirectionIndex=0):
+        from . import mode_calculations
+
+        return mode_calculations.LLDominantEigenvector(self, RoughDirection, RoughDirectionIndex)
+
     def angular_velocity(self, include_frame_velocity=False):
         from . import mode_calculations
 

@@ -76,3 +76,43 @@ def test_reference_corotating_frame_case(ctx):
     w_rot.to_corotating_frame(R0=R_in[0], tolerance=1e-12)
     assert np.allclose(w_rot.data, w.data, atol=1e-8, rtol=1e-5)
     assert w_rot.frameType == scri_amd.Corotating
+
+
+def _sign_free_distance(a, b):
+    return max(np.amin(np.vstack((np.linalg.norm(a - b, axis=1), np.linalg.norm(a + b, axis=1))), axis=0))
+
+
+def test_reference_dominant_eigenvector_cases(ctx):
+    """tests/test_mode_calculations.py:14-71: the principal axis of <LL> is z for the simple waveforms, and rotates with
+    the waveform."""
+    import scri_amd
+    from oracle import sample_waveforms_ref as sw
+
+    Rs = sw.Rs()
+    n = len(Rs)
+    t = np.linspace(1.0, 100.0, n)
+    LM = np.array([[l, m] for l in range(0, 9) for m in range(-l, l + 1)])
+    base = (LM[:, 1] - 1j * LM[:, 1]).astype(complex)
+    for data in (np.repeat(base[None, :], n, axis=0), base[None, :] * t[:, None]):  # constant_waveform, linear_waveform
+        w = scri_amd.WaveformModes(t=t, data=data.copy(), ell_min=0, ell_max=8, dataType=scri_amd.h, frameType=scri_amd.Inertial,
+                                   r_is_scaled_out=True, m_is_scaled_out=True, ctx=ctx)
+        dpa = w.LLDominantEigenvector()
+        expect = np.zeros_like(dpa)
+        expect[:, 2] = 1.0
+        assert np.allclose(dpa, expect)
+        w.rotate_physical_system(Rs)
+        z = np.zeros((n, 4))
+        z[:, 3] = 1.0
+        expected = quat.qmul(quat.qmul(Rs, z), quat.qconj(Rs))[:, 1:]
+        assert _sign_free_distance(w.LLDominantEigenvector(), expected) < 1.0e-13
+    # z alignment of the corotating frame: a waveform precessing about a tilted axis ends up with that axis along z
+    w = _constant_waveform(20000, ctx)
+    omega = 2 * math.pi / 5.0
+    R0 = np.array([1.0, 2, 3, 4]) / math.sqrt(30)
+    half = np.zeros((w.n_times, 4))
+    half[:, 3] = omega / 2 * w.t
+    w.rotate_physical_system(quat.qmul(R0[None, :], quat.qexp(half)))
+    frame = scri_amd.mode_calculations.corotating_frame(w, z_alignment_region=(0.1, 0.9))
+    w.rotate_decomposition_basis(frame)
+    dpa = w.LLDominantEigenvector()
+    assert np.abs(np.abs(dpa[:, 2]) - 1).max() < 1e-9
