@@ -211,6 +211,16 @@ int bms_angular_velocity(bms_ctx* ctx, const double* t, int64_t n_times, const v
 int bms_integrate_angular_velocity(bms_ctx* ctx, const double* t, int64_t n_times, const double* omega, const double R0[4],
                                    double tolerance, double* R_out);
 
+/* ---- bit transforms of the storage formats (scri/utilities.py:194-406), bit-exact ------------ */
+/* xor_timeseries (reverse = 0) / xor_timeseries_reverse (reverse = 1), in place: data viewed as uint64[n_rows][words_per_row],
+ * time along the rows; row 0 is unchanged, row i becomes row[i-1] ^ row[i] (forward) or the running XOR (reverse). */
+int bms_xor_timeseries(bms_ctx* ctx, void* data, int mem, int64_t n_rows, int64_t words_per_row, int reverse);
+/* multishuffle(shuffle_widths, forward)(a): n elements of sum(widths) in {8,16,32,64} bits; widths from the most significant
+ * piece down.  in and out must not overlap. */
+int bms_multishuffle(bms_ctx* ctx, const void* in, void* out, int mem, int64_t n, const int* widths, int n_widths, int forward);
+/* fletcher32(data): 16-bit words, modulus 65535; returns c1 << 16 | c0 */
+int bms_fletcher32(bms_ctx* ctx, const void* data, int mem, int64_t n_bytes, uint32_t* checksum);
+
 #ifdef __cplusplus
 }
 #endif

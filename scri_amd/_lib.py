@@ -106,6 +106,9 @@ SIGNATURES = {
     "bms_spline_derivative": (c_int, [c_vp, c_dp, c_i64, c_vp, c_i64, c_i64, c_int, c_dp, c_i64, c_int, c_vp]),
     "bms_angular_velocity": (c_int, [c_vp, c_dp, c_i64, c_vp, c_i64, c_int, c_int, c_int, c_dp, c_dp, c_dp]),
     "bms_integrate_angular_velocity": (c_int, [c_vp, c_dp, c_i64, c_dp, c_dp, ctypes.c_double, c_dp]),
+    "bms_xor_timeseries": (c_int, [c_vp, c_vp, c_int, c_i64, c_i64, c_int]),
+    "bms_multishuffle": (c_int, [c_vp, c_vp, c_vp, c_int, c_i64, ctypes.POINTER(c_int), c_int, c_int]),
+    "bms_fletcher32": (c_int, [c_vp, c_vp, c_int, c_i64, ctypes.POINTER(ctypes.c_uint32)]),
     "bms_grid_multiply": (c_int, [c_vp, c_vp, c_int, c_int, c_vp, c_int, c_int, c_int, c_i64, c_int, c_int, c_vp]),
 }
 

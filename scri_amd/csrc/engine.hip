@@ -1460,6 +1460,89 @@ extern "C" int bms_grid_multiply(bms_ctx* c, const void* a, int spin_a, int ell_
   return BMS_OK;
 }
 
+// ====================================================================================================== storage formats
+// scri/utilities.py:194-232: XOR differencing of a time series in place (rows of 64-bit words)
+extern "C" int bms_xor_timeseries(bms_ctx* c, void* data, int mem, int64_t n_rows, int64_t words_per_row, int reverse) {
+  if (!c || !data) return BMS_ERR_INVALID;
+  HIP_TRY(c, hipSetDevice(c->device));
+  if (n_rows < 0 || words_per_row < 0) return fail(c, BMS_ERR_INVALID, "negative size");
+  if (n_rows == 0 || words_per_row == 0) return BMS_OK;
+  const size_t bytes = (size_t)n_rows * words_per_row * 8;
+  hipStream_t S = c->stream;
+  int rc;
+  uint64_t *d_in = (uint64_t*)data, *d_out, *d_carry = nullptr;
+  if (mem == BMS_HOST) {
+    if ((rc = dev_buf_t(c, "bits_in", bytes / 8, &d_in))) return rc;
+    HIP_TRY(c, hipMemcpyAsync(d_in, data, bytes, hipMemcpyHostToDevice, S));
+  }
+  if ((rc = dev_buf_t(c, "bits_out", bytes / 8, &d_out))) return rc;
+  if (reverse)
+    if ((rc = dev_buf_t(c, "bits_carry", (size_t)xor_carry_words(n_rows, words_per_row), &d_carry))) return rc;
+  TIMED(c, BMS_TAG_POINTWISE, launch_xor_timeseries(S, d_in, d_out, d_carry, n_rows, words_per_row, reverse));
+  HIP_TRY(c, hipMemcpyAsync(data, d_out, bytes, mem == BMS_HOST ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice, S));
+  HIP_TRY(c, hipStreamSynchronize(S));
+  return BMS_OK;
+}
+
+// scri/utilities.py:271-406: the function multishuffle(shuffle_widths, forward) returns, applied to n elements
+extern "C" int bms_multishuffle(bms_ctx* c, const void* in, void* out, int mem, int64_t n, const int* widths, int n_widths,
+                                int forward) {
+  if (!c || !in || !out || !widths) return BMS_ERR_INVALID;
+  HIP_TRY(c, hipSetDevice(c->device));
+  int bit_width = 0;
+  for (int i = 0; i < n_widths; ++i) {
+    if (widths[i] < 1) return fail(c, BMS_ERR_INVALID, "shuffle widths must be positive");
+    bit_width += widths[i];
+  }
+  if (n_widths < 1 || n_widths > 64 || (bit_width != 8 && bit_width != 16 && bit_width != 32 && bit_width != 64))
+    return fail(c, BMS_ERR_INVALID, "Total bit width must be one of [8, 16, 32, 64], not %d", bit_width);
+  if (n < 0) return fail(c, BMS_ERR_INVALID, "negative size");
+  if (n == 0) return BMS_OK;
+  const size_t bytes = (size_t)n * (bit_width / 8);
+  hipStream_t S = c->stream;
+  int rc;
+  const void* d_in = in;
+  void* d_out = out;
+  if (mem == BMS_HOST) {
+    uint64_t *a, *b;
+    if ((rc = dev_buf_t(c, "bits_in", (bytes + 7) / 8 + 1, &a))) return rc;
+    if ((rc = dev_buf_t(c, "bits_out", (bytes + 7) / 8 + 1, &b))) return rc;
+    HIP_TRY(c, hipMemcpyAsync(a, in, bytes, hipMemcpyHostToDevice, S));
+    d_in = a, d_out = b;
+  }
+  TIMED(c, BMS_TAG_POINTWISE, launch_multishuffle(S, d_in, d_out, n, widths, n_widths, bit_width, forward));
+  if (mem == BMS_HOST) HIP_TRY(c, hipMemcpyAsync(out, d_out, bytes, hipMemcpyDeviceToHost, S));
+  HIP_TRY(c, hipStreamSynchronize(S));
+  return BMS_OK;
+}
+
+// scri/utilities.py:235-268: Fletcher-32 over the data viewed as 16-bit words (n_bytes must be even)
+extern "C" int bms_fletcher32(bms_ctx* c, const void* data, int mem, int64_t n_bytes, uint32_t* checksum) {
+  if (!c || !checksum || (!data && n_bytes)) return BMS_ERR_INVALID;
+  HIP_TRY(c, hipSetDevice(c->device));
+  if (n_bytes < 0 || (n_bytes & 1)) return fail(c, BMS_ERR_INVALID, "the data must be viewable as 16-bit words");
+  *checksum = 0;
+  if (n_bytes == 0) return BMS_OK;
+  hipStream_t S = c->stream;
+  int rc;
+  const void* d_in = data;
+  if (mem == BMS_HOST) {
+    uint64_t* a;
+    if ((rc = dev_buf_t(c, "bits_in", (size_t)(n_bytes + 7) / 8, &a))) return rc;
+    HIP_TRY(c, hipMemcpyAsync(a, data, (size_t)n_bytes, hipMemcpyHostToDevice, S));
+    d_in = a;
+  }
+  unsigned long long* d_acc;
+  if ((rc = dev_buf_t(c, "bits_acc", 2, &d_acc))) return rc;
+  HIP_TRY(c, hipMemsetAsync(d_acc, 0, 16, S));
+  TIMED(c, BMS_TAG_POINTWISE, launch_fletcher32(S, d_in, n_bytes / 2, d_acc));
+  unsigned long long acc[2];
+  HIP_TRY(c, hipMemcpyAsync(acc, d_acc, 16, hipMemcpyDeviceToHost, S));
+  HIP_TRY(c, hipStreamSynchronize(S));
+  *checksum = (uint32_t)((acc[1] % 65535) << 16 | (acc[0] % 65535));
+  return BMS_OK;
+}
+
 // ====================================================================================================== ABD flavour
 extern "C" int bms_transform_abd_shard(bms_ctx* c, const double* u, const void* raw, int mem, int64_t n_times, int ell_max,
                                        const bms_transformation* tr, const bms_shard* sh, double* u_out, void* raw_out,

@@ -118,6 +118,17 @@ hipError_t launch_cmul(hipStream_t stream, const double* a, const double* b, dou
 hipError_t launch_angular_velocity(hipStream_t stream, const double* F, const double* Fdot, long long ld, long long n_times,
                                    int ell_min, int n_modes, double* ldt_out, double* ll_out, double* omega_out);
 
+// ---- bit transforms of the storage formats (kernels_bits.hip; scri/utilities.py:194-406)
+// rows of n_cols 64-bit words; forward: out[i] = in[i-1] ^ in[i]; reverse: running XOR (carry: xor_carry_words words)
+long long xor_carry_words(long long n_rows, long long n_cols);
+hipError_t launch_xor_timeseries(hipStream_t stream, const void* in, void* out, void* carry, long long n_rows, long long n_cols,
+                                 int reverse);
+// n elements of bit_width bits; widths[n_widths] from the most significant piece down, summing to bit_width
+hipError_t launch_multishuffle(hipStream_t stream, const void* in, void* out, long long n, const int* widths, int n_widths,
+                               int bit_width, int forward);
+// acc[0] += sum d_j mod 65535-ish, acc[1] += sum (N-j) d_j (both to be reduced mod 65535 by the caller); acc zeroed before
+hipError_t launch_fletcher32(hipStream_t stream, const void* data, long long n_words, unsigned long long* acc);
+
 // ---- pointwise helpers
 // Y[t][p] += coeff * Yaux[t][p] * X[t][p]^power,  X = (x_t - alpha_p) * xa_p - xb_p   (waveform_grid.py:516-550)
 hipError_t launch_psi_mix(hipStream_t stream, double* Y, const double* Yaux, long long ld, int n_pix, long long n_rows,

@@ -1,0 +1,75 @@
+"""Bit transforms of the storage formats (scri/utilities.py:194-406): xor_timeseries, xor_timeseries_reverse,
+fletcher32, multishuffle -- same names and calling conventions, executed on the GPU through the C ABI, bit-exact."""
+import ctypes
+import functools
+
+import numpy as np
+
+from . import _lib
+from ._lib import BMS_HOST, default_context
+
+
+def _ctx(ctx):
+    return ctx if ctx is not None else default_context()
+
+
+def _xor(c, reverse, ctx):
+    ctx = _ctx(ctx)
+    c = np.asarray(c)
+    if not c.flags.c_contiguous or c.itemsize * int(np.prod(c.shape[1:], dtype=np.int64)) % 8:
+        raise ValueError("xor_timeseries needs a C-contiguous array whose rows are a whole number of 64-bit words")
+    n_rows = c.shape[0] if c.ndim else 0
+    words = c.itemsize * int(np.prod(c.shape[1:], dtype=np.int64)) // 8
+    rc = _lib.load().bms_xor_timeseries(ctx.handle, ctypes.c_void_p(c.ctypes.data), BMS_HOST, n_rows, words, int(reverse))
+    ctx.check(rc, "bms_xor_timeseries")
+    return c
+
+
+def xor_timeseries(c, ctx=None):
+    """XOR a time series in place (time along the first axis): each time step keeps only the bits that changed."""
+    return _xor(c, False, ctx)
+
+
+def xor_timeseries_reverse(c, ctx=None):
+    """Undo xor_timeseries, bit for bit."""
+    return _xor(c, True, ctx)
+
+
+def fletcher32(data, ctx=None):
+    """Fletcher-32 checksum of an array viewed as uint16 (blocks of 360, modulus 65535)."""
+    ctx = _ctx(ctx)
+    d = np.ascontiguousarray(data).reshape(-1).view(np.uint16)
+    out = ctypes.c_uint32(0)
+    rc = _lib.load().bms_fletcher32(ctx.handle, ctypes.c_void_p(d.ctypes.data), BMS_HOST, d.nbytes, ctypes.byref(out))
+    ctx.check(rc, "bms_fletcher32")
+    return np.uint32(out.value)
+
+
+@functools.lru_cache()
+def multishuffle(shuffle_widths, forward=True, ctx=None):
+    """Function that "multi-shuffles" (forward) or un-shuffles a flat array: shuffle_widths lists the bits of each piece
+    from the highest significance down and must sum to 8, 16, 32 or 64."""
+    widths = [int(w) for w in shuffle_widths]
+    bit_width = int(np.sum(widths, dtype=np.int64))
+    if bit_width not in [8, 16, 32, 64]:
+        raise ValueError(f"Total bit width must be one of [8, 16, 32, 64], not {bit_width}")
+    dtype = np.dtype(f"u{bit_width // 8}")
+    warr = (ctypes.c_int * len(widths))(*widths)
+
+    def shuffle(a):
+        a = np.ascontiguousarray(a).view(dtype)
+        if a.ndim != 1:
+            raise ValueError(
+                "\nThis function only accepts flat arrays.  Make sure you flatten "
+                "(using ravel, reshape, or flatten)\n in a way that keeps your data"
+                "contiguous in the order you want."
+            )
+        b = np.zeros_like(a)
+        c = _ctx(ctx)
+        rc = _lib.load().bms_multishuffle(
+            c.handle, ctypes.c_void_p(a.ctypes.data), ctypes.c_void_p(b.ctypes.data), BMS_HOST, a.size, warr, len(widths), int(forward)
+        )
+        c.check(rc, "bms_multishuffle")
+        return b
+
+    return shuffle
