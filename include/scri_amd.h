@@ -180,6 +180,9 @@ int bms_swsh_grid(bms_ctx* ctx, const double* rotors_host /* f8[n][4] */, int64_
 /* spinsfast.map2salm(grid[n_maps][n_theta][n_phi], s, ell_max)[..., ell_min^2:] (waveform_grid.py:303-307) */
 int bms_map2salm(bms_ctx* ctx, const void* grid, int mem, int64_t n_maps, int n_theta, int n_phi, int spin,
                  int ell_min, int ell_max, void* modes_out);
+/* spinsfast.salm2map(modes[n_maps][(ell_max+1)^2], s, ell_max, n_theta, n_phi) -> c16[n_maps][n_theta][n_phi] */
+int bms_salm2map(bms_ctx* ctx, const void* modes, int mem, int64_t n_maps, int spin, int ell_max, int n_theta, int n_phi,
+                 void* grid_out);
 /* not-a-knot cubic spline through (x[n], y c16[n][n_cols]) evaluated at x_new[n_new] (all x host; y/out in
  * `mem`): scipy CubicSpline(x, y)(x_new) of waveform_base.py:964 / modes_time_series.py:90 */
 int bms_cubic_spline(bms_ctx* ctx, const double* x, int64_t n, const void* y, int64_t ld, int64_t n_cols, int mem,

@@ -109,6 +109,7 @@ SIGNATURES = {
     "bms_xor_timeseries": (c_int, [c_vp, c_vp, c_int, c_i64, c_i64, c_int]),
     "bms_multishuffle": (c_int, [c_vp, c_vp, c_vp, c_int, c_i64, ctypes.POINTER(c_int), c_int, c_int]),
     "bms_fletcher32": (c_int, [c_vp, c_vp, c_int, c_i64, ctypes.POINTER(ctypes.c_uint32)]),
+    "bms_salm2map": (c_int, [c_vp, c_vp, c_int, c_i64, c_int, c_int, c_int, c_int, c_vp]),
     "bms_grid_multiply": (c_int, [c_vp, c_vp, c_int, c_int, c_vp, c_int, c_int, c_int, c_i64, c_int, c_int, c_vp]),
 }
 

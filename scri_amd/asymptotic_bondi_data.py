@@ -71,6 +71,14 @@ class AsymptoticBondiData:
         new._raw_data[:] = self._raw_data
         return new
 
+    def __getitem__(self, key):
+        """Slice along time (scri/asymptotic_bondi_data/__init__.py: abd[i0:i1])"""
+        if not isinstance(key, slice):
+            raise TypeError("AsymptoticBondiData can only be sliced along time: abd[i0:i1]")
+        new = type(self)(self._time[key], self._ell_max, frameType=self.frameType, ctx=self._ctx)
+        new._raw_data[:] = self._raw_data[:, key]
+        return new
+
     def interpolate(self, new_times):
         """scri/asymptotic_bondi_data/__init__.py:218-233: cubic-spline all six fields to `new_times`."""
         new_times = np.asarray(new_times, dtype=float)
@@ -122,3 +130,7 @@ from . import bms_charges as _bms_charges  # noqa: E402
 for _f in _bms_charges.METHODS:
     setattr(AsymptoticBondiData, _f.__name__, _f)
 AsymptoticBondiData.charge_vector_from_aspect = staticmethod(_bms_charges.charge_vector_from_aspect)
+
+from . import map_to_superrest_frame as _superrest  # noqa: E402
+
+AsymptoticBondiData.map_to_superrest_frame = _superrest.map_to_superrest_frame

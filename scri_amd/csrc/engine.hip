@@ -1399,6 +1399,42 @@ extern "C" int bms_integrate_angular_velocity(bms_ctx* c, const double* t, int64
   return BMS_OK;
 }
 
+// spinsfast.salm2map(modes, s, ell_max, n_theta, n_phi): values on the equiangular grid (sf.Modes.grid, used by the
+// super-rest-frame iteration, scri/asymptotic_bondi_data/map_to_superrest_frame.py:171,216); modes from l = 0
+extern "C" int bms_salm2map(bms_ctx* c, const void* modes, int mem, int64_t n_maps, int spin, int ell_max, int n_theta, int n_phi,
+                            void* grid_out) {
+  if (!c || !modes || !grid_out) return BMS_ERR_INVALID;
+  HIP_TRY(c, hipSetDevice(c->device));
+  if (ell_max < 0 || n_theta < 2 || n_phi < 1 || std::abs(spin) > 4) return fail(c, BMS_ERR_INVALID, "bad sizes");
+  if (n_maps <= 0) return BMS_OK;
+  const int n_pix = n_theta * n_phi, nm = (ell_max + 1) * (ell_max + 1);
+  hipStream_t S = c->stream;
+  int rc;
+  std::vector<double> rot(4 * (size_t)n_pix);
+  for (int j = 0; j < n_theta; ++j)
+    for (int k = 0; k < n_phi; ++k) {
+      const Quat q = from_spherical_coords(M_PI * j / (n_theta - 1), (2 * M_PI) * k / n_phi);
+      double* r = &rot[4 * ((size_t)j * n_phi + k)];
+      r[0] = q.w, r[1] = q.x, r[2] = q.y, r[3] = q.z;
+    }
+  void* vp;
+  if ((rc = upload(c, "gm_rotors", rot.data(), 8 * rot.size(), &vp))) return rc;
+  const long long P2 = 2LL * n_pix, ldb = round_up(P2, 128);
+  double* d_B;
+  if ((rc = dev_buf_t(c, "gm_Ba", (size_t)round_up(nm, 8) * ldb, &d_B))) return rc;
+  HIP_TRY(c, hipMemsetAsync(d_B, 0, sizeof(double) * round_up(nm, 8) * ldb, S));
+  TIMED(c, BMS_TAG_SETUP, launch_swsh_matrix_complex(S, (const double*)vp, n_pix, spin, 0, ell_max, d_B, ldb));
+  const double* d_a;
+  if ((rc = stage_in(c, "in_data", modes, mem, (size_t)n_maps * nm * 16, &d_a))) return rc;
+  double* d_G = (double*)grid_out;
+  if (mem == BMS_HOST)
+    if ((rc = dev_buf_t(c, "out_data", (size_t)n_maps * P2, &d_G))) return rc;
+  TIMED(c, BMS_TAG_GEMM_SYNTHESIS, launch_zgemm3m(S, d_a, 2LL * nm, d_B, ldb, d_G, P2, n_maps, n_pix, nm, nullptr, nullptr));
+  if (mem == BMS_HOST) HIP_TRY(c, hipMemcpyAsync(grid_out, d_G, (size_t)n_maps * n_pix * 16, hipMemcpyDeviceToHost, S));
+  HIP_TRY(c, hipStreamSynchronize(S));
+  return BMS_OK;
+}
+
 // ModesTimeSeries.grid_multiply (scri/modes_time_series.py:142-202): both mode sets (l_min = 0) are synthesised on the
 // (2W+1) x (2W+1) equiangular grid, multiplied there, and the product (spin s_a + s_b) is analysed up to output_ell_max.
 extern "C" int bms_grid_multiply(bms_ctx* c, const void* a, int spin_a, int ell_max_a, const void* b, int spin_b, int ell_max_b,

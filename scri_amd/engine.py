@@ -378,3 +378,17 @@ def integrate_angular_velocity(t, omega, R0=(1.0, 0.0, 0.0, 0.0), tolerance=1e-1
     if rc != 0:
         _lib._raise(rc, None, "bms_integrate_angular_velocity")
     return out
+
+
+def salm2map(modes, spin, ell_max, n_theta, n_phi, ctx=None):
+    """spinsfast.salm2map(modes[..., (ell_max+1)^2], s, ell_max, n_theta, n_phi) -> grid[..., n_theta, n_phi]."""
+    ctx = _ctx(ctx)
+    a = _lib.as_c16(modes)
+    if a.shape[-1] != (ell_max + 1) ** 2:
+        raise ValueError("modes must start at l = 0 and end at ell_max")
+    lead = a.shape[:-1]
+    a2 = a.reshape(-1, a.shape[-1])
+    out = np.empty((a2.shape[0], n_theta * n_phi), dtype=np.complex128)
+    rc = _lib.load().bms_salm2map(ctx.handle, vptr(a2), BMS_HOST, a2.shape[0], int(spin), int(ell_max), int(n_theta), int(n_phi), vptr(out))
+    ctx.check(rc, "bms_salm2map")
+    return out.reshape(lead + (n_theta, n_phi))
