@@ -123,3 +123,13 @@ def supermomentum(u, psi2, sigma, definition, working_ell_max=None, integrated=F
     else:
         raise ValueError(definition)
     return -0.5 * bar(res, 0) / math.sqrt(math.pi) if integrated else res
+
+
+def cwwy_angular_momentum(u, psi1, psi2, sigma):
+    """bms_charges.py:109-136"""
+    lmax = int(round(math.sqrt(sigma.shape[-1]))) - 1
+    fac = np.concatenate([np.full(2 * l + 1, 0.0 if l < 2 else 4.0 / ((l + 2) * (l + 1) * l * (l - 1))) for l in range(lmax + 1)])
+    pot = fac * (wigner.ethbar_GHP(wigner.ethbar_GHP(sigma, 2), 1) + wigner.eth_GHP(wigner.eth_GHP(bar(sigma, 2), -2), -1))
+    m_eth = wigner.eth_GHP(mass_aspect(u, psi2, sigma, lmax), 0)
+    a = 1j * (_psi1_sigma(psi1, sigma) + multiply(pot, 0, m_eth, 1, 1))
+    return charge_vector_from_aspect(a)[:, 1:]

@@ -102,7 +102,18 @@ def bondi_dimensionless_spin(self):
 
 
 def CWWY_angular_momentum(self):
-    raise NotImplementedError("needs the inverse of eth^2 ethbar^2 from map_to_superrest_frame, which is outside this build")
+    """Chen/Wang/Wang/Yau angular momentum vector, Eq. (5) of arXiv:2102.03235 (bms_charges.py:109-136): the Bondi
+    expression plus the supertranslation potential D^-1 (ethbar^2 sigma + eth^2 sigma-bar) times eth of the mass aspect."""
+    from .map_to_superrest_frame import D_inverse
+    from .modes_time_series import ModesTimeSeries
+
+    ell_max = 1
+    potential = D_inverse((self.sigma.ethbar_GHP.ethbar_GHP + self.sigma.bar.eth_GHP.eth_GHP).ndarray, self.ell_max)
+    potential = ModesTimeSeries(potential, self.t, spin_weight=0, ell_min=0, ell_max=self.ell_max)
+    charge_aspect = (
+        1j * (_psi1_sigma_term(self, ell_max) + potential.multiply(self.mass_aspect().eth_GHP, truncator=lambda tup: ell_max))
+    ).ndarray
+    return charge_vector_from_aspect(charge_aspect)[:, 1:]
 
 
 def supermomentum(self, supermomentum_def, **kwargs):

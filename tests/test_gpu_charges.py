@@ -45,6 +45,7 @@ def test_charges_match_oracle_on_generic_data(ctx):
     assert np.abs(a.bondi_CoM_charge() - cref.com_charge(psi1, sigma)).max() < tol
     assert np.abs(a.bondi_boost_charge() - cref.boost_charge(u, psi1, psi2, sigma)).max() < 20 * tol  # x |u| <= 20
     assert np.abs(a.bondi_dimensionless_spin() - cref.dimensionless_spin(u, psi1, psi2, sigma)).max() < 1e-9
+    assert np.abs(a.CWWY_angular_momentum() - cref.cwwy_angular_momentum(u, psi1, psi2, sigma)).max() < tol
     P = a.bondi_four_momentum()
     assert np.allclose(a.bondi_rest_mass() ** 2, P[:, 0] ** 2 - (P[:, 1:] ** 2).sum(axis=1), rtol=1e-14)
     for name in ("Bondi-Sachs", "M", "geroch", "GW"):
