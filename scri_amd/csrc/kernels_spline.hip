@@ -328,17 +328,27 @@ __global__ __launch_bounds__(64) void spline_backward_eval_kernel(
     y1 = y0;
   };
   long long j = jI - 1;
-  for (; j - 3 >= jA; j -= 4) {
-    // 8 x 16 B per lane in flight before the dependent chain starts
-    const double2 r0 = ld2(rp, j), r1 = ld2(rp, j - 1), r2 = ld2(rp, j - 2), r3 = ld2(rp, j - 3);
-    const double2 q0 = ld2(yp, j), q1 = ld2(yp, j - 1), q2 = ld2(yp, j - 2), q3 = ld2(yp, j - 3);
-    interval(j, r0, q0);
-    interval(j - 1, r1, q1);
-    interval(j - 2, r2, q2);
-    interval(j - 3, r3, q3);
-    // rows every lane has left behind (a finished lane, i = -1, holds nobody back)
-    flush(wave_max_i32(i));
-    if (!__any(i >= 0)) break;
+  if (j - 3 >= jA) {
+    // software pipeline: the 8 x 16 B of the NEXT four knots are requested before the dependent chain of the current
+    // four starts (rows below jA are clamped: loaded, never used)
+    double2 r0 = ld2(rp, j), r1 = ld2(rp, j - 1), r2 = ld2(rp, j - 2), r3 = ld2(rp, j - 3);
+    double2 q0 = ld2(yp, j), q1 = ld2(yp, j - 1), q2 = ld2(yp, j - 2), q3 = ld2(yp, j - 3);
+    for (; j - 3 >= jA; j -= 4) {
+      const long long jn = j - 4;
+      const long long c0 = jn >= jA ? jn : jA, c1 = jn - 1 >= jA ? jn - 1 : jA, c2 = jn - 2 >= jA ? jn - 2 : jA,
+                      c3 = jn - 3 >= jA ? jn - 3 : jA;
+      const double2 nr0 = ld2(rp, c0), nr1 = ld2(rp, c1), nr2 = ld2(rp, c2), nr3 = ld2(rp, c3);
+      const double2 nq0 = ld2(yp, c0), nq1 = ld2(yp, c1), nq2 = ld2(yp, c2), nq3 = ld2(yp, c3);
+      interval(j, r0, q0);
+      interval(j - 1, r1, q1);
+      interval(j - 2, r2, q2);
+      interval(j - 3, r3, q3);
+      // rows every lane has left behind (a finished lane, i = -1, holds nobody back)
+      flush(wave_max_i32(i));
+      if (!__any(i >= 0)) break;
+      r0 = nr0, r1 = nr1, r2 = nr2, r3 = nr3;
+      q0 = nq0, q1 = nq1, q2 = nq2, q3 = nq3;
+    }
   }
   if (__any(i >= 0))
     for (; j >= jA; --j) interval(j, ld2(rp, j), ld2(yp, j));
