@@ -59,6 +59,73 @@ def cpu_baseline(spec, n_sample):
     }
 
 
+def _host_cores():
+    """cores this process can actually use: affinity mask, cut by the cgroup CPU quota when there is one, capped at 64"""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    for path, parse in (
+        ("/sys/fs/cgroup/cpu.max", lambda s: (s.split()[0], s.split()[1])),
+        ("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", lambda s: (s.strip(), open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read().strip())),
+    ):
+        try:
+            quota, period = parse(open(path).read())
+            if quota not in ("max", "-1"):
+                n = min(n, max(1, int(int(quota) / int(period))))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return max(1, min(n, 64))
+
+
+def _cpu_worker(job):
+    """One process of the all-cores CPU baseline: the oracle on its own slice of the sample (spawned, never touches the GPU)."""
+    name, i0, i1, n_total = job
+    from oracle import waveform_grid_ref as grid_ref
+    from oracle.containers import WM, h
+    from scri_amd import synthetic
+
+    spec = dict(synthetic.CONFIGS[name])
+    t, data, _ = synthetic.workload(name, n_times=n_total, rows=(i0, i1))
+    w = WM(t=t[i0:i1], data=data, ell_min=2, ell_max=spec["ell_max"], dataType=h)
+    t0 = time.perf_counter()
+    grid_ref.transform(w, **spec["kwargs"])
+    return time.perf_counter() - t0
+
+
+def cpu_baseline_all_cores(spec, n_sample):
+    """The same oracle on every host core at once: the sample is cut into one contiguous slice per process (each slice is a
+    complete transform of its own rows), BLAS threads pinned to 1 per process.  The generous "one socket" denominator."""
+    import multiprocessing as mp
+
+    procs = _host_cores()
+    per = max(200, n_sample // procs)
+    jobs = [(spec["name"], p * per, (p + 1) * per, procs * per) for p in range(procs)]
+    saved = {k: os.environ.get(k) for k in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS")}
+    for k in saved:
+        os.environ[k] = "1"
+    try:
+        with mp.get_context("spawn").Pool(procs) as pool:
+            pool.map(_cpu_worker, [(spec["name"], 0, 200, 200)] * procs)  # imports paid before the clock starts
+            t0 = time.perf_counter()
+            pool.map(_cpu_worker, jobs)
+            dt = time.perf_counter() - t0
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    return {
+        "value": procs * per / dt,
+        "unit": "timesteps/s",
+        "cores": procs,
+        "kind": "port",
+        "sample": f"{procs} processes x {per} time steps each of the same workload, oracle/waveform_grid_ref.transform, {dt:.1f} s wall",
+    }
+
+
 def rotation_line(local, ell_max, ctx, cpu_steps):
     """Secondary measurement (configs[0] of BASELINE.json at the cfg3 size): in-place time-series rotation of the resident
     modes by one rotor per time step (scri/rotations.py:370-392), HIP-event kernel time against the HBM roofline
@@ -103,6 +170,13 @@ def rotation_line(local, ell_max, ctx, cpu_steps):
         dt = time.perf_counter() - t0
         out["cpu_baseline"] = {"value": ns / dt, "unit": "timesteps/s", "cores": 1, "kind": "port",
                                "sample": f"{ns} steps, oracle/rotate_port.c (scalar C port of the numba kernel incl. per-step Wigner-D), {dt:.1f} s"}
+        nsa = min(8 * ns, n)
+        da = np.ascontiguousarray(local[:nsa].cpu().numpy())
+        t0 = time.perf_counter()
+        _, used = rotate_port.rotate_by_series_omp(da, np.ascontiguousarray(sp_host[:nsa]), 2, ell_max, n_threads=_host_cores())
+        dt = time.perf_counter() - t0
+        out["cpu_baseline_all_cores"] = {"value": nsa / dt, "unit": "timesteps/s", "cores": used, "kind": "port",
+                                         "sample": f"{nsa} steps, the same C port with the time loop under OpenMP, {dt:.1f} s"}
     return out
 
 
@@ -276,6 +350,7 @@ def main():
         }
         if world == 1 and args.cpu_sample > 0 and not abd:
             line["cpu_baseline"] = cpu_baseline(spec, args.cpu_sample)
+            line["cpu_baseline_all_cores"] = cpu_baseline_all_cores(spec, args.cpu_sample)
         if world == 1 and not abd:
             line["rotation"] = rotation_line(local, ell_max, ctx, 3000 if args.cpu_sample > 0 else 0)
         print(json.dumps(line))

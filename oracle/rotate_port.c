@@ -118,6 +118,32 @@ void rotate_by_series(double complex* data, const double complex* R_basis, int64
   }
 }
 
+/* the same kernel with the time loop shared among threads (what numba's prange over time would do): every thread has its
+ * own D work space; D_all holds n_threads * d_size entries.  Returns the number of threads used. */
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+int rotate_by_series_omp(double complex* data, const double complex* R_basis, int64_t n_times, int64_t n_modes, int ell_min,
+                         int ell_max, double complex* D_all, int64_t d_size, int n_threads) {
+  int used = 1;
+#ifdef _OPENMP
+  if (n_threads > 0) omp_set_num_threads(n_threads);
+#pragma omp parallel
+  {
+#pragma omp single
+    used = omp_get_num_threads();
+    double complex* D = D_all + (int64_t)omp_get_thread_num() * d_size;
+#pragma omp for schedule(static)
+    for (int64_t it = 0; it < n_times; ++it) rotate_by_series(data + it * n_modes, R_basis + 2 * it, 1, n_modes, ell_min, ell_max, D);
+  }
+#else
+  (void)d_size;
+  (void)n_threads;
+  rotate_by_series(data, R_basis, n_times, n_modes, ell_min, ell_max, D_all);
+#endif
+  return used;
+}
+
 /* pointer-argument wrapper for ctypes */
 void wigner_D_matrices_p(const double* RaRb, int ell_min, int ell_max, double complex* D) {
   wigner_D_matrices(RaRb[0] + I * RaRb[1], RaRb[2] + I * RaRb[3], ell_min, ell_max, D);

@@ -38,3 +38,18 @@ def rotate_by_series(data, RaRb, ell_min, ell_max):
     f.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
     f(out.ctypes.data, R.ctypes.data, out.shape[0], out.shape[1], ell_min, ell_max, D.ctypes.data)
     return out
+
+
+def rotate_by_series_omp(data, RaRb, ell_min, ell_max, n_threads=0):
+    """OpenMP-over-time variant (all cores unless n_threads > 0): returns (rotated data, threads used)."""
+    out = np.ascontiguousarray(data, dtype=np.complex128).copy()
+    R = np.ascontiguousarray(RaRb, dtype=np.complex128)
+    d_size = total_size_D_matrices(ell_min, ell_max)
+    nt = n_threads if n_threads > 0 else (os.cpu_count() or 1)
+    D = np.zeros(d_size * nt, dtype=np.complex128)
+    f = load().rotate_by_series_omp
+    f.restype = ctypes.c_int
+    f.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_void_p,
+                  ctypes.c_int64, ctypes.c_int]
+    used = f(out.ctypes.data, R.ctypes.data, out.shape[0], out.shape[1], ell_min, ell_max, D.ctypes.data, d_size, nt)
+    return out, used
