@@ -1,0 +1,107 @@
+"""Seeded random sweep of the transformation's parameter space on the GPU against the oracle: data types (with the psi
+mixing terms), l ranges, output l, grid sizes (square / not, odd / even), supertranslation order, boost size (up to 0.3 c:
+time skews of hundreds of samples, ring overflows, sorted columns), frame rotations, uniform and jittered time axes, and
+the same for AsymptoticBondiData.  Small series so that the oracle stays cheap; every case prints its seed on failure."""
+import numpy as np
+import pytest
+
+from oracle import abd_ref
+from oracle import waveform_grid_ref as grid_ref
+from oracle.containers import ABD, WM, SpinWeights, h, news, psi0, psi1, psi2, psi3, psi4, sigma
+from tests.test_gpu_transform_modes import real_supertranslation
+
+pytestmark = pytest.mark.gpu
+
+
+def _series(rng, n, ell_min, ell_max, jitter):
+    t = np.linspace(-8.0, 14.0, n)
+    if jitter:
+        t = t + rng.uniform(-0.3, 0.3, n) * (t[1] - t[0])
+    m = np.concatenate([np.arange(-l, l + 1) for l in range(ell_min, ell_max + 1)])
+    ell = np.concatenate([np.full(2 * l + 1, l) for l in range(ell_min, ell_max + 1)])
+    a = (rng.normal(size=m.size) + 1j * rng.normal(size=m.size)) * 10.0 ** (-ell / 4.0)
+    ph = rng.uniform(0.02, 0.12) * t + rng.uniform(0, 2e-3) * t**2
+    return t, a[None, :] * np.exp(1j * m[None, :] * ph[:, None]) * (1 + 0.02 * t[:, None])
+
+
+def _random_kwargs(rng, ell_max):
+    kw = {}
+    if rng.random() < 0.8:
+        lst = int(rng.integers(1, 4))
+        kw["supertranslation"] = real_supertranslation(lst, int(rng.integers(1 << 30)), 10.0 ** rng.uniform(-2.5, -0.7))
+    if rng.random() < 0.7:
+        q = rng.normal(size=4)
+        kw["frame_rotation"] = q / np.linalg.norm(q)
+    if rng.random() < 0.8:
+        v = rng.normal(size=3)
+        kw["boost_velocity"] = v / np.linalg.norm(v) * 10.0 ** rng.uniform(-4, np.log10(0.3))
+    return kw
+
+
+@pytest.mark.parametrize("seed", range(36))
+def test_random_waveform_transform(ctx, seed):
+    import scri_amd
+
+    rng = np.random.default_rng(1000 + seed)
+    dataType = [h, sigma, news, psi4, psi3, psi2, psi1, psi0][seed % 8]
+    s = SpinWeights[dataType]
+    ell_max = int(rng.integers(max(2, abs(s)), 8))
+    n = int(rng.integers(60, 260))
+    t, data = _series(rng, n, abs(s), ell_max, jitter=rng.random() < 0.5)
+    w = WM(t=t, data=data, ell_min=abs(s), ell_max=ell_max, dataType=dataType)
+    kw = _random_kwargs(rng, ell_max)
+    if rng.random() < 0.4:
+        kw["n_theta"] = int(rng.integers(2 * ell_max + 3, 2 * ell_max + 12))
+        kw["n_phi"] = int(rng.integers(2 * ell_max + 3, 2 * ell_max + 12))
+    if rng.random() < 0.3:
+        kw["ell_max"] = int(rng.integers(abs(s), ell_max + 1))
+    aux_o, aux_g = {}, {}
+    if dataType in (psi3, psi2, psi1, psi0):  # the mixing terms need the higher Weyl scalars
+        for DT in range(dataType + 1, psi4 + 1):
+            la = int(rng.integers(abs(SpinWeights[DT]), ell_max + 1))
+            _, ad = _series(rng, n, abs(SpinWeights[DT]), la, jitter=False)
+            aux_o[f"psi{DT-1}_modes"] = WM(t=t, data=ad, ell_min=abs(SpinWeights[DT]), ell_max=la, dataType=DT)
+
+    def gpu(x):
+        return scri_amd.WaveformModes(t=x.t, data=x.data, ell_min=x.ell_min, ell_max=x.ell_max, dataType=x.dataType,
+                                      frameType=scri_amd.Inertial, r_is_scaled_out=True, m_is_scaled_out=True, ctx=ctx)
+
+    aux_g = {k: gpu(v) for k, v in aux_o.items()}
+    expect = grid_ref.transform(w, **kw, **aux_o)
+    got = gpu(w).transform(**kw, **aux_g)
+    info = (seed, dataType, ell_max, n, {k: (v if np.ndim(v) == 0 else np.round(np.asarray(v), 4).tolist()[:4]) for k, v in kw.items()})
+    assert got.t.shape == expect.t.shape, info
+    if expect.t.size:
+        assert np.abs(got.t - expect.t).max() < 1e-12, info
+        assert np.abs(got.data - expect.data).max() < 2e-12 * max(1.0, np.abs(expect.data).max()), info
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_random_abd_transform(ctx, seed):
+    import scri_amd
+
+    rng = np.random.default_rng(5000 + seed)
+    ell_max = int(rng.integers(2, 6))
+    n = int(rng.integers(60, 200))
+    t, _ = _series(rng, n, 0, 0, jitter=rng.random() < 0.5)
+    raw = np.zeros((6, n, (ell_max + 1) ** 2), dtype=complex)
+    for f, s in enumerate(ABD.spins):
+        _, d = _series(rng, n, 0, ell_max, jitter=False)
+        d[:, : s * s] = 0
+        raw[f] = d
+    kw = _random_kwargs(rng, ell_max)
+    if "boost_velocity" in kw:
+        kw["boost_velocity"] = kw["boost_velocity"] * min(1.0, 0.1 / np.linalg.norm(kw["boost_velocity"]))
+    if rng.random() < 0.4:
+        kw["working_ell_max"] = int(rng.integers(ell_max + 1, 2 * ell_max + 4))
+    if rng.random() < 0.4:
+        kw["output_ell_max"] = int(rng.integers(2, ell_max + 1))
+    expect = abd_ref.transform(ABD(t, raw, ell_max), **kw)
+    g = scri_amd.AsymptoticBondiData(t, ell_max, ctx=ctx)
+    g._raw_data[:] = raw
+    got = g.transform(**kw)
+    info = (seed, ell_max, n, sorted(kw))
+    assert got.n_times == expect.n_times and got.ell_max == expect.ell_max, info
+    if expect.n_times:
+        assert np.abs(got.u - expect.u).max() < 1e-12, info
+        assert np.abs(got._raw_data - expect.raw).max() < 2e-12 * max(1.0, np.abs(expect.raw).max()), info
