@@ -1,7 +1,5 @@
 """Adapters between `scri` objects and the engine, used by `scri_amd.patch_scri()`."""
-import numpy as np
-
-from . import engine, quaternions, waveform_grid
+from . import waveform_grid
 from .waveform_modes import WaveformModes as _WM
 
 

@@ -7,7 +7,6 @@ input rows up to `H = H_spline + H_skew` away; `bms_shard_
 range a rank needs, and `exchange_halos` fetches the missing rows from the neighbouring ranks with
 point-to-point sends -- the only communication of the path (no collective on the data).
 """
-import numpy as np
 
 
 def shard_bounds(n_times, world_size, rank):

@@ -2,11 +2,10 @@
 ``scri.WaveformModes`` that the path touches (scri/waveform_base.py:222-231 fields, :299-367 validity
 checks, :440-446 weights, :706-729 history, :950-967 interpolate; scri/waveform_modes.py:705-719
 transform).  Everything numerical is delegated to the GPU engine."""
-import numbers
 import numpy as np
 
 from . import engine, quaternions
-from . import Inertial, UnknownFrameType, UnknownDataType, h, SpinWeights, ConformalWeights, RScaling, DataNames, FrameNames
+from . import UnknownFrameType, UnknownDataType, SpinWeights, ConformalWeights, RScaling, DataNames, FrameNames
 from .mode_algebra import LM_range, LM_total_size
 
 _next_num = [0]
