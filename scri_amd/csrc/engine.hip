@@ -40,6 +40,7 @@ struct AnalysisPlan {
   bool fused = false;  // single-kernel analysis (kernels_analysis.hip, analysis_fused_kernel)
   bool large = false;  // folded phi-DFT + MFMA theta quadrature for grids too large for the fused kernel
   int ell_min_out = 0;
+  int spin = 0;
   double* d_dcs = nullptr;
   int n_theta = 0, n_phi = 0, n_pix = 0, n_out = 0, L = 0, nm = 0;
   // separable
@@ -665,6 +666,7 @@ static int build_analysis(bms_ctx* c, const char* tag, int n_theta, int n_phi, i
   A.large = A.separable && !A.fused && large_analysis_supported(n_theta, n_phi, A.L) && !getenv("SCRI_AMD_NO_LARGE_ANALYSIS") &&
             !getenv("SCRI_AMD_NO_FUSED_ANALYSIS");
   A.ell_min_out = ell_min_out;
+  A.spin = spin;
   if (A.separable) {
     if (A.large) {
       // twiddles are computed in the kernel; only the theta table below is needed
@@ -738,12 +740,12 @@ static int build_analysis(bms_ctx* c, const char* tag, int n_theta, int n_phi, i
 
 // G: [rows][2 n_pix] (row stride exactly 2 n_pix doubles) -> out[rows][ldo] complex modes
 static int run_analysis(bms_ctx* c, const AnalysisPlan& A, const double* d_G, long long rows, double* d_out, long long ldo,
-                        const int* col_of_pixel = nullptr) {
+                        const int* col_of_pixel = nullptr, long long ld_cols = 0) {
   hipStream_t S = c->stream;
   const long long P2 = 2LL * A.n_pix;
   if (A.fused) {
-    TIMED(c, BMS_TAG_ANALYSIS_FUSED, launch_analysis_fused(S, d_G, P2, rows, A.n_theta, A.n_phi, A.L, A.n_out, A.d_mindex, A.d_T,
-                                                           A.d_dcs, d_out, ldo, col_of_pixel));
+    TIMED(c, BMS_TAG_ANALYSIS_FUSED, launch_analysis_fused(S, d_G, col_of_pixel ? ld_cols : P2, rows, A.n_theta, A.n_phi, A.L, A.n_out,
+                                                           A.d_mindex, A.d_T, A.d_dcs, d_out, ldo, col_of_pixel, A.spin));
   } else if (A.large) {
     if (col_of_pixel) return fail(c, BMS_ERR_UNSUPPORTED, "internal: sorted columns need the fused analysis");
     double* d_F;
@@ -827,22 +829,26 @@ static int validate_common(bms_ctx* c, int64_t n, const double* t, const bms_tra
 // supertranslation modes; the four scalars the host needs for the output window and the chunk plan come back in T.
 struct DevPixel {
   double *rotors, *k, *alpha, *skew_a, *skew_b, *col_off, *col_scale, *xa, *xb, *ethk, *etha, *ethetha, *ik, *ik3;
-  const int* col_of_pixel = nullptr;  // set when the columns are stored sorted by time skew (kernels_swsh.hip)
+  const int* col_of_pixel = nullptr;  // set when the grid is stored as a column plan (kernels_swsh.hip, pixel_sort_kernel)
 };
-// the columns are sorted when there is a boost (time skew that grows with |u|) and the analysis can read them in any
-// order, i.e. runs as the fused kernel
-static bool sort_columns(const bms_transformation* tr, int n_out) {
+// Column plan of the grids: 0 = one column per grid pixel, in grid order.  When the analysis can read the columns in any
+// order (the fused kernel) the two pole rings are stored once each (1) and, with a boost, whose time skew grows with |u|,
+// the columns are also sorted by the skew rate (2).
+static int column_plan(const bms_transformation* tr, int n_out) {
+  if (getenv("SCRI_AMD_NO_COLUMN_SORT") || getenv("SCRI_AMD_NO_FUSED_ANALYSIS")) return 0;
+  if (tr->n_theta < 3 || tr->n_theta * tr->n_phi > pixel_sort_max() || tr->n_theta > MAX_THETA_SEPARABLE ||
+      !fused_analysis_supported(tr->n_theta, tr->n_phi, tr->ell_max_out, n_out))
+    return 0;
   const double* v = tr->boost_velocity;
-  if (v[0] == 0 && v[1] == 0 && v[2] == 0) return false;
-  if (getenv("SCRI_AMD_NO_COLUMN_SORT") || getenv("SCRI_AMD_NO_FUSED_ANALYSIS")) return false;
-  return tr->n_theta * tr->n_phi <= pixel_sort_max() && tr->n_theta <= MAX_THETA_SEPARABLE &&
-         fused_analysis_supported(tr->n_theta, tr->n_phi, tr->ell_max_out, n_out);
+  return (v[0] == 0 && v[1] == 0 && v[2] == 0) ? 1 : 2;
 }
+// On return T.n_pix is the number of COLUMNS (everything downstream is per column); T.n_theta * T.n_phi stays the grid.
 static int device_pixel_tables(bms_ctx* c, const bms_transformation* tr, PixelTables& T, int mode, int spin, int cw,
                                const std::vector<cplx>* coef0, const std::vector<cplx>* coef1, const cplx cv[4], DevPixel& D,
-                               bool sorted) {
+                               int plan) {
   init_pixel_tables(tr, T);
   const int n_pix = T.n_pix, lst = tr->ell_max_supertranslation, nst = (lst + 1) * (lst + 1);
+  const int n_cols = plan ? n_pix - 2 * (tr->n_phi - 1) : n_pix;
   PixelSpec P = base_pixel_spec(tr, T);
   P.mode = mode;
   P.spin = spin;
@@ -882,23 +888,24 @@ static int device_pixel_tables(bms_ctx* c, const bms_transformation* tr, PixelTa
   O.rotors = D.rotors, O.k = D.k, O.alpha = D.alpha, O.skew_a = D.skew_a, O.skew_b = D.skew_b;
   O.col_off = D.col_off, O.col_scale = D.col_scale, O.xa = D.xa, O.xb = D.xb;
   O.ethk = D.ethk, O.etha = D.etha, O.ethetha = D.ethetha, O.ik = D.ik, O.ik3 = D.ik3;
-  TIMED(c, BMS_TAG_SETUP, launch_pixel_tables(c->stream, P, O, n_pix, nullptr));
-  if (sorted) {
-    // sort on the skew rate just computed, then rebuild every table in that column order
-    int* d_perm;
+  int* d_perm = nullptr;
+  if (plan) {
     if ((rc = dev_buf_t(c, "pix_perm", (size_t)2 * n_pix, &d_perm))) return rc;
-    TIMED(c, BMS_TAG_SETUP, launch_pixel_sort(c->stream, D.skew_a, n_pix, d_perm, d_perm + n_pix));
-    TIMED(c, BMS_TAG_SETUP, launch_pixel_tables(c->stream, P, O, n_pix, d_perm));
+    if (plan == 2)  // the skew rate of every grid pixel first: it is the sort key
+      TIMED(c, BMS_TAG_SETUP, launch_pixel_tables(c->stream, P, O, n_pix, nullptr));
+    TIMED(c, BMS_TAG_SETUP, launch_pixel_sort(c->stream, D.skew_a, tr->n_theta, tr->n_phi, plan == 2, d_perm, d_perm + n_pix));
     D.col_of_pixel = d_perm + n_pix;
   }
-  // k, alpha, skew_a, skew_b are contiguous: one copy back
+  TIMED(c, BMS_TAG_SETUP, launch_pixel_tables(c->stream, P, O, n_cols, d_perm));
+  // k, alpha, skew_a, skew_b are contiguous (n_pix apart): one copy back
   std::vector<double> back((size_t)4 * n_pix);
   HIP_TRY(c, hipMemcpyAsync(back.data(), D.k, sizeof(double) * 4 * n_pix, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
-  std::memcpy(T.k.data(), back.data(), sizeof(double) * n_pix);
-  std::memcpy(T.alpha.data(), back.data() + n_pix, sizeof(double) * n_pix);
-  std::memcpy(T.skew_a.data(), back.data() + 2 * (size_t)n_pix, sizeof(double) * n_pix);
-  std::memcpy(T.skew_b.data(), back.data() + 3 * (size_t)n_pix, sizeof(double) * n_pix);
+  T.n_pix = n_cols;
+  T.k.assign(back.data(), back.data() + n_cols);
+  T.alpha.assign(back.data() + n_pix, back.data() + n_pix + n_cols);
+  T.skew_a.assign(back.data() + 2 * (size_t)n_pix, back.data() + 2 * (size_t)n_pix + n_cols);
+  T.skew_b.assign(back.data() + 3 * (size_t)n_pix, back.data() + 3 * (size_t)n_pix + n_cols);
   return BMS_OK;
 }
 
@@ -1011,7 +1018,7 @@ extern "C" int bms_transform_modes_shard(bms_ctx* c, const bms_wm_input* in, con
   }
   PixelTables T;
   DevPixel DP;
-  if ((rc = device_pixel_tables(c, tr, T, psi ? 1 : 0, s, in->conformal_weight, coef0.empty() ? nullptr : &coef0, nullptr, cv, DP, sort_columns(tr, n_out))))
+  if ((rc = device_pixel_tables(c, tr, T, psi ? 1 : 0, s, in->conformal_weight, coef0.empty() ? nullptr : &coef0, nullptr, cv, DP, column_plan(tr, n_out))))
     return rc;
   trace.mark("pixel tables (GPU) + copy back");
   const int n_pix = T.n_pix;
@@ -1120,7 +1127,7 @@ extern "C" int bms_transform_modes_shard(bms_ctx* c, const bms_wm_input* in, con
     TIMED(c, BMS_TAG_SPLINE_BACKWARD, launch_spline_backward_eval(S, d_Y, d_R, ldg, n_pix, g0, rows_in, n, d_x, d_tab, SPLINE_TILE, SPLINE_HALO,
                                            d_x, d_skewa, d_skewb, T.tt, c0, c1, d_G, P2));
     // analysis
-    if ((rc = run_analysis(c, ana, d_G, rows_out, d_out + (c0 - i_lo) * n_out * 2, 2LL * n_out, DP.col_of_pixel))) return rc;
+    if ((rc = run_analysis(c, ana, d_G, rows_out, d_out + (c0 - i_lo) * n_out * 2, 2LL * n_out, DP.col_of_pixel, P2))) return rc;
   }
   trace.mark("chunk loop (enqueue)");
   if (in->mem == BMS_HOST)
@@ -1156,7 +1163,7 @@ extern "C" int bms_rotor_grid(bms_ctx* c, const double fr[4], const double v[3],
   tr.n_phi = n_phi;
   PixelTables T;
   DevPixel DP;
-  int rc = device_pixel_tables(c, &tr, T, -1, 0, 0, nullptr, nullptr, nullptr, DP, false);
+  int rc = device_pixel_tables(c, &tr, T, -1, 0, 0, nullptr, nullptr, nullptr, DP, 0);
   if (rc) return rc;
   HIP_TRY(c, hipMemcpyAsync(out, DP.rotors, sizeof(double) * 4 * T.n_pix, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -1616,7 +1623,7 @@ extern "C" int bms_transform_abd_shard(bms_ctx* c, const double* u, const void* 
                       {-v[0] * std::sqrt(2 * M_PI / 3), v[1] * std::sqrt(2 * M_PI / 3)}};
   PixelTables T;
   DevPixel DP;
-  if ((rc = device_pixel_tables(c, tr, T, 2, 0, 0, &c1, &c2, cv, DP, sort_columns(tr, n_out)))) return rc;
+  if ((rc = device_pixel_tables(c, tr, T, 2, 0, 0, &c1, &c2, cv, DP, column_plan(tr, n_out)))) return rc;
   const int n_pix = T.n_pix;
   // window: timeprime = (u - tt) / gamma  (division, unlike the WaveformModes flavour)
   double umin = -INFINITY, umax = INFINITY;
@@ -1707,7 +1714,7 @@ extern "C" int bms_transform_abd_shard(bms_ctx* c, const double* u, const void* 
       TIMED(c, BMS_TAG_SPLINE_BACKWARD,
             launch_spline_backward_eval(S, grids.y[f], Rf, ldg, n_pix, g0, rows_in, n, d_x, d_tab, SPLINE_TILE, SPLINE_HALO,
                                         d_x, d_skewa, d_skewb, T.tt, c0, c1_, Gf, P2));
-      if ((rc = run_analysis(c, ana[spins[f] + 2], Gf, rows_out, d_out + ((size_t)f * fs_out + (c0 - i_lo)) * n_out * 2, 2LL * n_out, DP.col_of_pixel)))
+      if ((rc = run_analysis(c, ana[spins[f] + 2], Gf, rows_out, d_out + ((size_t)f * fs_out + (c0 - i_lo)) * n_out * 2, 2LL * n_out, DP.col_of_pixel, P2)))
         return rc;
     }
   }

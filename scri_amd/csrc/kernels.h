@@ -41,9 +41,11 @@ struct PixelSpec;
 struct PixelOut;
 // perm (device, may be null): column p holds grid pixel perm[p]
 hipError_t launch_pixel_tables(hipStream_t stream, const PixelSpec& P, const PixelOut& O, int n_pix, const int* perm);
-// perm = argsort(key) (ties by index), inv = its inverse; n <= pixel_sort_max()
+// Column plan of an n_theta x n_phi grid (n_theta n_phi <= pixel_sort_max(), n_theta >= 3): the pole rings contribute one
+// column each (n_cols = n_pix - 2 (n_phi - 1)); perm[n_cols] = grid pixel of a column, in grid order (by_key = 0) or sorted by
+// key (by_key = 1); inv[n_pix] = column of a grid pixel (pole pixels share their ring's column)
 int pixel_sort_max();
-hipError_t launch_pixel_sort(hipStream_t stream, const double* key, int n, int* perm, int* inv);
+hipError_t launch_pixel_sort(hipStream_t stream, const double* key, int n_theta, int n_phi, int by_key, int* perm, int* inv);
 
 // ---- separable analysis (kernels_analysis.hip): phi-DFT matrix for the GEMM, theta table, theta quadrature
 hipError_t launch_dft_matrix(hipStream_t stream, int n_phi, int L, double* B, long long ldb);
@@ -62,10 +64,11 @@ struct FusedGeom;
 int fused_analysis_supported(int n_theta, int n_phi, int L, int n_out);
 size_t fused_dft_table_size(int n_phi, int L);  // doubles
 hipError_t launch_dft_cs_matrix(hipStream_t stream, int n_phi, int L, double* D);
-// col_of_pixel (device, may be null): grid pixel g is column col_of_pixel[g] of G
+// col_of_pixel (device, may be null): grid pixel g is column col_of_pixel[g] of G; then the pixels k > 0 of the two pole
+// rings are read from their ring's column times the spin phase e^{-+ i spin phi_k}
 hipError_t launch_analysis_fused(hipStream_t stream, const double* G, long long ldg, long long n_rows, int n_theta, int n_phi,
                                  int L, int n_out, const int* m_index, const double* T, const double* D, double* out,
-                                 long long ldo, const int* col_of_pixel);
+                                 long long ldo, const int* col_of_pixel, int spin);
 
 // ---- dense fp64 GEMM on MFMA: C[M x N] = (A[M x K] * B[K x N] - col_off[N]) * col_scale[N]
 // A row-major (lda), B row-major (ldb, zero padded to a multiple of 128 columns and 16 rows), C row-major (ldc).

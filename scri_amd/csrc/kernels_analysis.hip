@@ -154,6 +154,7 @@ struct FusedGeom {
   int nk;  // folded ring length n_phi / 2 + 1
   int ks;  // k-steps of 4 covering nk, rounded up to a built kernel: 3, 5 or 6 (tables are zero padded to it)
   int n_sec;  // output modes beyond one per thread (<= 64): handled by the first threads with their T rows in LDS
+  int spin;   // spin weight of the field: phase of the de-duplicated pole pixels (used with col_of_pixel)
 };
 
 __host__ __device__ inline int fused_pd(int L) { return L <= 16 ? 16 : 48; }  // = 16 mod 32: B fragment halves on different banks
@@ -222,7 +223,7 @@ __device__ __forceinline__ void analysis_fused_body(const double* __restrict__ G
   // A sample that is its own partner (k = 0, Nyquist) is loaded twice and its partner weighted by 0.
   int slot[F_EPT], off1[F_EPT], off2[F_EPT];
   double wb[F_EPT];
-  double2 pa[F_EPT], pb[F_EPT];
+  double2 pa[F_EPT], pb[F_EPT], pha[F_EPT], phb[F_EPT];
 #pragma unroll
   for (int q = 0; q < F_EPT; ++q) {
     const int e = tid + q * nthreads;
@@ -234,6 +235,15 @@ __device__ __forceinline__ void analysis_fused_body(const double* __restrict__ G
     off1[q] = 2 * (col_of_pixel ? col_of_pixel[g1] : g1);
     off2[q] = 2 * (col_of_pixel ? col_of_pixel[g2] : g2);
     wb[q] = k2 == kk ? 0.0 : 1.0;
+    // a pole ring is stored as its pixel k = 0: pixel k is that value times e^{-i s phi_k} (north) / e^{+i s phi_k} (south)
+    double a1 = 0.0, a2 = 0.0;
+    if (col_of_pixel && ok && (j == 0 || j == g.n_theta - 1)) {
+      const double sg = j == 0 ? -1.0 : 1.0;
+      a1 = sg * (double)((g.spin * kk) % g.n_phi) / (double)g.n_phi;
+      a2 = sg * (double)((g.spin * k2) % g.n_phi) / (double)g.n_phi;
+    }
+    sincospi(2.0 * a1, &pha[q].y, &pha[q].x);
+    sincospi(2.0 * a2, &phb[q].y, &phb[q].x);
   }
   auto fetch = [&](long long t) {
 #pragma unroll
@@ -249,12 +259,13 @@ __device__ __forceinline__ void analysis_fused_body(const double* __restrict__ G
     // ---- step 0: fold into the operands
 #pragma unroll
     for (int q = 0; q < F_EPT; ++q) {
-      const double bx = wb[q] * pb[q].x, by = wb[q] * pb[q].y;
+      const double ax = pa[q].x * pha[q].x - pa[q].y * pha[q].y, ay = pa[q].x * pha[q].y + pa[q].y * pha[q].x;
+      const double bx = wb[q] * (pb[q].x * phb[q].x - pb[q].y * phb[q].y), by = wb[q] * (pb[q].x * phb[q].y + pb[q].y * phb[q].x);
       if (slot[q] >= 0) {
-        Es[slot[q]] = pa[q].x + bx;
-        Es[slot[q] + 4 * F_PA] = pa[q].y + by;
-        Os[slot[q]] = wb[q] * pa[q].x - bx;
-        Os[slot[q] + 4 * F_PA] = wb[q] * pa[q].y - by;
+        Es[slot[q]] = ax + bx;
+        Es[slot[q] + 4 * F_PA] = ay + by;
+        Os[slot[q]] = wb[q] * ax - bx;
+        Os[slot[q] + 4 * F_PA] = wb[q] * ay - by;
       }
     }
     __syncthreads();  // operands complete; every thread has finished step 2 of the previous row
@@ -399,12 +410,13 @@ static hipError_t launch_fused_t(K kernel, hipStream_t stream, dim3 grid, dim3 b
 
 hipError_t launch_analysis_fused(hipStream_t stream, const double* G, long long ldg, long long n_rows, int n_theta, int n_phi,
                                  int L, int n_out, const int* m_index, const double* T, const double* D, double* out,
-                                 long long ldo, const int* col_of_pixel) {
+                                 long long ldo, const int* col_of_pixel, int spin) {
   if (n_rows <= 0) return hipSuccess;
   FusedGeom g;
   size_t lds;
   int pj;
   fused_geometry(n_theta, n_phi, L, n_out, g, lds, pj);
+  g.spin = spin;
   // one thread per output mode (up to 64 modes beyond 256 ride along as second modes), never fewer than 4 waves
   int threads = g.n_sec ? 256 : ((n_out + 63) / 64) * 64;
   if (threads < 256) threads = 256;

@@ -127,13 +127,21 @@ hipError_t launch_pixel_tables(hipStream_t stream, const PixelSpec& P, const Pix
 // cares about the order (the synthesis matrix and every per-pixel table are simply built in it); the analysis reads
 // grid pixel g from column inv[g].  One workgroup, bitonic sort of (key, index) pairs in LDS; n <= 2048.
 constexpr int SORT_N = 2048;
-__global__ __launch_bounds__(1024) void pixel_sort_kernel(const double* __restrict__ key, int n, int* __restrict__ perm,
-                                                          int* __restrict__ inv) {
+// The rings theta = 0 and theta = pi are one direction each: their n_phi pixels differ only by a rotation of the rotor
+// about its own z axis, i.e. by the spin phase e^{-+ i s phi_k} of the value.  Only pixel k = 0 of a pole ring becomes a
+// column (n_cols = n_pix - 2 (n_phi - 1)); the analysis re-creates the others from it.  by_key = 0: columns in grid
+// order (no boost); by_key = 1: sorted by key.
+__global__ __launch_bounds__(1024) void pixel_sort_kernel(const double* __restrict__ key, int n, int n_theta, int n_phi, int by_key,
+                                                          int* __restrict__ perm, int* __restrict__ inv) {
   __shared__ double k[SORT_N];
   __shared__ int id[SORT_N];
   const int tid = threadIdx.x;
+  auto duplicate = [&](int g) {
+    const int j = g / n_phi, kk = g - j * n_phi;
+    return (j == 0 || j == n_theta - 1) && kk > 0;
+  };
   for (int i = tid; i < SORT_N; i += blockDim.x) {
-    k[i] = i < n ? key[i] : INFINITY;
+    k[i] = (i < n && !duplicate(i)) ? (by_key ? key[i] : (double)i) : INFINITY;
     id[i] = i;
   }
   for (int size = 2; size <= SORT_N; size <<= 1) {
@@ -153,17 +161,24 @@ __global__ __launch_bounds__(1024) void pixel_sort_kernel(const double* __restri
     }
   }
   __syncthreads();
-  for (int i = tid; i < n; i += blockDim.x) {
+  const int n_cols = n - 2 * (n_phi - 1);
+  for (int i = tid; i < n_cols; i += blockDim.x) {
     perm[i] = id[i];
     inv[id[i]] = i;
+  }
+  __syncthreads();  // inv of the pole representatives is visible to the whole (single) workgroup
+  for (int kk = 1 + tid; kk < n_phi; kk += blockDim.x) {
+    inv[kk] = inv[0];
+    inv[(n_theta - 1) * n_phi + kk] = inv[(n_theta - 1) * n_phi];
   }
 }
 
 int pixel_sort_max() { return SORT_N; }
 
-hipError_t launch_pixel_sort(hipStream_t stream, const double* key, int n, int* perm, int* inv) {
-  if (n > SORT_N) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(pixel_sort_kernel, dim3(1), dim3(1024), 0, stream, key, n, perm, inv);
+hipError_t launch_pixel_sort(hipStream_t stream, const double* key, int n_theta, int n_phi, int by_key, int* perm, int* inv) {
+  const int n = n_theta * n_phi;
+  if (n > SORT_N || n_theta < 3) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(pixel_sort_kernel, dim3(1), dim3(1024), 0, stream, key, n, n_theta, n_phi, by_key, perm, inv);
   return hipGetLastError();
 }
 
