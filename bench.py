@@ -24,7 +24,7 @@ FP64_MATRIX_PEAK_TFLOPS = 78.6  # MI355X fp64 matrix (= vector) peak, AMD public
 # HBM traffic of the dominant kernel comes from separate rocprofv3 --pmc passes of this same command
 # (tools/run_profiles.sh -> tools/pmc_summary.py; 2 x FETCH_SIZE + WRITE_SIZE as MI355X_MICROARCH.md prescribes for
 # gfx950); the committed summary is read back here so the bench line carries it.
-PMC_SUMMARY = os.path.join(ROOT, "profiles", "r01_f_pmc_cfg3.json")
+PMC_SUMMARY = os.path.join(ROOT, "profiles", "r01_g_pmc_cfg3.json")
 DOMINANT_KERNEL = "bms::zgemm3m_mfma_kernel"
 
 
@@ -340,11 +340,12 @@ def main():
                 "unit": "TFLOP/s",
                 "frac": (achieved / FP64_MATRIX_PEAK_TFLOPS) if achieved else None,
                 "traffic": pmc_traffic(args.workload, world, per_gpu),
-                "traffic_unit": "bytes of HBM per launch (profiles/r01_f_pmc_cfg3.json)",
+                "traffic_unit": "bytes of HBM per launch (profiles/r01_g_pmc_cfg3.json)",
                 "flops_per_launch": flops_per_launch,
                 "ms_per_launch": g_ms / max(g_calls, 1),
-                # the kernel forms each complex product from 3 real MFMA products (not 4): flops it actually executes
-                "executed_tflops": 0.75 * achieved if achieved else None,
+                # what the MFMA pipe actually executes: 3 real products per complex one (not 4), and, when the fused analysis
+                # is in use (grids up to 40 x 40), one column per pole ring instead of n_phi
+                "executed_tflops": 0.75 * achieved * ((n_pix - 2 * (n_theta - 1)) / n_pix if n_theta <= 40 else 1.0) if achieved else None,
             },
             "kernels": kernels,
         }
