@@ -251,12 +251,20 @@ def main():
         out = torch.empty((own, n_modes), dtype=torch.complex128, device=dev)
     local = torch.from_numpy(local_host).to(dev)
     del local_host
+    # N > 1, WaveformModes: the rows a rank needs (own rows + halos) live in one buffer; the own rows are placed there once
+    # and every step only moves the halo rows
+    ext_buf = None
+    if world > 1 and not abd and backend == "nccl":
+        ext_buf = torch.empty((need[rank][1] - need[rank][0], n_modes), dtype=torch.complex128, device=dev)
+        lo = have[rank][0] - need[rank][0]
+        ext_buf[lo : lo + own] = local
+        local = ext_buf[lo : lo + own]
     ctx = _lib.Context(dev_index)
     ctx.enable_timing(True)
 
     def step():
         if world > 1:
-            ext = sharding.exchange_halos(local, have[rank], need[rank], have, need, dim=1 if abd else 0)
+            ext = sharding.exchange_halos(local, have[rank], need[rank], have, need, dim=1 if abd else 0, out=ext_buf)
             torch.cuda.synchronize()
         else:
             ext = local

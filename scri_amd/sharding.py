@@ -16,13 +16,15 @@ def shard_bounds(n_times, world_size, rank):
     return i0, i0 + base + (1 if rank < rem else 0)
 
 
-def exchange_halos(local, have, need, all_have, all_need, group=None, dim=0):
+def exchange_halos(local, have, need, all_have, all_need, group=None, dim=0, out=None):
     """Return rows [need[0], need[1]) of the global array, given this rank's rows `local` = [have[0], have[1]).
 
     local: torch tensor [rows, cols] float64/complex128 (CPU for gloo, GPU for nccl); `dim` names the time axis
     when it is not the first one (AsymptoticBondiData storage is [6, rows, modes]: dim=1).
     all_have / all_need: per-rank (start, stop) lists known to every rank (static plan, no communication).
-    Rows outside every rank's range are never requested."""
+    Rows outside every rank's range are never requested.
+    out: optional preallocated result (time axis first, shape of the return value) whose own-row block already holds
+    `local` (e.g. `local` is a view of it): then only the halo rows move."""
     import torch
     import torch.distributed as dist
 
@@ -38,11 +40,20 @@ def exchange_halos(local, have, need, all_have, all_need, group=None, dim=0):
         local = local.cpu()
     loc = torch.view_as_real(local) if is_complex else local
     out_shape = (need[1] - need[0],) + tuple(loc.shape[1:])
-    out = torch.empty(out_shape, dtype=loc.dtype, device=loc.device)
-    # own rows
-    a, b = max(need[0], have[0]), min(need[1], have[1])
-    if b > a:
-        out[a - need[0] : b - need[0]] = loc[a - have[0] : b - have[0]]
+    prefilled = out is not None
+    if prefilled:
+        if dim != 0 or out.device != loc.device:
+            raise ValueError("a preallocated result needs the time axis first and the device of `local`")
+        result = out
+        out = torch.view_as_real(out) if is_complex else out
+        if tuple(out.shape) != out_shape:
+            raise ValueError(f"preallocated result has shape {tuple(out.shape)}, expected {out_shape}")
+    else:
+        out = torch.empty(out_shape, dtype=loc.dtype, device=loc.device)
+        # own rows
+        a, b = max(need[0], have[0]), min(need[1], have[1])
+        if b > a:
+            out[a - need[0] : b - need[0]] = loc[a - have[0] : b - have[0]]
     ops, recv_bufs = [], []
     for peer in range(world):
         if peer == rank:
@@ -62,6 +73,8 @@ def exchange_halos(local, have, need, all_have, all_need, group=None, dim=0):
             req.wait()
     for a, b, buf in recv_bufs:
         out[a - need[0] : b - need[0]] = buf
+    if prefilled:
+        return result
     out = torch.view_as_complex(out) if is_complex else out
     if out.device != device:
         out = out.to(device)

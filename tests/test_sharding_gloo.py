@@ -62,6 +62,12 @@ def _worker(rank, world, port, n_times, ell_max, tmpdir):
         # the exchanged rows are exactly the global rows [need0, need1)
         _, ref_rows, _ = synthetic.workload("cfg3", n_times=n_times, rows=need[rank])
         assert np.array_equal(ext.numpy(), ref_rows[:, :nm])
+        # the same exchange into a preallocated buffer that already holds the own rows: only the halos move
+        buf = torch.full((need[rank][1] - need[rank][0], nm), np.nan + 0j, dtype=torch.complex128)
+        lo = have[rank][0] - need[rank][0]
+        buf[lo : lo + local.shape[0]] = local
+        ext2 = sharding.exchange_halos(buf[lo : lo + local.shape[0]], have[rank], need[rank], have, need, out=buf)
+        assert ext2 is buf and np.array_equal(buf.numpy(), ref_rows[:, :nm])
         idx, t_out, data = _oracle_shard(t, ext.numpy(), need[rank][0], have[rank][0], have[rank][1], kw, ell_max)
         np.savez(os.path.join(tmpdir, f"rank{rank}.npz"), idx=idx, t=t_out, data=data, window=np.array(window))
     finally:
