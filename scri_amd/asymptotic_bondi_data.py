@@ -39,6 +39,7 @@ class AsymptoticBondiData:
         if self._time.ndim != 1:
             raise ValueError(f"Input `time` parameter must be a 1-d array of floats; it has shape {self._time.shape}")
         self._ell_max = int(ell_max)
+        self._truncator = multiplication_truncator
         self._raw_data = np.zeros((6, self._time.size, (self._ell_max + 1) ** 2), dtype=complex)
         self.frameType = Inertial if frameType is None else frameType
         self.frame = np.zeros((0, 4))
@@ -67,7 +68,7 @@ class AsymptoticBondiData:
         return self._raw_data.shape[-1]
 
     def copy(self):
-        new = type(self)(self._time.copy(), self._ell_max, frameType=self.frameType, ctx=self._ctx)
+        new = type(self)(self._time.copy(), self._ell_max, multiplication_truncator=self._truncator, frameType=self.frameType, ctx=self._ctx)
         new._raw_data[:] = self._raw_data
         return new
 
@@ -75,14 +76,14 @@ class AsymptoticBondiData:
         """Slice along time (scri/asymptotic_bondi_data/__init__.py: abd[i0:i1])"""
         if not isinstance(key, slice):
             raise TypeError("AsymptoticBondiData can only be sliced along time: abd[i0:i1]")
-        new = type(self)(self._time[key], self._ell_max, frameType=self.frameType, ctx=self._ctx)
+        new = type(self)(self._time[key], self._ell_max, multiplication_truncator=self._truncator, frameType=self.frameType, ctx=self._ctx)
         new._raw_data[:] = self._raw_data[:, key]
         return new
 
     def interpolate(self, new_times):
         """scri/asymptotic_bondi_data/__init__.py:218-233: cubic-spline all six fields to `new_times`."""
         new_times = np.asarray(new_times, dtype=float)
-        new = type(self)(new_times, self._ell_max, frameType=self.frameType, ctx=self._ctx)
+        new = type(self)(new_times, self._ell_max, multiplication_truncator=self._truncator, frameType=self.frameType, ctx=self._ctx)
         y = np.ascontiguousarray(np.moveaxis(self._raw_data, 0, 1)).reshape(self.n_times, -1)
         out = engine.cubic_spline(self._time, y, new_times, ctx=self._ctx)
         new._raw_data[:] = np.moveaxis(out.reshape(new_times.size, 6, -1), 1, 0)
@@ -99,7 +100,7 @@ class AsymptoticBondiData:
         n_theta = 2 * working_ell_max + 1
         tr = engine.make_transformation(supertranslation, frame_rotation, boost_velocity, n_theta, n_theta, output_ell_max)
         u_new, raw_new = engine.transform_abd(self._time, self._raw_data, self.ell_max, tr, ctx=self._ctx)
-        abdprime = type(self)(u_new, output_ell_max, frameType=self.frameType, ctx=self._ctx)
+        abdprime = type(self)(u_new, output_ell_max, multiplication_truncator=self._truncator, frameType=self.frameType, ctx=self._ctx)
         abdprime._raw_data[:] = raw_new
         return abdprime
 
@@ -112,7 +113,8 @@ def _field_property(i):
         # a ModesTimeSeries VIEW of the field (scri/asymptotic_bondi_data/__init__.py:117-216): writes go to _raw_data
         from .modes_time_series import ModesTimeSeries
 
-        return ModesTimeSeries(self._raw_data[i], self._time, spin_weight=_SPINS[i], ell_min=0, ell_max=self._ell_max)
+        return ModesTimeSeries(self._raw_data[i], self._time, spin_weight=_SPINS[i], ell_min=0, ell_max=self._ell_max,
+                               multiplication_truncator=self._truncator)
 
     def set(self, value):
         self._raw_data[i] = value
@@ -134,3 +136,11 @@ AsymptoticBondiData.charge_vector_from_aspect = staticmethod(_bms_charges.charge
 from . import map_to_superrest_frame as _superrest  # noqa: E402
 
 AsymptoticBondiData.map_to_superrest_frame = _superrest.map_to_superrest_frame
+
+from . import abd_ivp as _ivp  # noqa: E402
+
+AsymptoticBondiData.from_initial_values = classmethod(_ivp.from_initial_values)
+for _f in _ivp.METHODS:
+    setattr(AsymptoticBondiData, _f.__name__, _f)
+AsymptoticBondiData.bondi_violations = property(_ivp.bondi_violations)
+AsymptoticBondiData.bondi_violation_norms = property(_ivp.bondi_violation_norms)

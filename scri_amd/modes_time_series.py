@@ -243,6 +243,10 @@ class ModesTimeSeries(np.ndarray):
             return self.multiply(other)
         return self._like(self.ndarray * other)
 
+    def norm(self):
+        """L2 norm over the sphere at every time: sqrt(sum |a_lm|^2) (sf.Modes.norm)"""
+        return np.linalg.norm(self.ndarray, axis=-1)
+
     def __rmul__(self, other):
         return self._like(other * self.ndarray)
 
@@ -255,7 +259,7 @@ class ModesTimeSeries(np.ndarray):
         """Modes of the product (sf.Modes.multiply): exact, formed on a grid fine enough for l_a + l_b, truncated to
         `truncator((l_a, l_b))` (default: the sum)."""
         if truncator is None:
-            truncator = sum
+            truncator = self._metadata.get("multiplication_truncator", sum)
         return self.grid_multiply(
             other, working_ell_max=self.ell_max + other.ell_max, output_ell_max=int(truncator((self.ell_max, other.ell_max)))
         )
