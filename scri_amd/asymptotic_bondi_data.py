@@ -49,7 +49,28 @@ class AsymptoticBondiData:
     def time(self):
         return self._time
 
+    @time.setter
+    def time(self, new_time):
+        self._time[:] = new_time
+
     u = t = time
+
+    @property
+    def LM(self):
+        from .mode_algebra import LM_range
+
+        return LM_range(0, self._ell_max)
+
+    @property
+    def h(self):
+        """The strain h = 2 sigma-bar as a WaveformModes object, l >= 2 (scri/asymptotic_bondi_data/__init__.py:119-131)"""
+        from . import Inertial, WaveformModes
+        from . import h as h_DataType
+
+        return WaveformModes(
+            t=self._time.copy(), data=2.0 * self.sigma.bar.ndarray[:, 4:], ell_min=2, ell_max=self._ell_max, frameType=Inertial,
+            dataType=h_DataType, r_is_scaled_out=True, m_is_scaled_out=True, ctx=self._ctx,
+        )
 
     @property
     def n_times(self):
