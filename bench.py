@@ -189,6 +189,10 @@ def main():
     ap.add_argument("--n-times", type=int, default=None, help="time steps PER GPU (default: 1e5; cfg5: 2e5 / 8)")
     ap.add_argument("--working-ell-max", type=int, default=None, help="cfg5 only (default 2 ell_max + 1 = 49 -> 99 x 99 grid)")
     ap.add_argument("--cpu-sample", type=int, default=30000, help="time steps of the CPU-baseline sample (0: skip)")
+    ap.add_argument("--partition", default="auto", choices=["auto", "rows", "columns"],
+                    help="N > 1: time shards + halo exchange (rows) or grid-column parts + reduce-scatter (columns, for strong "
+                    "boosts); auto = sharding.choose_partition (rows for the BASELINE.json workloads)")
+    ap.add_argument("--boost-scale", type=float, default=1.0, help="multiplies the workload's boost velocity (stress variants)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -225,7 +229,10 @@ def main():
     abd = args.workload == "cfg5"
     per_gpu = int(args.n_times or (spec["n_times"] // 8 if abd else spec["n_times"]))
     n_global = per_gpu * world
-    kw = spec["kwargs"]
+    kw = dict(spec["kwargs"])
+    if args.boost_scale != 1.0:
+        kw["boost_velocity"] = np.asarray(kw["boost_velocity"], dtype=float) * args.boost_scale
+        spec["kwargs"] = kw
     ell_max = spec["ell_max"]
     lst = int(round(np.sqrt(len(kw["supertranslation"])))) - 1
     if abd:
@@ -243,6 +250,9 @@ def main():
     # this rank's rows of the global series, resident in HBM before the timed region
     have, need, window = sharding.plan(np.arange(n_global) * spec["dt"], tr, world)
     own = have[rank][1] - have[rank][0]
+    columns = world > 1 and (args.partition == "columns" or (args.partition == "auto" and sharding.choose_partition(have, need) == "columns"))
+    if columns and abd:
+        raise SystemExit("--partition columns is wired into the bench for the WaveformModes workloads only")
     if abd:
         t_global, local_host, _ = synthetic.abd_workload(args.workload, n_times=n_global, rows=have[rank])
         out = torch.empty((6, own, n_modes), dtype=torch.complex128, device=dev)
@@ -254,7 +264,11 @@ def main():
     # N > 1, WaveformModes: the rows a rank needs (own rows + halos) live in one buffer; the own rows are placed there once
     # and every step only moves the halo rows
     ext_buf = None
-    if world > 1 and not abd and backend == "nccl":
+    if columns:
+        # every rank's contribution covers all output rows; equal blocks for the reduce-scatter
+        n_new_all = window[1] - window[0]
+        part_buf = torch.zeros((sharding.padded_rows(n_new_all, world)[0], n_modes), dtype=torch.complex128, device=dev)
+    if world > 1 and not abd and backend == "nccl" and not columns:
         ext_buf = torch.empty((need[rank][1] - need[rank][0], n_modes), dtype=torch.complex128, device=dev)
         lo = have[rank][0] - need[rank][0]
         ext_buf[lo : lo + own] = local
@@ -263,6 +277,16 @@ def main():
     ctx.enable_timing(True)
 
     def step():
+        if columns:
+            # plan B: gather the whole input series, transform this rank's grid columns over all times, reduce-scatter the sum
+            full = sharding.replicate_rows(local, have)
+            torch.cuda.synchronize()
+            engine.transform_modes(
+                t_global, full.data_ptr(), 2, ell_max, -2, -1, engine.BMS_TERM_H, tr, ctx=ctx, device=True, ld=n_modes,
+                out_ptr=part_buf.data_ptr(), shard=(0, n_global, 0, n_global, rank, world),
+            )
+            rows, _ = sharding.reduce_scatter_rows(part_buf, n_new_all)
+            return rows.shape[0]
         if world > 1:
             ext = sharding.exchange_halos(local, have[rank], need[rank], have, need, dim=1 if abd else 0, out=ext_buf)
             torch.cuda.synchronize()
@@ -306,12 +330,12 @@ def main():
         value = n_global * args.steps / elapsed
         # roofline of the dominant kernel (zgemm3m_mfma_kernel, synthesis launches): algorithmic flops
         # 8 * n_modes * n_pix per time row x rows per launch / HIP-event duration per launch
-        rows_in = (need[0][1] - need[0][0]) if world > 1 else n_global
+        rows_in = n_global if columns or world == 1 else (need[0][1] - need[0][0])
         g_ms, g_calls = timing["gemm_synthesis"]
         # (cfg5: the work space is walked in chunks, 6 launches each; per-launch figures are averages over them and
         # ignore the few halo rows that neighbouring chunks both synthesise)
         launches_per_step = max(g_calls, 1) / args.steps
-        flops_per_launch = 8.0 * n_modes * n_pix * rows_in * n_fields / launches_per_step
+        flops_per_launch = 8.0 * n_modes * n_pix * rows_in * n_fields / launches_per_step / (world if columns else 1)
         achieved = flops_per_launch / (g_ms / max(g_calls, 1) * 1e-3) / 1e12 if g_ms > 0 else None
         kernels = {k: {"ms_per_step": v[0] / args.steps, "launches_per_step": v[1] / args.steps} for k, v in timing.items() if v[1]}
         line = {
@@ -336,9 +360,11 @@ def main():
                     f"{args.workload}: AsymptoticBondiData psi0..psi4 + sigma, ell 0..{ell_max} (6 x {n_modes} modes), " if abd
                     else f"{args.workload}: WaveformModes h, ell 2..{ell_max} ({n_modes} modes), "
                 )
-                + f"{per_gpu} time steps per GPU ({n_global} total), supertranslation(l<=2) + frame_rotation + boost |v|=3.7e-4, "
+                + f"{per_gpu} time steps per GPU ({n_global} total), supertranslation(l<=2) + frame_rotation + boost |v|={3.7417e-4 * args.boost_scale:.3g}, "
                 f"{n_theta}x{n_theta} grid, {n_out} output steps on rank 0",
-                "sharding": f"time axis x{world}, RCCL point-to-point halo exchange of input modes" if world > 1 else "none",
+                "sharding": "none" if world == 1 else (
+                    f"grid columns x{world}: all-gather of input modes, reduce-scatter of output modes (RCCL)" if columns
+                    else f"time axis x{world}, RCCL point-to-point halo exchange of input modes"),
             },
             "roofline": {
                 "bound": "mfma",

@@ -142,6 +142,11 @@ int bms_transform_modes(bms_ctx* ctx, const bms_wm_input* in, const bms_transfor
 typedef struct {
   int64_t data_row0, data_rows;
   int64_t out_i0, out_i1;
+  /* Pixel-column partition (SURVEY 8(e) plan B, for boosts whose time skew makes the row halo comparable to a time
+   * shard): with col_parts > 1 the call synthesises, splines and analyses only part col_part of the grid columns and
+   * data_out receives that part's CONTRIBUTION to every output sample (the analysis is linear in the grid columns):
+   * the sum over the col_parts parts is the result, i.e. one reduce-scatter over ranks.  0 or 1: all columns. */
+  int32_t col_part, col_parts;
 } bms_shard;
 int bms_shard_plan(bms_ctx* ctx, const double* t, int64_t n_times, const bms_transformation* tr, int64_t out_i0,
                    int64_t out_i1, int64_t need_rows[2], int64_t window[2]);

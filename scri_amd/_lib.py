@@ -58,7 +58,8 @@ class bms_transformation(ctypes.Structure):
 
 
 class bms_shard(ctypes.Structure):
-    _fields_ = [("data_row0", c_i64), ("data_rows", c_i64), ("out_i0", c_i64), ("out_i1", c_i64)]
+    _fields_ = [("data_row0", c_i64), ("data_rows", c_i64), ("out_i0", c_i64), ("out_i1", c_i64), ("col_part", ctypes.c_int32),
+                ("col_parts", ctypes.c_int32)]
 
 
 KERNEL_TAGS = ("rotate", "setup", "gemm_synthesis", "spline_forward", "spline_backward", "gemm_analysis", "pointwise", "theta_quadrature", "analysis_fused")
@@ -121,6 +122,31 @@ class BMSError(RuntimeError):
     pass
 
 
+def _share_hip_runtime_with_torch():
+    """One HIP runtime per process.  The PyTorch-ROCm wheel bundles its own libamdhip64.so; if this library pulled in
+    the system copy first and torch were imported afterwards, the process would hold two runtimes and the second one to
+    initialise sees no GPU ("No HIP GPUs are available").  Loading torch's copy first (same soname) makes the dynamic
+    linker resolve this library's dependency to it, whichever of the two packages the user touches first.  Without a
+    torch installation the system runtime is used."""
+    import importlib.util
+    import sys
+
+    if "torch" in sys.modules:
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    for root in (spec.submodule_search_locations if spec and spec.submodule_search_locations else ()):
+        path = os.path.join(root, "lib", "libamdhip64.so")
+        if os.path.exists(path):
+            try:
+                ctypes.CDLL(path, mode=ctypes.RTLD_GLOBAL)
+            except OSError:
+                pass
+            return
+
+
 def load():
     """Load libscri_amd.so (once).  Raises ImportError with build instructions if it is missing."""
     global _lib
@@ -131,6 +157,7 @@ def load():
                     f"{LIB_PATH} not found: build it with `make -C {os.path.join(_HERE, 'csrc')}` "
                     "(or `python -c 'import __graft_entry__ as g; g.build()'`).  scri_amd has no CPU fallback."
                 )
+            _share_hip_runtime_with_torch()
             lib = ctypes.CDLL(LIB_PATH)
             for name, (res, args) in SIGNATURES.items():
                 fn = getattr(lib, name)  # AttributeError if the library lacks a declared symbol

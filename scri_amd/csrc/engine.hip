@@ -909,6 +909,40 @@ static int device_pixel_tables(bms_ctx* c, const bms_transformation* tr, PixelTa
   return BMS_OK;
 }
 
+// unit maps: row r of the (zeroed) [n][2 n] matrix gets 1 + 0i in complex column r
+__global__ __launch_bounds__(256) void unit_maps_kernel(double* __restrict__ I, int n) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r < n) I[(size_t)r * 2 * n + 2 * r] = 1.0;
+}
+
+// pixel-column partition (plan B of SURVEY 8(e)): whole 64-column GEMM tiles [cA, cB) of the column plan
+static int column_range(bms_ctx* c, const bms_shard* sh, int n_cols, int& cA, int& cB) {
+  cA = 0, cB = n_cols;
+  if (!sh || sh->col_parts <= 1) return BMS_OK;
+  if (sh->col_part < 0 || sh->col_part >= sh->col_parts) return fail(c, BMS_ERR_INVALID, "column part %d outside [0, %d)", sh->col_part, sh->col_parts);
+  const long long n_tiles = (n_cols + 63) / 64;
+  cA = (int)std::min<long long>(n_cols, 64 * (n_tiles * sh->col_part / sh->col_parts));
+  cB = (int)std::min<long long>(n_cols, 64 * (n_tiles * (sh->col_part + 1) / sh->col_parts));
+  return BMS_OK;
+}
+// The analysis is linear in the grid columns, so a part's contribution is G[:, cA:cB] . At[cA:cB, :] with At = the analysis
+// of the n_cols unit maps (row r = modes of "1 in column r"), produced by the same analysis kernel the unsplit path runs.
+static int part_analysis_matrix(bms_ctx* c, const AnalysisPlan& A, const char* name, int n_cols, const int* col_of_pixel,
+                                double** d_At, long long* ld_at) {
+  hipStream_t S = c->stream;
+  *ld_at = round_up(2LL * A.n_out, 128);
+  const size_t at_rows = (size_t)round_up(n_cols, 8) + 8;
+  double* d_I;
+  int rc;
+  if ((rc = dev_buf_t(c, name, at_rows * *ld_at, d_At))) return rc;
+  if ((rc = dev_buf_t(c, "unit_maps", (size_t)n_cols * 2 * n_cols, &d_I))) return rc;
+  HIP_TRY(c, hipMemsetAsync(*d_At, 0, sizeof(double) * at_rows * *ld_at, S));
+  HIP_TRY(c, hipMemsetAsync(d_I, 0, sizeof(double) * (size_t)n_cols * 2 * n_cols, S));
+  hipLaunchKernelGGL(unit_maps_kernel, dim3((n_cols + 255) / 256), dim3(256), 0, S, d_I, n_cols);
+  HIP_TRY(c, hipGetLastError());
+  return run_analysis(c, A, d_I, n_cols, *d_At, *ld_at, col_of_pixel, 2LL * n_cols);
+}
+
 // The shared pipeline: `nf` synthesised fields -> pointwise stage -> spline -> analysis, chunked over time.
 struct PointwiseWM {
   // WM flavour: y = (f0 + sum_i coeff_i f_i X^power_i - off) * scale, see bms_transform_modes
@@ -1021,7 +1055,11 @@ extern "C" int bms_transform_modes_shard(bms_ctx* c, const bms_wm_input* in, con
   if ((rc = device_pixel_tables(c, tr, T, psi ? 1 : 0, s, in->conformal_weight, coef0.empty() ? nullptr : &coef0, nullptr, cv, DP, column_plan(tr, n_out))))
     return rc;
   trace.mark("pixel tables (GPU) + copy back");
-  const int n_pix = T.n_pix;
+  const int n_cols = T.n_pix;
+  const bool col_split = sh && sh->col_parts > 1;
+  int cA, cB;
+  if ((rc = column_range(c, sh, n_cols, cA, cB))) return rc;
+  const int n_pix = cB - cA;  // columns this call synthesises and splines
   int64_t i_lo, i_hi;
   output_window(T, in->t, n, i_lo, i_hi);
   // shard: rows [row0, row0 + rows) of the global data are present; produce outputs with global index in [out_i0, out_i1)
@@ -1036,8 +1074,8 @@ extern "C" int bms_transform_modes_shard(bms_ctx* c, const bms_wm_input* in, con
   const int64_t n_new = i_hi - i_lo;
   *n_times_out = n_new;
   if (n_new == 0) return BMS_OK;
-  double *d_rot = DP.rotors, *d_off = DP.col_off, *d_scale = DP.col_scale, *d_skewa = DP.skew_a, *d_skewb = DP.skew_b;
-  double *d_alpha = DP.alpha, *d_xa = DP.xa, *d_xb = DP.xb, *d_x;
+  double *d_rot = DP.rotors, *d_off = DP.col_off + 2 * cA, *d_scale = DP.col_scale + 2 * cA, *d_skewa = DP.skew_a + cA, *d_skewb = DP.skew_b + cA;
+  double *d_alpha = DP.alpha + cA, *d_xa = DP.xa + 2 * cA, *d_xb = DP.xb + 2 * cA, *d_x;
   SplineTable* d_tab;
   if ((rc = upload_times(c, in->t, n, t_lo, t_hi, row0, row0 + rows_avail, &d_x, &d_tab))) return rc;
   trace.mark("window (host) + time upload + spline factors");
@@ -1063,7 +1101,7 @@ extern "C" int bms_transform_modes_shard(bms_ctx* c, const bms_wm_input* in, con
     snprintf(nm, sizeof nm, "in_aux%d", a);
     if ((rc = stage_in(c, nm, in->aux_data[a], in->mem, (size_t)rows_avail * f.ld * 16, &f.d_data))) return rc;
   }
-  const long long ldb = round_up(P2, 128);
+  const long long ldb = round_up(2LL * n_cols, 128);
   for (int fi = 0; fi < n_fields; ++fi) {
     FieldPlan& f = F[fi];
     f.K = 2 * LM_total_size(f.ell_min, f.ell_max);
@@ -1073,11 +1111,15 @@ extern "C" int bms_transform_modes_shard(bms_ctx* c, const bms_wm_input* in, con
     snprintf(nm, sizeof nm, "Bsyn%d", fi);
     if ((rc = dev_buf_t(c, nm, (size_t)rows * ldb, &f.d_B))) return rc;
     HIP_TRY(c, hipMemsetAsync(f.d_B, 0, sizeof(double) * rows * ldb, S));
-    TIMED(c, BMS_TAG_SETUP, launch_swsh_matrix_complex(S, d_rot, n_pix, f.spin, f.ell_min, f.ell_max, f.d_B, ldb));
+    TIMED(c, BMS_TAG_SETUP, launch_swsh_matrix_complex(S, d_rot, n_cols, f.spin, f.ell_min, f.ell_max, f.d_B, ldb));
   }
   trace.mark("uploads + synthesis matrices");
   AnalysisPlan ana;
   if ((rc = build_analysis(c, "wm", T.n_theta, T.n_phi, s, ell_min_out, tr->ell_max_out, ana))) return rc;
+  double* d_At = nullptr;
+  long long ld_at = 0;
+  if (col_split && n_pix > 0)
+    if ((rc = part_analysis_matrix(c, ana, "At", n_cols, DP.col_of_pixel, &d_At, &ld_at))) return rc;
   trace.mark("analysis plan");
   // spline factors
 
@@ -1085,6 +1127,16 @@ extern "C" int bms_transform_modes_shard(bms_ctx* c, const bms_wm_input* in, con
   double* d_out = (double*)data_out;
   if (in->mem == BMS_HOST)
     if ((rc = dev_buf_t(c, "out_data", (size_t)n_new * n_out * 2, &d_out))) return rc;
+
+  if (n_pix == 0) {  // more parts than column tiles: this part contributes nothing
+    if (in->mem == BMS_HOST)
+      std::memset(data_out, 0, (size_t)n_new * n_out * 16);
+    else
+      HIP_TRY(c, hipMemsetAsync(d_out, 0, (size_t)n_new * n_out * 16, S));
+    for (int64_t i = 0; i < n_new; ++i) t_out[i] = (1 / T.gamma) * (in->t[i_lo + i] - T.tt);
+    HIP_TRY(c, hipStreamSynchronize(S));
+    return BMS_OK;
+  }
 
   // ---------------------------------------------------------------- chunk loop over output samples
   const int margin = SPLINE_HALO + 2;
@@ -1110,12 +1162,12 @@ extern "C" int bms_transform_modes_shard(bms_ctx* c, const bms_wm_input* in, con
     if (psi)
       if ((rc = dev_buf_t(c, "Yaux", (size_t)rows_in * ldg, &d_Yaux))) return rc;
     // synthesis (+ fused affine map when there is no psi mixing)
-    TIMED(c, BMS_TAG_GEMM_SYNTHESIS, launch_zgemm3m(S, F[0].d_data + (g0 - row0) * F[0].ld * 2, F[0].ld * 2, F[0].d_B, ldb, d_Y, ldg, rows_in, n_pix,
+    TIMED(c, BMS_TAG_GEMM_SYNTHESIS, launch_zgemm3m(S, F[0].d_data + (g0 - row0) * F[0].ld * 2, F[0].ld * 2, F[0].d_B + 2 * cA, ldb, d_Y, ldg, rows_in, n_pix,
                             F[0].K / 2, psi ? nullptr : d_off, psi ? nullptr : d_scale));
     if (psi) {
       for (int a = 0; a < in->n_aux; ++a) {
         const FieldPlan& f = F[1 + a];
-        TIMED(c, BMS_TAG_GEMM_SYNTHESIS, launch_zgemm3m(S, f.d_data + (g0 - row0) * f.ld * 2, f.ld * 2, f.d_B, ldb, d_Yaux, ldg, rows_in, n_pix, f.K / 2,
+        TIMED(c, BMS_TAG_GEMM_SYNTHESIS, launch_zgemm3m(S, f.d_data + (g0 - row0) * f.ld * 2, f.ld * 2, f.d_B + 2 * cA, ldb, d_Yaux, ldg, rows_in, n_pix, f.K / 2,
                                 nullptr, nullptr));
         TIMED(c, BMS_TAG_POINTWISE, launch_psi_mix(S, d_Y, d_Yaux, ldg, n_pix, rows_in, d_x + g0, d_alpha, d_xa, d_xb, in->aux_coeff[a],
                                   in->aux_power[a]));
@@ -1127,7 +1179,11 @@ extern "C" int bms_transform_modes_shard(bms_ctx* c, const bms_wm_input* in, con
     TIMED(c, BMS_TAG_SPLINE_BACKWARD, launch_spline_backward_eval(S, d_Y, d_R, ldg, n_pix, g0, rows_in, n, d_x, d_tab, SPLINE_TILE, SPLINE_HALO,
                                            d_x, d_skewa, d_skewb, T.tt, c0, c1, d_G, P2));
     // analysis
-    if ((rc = run_analysis(c, ana, d_G, rows_out, d_out + (c0 - i_lo) * n_out * 2, 2LL * n_out, DP.col_of_pixel, P2))) return rc;
+    if (col_split) {
+      TIMED(c, BMS_TAG_GEMM_ANALYSIS, launch_zgemm3m(S, d_G, P2, d_At + (size_t)cA * ld_at, ld_at, d_out + (c0 - i_lo) * n_out * 2, 2LL * n_out,
+                                                     rows_out, n_out, n_pix, nullptr, nullptr));
+    } else if ((rc = run_analysis(c, ana, d_G, rows_out, d_out + (c0 - i_lo) * n_out * 2, 2LL * n_out, DP.col_of_pixel, P2)))
+      return rc;
   }
   trace.mark("chunk loop (enqueue)");
   if (in->mem == BMS_HOST)
@@ -1624,10 +1680,14 @@ extern "C" int bms_transform_abd_shard(bms_ctx* c, const double* u, const void* 
   PixelTables T;
   DevPixel DP;
   if ((rc = device_pixel_tables(c, tr, T, 2, 0, 0, &c1, &c2, cv, DP, column_plan(tr, n_out)))) return rc;
-  const int n_pix = T.n_pix;
+  const int n_cols = T.n_pix;
+  const bool col_split = sh && sh->col_parts > 1;
+  int cA, cB;
+  if ((rc = column_range(c, sh, n_cols, cA, cB))) return rc;
+  const int n_pix = cB - cA;  // columns this call synthesises and splines
   // window: timeprime = (u - tt) / gamma  (division, unlike the WaveformModes flavour)
   double umin = -INFINITY, umax = INFINITY;
-  for (int p = 0; p < n_pix; ++p) {
+  for (int p = 0; p < n_cols; ++p) {
     umin = std::max(umin, T.k[p] * (u[0] - T.alpha[p]));
     umax = std::min(umax, T.k[p] * (u[n - 1] - T.alpha[p]));
   }
@@ -1649,17 +1709,18 @@ extern "C" int bms_transform_abd_shard(bms_ctx* c, const double* u, const void* 
   if (first_index_out) *first_index_out = i_lo;
   for (int64_t i = 0; i < n_new; ++i) u_out[i] = (u[i_lo + i] - T.tt) / T.gamma;
   if (n_new == 0) return BMS_OK;
-  double *d_rot = DP.rotors, *d_skewa = DP.skew_a, *d_skewb = DP.skew_b, *d_alpha = DP.alpha, *d_ethk = DP.ethk,
-         *d_etha = DP.etha, *d_ethetha = DP.ethetha, *d_ik = DP.ik, *d_ik3 = DP.ik3;
+  double *d_rot = DP.rotors, *d_skewa = DP.skew_a + cA, *d_skewb = DP.skew_b + cA, *d_alpha = DP.alpha + cA, *d_ethk = DP.ethk + 2 * cA,
+         *d_etha = DP.etha + 2 * cA, *d_ethetha = DP.ethetha + 2 * cA, *d_ik = DP.ik + cA, *d_ik3 = DP.ik3 + cA;
   double* d_x;
   SplineTable* d_tab;
   if ((rc = upload_times(c, u, n, t_lo, t_hi, row0, row0 + rows_avail, &d_x, &d_tab))) return rc;
 
-  const long long P2 = 2LL * n_pix, ldg = round_up(P2, 16), ldb = round_up(P2, 128);
+  const long long P2 = 2LL * n_pix, ldg = round_up(P2, 16), ldb = round_up(2LL * n_cols, 128);
   const int K = 2 * nm;
   const long long brows = round_up(K, 16);
   // five distinct spins: matrices / analysis plans indexed by spin + 2
-  double* d_B[5];
+  double *d_B[5], *d_At[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+  long long ld_at = 0;
   AnalysisPlan ana[5];
   for (int si = 0; si < 5; ++si) {
     char nm1[32], tag[16];
@@ -1667,8 +1728,12 @@ extern "C" int bms_transform_abd_shard(bms_ctx* c, const double* u, const void* 
     snprintf(tag, sizeof tag, "abd%d", si);
     if ((rc = dev_buf_t(c, nm1, (size_t)brows * ldb, &d_B[si]))) return rc;
     HIP_TRY(c, hipMemsetAsync(d_B[si], 0, sizeof(double) * brows * ldb, S));
-    TIMED(c, BMS_TAG_SETUP, launch_swsh_matrix_complex(S, d_rot, n_pix, si - 2, 0, ell_max, d_B[si], ldb));
+    TIMED(c, BMS_TAG_SETUP, launch_swsh_matrix_complex(S, d_rot, n_cols, si - 2, 0, ell_max, d_B[si], ldb));
     if ((rc = build_analysis(c, tag, T.n_theta, T.n_phi, si - 2, 0, tr->ell_max_out, ana[si]))) return rc;
+    if (col_split && n_pix > 0) {
+      snprintf(nm1, sizeof nm1, "abd_At%d", si);
+      if ((rc = part_analysis_matrix(c, ana[si], nm1, n_cols, DP.col_of_pixel, &d_At[si], &ld_at))) return rc;
+    }
   }
 
   const double* d_raw;
@@ -1676,6 +1741,17 @@ extern "C" int bms_transform_abd_shard(bms_ctx* c, const double* u, const void* 
   double* d_out = (double*)raw_out;
   if (mem == BMS_HOST)
     if ((rc = dev_buf_t(c, "out_data", (size_t)6 * fs_out * n_out * 2, &d_out))) return rc;
+
+  if (n_pix == 0) {  // more parts than column tiles: this part contributes nothing
+    for (int f = 0; f < 6; ++f) {
+      if (mem == BMS_HOST)
+        std::memset((char*)raw_out + (size_t)f * fs_out * n_out * 16, 0, (size_t)n_new * n_out * 16);
+      else
+        HIP_TRY(c, hipMemsetAsync(d_out + (size_t)f * fs_out * n_out * 2, 0, (size_t)n_new * n_out * 16, S));
+    }
+    HIP_TRY(c, hipStreamSynchronize(S));
+    return BMS_OK;
+  }
 
   // ---- chunk loop: 6 fields x (Y, R, G)
   const int margin = SPLINE_HALO + 2;
@@ -1701,7 +1777,7 @@ extern "C" int bms_transform_abd_shard(bms_ctx* c, const double* u, const void* 
     for (int f = 0; f < 6; ++f) {
       grids.y[f] = d_Y + (size_t)f * rows_in * ldg;
       TIMED(c, BMS_TAG_GEMM_SYNTHESIS,
-            launch_zgemm3m(S, d_raw + ((size_t)f * rows_avail + (g0 - row0)) * nm * 2, 2LL * nm, d_B[spins[f] + 2], ldb, grids.y[f], ldg, rows_in,
+            launch_zgemm3m(S, d_raw + ((size_t)f * rows_avail + (g0 - row0)) * nm * 2, 2LL * nm, d_B[spins[f] + 2] + 2 * cA, ldb, grids.y[f], ldg, rows_in,
                            n_pix, K / 2, nullptr, nullptr));
     }
     TIMED(c, BMS_TAG_POINTWISE,
@@ -1714,7 +1790,11 @@ extern "C" int bms_transform_abd_shard(bms_ctx* c, const double* u, const void* 
       TIMED(c, BMS_TAG_SPLINE_BACKWARD,
             launch_spline_backward_eval(S, grids.y[f], Rf, ldg, n_pix, g0, rows_in, n, d_x, d_tab, SPLINE_TILE, SPLINE_HALO,
                                         d_x, d_skewa, d_skewb, T.tt, c0, c1_, Gf, P2));
-      if ((rc = run_analysis(c, ana[spins[f] + 2], Gf, rows_out, d_out + ((size_t)f * fs_out + (c0 - i_lo)) * n_out * 2, 2LL * n_out, DP.col_of_pixel, P2)))
+      double* out_f = d_out + ((size_t)f * fs_out + (c0 - i_lo)) * n_out * 2;
+      if (col_split) {
+        TIMED(c, BMS_TAG_GEMM_ANALYSIS, launch_zgemm3m(S, Gf, P2, d_At[spins[f] + 2] + (size_t)cA * ld_at, ld_at, out_f, 2LL * n_out, rows_out, n_out, n_pix,
+                                                       nullptr, nullptr));
+      } else if ((rc = run_analysis(c, ana[spins[f] + 2], Gf, rows_out, out_f, 2LL * n_out, DP.col_of_pixel, P2)))
         return rc;
     }
   }

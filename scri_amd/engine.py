@@ -135,7 +135,9 @@ def transform_modes(
     aux: sequence of (data, ell_min, ell_max, spin, coeff, power[, ld]).
     shard: optional (data_row0, data_rows, out_i0, out_i1) -- `t` stays the GLOBAL time array, `data` holds only
     rows [data_row0, data_row0 + data_rows); outputs are those with global input index in [out_i0, out_i1);
-    the returned tuple then has the first global index appended."""
+    the returned tuple then has the first global index appended.  Two more entries (col_part, col_parts) select a
+    part of the grid columns (include/scri_amd.h, bms_shard): the output is then that part's contribution, to be
+    summed over the parts."""
     ctx = _ctx(ctx)
     t = np.ascontiguousarray(t, dtype=float)
     n = t.shape[0]
@@ -180,7 +182,7 @@ def transform_modes(
     sh = None
     n_alloc = n
     if shard is not None:
-        sh = bms_shard(int(shard[0]), int(shard[1]), int(shard[2]), int(shard[3]))
+        sh = bms_shard(*[int(x) for x in shard])
         n_alloc = max(0, min(n, int(shard[3])) - max(0, int(shard[2])))
     t_out = np.empty(max(n_alloc, 1), dtype=float)
     shp = ctypes.byref(sh) if sh is not None else None
@@ -230,7 +232,7 @@ def transform_abd(u, raw, ell_max, transformation, ctx=None, shard=None, device=
     sh = None
     fs_out = n
     if shard is not None:
-        sh = bms_shard(int(shard[0]), int(shard[1]), int(shard[2]), int(shard[3]))
+        sh = bms_shard(*[int(x) for x in shard])
         fs_out = int(shard[3]) - int(shard[2])
     shp = ctypes.byref(sh) if sh is not None else None
     u_out = np.empty(max(fs_out, 1), dtype=float)

@@ -93,3 +93,75 @@ def plan(t_global, transformation, world_size):
         # a rank with no output still "needs" nothing
         need.append(tuple(nr) if nr[1] > nr[0] else (have[r][0], have[r][0]))
     return have, need, tuple(window)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# Plan B of SURVEY section 8(e): partition the grid COLUMNS instead of the time axis.  A strong boost skews the time
+# axis of each direction by up to beta |u|, so the row halo of a time shard grows until the shards overlap almost
+# entirely (beta = 0.1 at |u| = 1e4 dt: 1e3 rows each side for every 1e4 rows of shard).  Splitting the columns needs no
+# halo at all: every rank holds the whole input series, synthesises and splines its own columns over all times, and
+# contributes its part of the (linear) analysis; one reduce-scatter over the ranks sums the parts and leaves each rank
+# with a block of output rows.
+
+
+def choose_partition(have, need, max_halo_fraction=0.25):
+    """"rows" (time shards + halo exchange) unless some rank's halo exceeds `max_halo_fraction` of its shard: "columns"."""
+    for (h0, h1), (n0, n1) in zip(have, need):
+        own = h1 - h0
+        if n1 > n0 and own > 0 and max(h0 - n0, n1 - h1) > max_halo_fraction * own:
+            return "columns"
+    return "rows"
+
+
+def replicate_rows(local, have, group=None, dim=0):
+    """Every rank's rows [have[r][0], have[r][1]) -> the whole series on every rank (one all_gather; the input modes are
+    a few GB at most against 288 GB of HBM)."""
+    import torch
+    import torch.distributed as dist
+
+    world = dist.get_world_size(group)
+    is_complex = local.is_complex()
+    if dim != 0:
+        local = local.movedim(dim, 0)
+    loc = (torch.view_as_real(local) if is_complex else local).contiguous()
+    widest = max(h1 - h0 for h0, h1 in have)
+    pad = torch.zeros((widest,) + tuple(loc.shape[1:]), dtype=loc.dtype, device=loc.device)
+    pad[: loc.shape[0]] = loc
+    gathered = torch.empty((world * widest,) + tuple(loc.shape[1:]), dtype=loc.dtype, device=loc.device)
+    dist.all_gather_into_tensor(gathered, pad, group=group)
+    out = torch.cat([gathered[r * widest : r * widest + (have[r][1] - have[r][0])] for r in range(world)])
+    out = torch.view_as_complex(out) if is_complex else out
+    return out.movedim(0, dim).contiguous() if dim != 0 else out
+
+
+def padded_rows(n_rows, world_size):
+    """Row count of the buffer a rank's contribution is written into: equal blocks for the reduce-scatter."""
+    block = -(-int(n_rows) // int(world_size))
+    return block * world_size, block
+
+
+def reduce_scatter_rows(partial, n_rows, group=None):
+    """Sum the ranks' contributions and leave rows [r0, r1) of the sum on this rank.
+
+    partial: torch complex128/float64 [padded_rows(n_rows, world)[0], ...] with this rank's contribution in the first
+    n_rows rows (the padding is ignored).  Returns (block [r1 - r0, ...], (r0, r1))."""
+    import torch
+    import torch.distributed as dist
+
+    rank = dist.get_rank(group)
+    world = dist.get_world_size(group)
+    total, block = padded_rows(n_rows, world)
+    if partial.shape[0] != total:
+        raise ValueError(f"contribution has {partial.shape[0]} rows, expected the padded count {total}")
+    is_complex = partial.is_complex()
+    src = torch.view_as_real(partial) if is_complex else partial
+    r0, r1 = min(n_rows, rank * block), min(n_rows, (rank + 1) * block)
+    if dist.get_backend(group) == "gloo":  # gloo has no reduce-scatter: all-reduce and keep the own block (CPU tests)
+        host = src.cpu() if src.device.type != "cpu" else src.clone()
+        dist.all_reduce(host, group=group)
+        mine = host[rank * block : (rank + 1) * block].to(src.device)
+    else:
+        mine = torch.empty((block,) + tuple(src.shape[1:]), dtype=src.dtype, device=src.device)
+        dist.reduce_scatter_tensor(mine, src, group=group)
+    mine = torch.view_as_complex(mine) if is_complex else mine
+    return mine[: r1 - r0], (r0, r1)

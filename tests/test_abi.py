@@ -33,7 +33,7 @@ def test_struct_layouts_match_header_sizes():
     from scri_amd import _lib
 
     # sizes implied by the header on LP64: guards against drift between the header and the ctypes mirror
-    assert ctypes.sizeof(_lib.bms_shard) == 32
+    assert ctypes.sizeof(_lib.bms_shard) == 32 + 8
     assert ctypes.sizeof(_lib.bms_transformation) == 8 + 8 + 32 + 24 + 16
     assert ctypes.sizeof(_lib.bms_wm_input) == 8 + 8 + 8 + 8 + 4 * 8 + 32 + 32 + 16 + 16 + 16 + 32 + 16
 
@@ -69,3 +69,21 @@ def test_product_does_not_import_the_oracle():
                 text = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", text, flags=re.M), f"{f} imports the oracle"
                 assert "/root/reference" not in text
+
+
+def test_one_hip_runtime_whichever_is_loaded_first():
+    """torch bundles its own libamdhip64; the library must end up on the same copy even when it is loaded before torch
+    (two runtimes in one process: the second to initialise finds no GPU)."""
+    import subprocess
+    import sys
+
+    code = (
+        "import os, sys; sys.path.insert(0, %r)\n"
+        "from scri_amd import _lib; _lib.load()\n"
+        "import torch\n"
+        "paths = {l.split()[-1] for l in open('/proc/self/maps') if 'libamdhip64' in l}\n"
+        "print(len(paths))\n"
+    ) % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr
+    assert out.stdout.strip().splitlines()[-1] == "1"

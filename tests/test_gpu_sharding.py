@@ -37,6 +37,69 @@ def test_shards_reassemble_to_unsharded(ctx):
         assert np.abs(np.concatenate(ds) - d_ref).max() < 1e-14 * max(1.0, np.abs(d_ref).max())
 
 
+def test_column_parts_sum_to_unsharded(ctx):
+    """Plan B of SURVEY 8(e): each part synthesises/splines its own grid columns over all times and returns its
+    contribution to the modes; the contributions add up to the unsharded result."""
+    from scri_amd import engine
+
+    t, data, tr, ell_max = _case()
+    n = t.size
+    t_ref, d_ref = engine.transform_modes(t, data, 2, ell_max, -2, -1, engine.BMS_TERM_H, tr, ctx=ctx)
+    scale = max(1.0, np.abs(d_ref).max())
+    for parts in (2, 3, 40):  # 40 > number of 64-column tiles: some parts are empty
+        total = 0
+        for p in range(parts):
+            to, do, first = engine.transform_modes(t, data, 2, ell_max, -2, -1, engine.BMS_TERM_H, tr, ctx=ctx, shard=(0, n, 0, n, p, parts))
+            assert np.array_equal(to, t_ref)
+            total = total + do
+        assert np.abs(total - d_ref).max() < 2e-14 * scale
+    # nothing special about a single part of one
+    to, do, _ = engine.transform_modes(t, data, 2, ell_max, -2, -1, engine.BMS_TERM_H, tr, ctx=ctx, shard=(0, n, 0, n, 0, 1))
+    assert np.array_equal(do, d_ref)
+    with pytest.raises(ValueError, match="column part"):
+        engine.transform_modes(t, data, 2, ell_max, -2, -1, engine.BMS_TERM_H, tr, ctx=ctx, shard=(0, n, 0, n, 3, 3))
+
+
+@pytest.mark.parametrize("n_theta_extra", [0, 12])
+def test_column_parts_strong_boost_and_psi_terms(ctx, n_theta_extra):
+    """beta = 0.1: the case plan B exists for (the row halo of a time shard would span most of the series); a psi3
+    waveform with its psi4 companion exercises the per-column tables of the mixing stage.  The larger grid takes the
+    unsorted column order (no pole-ring merging) through the same code."""
+    from scri_amd import engine, sharding
+
+    rng = np.random.default_rng(5)
+    n, ell_max = 3000, 6
+    t = np.arange(n) * 0.1
+    m3 = np.concatenate([np.arange(-l, l + 1) for l in range(1, ell_max + 1)])
+    m4 = np.concatenate([np.arange(-l, l + 1) for l in range(2, ell_max + 1)])
+    ph = 0.05 * t + 2e-5 * t**2
+    psi3 = (rng.normal(size=m3.size) + 1j * rng.normal(size=m3.size))[None, :] * np.exp(1j * m3[None, :] * ph[:, None])
+    psi4 = (rng.normal(size=m4.size) + 1j * rng.normal(size=m4.size))[None, :] * np.exp(1j * m4[None, :] * ph[:, None])
+    st = np.zeros(9, dtype=complex)
+    st[0], st[2], st[6] = 0.4, 0.1, 0.05
+    n_theta = 2 * (ell_max + 2) + 1 + n_theta_extra
+    tr = engine.make_transformation(st, [0.9, 0.1, -0.3, 0.2], [0.06, -0.05, 0.06], n_theta, n_theta, ell_max)
+    aux = [(psi4, 2, ell_max, -2, 1.0, 1)]
+    args = (t, psi3, 1, ell_max, -1, -4, engine.BMS_TERM_PSI, tr)
+    t_ref, d_ref = engine.transform_modes(*args, ctx=ctx, aux=aux)
+    have, need, _ = sharding.plan(t, tr, 4)
+    assert sharding.choose_partition(have, need) == "columns"
+    total = 0
+    for p in range(4):
+        to, do, _ = engine.transform_modes(*args, ctx=ctx, aux=aux, shard=(0, n, 0, n, p, 4))
+        total = total + do
+    assert np.array_equal(to, t_ref)
+    assert np.abs(total - d_ref).max() < 2e-14 * max(1.0, np.abs(d_ref).max())
+    # a column part of a time block: rows [a, b) of the contributions
+    a, b = 1000, 1700
+    part = 0
+    for p in range(2):
+        to, do, first = engine.transform_modes(*args, ctx=ctx, aux=aux, shard=(0, n, a, b, p, 2))
+        part = part + do
+    i0 = np.searchsorted(t_ref, to[0] - 1e-9)
+    assert np.abs(part - d_ref[i0 : i0 + part.shape[0]]).max() < 2e-14 * max(1.0, np.abs(d_ref).max())
+
+
 def test_insufficient_halo_is_rejected(ctx):
     from scri_amd import engine, sharding
 
@@ -99,6 +162,32 @@ def test_abd_shards_reassemble_to_unsharded(ctx):
         assert firsts[0] == window[0]
         assert np.array_equal(np.concatenate(us), u_ref)
         assert np.abs(np.concatenate(rs, axis=1) - r_ref).max() < 1e-14 * max(1.0, np.abs(r_ref).max())
+
+
+@pytest.mark.parametrize("ell_max", [4, 9])  # 9: a 39 x 39 grid, past the fused analysis (columns in grid order)
+def test_abd_column_parts_sum_to_unsharded(ctx, ell_max):
+    """Plan B for the six AsymptoticBondiData fields: per-part contributions add up to the unsharded transformation."""
+    from scri_amd import engine
+
+    u, raw, tr, ell_max = _abd_case(n=1500, ell_max=ell_max)
+    n = u.size
+    u_ref, r_ref = engine.transform_abd(u, raw, ell_max, tr, ctx=ctx)
+    scale = max(1.0, np.abs(r_ref).max())
+    for parts in (2, 5):
+        total = 0
+        for p in range(parts):
+            uo, ro, first = engine.transform_abd(u, raw, ell_max, tr, ctx=ctx, shard=(0, n, 0, n, p, parts))
+            assert np.array_equal(uo, u_ref)
+            total = total + ro[:, : u_ref.size]
+        assert np.abs(total - r_ref).max() < 5e-14 * scale
+    # a column part of a block of output rows
+    a, b = 400, 900
+    part = 0
+    for p in range(3):
+        uo, ro, first = engine.transform_abd(u, raw, ell_max, tr, ctx=ctx, shard=(0, n, a, b, p, 3))
+        part = part + ro[:, : uo.size]
+    i0 = np.searchsorted(u_ref, uo[0] - 1e-9)
+    assert np.abs(part - r_ref[:, i0 : i0 + uo.size]).max() < 5e-14 * scale
 
 
 def test_abd_shard_with_insufficient_halo_is_rejected(ctx):

@@ -173,3 +173,77 @@ def test_two_rank_sharded_abd_transform_equals_global(tmp_path):
     assert np.abs(np.concatenate([p["u"] for p in parts]) - ref.u).max() < 1e-13
     got = np.concatenate([p["raw"] for p in parts], axis=1)
     assert np.abs(got - ref.raw).max() < 1e-12 * max(1.0, np.abs(ref.raw).max())
+
+
+# ------------------------------------------------------------------------------------------------- plan B: grid columns
+def _columns_worker(rank, world, port, n_times, ell_max, tmpdir):
+    import torch
+    import torch.distributed as dist
+
+    from oracle import waveform_grid_ref as grid_ref
+    from oracle.containers import WM, h
+    from scri_amd import engine, synthetic, sharding
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        t, _, spec = synthetic.workload("cfg3", n_times=n_times)
+        kw = dict(spec["kwargs"])
+        kw["boost_velocity"] = np.array([0.06, -0.05, 0.06])  # beta = 0.1: time shards would overlap almost entirely
+        n_theta = 2 * (ell_max + 2) + 1
+        tr = engine.make_transformation(kw["supertranslation"], kw["frame_rotation"], kw["boost_velocity"], n_theta, n_theta, ell_max)
+        have, need, window = sharding.plan(t, tr, world)
+        assert sharding.choose_partition(have, need) == "columns"
+        nm = (ell_max + 1) ** 2 - 4
+        _, mine, _ = synthetic.workload("cfg3", n_times=n_times, rows=have[rank])
+        full = sharding.replicate_rows(torch.from_numpy(np.ascontiguousarray(mine[:, :nm])), have)
+        _, ref_rows, _ = synthetic.workload("cfg3", n_times=n_times)
+        assert np.array_equal(full.numpy(), ref_rows[:, :nm])
+        # this rank's columns: every world-th pixel of the grid (any partition of the columns sums to the whole)
+        w = WM(t=t, data=full.numpy(), ell_min=2, ell_max=ell_max, dataType=h)
+        uprm, grid, n_th, n_ph = grid_ref.from_modes(w, **kw)
+        mask = (np.arange(n_th * n_ph) % world == rank).reshape(n_th, n_ph)
+        contribution = grid_ref.to_modes(uprm, grid * mask[None], -2, ell_max)
+        n_new = uprm.size
+        assert n_new == window[1] - window[0]
+        total, block = sharding.padded_rows(n_new, world)
+        buf = torch.zeros((total, contribution.shape[1]), dtype=torch.complex128)
+        buf[:n_new] = torch.from_numpy(contribution)
+        rows, (r0, r1) = sharding.reduce_scatter_rows(buf, n_new)
+        np.savez(os.path.join(tmpdir, f"col{rank}.npz"), r=np.array([r0, r1]), t=uprm[r0:r1], data=rows.numpy())
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_two_rank_column_partition_equals_global(tmp_path):
+    import torch.multiprocessing as mp
+
+    from oracle import waveform_grid_ref as grid_ref
+    from oracle.containers import WM, h
+    from scri_amd import synthetic
+
+    n_times, ell_max, world = 401, 4, 2
+    port = _free_port()
+    mp.spawn(_columns_worker, args=(world, port, n_times, ell_max, str(tmp_path)), nprocs=world, join=True)
+    parts = [np.load(tmp_path / f"col{r}.npz") for r in range(world)]
+    t, data, spec = synthetic.workload("cfg3", n_times=n_times)
+    kw = dict(spec["kwargs"])
+    kw["boost_velocity"] = np.array([0.06, -0.05, 0.06])
+    nm = (ell_max + 1) ** 2 - 4
+    ref = grid_ref.transform(WM(t=t, data=data[:, :nm], ell_min=2, ell_max=ell_max, dataType=h), **kw)
+    assert parts[0]["r"][0] == 0 and parts[0]["r"][1] == parts[1]["r"][0] and parts[1]["r"][1] == ref.t.size
+    assert np.array_equal(np.concatenate([p["t"] for p in parts]), ref.t)
+    got = np.concatenate([p["data"] for p in parts])
+    assert np.abs(got - ref.data).max() < 1e-13 * max(1.0, np.abs(ref.data).max())
+
+
+def test_choose_partition():
+    from scri_amd import sharding
+
+    have = [(0, 100), (100, 200)]
+    assert sharding.choose_partition(have, [(0, 110), (90, 200)]) == "rows"
+    assert sharding.choose_partition(have, [(0, 140), (90, 200)]) == "columns"
+    assert sharding.choose_partition(have, [(0, 0), (100, 100)]) == "rows"  # nothing to produce
+    assert sharding.padded_rows(10, 4) == (12, 3)
