@@ -32,6 +32,8 @@ from .asymptotic_bondi_data import AsymptoticBondiData  # noqa: E402,F401
 from . import bms_transformations  # noqa: E402,F401
 from . import mode_calculations  # noqa: E402,F401
 from .modes_time_series import ModesTimeSeries  # noqa: E402,F401
+from . import file_io  # noqa: E402,F401
+from .file_io import create_abd_from_h5, create_abd_from_waveforms  # noqa: E402,F401
 from .bms_transformations import LorentzTransformation, BMSTransformation  # noqa: E402,F401
 
 # Same grafting the reference performs at import (scri/__init__.py:140-142)
