@@ -479,30 +479,50 @@ __global__ __launch_bounds__(64) void phi_dft_folded_kernel(const double* __rest
     }
   for (int e = lane; e < 16 * PA; e += 64) Es[e] = Os[e] = 0.0;
   const long long n_items = n_rows * mt;
+  // This lane's pieces of an item (8 rings x nk folded pairs): element e = lane + 64 i is pair kk of ring r.  Offsets and
+  // operand slots are the same for every item; the loads of the next item are issued before the products of this one.
+  constexpr int NPRE = (8 * 4 * KS + 63) / 64;
+  int ga[NPRE], gb[NPRE], so[NPRE];  // offsets (doubles) of x_k and x_{n-k} in the tile (-1: none), r << 16 | LDS slot
+#pragma unroll
+  for (int i = 0; i < NPRE; ++i) {
+    const int e = lane + 64 * i;
+    const int r = e / nk, kk = e - r * nk;
+    const int k2 = kk == 0 ? 0 : n_phi - kk;
+    ga[i] = e < 8 * nk ? 2 * (r * n_phi + kk) : -1;
+    gb[i] = (e < 8 * nk && k2 != kk) ? 2 * (r * n_phi + k2) : -1;
+    so[i] = (r << 16) | (((r & 3) + 8 * (r >> 2)) * PA + kk);
+  }
+  double2 pa[NPRE], pb[NPRE];
+#define DFT_LOAD(ITEM)                                                                                          \
+  {                                                                                                             \
+    const long long t_ = (ITEM) / mt;                                                                           \
+    const int rt_ = (int)((ITEM)-t_ * mt);                                                                      \
+    const int rings_ = n_theta - 8 * rt_ < 8 ? n_theta - 8 * rt_ : 8;                                           \
+    const double* g_ = G + t_ * ldg + 2LL * (8 * rt_) * n_phi;                                                  \
+    _Pragma("unroll") for (int i = 0; i < NPRE; ++i) {                                                          \
+      const bool in_ = (so[i] >> 16) < rings_;                                                                  \
+      pa[i] = (in_ && ga[i] >= 0) ? *reinterpret_cast<const double2*>(g_ + ga[i]) : double2{0.0, 0.0};          \
+      pb[i] = (in_ && gb[i] >= 0) ? *reinterpret_cast<const double2*>(g_ + gb[i]) : double2{0.0, 0.0};          \
+    }                                                                                                           \
+  }
+  if (blockIdx.x < n_items) DFT_LOAD((long long)blockIdx.x)
   for (long long item = blockIdx.x; item < n_items; item += gridDim.x) {
     const long long t = item / mt;
     const int rt = (int)(item - t * mt);
     const int rings = n_theta - 8 * rt < 8 ? n_theta - 8 * rt : 8;
-    const double* g = G + t * ldg + 2LL * (8 * rt) * n_phi;
     // ---- fold 8 rings into the operands (row g + 8 h (+4 for Im) holds ring g + 4 h of the tile)
-    for (int e = lane; e < 8 * nk; e += 64) {
-      const int r = e / nk, kk = e - r * nk;
-      double2 a = {0.0, 0.0}, b = {0.0, 0.0};
-      double wb = 0.0;
-      if (r < rings) {
-        const int k2 = kk == 0 ? 0 : n_phi - kk;
-        a = *reinterpret_cast<const double2*>(g + 2LL * (r * n_phi + kk));
-        if (k2 != kk) {
-          b = *reinterpret_cast<const double2*>(g + 2LL * (r * n_phi + k2));
-          wb = 1.0;
-        }
+#pragma unroll
+    for (int i = 0; i < NPRE; ++i)
+      if (ga[i] >= 0) {
+        const int slot = so[i] & 0xffff;
+        const bool in = (so[i] >> 16) < rings;
+        const double wb = (in && gb[i] >= 0) ? 1.0 : 0.0;
+        Es[slot] = pa[i].x + pb[i].x;
+        Es[slot + 4 * PA] = pa[i].y + pb[i].y;
+        Os[slot] = wb * (pa[i].x - pb[i].x);
+        Os[slot + 4 * PA] = wb * (pa[i].y - pb[i].y);
       }
-      const int row = (r & 3) + 8 * (r >> 2);
-      Es[row * PA + kk] = a.x + b.x;
-      Es[(row + 4) * PA + kk] = a.y + b.y;
-      Os[row * PA + kk] = wb * (a.x - b.x);
-      Os[(row + 4) * PA + kk] = wb * (a.y - b.y);
-    }
+    if (item + gridDim.x < n_items) DFT_LOAD(item + gridDim.x)
     // (one wave: its LDS writes are visible to its own reads in program order)
     v4d_t ac[NTC], as[NTC];
 #pragma unroll
@@ -549,6 +569,8 @@ __global__ __launch_bounds__(64) void phi_dft_folded_kernel(const double* __rest
   }
 }
 
+#undef DFT_LOAD
+
 // ---- step 2: out[t][(l, m)] = sum_j T[(l,m)][j] F[t][m][j].  Workgroup = (m, block of time steps); the quadrature
 // table of that m sits in registers as MFMA B fragments; a wave multiplies 8 time steps (16 real rows) per trip.
 template <int KQ, int NTQ>
@@ -579,18 +601,39 @@ __global__ __launch_bounds__(256) void theta_quadrature_mfma_kernel(const double
   const long long t_begin = (long long)blockIdx.y * rows_per_block;
   long long t_end = t_begin + rows_per_block;
   if (t_end > n_rows) t_end = n_rows;
+  // This lane's pieces of a trip (8 time steps of F[.][mi][0 .. jp)): element e = lane + 64 i is ring j of time step r.
+  // Their addresses relative to the trip and their operand slots do not change from trip to trip; the loads of the next
+  // trip are issued before the products of the current one.
+  constexpr int NPRE = (8 * (4 * KQ + 4) + 63) / 64;
+  int goff[NPRE], soff[NPRE];  // global offset (doubles) from the trip's first time step (-1: nothing to load), r << 16 | LDS slot
+  const long long tstride = (long long)nm * jp * 2;
+#pragma unroll
+  for (int i = 0; i < NPRE; ++i) {
+    const int e = lane + 64 * i;
+    const int r = e / jp, j = e - r * jp;
+    const bool ok = e < 8 * jp && j < n_theta && j < 4 * KQ;
+    goff[i] = ok ? 2 * j : -1;
+    soff[i] = (r << 16) | (((r & 3) + 8 * (r >> 2)) * PQ + j);
+  }
+  double2 pre[NPRE];
+  const double* Fm = F + (long long)mi * jp * 2;
+#define TQ_LOAD(T0)                                                                                                   \
+  _Pragma("unroll") for (int i = 0; i < NPRE; ++i) {                                                                  \
+    const int r = soff[i] >> 16;                                                                                      \
+    pre[i] = (goff[i] >= 0 && (T0) + r < t_end) ? *reinterpret_cast<const double2*>(Fm + ((T0) + r) * tstride + goff[i]) \
+                                                 : double2{0.0, 0.0};                                                  \
+  }
+  if (t_begin + 8 * wave < t_end) TQ_LOAD(t_begin + 8 * wave)
   for (long long t0 = t_begin + 8 * wave; t0 < t_end; t0 += 32) {
-    // ---- 8 time steps of F[.][mi][0 .. jp) into the operand: row g + 8 h (+4 for Im) holds time step t0 + g + 4 h
-    for (int e = lane; e < 8 * jp; e += 64) {
-      const int r = e / jp, j = e - r * jp;
-      double2 v = {0.0, 0.0};
-      if (t0 + r < t_end && j < n_theta) v = *reinterpret_cast<const double2*>(F + (((t0 + r) * nm + mi) * (long long)jp + j) * 2);
-      const int row = (r & 3) + 8 * (r >> 2);
-      if (j < 4 * KQ) {  // jp may exceed the operand width; those rings carry no weight
-        A[row * PQ + j] = v.x;
-        A[(row + 4) * PQ + j] = v.y;
+    // ---- operand: row g + 8 h (+4 for Im) holds time step t0 + g + 4 h
+#pragma unroll
+    for (int i = 0; i < NPRE; ++i)
+      if (goff[i] >= 0) {
+        const int slot = soff[i] & 0xffff;
+        A[slot] = pre[i].x;
+        A[slot + 4 * PQ] = pre[i].y;
       }
-    }
+    if (t0 + 32 < t_end) TQ_LOAD(t0 + 32)
     v4d_t acc[NTQ];
 #pragma unroll
     for (int n = 0; n < NTQ; ++n) acc[n] = v4d_t{0.0, 0.0, 0.0, 0.0};
@@ -652,7 +695,7 @@ hipError_t launch_analysis_large(hipStream_t stream, const double* G, long long 
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
   const int kq = (n_theta + 3) / 4;
-  const int rows_per_block = 512;
+  static const int rows_per_block = getenv("SCRI_AMD_TQ_ROWS") ? atoi(getenv("SCRI_AMD_TQ_ROWS")) : 256;
   const dim3 grid2(nm, (unsigned)((n_rows + rows_per_block - 1) / rows_per_block));
   // columns of one m: l = max(|m|, ell_min_out) .. L, at most L + 1 - ell_min_out
   const int ntq = (L + 1 - ell_min_out + 15) / 16;
@@ -675,6 +718,7 @@ hipError_t launch_analysis_large(hipStream_t stream, const double* G, long long 
   }
 #undef TQ_KQ
 #undef TQ_GO
+#undef TQ_LOAD
   return hipGetLastError();
 }
 
