@@ -150,6 +150,12 @@ typedef struct {
 } bms_shard;
 int bms_shard_plan(bms_ctx* ctx, const double* t, int64_t n_times, const bms_transformation* tr, int64_t out_i0,
                    int64_t out_i1, int64_t need_rows[2], int64_t window[2]);
+/* The valid output window [i_lo, i_hi) of a transformation (scri/waveform_grid.py:564-568; abd != 0: the
+ * AsymptoticBondiData flavour, transformations.py:391-396), from the same per-direction tables the transformations
+ * compute on the GPU: output sample r of bms_transform_modes / bms_transform_abd has input index i_lo + r, so a caller
+ * can size its (device) output buffers exactly: i_hi - i_lo rows. */
+int bms_output_window(bms_ctx* ctx, const double* t, int64_t n_times, const bms_transformation* tr, int abd,
+                      int64_t window[2]);
 /* as bms_transform_modes; t_out/data_out receive only the rank's samples, *first_index_out their first global
  * input index (output row r corresponds to input index *first_index_out + r).  shard == NULL: whole series. */
 int bms_transform_modes_shard(bms_ctx* ctx, const bms_wm_input* in, const bms_transformation* tr,

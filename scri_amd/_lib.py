@@ -79,6 +79,7 @@ SIGNATURES = {
         c_int,
         [c_vp, c_dp, c_i64, ctypes.POINTER(bms_transformation), c_i64, c_i64, ctypes.POINTER(c_i64), ctypes.POINTER(c_i64)],
     ),
+    "bms_output_window": (c_int, [c_vp, c_dp, c_i64, ctypes.POINTER(bms_transformation), c_int, ctypes.POINTER(c_i64)]),
     "bms_transform_modes_shard": (
         c_int,
         [c_vp, ctypes.POINTER(bms_wm_input), ctypes.POINTER(bms_transformation), ctypes.POINTER(bms_shard), c_dp, c_vp,

@@ -32,7 +32,7 @@ class AsymptoticBondiData:
     psi0, psi1, psi2, psi3, psi4, sigma as complex mode weights [n_times, (ell_max+1)^2]
     (l from 0; modes with l < |s| are zero), stored contiguously as `_raw_data[6, n_times, n_modes]`."""
 
-    def __init__(self, time, ell_max, multiplication_truncator=sum, frameType=None, ctx=None):
+    def __init__(self, time, ell_max, multiplication_truncator=sum, frameType=None, ctx=None, _raw=None):
         from . import Inertial
 
         self._time = np.array(time, dtype=float)
@@ -40,7 +40,13 @@ class AsymptoticBondiData:
             raise ValueError(f"Input `time` parameter must be a 1-d array of floats; it has shape {self._time.shape}")
         self._ell_max = int(ell_max)
         self._truncator = multiplication_truncator
-        self._raw_data = np.zeros((6, self._time.size, (self._ell_max + 1) ** 2), dtype=complex)
+        shape = (6, self._time.size, (self._ell_max + 1) ** 2)
+        if _raw is None:
+            self._raw_data = np.zeros(shape, dtype=complex)
+        else:  # adopt freshly computed storage instead of zero-filling and copying (hundreds of MB per transformation)
+            if _raw.shape != shape or _raw.dtype != np.complex128 or not _raw.flags.c_contiguous:
+                raise ValueError(f"storage of shape {_raw.shape} does not fit {shape}")
+            self._raw_data = _raw
         self.frameType = Inertial if frameType is None else frameType
         self.frame = np.zeros((0, 4))
         self._ctx = ctx
@@ -121,9 +127,7 @@ class AsymptoticBondiData:
         n_theta = 2 * working_ell_max + 1
         tr = engine.make_transformation(supertranslation, frame_rotation, boost_velocity, n_theta, n_theta, output_ell_max)
         u_new, raw_new = engine.transform_abd(self._time, self._raw_data, self.ell_max, tr, ctx=self._ctx)
-        abdprime = type(self)(u_new, output_ell_max, multiplication_truncator=self._truncator, frameType=self.frameType, ctx=self._ctx)
-        abdprime._raw_data[:] = raw_new
-        return abdprime
+        return type(self)(u_new, output_ell_max, multiplication_truncator=self._truncator, frameType=self.frameType, ctx=self._ctx, _raw=raw_new)
 
 
 _SPINS = (2, 1, 0, -1, -2, 2)  # psi0..psi4, sigma

@@ -610,6 +610,18 @@ void output_window(const PixelTables& T, const double* t, int64_t n, int64_t& i_
   if (i_hi < i_lo) i_hi = i_lo;
 }
 
+// the AsymptoticBondiData flavour divides: timeprime = (u - tt) / gamma (transformations.py:391-396)
+void output_window_abd(const PixelTables& T, const double* u, int64_t n, int64_t& i_lo, int64_t& i_hi) {
+  double umin = -INFINITY, umax = INFINITY;
+  for (int p = 0; p < T.n_pix; ++p) {
+    umin = std::max(umin, T.k[p] * (u[0] - T.alpha[p]));
+    umax = std::min(umax, T.k[p] * (u[n - 1] - T.alpha[p]));
+  }
+  i_lo = std::partition_point(u, u + n, [&](double ui) { return (ui - T.tt) / T.gamma < umin; }) - u;
+  i_hi = std::partition_point(u, u + n, [&](double ui) { return (ui - T.tt) / T.gamma <= umax; }) - u;
+  if (i_hi < i_lo) i_hi = i_lo;
+}
+
 // knots needed to evaluate output samples [c0, c1): [ja, jb] inclusive (before halo)
 void needed_knots(const PixelTables& T, const double* t, int64_t n, int64_t c0, int64_t c1, int64_t& ja, int64_t& jb) {
   double lo = INFINITY, hi = -INFINITY;
@@ -981,6 +993,23 @@ extern "C" int bms_shard_plan(bms_ctx* c, const double* t, int64_t n, const bms_
   const int margin = SPLINE_HALO + 2;
   need_rows[0] = std::max<int64_t>(0, ja - margin);
   need_rows[1] = std::min<int64_t>(n, jb + margin + 1);
+  return BMS_OK;
+}
+
+extern "C" int bms_output_window(bms_ctx* c, const double* t, int64_t n, const bms_transformation* tr, int abd, int64_t window[2]) {
+  if (!c) return BMS_ERR_INVALID;
+  if (!t || !tr || !window) return fail(c, BMS_ERR_INVALID, "NULL argument");
+  HIP_TRY(c, hipSetDevice(c->device));
+  int rc = validate_common(c, n, t, tr, 0, 0);
+  if (rc) return rc;
+  PixelTables T;
+  DevPixel DP;
+  const cplx cv[4] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}};
+  if ((rc = device_pixel_tables(c, tr, T, 0, 0, 0, nullptr, nullptr, cv, DP, 0))) return rc;
+  if (abd)
+    output_window_abd(T, t, n, window[0], window[1]);
+  else
+    output_window(T, t, n, window[0], window[1]);
   return BMS_OK;
 }
 
@@ -1686,14 +1715,8 @@ extern "C" int bms_transform_abd_shard(bms_ctx* c, const double* u, const void* 
   if ((rc = column_range(c, sh, n_cols, cA, cB))) return rc;
   const int n_pix = cB - cA;  // columns this call synthesises and splines
   // window: timeprime = (u - tt) / gamma  (division, unlike the WaveformModes flavour)
-  double umin = -INFINITY, umax = INFINITY;
-  for (int p = 0; p < n_cols; ++p) {
-    umin = std::max(umin, T.k[p] * (u[0] - T.alpha[p]));
-    umax = std::min(umax, T.k[p] * (u[n - 1] - T.alpha[p]));
-  }
-  int64_t i_lo = std::partition_point(u, u + n, [&](double ui) { return (ui - T.tt) / T.gamma < umin; }) - u;
-  int64_t i_hi = std::partition_point(u, u + n, [&](double ui) { return (ui - T.tt) / T.gamma <= umax; }) - u;
-  if (i_hi < i_lo) i_hi = i_lo;
+  int64_t i_lo, i_hi;
+  output_window_abd(T, u, n, i_lo, i_hi);
   // the shard's share of the window, and the rows of the global series it was given
   int64_t row0 = 0, rows_avail = n, fs_out = n;
   if (sh) {

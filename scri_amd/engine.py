@@ -200,8 +200,18 @@ def transform_modes(
         ctypes.byref(first),
     )
     ctx.check(rc, "bms_transform_modes")
-    res = (t_out[: n_new.value].copy(), out[: n_new.value].copy())
+    res = (t_out[: n_new.value], out[: n_new.value])  # leading rows: contiguous views, no trimming copy
     return res + (first.value,) if shard is not None else res
+
+
+def output_window(t, transformation, abd=False, ctx=None):
+    """bms_output_window -> (i_lo, i_hi): output sample r of the transformation has input index i_lo + r."""
+    ctx = _ctx(ctx)
+    t = np.ascontiguousarray(t, dtype=float)
+    win = (c_i64 * 2)()
+    rc = _lib.load().bms_output_window(ctx.handle, dptr(t), t.shape[0], ctypes.byref(transformation), int(bool(abd)), win)
+    ctx.check(rc, "bms_output_window")
+    return int(win[0]), int(win[1])
 
 
 def shard_plan(t, transformation, out_i0, out_i1, ctx=None):
@@ -249,13 +259,23 @@ def transform_abd(u, raw, ell_max, transformation, ctx=None, shard=None, device=
     raw = _lib.as_c16(raw)
     if raw.shape != (6, n_rows, (ell_max + 1) ** 2):
         raise ValueError(f"raw shape {raw.shape} inconsistent")
+    if shard is None:
+        # size the result exactly (the window is known before the data move): no trimming copy of hundreds of MB afterwards
+        i_lo, i_hi = output_window(u, transformation, abd=True, ctx=ctx)
+        sh = bms_shard(0, n, i_lo, i_hi)
+        shp = ctypes.byref(sh)
+        fs_out = i_hi - i_lo
+        u_out = np.empty(max(fs_out, 1), dtype=float)
     out = np.empty((6, max(fs_out, 1), n_out), dtype=np.complex128)
     rc = _lib.load().bms_transform_abd_shard(
         ctx.handle, dptr(u), vptr(raw), BMS_HOST, n, int(ell_max), ctypes.byref(transformation), shp, dptr(u_out), vptr(out),
         ctypes.byref(n_new), ctypes.byref(first),
     )
     ctx.check(rc, "bms_transform_abd")
-    res = (u_out[: n_new.value].copy(), out[:, : n_new.value].copy())
+    if n_new.value == out.shape[1]:
+        res = (u_out, out)
+    else:
+        res = (u_out[: n_new.value].copy(), out[:, : n_new.value].copy())
     return res + (first.value,) if shard is not None else res
 
 

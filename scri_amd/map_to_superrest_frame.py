@@ -79,11 +79,26 @@ def _interpolate_each_pixel(t, series_grid, times_grid, ctx=None):
     return np.real(np.diagonal(vals)).reshape(nt, nphi)
 
 
+SPLINE_REACH = 64  # knots: a cubic spline forgets its far data like 0.268^n (3e-37 at 64), far below one rounding
+
+
+def _rows_near(t, times, reach=SPLINE_REACH):
+    """Row range of `t` that determines, to rounding, a cubic spline through it at the requested `times`.  The reference
+    fits every pixel's spline through the whole series to evaluate it at one time near u = 0
+    (map_to_superrest_frame.py:176-181); the knots further than `reach` from the evaluation points contribute < 1e-36."""
+    times = np.asarray(times, dtype=float)
+    lo = int(np.searchsorted(t, times.min(), side="right")) - 1 - reach
+    hi = int(np.searchsorted(t, times.max(), side="left")) + 1 + reach
+    return max(lo, 0), min(hi, len(t))
+
+
 def compute_Moreschi_supermomentum(PsiM, alpha, ell_max, ctx=None):
     """Moreschi supermomentum in the frame supertranslated by alpha (a real grid function): Eq. (9) of
     doi:10.1063/1.532646 (map_to_superrest_frame.py:155-197)."""
     data = np.asarray(PsiM.ndarray if hasattr(PsiM, "ndarray") else PsiM)
     t = PsiM.t
+    lo, hi = _rows_near(t, alpha)
+    data, t = data[lo:hi], t[lo:hi]
     M_Grid, K_Grid = compute_bondi_rest_mass_and_conformal_factor(data, ell_max, ctx)
     PsiM_Grid = _to_grid(data, ell_max, ctx).real
     PsiM_at_alpha = _interpolate_each_pixel(t, PsiM_Grid, alpha, ctx)
@@ -110,8 +125,9 @@ def supertranslation_to_map_to_superrest_frame(abd, target_PsiM=None, N_itr_max=
     PsiM = abd.supermomentum("Moreschi")
 
     def target_at(times_grid):
-        tg = _to_grid(np.asarray(target_PsiM.data), target_PsiM.ell_max, ctx).real
-        return _interpolate_each_pixel(target_PsiM.t, tg, times_grid, ctx)
+        lo, hi = _rows_near(target_PsiM.t, times_grid)
+        tg = _to_grid(np.asarray(target_PsiM.data)[lo:hi], target_PsiM.ell_max, ctx).real
+        return _interpolate_each_pixel(target_PsiM.t[lo:hi], tg, times_grid, ctx)
 
     itr, rel_err, rel_errs = 0, np.inf, [np.inf]
     PsiM_interp = M_Grid = K_Grid = None

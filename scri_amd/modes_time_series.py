@@ -7,12 +7,21 @@ bms_spline_derivative, grid_multiply -> bms_grid_multiply.  The mode-space opera
 or permutation maps on the mode axis, applied here with numpy.
 """
 import copy
+import functools
 import math
 
 import numpy as np
 
 from . import engine
 from .mode_algebra import LM_index, LM_range, LM_total_size
+
+
+@functools.lru_cache(maxsize=64)
+def _bar_tables(ell_min, ell_max, s):
+    """(source index, sign) of every mode of the conjugate function: bar(a)_{l,m} = (-1)^(s+m) conj(a_{l,-m})"""
+    perm = np.array([LM_index(ell, -m, ell_min) for ell in range(ell_min, ell_max + 1) for m in range(-ell, ell + 1)], dtype=np.intp)
+    sign = np.array([(-1.0) ** (s + m) for ell in range(ell_min, ell_max + 1) for m in range(-ell, ell + 1)])
+    return perm, sign
 
 
 class ModesTimeSeries(np.ndarray):
@@ -188,11 +197,10 @@ class ModesTimeSeries(np.ndarray):
     def bar(self):
         """Modes of the complex-conjugate function: (-1)^(s+m) conj(a_{l,-m}), spin -s"""
         s = self.spin_weight
-        d = self.ndarray
-        res = np.empty_like(d)
-        for ell in range(self.ell_min, self.ell_max + 1):
-            for m in range(-ell, ell + 1):
-                res[..., LM_index(ell, m, self.ell_min)] = (-1.0) ** (s + m) * np.conj(d[..., LM_index(ell, -m, self.ell_min)])
+        perm, sign = _bar_tables(self.ell_min, self.ell_max, s)
+        res = np.take(self.ndarray, perm, axis=-1)
+        np.conjugate(res, out=res)
+        res *= sign
         return self._like(res, spin_weight=-s)
 
     @property

@@ -151,3 +151,32 @@ def test_strided_rows_and_interpolate(ctx):
     x = np.linspace(0, 1, 50)
     xn = np.array([0.0, 0.013, 0.5, 0.99, 1.0])
     assert np.abs(engine.cubic_spline(x, big, xn, ctx=ctx) - CubicSpline(x, big)(xn)).max() < 1e-12
+
+
+def test_output_window_matches_the_transforms(ctx):
+    """bms_output_window announces exactly the rows the transformations produce (both flavours), so buffers can be sized
+    before the data move."""
+    from scri_amd import engine
+
+    rng = np.random.default_rng(8)
+    for trial in range(6):
+        n, ell_max = int(rng.integers(50, 400)), 3
+        t = np.cumsum(rng.uniform(0.05, 0.2, size=n)) - 10.0
+        st = (rng.normal(size=9) + 1j * rng.normal(size=9)) * 0.3
+        st[0] = st[0].real
+        st[2], st[6] = st[2].real, st[6].real
+        st[1], st[3] = np.conj(st[3]) * -1, st[3]
+        st[4], st[8] = np.conj(st[8]), st[8]
+        st[5], st[7] = -np.conj(st[7]), st[7]
+        v = rng.normal(size=3) * (0.0 if trial == 0 else 0.05)
+        n_theta = 2 * (ell_max + 2) + 1
+        tr = engine.make_transformation(st, [1, 0, 0, 0], v, n_theta, n_theta, ell_max)
+        data = rng.normal(size=(n, (ell_max + 1) ** 2 - 4)) + 0j
+        t_new, d_new = engine.transform_modes(t, data, 2, ell_max, -2, -1, engine.BMS_TERM_H, tr, ctx=ctx)
+        lo, hi = engine.output_window(t, tr, ctx=ctx)
+        assert hi - lo == t_new.size
+        raw = rng.normal(size=(6, n, (ell_max + 1) ** 2)) + 0j
+        tr2 = engine.make_transformation(st, [1, 0, 0, 0], v, 2 * (2 * ell_max + 1) + 1, 2 * (2 * ell_max + 1) + 1, ell_max)
+        u_new, r_new = engine.transform_abd(t, raw, ell_max, tr2, ctx=ctx)
+        lo, hi = engine.output_window(t, tr2, abd=True, ctx=ctx)
+        assert hi - lo == u_new.size and r_new.shape[1] == u_new.size and r_new.flags.c_contiguous
