@@ -298,7 +298,12 @@ hipError_t launch_zgemm3m(hipStream_t stream, const double* A, long long lda, co
   if (M <= 0 || N <= 0) return hipSuccess;
   const int nbm = (int)((M + Z_BM - 1) / Z_BM);
   const int nbn = (N + Z_BN - 1) / Z_BN;
-  static const int st_rows_log2 = getenv("SCRI_AMD_ZGEMM_ST_ROWS_LOG2") ? atoi(getenv("SCRI_AMD_ZGEMM_ST_ROWS_LOG2")) : 5;
+  // Super-tile of 64 workgroup tiles per XCD turn: 64 row tiles x 1 column tile for tall launches (every workgroup of the
+  // XCD shares one 64-column slice of B, which then lives in L2/L1 while A streams: 4.07 against 4.18 ms at cfg3, 1563 row
+  // tiles), 32 x 2 otherwise (cfg5's chunks are ~130 row tiles: 64-row super-tiles would leave every third one nearly
+  // empty; 94.6 against 96.6 ms).  SCRI_AMD_ZGEMM_ST_ROWS_LOG2 overrides.
+  static const int st_env = getenv("SCRI_AMD_ZGEMM_ST_ROWS_LOG2") ? atoi(getenv("SCRI_AMD_ZGEMM_ST_ROWS_LOG2")) : -1;
+  const int st_rows_log2 = (st_env >= 0 && st_env <= 6) ? st_env : (nbm >= 512 ? 6 : 5);
   const int sr = 1 << st_rows_log2, sc = 64 >> st_rows_log2;
   const long long n_super = (long long)((nbm + sr - 1) / sr) * ((nbn + sc - 1) / sc);
   const long long grid = ((n_super + 7) / 8) * 8 * 64;
