@@ -374,7 +374,8 @@ def main():
                 "unit": "TFLOP/s",
                 "frac": (achieved / FP64_MATRIX_PEAK_TFLOPS) if achieved else None,
                 "traffic": pmc_traffic(args.workload, world, per_gpu),
-                "traffic_unit": "bytes of HBM per launch (profiles/r01_h_pmc_cfg3.json)",
+                "traffic_unit": "bytes per launch from the PMC passes, 2 x FETCH_SIZE + WRITE_SIZE (profiles/r01_h_pmc_cfg3.json); the reads are "
+                "L2 misses, Infinity-Cache hits included: the A operand passes each of the 21 column panels (DESIGN.md section 4)",
                 "flops_per_launch": flops_per_launch,
                 "ms_per_launch": g_ms / max(g_calls, 1),
                 # what the MFMA pipe actually executes: 3 real products per complex one (not 4), and, when the fused analysis
