@@ -800,6 +800,23 @@ static int upload_times(bms_ctx* c, const double* t, int64_t n, int64_t lo, int6
   return BMS_OK;
 }
 
+// the same for the B-spline form of the spline (kernels_bspline.hip)
+static int upload_times_bspline(bms_ctx* c, const double* t, int64_t n, int64_t lo, int64_t hi, int64_t j0, int64_t j1, double** d_x,
+                                BsplineTable** d_tab, BsplineForward** d_fwd) {
+  void* vp;
+  int rc = upload(c, "times", t + lo, 8 * (size_t)(hi - lo), &vp);
+  if (rc) return rc;
+  *d_x = (double*)vp - lo;
+  BsplineTable* tab;
+  BsplineForward* fwd;
+  if ((rc = dev_buf_t(c, "bspline_table", (size_t)(hi - lo), &tab))) return rc;
+  if ((rc = dev_buf_t(c, "bspline_forward", (size_t)(hi - lo), &fwd))) return rc;
+  *d_tab = tab - lo;
+  *d_fwd = fwd - lo;
+  TIMED(c, BMS_TAG_SETUP, launch_bspline_table(c->stream, *d_x, n, *d_tab, *d_fwd, lo, std::max(j0, lo), std::min(j1, hi)));
+  return BMS_OK;
+}
+
 static int stage_in(bms_ctx* c, const char* name, const void* src, int mem, size_t bytes, const double** dev) {
   if (mem == BMS_DEVICE) {
     *dev = (const double*)src;
@@ -1105,8 +1122,19 @@ extern "C" int bms_transform_modes_shard(bms_ctx* c, const bms_wm_input* in, con
   if (n_new == 0) return BMS_OK;
   double *d_rot = DP.rotors, *d_off = DP.col_off + 2 * cA, *d_scale = DP.col_scale + 2 * cA, *d_skewa = DP.skew_a + cA, *d_skewb = DP.skew_b + cA;
   double *d_alpha = DP.alpha + cA, *d_xa = DP.xa + 2 * cA, *d_xb = DP.xb + 2 * cA, *d_x;
-  SplineTable* d_tab;
-  if ((rc = upload_times(c, in->t, n, t_lo, t_hi, row0, row0 + rows_avail, &d_x, &d_tab))) return rc;
+  // Without psi mixing the map modes -> grid values is linear along the columns with time-independent coefficients, so
+  // the spline's forward elimination is done on the modes (B-spline form, kernels_bspline.hip) and the grid is passed over
+  // once, by the back substitution + evaluation.
+  const bool bsg = n >= 8 && !getenv("SCRI_AMD_NO_BSPLINE");  // B-spline form at all (else: the slope form, kernels_spline.hip)
+  const bool bs = bsg && !psi;                                 // ... with the elimination commuted onto the modes
+  SplineTable* d_tab = nullptr;
+  BsplineTable* d_bstab = nullptr;
+  BsplineForward* d_bsfwd = nullptr;
+  if (bsg)
+    rc = upload_times_bspline(c, in->t, n, t_lo, t_hi, row0, row0 + rows_avail, &d_x, &d_bstab, &d_bsfwd);
+  else
+    rc = upload_times(c, in->t, n, t_lo, t_hi, row0, row0 + rows_avail, &d_x, &d_tab);
+  if (rc) return rc;
   trace.mark("window (host) + time upload + spline factors");
 
   const long long P2 = 2LL * n_pix;
@@ -1142,6 +1170,10 @@ extern "C" int bms_transform_modes_shard(bms_ctx* c, const bms_wm_input* in, con
     HIP_TRY(c, hipMemsetAsync(f.d_B, 0, sizeof(double) * rows * ldb, S));
     TIMED(c, BMS_TAG_SETUP, launch_swsh_matrix_complex(S, d_rot, n_cols, f.spin, f.ell_min, f.ell_max, f.d_B, ldb));
   }
+  const int n_modes_in = F[0].K / 2;
+  if (bs)  // row n_modes of B multiplies the eliminated constant series: it carries the per-column offset
+    TIMED(c, BMS_TAG_SETUP, launch_negated_row(S, DP.col_off, F[0].d_B + (size_t)n_modes_in * ldb, 2 * n_cols));
+  const long long ld_af = 2LL * (n_modes_in + 1);
   trace.mark("uploads + synthesis matrices");
   AnalysisPlan ana;
   if ((rc = build_analysis(c, "wm", T.n_theta, T.n_phi, s, ell_min_out, tr->ell_max_out, ana))) return rc;
@@ -1184,10 +1216,20 @@ extern "C" int bms_transform_modes_shard(bms_ctx* c, const bms_wm_input* in, con
                   "shard holds rows [%lld, %lld) but outputs [%lld, %lld) need rows [%lld, %lld): halo too small "
                   "(use bms_shard_plan)",
                   (long long)row0, (long long)(row0 + rows_avail), (long long)c0, (long long)c1, (long long)g0, (long long)g1);
-    double *d_Y, *d_R, *d_G, *d_Yaux = nullptr;
+    double *d_Y, *d_R = nullptr, *d_G, *d_Yaux = nullptr;
     if ((rc = dev_buf_t(c, "Y", (size_t)rows_in * ldg, &d_Y))) return rc;
-    if ((rc = dev_buf_t(c, "R", (size_t)rows_in * ldg, &d_R))) return rc;
+    if (!bs)
+      if ((rc = dev_buf_t(c, "R", (size_t)rows_in * ldg, &d_R))) return rc;  // eliminated rows (either form)
     if ((rc = dev_buf_t(c, "G", (size_t)rows_out * P2, &d_G))) return rc;
+    if (bs) {
+      double* d_Af;
+      if ((rc = dev_buf_t(c, "Afwd", (size_t)rows_in * ld_af, &d_Af))) return rc;
+      TIMED(c, BMS_TAG_SPLINE_FORWARD, launch_bspline_forward_modes(S, F[0].d_data + (g0 - row0) * F[0].ld * 2, F[0].ld * 2, n_modes_in, d_Af, ld_af, g0,
+                                                                    rows_in, n, d_bsfwd, SPLINE_TILE, SPLINE_HALO, 1));
+      TIMED(c, BMS_TAG_GEMM_SYNTHESIS, launch_zgemm3m(S, d_Af, ld_af, F[0].d_B + 2 * cA, ldb, d_Y, ldg, rows_in, n_pix, n_modes_in + 1, nullptr, d_scale));
+      TIMED(c, BMS_TAG_SPLINE_BACKWARD, launch_bspline_backward_eval(S, d_Y, ldg, n_pix, g0, rows_in, n, d_x, d_bstab, SPLINE_TILE, SPLINE_HALO, d_x, d_skewa,
+                                                                     d_skewb, T.tt, c0, c1, d_G, P2));
+    } else {
     if (psi)
       if ((rc = dev_buf_t(c, "Yaux", (size_t)rows_in * ldg, &d_Yaux))) return rc;
     // synthesis (+ fused affine map when there is no psi mixing)
@@ -1204,9 +1246,16 @@ extern "C" int bms_transform_modes_shard(bms_ctx* c, const bms_wm_input* in, con
       TIMED(c, BMS_TAG_POINTWISE, launch_affine_cols(S, d_Y, ldg, (int)P2, rows_in, d_off, d_scale));
     }
     // spline along time on the shared knots, evaluated on the distorted slices
+    if (bsg) {  // mixing is time dependent: eliminate on the grid, then the coefficient-only back substitution
+      TIMED(c, BMS_TAG_SPLINE_FORWARD, launch_bspline_forward_modes(S, d_Y, ldg, n_pix, d_R, ldg, g0, rows_in, n, d_bsfwd, SPLINE_TILE, SPLINE_HALO, 0));
+      TIMED(c, BMS_TAG_SPLINE_BACKWARD, launch_bspline_backward_eval(S, d_R, ldg, n_pix, g0, rows_in, n, d_x, d_bstab, SPLINE_TILE, SPLINE_HALO, d_x, d_skewa,
+                                                                     d_skewb, T.tt, c0, c1, d_G, P2));
+    } else {
     TIMED(c, BMS_TAG_SPLINE_FORWARD, launch_spline_forward(S, d_Y, d_R, ldg, n_pix, g0, rows_in, n, d_x, d_tab, SPLINE_TILE, SPLINE_HALO));
     TIMED(c, BMS_TAG_SPLINE_BACKWARD, launch_spline_backward_eval(S, d_Y, d_R, ldg, n_pix, g0, rows_in, n, d_x, d_tab, SPLINE_TILE, SPLINE_HALO,
                                            d_x, d_skewa, d_skewb, T.tt, c0, c1, d_G, P2));
+    }
+    }
     // analysis
     if (col_split) {
       TIMED(c, BMS_TAG_GEMM_ANALYSIS, launch_zgemm3m(S, d_G, P2, d_At + (size_t)cA * ld_at, ld_at, d_out + (c0 - i_lo) * n_out * 2, 2LL * n_out,
@@ -1735,8 +1784,17 @@ extern "C" int bms_transform_abd_shard(bms_ctx* c, const double* u, const void* 
   double *d_rot = DP.rotors, *d_skewa = DP.skew_a + cA, *d_skewb = DP.skew_b + cA, *d_alpha = DP.alpha + cA, *d_ethk = DP.ethk + 2 * cA,
          *d_etha = DP.etha + 2 * cA, *d_ethetha = DP.ethetha + 2 * cA, *d_ik = DP.ik + cA, *d_ik3 = DP.ik3 + cA;
   double* d_x;
-  SplineTable* d_tab;
-  if ((rc = upload_times(c, u, n, t_lo, t_hi, row0, row0 + rows_avail, &d_x, &d_tab))) return rc;
+  // the Horner mixing has time-dependent coefficients, so the elimination stays on the grid; the B-spline form still saves
+  // the back substitution its second input stream (kernels_bspline.hip)
+  const bool bsg = n >= 8 && !getenv("SCRI_AMD_NO_BSPLINE");
+  SplineTable* d_tab = nullptr;
+  BsplineTable* d_bstab = nullptr;
+  BsplineForward* d_bsfwd = nullptr;
+  if (bsg)
+    rc = upload_times_bspline(c, u, n, t_lo, t_hi, row0, row0 + rows_avail, &d_x, &d_bstab, &d_bsfwd);
+  else
+    rc = upload_times(c, u, n, t_lo, t_hi, row0, row0 + rows_avail, &d_x, &d_tab);
+  if (rc) return rc;
 
   const long long P2 = 2LL * n_pix, ldg = round_up(P2, 16), ldb = round_up(2LL * n_cols, 128);
   const int K = 2 * nm;
@@ -1808,11 +1866,18 @@ extern "C" int bms_transform_abd_shard(bms_ctx* c, const double* u, const void* 
     for (int f = 0; f < 6; ++f) {
       double* Rf = d_R + (size_t)f * rows_in * ldg;
       double* Gf = d_G + (size_t)f * rows_out * P2;
-      TIMED(c, BMS_TAG_SPLINE_FORWARD,
-            launch_spline_forward(S, grids.y[f], Rf, ldg, n_pix, g0, rows_in, n, d_x, d_tab, SPLINE_TILE, SPLINE_HALO));
-      TIMED(c, BMS_TAG_SPLINE_BACKWARD,
-            launch_spline_backward_eval(S, grids.y[f], Rf, ldg, n_pix, g0, rows_in, n, d_x, d_tab, SPLINE_TILE, SPLINE_HALO,
-                                        d_x, d_skewa, d_skewb, T.tt, c0, c1_, Gf, P2));
+      if (bsg) {
+        TIMED(c, BMS_TAG_SPLINE_FORWARD,
+              launch_bspline_forward_modes(S, grids.y[f], ldg, n_pix, Rf, ldg, g0, rows_in, n, d_bsfwd, SPLINE_TILE, SPLINE_HALO, 0));
+        TIMED(c, BMS_TAG_SPLINE_BACKWARD, launch_bspline_backward_eval(S, Rf, ldg, n_pix, g0, rows_in, n, d_x, d_bstab, SPLINE_TILE, SPLINE_HALO,
+                                                                       d_x, d_skewa, d_skewb, T.tt, c0, c1_, Gf, P2));
+      } else {
+        TIMED(c, BMS_TAG_SPLINE_FORWARD,
+              launch_spline_forward(S, grids.y[f], Rf, ldg, n_pix, g0, rows_in, n, d_x, d_tab, SPLINE_TILE, SPLINE_HALO));
+        TIMED(c, BMS_TAG_SPLINE_BACKWARD,
+              launch_spline_backward_eval(S, grids.y[f], Rf, ldg, n_pix, g0, rows_in, n, d_x, d_tab, SPLINE_TILE, SPLINE_HALO,
+                                          d_x, d_skewa, d_skewb, T.tt, c0, c1_, Gf, P2));
+      }
       double* out_f = d_out + ((size_t)f * fs_out + (c0 - i_lo)) * n_out * 2;
       if (col_split) {
         TIMED(c, BMS_TAG_GEMM_ANALYSIS, launch_zgemm3m(S, Gf, P2, d_At[spins[f] + 2] + (size_t)cA * ld_at, ld_at, out_f, 2LL * n_out, rows_out, n_out, n_pix,

@@ -101,6 +101,33 @@ hipError_t launch_spline_backward_eval(hipStream_t stream, const double* Y, cons
                                        const double* skew_a, const double* skew_b, double tt, long long i_lo,
                                        long long i_hi, double* out, long long ldo);
 
+// ---- the same spline in B-spline form (kernels_bspline.hip): coefficients c with s(u) = sum_k c_k B_k(u) on the
+// not-a-knot knot vector.  Forward elimination of the collocation system commutes with the synthesis contraction, so it
+// runs on the MODES and the grid pass is the back substitution + evaluation alone.
+struct BsplineTable {  // per knot j: what the back substitution + evaluation reads (20 words, staged through LDS)
+  double m[16];        // m[4 d + q]: coefficient of t^d of B_{f_j + q} on [x_j, x_{j+1}], t = u - x_j, f_j = clamp(j-1, 0, n-4)
+  double G, D;         // c_j = c'_j - G c_{j+1} - D c_{j+2}
+  double x;            // x_j
+  double pad;
+};
+struct BsplineForward {  // per knot j: c'_j = P y_j - A c'_{j-1} - E c'_{j-2}
+  double P, A, E, pad;
+};
+hipError_t launch_bspline_table(hipStream_t stream, const double* x, long long n, BsplineTable* table, BsplineForward* fwd,
+                                long long j_lo /* first knot the arrays are backed for */, long long j0, long long j1);
+// Aout[r][0 .. n_modes] = forward-eliminated [A | 1] over rows r = knots g0 .. g0 + n_rows (complex; with_ones: the extra
+// last column is the eliminated constant series, which carries the per-column offset through the contraction)
+hipError_t launch_bspline_forward_modes(hipStream_t stream, const double* A, long long lda, int n_modes, double* Aout,
+                                        long long ldo, long long g0, long long n_rows, long long n_knots,
+                                        const BsplineForward* table, int tile, int halo, int with_ones);
+// B[row][0 .. 2 n_cols) = -off[0 .. 2 n_cols): the synthesis-matrix row that multiplies the constant column
+hipError_t launch_negated_row(hipStream_t stream, const double* off, double* row, int n);
+// back substitution + evaluation (arguments as launch_spline_backward_eval, C = eliminated grid coefficients)
+hipError_t launch_bspline_backward_eval(hipStream_t stream, const double* C, long long ld, int n_cols, long long g0,
+                                        long long n_rows, long long n_knots, const double* x, const BsplineTable* table,
+                                        int tile, int halo, const double* base, const double* skew_a, const double* skew_b,
+                                        double tt, long long i_lo, long long i_hi, double* out, long long ldo);
+
 // ---- time-series calculus and grid products (kernels_series.hip; scri/modes_time_series.py:72-202)
 // spline slopes s_j at all knots from the forward-pass result R (S != R)
 hipError_t launch_spline_slopes(hipStream_t stream, const double* R, double* S, long long ld, int n_cols, long long n,

@@ -1,0 +1,448 @@
+// The per-pixel not-a-knot cubic spline of kernels_spline.hip in B-spline form (same interpolant:
+// scipy InterpolatedUnivariateSpline at scri/waveform_grid.py:574-588 is this very representation, FITPACK's).
+//
+// Why a second form.  In the slope form an evaluation needs the samples y AND the slopes s, so the grid is written once
+// (synthesis), read and written by the forward elimination, and read twice more (y and the eliminated right-hand sides) by
+// the back substitution: 5 passes over 2 GB at cfg3.  In B-spline form s(u) = sum_k c_k B_k(u) the evaluation needs the
+// coefficients only, and the forward elimination of the collocation system N c = y is a linear map along TIME with
+// coefficients shared by all columns, while the synthesis (modes -> grid, per-column offset and scale) is linear along
+// the COLUMN axis -- the two commute:
+//     F[ (A.B - off) scale ] = ( F[A].B - F[1] off ) scale .
+// So the elimination runs on the 285 mode columns instead of the 1297 grid columns, the constant series F[1] rides along
+// as one more column of A (multiplying a row -off of B: K goes from 285 to 286, inside the same 8-wide k-chunk), the
+// unchanged GEMM writes eliminated coefficients c' directly, and the only pass over the grid is the back substitution +
+// evaluation below: 1 read + 1 write.
+//
+// Not-a-knot = cubic spline space on the knots x_0, x_2, x_3, ..., x_{n-3}, x_{n-1} (x_1 and x_{n-2} are no knots), clamped:
+//     tau_0..3 = x_0,  tau_{k+2} = x_k (k = 2..n-3),  tau_n..n+3 = x_{n-1};   B_k supported on [tau_k, tau_{k+4}].
+// On the data interval [x_j, x_{j+1}] the four B-splines B_{f_j} .. B_{f_j+3}, f_j = clamp(j - 1, 0, n - 4), are non-zero.
+// Collocation rows (site x_i): tridiagonal (c_{i-1}, c_i, c_{i+1}) for 2 <= i <= n-3, four entries c_0..c_3 at i = 1 and
+// c_{n-4}..c_{n-1} at i = n-2, c_0 = y_0, c_{n-1} = y_{n-1}.  The matrix is totally positive: elimination without pivoting
+// is stable, and the factors decay like 0.268^n on average for any mesh (same tiling + halo as the slope form).
+#include <cstdlib>
+#include "wigner.h"
+#include "kernels.h"
+
+namespace bms {
+
+// ------------------------------------------------------------------------------------------------ table
+// Power-basis coefficients (in t = u - x_j) of the four B-splines that live on data interval j: Cox-de Boor recursion
+// carried out on polynomials.  P[4 d + q] = coefficient of t^d of B_{f_j + q}.
+__device__ __forceinline__ void bspline_local(const double* __restrict__ x, long long n, long long j, double P[16]) {
+  long long f = j - 1;
+  if (f < 0) f = 0;
+  if (f > n - 4) f = n - 4;
+  const long long mu = f + 3;  // knot span [tau_mu, tau_mu+1) containing the interval
+  const double xj = x[j];
+  auto tau = [&](long long k) { return k <= 3 ? x[0] : (k >= n ? x[n - 1] : x[k - 2]); };
+  double prev[4][4], cur[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int d = 0; d < 4; ++d) prev[i][d] = 0.0;
+  prev[0][0] = 1.0;
+#pragma unroll
+  for (int d = 1; d <= 3; ++d) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) cur[i][g] = 0.0;
+#pragma unroll
+    for (int i = 0; i <= d; ++i) {
+      const long long k = mu - d + i;
+      if (i >= 1) {  // (u - tau_k) / (tau_{k+d} - tau_k) * B_{k, d-1}
+        const double tk = tau(k);
+        const double inv = 1.0 / (tau(k + d) - tk);
+        const double c0 = (xj - tk) * inv;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) cur[i][g] += c0 * prev[i - 1][g];
+#pragma unroll
+        for (int g = 1; g < 4; ++g) cur[i][g] += inv * prev[i - 1][g - 1];
+      }
+      if (i <= d - 1) {  // (tau_{k+d+1} - u) / (tau_{k+d+1} - tau_{k+1}) * B_{k+1, d-1}
+        const double tk = tau(k + d + 1);
+        const double inv = 1.0 / (tk - tau(k + 1));
+        const double c0 = (tk - xj) * inv;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) cur[i][g] += c0 * prev[i][g];
+#pragma unroll
+        for (int g = 1; g < 4; ++g) cur[i][g] -= inv * prev[i][g - 1];
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) prev[i][g] = cur[i][g];
+  }
+#pragma unroll
+  for (int d = 0; d < 4; ++d)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) P[4 * d + q] = prev[q][d];
+}
+
+constexpr int BS_TABLE_WARMUP = 40;  // 0.268^40 ~ 1e-23
+
+// Pass 1, one thread per knot: the interval's power-basis table (its first row = the collocation row of site x_j).
+__global__ __launch_bounds__(128) void bspline_basis_kernel(const double* __restrict__ x, long long n, BsplineTable* __restrict__ table,
+                                                            long long j0, long long j1) {
+  const long long j = j0 + (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= j1) return;
+  BsplineTable e;
+  if (j <= n - 2) {
+    bspline_local(x, n, j, e.m);
+  } else {
+#pragma unroll
+    for (int q = 0; q < 16; ++q) e.m[q] = 0.0;
+  }
+  e.G = 0.0, e.D = 0.0, e.x = x[j], e.pad = 0.0;
+  table[j] = e;
+}
+
+// Pass 2: elimination factors of row j from the recursion run over rows [j - 40, j] (exactly from row 0 near the start, and
+// never below `j_lo`, the first row pass 1 produced): the pivot recursion forgets its start geometrically.
+__global__ __launch_bounds__(128) void bspline_factors_kernel(long long n, BsplineTable* __restrict__ table,
+                                                              BsplineForward* __restrict__ fwd, long long j_lo, long long j0,
+                                                              long long j1) {
+  const long long j = j0 + (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= j1) return;
+  long long js = j - BS_TABLE_WARMUP;
+  if (js < j_lo) js = j_lo;
+  if (js <= 2) js = 0;
+  double g1 = 0.25, g2 = 0.25, d1 = 0.0;  // G_{i-1}, G_{i-2}, D_1
+  double p_ = 1.0, a_ = 0.0, e_ = 0.0, g_ = 0.0, dd_ = 0.0;
+  for (long long i = js; i <= j; ++i) {
+    const double v0 = table[i].m[0], v1 = table[i].m[1], v2 = table[i].m[2], v3 = table[i].m[3];  // B_{f_i + q}(x_i)
+    e_ = 0.0, dd_ = 0.0;
+    if (i == 0 || i == n - 1) {
+      p_ = 1.0, a_ = 0.0, g_ = 0.0;
+    } else if (i == 1) {  // a c_0 + b c_1 + c c_2 + d c_3 = y_1
+      const double ib = 1.0 / v1;
+      p_ = ib, a_ = v0 * ib, g_ = v2 * ib, dd_ = v3 * ib;
+      d1 = dd_;
+    } else if (i == n - 2) {  // e c_{n-4} + l c_{n-3} + d c_{n-2} + u c_{n-1} = y_{n-2}
+      const double lp = v1 - v0 * g2;
+      const double m = 1.0 / (v2 - lp * g1);
+      p_ = m, a_ = lp * m, e_ = v0 * m, g_ = v3 * m;
+    } else {  // l c_{i-1} + d c_i + u c_{i+1} = y_i   (B_{i+2} vanishes at its first knot x_i)
+      const double m = 1.0 / (v1 - v0 * g1);
+      p_ = m, a_ = v0 * m, g_ = (i == 2 ? v2 - v0 * d1 : v2) * m;
+    }
+    g2 = g1;
+    g1 = g_;
+  }
+  table[j].G = g_;
+  table[j].D = dd_;
+  fwd[j] = BsplineForward{p_, a_, e_, 0.0};
+}
+
+// entries [j0, j1); x and the tables are indexed by global knot number and backed from knot j_lo on
+hipError_t launch_bspline_table(hipStream_t stream, const double* x, long long n, BsplineTable* table, BsplineForward* fwd,
+                                long long j_lo, long long j0, long long j1) {
+  if (n < 8 || j0 < 0 || j1 > n || j_lo > j0) return hipErrorInvalidValue;
+  if (j1 <= j0) return hipSuccess;
+  // pass 1 covers the warm-up rows too; it reads x[j - 2 .. j + 3] (clipped at the true ends)
+  long long b0 = j0 - BS_TABLE_WARMUP;
+  const long long floor = j_lo == 0 ? 0 : j_lo + 2;
+  if (b0 < floor) b0 = floor;
+  if (b0 > j0) b0 = j0;
+  hipLaunchKernelGGL(bspline_basis_kernel, dim3((unsigned)((j1 - b0 + 127) / 128)), dim3(128), 0, stream, x, n, table, b0, j1);
+  hipLaunchKernelGGL(bspline_factors_kernel, dim3((unsigned)((j1 - j0 + 127) / 128)), dim3(128), 0, stream, n, table, fwd, b0, j0, j1);
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------ forward, on the modes
+// Thread (column p, tile): c'_j = P_j y_j - A_j c'_{j-1} - E_j c'_{j-2} for knots of the tile, started `halo` knots
+// earlier.  With `with_ones`, column n_modes of the output is the eliminated constant series 1.  (The same kernel
+// eliminates grid columns where the synthesis is followed by a time-dependent mixing stage and cannot be commuted.)
+__global__ __launch_bounds__(64) void bspline_forward_modes_kernel(const double* __restrict__ A, long long lda, int n_modes,
+                                                                   double* __restrict__ O, long long ldo, long long g0,
+                                                                   long long n_rows, const BsplineForward* __restrict__ table,
+                                                                   int tile, int halo, int with_ones) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n_modes + with_ones) return;
+  const bool ones = p == n_modes;
+  const long long jA = g0 + (long long)blockIdx.y * tile;
+  long long jB = jA + tile;
+  const long long jend = g0 + n_rows;
+  if (jB > jend) jB = jend;
+  long long jS = jA - halo;
+  if (jS < g0) jS = g0;
+  const double* ap = A + 2LL * (ones ? 0 : p) - g0 * lda;
+  double* op = O + 2LL * p - g0 * ldo;
+  const double2 one = {1.0, 0.0};
+  auto ld2 = [&](long long j) { return ones ? one : *reinterpret_cast<const double2*>(ap + j * lda); };
+  // The row factors are the same for every lane; as scalar loads each would be an L2 round trip inside the dependent
+  // chain.  A zero the compiler cannot see through keeps them vector loads, requested together with the data.
+  int opaque_zero;
+  asm volatile("v_mov_b32 %0, 0" : "=v"(opaque_zero));
+  const BsplineForward* tv = table + opaque_zero;
+  auto ldt = [&](long long j, double2& pa, double& e) {
+    pa = *reinterpret_cast<const double2*>(&tv[j].P);
+    e = tv[j].E;
+  };
+  double2 c1 = {0.0, 0.0}, c2 = {0.0, 0.0};
+  auto step = [&](long long j, double2 y, double2 pa, double E) {
+    double2 c0;
+    c0.x = pa.x * y.x - pa.y * c1.x - E * c2.x;
+    c0.y = pa.x * y.y - pa.y * c1.y - E * c2.y;
+    if (j >= jA) *reinterpret_cast<double2*>(op + j * ldo) = c0;
+    c2 = c1;
+    c1 = c0;
+  };
+  long long j = jS;
+  for (; j + 4 <= jB; j += 4) {
+    double2 y[4], pa[4];
+    double e[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      y[g] = ld2(j + g);
+      ldt(j + g, pa[g], e[g]);
+    }
+#pragma unroll
+    for (int g = 0; g < 4; ++g) step(j + g, y[g], pa[g], e[g]);
+  }
+  for (; j < jB; ++j) {
+    double2 pa;
+    double e;
+    ldt(j, pa, e);
+    step(j, ld2(j), pa, e);
+  }
+}
+
+hipError_t launch_bspline_forward_modes(hipStream_t stream, const double* A, long long lda, int n_modes, double* Aout,
+                                        long long ldo, long long g0, long long n_rows, long long n_knots,
+                                        const BsplineForward* table, int tile, int halo, int with_ones) {
+  (void)n_knots;
+  if (n_rows <= 0 || n_modes <= 0) return hipSuccess;
+  static const int tile_env = getenv("SCRI_AMD_BSPLINE_TILE_FWD") ? atoi(getenv("SCRI_AMD_BSPLINE_TILE_FWD")) : 0;
+  tile = tile_env > 0 ? tile_env : tile;
+  const long long n_tiles = (n_rows + tile - 1) / tile;
+  dim3 grid((n_modes + with_ones + 63) / 64, (unsigned)n_tiles);
+  hipLaunchKernelGGL(bspline_forward_modes_kernel, grid, dim3(64), 0, stream, A, lda, n_modes, Aout, ldo, g0, n_rows, table,
+                     tile, halo, with_ones);
+  return hipGetLastError();
+}
+
+__global__ __launch_bounds__(256) void negated_row_kernel(const double* __restrict__ off, double* __restrict__ row, int n) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e < n) row[e] = -off[e];
+}
+hipError_t launch_negated_row(hipStream_t stream, const double* off, double* row, int n) {
+  if (n <= 0) return hipSuccess;
+  hipLaunchKernelGGL(negated_row_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, off, row, n);
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------ backward + evaluate
+// One wave = 64 adjacent grid columns marching backward over the knots of one time tile:
+//     c_k = c'_k - G_k c_{k+1} - D_k c_{k+2}            (started `halo` knots above the tile)
+// and, as soon as c_k is known, every output sample on the interval [x_{k+1}, x_{k+2}) is evaluated from the window
+// (c_k, c_{k+1}, c_{k+2}, c_{k+3}) with the interval's power-basis table.  The two end intervals share their neighbour's
+// window (no knot at x_1, x_{n-2}).  Output rows are parked in an LDS ring and written whole, as in the slope form.
+//
+// What bounds the march is neither HBM nor the arithmetic but the latency of the per-knot table values: as scalar loads
+// each is an L2 round trip in the dependent chain of every knot (measured: ~4000 cycles per knot whatever the prefetch
+// depth of the data, with or without the stores, with or without the polynomial).  So the table entries of a whole group
+// of knots travel like the data: requested one group ahead with coalesced vector loads, dropped into LDS, and read back as
+// broadcasts.
+constexpr int BS_WORDS = sizeof(BsplineTable) / sizeof(double);  // 20
+constexpr int BS_W_G = 16, BS_W_D = 17, BS_W_X = 18;
+
+__device__ __forceinline__ int bs_wave_max_i32(int v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    const int o = __shfl_xor(v, off, 64);
+    v = o > v ? o : v;
+  }
+  return v;
+}
+
+template <int RING, int GS>
+__global__ __launch_bounds__(64) void bspline_backward_eval_kernel(
+    const double* __restrict__ C, long long ld, int n_cols, long long g0, long long n_rows, long long n,
+    const double* __restrict__ x, const BsplineTable* __restrict__ table, int tile, int halo, const double* __restrict__ base,
+    const double* __restrict__ skew_a, const double* __restrict__ skew_b, double tt, long long i_lo, long long i_hi,
+    double* __restrict__ out, long long ldo) {
+  constexpr int TN = (GS + 2) * BS_WORDS;  // staged words per group: entries k+2 .. k-GS+1
+  constexpr int TU = (TN + 63) / 64;
+  __shared__ double2 ring[RING][64];
+  __shared__ double tbuf[2][TU * 64];
+  const int lane = threadIdx.x;
+  int p = blockIdx.x * blockDim.x + lane;
+  bool alive = p < n_cols;
+  if (!alive) p = n_cols - 1;
+  const long long jend = g0 + n_rows;
+  const long long jA = g0 + (long long)blockIdx.y * tile;
+  long long jB = jA + tile;
+  if (jB > jend) jB = jend;
+  const long long jI = jB < n - 1 ? jB : n - 1;  // intervals handled: [jA, jI)
+  if (jI <= jA) return;
+  const bool open_top = (jI == n - 1);
+  const bool open_bottom = (jA == 0);
+  const double sa = skew_a ? skew_a[p] : 0.0, sb = skew_b ? skew_b[p] : 0.0;
+  const double* bp = base + i_lo;
+  const int n_i = (int)(i_hi - i_lo);
+  auto ueval = [&](int i) {
+    const double xi = bp[i];
+    return xi + (sa * (xi - tt) + sb);
+  };
+  int i;
+  if (open_top) {
+    i = n_i - 1;
+  } else {
+    const double xt = x[jI];
+    int lo = 0, hi = n_i;
+    while (lo < hi) {
+      const int mid = (lo + hi) >> 1;
+      if (ueval(mid) < xt)
+        lo = mid + 1;
+      else
+        hi = mid;
+    }
+    i = lo - 1;
+  }
+  if (i < 0) alive = false;
+  if (alive && !open_bottom && ueval(i) < x[jA]) alive = false;
+  if (!__any(alive)) return;
+  if (!alive) i = -1;
+
+  const double* cp = C + 2LL * p - g0 * ld;
+  double* op = out + 2LL * p;
+  long long k_min = jA - 1 < n - 4 ? jA - 1 : n - 4;
+  if (k_min < g0) k_min = g0;  // (the first interval of a shard's buffer would need the row before it: the caller's margin
+                               // keeps every output sample away from there)
+  long long jE = jI + halo;
+  if (jE > jend - 1) jE = jend - 1;
+  auto ld2 = [&](long long j) { return *reinterpret_cast<const double2*>(cp + (j >= k_min ? j : k_min) * ld); };
+
+  // this lane's share of a group's table words: word (lane + 64 u) of the block = word tw of entry k_top - te
+  int te[TU], tw[TU];
+#pragma unroll
+  for (int u = 0; u < TU; ++u) {
+    const int idx = lane + 64 * u;
+    te[u] = idx < TN ? idx / BS_WORDS : -1;
+    tw[u] = idx % BS_WORDS;
+  }
+  auto tfetch = [&](long long k_top, double* tl) {
+#pragma unroll
+    for (int u = 0; u < TU; ++u)
+      if (te[u] >= 0) {
+        long long kk = k_top - te[u];
+        kk = kk < k_min ? k_min : (kk > jE ? jE : kk);
+        tl[u] = reinterpret_cast<const double*>(table + kk)[tw[u]];
+      }
+  };
+
+  double ue = alive ? ueval(i) : 0.0;
+  int fl = i;
+  int ftop = bs_wave_max_i32(i);
+  auto park = [&](double2 v) {
+    if (fl - i >= RING) {  // ring full (output much denser than the knots): let the oldest row go
+      *reinterpret_cast<double2*>(op + fl * ldo) = ring[fl & (RING - 1)][lane];
+      --fl;
+    }
+    ring[i & (RING - 1)][lane] = v;
+  };
+  auto flush = [&](int bot) {
+    for (int row = ftop; row > bot; --row)
+      if (row <= fl && row > i) *reinterpret_cast<double2*>(op + row * ldo) = ring[row & (RING - 1)][lane];
+    const int keep = bot > i ? bot : i;
+    if (fl > keep) fl = keep;
+    if (ftop > bot) ftop = bot;
+  };
+  // every output sample on data interval jj (table entry at tb), from the window q0..q3 = c_{f_jj} .. c_{f_jj + 3}
+  auto interval = [&](long long jj, const double* tb, double2 q0, double2 q1, double2 q2, double2 q3) {
+    const double xj = tb[BS_W_X];
+    const bool last_interval = (jj == 0);  // only the tile with jA = 0 gets here: claims everything below
+    if (i >= 0 && (ue >= xj || last_interval)) {
+      const double p0x = tb[0] * q0.x + tb[1] * q1.x + tb[2] * q2.x + tb[3] * q3.x, p0y = tb[0] * q0.y + tb[1] * q1.y + tb[2] * q2.y + tb[3] * q3.y;
+      const double p1x = tb[4] * q0.x + tb[5] * q1.x + tb[6] * q2.x + tb[7] * q3.x, p1y = tb[4] * q0.y + tb[5] * q1.y + tb[6] * q2.y + tb[7] * q3.y;
+      const double p2x = tb[8] * q0.x + tb[9] * q1.x + tb[10] * q2.x + tb[11] * q3.x,
+                   p2y = tb[8] * q0.y + tb[9] * q1.y + tb[10] * q2.y + tb[11] * q3.y;
+      const double p3x = tb[12] * q0.x + tb[13] * q1.x + tb[14] * q2.x + tb[15] * q3.x,
+                   p3y = tb[12] * q0.y + tb[13] * q1.y + tb[14] * q2.y + tb[15] * q3.y;
+      while (i >= 0 && (ue >= xj || last_interval)) {
+        // t = u_eval - x_j, formed as (x_i - x_j) + skew to keep the small difference exact
+        const double xi = bp[i];
+        const double t = (xi - xj) + (sa * (xi - tt) + sb);
+        double2 v;
+        v.x = ((p3x * t + p2x) * t + p1x) * t + p0x;
+        v.y = ((p3y * t + p2y) * t + p1y) * t + p0y;
+        park(v);
+        --i;
+        if (i >= 0) ue = ueval(i);
+      }
+    }
+  };
+  const bool has_top_extra = (n - 2 >= jA) && (n - 2 < jI);
+  // window above the coefficient being computed: w0 = c_{k+1}, w1 = c_{k+2}, w2 = c_{k+3}
+  double2 w0 = *reinterpret_cast<const double2*>(cp + jE * ld), w1 = {0.0, 0.0}, w2 = {0.0, 0.0};
+  auto stepk = [&](long long k, double2 r, const double* tk /* entry k; entries k+1, k+2 sit below it in LDS */) {
+    const double G = tk[BS_W_G], D = tk[BS_W_D];
+    double2 c;
+    c.x = r.x - G * w0.x - D * w1.x;
+    c.y = r.y - G * w0.y - D * w1.y;
+    if (k == n - 4 && has_top_extra) interval(n - 2, tk - 2 * BS_WORDS, c, w0, w1, w2);
+    if (k + 1 >= jA && k + 1 < jI && k <= n - 4) interval(k + 1, tk - BS_WORDS, c, w0, w1, w2);
+    if (k == 0 && open_bottom) interval(0, tk, c, w0, w1, w2);
+    w2 = w1, w1 = w0, w0 = c;
+  };
+
+  // march: knots jE-1 .. k_min in groups of GS; above the tile only the recurrence runs (its start decays as 0.268^halo)
+  long long k = jE - 1;
+  double2 r[GS], nx[GS];
+  double tl[TU];
+#pragma unroll
+  for (int g = 0; g < GS; ++g) r[g] = ld2(k - g);
+  tfetch(k + 2, tl);
+  int buf = 0;
+  for (; k >= k_min; k -= GS) {
+    double* tb = tbuf[buf];
+#pragma unroll
+    for (int u = 0; u < TU; ++u) tb[lane + 64 * u] = tl[u];
+    // the NEXT group's rows and table entries are requested before the dependent chain of this group starts
+    const long long kn = k - GS;
+    if (kn >= k_min) {
+#pragma unroll
+      for (int g = 0; g < GS; ++g) nx[g] = ld2(kn - g);
+      tfetch(kn + 2, tl);
+    }
+#pragma unroll
+    for (int g = 0; g < GS; ++g) {
+      if (k - g >= k_min) stepk(k - g, r[g], tb + (2 + g) * BS_WORDS);
+      if ((g & 3) == 3 || g == GS - 1) flush(bs_wave_max_i32(i));  // rows every lane has left behind (a finished lane holds nobody back)
+    }
+    if (!__any(i >= 0)) break;
+#pragma unroll
+    for (int g = 0; g < GS; ++g) r[g] = nx[g];
+    buf ^= 1;
+  }
+  // lanes stop at different rows at the bottom of the tile: whatever is still parked goes out now
+  const int low = -bs_wave_max_i32(fl > i ? -i : -0x7fffffff);
+  flush(low);
+}
+
+hipError_t launch_bspline_backward_eval(hipStream_t stream, const double* C, long long ld, int n_cols, long long g0,
+                                        long long n_rows, long long n_knots, const double* x, const BsplineTable* table,
+                                        int tile, int halo, const double* base, const double* skew_a, const double* skew_b,
+                                        double tt, long long i_lo, long long i_hi, double* out, long long ldo) {
+  static const int tile_env = getenv("SCRI_AMD_SPLINE_TILE_BWD") ? atoi(getenv("SCRI_AMD_SPLINE_TILE_BWD")) : 0;
+  if (tile_env > 0) tile = tile_env;
+  if (n_rows <= 0 || n_cols <= 0 || i_hi <= i_lo) return hipSuccess;
+  const long long n_tiles = (n_rows + tile - 1) / tile;
+  dim3 grid((n_cols + 63) / 64, (unsigned)n_tiles);
+  static const int xp = getenv("SCRI_AMD_BS_XP") ? atoi(getenv("SCRI_AMD_BS_XP")) : 0;
+#define BS_GO(R, G_)                                                                                                        \
+  hipLaunchKernelGGL((bspline_backward_eval_kernel<R, G_>), grid, dim3(64), 0, stream, C, ld, n_cols, g0, n_rows, n_knots, x, table, \
+                     tile, halo, base, skew_a, skew_b, tt, i_lo, i_hi, out, ldo)
+  switch (xp) {
+    case 1: BS_GO(4, 4); break;
+    case 2: BS_GO(16, 4); break;
+    case 3: BS_GO(8, 5); break;
+    default: BS_GO(8, 4);
+  }
+#undef BS_GO
+  return hipGetLastError();
+}
+
+}  // namespace bms
