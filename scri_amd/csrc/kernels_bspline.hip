@@ -257,7 +257,7 @@ __device__ __forceinline__ int bs_wave_max_i32(int v) {
   return v;
 }
 
-template <int RING, int GS>
+template <int RING, int GS, int DEFER>
 __global__ __launch_bounds__(64) void bspline_backward_eval_kernel(
     const double* __restrict__ C, long long ld, int n_cols, long long g0, long long n_rows, long long n,
     const double* __restrict__ x, const BsplineTable* __restrict__ table, int tile, int halo, const double* __restrict__ base,
@@ -333,7 +333,10 @@ __global__ __launch_bounds__(64) void bspline_backward_eval_kernel(
       }
   };
 
-  double ue = alive ? ueval(i) : 0.0;
+  // the output abscissa of the sample in hand and of the one after it: the gather of base[i - 1] is in flight while sample i
+  // is evaluated (it sits in the dependent chain of the march otherwise)
+  double xi_cur = alive ? bp[i] : 0.0, xi_nxt = (alive && i > 0) ? bp[i - 1] : 0.0;
+  double ue = xi_cur + (sa * (xi_cur - tt) + sb);
   int fl = i;
   int ftop = bs_wave_max_i32(i);
   auto park = [&](double2 v) {
@@ -363,14 +366,15 @@ __global__ __launch_bounds__(64) void bspline_backward_eval_kernel(
                    p3y = tb[12] * q0.y + tb[13] * q1.y + tb[14] * q2.y + tb[15] * q3.y;
       while (i >= 0 && (ue >= xj || last_interval)) {
         // t = u_eval - x_j, formed as (x_i - x_j) + skew to keep the small difference exact
-        const double xi = bp[i];
-        const double t = (xi - xj) + (sa * (xi - tt) + sb);
+        const double t = (xi_cur - xj) + (sa * (xi_cur - tt) + sb);
         double2 v;
         v.x = ((p3x * t + p2x) * t + p1x) * t + p0x;
         v.y = ((p3y * t + p2y) * t + p1y) * t + p0y;
         park(v);
         --i;
-        if (i >= 0) ue = ueval(i);
+        xi_cur = xi_nxt;
+        if (i > 0) xi_nxt = bp[i - 1];
+        ue = xi_cur + (sa * (xi_cur - tt) + sb);
       }
     }
   };
@@ -396,10 +400,14 @@ __global__ __launch_bounds__(64) void bspline_backward_eval_kernel(
   for (int g = 0; g < GS; ++g) r[g] = ld2(k - g);
   tfetch(k + 2, tl);
   int buf = 0;
+  int pending_bot = 0x7fffffff;  // rows above it are complete but not yet written (DEFER: written one group late)
   for (; k >= k_min; k -= GS) {
     double* tb = tbuf[buf];
 #pragma unroll
     for (int u = 0; u < TU; ++u) tb[lane + 64 * u] = tl[u];
+    // (the wait for this group's loads has just drained the memory pipe: the stores of the previous group go out now, a
+    // whole group ahead of the next wait, instead of right in front of it)
+    if (DEFER && pending_bot != 0x7fffffff) flush(pending_bot);
     // the NEXT group's rows and table entries are requested before the dependent chain of this group starts
     const long long kn = k - GS;
     if (kn >= k_min) {
@@ -410,13 +418,15 @@ __global__ __launch_bounds__(64) void bspline_backward_eval_kernel(
 #pragma unroll
     for (int g = 0; g < GS; ++g) {
       if (k - g >= k_min) stepk(k - g, r[g], tb + (2 + g) * BS_WORDS);
-      if ((g & 3) == 3 || g == GS - 1) flush(bs_wave_max_i32(i));  // rows every lane has left behind (a finished lane holds nobody back)
+      if (!DEFER && ((g & 3) == 3 || g == GS - 1)) flush(bs_wave_max_i32(i));  // rows every lane has left behind
     }
+    if (DEFER) pending_bot = bs_wave_max_i32(i);
     if (!__any(i >= 0)) break;
 #pragma unroll
     for (int g = 0; g < GS; ++g) r[g] = nx[g];
     buf ^= 1;
   }
+  if (DEFER && pending_bot != 0x7fffffff) flush(pending_bot);
   // lanes stop at different rows at the bottom of the tile: whatever is still parked goes out now
   const int low = -bs_wave_max_i32(fl > i ? -i : -0x7fffffff);
   flush(low);
@@ -432,14 +442,14 @@ hipError_t launch_bspline_backward_eval(hipStream_t stream, const double* C, lon
   const long long n_tiles = (n_rows + tile - 1) / tile;
   dim3 grid((n_cols + 63) / 64, (unsigned)n_tiles);
   static const int xp = getenv("SCRI_AMD_BS_XP") ? atoi(getenv("SCRI_AMD_BS_XP")) : 0;
-#define BS_GO(R, G_)                                                                                                        \
-  hipLaunchKernelGGL((bspline_backward_eval_kernel<R, G_>), grid, dim3(64), 0, stream, C, ld, n_cols, g0, n_rows, n_knots, x, table, \
+#define BS_GO(R, G_, X_)                                                                                                        \
+  hipLaunchKernelGGL((bspline_backward_eval_kernel<R, G_, X_>), grid, dim3(64), 0, stream, C, ld, n_cols, g0, n_rows, n_knots, x, table, \
                      tile, halo, base, skew_a, skew_b, tt, i_lo, i_hi, out, ldo)
-  switch (xp) {
-    case 1: BS_GO(4, 4); break;
-    case 2: BS_GO(16, 4); break;
-    case 3: BS_GO(8, 5); break;
-    default: BS_GO(8, 4);
+  switch (xp) {  // (ring rows, knots per group, deferred stores): measured 1.21 / 1.12 / 1.06 ms at cfg3 for the first three
+    case 1: BS_GO(8, 4, 0); break;
+    case 2: BS_GO(8, 4, 1); break;
+    case 3: BS_GO(16, 4, 1); break;
+    default: BS_GO(8, 3, 1);
   }
 #undef BS_GO
   return hipGetLastError();
