@@ -180,3 +180,37 @@ def test_output_window_matches_the_transforms(ctx):
         u_new, r_new = engine.transform_abd(t, raw, ell_max, tr2, ctx=ctx)
         lo, hi = engine.output_window(t, tr2, abd=True, ctx=ctx)
         assert hi - lo == u_new.size and r_new.shape[1] == u_new.size and r_new.flags.c_contiguous
+
+
+@pytest.mark.parametrize("n", [8, 9, 10, 13, 40, 320, 321, 353, 700, 1500])
+@pytest.mark.parametrize("mesh", ["uniform", "ratio30", "alternating"])
+def test_bspline_path_on_short_and_irregular_time_axes(ctx, n, mesh):
+    """The B-spline form of the spline (elimination on the modes) against the oracle's scipy splines: series as short as
+    the form allows (8 samples: below that the slope form runs), lengths around the 320-knot tile and its 32-knot halo,
+    and irregular meshes, where the end rows of the collocation system and the decay of the tiled recurrences matter."""
+    import scri_amd
+    from oracle import waveform_grid_ref as grid_ref
+    from oracle.containers import WM, h
+
+    rng = np.random.default_rng(1000 + n)
+    if mesh == "uniform":
+        dt = np.full(n, 0.1)
+    elif mesh == "ratio30":
+        dt = rng.uniform(0.01, 0.3, size=n)
+    else:
+        dt = np.where(np.arange(n) % 2 == 0, 0.2, 0.01)
+    t = np.cumsum(dt)
+    ell_max = 3
+    nm = (ell_max + 1) ** 2 - 4
+    data = (np.sin(np.outer(t, rng.uniform(0.5, 3.0, size=nm))) + 1j * np.cos(np.outer(t, rng.uniform(0.5, 3.0, size=nm)))) * rng.normal(size=nm)
+    data += 0.05 * (rng.normal(size=(n, nm)) + 1j * rng.normal(size=(n, nm)))  # rough on purpose: nothing is smoothed away
+    st = np.zeros(9, dtype=complex)
+    st[0] = 0.37 * dt.mean() * np.sqrt(4 * np.pi)  # a time translation by a fraction of a step ...
+    st[2], st[6] = 0.02, -0.01                      # ... plus a direction-dependent part
+    kw = dict(supertranslation=st, boost_velocity=np.array([0.01, -0.02, 0.015]))
+    expect = grid_ref.transform(WM(t=t, data=data, ell_min=2, ell_max=ell_max, dataType=h), **kw)
+    got = scri_amd.WaveformModes(t=t, data=data, ell_min=2, ell_max=ell_max, dataType=scri_amd.h, frameType=scri_amd.Inertial, r_is_scaled_out=True, m_is_scaled_out=True,
+                                ctx=ctx).transform(**kw)
+    assert got.t.size == expect.t.size and got.t.size > 0
+    assert np.abs(got.t - expect.t).max() < 1e-13 * max(1.0, np.abs(t).max())
+    assert np.abs(got.data - expect.data).max() < 2e-12 * max(1.0, np.abs(expect.data).max())
