@@ -57,6 +57,7 @@ struct bms_ctx {
   int device = 0;
   hipStream_t own_stream = nullptr;
   hipStream_t stream = nullptr;
+  hipStream_t aux = nullptr;  // set-up kernels whose results the host waits for run here, beside the main stream's work
   std::string err;
   uint64_t ws_limit = 32ull << 30;
   std::map<std::string, DevBuf> bufs;  // grow-only named work space
@@ -207,6 +208,7 @@ extern "C" int bms_ctx_create(int device, bms_ctx** out) {
     return fail(nullptr, BMS_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(e));
   }
   c->stream = c->own_stream;
+  if (hipStreamCreateWithFlags(&c->aux, hipStreamNonBlocking) != hipSuccess) c->aux = nullptr;
   *out = c;
   return BMS_OK;
 }
@@ -223,6 +225,7 @@ extern "C" void bms_ctx_destroy(bms_ctx* c) {
   }
   for (auto e : c->event_pool) (void)hipEventDestroy(e);
   if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+  if (c->aux) (void)hipStreamDestroy(c->aux);
   delete c;
 }
 
@@ -874,7 +877,8 @@ static int column_plan(const bms_transformation* tr, int n_out) {
 // On return T.n_pix is the number of COLUMNS (everything downstream is per column); T.n_theta * T.n_phi stays the grid.
 static int device_pixel_tables(bms_ctx* c, const bms_transformation* tr, PixelTables& T, int mode, int spin, int cw,
                                const std::vector<cplx>* coef0, const std::vector<cplx>* coef1, const cplx cv[4], DevPixel& D,
-                               int plan) {
+                               int plan, hipStream_t PS = nullptr) {
+  if (!PS) PS = c->stream;
   init_pixel_tables(tr, T);
   const int n_pix = T.n_pix, lst = tr->ell_max_supertranslation, nst = (lst + 1) * (lst + 1);
   const int n_cols = plan ? n_pix - 2 * (tr->n_phi - 1) : n_pix;
@@ -892,7 +896,7 @@ static int device_pixel_tables(bms_ctx* c, const bms_transformation* tr, PixelTa
   cplx* d_coefs;
   int rc = dev_buf_t(c, "pix_coefs", (size_t)3 * nst, &d_coefs);
   if (rc) return rc;
-  HIP_TRY(c, hipMemcpyAsync(d_coefs, coefs.data(), sizeof(cplx) * 3 * nst, hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(c, hipMemcpyAsync(d_coefs, coefs.data(), sizeof(cplx) * 3 * nst, hipMemcpyHostToDevice, PS));
   P.st = d_coefs;
   P.c0 = coef0 ? d_coefs + nst : nullptr;
   P.c1 = coef1 ? d_coefs + 2 * nst : nullptr;
@@ -921,15 +925,15 @@ static int device_pixel_tables(bms_ctx* c, const bms_transformation* tr, PixelTa
   if (plan) {
     if ((rc = dev_buf_t(c, "pix_perm", (size_t)2 * n_pix, &d_perm))) return rc;
     if (plan == 2)  // the skew rate of every grid pixel first: it is the sort key
-      TIMED(c, BMS_TAG_SETUP, launch_pixel_tables(c->stream, P, O, n_pix, nullptr));
-    TIMED(c, BMS_TAG_SETUP, launch_pixel_sort(c->stream, D.skew_a, tr->n_theta, tr->n_phi, plan == 2, d_perm, d_perm + n_pix));
+      TIMED(c, BMS_TAG_SETUP, launch_pixel_tables(PS, P, O, n_pix, nullptr));
+    TIMED(c, BMS_TAG_SETUP, launch_pixel_sort(PS, D.skew_a, tr->n_theta, tr->n_phi, plan == 2, d_perm, d_perm + n_pix));
     D.col_of_pixel = d_perm + n_pix;
   }
-  TIMED(c, BMS_TAG_SETUP, launch_pixel_tables(c->stream, P, O, n_cols, d_perm));
+  TIMED(c, BMS_TAG_SETUP, launch_pixel_tables(PS, P, O, n_cols, d_perm));
   // k, alpha, skew_a, skew_b are contiguous (n_pix apart): one copy back
   std::vector<double> back((size_t)4 * n_pix);
-  HIP_TRY(c, hipMemcpyAsync(back.data(), D.k, sizeof(double) * 4 * n_pix, hipMemcpyDeviceToHost, c->stream));
-  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  HIP_TRY(c, hipMemcpyAsync(back.data(), D.k, sizeof(double) * 4 * n_pix, hipMemcpyDeviceToHost, PS));
+  HIP_TRY(c, hipStreamSynchronize(PS));
   T.n_pix = n_cols;
   T.k.assign(back.data(), back.data() + n_cols);
   T.alpha.assign(back.data() + n_pix, back.data() + n_pix + n_cols);
@@ -1096,37 +1100,28 @@ extern "C" int bms_transform_modes_shard(bms_ctx* c, const bms_wm_input* in, con
     cv[2] = {is2 * v[2] * std::sqrt(4 * M_PI / 3), 0};
     cv[3] = {-is2 * v[0] * std::sqrt(2 * M_PI / 3), is2 * v[1] * std::sqrt(2 * M_PI / 3)};
   }
-  PixelTables T;
-  DevPixel DP;
-  if ((rc = device_pixel_tables(c, tr, T, psi ? 1 : 0, s, in->conformal_weight, coef0.empty() ? nullptr : &coef0, nullptr, cv, DP, column_plan(tr, n_out))))
-    return rc;
-  trace.mark("pixel tables (GPU) + copy back");
-  const int n_cols = T.n_pix;
-  const bool col_split = sh && sh->col_parts > 1;
-  int cA, cB;
-  if ((rc = column_range(c, sh, n_cols, cA, cB))) return rc;
-  const int n_pix = cB - cA;  // columns this call synthesises and splines
-  int64_t i_lo, i_hi;
-  output_window(T, in->t, n, i_lo, i_hi);
-  // shard: rows [row0, row0 + rows) of the global data are present; produce outputs with global index in [out_i0, out_i1)
+  // shard: rows [row0, row0 + rows) of the global data are present
   const int64_t row0 = sh ? sh->data_row0 : 0;
   const int64_t rows_avail = sh ? sh->data_rows : n;
-  if (sh) {
-    if (row0 < 0 || rows_avail < 0 || row0 + rows_avail > n) return fail(c, BMS_ERR_INVALID, "shard rows outside [0, n_times)");
-    i_lo = std::max(i_lo, sh->out_i0);
-    i_hi = std::max(i_lo, std::min(i_hi, sh->out_i1));
-  }
-  if (first_index_out) *first_index_out = i_lo;
-  const int64_t n_new = i_hi - i_lo;
-  *n_times_out = n_new;
-  if (n_new == 0) return BMS_OK;
-  double *d_rot = DP.rotors, *d_off = DP.col_off + 2 * cA, *d_scale = DP.col_scale + 2 * cA, *d_skewa = DP.skew_a + cA, *d_skewb = DP.skew_b + cA;
-  double *d_alpha = DP.alpha + cA, *d_xa = DP.xa + 2 * cA, *d_xb = DP.xb + 2 * cA, *d_x;
+  if (sh && (row0 < 0 || rows_avail < 0 || row0 + rows_avail > n)) return fail(c, BMS_ERR_INVALID, "shard rows outside [0, n_times)");
   // Without psi mixing the map modes -> grid values is linear along the columns with time-independent coefficients, so
   // the spline's forward elimination is done on the modes (B-spline form, kernels_bspline.hip) and the grid is passed over
   // once, by the back substitution + evaluation.
   const bool bsg = n >= 8 && !getenv("SCRI_AMD_NO_BSPLINE");  // B-spline form at all (else: the slope form, kernels_spline.hip)
   const bool bs = bsg && !psi;                                 // ... with the elimination commuted onto the modes
+  // Everything that depends on the time axis and the input modes only goes to the main stream first; the per-direction
+  // tables, whose window the host has to wait for, are computed beside it on the auxiliary stream.
+  struct DrainOnExit {  // whatever path leaves this call, nothing enqueued here still reads the caller's buffers
+    hipStream_t s;
+    ~DrainOnExit() { (void)hipStreamSynchronize(s); }
+  } drain{S};
+  FieldPlan F[5];
+  F[0].ell_min = in->ell_min;
+  F[0].ell_max = in->ell_max;
+  F[0].spin = s;
+  F[0].ld = in->ld;
+  if ((rc = stage_in(c, "in_data", in->data, in->mem, (size_t)rows_avail * in->ld * 16, &F[0].d_data))) return rc;
+  double* d_x;
   SplineTable* d_tab = nullptr;
   BsplineTable* d_bstab = nullptr;
   BsplineForward* d_bsfwd = nullptr;
@@ -1135,18 +1130,47 @@ extern "C" int bms_transform_modes_shard(bms_ctx* c, const bms_wm_input* in, con
   else
     rc = upload_times(c, in->t, n, t_lo, t_hi, row0, row0 + rows_avail, &d_x, &d_tab);
   if (rc) return rc;
-  trace.mark("window (host) + time upload + spline factors");
+  const long long ld_af = 2LL * (n_modes + 1);
+  double* d_Af = nullptr;
+  if (bs && rows_avail > 0) {
+    if ((rc = dev_buf_t(c, "Afwd", (size_t)rows_avail * ld_af, &d_Af))) return rc;
+    TIMED(c, BMS_TAG_SPLINE_FORWARD, launch_bspline_forward_modes(S, F[0].d_data, F[0].ld * 2, n_modes, d_Af, ld_af, row0, rows_avail, n, d_bsfwd,
+                                                                  SPLINE_TILE, SPLINE_HALO, 1));
+  }
+  trace.mark("input staging, time upload, spline factors, elimination on the modes (enqueue)");
+  PixelTables T;
+  DevPixel DP;
+  if ((rc = device_pixel_tables(c, tr, T, psi ? 1 : 0, s, in->conformal_weight, coef0.empty() ? nullptr : &coef0, nullptr, cv, DP, column_plan(tr, n_out),
+                                c->aux)))
+    return rc;
+  trace.mark("pixel tables (GPU, auxiliary stream) + copy back");
+  const int n_cols = T.n_pix;
+  const bool col_split = sh && sh->col_parts > 1;
+  int cA, cB;
+  if ((rc = column_range(c, sh, n_cols, cA, cB))) return rc;
+  const int n_pix = cB - cA;  // columns this call synthesises and splines
+  int64_t i_lo, i_hi;
+  output_window(T, in->t, n, i_lo, i_hi);
+  // produce outputs with global index in [out_i0, out_i1)
+  if (sh) {
+    i_lo = std::max(i_lo, sh->out_i0);
+    i_hi = std::max(i_lo, std::min(i_hi, sh->out_i1));
+  }
+  if (first_index_out) *first_index_out = i_lo;
+  const int64_t n_new = i_hi - i_lo;
+  *n_times_out = n_new;
+  if (n_new == 0) {
+    HIP_TRY(c, hipStreamSynchronize(S));  // the work enqueued above reads the caller's buffers
+    return BMS_OK;
+  }
+  double *d_rot = DP.rotors, *d_off = DP.col_off + 2 * cA, *d_scale = DP.col_scale + 2 * cA, *d_skewa = DP.skew_a + cA, *d_skewb = DP.skew_b + cA;
+  double *d_alpha = DP.alpha + cA, *d_xa = DP.xa + 2 * cA, *d_xb = DP.xb + 2 * cA;
+  trace.mark("window (host)");
 
   const long long P2 = 2LL * n_pix;
   const long long ldg = round_up(P2, 16);
   // synthesis matrices
   const int n_fields = 1 + (psi ? in->n_aux : 0);
-  FieldPlan F[5];
-  F[0].ell_min = in->ell_min;
-  F[0].ell_max = in->ell_max;
-  F[0].spin = s;
-  F[0].ld = in->ld;
-  if ((rc = stage_in(c, "in_data", in->data, in->mem, (size_t)rows_avail * in->ld * 16, &F[0].d_data))) return rc;
   for (int a = 0; a < (psi ? in->n_aux : 0); ++a) {
     FieldPlan& f = F[1 + a];
     f.ell_min = in->aux_ell_min[a];
@@ -1173,7 +1197,6 @@ extern "C" int bms_transform_modes_shard(bms_ctx* c, const bms_wm_input* in, con
   const int n_modes_in = F[0].K / 2;
   if (bs)  // row n_modes of B multiplies the eliminated constant series: it carries the per-column offset
     TIMED(c, BMS_TAG_SETUP, launch_negated_row(S, DP.col_off, F[0].d_B + (size_t)n_modes_in * ldb, 2 * n_cols));
-  const long long ld_af = 2LL * (n_modes_in + 1);
   trace.mark("uploads + synthesis matrices");
   AnalysisPlan ana;
   if ((rc = build_analysis(c, "wm", T.n_theta, T.n_phi, s, ell_min_out, tr->ell_max_out, ana))) return rc;
@@ -1222,11 +1245,8 @@ extern "C" int bms_transform_modes_shard(bms_ctx* c, const bms_wm_input* in, con
       if ((rc = dev_buf_t(c, "R", (size_t)rows_in * ldg, &d_R))) return rc;  // eliminated rows (either form)
     if ((rc = dev_buf_t(c, "G", (size_t)rows_out * P2, &d_G))) return rc;
     if (bs) {
-      double* d_Af;
-      if ((rc = dev_buf_t(c, "Afwd", (size_t)rows_in * ld_af, &d_Af))) return rc;
-      TIMED(c, BMS_TAG_SPLINE_FORWARD, launch_bspline_forward_modes(S, F[0].d_data + (g0 - row0) * F[0].ld * 2, F[0].ld * 2, n_modes_in, d_Af, ld_af, g0,
-                                                                    rows_in, n, d_bsfwd, SPLINE_TILE, SPLINE_HALO, 1));
-      TIMED(c, BMS_TAG_GEMM_SYNTHESIS, launch_zgemm3m(S, d_Af, ld_af, F[0].d_B + 2 * cA, ldb, d_Y, ldg, rows_in, n_pix, n_modes_in + 1, nullptr, d_scale));
+      TIMED(c, BMS_TAG_GEMM_SYNTHESIS, launch_zgemm3m(S, d_Af + (g0 - row0) * ld_af, ld_af, F[0].d_B + 2 * cA, ldb, d_Y, ldg, rows_in, n_pix,
+                                                      n_modes_in + 1, nullptr, d_scale));
       TIMED(c, BMS_TAG_SPLINE_BACKWARD, launch_bspline_backward_eval(S, d_Y, ldg, n_pix, g0, rows_in, n, d_x, d_bstab, SPLINE_TILE, SPLINE_HALO, d_x, d_skewa,
                                                                      d_skewb, T.tt, c0, c1, d_G, P2));
     } else {
