@@ -924,9 +924,7 @@ static int device_pixel_tables(bms_ctx* c, const bms_transformation* tr, PixelTa
   int* d_perm = nullptr;
   if (plan) {
     if ((rc = dev_buf_t(c, "pix_perm", (size_t)2 * n_pix, &d_perm))) return rc;
-    if (plan == 2)  // the skew rate of every grid pixel first: it is the sort key
-      TIMED(c, BMS_TAG_SETUP, launch_pixel_tables(PS, P, O, n_pix, nullptr));
-    TIMED(c, BMS_TAG_SETUP, launch_pixel_sort(PS, D.skew_a, tr->n_theta, tr->n_phi, plan == 2, d_perm, d_perm + n_pix));
+    TIMED(c, BMS_TAG_SETUP, launch_pixel_sort(PS, P, tr->n_theta, tr->n_phi, plan == 2, d_perm, d_perm + n_pix));
     D.col_of_pixel = d_perm + n_pix;
   }
   TIMED(c, BMS_TAG_SETUP, launch_pixel_tables(PS, P, O, n_cols, d_perm));

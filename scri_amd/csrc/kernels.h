@@ -45,7 +45,7 @@ hipError_t launch_pixel_tables(hipStream_t stream, const PixelSpec& P, const Pix
 // column each (n_cols = n_pix - 2 (n_phi - 1)); perm[n_cols] = grid pixel of a column, in grid order (by_key = 0) or sorted by
 // key (by_key = 1); inv[n_pix] = column of a grid pixel (pole pixels share their ring's column)
 int pixel_sort_max();
-hipError_t launch_pixel_sort(hipStream_t stream, const double* key, int n_theta, int n_phi, int by_key, int* perm, int* inv);
+hipError_t launch_pixel_sort(hipStream_t stream, const PixelSpec& P, int n_theta, int n_phi, int by_key, int* perm, int* inv);
 
 // ---- separable analysis (kernels_analysis.hip): phi-DFT matrix for the GEMM, theta table, theta quadrature
 hipError_t launch_dft_matrix(hipStream_t stream, int n_phi, int L, double* B, long long ldb);

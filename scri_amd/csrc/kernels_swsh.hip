@@ -131,7 +131,9 @@ constexpr int SORT_N = 2048;
 // about its own z axis, i.e. by the spin phase e^{-+ i s phi_k} of the value.  Only pixel k = 0 of a pole ring becomes a
 // column (n_cols = n_pix - 2 (n_phi - 1)); the analysis re-creates the others from it.  by_key = 0: columns in grid
 // order (no boost); by_key = 1: sorted by key.
-__global__ __launch_bounds__(1024) void pixel_sort_kernel(const double* __restrict__ key, int n, int n_theta, int n_phi, int by_key,
+// The key is the time-skew rate -(v . r) of the pixel's direction: geometry only (rotor of the pixel, no supertranslation
+// sums), computed here; `sort_n`: power of two >= n actually sorted.
+__global__ __launch_bounds__(1024) void pixel_sort_kernel(PixelSpec P, int n, int n_theta, int n_phi, int by_key, int sort_n,
                                                           int* __restrict__ perm, int* __restrict__ inv) {
   __shared__ double k[SORT_N];
   __shared__ int id[SORT_N];
@@ -140,14 +142,25 @@ __global__ __launch_bounds__(1024) void pixel_sort_kernel(const double* __restri
     const int j = g / n_phi, kk = g - j * n_phi;
     return (j == 0 || j == n_theta - 1) && kk > 0;
   };
-  for (int i = tid; i < SORT_N; i += blockDim.x) {
-    k[i] = (i < n && !duplicate(i)) ? (by_key ? key[i] : (double)i) : INFINITY;
+  for (int i = tid; i < sort_n; i += blockDim.x) {
+    double key = INFINITY;
+    if (i < n && !duplicate(i)) {
+      key = (double)i;
+      if (by_key) {
+        const int j = i / n_phi, kk = i - j * n_phi;
+        const Quat R = pixel_rotor(P.frq, P.bs, j, kk, n_theta, n_phi);
+        double r[3];
+        rotate_z(R, r);
+        key = -(P.v[0] * r[0] + P.v[1] * r[1] + P.v[2] * r[2]);
+      }
+    }
+    k[i] = key;
     id[i] = i;
   }
-  for (int size = 2; size <= SORT_N; size <<= 1) {
+  for (int size = 2; size <= sort_n; size <<= 1) {
     for (int stride = size >> 1; stride > 0; stride >>= 1) {
       __syncthreads();
-      for (int t = tid; t < SORT_N / 2; t += blockDim.x) {
+      for (int t = tid; t < sort_n / 2; t += blockDim.x) {
         const int a = 2 * t - (t & (stride - 1)), b = a + stride;
         const bool up = (a & size) == 0;
         const double ka = k[a], kb = k[b];
@@ -175,10 +188,12 @@ __global__ __launch_bounds__(1024) void pixel_sort_kernel(const double* __restri
 
 int pixel_sort_max() { return SORT_N; }
 
-hipError_t launch_pixel_sort(hipStream_t stream, const double* key, int n_theta, int n_phi, int by_key, int* perm, int* inv) {
+hipError_t launch_pixel_sort(hipStream_t stream, const PixelSpec& P, int n_theta, int n_phi, int by_key, int* perm, int* inv) {
   const int n = n_theta * n_phi;
   if (n > SORT_N || n_theta < 3) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(pixel_sort_kernel, dim3(1), dim3(1024), 0, stream, key, n, n_theta, n_phi, by_key, perm, inv);
+  int sort_n = 2;
+  while (sort_n < n) sort_n <<= 1;
+  hipLaunchKernelGGL(pixel_sort_kernel, dim3(1), dim3(1024), 0, stream, P, n, n_theta, n_phi, by_key, sort_n, perm, inv);
   return hipGetLastError();
 }
 
