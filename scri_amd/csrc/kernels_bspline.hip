@@ -437,8 +437,26 @@ hipError_t launch_bspline_backward_eval(hipStream_t stream, const double* C, lon
                                         int tile, int halo, const double* base, const double* skew_a, const double* skew_b,
                                         double tt, long long i_lo, long long i_hi, double* out, long long ldo) {
   static const int tile_env = getenv("SCRI_AMD_SPLINE_TILE_BWD") ? atoi(getenv("SCRI_AMD_SPLINE_TILE_BWD")) : 0;
-  if (tile_env > 0) tile = tile_env;
   if (n_rows <= 0 || n_cols <= 0 || i_hi <= i_lo) return hipSuccess;
+  if (tile_env > 0) {
+    tile = tile_env;
+  } else {
+    // A wave's time grows with tile + halo knots and the launch takes a whole number of rounds of resident waves
+    // (16 per CU) plus a tail: measured over 96..1280-knot tiles on the three benchmark shapes (21, 154 and 7 column
+    // blocks), time ~ (ceil(waves / slots) + 1/4) (tile + halo) ranks the candidates within a few per cent.
+    static const long long slots = [] {
+      int dev = 0, cus = 256;
+      if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 256;
+      return 16LL * cus;
+    }();
+    const int cand[4] = {96, 160, 320, 640};
+    double best = 1e300;
+    for (int t : cand) {
+      const long long waves = ((n_cols + 63) / 64) * ((n_rows + t - 1) / t);
+      const double cost = ((double)((waves + slots - 1) / slots) + 0.25) * (t + halo);
+      if (cost < best) best = cost, tile = t;
+    }
+  }
   const long long n_tiles = (n_rows + tile - 1) / tile;
   dim3 grid((n_cols + 63) / 64, (unsigned)n_tiles);
   static const int xp = getenv("SCRI_AMD_BS_XP") ? atoi(getenv("SCRI_AMD_BS_XP")) : 0;
