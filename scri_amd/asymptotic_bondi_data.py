@@ -161,6 +161,9 @@ AsymptoticBondiData.charge_vector_from_aspect = staticmethod(_bms_charges.charge
 from . import map_to_superrest_frame as _superrest  # noqa: E402
 
 AsymptoticBondiData.map_to_superrest_frame = _superrest.map_to_superrest_frame
+from . import map_to_abd_frame as _abd_frame  # noqa: E402
+
+AsymptoticBondiData.map_to_abd_frame = _abd_frame.map_to_abd_frame
 
 from . import abd_ivp as _ivp  # noqa: E402
 

@@ -70,3 +70,39 @@ def test_abd_kerr_target_superrest_frame(ctx):
     chi = rec.bondi_dimensionless_spin()
     chi = chi / np.linalg.norm(chi, axis=-1)[:, None]
     assert np.allclose(chi, [[0, 0, 1]] * rec.t.size, atol=tolerance, rtol=tolerance)
+
+
+def test_abd_to_abd(ctx):
+    """The reference's tests/test_abd_frame.py:25-92: a Kerr solution (from initial values) is moved by a supertranslation +
+    rotation + boost; mapping the original to the frame of the moved one recovers all six fields (np.allclose defaults).
+    fix_time_phase_freedom=False as in the reference test (the data is radiation free)."""
+    import scri_amd
+
+    mass, spin, ell_max = 2.0, 0.456, 8
+    u = np.linspace(-100, 100, num=5000)
+    nm = (ell_max + 1) ** 2
+    psi2 = np.zeros(nm, dtype=complex)
+    psi1 = np.zeros(nm, dtype=complex)
+    psi2[0] = -mass * np.sqrt(4 * np.pi)
+    psi1[2] = -np.sqrt(2) * (3j * spin / 2) * (np.sqrt((8 / 3) * np.pi))
+    abd = scri_amd.AsymptoticBondiData.from_initial_values(u, ell_max=ell_max, psi2=psi2, psi1=psi1, ctx=ctx)
+    target = abd.transform(
+        supertranslation=SUPERTRANSLATION, frame_rotation=np.array([1.0, 2, 3, 4]) / np.sqrt(30), boost_velocity=np.array([2e-4, -3e-4, -5e-4])
+    )
+    rec, transformation, rel_err = abd.map_to_abd_frame(
+        target, t_0=0, padding_time=20,
+        N_itr_maxes={"abd": 2, "superrest": 1, "CoM_transformation": 10, "rotation": 10, "supertranslation": 10},
+        fix_time_phase_freedom=False, nprocs=-1,
+    )
+
+    def window(a, other):
+        lo = np.argmin(abs(a.t - max(target.t[0], rec.t[0])))
+        hi = np.argmin(abs(a.t - min(target.t[-1], rec.t[-1]))) + 1
+        return a.interpolate(a.t[lo:hi])
+
+    ti, ri = window(target, rec), window(rec, target)
+    for name in ("sigma", "psi4", "psi3", "psi2", "psi1", "psi0"):
+        assert np.allclose(np.asarray(getattr(ti, name)), np.asarray(getattr(ri, name))), name
+    assert rel_err < 1e-8
+    with pytest.raises(NotImplementedError, match="align2d"):
+        abd.map_to_abd_frame(target)
