@@ -66,3 +66,47 @@ def test_abd_interpolate_matches_oracle(ctx):
     g._raw_data[:] = o.raw
     tn = np.linspace(o.u[3], o.u[-5], 333)
     assert np.abs(g.interpolate(tn)._raw_data - o.interpolate(tn).raw).max() < 1e-12
+
+
+def test_abd_WaveformModes(ctx):
+    """The reference's tests/test_asymptoticbondidata.py:165-212 on the GPU: a general BMS transformation of a random
+    AsymptoticBondiData object (Kerr-Schild + quadratic-in-time shear, from initial values) agrees with the same
+    transformation of its strain h = 2 conj(sigma) as a WaveformModes object -- two different pipelines (six fields with
+    Horner mixing vs. one field with the inhomogeneous h term), at the reference's tolerance."""
+    import scri_amd
+    from tests.test_gpu_transform_modes import real_supertranslation
+
+    tolerance = 4e-12
+    rng = np.random.default_rng(123)
+    mass, spin, ell_max = 1.23, 0.35, 6
+    nm = (ell_max + 1) ** 2
+    u = np.linspace(-10, 10, num=1_000)
+    psi2, psi1, psi0 = (np.zeros(nm, dtype=complex) for _ in range(3))
+    psi2[0] = -mass * np.sqrt(4 * np.pi)
+    psi1[2] = -np.sqrt(2) * (3j * spin / 2) * (np.sqrt((8 / 3) * np.pi))
+    psi0[6] = 2 * (3 * spin**2 / mass / 2) * (np.sqrt((32 / 15) * np.pi))
+
+    def shear(scale):
+        a = scale * ((rng.random(nm) - 0.5) + 1j * (rng.random(nm) - 0.5))
+        a[:4] = 0
+        return a
+
+    abd = scri_amd.AsymptoticBondiData.from_initial_values(
+        u, ell_max=ell_max, sigma0=shear(0.01), sigmadot0=shear(0.0002), sigmaddot0=shear(0.00003), psi2=psi2, psi1=psi1, psi0=psi0, ctx=ctx
+    )
+    h = scri_amd.WaveformModes(
+        t=abd.t, data=2 * abd.sigma.bar.ndarray.copy(), ell_min=0, ell_max=ell_max, frameType=scri_amd.Inertial, dataType=scri_amd.h,
+        r_is_scaled_out=True, m_is_scaled_out=True, ctx=ctx,
+    )
+    alpha = real_supertranslation(ell_max, 7, 0.01)
+    R = rng.normal(size=4)
+    R /= np.linalg.norm(R)
+    v = 0.01 * (rng.random(3) - 0.5)
+    abdprime = abd.transform(supertranslation=alpha, frame_rotation=R, boost_velocity=v)
+    hprime = h.transform(supertranslation=alpha, frame_rotation=R, boost_velocity=v)
+    lo, hi = max(hprime.t[0], abdprime.t[0]), min(hprime.t[-1], abdprime.t[-1])
+    t = hprime.t[(hprime.t >= lo) & (hprime.t <= hi)]
+    assert t.size > 900
+    hprime = hprime.interpolate(t)
+    abdprime = abdprime.interpolate(t)
+    assert np.allclose(hprime.data, 2 * abdprime.sigma.bar.ndarray[:, 4:], atol=tolerance, rtol=tolerance)
