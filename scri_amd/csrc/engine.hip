@@ -1879,14 +1879,19 @@ extern "C" int bms_transform_abd_shard(bms_ctx* c, const double* u, const void* 
             launch_zgemm3m(S, d_raw + ((size_t)f * rows_avail + (g0 - row0)) * nm * 2, 2LL * nm, d_B[spins[f] + 2] + 2 * cA, ldb, grids.y[f], ldg, rows_in,
                            n_pix, K / 2, nullptr, nullptr));
     }
-    TIMED(c, BMS_TAG_POINTWISE,
-          launch_abd_mix(S, grids, ldg, n_pix, rows_in, d_x + g0, d_alpha, d_ethk, d_etha, d_ethetha, d_ik, d_ik3));
+    if (bsg) {  // mixing and elimination of the six fields in one pass over the grids
+      AbdGrids elim;
+      for (int f = 0; f < 6; ++f) elim.y[f] = d_R + (size_t)f * rows_in * ldg;
+      TIMED(c, BMS_TAG_SPLINE_FORWARD, launch_abd_mix_forward(S, grids, elim, ldg, n_pix, g0, rows_in, d_bsfwd, SPLINE_TILE, SPLINE_HALO, d_alpha, d_ethk,
+                                                              d_etha, d_ethetha, d_ik, d_ik3));
+    } else {
+      TIMED(c, BMS_TAG_POINTWISE,
+            launch_abd_mix(S, grids, ldg, n_pix, rows_in, d_x + g0, d_alpha, d_ethk, d_etha, d_ethetha, d_ik, d_ik3));
+    }
     for (int f = 0; f < 6; ++f) {
       double* Rf = d_R + (size_t)f * rows_in * ldg;
       double* Gf = d_G + (size_t)f * rows_out * P2;
       if (bsg) {
-        TIMED(c, BMS_TAG_SPLINE_FORWARD,
-              launch_bspline_forward_modes(S, grids.y[f], ldg, n_pix, Rf, ldg, g0, rows_in, n, d_bsfwd, SPLINE_TILE, SPLINE_HALO, 0));
         TIMED(c, BMS_TAG_SPLINE_BACKWARD, launch_bspline_backward_eval(S, Rf, ldg, n_pix, g0, rows_in, n, d_x, d_bstab, SPLINE_TILE, SPLINE_HALO,
                                                                        d_x, d_skewa, d_skewb, T.tt, c0, c1_, Gf, P2));
       } else {

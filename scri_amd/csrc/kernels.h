@@ -111,7 +111,7 @@ struct BsplineTable {  // per knot j: what the back substitution + evaluation re
   double pad;
 };
 struct BsplineForward {  // per knot j: c'_j = P y_j - A c'_{j-1} - E c'_{j-2}
-  double P, A, E, pad;
+  double P, A, E, x;     // x = x_j
 };
 hipError_t launch_bspline_table(hipStream_t stream, const double* x, long long n, BsplineTable* table, BsplineForward* fwd,
                                 long long j_lo /* first knot the arrays are backed for */, long long j0, long long j1);
@@ -120,6 +120,12 @@ hipError_t launch_bspline_table(hipStream_t stream, const double* x, long long n
 hipError_t launch_bspline_forward_modes(hipStream_t stream, const double* A, long long lda, int n_modes, double* Aout,
                                         long long ldo, long long g0, long long n_rows, long long n_knots,
                                         const BsplineForward* table, int tile, int halo, int with_ones);
+// AsymptoticBondiData: Horner mixing of the six synthesised fields (as launch_abd_mix) fused with their elimination
+struct AbdGrids;
+hipError_t launch_abd_mix_forward(hipStream_t stream, const AbdGrids& Y, const AbdGrids& R, long long ld, int n_cols, long long g0,
+                                  long long n_rows, const BsplineForward* table, int tile, int halo, const double* alpha,
+                                  const double* ethk_over_k, const double* eth_alpha, const double* etheth_alpha,
+                                  const double* inv_k, const double* inv_k3);
 // B[row][0 .. 2 n_cols) = -off[0 .. 2 n_cols): the synthesis-matrix row that multiplies the constant column
 hipError_t launch_negated_row(hipStream_t stream, const double* off, double* row, int n);
 // back substitution + evaluation (arguments as launch_spline_backward_eval, C = eliminated grid coefficients)

@@ -132,7 +132,7 @@ __global__ __launch_bounds__(128) void bspline_factors_kernel(long long n, Bspli
   }
   table[j].G = g_;
   table[j].D = dd_;
-  fwd[j] = BsplineForward{p_, a_, e_, 0.0};
+  fwd[j] = BsplineForward{p_, a_, e_, table[j].x};
 }
 
 // entries [j0, j1); x and the tables are indexed by global knot number and backed from knot j_lo on
@@ -220,6 +220,105 @@ hipError_t launch_bspline_forward_modes(hipStream_t stream, const double* A, lon
   dim3 grid((n_modes + with_ones + 63) / 64, (unsigned)n_tiles);
   hipLaunchKernelGGL(bspline_forward_modes_kernel, grid, dim3(64), 0, stream, A, lda, n_modes, Aout, ldo, g0, n_rows, table,
                      tile, halo, with_ones);
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------ ABD: mixing + forward
+// The Horner mixing of the six AsymptoticBondiData fields (kernels_swsh.hip, abd_mix_kernel; transformations.py:340-385)
+// has time-dependent coefficients, so the elimination cannot move onto the modes -- but the two grid passes can be one:
+// read the six synthesised fields once, mix in registers, run the six recurrences, write the six eliminated fields.
+__global__ __launch_bounds__(64) void abd_mix_forward_kernel(AbdGrids Yg, AbdGrids Rg, long long ld, int n_cols, long long g0,
+                                                             long long n_rows, const BsplineForward* __restrict__ table, int tile,
+                                                             int halo, const double* __restrict__ alpha,
+                                                             const double* __restrict__ ethk_over_k,
+                                                             const double* __restrict__ eth_alpha,
+                                                             const double* __restrict__ etheth_alpha,
+                                                             const double* __restrict__ inv_k, const double* __restrict__ inv_k3) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n_cols) return;
+  const long long jA = g0 + (long long)blockIdx.y * tile;
+  long long jB = jA + tile;
+  const long long jend = g0 + n_rows;
+  if (jB > jend) jB = jend;
+  long long jS = jA - halo;
+  if (jS < g0) jS = g0;
+  const double al = alpha[p], ik = inv_k[p], ik3 = inv_k3[p];
+  const cplx A = {ethk_over_k[2 * p], ethk_over_k[2 * p + 1]}, B = {eth_alpha[2 * p], eth_alpha[2 * p + 1]};
+  const cplx EE = {etheth_alpha[2 * p], etheth_alpha[2 * p + 1]};
+  int opaque_zero;
+  asm volatile("v_mov_b32 %0, 0" : "=v"(opaque_zero));
+  const BsplineForward* tv = table + opaque_zero;  // row factors as vector loads, requested with the data
+  const long long col = 2LL * p - g0 * ld;
+  double2 c1[6], c2[6];
+#pragma unroll
+  for (int f = 0; f < 6; ++f) c1[f] = c2[f] = double2{0.0, 0.0};
+  auto load = [&](long long j, double2* y, double2& pa, double2& ex) {
+#pragma unroll
+    for (int f = 0; f < 6; ++f) y[f] = *reinterpret_cast<const double2*>(Yg.y[f] + col + j * ld);
+    pa = *reinterpret_cast<const double2*>(&tv[j].P);
+    ex = *reinterpret_cast<const double2*>(&tv[j].E);  // (E, x_j)
+  };
+  auto step = [&](long long j, const double2* y, double2 pa, double2 ex) {
+    const double dt = ex.y - al;
+    const cplx X = {A.re * dt - B.re, A.im * dt - B.im};
+    cplx f[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) f[i] = {y[i].x, y[i].y};
+    auto axpy = [](cplx t, cplx X, double c, cplx f) {  // t*X + c*f
+      cplx r = cmul(t, X);
+      return cplx{r.re + c * f.re, r.im + c * f.im};
+    };
+    cplx t0 = f[4];
+    t0 = axpy(t0, X, -4.0, f[3]);
+    t0 = axpy(t0, X, 6.0, f[2]);
+    t0 = axpy(t0, X, -4.0, f[1]);
+    t0 = axpy(t0, X, 1.0, f[0]);
+    cplx t1 = {-f[4].re, -f[4].im};
+    t1 = axpy(t1, X, 3.0, f[3]);
+    t1 = axpy(t1, X, -3.0, f[2]);
+    t1 = axpy(t1, X, 1.0, f[1]);
+    cplx t2 = f[4];
+    t2 = axpy(t2, X, -2.0, f[3]);
+    t2 = axpy(t2, X, 1.0, f[2]);
+    cplx t3 = {-f[4].re, -f[4].im};
+    t3 = axpy(t3, X, 1.0, f[3]);
+    const cplx mixed[6] = {{t0.re * ik3, t0.im * ik3}, {t1.re * ik3, t1.im * ik3}, {t2.re * ik3, t2.im * ik3},
+                           {t3.re * ik3, t3.im * ik3}, {f[4].re * ik3, f[4].im * ik3},
+                           {(f[5].re - EE.re) * ik, (f[5].im - EE.im) * ik}};
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      double2 c0;
+      c0.x = pa.x * mixed[i].re - pa.y * c1[i].x - ex.x * c2[i].x;
+      c0.y = pa.x * mixed[i].im - pa.y * c1[i].y - ex.x * c2[i].y;
+      if (j >= jA) *reinterpret_cast<double2*>(Rg.y[i] + col + j * ld) = c0;
+      c2[i] = c1[i];
+      c1[i] = c0;
+    }
+  };
+  long long j = jS;
+  for (; j + 2 <= jB; j += 2) {
+    double2 y0[6], y1[6], pa0, pa1, ex0, ex1;
+    load(j, y0, pa0, ex0);
+    load(j + 1, y1, pa1, ex1);
+    step(j, y0, pa0, ex0);
+    step(j + 1, y1, pa1, ex1);
+  }
+  for (; j < jB; ++j) {
+    double2 y0[6], pa0, ex0;
+    load(j, y0, pa0, ex0);
+    step(j, y0, pa0, ex0);
+  }
+}
+
+hipError_t launch_abd_mix_forward(hipStream_t stream, const AbdGrids& Y, const AbdGrids& R, long long ld, int n_cols, long long g0,
+                                  long long n_rows, const BsplineForward* table, int tile, int halo, const double* alpha,
+                                  const double* ethk_over_k, const double* eth_alpha, const double* etheth_alpha,
+                                  const double* inv_k, const double* inv_k3) {
+  if (n_rows <= 0 || n_cols <= 0) return hipSuccess;
+  const long long n_tiles = (n_rows + tile - 1) / tile;
+  dim3 grid((n_cols + 63) / 64, (unsigned)n_tiles);
+  hipLaunchKernelGGL(abd_mix_forward_kernel, grid, dim3(64), 0, stream, Y, R, ld, n_cols, g0, n_rows, table, tile, halo, alpha,
+                     ethk_over_k, eth_alpha, etheth_alpha, inv_k, inv_k3);
   return hipGetLastError();
 }
 
