@@ -237,13 +237,16 @@ __global__ __launch_bounds__(256, 3) void zgemm3m_mfma_kernel(const double* __re
   Z_STORE_LDS(0);
   __syncthreads();
 
+  // In the last column panel the right-hand waves (columns 32..63 of the tile) may lie entirely beyond N: they keep
+  // staging and synchronising but leave the matrix pipe to the other workgroups of the CU (cfg3: 1297 = 20 x 64 + 17).
+  const bool wave_has_columns = n0 + wn * 32 < N;
   for (int kt = 0; kt < nk; ++kt) {
     const int buf = kt & 1;
     if (kt + 1 < nk) Z_LOAD_GLOBAL(kt + 1);
     const double2* as = As + buf * Z_ASZ + (wm * 32 + fi) * Z_PA + fk;
     const double2* bs = Bs + buf * Z_BSZ + fk * Z_PB + wn * 32 + fi;
 #pragma unroll
-    for (int kk = 0; kk < Z_KC / 4; ++kk) {
+    for (int kk = 0; wave_has_columns && kk < Z_KC / 4; ++kk) {
       const double2 a0 = as[kk * 4], a1 = as[16 * Z_PA + kk * 4];
       const double2 b0 = bs[kk * 4 * Z_PB], b1 = bs[kk * 4 * Z_PB + 16];
       const double sa0 = a0.x + a0.y, sa1 = a1.x + a1.y, sb0 = b0.x + b0.y, sb1 = b1.x + b1.y;
