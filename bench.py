@@ -384,6 +384,32 @@ def main():
             },
             "kernels": kernels,
         }
+        if not abd:
+            # the HBM-bound stages against the 8 TB/s peak, with the algorithmic bytes of SURVEY 8(d) (grid = the columns
+            # actually stored, n_cols) over the HIP-event kernel times; and the whole transform against the same table
+            n_cols_b = n_pix - 2 * (n_theta - 1) if n_theta <= 40 else n_pix
+            rows_b = rows_in / (world if columns else 1)
+            n_modes_out = n_modes
+
+            def stage(tag, bytes_per_row):
+                ms, calls = timing.get(tag, (0.0, 0))
+                if not calls or ms <= 0:
+                    return None
+                gbs = bytes_per_row * rows_b / (ms / calls * 1e-3) / 1e9  # per launch
+                return {"algorithmic_bytes_per_step": bytes_per_row, "achieved_GBps": gbs, "frac_of_8TBps": gbs / 8000.0}
+
+            total_bytes = 16 * (n_modes + n_cols_b) + 32 * n_cols_b + 16 * (n_cols_b + n_modes_out)
+            line["hbm_stages"] = {
+                "spline_back_substitution": stage("spline_backward", 32 * n_cols_b),
+                "analysis": stage("analysis_fused", 16 * (n_cols_b + n_modes_out)),
+                "spline_elimination_on_modes": stage("spline_forward", 32 * (n_modes + 1)),
+                "whole_transform_materialised_grid": {
+                    "algorithmic_bytes_per_step": total_bytes,
+                    "achieved_GBps": total_bytes * (n_global / world) / (ms_per_step * 1e-3) / 1e9,
+                    "frac_of_8TBps": total_bytes * (n_global / world) / (ms_per_step * 1e-3) / 8e12,
+                },
+                "ideal_fusion_bytes_per_step": 2 * (16 * n_modes + 8),
+            }
         if world == 1 and args.cpu_sample > 0 and not abd:
             line["cpu_baseline"] = cpu_baseline(spec, args.cpu_sample)
             line["cpu_baseline_all_cores"] = cpu_baseline_all_cores(spec, args.cpu_sample)
