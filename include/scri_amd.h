@@ -162,6 +162,13 @@ int bms_transform_modes_shard(bms_ctx* ctx, const bms_wm_input* in, const bms_tr
                               const bms_shard* shard, double* t_out, void* data_out, int64_t* n_times_out,
                               int64_t* first_index_out);
 
+/* ---- page-locked host memory -----------------------------------------------------------------------------
+ * Results that go back to host arrays (mem = BMS_HOST) cross PCIe at full rate only into page-locked memory; a caller
+ * that lets the library allocate its result arrays gets that without a staging copy (scri_amd/_lib.py: pinned_empty).
+ * NULL on failure. */
+void* bms_host_alloc(uint64_t bytes);
+void bms_host_free(void* p);
+
 /* ---- BMS transformation of AsymptoticBondiData ---------------------------------------------------------
  * replaces AsymptoticBondiData.transform (scri/asymptotic_bondi_data/transformations.py:199-431) after
  * _process_transformation_kwargs (:8-97).  raw: c16[6][n_times][(ell_max+1)^2] = psi0..psi4, sigma

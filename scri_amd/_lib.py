@@ -79,6 +79,8 @@ SIGNATURES = {
         c_int,
         [c_vp, c_dp, c_i64, ctypes.POINTER(bms_transformation), c_i64, c_i64, ctypes.POINTER(c_i64), ctypes.POINTER(c_i64)],
     ),
+    "bms_host_alloc": (c_vp, [ctypes.c_uint64]),
+    "bms_host_free": (None, [c_vp]),
     "bms_output_window": (c_int, [c_vp, c_dp, c_i64, ctypes.POINTER(bms_transformation), c_int, ctypes.POINTER(c_i64)]),
     "bms_transform_modes_shard": (
         c_int,
@@ -166,6 +168,57 @@ def load():
                 fn.argtypes = args
             _lib = lib
     return _lib
+
+
+class _PinnedBlock:
+    """A page-locked host allocation that numpy arrays can sit on (their .base keeps it alive).  Freed blocks of the sizes
+    in recent use are kept for the next result of that size: pinning hundreds of MB costs as much as copying them."""
+
+    _pool = {}  # nbytes -> [ptr, ...]
+    _pool_lock = threading.RLock()  # re-entrant: a collection inside the critical section may finalise another block
+    _pooled_bytes = 0
+    POOL_LIMIT = 8 << 30
+
+    def __init__(self, nbytes):
+        self.nbytes = int(nbytes)
+        with _PinnedBlock._pool_lock:
+            free = _PinnedBlock._pool.get(self.nbytes)
+            self.ptr = free.pop() if free else None
+            if self.ptr is not None:
+                _PinnedBlock._pooled_bytes -= self.nbytes
+        if self.ptr is None:
+            self.ptr = load().bms_host_alloc(self.nbytes)
+        if not self.ptr:
+            raise MemoryError("page-locked allocation failed")
+        self.__array_interface__ = {"data": (int(self.ptr), False), "shape": (self.nbytes,), "typestr": "|u1", "version": 3}
+
+    def __del__(self):
+        ptr, self.ptr = getattr(self, "ptr", None), None
+        if not ptr:
+            return
+        try:
+            with _PinnedBlock._pool_lock:
+                if _PinnedBlock._pooled_bytes + self.nbytes <= _PinnedBlock.POOL_LIMIT:
+                    _PinnedBlock._pool.setdefault(self.nbytes, []).append(ptr)
+                    _PinnedBlock._pooled_bytes += self.nbytes
+                    return
+            load().bms_host_free(ptr)
+        except Exception:  # interpreter shutdown
+            pass
+
+
+def pinned_empty(shape, dtype):
+    """np.empty(shape, dtype) in page-locked host memory (device-to-host copies land there at PCIe rate); falls back to
+    ordinary memory for small arrays or when pinning fails."""
+    dtype = np.dtype(dtype)
+    nbytes = int(np.prod(shape, dtype=np.int64)) * dtype.itemsize
+    if nbytes < (1 << 20) or os.environ.get("SCRI_AMD_NO_PINNED"):
+        return np.empty(shape, dtype=dtype)
+    try:
+        block = _PinnedBlock(nbytes)
+    except (MemoryError, OSError):
+        return np.empty(shape, dtype=dtype)
+    return np.asarray(block).view(dtype).reshape(shape)
 
 
 def _raise(code, ctx, what):

@@ -231,6 +231,15 @@ extern "C" void bms_ctx_destroy(bms_ctx* c) {
 
 extern "C" const char* bms_last_error(const bms_ctx* c) { return c ? c->err.c_str() : g_create_error.c_str(); }
 
+extern "C" void* bms_host_alloc(uint64_t bytes) {
+  void* p = nullptr;
+  if (bytes == 0 || hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) return nullptr;
+  return p;
+}
+extern "C" void bms_host_free(void* p) {
+  if (p) (void)hipHostFree(p);
+}
+
 extern "C" int bms_ctx_set_stream(bms_ctx* c, void* s) {
   if (!c) return BMS_ERR_INVALID;
   c->stream = s ? (hipStream_t)s : c->own_stream;

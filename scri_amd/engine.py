@@ -194,7 +194,7 @@ def transform_modes(
         ctx.check(rc, "bms_transform_modes")
         res = (t_out[: n_new.value], n_new.value)
         return res + (first.value,) if shard is not None else res
-    out = np.empty((max(n_alloc, 1), n_out), dtype=np.complex128)
+    out = _lib.pinned_empty((max(n_alloc, 1), n_out), np.complex128)
     rc = _lib.load().bms_transform_modes_shard(
         ctx.handle, ctypes.byref(inp), ctypes.byref(transformation), shp, dptr(t_out), vptr(out), ctypes.byref(n_new),
         ctypes.byref(first),
@@ -266,7 +266,7 @@ def transform_abd(u, raw, ell_max, transformation, ctx=None, shard=None, device=
         shp = ctypes.byref(sh)
         fs_out = i_hi - i_lo
         u_out = np.empty(max(fs_out, 1), dtype=float)
-    out = np.empty((6, max(fs_out, 1), n_out), dtype=np.complex128)
+    out = _lib.pinned_empty((6, max(fs_out, 1), n_out), np.complex128)
     rc = _lib.load().bms_transform_abd_shard(
         ctx.handle, dptr(u), vptr(raw), BMS_HOST, n, int(ell_max), ctypes.byref(transformation), shp, dptr(u_out), vptr(out),
         ctypes.byref(n_new), ctypes.byref(first),
