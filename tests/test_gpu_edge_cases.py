@@ -214,3 +214,23 @@ def test_bspline_path_on_short_and_irregular_time_axes(ctx, n, mesh):
     assert got.t.size == expect.t.size and got.t.size > 0
     assert np.abs(got.t - expect.t).max() < 1e-13 * max(1.0, np.abs(t).max())
     assert np.abs(got.data - expect.data).max() < 2e-12 * max(1.0, np.abs(expect.data).max())
+
+
+def test_pinned_result_arrays(ctx):
+    """Results of host-mode transformations sit on page-locked memory owned by the array (freed blocks are reused for the
+    next result of the same size); they behave like any numpy array."""
+    from scri_amd import _lib
+
+    a = _lib.pinned_empty((1 << 17, 2), np.complex128)  # 4 MiB
+    assert a.flags.c_contiguous and a.flags.writeable and a.dtype == np.complex128
+    a[:] = 1 + 2j
+    assert a.sum() == (1 + 2j) * a.size
+    where = a.ctypes.data
+    view = a[10:20]  # keeps the block alive through .base
+    del a
+    assert view[0, 0] == 1 + 2j
+    del view
+    b = _lib.pinned_empty((1 << 17, 2), np.complex128)
+    assert b.ctypes.data == where  # the freed block came back from the pool
+    small = _lib.pinned_empty((8,), float)  # small arrays: ordinary memory
+    assert small.base is None
