@@ -852,12 +852,34 @@ static void time_window(int64_t n, const bms_shard* sh, int64_t& lo, int64_t& hi
   }
 }
 
-static int validate_common(bms_ctx* c, int64_t n, const double* t, const bms_transformation* tr, int64_t lo = 0, int64_t hi = -1) {
+// `regular` (optional): whether the tiled spline recurrences may be trusted on this time axis.  Their truncated starts
+// rely on the factors of the spline systems decaying over a 32-knot halo; that holds for any mesh whose steps do not
+// grow or shrink geometrically over many knots in a row (a sudden jump of any size is harmless), and fails for sustained
+// grading: a ratio of 1.3 per step over 33 knots (steps varying 4e3-fold inside the halo) costs 5e-14, 1.4 already 2e-12,
+// 2.0 1e-5.  Criterion: steps within any 48 consecutive knots vary by at most 1e3 (then <= 1e-14); otherwise the caller
+// runs the exact single-tile recurrences of the slope form.
+static int validate_common(bms_ctx* c, int64_t n, const double* t, const bms_transformation* tr, int64_t lo = 0, int64_t hi = -1,
+                           bool* regular = nullptr) {
   if (n < 4) return fail(c, BMS_ERR_INVALID, "need at least 4 time steps for the cubic spline, got %lld", (long long)n);
   if (hi < 0) hi = n;
   if (!(t[n - 1] > t[0])) return fail(c, BMS_ERR_INVALID, "time array must be strictly increasing (first/last)");
-  for (int64_t i = std::max<int64_t>(lo, 0) + 1; i < hi; ++i)
-    if (!(t[i] > t[i - 1])) return fail(c, BMS_ERR_INVALID, "time array must be strictly increasing (index %lld)", (long long)i);
+  double bmin[3] = {INFINITY, INFINITY, INFINITY}, bmax[3] = {0.0, 0.0, 0.0};  // step range of the last three 16-step blocks
+  bool reg = true;
+  int64_t in_block = 0;
+  for (int64_t i = std::max<int64_t>(lo, 0) + 1; i < hi; ++i) {
+    const double h = t[i] - t[i - 1];
+    if (!(h > 0)) return fail(c, BMS_ERR_INVALID, "time array must be strictly increasing (index %lld)", (long long)i);
+    bmin[2] = std::min(bmin[2], h);
+    bmax[2] = std::max(bmax[2], h);
+    if (++in_block == 16 || i == hi - 1) {
+      const double mn = std::min(bmin[0], std::min(bmin[1], bmin[2])), mx = std::max(bmax[0], std::max(bmax[1], bmax[2]));
+      if (mx > 1e3 * mn) reg = false;
+      bmin[0] = bmin[1], bmin[1] = bmin[2], bmin[2] = INFINITY;
+      bmax[0] = bmax[1], bmax[1] = bmax[2], bmax[2] = 0.0;
+      in_block = 0;
+    }
+  }
+  if (regular) *regular = reg || getenv("SCRI_AMD_ASSUME_REGULAR_MESH") != nullptr;  // (the switch exists to show what the guard prevents)
   if (tr->n_theta < 2 || tr->n_phi < 1) return fail(c, BMS_ERR_INVALID, "bad grid size %d x %d", tr->n_theta, tr->n_phi);
   if (tr->ell_max_supertranslation < 1 || !tr->supertranslation) return fail(c, BMS_ERR_INVALID, "supertranslation must hold at least l <= 1");
   const double* v = tr->boost_velocity;
@@ -1050,7 +1072,8 @@ extern "C" int bms_transform_modes_shard(bms_ctx* c, const bms_wm_input* in, con
   const int64_t n = in->n_times;
   int64_t t_lo, t_hi;
   time_window(n, sh, t_lo, t_hi);
-  int rc = validate_common(c, n, in->t, tr, t_lo, t_hi);
+  bool regular_mesh = true;
+  int rc = validate_common(c, n, in->t, tr, t_lo, t_hi, &regular_mesh);
   if (rc) return rc;
   const int s = in->spin_weight;
   if (in->ell_min < 0 || in->ell_max < in->ell_min) return fail(c, BMS_ERR_INVALID, "bad ell range");
@@ -1114,8 +1137,12 @@ extern "C" int bms_transform_modes_shard(bms_ctx* c, const bms_wm_input* in, con
   // Without psi mixing the map modes -> grid values is linear along the columns with time-independent coefficients, so
   // the spline's forward elimination is done on the modes (B-spline form, kernels_bspline.hip) and the grid is passed over
   // once, by the back substitution + evaluation.
-  const bool bsg = n >= 8 && !getenv("SCRI_AMD_NO_BSPLINE");  // B-spline form at all (else: the slope form, kernels_spline.hip)
-  const bool bs = bsg && !psi;                                 // ... with the elimination commuted onto the modes
+  const bool bsg = n >= 8 && regular_mesh && !getenv("SCRI_AMD_NO_BSPLINE");  // B-spline form (else: the slope form, kernels_spline.hip)
+  const bool bs = bsg && !psi;                                                 // ... with the elimination commuted onto the modes
+  if (!regular_mesh && (sh != nullptr))
+    return fail(c, BMS_ERR_UNSUPPORTED,
+                "the time steps vary by more than 1e3 within 48 samples: such a series is transformed with exact untiled spline "
+                "recurrences, which a time shard cannot provide");
   // Everything that depends on the time axis and the input modes only goes to the main stream first; the per-direction
   // tables, whose window the host has to wait for, are computed beside it on the auxiliary stream.
   struct DrainOnExit {  // whatever path leaves this call, nothing enqueued here still reads the caller's buffers
@@ -1235,11 +1262,15 @@ extern "C" int bms_transform_modes_shard(bms_ctx* c, const bms_wm_input* in, con
   const double bytes_per_row = (4.0 + (psi ? 1.0 : 0.0)) * ldg * 8.0;  // Y, R, G, F (+ Yaux)
   int64_t chunk = (int64_t)std::max(1024.0, (double)c->ws_limit / bytes_per_row - 4.0 * margin);
   chunk = std::min<int64_t>(chunk, n_new);
+  if (!regular_mesh && chunk < n_new)
+    return fail(c, BMS_ERR_UNSUPPORTED, "irregular time axis (steps vary by more than 1e3 within 48 samples): the series does not fit the work space in one piece");
+  const int spline_tile = regular_mesh ? SPLINE_TILE : (int)std::min<int64_t>(n + 1, 0x7fffffff);  // one tile: exact recurrences
   for (int64_t c0 = i_lo; c0 < i_hi; c0 += chunk) {
     const int64_t c1 = std::min<int64_t>(c0 + chunk, i_hi);
     int64_t ja, jb;
     needed_knots(T, in->t, n, c0, c1, ja, jb);
-    const int64_t g0 = std::max<int64_t>(0, ja - margin), g1 = std::min<int64_t>(n, jb + margin + 1);
+    // (irregular time axis: the whole series, so that the single-tile recurrences start and end at the true ends)
+    const int64_t g0 = regular_mesh ? std::max<int64_t>(0, ja - margin) : 0, g1 = regular_mesh ? std::min<int64_t>(n, jb + margin + 1) : n;
     const int64_t rows_in = g1 - g0, rows_out = c1 - c0;
     if (g0 < row0 || g1 > row0 + rows_avail)
       return fail(c, BMS_ERR_INVALID,
@@ -1278,8 +1309,8 @@ extern "C" int bms_transform_modes_shard(bms_ctx* c, const bms_wm_input* in, con
       TIMED(c, BMS_TAG_SPLINE_BACKWARD, launch_bspline_backward_eval(S, d_R, ldg, n_pix, g0, rows_in, n, d_x, d_bstab, SPLINE_TILE, SPLINE_HALO, d_x, d_skewa,
                                                                      d_skewb, T.tt, c0, c1, d_G, P2));
     } else {
-    TIMED(c, BMS_TAG_SPLINE_FORWARD, launch_spline_forward(S, d_Y, d_R, ldg, n_pix, g0, rows_in, n, d_x, d_tab, SPLINE_TILE, SPLINE_HALO));
-    TIMED(c, BMS_TAG_SPLINE_BACKWARD, launch_spline_backward_eval(S, d_Y, d_R, ldg, n_pix, g0, rows_in, n, d_x, d_tab, SPLINE_TILE, SPLINE_HALO,
+    TIMED(c, BMS_TAG_SPLINE_FORWARD, launch_spline_forward(S, d_Y, d_R, ldg, n_pix, g0, rows_in, n, d_x, d_tab, spline_tile, SPLINE_HALO));
+    TIMED(c, BMS_TAG_SPLINE_BACKWARD, launch_spline_backward_eval(S, d_Y, d_R, ldg, n_pix, g0, rows_in, n, d_x, d_tab, spline_tile, SPLINE_HALO,
                                            d_x, d_skewa, d_skewb, T.tt, c0, c1, d_G, P2));
     }
     }
@@ -1757,8 +1788,13 @@ extern "C" int bms_transform_abd_shard(bms_ctx* c, const double* u, const void* 
   const int64_t n = n_times;
   int64_t t_lo, t_hi;
   time_window(n, sh, t_lo, t_hi);
-  int rc = validate_common(c, n, u, tr, t_lo, t_hi);
+  bool regular_mesh = true;
+  int rc = validate_common(c, n, u, tr, t_lo, t_hi, &regular_mesh);
   if (rc) return rc;
+  if (!regular_mesh && sh)
+    return fail(c, BMS_ERR_UNSUPPORTED,
+                "the time steps vary by more than 1e3 within 48 samples: such a series is transformed with exact untiled spline "
+                "recurrences, which a time shard cannot provide");
   if (ell_max < 0 || tr->ell_max_out < 0) return fail(c, BMS_ERR_INVALID, "bad ell_max");
   static const int spins[6] = {2, 1, 0, -1, -2, 2};  // psi0..psi4, sigma
   const int nm = (ell_max + 1) * (ell_max + 1);
@@ -1813,7 +1849,7 @@ extern "C" int bms_transform_abd_shard(bms_ctx* c, const double* u, const void* 
   double* d_x;
   // the Horner mixing has time-dependent coefficients, so the elimination stays on the grid; the B-spline form still saves
   // the back substitution its second input stream (kernels_bspline.hip)
-  const bool bsg = n >= 8 && !getenv("SCRI_AMD_NO_BSPLINE");
+  const bool bsg = n >= 8 && regular_mesh && !getenv("SCRI_AMD_NO_BSPLINE");
   SplineTable* d_tab = nullptr;
   BsplineTable* d_bstab = nullptr;
   BsplineForward* d_bsfwd = nullptr;
@@ -1866,11 +1902,14 @@ extern "C" int bms_transform_abd_shard(bms_ctx* c, const double* u, const void* 
   const double bytes_per_row = 19.0 * ldg * 8.0;  // 6 x (Y, R, G) + F
   int64_t chunk = (int64_t)std::max(256.0, (double)c->ws_limit / bytes_per_row - 4.0 * margin);
   chunk = std::min<int64_t>(chunk, n_new);
+  if (!regular_mesh && chunk < n_new)
+    return fail(c, BMS_ERR_UNSUPPORTED, "irregular time axis (steps vary by more than 1e3 within 48 samples): the series does not fit the work space in one piece");
+  const int spline_tile = regular_mesh ? SPLINE_TILE : (int)std::min<int64_t>(n + 1, 0x7fffffff);  // one tile: exact recurrences
   for (int64_t c0 = i_lo; c0 < i_hi; c0 += chunk) {
     const int64_t c1_ = std::min<int64_t>(c0 + chunk, i_hi);
     int64_t ja, jb;
     needed_knots(T, u, n, c0, c1_, ja, jb);
-    const int64_t g0 = std::max<int64_t>(0, ja - margin), g1 = std::min<int64_t>(n, jb + margin + 1);
+    const int64_t g0 = regular_mesh ? std::max<int64_t>(0, ja - margin) : 0, g1 = regular_mesh ? std::min<int64_t>(n, jb + margin + 1) : n;
     const int64_t rows_in = g1 - g0, rows_out = c1_ - c0;
     if (g0 < row0 || g1 > row0 + rows_avail)
       return fail(c, BMS_ERR_INVALID,
@@ -1905,9 +1944,9 @@ extern "C" int bms_transform_abd_shard(bms_ctx* c, const double* u, const void* 
                                                                        d_x, d_skewa, d_skewb, T.tt, c0, c1_, Gf, P2));
       } else {
         TIMED(c, BMS_TAG_SPLINE_FORWARD,
-              launch_spline_forward(S, grids.y[f], Rf, ldg, n_pix, g0, rows_in, n, d_x, d_tab, SPLINE_TILE, SPLINE_HALO));
+              launch_spline_forward(S, grids.y[f], Rf, ldg, n_pix, g0, rows_in, n, d_x, d_tab, spline_tile, SPLINE_HALO));
         TIMED(c, BMS_TAG_SPLINE_BACKWARD,
-              launch_spline_backward_eval(S, grids.y[f], Rf, ldg, n_pix, g0, rows_in, n, d_x, d_tab, SPLINE_TILE, SPLINE_HALO,
+              launch_spline_backward_eval(S, grids.y[f], Rf, ldg, n_pix, g0, rows_in, n, d_x, d_tab, spline_tile, SPLINE_HALO,
                                           d_x, d_skewa, d_skewb, T.tt, c0, c1_, Gf, P2));
       }
       double* out_f = d_out + ((size_t)f * fs_out + (c0 - i_lo)) * n_out * 2;

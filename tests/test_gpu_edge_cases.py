@@ -234,3 +234,34 @@ def test_pinned_result_arrays(ctx):
     assert b.ctypes.data == where  # the freed block came back from the pool
     small = _lib.pinned_empty((8,), float)  # small arrays: ordinary memory
     assert small.base is None
+
+
+@pytest.mark.parametrize("ratio", [1.5, 2.0, 1 / 1.7])
+def test_geometrically_graded_time_axis_takes_the_exact_path(ctx, ratio):
+    """Steps that grow (or shrink) geometrically over dozens of samples defeat the decay the tiled spline recurrences rely
+    on (ratio 2 per step: 1e-5 with a 32-knot halo).  The engine detects such an axis (steps varying more than 1e3-fold
+    within 48 samples) and runs the exact single-tile recurrences instead; a time shard of it is refused."""
+    import scri_amd
+    from oracle import waveform_grid_ref as grid_ref
+    from oracle.containers import WM, h
+    from scri_amd import engine
+
+    rng = np.random.default_rng(17)
+    n, ell_max = 700, 3  # the graded stretch straddles the boundary of the first 320-knot tile
+    dt = np.concatenate([np.full(300, 1.0), ratio ** np.arange(1, 41), np.full(360, ratio**40)])
+    dt /= dt.mean()
+    t = np.cumsum(dt)
+    nm = (ell_max + 1) ** 2 - 4
+    phase = np.outer(np.log(t + 1.0), rng.uniform(0.5, 3.0, size=nm))
+    data = (np.sin(phase) + 1j * np.cos(phase)) * rng.normal(size=nm)
+    st = np.zeros(9, dtype=complex)
+    st[0], st[2], st[6] = 0.05, 0.02, -0.01
+    kw = dict(supertranslation=st, boost_velocity=np.array([0.01, -0.02, 0.015]))
+    expect = grid_ref.transform(WM(t=t, data=data, ell_min=2, ell_max=ell_max, dataType=h), **kw)
+    got = scri_amd.WaveformModes(t=t, data=data, ell_min=2, ell_max=ell_max, dataType=scri_amd.h, frameType=scri_amd.Inertial,
+                                r_is_scaled_out=True, m_is_scaled_out=True, ctx=ctx).transform(**kw)
+    assert got.t.size == expect.t.size and got.t.size > 100
+    assert np.abs(got.data - expect.data).max() < 2e-12 * max(1.0, np.abs(expect.data).max())
+    tr = engine.make_transformation(st, [1, 0, 0, 0], kw["boost_velocity"], 11, 11, ell_max)
+    with pytest.raises(NotImplementedError, match="time steps vary"):
+        engine.transform_modes(t, data, 2, ell_max, -2, -1, engine.BMS_TERM_H, tr, ctx=ctx, shard=(0, n, 0, n))
