@@ -858,6 +858,9 @@ static void time_window(int64_t n, const bms_shard* sh, int64_t& lo, int64_t& hi
 // grading: a ratio of 1.3 per step over 33 knots (steps varying 4e3-fold inside the halo) costs 5e-14, 1.4 already 2e-12,
 // 2.0 1e-5.  Criterion: steps within any 48 consecutive knots vary by at most 1e3 (then <= 1e-14); otherwise the caller
 // runs the exact single-tile recurrences of the slope form.
+// spline tile for the whole-series building blocks (slope form): one tile = exact recurrences on an irregular axis
+static int spline_tile_for(const double* x, int64_t n);
+
 static int validate_common(bms_ctx* c, int64_t n, const double* t, const bms_transformation* tr, int64_t lo = 0, int64_t hi = -1,
                            bool* regular = nullptr) {
   if (n < 4) return fail(c, BMS_ERR_INVALID, "need at least 4 time steps for the cubic spline, got %lld", (long long)n);
@@ -887,6 +890,24 @@ static int validate_common(bms_ctx* c, int64_t n, const double* t, const bms_tra
   return BMS_OK;
 }
 
+
+static int spline_tile_for(const double* x, int64_t n) {
+  double bmin[3] = {INFINITY, INFINITY, INFINITY}, bmax[3] = {0.0, 0.0, 0.0};
+  int64_t in_block = 0;
+  for (int64_t i = 1; i < n; ++i) {
+    const double h = x[i] - x[i - 1];
+    bmin[2] = std::min(bmin[2], h);
+    bmax[2] = std::max(bmax[2], h);
+    if (++in_block == 16 || i == n - 1) {
+      const double mn = std::min(bmin[0], std::min(bmin[1], bmin[2])), mx = std::max(bmax[0], std::max(bmax[1], bmax[2]));
+      if (mx > 1e3 * mn && !getenv("SCRI_AMD_ASSUME_REGULAR_MESH")) return (int)std::min<int64_t>(n + 1, 0x7fffffff);
+      bmin[0] = bmin[1], bmin[1] = bmin[2], bmin[2] = INFINITY;
+      bmax[0] = bmax[1], bmax[1] = bmax[2], bmax[2] = 0.0;
+      in_block = 0;
+    }
+  }
+  return SPLINE_TILE;
+}
 
 // Per-pixel tables on the GPU.  `coef0/coef1` (host, (lst+1)^2 complex each, may be null) are uploaded next to the
 // supertranslation modes; the four scalars the host needs for the output window and the chunk plan come back in T.
@@ -1424,8 +1445,9 @@ extern "C" int bms_cubic_spline(bms_ctx* c, const double* x, int64_t n, const vo
   double* d_out = (double*)out;
   if (mem == BMS_HOST)
     if ((rc = dev_buf_t(c, "out_data", (size_t)n_new * n_cols * 2, &d_out))) return rc;
-  TIMED(c, BMS_TAG_SPLINE_FORWARD, launch_spline_forward(c->stream, d_y, d_R, 2 * ld, (int)n_cols, 0, n, n, (const double*)d_x, d_tab, SPLINE_TILE, SPLINE_HALO));
-  TIMED(c, BMS_TAG_SPLINE_BACKWARD, launch_spline_backward_eval(c->stream, d_y, d_R, 2 * ld, (int)n_cols, 0, n, n, (const double*)d_x, d_tab, SPLINE_TILE,
+  const int tile = spline_tile_for(x, n);
+  TIMED(c, BMS_TAG_SPLINE_FORWARD, launch_spline_forward(c->stream, d_y, d_R, 2 * ld, (int)n_cols, 0, n, n, (const double*)d_x, d_tab, tile, SPLINE_HALO));
+  TIMED(c, BMS_TAG_SPLINE_BACKWARD, launch_spline_backward_eval(c->stream, d_y, d_R, 2 * ld, (int)n_cols, 0, n, n, (const double*)d_x, d_tab, tile,
                                          SPLINE_HALO, (const double*)d_xn, nullptr, nullptr, 0.0, 0, n_new, d_out, 2 * n_cols));
   if (mem == BMS_HOST) HIP_TRY(c, hipMemcpyAsync(out, d_out, (size_t)n_new * n_cols * 16, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -1456,8 +1478,9 @@ extern "C" int bms_spline_derivative(bms_ctx* c, const double* x, int64_t n, con
   if ((rc = dev_buf_t(c, "R", (size_t)n * ld * 2, &d_R))) return rc;
   if ((rc = dev_buf_t(c, "S", (size_t)n * ld * 2, &d_S))) return rc;
   hipStream_t S = c->stream;
-  TIMED(c, BMS_TAG_SPLINE_FORWARD, launch_spline_forward(S, d_y, d_R, 2 * ld, (int)n_cols, 0, n, n, d_x, d_tab, SPLINE_TILE, SPLINE_HALO));
-  TIMED(c, BMS_TAG_SPLINE_BACKWARD, launch_spline_slopes(S, d_R, d_S, 2 * ld, (int)n_cols, n, d_tab, SPLINE_TILE, SPLINE_HALO));
+  const int tile = spline_tile_for(x, n);
+  TIMED(c, BMS_TAG_SPLINE_FORWARD, launch_spline_forward(S, d_y, d_R, 2 * ld, (int)n_cols, 0, n, n, d_x, d_tab, tile, SPLINE_HALO));
+  TIMED(c, BMS_TAG_SPLINE_BACKWARD, launch_spline_slopes(S, d_R, d_S, 2 * ld, (int)n_cols, n, d_tab, tile, SPLINE_HALO));
   if (order < 0) {
     if ((rc = dev_buf_t(c, "P1", (size_t)n * ld * 2, &d_P1))) return rc;
     if (order < -1)
@@ -1498,8 +1521,9 @@ extern "C" int bms_angular_velocity(bms_ctx* c, const double* t, int64_t n, cons
   if ((rc = dev_buf_t(c, "S", (size_t)n * ld * 2, &d_S))) return rc;
   if ((rc = dev_buf_t(c, "av_out", (size_t)n * 15, &d_res))) return rc;
   hipStream_t S = c->stream;
-  TIMED(c, BMS_TAG_SPLINE_FORWARD, launch_spline_forward(S, d_y, d_R, 2 * ld, n_modes, 0, n, n, d_x, d_tab, SPLINE_TILE, SPLINE_HALO));
-  TIMED(c, BMS_TAG_SPLINE_BACKWARD, launch_spline_slopes(S, d_R, d_S, 2 * ld, n_modes, n, d_tab, SPLINE_TILE, SPLINE_HALO));
+  const int tile = spline_tile_for(t, n);
+  TIMED(c, BMS_TAG_SPLINE_FORWARD, launch_spline_forward(S, d_y, d_R, 2 * ld, n_modes, 0, n, n, d_x, d_tab, tile, SPLINE_HALO));
+  TIMED(c, BMS_TAG_SPLINE_BACKWARD, launch_spline_slopes(S, d_R, d_S, 2 * ld, n_modes, n, d_tab, tile, SPLINE_HALO));
   double *d_ldt = d_res, *d_ll = d_res + 3 * n, *d_om = d_res + 12 * n;
   TIMED(c, BMS_TAG_POINTWISE, launch_angular_velocity(S, d_y, d_S, 2 * ld, n, ell_min, n_modes, d_ldt, d_ll, d_om));
   if (ldt_out) HIP_TRY(c, hipMemcpyAsync(ldt_out, d_ldt, sizeof(double) * 3 * n, hipMemcpyDeviceToHost, S));
