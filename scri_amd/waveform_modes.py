@@ -121,6 +121,124 @@ class WaveformModes:
     def copy(self):
         return type(self)(self)
 
+    # ---- container conveniences (waveform_modes.py:385-455, waveform_base.py:520-575, :917-948, waveform_modes.py:953-1021)
+    @property
+    def ells(self):
+        """(ell_min, ell_max)"""
+        return self.ell_min, self.ell_max
+
+    @ells.setter
+    def ells(self, new_ells):
+        self.ell_min, self.ell_max = int(new_ells[0]), int(new_ells[1])
+        if self.n_modes != LM_total_size(self.ell_min, self.ell_max):
+            import warnings
+
+            warnings.warn(
+                f"\nWaveform's data.shape={self.data.shape} does not agree with "
+                f"(ell_min,ell_max)=({self.ell_min},{self.ell_max}).\n"
+                "Hopefully you are about to reset `data`.  To avoid this warning,\n"
+                "reset `data` before resetting ell_min and/or ell_max."
+            )
+
+    def index(self, ell, m):
+        """Index of the (ell, m) mode in the data"""
+        return ell * (ell + 1) - self.ell_min**2 + m
+
+    def indices(self, ell_m):
+        """Indices of the given (ell, m) modes, an N x 2 integer array, in the data"""
+        ell_m = np.asarray(ell_m)
+        if not (ell_m.dtype.kind == "i" and ell_m.ndim == 2 and ell_m.shape[1] == 2):
+            raise ValueError("Input `ell_m` should be an Nx2 sequence of integers")
+        return ell_m[:, 0] * (ell_m[:, 0] + 1) - self.ell_min**2 + ell_m[:, 1]
+
+    @property
+    def n_data_sets(self):
+        return int(np.prod(self.data.shape[1:]))
+
+    @property
+    def data_2d(self):
+        return self.data.reshape((self.n_times, self.n_data_sets))
+
+    @property
+    def abs(self):
+        return np.abs(self.data)
+
+    @property
+    def arg(self):
+        return np.angle(self.data)
+
+    @property
+    def arg_unwrapped(self):
+        return np.unwrap(np.angle(self.data), axis=0)
+
+    def norm(self, take_sqrt=False, indices=slice(None, None, None)):
+        """L2 norm of the waveform at each time: sum over modes of |data|^2 (its square root with take_sqrt), optionally on
+        a slice of the times"""
+        n = np.sum(np.abs(self.data_2d[indices]) ** 2, axis=-1)
+        return np.sqrt(n) if take_sqrt else n
+
+    def max_norm_index(self, skip_fraction_of_data=4):
+        """Index of the time step with the largest norm, searching only the last (1 - 1/skip) of the data (0 or 1: all)"""
+        if skip_fraction_of_data == 0 or skip_fraction_of_data == 1:
+            return int(np.argmax(self.norm()))
+        first = self.n_times // skip_fraction_of_data
+        return int(np.argmax(self.norm(indices=slice(first, None, None)))) + first
+
+    def max_norm_time(self, skip_fraction_of_data=4):
+        return self.t[self.max_norm_index(skip_fraction_of_data=skip_fraction_of_data)]
+
+    def __getitem__(self, key):
+        """w[times], w[times, ells]: the second index selects a contiguous range of ell values (or one ell), not data
+        columns -- scri/waveform_modes.py:953-1021."""
+        if isinstance(key, tuple) and len(key) == 1:
+            key = key[0]
+        new_ells = self.ells
+        if isinstance(key, tuple) and len(key) == 2:
+            k1 = key[1]
+            if isinstance(k1, (int, np.integer)):
+                if k1 < self.ell_min or k1 > self.ell_max:
+                    raise ValueError(
+                        "Requested ell value {} lies outside ".format(k1)
+                        + f"WaveformModes object's ell range ({self.ell_min},{self.ell_max})."
+                    )
+                new_ells = (int(k1), int(k1))
+            elif isinstance(k1, slice):
+                if k1.step and k1.step != 1:
+                    raise ValueError("Can only slice WaveformModes over contiguous ell values (step={})".format(k1.step))
+                if not k1.start and k1.stop == 0:
+                    new_ells = (0, -1)
+                else:
+                    lo = self.ell_min if not k1.start else k1.start
+                    hi = self.ell_max if not k1.stop else k1.stop - 1
+                    if lo < self.ell_min or hi > self.ell_max:
+                        raise ValueError(
+                            f"Requested ell range [{lo},{hi}] lies outside "
+                            + f"WaveformBase's ell range [{self.ell_min},{self.ell_max}]."
+                        )
+                    new_ells = (lo, hi)
+            else:
+                raise ValueError("Don't know what to do with slice of type `{}`".format(type(k1)))
+            if new_ells == (0, -1):
+                cols = slice(0)
+            else:
+                cols = slice(new_ells[0] ** 2 - self.ell_min**2, new_ells[1] * (new_ells[1] + 2) + 1 - self.ell_min**2)
+            tkey = key[0]
+        elif isinstance(key, (slice, int, np.integer)):
+            cols, tkey = slice(None), key
+        else:
+            raise ValueError("Could not understand input `{}` (of type `{}`) ".format(key, type(key)))
+        if isinstance(tkey, (int, np.integer)):
+            tkey = slice(tkey, tkey + 1 if tkey != -1 else None)
+        W = type(self)(
+            t=self.t[tkey], data=self.data[tkey, cols], ell_min=new_ells[0], ell_max=new_ells[1],
+            frame=self.frame[tkey] if self.frame.shape[0] == self.n_times else self.frame, frameType=self.frameType,
+            dataType=self.dataType, r_is_scaled_out=self.r_is_scaled_out, m_is_scaled_out=self.m_is_scaled_out,
+            history=list(self.history), ctx=self._ctx,
+        )
+        W.history.pop()  # the constructor's line, replaced by the slicing statement
+        W._append_history(f"{W} = {self}[{key}]")
+        return W
+
     def copy_without_data(self):
         W = type(self)(
             t=np.empty((0,)), data=np.empty((0, self.n_modes), dtype=complex), ell_min=self.ell_min, ell_max=self.ell_max,

@@ -1,0 +1,100 @@
+"""Container behaviour of WaveformModes that the path's callers rely on (slicing by times and ell ranges, mode indices,
+norms): the reference's tests/test_waveform.py:76-181 on the same linear-in-time waveform (host logic only)."""
+import numpy as np
+import pytest
+
+
+def linear_waveform(begin=-10.0, end=100.0, n_times=1000, ell_min=2, ell_max=8):
+    """tests/conftest.py:82-106 of the reference: mode (l, m) = (m - i m) t, in a rotating frame"""
+    import scri_amd
+
+    rng = np.random.default_rng(1234)
+    axis = rng.uniform(-1, 1, size=3)
+    axis /= np.linalg.norm(axis)
+    t = np.linspace(begin, end, num=n_times)
+    omega = 2 * np.pi * 4 / (t[-1] - t[0])
+    frame = np.array([[np.cos(omega * ti / 2), *(np.sin(omega * ti / 2) * axis)] for ti in t])
+    lm = np.array([[ell, m] for ell in range(ell_min, ell_max + 1) for m in range(-ell, ell + 1)])
+    data = np.empty((t.shape[0], lm.shape[0]), dtype=complex)
+    for i, m in enumerate(lm[:, 1]):
+        data[:, i] = (m - 1j * m) * t
+    return scri_amd.WaveformModes(
+        t=t, frame=frame, data=data, ell_min=ell_min, ell_max=ell_max, history=["# Called from linear_waveform"],
+        frameType=scri_amd.Corotating, dataType=scri_amd.h, r_is_scaled_out=True, m_is_scaled_out=True,
+    )
+
+
+def test_indexing():
+    w = linear_waveform()
+    for i, (ell, m) in enumerate(w.LM):
+        assert w.index(ell, m) == i
+        assert np.allclose(w.data[:, w.index(ell, m)], (m - 1j * m) * w.t, rtol=0, atol=0)
+    assert np.all(w.indices(w.LM) == range(w.n_modes))
+    with pytest.raises(ValueError):
+        w.indices([1.0, 2.0])
+
+
+def test_empty_slice():
+    import scri_amd
+
+    w = linear_waveform()
+    W = w[:0, :0]
+    assert W.ensure_validity(alter=False)
+    assert W.history[:1] == ["# Called from linear_waveform"]
+    assert W.frameType == scri_amd.Corotating and W.dataType == scri_amd.h
+    assert W.r_is_scaled_out and W.m_is_scaled_out
+    assert W.num != w.num
+    assert W.t.shape == (0,) and W.frame.shape[0] == 0 and W.data.shape == (0, 0)
+    assert W.ell_min == 0 and W.ell_max == -1
+
+
+def test_empty_mode_slice():
+    w = linear_waveform()
+    W = w[:, :0]
+    assert W.ensure_validity(alter=False)
+    assert np.all(W.t == w.t) and np.all(W.frame == w.frame)
+    assert W.data.size == 0 and W.LM.size == 0
+    assert W.ell_min == 0 and W.ell_max == -1
+    assert W.history[:1] == ["# Called from linear_waveform"]
+    assert (W.frameType, W.dataType, W.r_is_scaled_out, W.m_is_scaled_out) == (w.frameType, w.dataType, w.r_is_scaled_out, w.m_is_scaled_out)
+    assert W.num != w.num
+
+
+def test_time_slice():
+    w = linear_waveform()
+    W = w[10:50]
+    assert W.ensure_validity(alter=False)
+    assert np.all(W.t == w.t[10:50]) and np.all(W.frame == w.frame[10:50]) and np.all(W.data == w.data[10:50])
+    assert np.all(W.LM == w.LM) and W.ells == w.ells
+    assert W.history[:1] == ["# Called from linear_waveform"]
+    assert isinstance(W.num, int) and W.num != w.num
+
+
+def test_time_and_mode_slice():
+    w = linear_waveform()
+    W = w[10:50, :5]
+    assert W.ensure_validity(alter=False)
+    assert np.all(W.t == w.t[10:50]) and np.all(W.frame == w.frame[10:50])
+    assert np.all(W.LM == np.array([[ell, m] for ell in range(w.ell_min, 5) for m in range(-ell, ell + 1)]))
+    assert np.all(W.data == w.data[10:50, :21])
+    one = w[:, 3]
+    assert one.ells == (3, 3) and np.all(one.data == w.data[:, 5:12])
+    with pytest.raises(ValueError, match="outside"):
+        w[:, 1]
+    with pytest.raises(ValueError, match="contiguous"):
+        w[:, 2:8:2]
+
+
+def test_norms():
+    W = linear_waveform()
+    W.data[0, :] = 6.0 * W.data[-1, :]
+    W.data[10, :] = 5.0 * W.data[-1, :]
+    assert W.ensure_validity(alter=False)
+    assert np.allclose(W.norm(), np.sum(np.abs(W.data) ** 2, axis=-1), rtol=1.0e-15)
+    assert np.allclose(W.norm(take_sqrt=True), np.sqrt(np.sum(np.abs(W.data) ** 2, axis=-1)), rtol=1.0e-15)
+    q = W.data.shape[0] // 4
+    assert np.allclose(W.norm(indices=slice(q, None, None)), np.sum(np.abs(W.data[q:]) ** 2, axis=-1), rtol=1.0e-15)
+    assert W.max_norm_index() == W.data.shape[0] - 1
+    assert W.max_norm_index(0) == 0 and W.max_norm_index(1) == 0
+    assert W.max_norm_index(W.data.shape[0]) == 10
+    assert W.max_norm_time() == W.t[-1] and W.max_norm_time(0) == W.t[0] and W.max_norm_time(W.data.shape[0]) == W.t[10]
