@@ -105,3 +105,33 @@ def test_modes_time_series_grid_multiply(ctx):
     assert np.abs(P.ndarray - ref).max() < 2e-13 * np.abs(ref).max()
     with pytest.raises(ValueError, match="must be the same"):
         A.grid_multiply(ModesTimeSeries(b, t + 1, spin_weight=1, ell_min=0, ell_max=3))
+
+
+def test_waveform_interpolation_reference_cases(ctx):
+    """The reference's tests/test_waveform.py:184-270 for a frame that does not depend on time (interpolating a rotating
+    frame needs quaternion.squad): interpolation onto the own times is the identity, constant data stay constant and
+    data linear in time stay linear -- to a few rounding errors (the reference states 4.5e-16 for scipy's spline)."""
+    import scri_amd
+
+    t = np.linspace(-10.0, 100.0, num=1000)
+    lm = np.array([[ell, m] for ell in range(2, 9) for m in range(-ell, ell + 1)])
+    for kind in ("constant", "linear"):
+        data = np.empty((t.size, lm.shape[0]), dtype=complex)
+        for i, m in enumerate(lm[:, 1]):
+            data[:, i] = (m - 1j * m) * (t if kind == "linear" else 1.0)
+        w = scri_amd.WaveformModes(
+            t=t, data=data, ell_min=2, ell_max=8, frame=np.array([[0.0, 1.0, 0.0, 0.0]]), history=[f"# Called from {kind}_waveform"],
+            frameType=scri_amd.Corotating, dataType=scri_amd.h, r_is_scaled_out=True, m_is_scaled_out=True, ctx=ctx,
+        )
+        same = w.interpolate(t.copy())
+        assert same.ensure_validity(alter=False) and same.num != w.num
+        assert np.array_equal(same.t, w.t) and np.array_equal(same.frame, w.frame) and np.array_equal(same.LM, w.LM)
+        assert np.array_equal(same.data, w.data)  # evaluation at a knot returns the sample itself
+        t_out = (t[:-1] + t[1:]) / 2.0
+        out = w.interpolate(t_out)
+        assert out.ensure_validity(alter=False)
+        assert out.history[:1] == [f"# Called from {kind}_waveform"]
+        assert (out.frameType, out.dataType, out.r_is_scaled_out, out.m_is_scaled_out) == (scri_amd.Corotating, scri_amd.h, True, True)
+        assert np.array_equal(out.t, t_out) and out.data.shape == (t_out.size, w.n_data_sets)
+        expect = np.array([(m - 1j * m) * (t_out if kind == "linear" else np.ones_like(t_out)) for m in lm[:, 1]]).T
+        assert np.allclose(out.data, expect, rtol=4e-15, atol=0)
