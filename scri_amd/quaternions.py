@@ -56,3 +56,76 @@ def as_spinor_array(q):
     """(w + i z, y + i x): quaternion.as_spinor_array (scri/rotations.py:311)."""
     q = np.asarray(q, dtype=float)
     return np.stack([q[..., 0] + 1j * q[..., 3], q[..., 2] + 1j * q[..., 1]], axis=-1)
+
+
+def log(q):
+    """Logarithm of unit(ish) quaternions [..., 4]: (ln |q|, v acos(w/|q|)/|v|)."""
+    q = np.asarray(q, dtype=float)
+    v = q[..., 1:]
+    vn = np.linalg.norm(v, axis=-1)
+    qn = np.linalg.norm(q, axis=-1)
+    angle = np.arctan2(vn, q[..., 0])
+    with np.errstate(invalid="ignore", divide="ignore"):
+        scale = np.where(vn > 1e-300, angle / np.where(vn > 1e-300, vn, 1.0), 0.0)
+    out = np.empty_like(q)
+    out[..., 0] = np.log(np.where(qn > 0, qn, 1.0))
+    out[..., 1:] = v * scale[..., None]
+    return out
+
+
+def exp(q):
+    """Exponential of quaternions [..., 4]."""
+    q = np.asarray(q, dtype=float)
+    v = q[..., 1:]
+    vn = np.linalg.norm(v, axis=-1)
+    e = np.exp(q[..., 0])
+    with np.errstate(invalid="ignore", divide="ignore"):
+        s = np.where(vn > 1e-300, np.sin(vn) / np.where(vn > 1e-300, vn, 1.0), 1.0)
+    out = np.empty_like(q)
+    out[..., 0] = e * np.cos(vn)
+    out[..., 1:] = (e * s)[..., None] * v
+    return out
+
+
+def slerp(q1, q2, tau):
+    """q1 (q1^-1 q2)^tau for unit quaternions; tau broadcasts against the leading axes."""
+    tau = np.asarray(tau, dtype=float)
+    return multiply(q1, exp(log(multiply(conjugate(q1), q2)) * tau[..., None]))
+
+
+def squad(R_in, t_in, t_out):
+    """Spherical "quadrangular" interpolation of rotors (the C^1 analogue of a cubic spline on the rotation group), as
+    `quaternion.squad` of the numpy-quaternion package, which scri/waveform_base.py:957 uses for the frame of an
+    interpolated waveform: control points from the logarithms of neighbouring relative rotations, end values mirrored
+    (R_{-1} = R_0 R_1^-1 R_0, R_n = R_{n-1} R_{n-2}^-1 R_{n-1}), and
+        squad = slerp( slerp(R_i, R_{i+1}, tau), slerp(A_i, B_{i+1}, tau), 2 tau (1 - tau) ).
+    R_in: float [n, 4] unit quaternions (n >= 2); t_in [n] increasing; t_out [m]."""
+    R = np.asarray(R_in, dtype=float)
+    t_in = np.asarray(t_in, dtype=float)
+    t_out = np.asarray(t_out, dtype=float)
+    if R.size == 0 or t_out.size == 0:
+        return np.zeros((0, 4))
+    if R.shape[0] < 2:
+        return np.repeat(R[:1], t_out.size, axis=0)
+    roll = lambda a, k: np.roll(a, k, axis=0)  # noqa: E731
+    inv = conjugate
+    i = np.clip(t_in.searchsorted(t_out, side="right") - 1, 0, t_in.size - 1)
+    with np.errstate(invalid="ignore", divide="ignore"):
+        r_next = ((roll(t_in, -1) - t_in) / (t_in - roll(t_in, 1)))[:, None]
+        r_after = ((roll(t_in, -1) - t_in) / (roll(t_in, -2) - roll(t_in, -1)))[:, None]
+    step = log(multiply(inv(R), roll(R, -1)))             # log(R_i^-1 R_{i+1})
+    back = log(multiply(inv(roll(R, 1)), R))              # log(R_{i-1}^-1 R_i)
+    ahead = log(multiply(inv(roll(R, -1)), roll(R, -2)))  # log(R_{i+1}^-1 R_{i+2})
+    A = multiply(R, exp((-step + back * r_next) * 0.25))
+    B = multiply(roll(R, -1), exp((ahead * r_after - step) * -0.25))
+    last_next = multiply(multiply(R[-1], inv(R[-2])), R[-1])  # R_n, the mirrored value beyond the end
+    A[0] = R[0]
+    A[-1] = R[-1]
+    B[-2] = R[-1]
+    B[-1] = last_next
+    R_ip1 = roll(R, -1).copy()
+    R_ip1[-1] = last_next
+    t_ip1 = roll(t_in, -1).copy()
+    t_ip1[-1] = t_in[-1] + (t_in[-1] - t_in[-2])
+    tau = (t_out - t_in[i]) / (t_ip1 - t_in)[i]
+    return slerp(slerp(R[i], R_ip1[i], tau), slerp(A[i], B[i], tau), 2 * tau * (1 - tau))

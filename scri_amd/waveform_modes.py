@@ -252,9 +252,10 @@ class WaveformModes:
         tprime = np.asarray(tprime, dtype=float)
         W = self.copy_without_data()
         W.t = np.copy(tprime)
-        if self.frame.shape[0] > 1:
-            raise NotImplementedError("interpolation of a time-dependent frame (quaternion.squad) is outside the BMS hot path")
-        W.frame = np.array(self.frame, copy=True)
+        if self.frame.shape[0] > 1:  # waveform_base.py:957
+            W.frame = quaternions.squad(self.frame, self.t, tprime)
+        else:
+            W.frame = np.array(self.frame, copy=True)
         W.data = engine.cubic_spline(self.t, self.data, tprime, ctx=self._ctx)
         W._append_history(f"{W} = {self}.interpolate({tprime})")
         return W

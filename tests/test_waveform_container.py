@@ -98,3 +98,34 @@ def test_norms():
     assert W.max_norm_index(0) == 0 and W.max_norm_index(1) == 0
     assert W.max_norm_index(W.data.shape[0]) == 10
     assert W.max_norm_time() == W.t[-1] and W.max_norm_time(0) == W.t[0] and W.max_norm_time(W.data.shape[0]) == W.t[10]
+
+
+def test_squad_rotor_interpolation():
+    """quaternions.squad (the numpy-quaternion algorithm scri/waveform_base.py:957 calls for the frame of an interpolated
+    waveform): identity at the knots, exact for a uniform rotation about a fixed axis (what the reference's
+    test_linear_interpolation checks), unit norm, and convergent for a general smooth rotor."""
+    from scri_amd import quaternions as Q
+
+    w = linear_waveform()
+    assert np.array_equal(Q.squad(w.frame, w.t, w.t), w.frame)
+    t_out = (w.t[:-1] + w.t[1:]) / 2.0
+    out = Q.squad(w.frame, w.t, t_out)
+    axis = w.frame[1, 1:] / np.linalg.norm(w.frame[1, 1:]) * np.sign(np.sin(2 * np.pi * 4 / 110 * w.t[1] / 2))
+    omega = 2 * np.pi * 4 / (w.t[-1] - w.t[0])
+    exact = np.array([[np.cos(omega * ti / 2), *(np.sin(omega * ti / 2) * axis)] for ti in t_out])
+    assert np.abs(out - exact).max() < 4e-15
+    assert np.abs(np.linalg.norm(out, axis=-1) - 1).max() < 2e-15
+
+    def rotor(tt):
+        v = np.stack([0.3 * np.sin(0.2 * tt), 0.025 * tt, 0.2 * np.cos(0.13 * tt)], axis=-1)
+        return Q.exp(np.concatenate([np.zeros(tt.shape + (1,)), v], axis=-1))
+
+    errs = []
+    for n in (200, 400):
+        tt = np.linspace(0, 50, n)
+        tm = (tt[:-1] + tt[1:]) / 2
+        errs.append(np.abs(Q.squad(rotor(tt), tt, tm) - rotor(tm)).max())
+    assert errs[0] < 1e-4 and errs[1] < errs[0] / 3.5
+    # a single rotor or no output times
+    assert Q.squad(w.frame[:1], w.t[:1], t_out[:5]).shape == (5, 4)
+    assert Q.squad(w.frame, w.t, np.array([])).shape == (0, 4)
