@@ -129,3 +129,44 @@ def squad(R_in, t_in, t_out):
     t_ip1[-1] = t_in[-1] + (t_in[-1] - t_in[-2])
     tau = (t_out - t_in[i]) / (t_ip1 - t_in)[i]
     return slerp(slerp(R[i], R_ip1[i], tau), slerp(A[i], B[i], tau), 2 * tau * (1 - tau))
+
+
+def sqrt(q):
+    """Square root of unit quaternions [..., 4] (the rotor of half the rotation); -1 maps to a rotation about x."""
+    q = np.asarray(q, dtype=float)
+    w = np.sqrt(np.maximum((1.0 + q[..., 0]) / 2.0, 0.0))
+    out = np.empty_like(q)
+    out[..., 0] = w
+    with np.errstate(invalid="ignore", divide="ignore"):
+        out[..., 1:] = np.where(w[..., None] > 1e-150, q[..., 1:] / (2.0 * np.where(w > 1e-150, w, 1.0))[..., None], np.array([1.0, 0.0, 0.0]))
+    return out
+
+
+def angular_velocity(R, t):
+    """omega(t) = 2 Rdot R^-1 (vector part) of a rotor series, with the derivative of a cubic spline through the components
+    (quaternion.angular_velocity)."""
+    from scipy.interpolate import CubicSpline
+
+    R = np.asarray(R, dtype=float)
+    Rdot = CubicSpline(t, R).derivative()(t)
+    return 2.0 * multiply(Rdot, conjugate(R))[..., 1:]
+
+
+def minimal_rotation(R, t, iterations=2):
+    """Adjust a frame R(t) by rotations about its own z axis so that the adjusted frame has no angular velocity along that
+    axis (numpy-quaternion's `minimal_rotation`, which scri/rotations.py:38 applies to the coprecessing frame):
+    R' = R exp(gamma z / 2) with  gamma-dot / 2 = Re[ Rdot z R^-1 ],  the time derivative and integral taken with cubic
+    splines, iterated because the spline of R' differs from the rotated spline of R."""
+    from scipy.interpolate import CubicSpline
+
+    R = np.asarray(R, dtype=float)
+    t = np.asarray(t, dtype=float)
+    z = np.array([0.0, 0.0, 0.0, 1.0])
+    for _ in range(int(iterations)):
+        Rdot = CubicSpline(t, R).derivative()(t)
+        halfgammadot = multiply(multiply(Rdot, z), conjugate(R))[..., 0]
+        halfgamma = CubicSpline(t, halfgammadot).antiderivative()(t)
+        Rgamma = np.zeros_like(R)
+        Rgamma[:, 0], Rgamma[:, 3] = np.cos(halfgamma), np.sin(halfgamma)
+        R = multiply(R, Rgamma)
+    return R

@@ -58,6 +58,33 @@ def rotate_decomposition_basis(W, R_basis):
     return W
 
 
+def to_coprecessing_frame(W, RoughDirection=np.array([0.0, 0.0, 1.0]), RoughDirectionIndex=None, transition_times=None):
+    """Transform a waveform (in place) to a coprecessing frame (scri/rotations.py:14-49): the dominant eigenvector of <LL>
+    (GPU) becomes the z axis, and the remaining freedom about it is fixed by the minimal-rotation condition."""
+    from . import Coprecessing
+    from .mode_calculations import LLDominantEigenvector
+
+    if RoughDirectionIndex is None:
+        RoughDirectionIndex = W.n_times // 8
+    dpa = LLDominantEigenvector(W, RoughDirection=RoughDirection, RoughDirectionIndex=RoughDirectionIndex)
+    v = dpa / np.linalg.norm(dpa, axis=-1)[:, None]
+    # sqrt(-v z): the rotor taking z to v
+    minus_vz = np.concatenate([v[:, 2:3], -np.cross(v, np.array([0.0, 0.0, 1.0]))], axis=-1)
+    R = quaternions.minimal_rotation(quaternions.sqrt(minus_vz), W.t, iterations=3)
+    if transition_times is not None:
+        from .utilities import transition_function
+
+        i0, i1 = np.argmin(np.abs(W.t - transition_times[0])), np.argmin(np.abs(W.t - transition_times[1]))
+        transition = transition_function(W.t[i0:], W.t[i0], W.t[i1], y0=1.0, y1=0.0)
+        omega = quaternions.angular_velocity(R[i0:], W.t[i0:]) * transition[:, np.newaxis]
+        slowing = engine.integrate_angular_velocity(W.t[i0:], omega, R[i0])
+        R = np.concatenate((R[:i0], slowing))
+    rotate_decomposition_basis(W, R)
+    W._append_history(f"{W}.to_coprecessing_frame({RoughDirection}, {RoughDirectionIndex}, {transition_times})")
+    W.frameType = Coprecessing
+    return W
+
+
 def to_inertial_frame(W):
     """Undo the rotations recorded in W.frame (scri/rotations.py:106-111)."""
     from . import Inertial

@@ -73,3 +73,19 @@ def multishuffle(shuffle_widths, forward=True, ctx=None):
         return b
 
     return shuffle
+
+
+def transition_function(x, x0, x1, y0=0.0, y1=1.0, return_indices=False):
+    """Smooth (C-infinity) step from y0 (x <= x0) to y1 (x >= x1): y0 + (y1 - y0) / (1 + exp(1/tau - 1/(1 - tau))),
+    tau = (x - x0) / (x1 - x0)  (scri/utilities.py:12-58)."""
+    x = np.asarray(x, dtype=float)
+    out = np.empty_like(x)
+    i0 = int(np.searchsorted(x, x0, side="right"))
+    i1 = int(np.searchsorted(x, x1, side="left"))
+    out[:i0] = y0
+    out[i1:] = y1
+    tau = (x[i0:i1] - x0) / (x1 - x0)
+    with np.errstate(over="ignore", divide="ignore"):
+        exponent = 1.0 / tau - 1.0 / (1.0 - tau)
+        out[i0:i1] = np.where(exponent >= np.log(np.finfo(float).max), y0, y0 + (y1 - y0) / (1.0 + np.exp(exponent)))
+    return (out, i0, i1) if return_indices else out

@@ -116,3 +116,48 @@ def test_reference_dominant_eigenvector_cases(ctx):
     w.rotate_decomposition_basis(frame)
     dpa = w.LLDominantEigenvector()
     assert np.abs(np.abs(dpa[:, 2]) - 1).max() < 1e-9
+
+
+def test_to_coprecessing_frame(ctx):
+    """scri/rotations.py:14-49: a waveform that is simple in a precessing frame (dominated by (2, +-2), constant) is
+    rotated into the inertial frame with a precessing, spinning rotor series; to_coprecessing_frame finds a frame in which
+    the dominant eigenvector of <LL> is the z axis again, with no angular velocity about that axis (minimal rotation),
+    and in which the modes are the original ones up to the phase e^{i m gamma(t)} of a rotation about z."""
+    import scri_amd
+    from scri_amd import quaternions as Q
+
+    n = 3000
+    t = np.linspace(0.0, 200.0, n)
+    LM = np.array([[l, m] for l in range(2, 5) for m in range(-l, l + 1)])
+    amp = np.zeros(LM.shape[0], dtype=complex)
+    for i, (l, m) in enumerate(LM):
+        amp[i] = {(2, 2): 1.0, (2, -2): 1.0, (3, 3): 0.1j, (3, -3): 0.1j, (4, 4): 0.03, (4, -4): 0.03}.get((l, m), 0.0)
+    data = np.repeat(amp[None, :], n, axis=0)
+    w = scri_amd.WaveformModes(t=t, data=data.copy(), ell_min=2, ell_max=4, dataType=scri_amd.h, frameType=scri_amd.Inertial,
+                               r_is_scaled_out=True, m_is_scaled_out=True, ctx=ctx)
+
+    def about(axis, angle):
+        axis = np.asarray(axis, dtype=float) / np.linalg.norm(axis)
+        return np.concatenate([np.cos(angle / 2)[:, None], np.sin(angle / 2)[:, None] * axis[None, :]], axis=-1)
+
+    # cone precession of the axis (tilt 0.3 about y, carried around z) plus a spin about the body's own axis
+    R = Q.multiply(Q.multiply(about([0, 0, 1], 0.02 * t), about([0, 1, 0], 0.3 + 0.0 * t)), about([0, 0, 1], 0.15 * t))
+    w.rotate_physical_system(R)
+    axis_inertial = Q.multiply(Q.multiply(R, np.array([0.0, 0, 0, 1])), Q.conjugate(R))[:, 1:]
+    w.to_coprecessing_frame()
+    assert w.frameType == scri_amd.Coprecessing and w.frame.shape == (n, 4)
+    # w.frame = R^-1 R_c (rotate_physical_system recorded R^-1): R_c is the coprecessing frame relative to the inertial one
+    R_c = Q.multiply(R, w.frame)
+    # its z axis is the dominant axis ...
+    z_frame = Q.multiply(Q.multiply(R_c, np.array([0.0, 0, 0, 1])), Q.conjugate(R_c))[:, 1:]
+    assert np.abs(z_frame - axis_inertial).max() < 1e-9
+    # ... and it does not rotate about it (the body's own spin of 0.15 rad per unit time is gone)
+    omega = Q.angular_velocity(R_c, t)
+    assert np.abs(np.sum(omega * z_frame, axis=-1))[100:-100].max() < 1e-8
+    assert np.abs(np.sum(Q.angular_velocity(R, t) * axis_inertial, axis=-1)).min() > 0.1
+    # ... and in it the waveform is the simple one again, up to a rotation about z
+    dpa = w.LLDominantEigenvector()
+    assert np.abs(np.abs(dpa[:, 2]) - 1).max() < 1e-9
+    assert np.abs(np.abs(w.data) - np.abs(data)).max() < 1e-9
+    w.to_inertial_frame()
+    assert w.frameType == scri_amd.Inertial
