@@ -31,9 +31,13 @@ def LLMatrix(W):
 
 def angular_velocity(W, include_frame_velocity=False):
     """Angular velocity of the waveform (arXiv:1302.2919 Sec. II): solve <Ldt> = -<LL> . omega at every time step."""
+    omega = _parts(W)[2]
     if include_frame_velocity and len(W.frame) == W.n_times:
-        raise NotImplementedError("include_frame_velocity needs quaternion.derivative, which is outside this build")
-    return _parts(W)[2]
+        # + 2 Rdot R^-1 of the frame, its derivative from a cubic spline (scri/mode_calculations.py:426-430)
+        from . import quaternions
+
+        omega = omega + quaternions.angular_velocity(W.frame, W.t)
+    return omega
 
 
 def _make_continuous(dpa, rough, i_index):

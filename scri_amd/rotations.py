@@ -102,10 +102,16 @@ def to_corotating_frame(W, R0=(1.0, 0.0, 0.0, 0.0), tolerance=1e-12, z_alignment
     from . import Corotating
     from .mode_calculations import corotating_frame
 
-    if truncate_log_frame:
-        raise NotImplementedError("truncate_log_frame is outside this build")
     frame, omega = corotating_frame(W, R0=R0, tolerance=tolerance, z_alignment_region=z_alignment_region, return_omega=True)
+    log_frame = None
+    if truncate_log_frame:
+        # keep only the bits of log(frame) above the tolerance: exp(truncated(log(frame))) rotates the waveform (:86-90)
+        log_frame = quaternions.log(frame)
+        power_of_2 = 2 ** int(-np.floor(np.log2(2 * tolerance)))
+        log_frame = np.round(log_frame * power_of_2) / power_of_2
+        frame = quaternions.exp(log_frame)
     W.rotate_decomposition_basis(frame)
     W._append_history(f"{W}.to_corotating_frame({R0}, {tolerance}, {z_alignment_region}, {return_omega}, {truncate_log_frame})")
     W.frameType = Corotating
-    return (W, omega) if return_omega else W
+    out = (W,) + ((omega,) if return_omega else ()) + ((log_frame,) if truncate_log_frame else ())
+    return out if len(out) > 1 else W

@@ -161,3 +161,29 @@ def test_to_coprecessing_frame(ctx):
     assert np.abs(np.abs(w.data) - np.abs(data)).max() < 1e-9
     w.to_inertial_frame()
     assert w.frameType == scri_amd.Inertial
+
+
+def test_frame_velocity_and_truncated_log_frame(ctx):
+    """angular_velocity(include_frame_velocity=True) adds the angular velocity of the recorded frame
+    (scri/mode_calculations.py:426-430): in its corotating frame a uniformly rotating waveform has zero mode velocity and
+    the frame carries all of it.  to_corotating_frame(truncate_log_frame=True) rotates with exp of the rounded log-frame
+    (scri/rotations.py:86-90) and returns it."""
+    import scri_amd
+
+    omega = 2 * math.pi / 5.0
+    w = _constant_waveform(6000, ctx)
+    half = np.zeros((w.n_times, 4))
+    half[:, 3] = omega / 2 * w.t
+    w.rotate_physical_system(quat.qexp(half))
+    # forget the bookkeeping: the same data as an inertial-frame waveform of a rotating system
+    w = scri_amd.WaveformModes(t=w.t, data=w.data, ell_min=2, ell_max=8, dataType=scri_amd.h, frameType=scri_amd.Inertial,
+                               r_is_scaled_out=True, m_is_scaled_out=True, ctx=ctx)
+    total_before = w.angular_velocity()
+    w2, om, log_frame = w.to_corotating_frame(return_omega=True, truncate_log_frame=True)
+    assert w2 is w and w.frameType == scri_amd.Corotating and log_frame.shape == (w.n_times, 4)
+    power_of_2 = 2 ** int(-np.floor(np.log2(2e-12)))
+    assert np.array_equal(log_frame * power_of_2, np.round(log_frame * power_of_2))
+    assert np.allclose(w.angular_velocity(), 0.0, atol=1e-6) and np.allclose(w.angular_velocity()[50:-50], 0.0, atol=1e-8)
+    total = w.angular_velocity(include_frame_velocity=True)
+    assert np.allclose(total[50:-50], [0.0, 0.0, omega], atol=1e-7)
+    assert np.allclose(total_before, [0.0, 0.0, omega], atol=1e-9, rtol=3e-7)
