@@ -255,15 +255,66 @@ def _unit_spin(abd):
     return chi / np.linalg.norm(chi, axis=-1)[:, None]
 
 
+def rotation_from_vectors(vector, target_vector, t=None, ctx=None):
+    """Frame rotation that best aligns `vector` with `target_vector` over the time interval (map_to_superrest_frame.py:510-526)"""
+    q = quaternions.optimal_alignment_in_Euclidean_metric(vector, target_vector, t=t)
+    return BMSTransformation(frame_rotation=quaternions.conjugate(q), ctx=ctx)
+
+
+def _news_angular_velocity_direction(abd):
+    """unit angular velocity of the news 2 d(sigma-bar)/du of an abd object, as a WaveformModes quantity on the GPU"""
+    from . import Inertial, WaveformModes, hdot
+
+    news = (2.0 * abd.sigma.bar).dot
+    w = WaveformModes(t=abd.t.copy(), data=np.asarray(news)[:, 4:], ell_min=2, ell_max=abd.ell_max, frameType=Inertial, dataType=hdot,
+                      r_is_scaled_out=True, m_is_scaled_out=True, ctx=getattr(abd, "_ctx", None))
+    omega = w.angular_velocity()
+    return omega / np.linalg.norm(omega, axis=-1)[:, None]
+
+
+def _target_omega_spline(target_strain):
+    """Cubic spline through the unit angular velocity of the target.  As in the reference (:575-590, :724-741) the target
+    strain is differentiated TWICE here (`data_dot`, then `.dot` of the series built from it), the abd's shear once."""
+    from scipy.interpolate import CubicSpline
+
+    from . import Inertial, WaveformModes, hdot
+
+    ctx = getattr(target_strain, "_ctx", None)
+    first = engine.spline_derivative(target_strain.t, target_strain.data, target_strain.t, 1, ctx=ctx)
+    second = engine.spline_derivative(target_strain.t, first, target_strain.t, 1, ctx=ctx)
+    w = WaveformModes(t=target_strain.t.copy(), data=second, ell_min=target_strain.ell_min, ell_max=target_strain.ell_max,
+                      frameType=Inertial, dataType=hdot, r_is_scaled_out=True, m_is_scaled_out=True, ctx=ctx)
+    omega = w.angular_velocity()
+    return CubicSpline(target_strain.t, omega / np.linalg.norm(omega, axis=-1)[:, None])
+
+
 def rotation_to_map_to_superrest_frame(abd, target_strain=None, N_itr_max=10, rel_err_tol=1e-12, fix_xz_plane=False,
                                        fix_yz_plane=False, print_conv=False):
-    """Iterative solve for the rotation that aligns the spin charge with the z axis (map_to_superrest_frame.py:529-663)."""
-    if target_strain is not None:
-        raise NotImplementedError("a target strain needs quaternion.optimal_alignment_in_Euclidean_metric, which is outside this build")
+    """Iterative solve for the rotation that aligns the spin charge with the z axis -- or, with a target strain, the
+    angular velocity of the news with the target's over the whole window (map_to_superrest_frame.py:529-663)."""
     ctx = getattr(abd, "_ctx", None)
     rot = BMSTransformation(ctx=ctx)
     best = BMSTransformation(ctx=ctx)
     itr, rel_err, rel_errs = 0, np.inf, [np.inf]
+    if target_strain is not None:
+        target = _target_omega_spline(target_strain)
+        omega = None
+        while itr < N_itr_max and not rel_err < rel_err_tol:
+            if itr == 0:
+                omega = _news_angular_velocity_direction(abd)
+            rot = (rotation_from_vectors(omega, target(abd.t), abd.t, ctx) * rot).reorder(NORMAL)
+            rot.supertranslation *= 0
+            rot.boost_velocity *= 0
+            abd_prime = abd.transform(frame_rotation=rot.frame_rotation.components)
+            omega = _news_angular_velocity_direction(abd_prime)
+            rel_err = _time_average(np.linalg.norm(omega - target(abd_prime.t), axis=-1), abd_prime.t, ctx)
+            if rel_err < min(rel_errs):
+                best = rot.copy()
+            rel_errs.append(rel_err)
+            itr += 1
+        if print_conv:
+            print(f"rotation: {'maximum number of iterations reached; the min error was ' + str(min(rel_errs)) if not itr < N_itr_max else 'tolerance achieved in ' + str(itr) + ' iterations!'}")
+        return best, rel_errs
     abd_prime = chi_prime = None
     while itr < N_itr_max and not rel_err < rel_err_tol:
         if itr == 0:
@@ -289,12 +340,14 @@ def rotation_to_map_to_superrest_frame(abd, target_strain=None, N_itr_max=10, re
 
 def rel_err_for_abd_in_superrest(abd, target_PsiM, target_strain):
     """(CoM, rotation, supermomentum) residuals of an abd object (map_to_superrest_frame.py:719-765)"""
-    if target_strain is not None:
-        raise NotImplementedError("a target strain is outside this build")
     ctx = getattr(abd, "_ctx", None)
     G = abd.bondi_CoM_charge() / abd.bondi_four_momentum()[:, 0, None]
     rel_err_CoM = _time_average(np.linalg.norm(G, axis=-1), abd.t, ctx)
-    rel_err_rot = _time_average(np.linalg.norm(_unit_spin(abd) - np.array([0.0, 0, 1])[None, :], axis=-1), abd.t, ctx)
+    if target_strain is not None:
+        omega = _news_angular_velocity_direction(abd)
+        rel_err_rot = _time_average(np.linalg.norm(omega - _target_omega_spline(target_strain)(abd.t), axis=-1), abd.t, ctx)
+    else:
+        rel_err_rot = _time_average(np.linalg.norm(_unit_spin(abd) - np.array([0.0, 0, 1])[None, :], axis=-1), abd.t, ctx)
     PsiM0 = abd.supermomentum("Moreschi").ndarray[np.argmin(abs(abd.t - 0)), 4:]
     if target_PsiM is not None:
         PsiM0 = PsiM0 - np.asarray(target_PsiM.data)[np.argmin(abs(target_PsiM.t - 0)), 4:]
@@ -329,8 +382,12 @@ def map_to_superrest_frame(
     abd = self.copy()
     if order == []:
         return abd, BMSTransformation(ctx=ctx), None
-    if target_strain_input is not None or "time_phase" in order:
-        raise NotImplementedError("target strains and the time_phase step are outside this build")
+    if "time_phase" in order:
+        raise NotImplementedError("the time_phase step needs sxs.waveforms.alignment.align2d, which is outside this build")
+    target_strain = None
+    if target_strain_input is not None:
+        target_strain = target_strain_input.copy()
+        target_strain.t = target_strain.t - t_0
     target_PsiM = None
     if target_PsiM_input is not None:
         tp = target_PsiM_input
@@ -366,7 +423,7 @@ def map_to_superrest_frame(
                 )
             elif step == "rotation":
                 new, _ = rotation_to_map_to_superrest_frame(
-                    abd_sliced_prime, N_itr_max=N_itr_maxes["rotation"], rel_err_tol=rel_err_tols["rotation"], fix_xz_plane=fix_xz_plane,
+                    abd_sliced_prime, target_strain=target_strain, N_itr_max=N_itr_maxes["rotation"], rel_err_tol=rel_err_tols["rotation"], fix_xz_plane=fix_xz_plane,
                     fix_yz_plane=fix_yz_plane, print_conv=print_conv,
                 )
             elif step == "CoM_transformation":
@@ -378,7 +435,7 @@ def map_to_superrest_frame(
                 raise ValueError(f"unknown step {step!r}")
             BMS = (new * BMS).reorder(NORMAL)
             abd_sliced_prime = _transform(abd_sliced, BMS)
-        rel_err = rel_err_for_abd_in_superrest(abd_sliced_prime, target_PsiM, None)
+        rel_err = rel_err_for_abd_in_superrest(abd_sliced_prime, target_PsiM, target_strain)
         if np.mean(rel_err) < min(np.mean(r) for r in rel_errs):
             best_BMS = BMS.copy()
             best_rel_err = rel_err

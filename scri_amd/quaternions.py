@@ -170,3 +170,30 @@ def minimal_rotation(R, t, iterations=2):
         Rgamma[:, 0], Rgamma[:, 3] = np.cos(halfgamma), np.sin(halfgamma)
         R = multiply(R, Rgamma)
     return R
+
+
+def optimal_alignment_in_Euclidean_metric(avec, bvec, t=None):
+    """Rotor R minimising  int |R a(t) R^-1 - b(t)|^2 dt  (a sum over the samples when t is None): numpy-quaternion's
+    function of this name, used by scri's rotation_from_vectors (map_to_superrest_frame.py:510-526).  Horn's closed form:
+    R is the eigenvector of the largest eigenvalue of the symmetric 4 x 4 matrix built from S_jk = int a_j b_k dt."""
+    a = np.asarray(avec, dtype=float).reshape(-1, 3)
+    b = np.asarray(bvec, dtype=float).reshape(-1, 3)
+    outer = a[:, :, None] * b[:, None, :]
+    if t is None:
+        S = outer.sum(axis=0)
+    else:
+        from scipy.interpolate import CubicSpline
+
+        t = np.asarray(t, dtype=float)
+        S = CubicSpline(t, outer.reshape(-1, 9)).integrate(t[0], t[-1]).reshape(3, 3)
+    N = np.array(
+        [
+            [S[0, 0] + S[1, 1] + S[2, 2], S[1, 2] - S[2, 1], S[2, 0] - S[0, 2], S[0, 1] - S[1, 0]],
+            [S[1, 2] - S[2, 1], S[0, 0] - S[1, 1] - S[2, 2], S[0, 1] + S[1, 0], S[2, 0] + S[0, 2]],
+            [S[2, 0] - S[0, 2], S[0, 1] + S[1, 0], -S[0, 0] + S[1, 1] - S[2, 2], S[1, 2] + S[2, 1]],
+            [S[0, 1] - S[1, 0], S[2, 0] + S[0, 2], S[1, 2] + S[2, 1], -S[0, 0] - S[1, 1] + S[2, 2]],
+        ]
+    )
+    vals, vecs = np.linalg.eigh(N)
+    q = vecs[:, -1]
+    return q if q[0] >= 0 else -q
