@@ -1,0 +1,23 @@
+"""Extended seeded sweep of tests/test_gpu_fuzz.py beyond the seeds in the suite (python tools/fuzz_sweep.py [last_seed]); prints failures."""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import scri_amd
+from oracle import quat
+quat.ROBUST_POLES = True
+import tests.test_gpu_fuzz as F
+ctx = scri_amd.Context(0)
+bad = 0
+for seed in range(36, int(sys.argv[1]) if len(sys.argv) > 1 else 240):
+    try:
+        F.test_random_waveform_transform.__wrapped__(ctx, seed) if hasattr(F.test_random_waveform_transform, "__wrapped__") else F.test_random_waveform_transform(ctx, seed)
+    except AssertionError as e:
+        bad += 1
+        print("WM seed", seed, "FAILED", str(e)[:300])
+for seed in range(10, 60):
+    try:
+        F.test_random_abd_transform(ctx, seed)
+    except AssertionError as e:
+        bad += 1
+        print("ABD seed", seed, "FAILED", str(e)[:300])
+print("done, failures:", bad)
