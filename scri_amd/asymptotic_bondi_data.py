@@ -101,8 +101,10 @@ class AsymptoticBondiData:
 
     def __getitem__(self, key):
         """Slice along time (scri/asymptotic_bondi_data/__init__.py: abd[i0:i1])"""
+        if isinstance(key, (int, np.integer)):
+            key = slice(key, key + 1 if key != -1 else None)  # one time step, kept as a series of length 1
         if not isinstance(key, slice):
-            raise TypeError("AsymptoticBondiData can only be sliced along time: abd[i0:i1]")
+            raise ValueError(f"Invalid key `{key}` of type `{type(key)}`.")
         new = type(self)(self._time[key], self._ell_max, multiplication_truncator=self._truncator, frameType=self.frameType, ctx=self._ctx)
         new._raw_data[:] = self._raw_data[:, key]
         return new
