@@ -192,6 +192,11 @@ int bms_transform_abd_shard(bms_ctx* ctx, const double* u, const void* raw, int 
 /* boosted_grid / R_j_k (transformations.py:100-148, waveform_grid.py:130-174): host f8[n_theta][n_phi][4] */
 int bms_rotor_grid(bms_ctx* ctx, const double frame_rotation[4], const double boost_velocity[3], int n_theta,
                    int n_phi, double* rotors_host);
+/* conformal_factors (transformations.py:151-196) on the given rotors (host f8[n][4]): k = 1 / (gamma (1 - v.r)) with r the
+ * direction the rotor takes z to, eth k / k (spin weight 1, c16[n]), 1/k and 1/k^3.  Host evaluation with the code the
+ * transformations run per direction on the GPU (pixel_math.h); ctx may be NULL. */
+int bms_conformal_factors(bms_ctx* ctx, const double boost_velocity[3], const double* rotors_host, int64_t n_rotors,
+                          double* k, void* ethk_over_k, double* one_over_k, double* one_over_k_cubed);
 /* sf.SWSH_grid(R, s, ell_max)[..., ell_min^2:] : host c16[n_rotors][(ell_max+1)^2 - ell_min^2] */
 int bms_swsh_grid(bms_ctx* ctx, const double* rotors_host /* f8[n][4] */, int64_t n_rotors, int spin, int ell_min,
                   int ell_max, void* Y_host);

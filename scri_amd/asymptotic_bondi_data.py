@@ -132,6 +132,23 @@ class AsymptoticBondiData:
         return type(self)(u_new, output_ell_max, multiplication_truncator=self._truncator, frameType=self.frameType, ctx=self._ctx, _raw=raw_new)
 
 
+def boosted_grid(frame_rotation, boost_velocity, n_theta, n_phi):
+    """Rotors of the grid directions after the rotation and boost, float [n_theta, n_phi, 4]
+    (scri/asymptotic_bondi_data/transformations.py:100-148)."""
+    from . import quaternions
+
+    return engine.rotor_grid(quaternions.as_float_array(frame_rotation), boost_velocity, n_theta, n_phi)
+
+
+def conformal_factors(boost_velocity, distorted_grid_rotors):
+    """k, eth k / k, 1/k, 1/k^3 on the distorted grid, each [1, n_theta, n_phi] so that they broadcast against time
+    (scri/asymptotic_bondi_data/transformations.py:151-196; plain arrays in place of sf.Grid: spin weights 0, 1, 0, 0)."""
+    from . import quaternions
+
+    k, ethk_over_k, one_over_k, one_over_k_cubed = engine.conformal_factors(boost_velocity, quaternions.as_float_array(distorted_grid_rotors))
+    return k[np.newaxis], ethk_over_k[np.newaxis], one_over_k[np.newaxis], one_over_k_cubed[np.newaxis]
+
+
 _SPINS = (2, 1, 0, -1, -2, 2)  # psi0..psi4, sigma
 
 

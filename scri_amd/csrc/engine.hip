@@ -1383,6 +1383,32 @@ extern "C" int bms_rotor_grid(bms_ctx* c, const double fr[4], const double v[3],
   return BMS_OK;
 }
 
+extern "C" int bms_conformal_factors(bms_ctx* c, const double v[3], const double* rotors, int64_t n, double* k, void* ethk_over_k,
+                                     double* one_over_k, double* one_over_k_cubed) {
+  if (!v || !rotors || !k || !ethk_over_k || !one_over_k || !one_over_k_cubed) return fail(c, BMS_ERR_INVALID, "NULL argument");
+  const double b2 = v[0] * v[0] + v[1] * v[1] + v[2] * v[2];
+  if (!(b2 < 1.0)) return fail(c, BMS_ERR_INVALID, "boost speed must be < 1");
+  const double gamma = 1 / std::sqrt(1 - b2);
+  // l <= 1 modes of v.r, evaluated with spin weight 1: eth(v.r) (the same coefficients the ABD transformation uses)
+  const cplx cv[4] = {{0, 0},
+                      {v[0] * std::sqrt(2 * M_PI / 3), v[1] * std::sqrt(2 * M_PI / 3)},
+                      {v[2] * std::sqrt(4 * M_PI / 3), 0},
+                      {-v[0] * std::sqrt(2 * M_PI / 3), v[1] * std::sqrt(2 * M_PI / 3)}};
+  cplx* e = (cplx*)ethk_over_k;
+  for (int64_t p = 0; p < n; ++p) {
+    const Quat R = {rotors[4 * p], rotors[4 * p + 1], rotors[4 * p + 2], rotors[4 * p + 3]};
+    double r[3];
+    rotate_z(R, r);
+    const double vr = v[0] * r[0] + v[1] * r[1] + v[2] * r[2];
+    const cplx ev = eval_modes(cv, 1, 1, R);
+    one_over_k[p] = gamma * (1 - vr);
+    k[p] = 1.0 / one_over_k[p];
+    e[p] = {ev.re / (1 - vr), ev.im / (1 - vr)};
+    one_over_k_cubed[p] = one_over_k[p] * one_over_k[p] * one_over_k[p];
+  }
+  return BMS_OK;
+}
+
 extern "C" int bms_swsh_grid(bms_ctx* c, const double* rotors, int64_t n, int spin, int ell_min, int ell_max, void* Y) {
   if (!c || !rotors || !Y) return BMS_ERR_INVALID;
   HIP_TRY(c, hipSetDevice(c->device));

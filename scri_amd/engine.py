@@ -295,6 +295,20 @@ def rotor_grid(frame_rotation, boost_velocity, n_theta, n_phi, ctx=None, device=
     return out
 
 
+def conformal_factors(boost_velocity, rotors):
+    """bms_conformal_factors: (k, eth k / k, 1/k, 1/k^3) on rotors [..., 4], each shaped like rotors[..., 0]."""
+    v = np.ascontiguousarray(boost_velocity, dtype=float)
+    R = np.ascontiguousarray(rotors, dtype=float)
+    shape = R.shape[:-1]
+    n = int(np.prod(shape))
+    k, ik, ik3 = np.empty(n), np.empty(n), np.empty(n)
+    e = np.empty(n, dtype=np.complex128)
+    rc = _lib.load().bms_conformal_factors(None, dptr(v), dptr(R), n, dptr(k), vptr(e), dptr(ik), dptr(ik3))
+    if rc != 0:
+        _lib._raise(rc, None, "bms_conformal_factors")
+    return k.reshape(shape), e.reshape(shape), ik.reshape(shape), ik3.reshape(shape)
+
+
 def swsh_grid(rotors, spin, ell_min, ell_max, ctx=None):
     ctx = _ctx(ctx)
     R = np.ascontiguousarray(rotors, dtype=float)

@@ -110,3 +110,38 @@ def test_abd_WaveformModes(ctx):
     hprime = hprime.interpolate(t)
     abdprime = abdprime.interpolate(t)
     assert np.allclose(hprime.data, 2 * abdprime.sigma.bar.ndarray[:, 4:], atol=tolerance, rtol=tolerance)
+
+
+def test_abd_conformal_factors(ctx):
+    """The reference's tests/test_asymptoticbondidata.py:33-93: conformal_factors(boost, boosted_grid) against the
+    band-limited route -- k and 1/k analysed on the undistorted grid (map2salm on the GPU), eth applied in mode space,
+    and the results evaluated on the distorted rotors (SWSH_grid on the GPU) -- at the reference's tolerance."""
+    from scri_amd import asymptotic_bondi_data as abd_mod
+    from scri_amd import engine
+
+    tolerance = 4e-14
+    ell_max = 32
+    n_theta = n_phi = 2 * ell_max + 1
+    v = np.array([0.01, 0.02, 0.03])
+    gamma = 1 / np.sqrt(1 - v @ v)
+    rotors = abd_mod.boosted_grid([1.0, 0, 0, 0], v, n_theta, n_phi)
+    k, ethk_over_k, one_over_k, one_over_k_cubed = abd_mod.conformal_factors(v, rotors)
+    assert k.shape == ethk_over_k.shape == one_over_k.shape == one_over_k_cubed.shape == (1, n_theta, n_phi)
+    theta = np.pi * np.arange(n_theta) / (n_theta - 1)
+    phi = 2 * np.pi * np.arange(n_phi) / n_phi
+    th, ph = np.meshgrid(theta, phi, indexing="ij")
+    kinv_grid = gamma * (1 - v[0] * np.sin(th) * np.cos(ph) - v[1] * np.sin(th) * np.sin(ph) - v[2] * np.cos(th))
+    kinv_modes = engine.map2salm(kinv_grid + 0j, 0, ell_max, ctx=ctx)
+    k_modes = engine.map2salm(1 / kinv_grid + 0j, 0, ell_max, ctx=ctx)
+    Y0 = engine.swsh_grid(rotors.reshape(-1, 4), 0, 0, ell_max, ctx=ctx)
+    Y1 = engine.swsh_grid(rotors.reshape(-1, 4), 1, 0, ell_max, ctx=ctx)
+    one_over_k2 = (Y0 @ kinv_modes).reshape(n_theta, n_phi)
+    ell = np.concatenate([np.full(2 * l + 1, l) for l in range(ell_max + 1)])
+    eth_k_modes = k_modes * np.sqrt(ell * (ell + 1.0)) / np.sqrt(2.0)  # eth_GHP on spin 0
+    ethk2 = (Y1 @ eth_k_modes).reshape(n_theta, n_phi)
+    k2 = 1 / one_over_k2
+    assert np.allclose(one_over_k[0], one_over_k2, atol=tolerance, rtol=tolerance)
+    assert np.allclose(k[0], k2, atol=tolerance, rtol=tolerance)
+    assert np.allclose(one_over_k_cubed[0], one_over_k2**3, atol=tolerance, rtol=tolerance)
+    # (the band-limited route itself carries ~1e-13 of rounding here: 1089-term sums of the GPU SWSH values)
+    assert np.allclose(ethk_over_k[0], ethk2 / k2, atol=2e-13, rtol=tolerance)
