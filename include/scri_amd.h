@@ -150,6 +150,11 @@ typedef struct {
 } bms_shard;
 int bms_shard_plan(bms_ctx* ctx, const double* t, int64_t n_times, const bms_transformation* tr, int64_t out_i0,
                    int64_t out_i1, int64_t need_rows[2], int64_t window[2]);
+/* WaveformGrid.from_modes on its own (scri/waveform_grid.py:331-613): the first half of bms_transform_modes -- the field on the
+ * boost-distorted grid at the new time slices, grid_out c16[n_times][n_theta * n_phi] (only the first *n_times_out rows are
+ * written; grid order, theta-major), in the memory space in->mem.  bms_map2salm of it is WaveformGrid.to_modes (:274-329). */
+int bms_modes_to_grid(bms_ctx* ctx, const bms_wm_input* in, const bms_transformation* tr, double* t_out, void* grid_out,
+                      int64_t* n_times_out);
 /* The valid output window [i_lo, i_hi) of a transformation (scri/waveform_grid.py:564-568; abd != 0: the
  * AsymptoticBondiData flavour, transformations.py:391-396), from the same per-direction tables the transformations
  * compute on the GPU: output sample r of bms_transform_modes / bms_transform_abd has input index i_lo + r, so a caller

@@ -27,6 +27,7 @@ from . import _lib  # noqa: E402  (raises ImportError if libscri_amd.so has not 
 from ._lib import Context, default_context, BMSError  # noqa: E402,F401
 from . import engine  # noqa: E402,F401
 from .waveform_modes import WaveformModes  # noqa: E402,F401
+from .waveform_grid import WaveformGrid  # noqa: E402,F401
 from .rotations import rotate_decomposition_basis, rotate_physical_system, to_inertial_frame, to_corotating_frame, to_coprecessing_frame  # noqa: E402,F401
 from .asymptotic_bondi_data import AsymptoticBondiData  # noqa: E402,F401
 from . import bms_transformations  # noqa: E402,F401

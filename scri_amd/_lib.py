@@ -81,6 +81,10 @@ SIGNATURES = {
     ),
     "bms_host_alloc": (c_vp, [ctypes.c_uint64]),
     "bms_host_free": (None, [c_vp]),
+    "bms_modes_to_grid": (
+        c_int,
+        [c_vp, ctypes.POINTER(bms_wm_input), ctypes.POINTER(bms_transformation), c_dp, c_vp, ctypes.POINTER(c_i64)],
+    ),
     "bms_output_window": (c_int, [c_vp, c_dp, c_i64, ctypes.POINTER(bms_transformation), c_int, ctypes.POINTER(c_i64)]),
     "bms_transform_modes_shard": (
         c_int,

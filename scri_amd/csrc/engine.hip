@@ -1084,11 +1084,29 @@ extern "C" int bms_output_window(bms_ctx* c, const double* t, int64_t n, const b
   return BMS_OK;
 }
 
+static int transform_modes_impl(bms_ctx* c, const bms_wm_input* in, const bms_transformation* tr, const bms_shard* sh, double* t_out,
+                                void* data_out, int64_t* n_times_out, int64_t* first_index_out, void* grid_out);
+
 extern "C" int bms_transform_modes_shard(bms_ctx* c, const bms_wm_input* in, const bms_transformation* tr,
                                          const bms_shard* sh, double* t_out, void* data_out, int64_t* n_times_out,
                                          int64_t* first_index_out) {
   if (!c) return BMS_ERR_INVALID;
-  if (!in || !tr || !t_out || !data_out || !n_times_out) return fail(c, BMS_ERR_INVALID, "NULL argument");
+  if (!data_out) return fail(c, BMS_ERR_INVALID, "NULL argument");
+  return transform_modes_impl(c, in, tr, sh, t_out, data_out, n_times_out, first_index_out, nullptr);
+}
+
+// WaveformGrid.from_modes on its own (scri/waveform_grid.py:331-613): the field on the distorted grid at the new time slices,
+// c16[N'][n_theta * n_phi] in grid order (no column plan), without the analysis back to modes
+extern "C" int bms_modes_to_grid(bms_ctx* c, const bms_wm_input* in, const bms_transformation* tr, double* t_out, void* grid_out,
+                                 int64_t* n_times_out) {
+  if (!c) return BMS_ERR_INVALID;
+  if (!grid_out) return fail(c, BMS_ERR_INVALID, "NULL argument");
+  return transform_modes_impl(c, in, tr, nullptr, t_out, nullptr, n_times_out, nullptr, grid_out);
+}
+
+static int transform_modes_impl(bms_ctx* c, const bms_wm_input* in, const bms_transformation* tr, const bms_shard* sh, double* t_out,
+                                void* data_out, int64_t* n_times_out, int64_t* first_index_out, void* grid_out) {
+  if (!in || !tr || !t_out || !n_times_out) return fail(c, BMS_ERR_INVALID, "NULL argument");
   HIP_TRY(c, hipSetDevice(c->device));
   const int64_t n = in->n_times;
   int64_t t_lo, t_hi;
@@ -1195,7 +1213,7 @@ extern "C" int bms_transform_modes_shard(bms_ctx* c, const bms_wm_input* in, con
   trace.mark("input staging, time upload, spline factors, elimination on the modes (enqueue)");
   PixelTables T;
   DevPixel DP;
-  if ((rc = device_pixel_tables(c, tr, T, psi ? 1 : 0, s, in->conformal_weight, coef0.empty() ? nullptr : &coef0, nullptr, cv, DP, column_plan(tr, n_out),
+  if ((rc = device_pixel_tables(c, tr, T, psi ? 1 : 0, s, in->conformal_weight, coef0.empty() ? nullptr : &coef0, nullptr, cv, DP, grid_out ? 0 : column_plan(tr, n_out),
                                 c->aux)))
     return rc;
   trace.mark("pixel tables (GPU, auxiliary stream) + copy back");
@@ -1264,8 +1282,9 @@ extern "C" int bms_transform_modes_shard(bms_ctx* c, const bms_wm_input* in, con
 
   // output staging
   double* d_out = (double*)data_out;
-  if (in->mem == BMS_HOST)
+  if (in->mem == BMS_HOST && !grid_out)
     if ((rc = dev_buf_t(c, "out_data", (size_t)n_new * n_out * 2, &d_out))) return rc;
+  if (grid_out && col_split) return fail(c, BMS_ERR_INVALID, "the grid output does not combine with a column partition");
 
   if (n_pix == 0) {  // more parts than column tiles: this part contributes nothing
     if (in->mem == BMS_HOST)
@@ -1302,7 +1321,10 @@ extern "C" int bms_transform_modes_shard(bms_ctx* c, const bms_wm_input* in, con
     if ((rc = dev_buf_t(c, "Y", (size_t)rows_in * ldg, &d_Y))) return rc;
     if (!bs)
       if ((rc = dev_buf_t(c, "R", (size_t)rows_in * ldg, &d_R))) return rc;  // eliminated rows (either form)
-    if ((rc = dev_buf_t(c, "G", (size_t)rows_out * P2, &d_G))) return rc;
+    if (grid_out && in->mem == BMS_DEVICE)
+      d_G = (double*)grid_out + (size_t)(c0 - i_lo) * P2;  // straight into the caller's grid
+    else if ((rc = dev_buf_t(c, "G", (size_t)rows_out * P2, &d_G)))
+      return rc;
     if (bs) {
       TIMED(c, BMS_TAG_GEMM_SYNTHESIS, launch_zgemm3m(S, d_Af + (g0 - row0) * ld_af, ld_af, F[0].d_B + 2 * cA, ldb, d_Y, ldg, rows_in, n_pix,
                                                       n_modes_in + 1, nullptr, d_scale));
@@ -1336,14 +1358,18 @@ extern "C" int bms_transform_modes_shard(bms_ctx* c, const bms_wm_input* in, con
     }
     }
     // analysis
-    if (col_split) {
+    if (grid_out) {
+      if (in->mem == BMS_HOST)
+        HIP_TRY(c, hipMemcpyAsync((double*)grid_out + (size_t)(c0 - i_lo) * P2, d_G, sizeof(double) * (size_t)rows_out * P2, hipMemcpyDeviceToHost, S));
+      if (in->mem == BMS_HOST && c1 < i_hi) HIP_TRY(c, hipStreamSynchronize(S));  // the staging buffer is reused by the next chunk
+    } else if (col_split) {
       TIMED(c, BMS_TAG_GEMM_ANALYSIS, launch_zgemm3m(S, d_G, P2, d_At + (size_t)cA * ld_at, ld_at, d_out + (c0 - i_lo) * n_out * 2, 2LL * n_out,
                                                      rows_out, n_out, n_pix, nullptr, nullptr));
     } else if ((rc = run_analysis(c, ana, d_G, rows_out, d_out + (c0 - i_lo) * n_out * 2, 2LL * n_out, DP.col_of_pixel, P2)))
       return rc;
   }
   trace.mark("chunk loop (enqueue)");
-  if (in->mem == BMS_HOST)
+  if (in->mem == BMS_HOST && !grid_out)
     HIP_TRY(c, hipMemcpyAsync(data_out, d_out, (size_t)n_new * n_out * 16, hipMemcpyDeviceToHost, S));
   // the new time axis is host work: done while the GPU runs
   for (int64_t i = 0; i < n_new; ++i) t_out[i] = (1 / T.gamma) * (in->t[i_lo + i] - T.tt);

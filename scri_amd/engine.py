@@ -128,8 +128,11 @@ def transform_modes(
     ld=None,
     out_ptr=None,
     shard=None,
+    grid=False,
 ):
     """bms_transform_modes.  Host mode: data complex128 [N, n_modes] -> (t_out[N'], data_out[N', n_out]).
+    grid=True (host mode, no shard): bms_modes_to_grid instead -- the field on the distorted grid at the new time slices,
+    (t_out[N'], grid[N', n_theta * n_phi]), i.e. WaveformGrid.from_modes without the analysis back to modes.
     Device mode (device=True): `data` and each aux data are device addresses, `ld` the row stride,
     `out_ptr` a device buffer of N * n_out complex; returns (t_out[N'], N').
     aux: sequence of (data, ell_min, ell_max, spin, coeff, power[, ld]).
@@ -194,6 +197,13 @@ def transform_modes(
         ctx.check(rc, "bms_transform_modes")
         res = (t_out[: n_new.value], n_new.value)
         return res + (first.value,) if shard is not None else res
+    if grid:
+        if shard is not None:
+            raise ValueError("the grid output does not combine with a shard")
+        out = _lib.pinned_empty((max(n, 1), transformation.n_theta * transformation.n_phi), np.complex128)
+        rc = _lib.load().bms_modes_to_grid(ctx.handle, ctypes.byref(inp), ctypes.byref(transformation), dptr(t_out), vptr(out), ctypes.byref(n_new))
+        ctx.check(rc, "bms_modes_to_grid")
+        return t_out[: n_new.value], out[: n_new.value]
     out = _lib.pinned_empty((max(n_alloc, 1), n_out), np.complex128)
     rc = _lib.load().bms_transform_modes_shard(
         ctx.handle, ctypes.byref(inp), ctypes.byref(transformation), shp, dptr(t_out), vptr(out), ctypes.byref(n_new),

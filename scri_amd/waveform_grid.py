@@ -142,30 +142,20 @@ def process_transformation_kwargs(ell_max, **kwargs):
     return supertranslation, ell_max_supertranslation, ell_max, n_theta, n_phi, frame_rotation, boost_velocity, kwargs
 
 
-def transform(w_modes, **kwargs):
-    """WaveformGrid.transform (scri/waveform_grid.py:615-630): from_modes(...).to_modes(ell_max).
-
-    Returns a new WaveformModes on the retarded-time slices of the transformed frame; `ell_max` of the
-    output defaults to that of the input, the output `ell_min` is |s| (to_modes default)."""
-    from .waveform_modes import WaveformModes
-
-    if not isinstance(w_modes, WaveformModes):
-        raise TypeError(
-            "Expected WaveformModes object in argument 1; " "got `{}` instead.".format(type(w_modes).__name__)
-        )
-    ell_max_out = kwargs.pop("ell_max", w_modes.ell_max)
-    # from_modes: frame check (waveform_grid.py:417-426)
+def _prepare(w_modes, kwargs):
+    """Everything from_modes does before touching the data (scri/waveform_grid.py:417-557): frame check, kwargs, the
+    type-specific term and the auxiliary Weyl scalars it needs.  Consumes the keys it understands from `kwargs`."""
     if w_modes.frameType != Inertial:
         raise ValueError(
             "\nInput waveform object must be in an inertial frame; "
             "this is in a frame of type `{}`".format(w_modes.frame_type_string)
         )
-    original_kwargs = kwargs.copy()
-    (supertranslation, ell_max_supertranslation, ell_max, n_theta, n_phi, frame_rotation, boost_velocity, kwargs) = (
+    (supertranslation, ell_max_supertranslation, ell_max, n_theta, n_phi, frame_rotation, boost_velocity, rest) = (
         process_transformation_kwargs(w_modes.ell_max, **kwargs)
     )
+    kwargs.clear()
+    kwargs.update(rest)
     beta = np.linalg.norm(boost_velocity)
-    s = w_modes.spin_weight
     dt = w_modes.dataType
 
     # type-specific term (waveform_grid.py:485-557)
@@ -195,6 +185,26 @@ def transform(w_modes, **kwargs):
                 "of dataType '{}'. Proceeding with the transformation as if it "
                 "were dataType 'Psi4'.".format(w_modes.data_type_string)
             )
+    if w_modes.data.ndim != 2:
+        raise NotImplementedError("extra trailing data dimensions are not supported by the GPU engine")
+    return supertranslation, frame_rotation, boost_velocity, n_theta, n_phi, type_term, aux
+
+
+def transform(w_modes, **kwargs):
+    """WaveformGrid.transform (scri/waveform_grid.py:615-630): from_modes(...).to_modes(ell_max), fused in one engine call.
+
+    Returns a new WaveformModes on the retarded-time slices of the transformed frame; `ell_max` of the
+    output defaults to that of the input, the output `ell_min` is |s| (to_modes default)."""
+    from .waveform_modes import WaveformModes
+
+    if not isinstance(w_modes, WaveformModes):
+        raise TypeError(
+            "Expected WaveformModes object in argument 1; " "got `{}` instead.".format(type(w_modes).__name__)
+        )
+    ell_max_out = kwargs.pop("ell_max", w_modes.ell_max)
+    original_kwargs = kwargs.copy()
+    supertranslation, frame_rotation, boost_velocity, n_theta, n_phi, type_term, aux = _prepare(w_modes, kwargs)
+    s = w_modes.spin_weight
 
     # to_modes argument checks (waveform_grid.py:291-297)
     import numbers
@@ -204,8 +214,6 @@ def transform(w_modes, **kwargs):
     ell_min_out = abs(s)
     if ell_min_out > ell_max_out:
         raise ValueError(f"Input `ell_min` should be an integer between 0 and {ell_max_out}; got `{ell_min_out}`.")
-    if w_modes.data.ndim != 2:
-        raise NotImplementedError("extra trailing data dimensions are not supported by the GPU engine")
 
     tr = engine.make_transformation(supertranslation, frame_rotation, boost_velocity, n_theta, n_phi, ell_max_out)
     t_new, data_new = engine.transform_modes(
@@ -228,3 +236,83 @@ def transform(w_modes, **kwargs):
         constructor_statement=f"WaveformGrid.from_modes({w_modes}, **{original_kwargs}).to_modes({ell_max_out})",
         ctx=w_modes._ctx,
     )
+
+
+class WaveformGrid:
+    """A waveform on a (theta, phi) grid at each time (the part of scri.WaveformGrid the transformation path shows:
+    scri/waveform_grid.py:193-630): `from_modes` puts a WaveformModes object on the -- optionally BMS-transformed -- grid,
+    `to_modes` analyses it back, `transform` does both.  data: complex [n_times, n_theta * n_phi], theta-major."""
+
+    def __init__(self, t, data, n_theta, n_phi, frameType, dataType, r_is_scaled_out, m_is_scaled_out, history=(), ctx=None,
+                 constructor_statement=None):
+        self.t = np.array(t, dtype=float)
+        self.data = np.asarray(data, dtype=complex)
+        self.n_theta, self.n_phi = int(n_theta), int(n_phi)
+        self.frameType, self.dataType = frameType, dataType
+        self.r_is_scaled_out, self.m_is_scaled_out = bool(r_is_scaled_out), bool(m_is_scaled_out)
+        self.history = list(history) + [constructor_statement or "WaveformGrid(...)"]
+        self._ctx = ctx
+        if self.data.ndim != 2 or self.data.shape != (self.t.size, self.n_theta * self.n_phi):
+            raise ValueError(f"data.shape={self.data.shape} does not agree with n_times={self.t.size}, n_theta*n_phi={self.n_theta * self.n_phi}")
+
+    @property
+    def n_times(self):
+        return self.t.shape[0]
+
+    @property
+    def spin_weight(self):
+        from . import SpinWeights
+
+        return SpinWeights[self.dataType]
+
+    @classmethod
+    def from_modes(cls, w_modes, **kwargs):
+        """The modes on the grid of the (rotated, boosted, supertranslated) frame at its retarded-time slices
+        (scri/waveform_grid.py:331-613); keyword arguments as `transform`, without `ell_max`."""
+        from .waveform_modes import WaveformModes
+
+        if not isinstance(w_modes, WaveformModes):
+            raise TypeError("Expected WaveformModes object in argument 1; " "got `{}` instead.".format(type(w_modes).__name__))
+        original_kwargs = kwargs.copy()
+        supertranslation, frame_rotation, boost_velocity, n_theta, n_phi, type_term, aux = _prepare(w_modes, kwargs)
+        tr = engine.make_transformation(supertranslation, frame_rotation, boost_velocity, n_theta, n_phi, w_modes.ell_max)
+        t_new, grid = engine.transform_modes(
+            w_modes.t, w_modes.data, w_modes.ell_min, w_modes.ell_max, w_modes.spin_weight, w_modes.conformal_weight, type_term, tr,
+            aux=aux, ctx=w_modes._ctx, grid=True,
+        )
+        if kwargs:
+            warnings.warn("\nUnused kwargs passed to this function:\n{}".format(pprint.pformat(kwargs, width=1)))
+        return cls(
+            t_new, grid, n_theta, n_phi, w_modes.frameType, w_modes.dataType, w_modes.r_is_scaled_out, w_modes.m_is_scaled_out,
+            history=w_modes.history, ctx=w_modes._ctx,
+            constructor_statement=f"{cls.__name__}.from_modes({w_modes}, **{original_kwargs})",
+        )
+
+    def to_modes(self, ell_max=None, ell_min=None):
+        """Spin-weighted spherical-harmonic modes of the grid data (scri/waveform_grid.py:274-329): map2salm on the GPU."""
+        import numbers
+
+        from .waveform_modes import WaveformModes
+
+        s = self.spin_weight
+        if ell_max is None:
+            ell_max = int((max(self.n_theta, self.n_phi) - 1) // 2)
+        if ell_min is None:
+            ell_min = abs(s)
+        if not isinstance(ell_max, numbers.Integral) or ell_max < 0:
+            raise ValueError(f"Input `ell_max` should be a nonnegative integer; got `{ell_max}`.")
+        if not isinstance(ell_min, numbers.Integral) or ell_min < 0 or ell_min > ell_max:
+            raise ValueError(f"Input `ell_min` should be an integer between 0 and {ell_max}; got `{ell_min}`.")
+        grid = self.data.reshape(self.n_times, self.n_theta, self.n_phi)
+        modes = engine.map2salm(grid, s, int(ell_max), ell_min=int(ell_min), ctx=self._ctx)
+        return WaveformModes(
+            t=self.t, data=modes, history=self.history, ell_min=int(ell_min), ell_max=int(ell_max), frameType=self.frameType,
+            dataType=self.dataType, r_is_scaled_out=self.r_is_scaled_out, m_is_scaled_out=self.m_is_scaled_out,
+            constructor_statement=f"{self}.to_modes({ell_max})", ctx=self._ctx,
+        )
+
+    @classmethod
+    def transform(cls, w_modes, **kwargs):
+        """from_modes(...).to_modes(ell_max), `ell_max` defaulting to the input's (scri/waveform_grid.py:615-630); the fused
+        engine call of the module-level `transform`."""
+        return transform(w_modes, **kwargs)

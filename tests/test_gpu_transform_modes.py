@@ -59,3 +59,40 @@ def test_transform_matches_oracle(ctx, case, dataType):
     assert np.abs(got.t - expect.t).max() <= 1e-13
     scale = np.abs(expect.data).max()
     assert np.abs(got.data - expect.data).max() < 1e-12 * max(1.0, scale)
+
+
+def test_waveform_grid_from_modes_and_to_modes(ctx):
+    """WaveformGrid.from_modes and .to_modes as separate steps (scri/waveform_grid.py:331-613, 274-329): the grid against
+    the oracle's from_modes, and from_modes(...).to_modes(ell_max) against the fused transform."""
+    import scri_amd
+    from oracle import waveform_grid_ref as grid_ref
+    from oracle.containers import WM, h, psi3, psi4
+
+    rng = np.random.default_rng(3)
+    n, ell_max = 300, 5
+    t = np.linspace(-5.0, 20.0, n)
+    nm = (ell_max + 1) ** 2 - 4
+    data = (rng.normal(size=nm) + 1j * rng.normal(size=nm))[None, :] * np.exp(1j * np.outer(0.1 * t + 1e-3 * t**2, np.arange(nm) % 5 - 2))
+    kw = dict(supertranslation=real_supertranslation(2, 11, 0.05), frame_rotation=np.array([0.9, 0.1, -0.3, 0.2]) / np.linalg.norm([0.9, 0.1, -0.3, 0.2]),
+              boost_velocity=np.array([0.02, -0.01, 0.03]))
+    w_o = WM(t=t, data=data, ell_min=2, ell_max=ell_max, dataType=h)
+    w_g = scri_amd.WaveformModes(t=t, data=data, ell_min=2, ell_max=ell_max, dataType=scri_amd.h, frameType=scri_amd.Inertial,
+                                 r_is_scaled_out=True, m_is_scaled_out=True, ctx=ctx)
+    uprm, grid, n_theta, n_phi = grid_ref.from_modes(w_o, **kw)
+    g = scri_amd.WaveformGrid.from_modes(w_g, **kw)
+    assert (g.n_theta, g.n_phi) == (n_theta, n_phi) and g.data.shape == (uprm.size, n_theta * n_phi)
+    assert np.abs(g.t - uprm).max() < 1e-13
+    assert np.abs(g.data - grid.reshape(uprm.size, -1)).max() < 2e-12 * np.abs(grid).max()
+    fused = w_g.transform(**kw)
+    two_steps = g.to_modes(ell_max)
+    assert two_steps.ell_min == 2 and two_steps.ell_max == ell_max and np.array_equal(two_steps.t, fused.t)
+    assert np.abs(two_steps.data - fused.data).max() < 2e-13 * np.abs(fused.data).max()
+    assert np.abs(scri_amd.WaveformGrid.transform(w_g, **kw).data - fused.data).max() == 0.0
+    # default ell_max of to_modes comes from the grid size; a psi3 waveform needs its psi4 companion here too
+    assert g.to_modes().ell_max == (n_theta - 1) // 2
+    w3 = scri_amd.WaveformModes(t=t, data=data[:, :], ell_min=2, ell_max=ell_max, dataType=scri_amd.psi3, frameType=scri_amd.Inertial,
+                                r_is_scaled_out=True, m_is_scaled_out=True, ctx=ctx)
+    with pytest.raises(ValueError, match="requires information from"):
+        scri_amd.WaveformGrid.from_modes(w3, **kw)
+    with pytest.raises(TypeError):
+        scri_amd.WaveformGrid.from_modes(data, **kw)
