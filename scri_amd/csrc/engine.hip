@@ -763,21 +763,24 @@ static int build_analysis(bms_ctx* c, const char* tag, int n_theta, int n_phi, i
 }
 
 // G: [rows][2 n_pix] (row stride exactly 2 n_pix doubles) -> out[rows][ldo] complex modes
+static bool analysis_reads_contiguous_rows(const AnalysisPlan& A) { return !A.fused && !A.large && A.separable; }
+
 static int run_analysis(bms_ctx* c, const AnalysisPlan& A, const double* d_G, long long rows, double* d_out, long long ldo,
                         const int* col_of_pixel = nullptr, long long ld_cols = 0) {
   hipStream_t S = c->stream;
-  const long long P2 = 2LL * A.n_pix;
+  const long long P2 = 2LL * A.n_pix, ld = ld_cols ? ld_cols : P2;  // row stride of d_G
   if (A.fused) {
-    TIMED(c, BMS_TAG_ANALYSIS_FUSED, launch_analysis_fused(S, d_G, col_of_pixel ? ld_cols : P2, rows, A.n_theta, A.n_phi, A.L, A.n_out,
+    TIMED(c, BMS_TAG_ANALYSIS_FUSED, launch_analysis_fused(S, d_G, ld, rows, A.n_theta, A.n_phi, A.L, A.n_out,
                                                            A.d_mindex, A.d_T, A.d_dcs, d_out, ldo, col_of_pixel, A.spin));
   } else if (A.large) {
     if (col_of_pixel) return fail(c, BMS_ERR_UNSUPPORTED, "internal: sorted columns need the fused analysis");
     double* d_F;
     int rc = dev_buf_t(c, "Fphi", (size_t)rows * A.nm * large_analysis_jp(A.n_theta) * 2, &d_F);
     if (rc) return rc;
-    TIMED(c, BMS_TAG_GEMM_ANALYSIS, launch_analysis_large(S, d_G, P2, rows, A.n_theta, A.n_phi, A.L, A.ell_min_out, A.d_T, d_F, d_out, ldo));
+    TIMED(c, BMS_TAG_GEMM_ANALYSIS, launch_analysis_large(S, d_G, ld, rows, A.n_theta, A.n_phi, A.L, A.ell_min_out, A.d_T, d_F, d_out, ldo));
   } else if (A.separable) {
     if (col_of_pixel) return fail(c, BMS_ERR_UNSUPPORTED, "internal: sorted columns need the fused analysis");
+    if (ld != P2) return fail(c, BMS_ERR_UNSUPPORTED, "internal: the separable analysis reads contiguous rows");
     double* d_F;
     int rc = dev_buf_t(c, "Fphi", (size_t)rows * A.n_theta * 2 * A.nm, &d_F);
     if (rc) return rc;
@@ -786,7 +789,7 @@ static int run_analysis(bms_ctx* c, const AnalysisPlan& A, const double* d_G, lo
     TIMED(c, BMS_TAG_THETA_QUADRATURE,
           launch_theta_quadrature(S, d_F, rows, A.n_theta, A.nm, A.n_out, A.d_mindex, A.d_T, d_out, ldo));
   } else {
-    TIMED(c, BMS_TAG_GEMM_ANALYSIS, launch_dgemm(S, d_G, P2, A.d_W, A.ldw, d_out, ldo, rows, 2 * A.n_out, (int)P2, nullptr, nullptr));
+    TIMED(c, BMS_TAG_GEMM_ANALYSIS, launch_dgemm(S, d_G, ld, A.d_W, A.ldw, d_out, ldo, rows, 2 * A.n_out, (int)P2, nullptr, nullptr));
   }
   return BMS_OK;
 }
@@ -1273,6 +1276,8 @@ static int transform_modes_impl(bms_ctx* c, const bms_wm_input* in, const bms_tr
   trace.mark("uploads + synthesis matrices");
   AnalysisPlan ana;
   if ((rc = build_analysis(c, "wm", T.n_theta, T.n_phi, s, ell_min_out, tr->ell_max_out, ana))) return rc;
+  // rows of the evaluated grid start on a 128-byte line too (7 % off the back substitution) wherever the consumer takes a stride
+  const long long ldG = (grid_out || (!col_split && analysis_reads_contiguous_rows(ana))) ? P2 : ldg;
   double* d_At = nullptr;
   long long ld_at = 0;
   if (col_split && n_pix > 0)
@@ -1323,13 +1328,13 @@ static int transform_modes_impl(bms_ctx* c, const bms_wm_input* in, const bms_tr
       if ((rc = dev_buf_t(c, "R", (size_t)rows_in * ldg, &d_R))) return rc;  // eliminated rows (either form)
     if (grid_out && in->mem == BMS_DEVICE)
       d_G = (double*)grid_out + (size_t)(c0 - i_lo) * P2;  // straight into the caller's grid
-    else if ((rc = dev_buf_t(c, "G", (size_t)rows_out * P2, &d_G)))
+    else if ((rc = dev_buf_t(c, "G", (size_t)rows_out * ldG, &d_G)))
       return rc;
     if (bs) {
       TIMED(c, BMS_TAG_GEMM_SYNTHESIS, launch_zgemm3m(S, d_Af + (g0 - row0) * ld_af, ld_af, F[0].d_B + 2 * cA, ldb, d_Y, ldg, rows_in, n_pix,
                                                       n_modes_in + 1, nullptr, d_scale));
       TIMED(c, BMS_TAG_SPLINE_BACKWARD, launch_bspline_backward_eval(S, d_Y, ldg, n_pix, g0, rows_in, n, d_x, d_bstab, SPLINE_TILE, SPLINE_HALO, d_x, d_skewa,
-                                                                     d_skewb, T.tt, c0, c1, d_G, P2));
+                                                                     d_skewb, T.tt, c0, c1, d_G, ldG));
     } else {
     if (psi)
       if ((rc = dev_buf_t(c, "Yaux", (size_t)rows_in * ldg, &d_Yaux))) return rc;
@@ -1350,11 +1355,11 @@ static int transform_modes_impl(bms_ctx* c, const bms_wm_input* in, const bms_tr
     if (bsg) {  // mixing is time dependent: eliminate on the grid, then the coefficient-only back substitution
       TIMED(c, BMS_TAG_SPLINE_FORWARD, launch_bspline_forward_modes(S, d_Y, ldg, n_pix, d_R, ldg, g0, rows_in, n, d_bsfwd, SPLINE_TILE, SPLINE_HALO, 0));
       TIMED(c, BMS_TAG_SPLINE_BACKWARD, launch_bspline_backward_eval(S, d_R, ldg, n_pix, g0, rows_in, n, d_x, d_bstab, SPLINE_TILE, SPLINE_HALO, d_x, d_skewa,
-                                                                     d_skewb, T.tt, c0, c1, d_G, P2));
+                                                                     d_skewb, T.tt, c0, c1, d_G, ldG));
     } else {
     TIMED(c, BMS_TAG_SPLINE_FORWARD, launch_spline_forward(S, d_Y, d_R, ldg, n_pix, g0, rows_in, n, d_x, d_tab, spline_tile, SPLINE_HALO));
     TIMED(c, BMS_TAG_SPLINE_BACKWARD, launch_spline_backward_eval(S, d_Y, d_R, ldg, n_pix, g0, rows_in, n, d_x, d_tab, spline_tile, SPLINE_HALO,
-                                           d_x, d_skewa, d_skewb, T.tt, c0, c1, d_G, P2));
+                                           d_x, d_skewa, d_skewb, T.tt, c0, c1, d_G, ldG));
     }
     }
     // analysis
@@ -1363,9 +1368,9 @@ static int transform_modes_impl(bms_ctx* c, const bms_wm_input* in, const bms_tr
         HIP_TRY(c, hipMemcpyAsync((double*)grid_out + (size_t)(c0 - i_lo) * P2, d_G, sizeof(double) * (size_t)rows_out * P2, hipMemcpyDeviceToHost, S));
       if (in->mem == BMS_HOST && c1 < i_hi) HIP_TRY(c, hipStreamSynchronize(S));  // the staging buffer is reused by the next chunk
     } else if (col_split) {
-      TIMED(c, BMS_TAG_GEMM_ANALYSIS, launch_zgemm3m(S, d_G, P2, d_At + (size_t)cA * ld_at, ld_at, d_out + (c0 - i_lo) * n_out * 2, 2LL * n_out,
+      TIMED(c, BMS_TAG_GEMM_ANALYSIS, launch_zgemm3m(S, d_G, ldG, d_At + (size_t)cA * ld_at, ld_at, d_out + (c0 - i_lo) * n_out * 2, 2LL * n_out,
                                                      rows_out, n_out, n_pix, nullptr, nullptr));
-    } else if ((rc = run_analysis(c, ana, d_G, rows_out, d_out + (c0 - i_lo) * n_out * 2, 2LL * n_out, DP.col_of_pixel, P2)))
+    } else if ((rc = run_analysis(c, ana, d_G, rows_out, d_out + (c0 - i_lo) * n_out * 2, 2LL * n_out, DP.col_of_pixel, ldG)))
       return rc;
   }
   trace.mark("chunk loop (enqueue)");
@@ -1956,6 +1961,7 @@ extern "C" int bms_transform_abd_shard(bms_ctx* c, const double* u, const void* 
     }
   }
 
+  const long long ldG = (!col_split && analysis_reads_contiguous_rows(ana[2])) ? P2 : ldg;  // row stride of the evaluated grids
   const double* d_raw;
   if ((rc = stage_in(c, "in_data", raw, mem, (size_t)6 * rows_avail * nm * 16, &d_raw))) return rc;
   double* d_out = (double*)raw_out;
@@ -1995,7 +2001,7 @@ extern "C" int bms_transform_abd_shard(bms_ctx* c, const double* u, const void* 
     double *d_Y, *d_R, *d_G;
     if ((rc = dev_buf_t(c, "Y", (size_t)6 * rows_in * ldg, &d_Y))) return rc;
     if ((rc = dev_buf_t(c, "R", (size_t)6 * rows_in * ldg, &d_R))) return rc;
-    if ((rc = dev_buf_t(c, "G", (size_t)6 * rows_out * P2, &d_G))) return rc;
+    if ((rc = dev_buf_t(c, "G", (size_t)6 * rows_out * ldG, &d_G))) return rc;
     AbdGrids grids;
     for (int f = 0; f < 6; ++f) {
       grids.y[f] = d_Y + (size_t)f * rows_in * ldg;
@@ -2014,22 +2020,22 @@ extern "C" int bms_transform_abd_shard(bms_ctx* c, const double* u, const void* 
     }
     for (int f = 0; f < 6; ++f) {
       double* Rf = d_R + (size_t)f * rows_in * ldg;
-      double* Gf = d_G + (size_t)f * rows_out * P2;
+      double* Gf = d_G + (size_t)f * rows_out * ldG;
       if (bsg) {
         TIMED(c, BMS_TAG_SPLINE_BACKWARD, launch_bspline_backward_eval(S, Rf, ldg, n_pix, g0, rows_in, n, d_x, d_bstab, SPLINE_TILE, SPLINE_HALO,
-                                                                       d_x, d_skewa, d_skewb, T.tt, c0, c1_, Gf, P2));
+                                                                       d_x, d_skewa, d_skewb, T.tt, c0, c1_, Gf, ldG));
       } else {
         TIMED(c, BMS_TAG_SPLINE_FORWARD,
               launch_spline_forward(S, grids.y[f], Rf, ldg, n_pix, g0, rows_in, n, d_x, d_tab, spline_tile, SPLINE_HALO));
         TIMED(c, BMS_TAG_SPLINE_BACKWARD,
               launch_spline_backward_eval(S, grids.y[f], Rf, ldg, n_pix, g0, rows_in, n, d_x, d_tab, spline_tile, SPLINE_HALO,
-                                          d_x, d_skewa, d_skewb, T.tt, c0, c1_, Gf, P2));
+                                          d_x, d_skewa, d_skewb, T.tt, c0, c1_, Gf, ldG));
       }
       double* out_f = d_out + ((size_t)f * fs_out + (c0 - i_lo)) * n_out * 2;
       if (col_split) {
-        TIMED(c, BMS_TAG_GEMM_ANALYSIS, launch_zgemm3m(S, Gf, P2, d_At[spins[f] + 2] + (size_t)cA * ld_at, ld_at, out_f, 2LL * n_out, rows_out, n_out, n_pix,
+        TIMED(c, BMS_TAG_GEMM_ANALYSIS, launch_zgemm3m(S, Gf, ldG, d_At[spins[f] + 2] + (size_t)cA * ld_at, ld_at, out_f, 2LL * n_out, rows_out, n_out, n_pix,
                                                        nullptr, nullptr));
-      } else if ((rc = run_analysis(c, ana[spins[f] + 2], Gf, rows_out, out_f, 2LL * n_out, DP.col_of_pixel, P2)))
+      } else if ((rc = run_analysis(c, ana[spins[f] + 2], Gf, rows_out, out_f, 2LL * n_out, DP.col_of_pixel, ldG)))
         return rc;
     }
   }
