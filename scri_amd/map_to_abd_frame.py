@@ -1,12 +1,13 @@
 """Map an AsymptoticBondiData object to the BMS frame of another one (scri/asymptotic_bondi_data/map_to_abd_frame.py:20-301):
 both objects are taken to their super rest frames and the two transformations composed, iterating on the result.  The data
 passes (transform, interpolate, charges, norms, time integrals) are the GPU building blocks of this package; the
-time/phase fixing step (`fix_time_phase_freedom=True`) is `sxs.waveforms.alignment.align2d`, a third-party minimiser that
-is not part of this build."""
+time/phase fixing step (`fix_time_phase_freedom=True`) uses scri_amd.alignment.align2d, this package's restatement of the
+third-party `sxs.waveforms.alignment.align2d`."""
 import numpy as np
 
 from . import engine
 from .bms_transformations import BMSTransformation
+from .mode_algebra import constant_as_ell_0_mode
 
 NORMAL = ["supertranslation", "frame_rotation", "boost_velocity"]
 
@@ -47,14 +48,30 @@ def map_to_abd_frame(
 ):
     """Transform an abd object to the frame of a target abd object using data around t_0
     (map_to_abd_frame.py:59-301).  Returns (abd_prime, BMSTransformation, rel_err)."""
-    if fix_time_phase_freedom:
-        raise NotImplementedError(
-            "fixing the time and phase freedom needs sxs.waveforms.alignment.align2d, which is outside this build; "
-            "pass fix_time_phase_freedom=False"
-        )
     ctx = getattr(self, "_ctx", None)
     abd = self.copy()
-    BMS = BMSTransformation(ctx=ctx).reorder(NORMAL)
+    target_strain = target_abd.h
+
+    def time_phase(strain, target, t_a, t_b):
+        """the time translation + turn about z that carries `strain` onto `target` on [t_a, t_b], and the alignment's error"""
+        from .alignment import align2d
+
+        err, _, res = align2d(strain, target, t_a, t_b, n_brute_force_δt=None, n_brute_force_δϕ=None, include_modes=None, nprocs=nprocs)
+        half = 0.5 * res.x[1]
+        return err, BMSTransformation(
+            supertranslation=[constant_as_ell_0_mode(res.x[0])], frame_rotation=np.array([np.cos(half), 0.0, 0.0, np.sin(half)]), ctx=ctx
+        )
+
+    time_translation = BMSTransformation(ctx=ctx)
+    if fix_time_phase_freedom:
+        # start from the time at which the Bondi energy is the target's at t_0, so that the two are reasonably close
+        energy = abd.bondi_four_momentum()[:, 0]
+        target_energy = target_abd.bondi_four_momentum()[:, 0]
+        time_translation = BMSTransformation(
+            supertranslation=[constant_as_ell_0_mode(abd.t[np.argmin(abs(energy - target_energy[np.argmin(abs(target_abd.t - t_0))]))] - t_0)],
+            ctx=ctx,
+        )
+    BMS = (time_translation * BMSTransformation(ctx=ctx)).reorder(NORMAL)
     abd_interp = abd.interpolate(
         abd.t[np.argmin(abs(abd.t - (t_0 - 1.5 * padding_time))) : np.argmin(abs(abd.t - (t_0 + 1.5 * padding_time))) + 1]
     )
@@ -62,7 +79,8 @@ def map_to_abd_frame(
         t_0=t_0, padding_time=padding_time, N_itr_maxes=N_itr_maxes, rel_err_tols=rel_err_tols, ell_max=ell_max,
         alpha_ell_max=alpha_ell_max, print_conv=print_conv, order=order,
     )
-    _, transformation2, _ = target_abd.map_to_superrest_frame(**superrest_kw)
+    target_abd_superrest, transformation2, _ = target_abd.map_to_superrest_frame(**superrest_kw)
+    target_strain_superrest = target_abd_superrest.h
 
     def apply(a, B):
         return a.transform(supertranslation=B.supertranslation, frame_rotation=B.frame_rotation.components, boost_velocity=B.boost_velocity)
@@ -74,10 +92,18 @@ def map_to_abd_frame(
         if itr == 0:
             abd_interp_prime = apply(abd_interp, BMS)
         # to the super rest frame, and from there to the target's frame
-        _, transformation1, _ = abd_interp_prime.map_to_superrest_frame(**superrest_kw)
-        BMS = (transformation2.inverse() * (BMSTransformation(ctx=ctx) * (transformation1 * BMS))).reorder(NORMAL)
+        abd_interp_superrest, transformation1, _ = abd_interp_prime.map_to_superrest_frame(**superrest_kw)
+        between = BMSTransformation(ctx=ctx)
+        if fix_time_phase_freedom:  # align in the super rest frame, where only time and phase are left free
+            _, between = time_phase(abd_interp_superrest.h, target_strain_superrest, t_0 - padding_time, t_0 + padding_time)
+        BMS = (transformation2.inverse() * (between * (transformation1 * BMS))).reorder(NORMAL)
         abd_interp_prime = apply(abd_interp, BMS)
-        rel_err = rel_err_between_abds(target_abd, abd_interp_prime, t_0 - padding_time, t_0 + padding_time)
+        if fix_time_phase_freedom:  # and once more in the target's frame
+            rel_err, again = time_phase(abd_interp_prime.h, target_strain, t_0 - padding_time, t_0 + padding_time)
+            BMS = (again * BMS).reorder(NORMAL)
+            abd_interp_prime = apply(abd_interp, BMS)
+        else:
+            rel_err = rel_err_between_abds(target_abd, abd_interp_prime, t_0 - padding_time, t_0 + padding_time)
         if rel_err < min(rel_errs):
             best, best_rel_err = BMS.copy(), rel_err
         rel_errs.append(rel_err)

@@ -8,8 +8,8 @@ Every pass over the data runs on the GPU through the C ABI: `abd.transform` (the
 interpolation (`bms_spline_derivative`).  What is left here is the control loop and the algebra of the BMS group
 (`scri_amd.bms_transformations`).
 
-Built: the target-free iteration and a target Moreschi supermomentum.  Not built: a target strain (needs
-quaternion.optimal_alignment_in_Euclidean_metric) and the "time_phase" step (sxs.waveforms.alignment.align2d).
+Built: the target-free iteration, a target Moreschi supermomentum, a target strain (rotation onto its angular velocity)
+and the "time_phase" step (scri_amd.alignment.align2d, this package's restatement of sxs.waveforms.alignment.align2d).
 """
 import math
 
@@ -162,11 +162,28 @@ def supertranslation_to_map_to_superrest_frame(abd, target_PsiM=None, N_itr_max=
     return BMSTransformation(supertranslation=supertranslation, ell_max=ell_max, ctx=ctx), rel_errs
 
 
-def transformation_from_CoM_charge(G, t, ctx=None):
-    """Space translation and boost velocity from a linear fit G(t) = -v t + x0 of the centre-of-mass charge
-    (Eq. (18) of PhysRevD.104.024051; map_to_superrest_frame.py:322-366 with the default linear model)."""
-    A = np.stack([-np.asarray(t, dtype=float), np.ones(len(t))], axis=1)
-    (v, x0), *_ = np.linalg.lstsq(A, np.asarray(G, dtype=float), rcond=None)
+def transformation_from_CoM_charge(G, t, Gfun=None, Gparams0=None, Gargs=None, ctx=None):
+    """Space translation and boost velocity from a fit of the centre-of-mass charge (Eq. (18) of PhysRevD.104.024051;
+    map_to_superrest_frame.py:322-366): by default the linear model G(t) = -v t + x0, solved directly; with `Gfun(Gparams,
+    time, *Gargs) -> [n, 3]` a nonlinear least-squares fit whose first six parameters are (v, x0)."""
+    if Gfun is None and Gargs is None:
+        A = np.stack([-np.asarray(t, dtype=float), np.ones(len(t))], axis=1)
+        (v, x0), *_ = np.linalg.lstsq(A, np.asarray(G, dtype=float), rcond=None)
+    else:
+        from scipy.optimize import least_squares
+
+        if Gfun is None:
+            Gfun = lambda Gparams, time, *args: -time[:, None] @ Gparams[:3][None, :] + Gparams[3:6][None, :]  # noqa: E731
+        Gparams0 = np.zeros(6) if Gparams0 is None else np.asarray(Gparams0)
+        if not (Gparams0.ndim == 1 and Gparams0.shape[0] >= 6):
+            raise ValueError(
+                "The shape of Gparams0 doesn't match with the expected input for Gfun. Refer to the documentation of "
+                "com_transformation_to_map_to_superrest_frame for the signature of Gfun."
+            )
+        G = np.asarray(G, dtype=float)
+        fit = least_squares(lambda Gparams, time, *args: (G - Gfun(Gparams, time, *args)).ravel(), Gparams0,
+                            args=(np.asarray(t, dtype=float), *(Gargs or ())), method="trf")
+        v, x0 = fit.x[0:3], fit.x[3:6]
     return BMSTransformation(
         supertranslation=-np.insert(vector_as_ell_1_modes(x0), 0, 0),
         boost_velocity=-v,
@@ -188,24 +205,28 @@ def _transform(abd, B):
     )
 
 
-def com_transformation_to_map_to_superrest_frame(abd, N_itr_max=10, rel_err_tol=1e-12, print_conv=False):
+def com_transformation_to_map_to_superrest_frame(abd, N_itr_max=10, rel_err_tol=1e-12, print_conv=False, Gfun=None, Gparams0=None,
+                                                 Gargsfun=None):
     """Iterative solve for the translation and boost that remove the centre-of-mass charge
-    (map_to_superrest_frame.py:369-465)."""
+    (map_to_superrest_frame.py:369-465).  Gfun / Gparams0: model and first guess of the fit (see
+    transformation_from_CoM_charge); Gargsfun: callables of the abd object whose values are passed on to Gfun."""
     ctx = getattr(abd, "_ctx", None)
     CoM = BMSTransformation(ctx=ctx)
     best = BMSTransformation(ctx=ctx)
     itr, rel_err, rel_errs = 0, np.inf, [np.inf]
-    abd_prime = G_prime = None
+    abd_prime = G_prime = Gargs = None
     while itr < N_itr_max and not rel_err < rel_err_tol:
         if itr == 0:
             abd_prime = abd.copy()
             G_prime = abd_prime.bondi_CoM_charge() / abd_prime.bondi_four_momentum()[:, 0, None]
-        new = transformation_from_CoM_charge(G_prime, abd_prime.t, ctx)
+            Gargs = [func(abd_prime) for func in Gargsfun] if Gargsfun else None
+        new = transformation_from_CoM_charge(G_prime, abd_prime.t, Gfun=Gfun, Gparams0=Gparams0, Gargs=Gargs, ctx=ctx)
         CoM = (new * CoM).reorder(NORMAL)
         CoM.supertranslation[4:] *= 0  # keep only the translation ...
         CoM.frame_rotation = type(CoM.frame_rotation)(np.array([1.0, 0, 0, 0]))  # ... and the boost
         abd_prime = _transform(abd, CoM)
         G_prime = abd_prime.bondi_CoM_charge() / abd_prime.bondi_four_momentum()[:, 0, None]
+        Gargs = [func(abd_prime) for func in Gargsfun] if Gargsfun else None
         rel_err = _time_average(np.linalg.norm(G_prime, axis=-1), abd_prime.t, ctx)
         if rel_err < min(rel_errs):
             best = CoM.copy()
@@ -372,9 +393,13 @@ def map_to_superrest_frame(
     order=["supertranslation", "rotation", "CoM_transformation"],
     ell_max=None,
     alpha_ell_max=None,
+    modes=None,
     fix_xz_plane=False,
     fix_yz_plane=False,
     print_conv=False,
+    Gfun=None,
+    Gparams0=None,
+    Gargsfun=None,
 ):
     """Transform an abd object to the super rest frame at time t_0 (or to the frame of a target Moreschi
     supermomentum): map_to_superrest_frame.py:768-1035.  Returns (abd_prime, BMSTransformation, best_rel_err)."""
@@ -382,8 +407,6 @@ def map_to_superrest_frame(
     abd = self.copy()
     if order == []:
         return abd, BMSTransformation(ctx=ctx), None
-    if "time_phase" in order:
-        raise NotImplementedError("the time_phase step needs sxs.waveforms.alignment.align2d, which is outside this build")
     target_strain = None
     if target_strain_input is not None:
         target_strain = target_strain_input.copy()
@@ -429,13 +452,29 @@ def map_to_superrest_frame(
             elif step == "CoM_transformation":
                 new, _ = com_transformation_to_map_to_superrest_frame(
                     abd_sliced_prime, N_itr_max=N_itr_maxes["CoM_transformation"], rel_err_tol=rel_err_tols["CoM_transformation"],
-                    print_conv=print_conv,
+                    print_conv=print_conv, Gfun=Gfun, Gparams0=Gparams0, Gargsfun=Gargsfun,
                 )
+            elif step == "time_phase":
+                # time translation + turn about z that best match the strain to the target's on [-padding, +padding]
+                # (map_to_superrest_frame.py:973-995).  Without a target there is nothing to align to and the step does
+                # nothing (the reference re-applies whatever the previous step found, or fails when it is the first step).
+                new = BMSTransformation(ell_max=ell_max, ctx=ctx)
+                if target_strain is not None:
+                    from .alignment import align2d
+
+                    rel_err, _, res = align2d(
+                        abd_sliced_prime.h, target_strain, 0 - padding_time, 0 + padding_time, n_brute_force_δt=None,
+                        n_brute_force_δϕ=None, include_modes=modes, nprocs=4,
+                    )
+                    new = BMSTransformation(
+                        supertranslation=[constant_as_ell_0_mode(res.x[0])], frame_rotation=_about_z(res.x[1]), ell_max=ell_max, ctx=ctx,
+                    )
             else:
                 raise ValueError(f"unknown step {step!r}")
             BMS = (new * BMS).reorder(NORMAL)
             abd_sliced_prime = _transform(abd_sliced, BMS)
-        rel_err = rel_err_for_abd_in_superrest(abd_sliced_prime, target_PsiM, target_strain)
+        if not (target_strain is not None and order[-1] == "time_phase"):  # else: the alignment's own error
+            rel_err = rel_err_for_abd_in_superrest(abd_sliced_prime, target_PsiM, target_strain)
         if np.mean(rel_err) < min(np.mean(r) for r in rel_errs):
             best_BMS = BMS.copy()
             best_rel_err = rel_err

@@ -104,8 +104,6 @@ def test_abd_to_abd(ctx):
     for name in ("sigma", "psi4", "psi3", "psi2", "psi1", "psi0"):
         assert np.allclose(np.asarray(getattr(ti, name)), np.asarray(getattr(ri, name))), name
     assert rel_err < 1e-8
-    with pytest.raises(NotImplementedError, match="align2d"):
-        abd.map_to_abd_frame(target)
 
 
 def test_rotation_to_a_target_strain(ctx):
@@ -150,5 +148,124 @@ def test_rotation_to_a_target_strain(ctx):
     assert np.abs(turned - axis).max() < 1e-6
     i = slice(n // 4, 3 * n // 4)
     assert np.abs(_news_angular_velocity_direction(rec)[i] - _news_angular_velocity_direction(abd)[i]).max() < 1e-6
-    with pytest.raises(NotImplementedError, match="align2d"):
-        moved.map_to_superrest_frame(t_0=0, padding_time=50, target_strain_input=target_strain, order=["rotation", "time_phase"])
+
+
+def _rotating_quadrupole(ctx, n=4000, ell_max=4):
+    import scri_amd
+
+    u = np.linspace(-300.0, 300.0, n)
+    nm = (ell_max + 1) ** 2
+    sigma = np.zeros((n, nm), dtype=complex)
+    phase = 0.07 * u + 1e-5 * u**2
+    sigma[:, 4 + 4] = 1e-2 * np.exp(-2j * phase) * (1 + 1e-3 * u)
+    sigma[:, 4 + 0] = 1e-2 * np.exp(+2j * phase) * (1 + 1e-3 * u)
+    sigma[:, 9 + 5] = 2e-3 * np.exp(-2j * phase)
+    sigma[:, 9 + 4] = 1e-3 * np.exp(-1j * phase)  # an odd-m mode: fixes the turn about z modulo 2 pi
+    psi2 = np.zeros(nm, dtype=complex)
+    psi2[0] = -np.sqrt(4 * np.pi)
+    return scri_amd.AsymptoticBondiData.from_initial_values(u, ell_max=ell_max, sigma0=sigma, psi2=psi2, ctx=ctx)
+
+
+def test_time_phase_step(ctx):
+    """The "time_phase" step of map_to_superrest_frame (map_to_superrest_frame.py:973-995): data moved by a time translation
+    and a turn about z is brought back onto the target strain by the alignment alone, and the transformation found is the
+    inverse of the one applied."""
+    from scri_amd.mode_algebra import constant_as_ell_0_mode
+
+    abd = _rotating_quadrupole(ctx)
+    dt, dphi = 4.25, 0.8
+    moved = abd.transform(supertranslation=[constant_as_ell_0_mode(dt)], frame_rotation=np.array([np.cos(dphi / 2), 0, 0, np.sin(dphi / 2)]))
+    rec, B, err = moved.map_to_superrest_frame(
+        t_0=0, padding_time=60, target_strain_input=abd.h, order=["time_phase"],
+        N_itr_maxes={"superrest": 1, "CoM_transformation": 10, "rotation": 10, "supertranslation": 10},
+    )
+    assert err < 1e-10
+    assert abs(B.supertranslation[0].real / np.sqrt(4 * np.pi) + dt) < 1e-5
+    assert np.abs(B.supertranslation[1:]).max() < 1e-12 and np.abs(B.boost_velocity).max() == 0
+    found = B.frame_rotation.components
+    assert abs(abs(found[0]) - np.cos(dphi / 2)) < 1e-6 and abs(found[3] / found[0] + np.tan(dphi / 2)) < 1e-6
+    i = slice(1000, 3000)
+    assert np.abs(rec.interpolate(abd.t[i]).sigma.ndarray - abd.sigma.ndarray[i]).max() < 1e-7
+    # after the rotation step (which leaves the turn about the axis free) the alignment completes a generic rotation
+    from scri_amd import quaternions as Q
+
+    q = np.array([1.0, 0.3, -0.2, 0.25])
+    q /= np.linalg.norm(q)
+    rec2, B2, err2 = abd.transform(frame_rotation=q).map_to_superrest_frame(
+        t_0=0, padding_time=60, target_strain_input=abd.h, order=["rotation", "time_phase"],
+        N_itr_maxes={"superrest": 2, "CoM_transformation": 10, "rotation": 10, "supertranslation": 10},
+    )
+    composed = Q.multiply(q, B2.frame_rotation.components)
+    assert min(np.abs(composed - [1, 0, 0, 0]).max(), np.abs(composed + [1, 0, 0, 0]).max()) < 1e-5
+    assert abs(B2.supertranslation[0]) < 1e-4 and np.abs(B2.boost_velocity).max() < 1e-15
+    assert np.abs(rec2.interpolate(abd.t[i]).sigma.ndarray - abd.sigma.ndarray[i]).max() < 1e-6
+    assert err2 < 1e-9  # the alignment's own error is what the iteration reports when time_phase comes last
+    # restricted to a few modes the same optimum is found
+    _, B3, _ = moved.map_to_superrest_frame(
+        t_0=0, padding_time=60, target_strain_input=abd.h, order=["time_phase"], modes=[(2, 2), (2, -2), (3, 1)],
+        N_itr_maxes={"superrest": 1, "CoM_transformation": 10, "rotation": 10, "supertranslation": 10},
+    )
+    assert abs(B3.supertranslation[0] - B.supertranslation[0]) < 1e-5
+    # without a target strain there is nothing to align to: the step does nothing
+    _, B4, _ = moved.map_to_superrest_frame(
+        t_0=0, padding_time=60, order=["time_phase"], N_itr_maxes={"superrest": 1, "CoM_transformation": 10, "rotation": 10, "supertranslation": 10}
+    )
+    assert np.abs(B4.supertranslation).max() < 1e-13 and np.abs(B4.frame_rotation.components - [1, 0, 0, 0]).max() < 1e-13
+
+
+def test_abd_to_abd_with_time_and_phase(ctx):
+    """map_to_abd_frame with fix_time_phase_freedom=True (its default; map_to_abd_frame.py:151-161,211-272) on radiating
+    data: the super rest frame leaves the time and the turn about the spin axis free, and the alignment of the strains fixes
+    them.  The target is the data moved by a full BMS transformation including a time translation and a turn about z."""
+    from scri_amd.mode_algebra import constant_as_ell_0_mode
+
+    abd = _rotating_quadrupole(ctx)
+    st = SUPERTRANSLATION[:9].copy() * 0.3
+    st[0] = constant_as_ell_0_mode(2.5)
+    q = np.array([np.cos(0.35), 0.02, -0.03, np.sin(0.35)])
+    q /= np.linalg.norm(q)
+    target = abd.transform(supertranslation=st, frame_rotation=q, boost_velocity=np.array([1e-4, -2e-4, 1.5e-4]))
+    rec, B, rel_err = abd.map_to_abd_frame(
+        target, t_0=0, padding_time=60,
+        N_itr_maxes={"abd": 2, "superrest": 2, "CoM_transformation": 10, "rotation": 10, "supertranslation": 10},
+    )
+    lo, hi = max(target.t[0], rec.t[0]) + 100, min(target.t[-1], rec.t[-1]) - 100
+    t = np.linspace(lo, hi, 500)
+    a, b = target.interpolate(t), rec.interpolate(t)
+    scale = np.abs(a.sigma.ndarray).max()
+    assert np.abs(a.sigma.ndarray - b.sigma.ndarray).max() < 1e-4 * scale
+    assert rel_err < 1e-7
+    # the time translation and the turn about z were found, not just the rest
+    assert abs(B.supertranslation[0].real / np.sqrt(4 * np.pi) - 2.5) < 1e-2
+    turned = B.frame_rotation.components
+    assert min(np.abs(turned - q).max(), np.abs(turned + q).max()) < 1e-3
+
+
+def test_com_fit_with_a_model_function(ctx):
+    """Gfun / Gparams0 / Gargsfun of the centre-of-mass step (map_to_superrest_frame.py:322-366,369-465): the default linear
+    model passed explicitly as Gfun gives the transformation of the direct solve; extra parameters and arguments reach Gfun."""
+    from scri_amd.map_to_superrest_frame import com_transformation_to_map_to_superrest_frame, transformation_from_CoM_charge
+
+    a, ell_max = _kerr(ctx)
+    moved = a.transform(boost_velocity=np.array([3e-4, -2e-4, 1e-4]), supertranslation=np.array([0.0, 1e-2 - 2e-3j, 3e-3, -1e-2 - 2e-3j]))
+    moved = moved[1000:4000]
+    G = moved.bondi_CoM_charge() / moved.bondi_four_momentum()[:, 0, None]
+    direct = transformation_from_CoM_charge(G, moved.t, ctx=ctx)
+    seen = []
+
+    def model(p, time, mass):
+        seen.append(float(np.mean(mass)))
+        return -time[:, None] @ p[:3][None, :] + p[3:6][None, :] + p[6] * 0.0
+
+    fitted = transformation_from_CoM_charge(G, moved.t, Gfun=model, Gparams0=np.zeros(7), Gargs=[moved.bondi_four_momentum()[:, 0]], ctx=ctx)
+    assert seen and abs(seen[0] - 2.0) < 1e-3
+    assert np.abs(fitted.boost_velocity - direct.boost_velocity).max() < 1e-10
+    assert np.abs(fitted.supertranslation - direct.supertranslation).max() < 1e-8
+    with pytest.raises(ValueError, match="Gparams0"):
+        transformation_from_CoM_charge(G, moved.t, Gfun=model, Gparams0=np.zeros(3), Gargs=[1.0], ctx=ctx)
+    best_d, errs_d = com_transformation_to_map_to_superrest_frame(moved, N_itr_max=3)
+    best_m, errs_m = com_transformation_to_map_to_superrest_frame(
+        moved, N_itr_max=3, Gfun=model, Gparams0=np.zeros(7), Gargsfun=(lambda x: x.bondi_four_momentum()[:, 0],)
+    )
+    assert np.abs(best_m.boost_velocity - best_d.boost_velocity).max() < 1e-9
+    assert abs(errs_m[-1] - errs_d[-1]) < 1e-9
