@@ -1206,7 +1206,7 @@ static int transform_modes_impl(bms_ctx* c, const bms_wm_input* in, const bms_tr
   else
     rc = upload_times(c, in->t, n, t_lo, t_hi, row0, row0 + rows_avail, &d_x, &d_tab);
   if (rc) return rc;
-  const long long ld_af = 2LL * (n_modes + 1);
+  const long long ld_af = round_up(2LL * (n_modes + 1), 16);  // rows on 128-byte lines
   double* d_Af = nullptr;
   if (bs && rows_avail > 0) {
     if ((rc = dev_buf_t(c, "Afwd", (size_t)rows_avail * ld_af, &d_Af))) return rc;
