@@ -146,7 +146,7 @@ typedef double v4d_t __attribute__((ext_vector_type(4)));
 
 constexpr int F_PA = 26;    // LDS pitch (doubles) of the folded operand rows: 2 x odd >= 24 -> conflict-free fragment reads
 constexpr int F_KSMAX = 6;  // k-steps of 4 along the folded ring: n_phi / 2 + 1 <= 24 (kernels are built for 3, 5 and 6)
-constexpr int F_EPT = 4;    // (ring, sample pair) items per thread: n_theta (n_phi/2 + 1) <= 40 x 21 <= 4 x 256 threads
+constexpr int F_EPT_MAX = 4;  // (ring, sample pair) items per thread: n_theta (n_phi/2 + 1) <= 40 x 21 <= 4 x 256 threads (kernels for 2, 3, 4)
 
 struct FusedGeom {
   int n_theta, n_phi, L, n_out;
@@ -179,7 +179,7 @@ __device__ __forceinline__ int fused_row(int j) { return (j >> 3) * 16 + (j & 3)
 // NT: max n_theta (T row length held in registers); NTC: 16-column tiles covering m = 1..L; KS: k-steps.
 // Everything inside the row loop is branch-free on purpose (zero padding instead of bounds tests): a uniform branch
 // around an LDS read makes the compiler wait for each read before issuing the next.
-template <int NT, int NTC, int KS>
+template <int NT, int NTC, int KS, int F_EPT>
 __device__ __forceinline__ void analysis_fused_body(const double* __restrict__ G, long long ldg, long long n_rows,
                                                     const FusedGeom& g, const int* __restrict__ m_index,
                                                     const double* __restrict__ T, const double* __restrict__ Dg,
@@ -221,9 +221,13 @@ __device__ __forceinline__ void analysis_fused_body(const double* __restrict__ G
 
   // this thread's (ring, sample pair) items: global offsets of the two samples, LDS slot of the folded pair.
   // A sample that is its own partner (k = 0, Nyquist) is loaded twice and its partner weighted by 0.
+  // Registers are what limits the rows in flight (two rows ahead are being fetched while one is processed), so the
+  // per-item constants are kept small: a bit per item for "own partner", and the two pole-ring phases a thread can
+  // meet (items of the north ring come with q = 0 only, those of the south ring with one q per thread).
   int slot[F_EPT], off1[F_EPT], off2[F_EPT];
-  double wb[F_EPT];
-  double2 pa[F_EPT], pb[F_EPT], pha[F_EPT], phb[F_EPT];
+  unsigned self_mask = 0;  // bit q: sample pair q is one sample (k = 0 or Nyquist): partner weighted by 0
+  int q_north = -1, q_south = -1;
+  double2 pn_a{1.0, 0.0}, pn_b{1.0, 0.0}, ps_a{1.0, 0.0}, ps_b{1.0, 0.0};
 #pragma unroll
   for (int q = 0; q < F_EPT; ++q) {
     const int e = tid + q * nthreads;
@@ -234,43 +238,56 @@ __device__ __forceinline__ void analysis_fused_body(const double* __restrict__ G
     const int g1 = j * g.n_phi + kk, g2 = j * g.n_phi + k2;
     off1[q] = 2 * (col_of_pixel ? col_of_pixel[g1] : g1);
     off2[q] = 2 * (col_of_pixel ? col_of_pixel[g2] : g2);
-    wb[q] = k2 == kk ? 0.0 : 1.0;
+    if (k2 == kk) self_mask |= 1u << q;
     // a pole ring is stored as its pixel k = 0: pixel k is that value times e^{-i s phi_k} (north) / e^{+i s phi_k} (south)
-    double a1 = 0.0, a2 = 0.0;
     if (col_of_pixel && ok && (j == 0 || j == g.n_theta - 1)) {
       const double sg = j == 0 ? -1.0 : 1.0;
-      a1 = sg * (double)((g.spin * kk) % g.n_phi) / (double)g.n_phi;
-      a2 = sg * (double)((g.spin * k2) % g.n_phi) / (double)g.n_phi;
+      const double a1 = sg * (double)((g.spin * kk) % g.n_phi) / (double)g.n_phi;
+      const double a2 = sg * (double)((g.spin * k2) % g.n_phi) / (double)g.n_phi;
+      double2 fa, fb;
+      sincospi(2.0 * a1, &fa.y, &fa.x);
+      sincospi(2.0 * a2, &fb.y, &fb.x);
+      if (j == 0 && g.n_theta > 1) {
+        q_north = q;
+        pn_a = fa;
+        pn_b = fb;
+      } else {
+        q_south = q;
+        ps_a = fa;
+        ps_b = fb;
+      }
     }
-    sincospi(2.0 * a1, &pha[q].y, &pha[q].x);
-    sincospi(2.0 * a2, &phb[q].y, &phb[q].x);
   }
-  auto fetch = [&](long long t) {
+  // two rows in flight where the registers allow it (up to 3 items per thread), else one
+  constexpr int AHEAD = F_EPT <= 3 ? 2 : 1;
+  double2 pa0[F_EPT], pb0[F_EPT], pa1[F_EPT], pb1[F_EPT];
+  auto fetch = [&](long long t, double2(&pa)[F_EPT], double2(&pb)[F_EPT]) {
 #pragma unroll
     for (int q = 0; q < F_EPT; ++q) {
       pa[q] = *reinterpret_cast<const double2*>(G + t * ldg + off1[q]);
       pb[q] = *reinterpret_cast<const double2*>(G + t * ldg + off2[q]);
     }
   };
-  long long t = blockIdx.x;
-  if (t < n_rows) fetch(t);
-  __syncthreads();
-  for (; t < n_rows; t += gridDim.x) {
+  const long long stride = gridDim.x;
+  auto one_row = [&](const long long t, double2(&pa)[F_EPT], double2(&pb)[F_EPT]) {
     // ---- step 0: fold into the operands
 #pragma unroll
     for (int q = 0; q < F_EPT; ++q) {
-      const double ax = pa[q].x * pha[q].x - pa[q].y * pha[q].y, ay = pa[q].x * pha[q].y + pa[q].y * pha[q].x;
-      const double bx = wb[q] * (pb[q].x * phb[q].x - pb[q].y * phb[q].y), by = wb[q] * (pb[q].x * phb[q].y + pb[q].y * phb[q].x);
+      const double2 fa = q == q_north ? pn_a : (q == q_south ? ps_a : double2{1.0, 0.0});
+      const double2 fb = q == q_north ? pn_b : (q == q_south ? ps_b : double2{1.0, 0.0});
+      const double w = (self_mask >> q) & 1u ? 0.0 : 1.0;
+      const double ax = pa[q].x * fa.x - pa[q].y * fa.y, ay = pa[q].x * fa.y + pa[q].y * fa.x;
+      const double bx = w * (pb[q].x * fb.x - pb[q].y * fb.y), by = w * (pb[q].x * fb.y + pb[q].y * fb.x);
       if (slot[q] >= 0) {
         Es[slot[q]] = ax + bx;
         Es[slot[q] + 4 * F_PA] = ay + by;
-        Os[slot[q]] = wb[q] * ax - bx;
-        Os[slot[q] + 4 * F_PA] = wb[q] * ay - by;
+        Os[slot[q]] = w * ax - bx;
+        Os[slot[q] + 4 * F_PA] = w * ay - by;
       }
     }
     __syncthreads();  // operands complete; every thread has finished step 2 of the previous row
-    const long long tn = t + gridDim.x;
-    if (tn < n_rows) fetch(tn);
+    const long long tn = t + AHEAD * stride;
+    if (tn < n_rows) fetch(tn, pa, pb);
     // ---- step 1: one 16-row tile (8 rings) per wave trip
     for (int tm = wave; tm < g.mt; tm += nwaves) {
       const double* ep = Es + (tm * 16 + fi) * F_PA + fk;
@@ -344,23 +361,36 @@ __device__ __forceinline__ void analysis_fused_body(const double* __restrict__ G
       }
       *reinterpret_cast<double2*>(out + t * ldo + 2LL * o2) = double2{pr0 + pr1, pi0 + pi1};
     }
+  };
+  long long t = blockIdx.x;
+  if (t < n_rows) fetch(t, pa0, pb0);
+  if constexpr (AHEAD == 2) {
+    if (t + stride < n_rows) fetch(t + stride, pa1, pb1);
+    __syncthreads();
+    for (; t < n_rows; t += 2 * stride) {
+      one_row(t, pa0, pb0);
+      if (t + stride < n_rows) one_row(t + stride, pa1, pb1);
+    }
+  } else {
+    __syncthreads();
+    for (; t < n_rows; t += stride) one_row(t, pa0, pb0);
   }
 }
 
-template <int NT, int KS>
+template <int NT, int KS, int EPT>
 __global__ __launch_bounds__(512) void analysis_fused_kernel(
     const double* __restrict__ G, long long ldg, long long n_rows, FusedGeom g, const int* __restrict__ m_index,
     const double* __restrict__ T, const double* __restrict__ Dg, double* __restrict__ out, long long ldo,
     const int* __restrict__ col_of_pixel) {
-  analysis_fused_body<NT, 1, KS>(G, ldg, n_rows, g, m_index, T, Dg, out, ldo, col_of_pixel);
+  analysis_fused_body<NT, 1, KS, EPT>(G, ldg, n_rows, g, m_index, T, Dg, out, ldo, col_of_pixel);
 }
 // 16 < L <= 32: two column tiles per product
-template <int NT, int KS>
+template <int NT, int KS, int EPT>
 __global__ __launch_bounds__(512) void analysis_fused_wide_kernel(
     const double* __restrict__ G, long long ldg, long long n_rows, FusedGeom g, const int* __restrict__ m_index,
     const double* __restrict__ T, const double* __restrict__ Dg, double* __restrict__ out, long long ldo,
     const int* __restrict__ col_of_pixel) {
-  analysis_fused_body<NT, 2, KS>(G, ldg, n_rows, g, m_index, T, Dg, out, ldo, col_of_pixel);
+  analysis_fused_body<NT, 2, KS, EPT>(G, ldg, n_rows, g, m_index, T, Dg, out, ldo, col_of_pixel);
 }
 
 static int fused_ks(int n_phi) {
@@ -432,19 +462,29 @@ hipError_t launch_analysis_fused(hipStream_t stream, const double* G, long long 
   const long long blocks = n_rows < max_blocks ? n_rows : max_blocks;
   const dim3 grid((unsigned)blocks), block(threads);
 #define FUSED_GO(K) return launch_fused_t(K, stream, grid, block, lds, G, ldg, n_rows, g, m_index, T, D, out, ldo, col_of_pixel)
-#define FUSED_KS(NT)                                       \
-  if (L <= 16) {                                           \
-    if (g.ks == 3) FUSED_GO((analysis_fused_kernel<NT, 3>)); \
-    if (g.ks == 5) FUSED_GO((analysis_fused_kernel<NT, 5>)); \
-    FUSED_GO((analysis_fused_kernel<NT, 6>));                \
-  }                                                        \
-  if (g.ks == 3) FUSED_GO((analysis_fused_wide_kernel<NT, 3>)); \
-  if (g.ks == 5) FUSED_GO((analysis_fused_wide_kernel<NT, 5>)); \
-  FUSED_GO((analysis_fused_wide_kernel<NT, 6>));
+#define FUSED_EPT(KERNEL, NT, KS)                        \
+  {                                                      \
+    if (ept <= 2) FUSED_GO((KERNEL<NT, KS, 2>));         \
+    if (ept == 3) FUSED_GO((KERNEL<NT, KS, 3>));         \
+    FUSED_GO((KERNEL<NT, KS, 4>));                       \
+  }
+#define FUSED_KS(NT)                                              \
+  if (L <= 16) {                                                  \
+    if (g.ks == 3) FUSED_EPT(analysis_fused_kernel, NT, 3)        \
+    if (g.ks == 5) FUSED_EPT(analysis_fused_kernel, NT, 5)        \
+    FUSED_EPT(analysis_fused_kernel, NT, 6)                       \
+  }                                                               \
+  if (g.ks == 3) FUSED_EPT(analysis_fused_wide_kernel, NT, 3)     \
+  if (g.ks == 5) FUSED_EPT(analysis_fused_wide_kernel, NT, 5)     \
+  FUSED_EPT(analysis_fused_wide_kernel, NT, 6)
+  // items per thread of the fold: as few as the grid needs (each one costs registers for the two rows in flight)
+  const int ept = (n_theta * g.nk + threads - 1) / threads;
+  if (ept > F_EPT_MAX) return hipErrorInvalidValue;
   if (n_theta <= 24) {
     FUSED_KS(24)
   }
   FUSED_KS(40)
+#undef FUSED_EPT
 #undef FUSED_KS
 #undef FUSED_GO
 }
