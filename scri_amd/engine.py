@@ -5,6 +5,7 @@ pointers (ints, e.g. ``torch.Tensor.data_ptr()``) for callers that keep data res
 The scri-compatible classes in ``scri_amd.waveform_modes`` etc. are built on top of these.
 """
 import ctypes
+import os
 import numpy as np
 
 from . import _lib
@@ -113,6 +114,69 @@ def make_transformation(supertranslation, frame_rotation, boost_velocity, n_thet
     return tr
 
 
+# Host arrays in and out: below this size one call moves the data and computes; above it the time axis is pipelined
+PIPELINE_MIN_BYTES = 64 << 20
+PIPELINE_PIECES = int(os.environ.get("SCRI_AMD_PIPELINE_PIECES", "6"))  # 26.9 ms unpipelined, 22.5-24.8 at 4, 21.5 at 6, 25 at 8 (cfg3)
+
+
+def _transform_modes_pipelined(t, data, inp, transformation, n_out, ctx):
+    """Host-memory callers of a long series wait for PCIe, not for the kernels (cfg3: 456 MB each way against 6 ms of
+    kernels), and one call does upload -> kernels -> download one after the other.  Here the output range is cut into
+    PIPELINE_PIECES time shards (bms_shard_plan names the input rows each one needs, exactly as for the multi-GPU split),
+    which run alternately on two contexts from two threads: the upload of one shard, the kernels of the next and the
+    download of a third overlap (PCIe is full duplex).  Results are those of the sharded path (equal to the one-call path
+    to rounding; tests/test_gpu_sharding.py).  Returns None when the series cannot be sharded (graded time steps)."""
+    import threading
+
+    n = t.shape[0]
+    i_lo, i_hi = output_window(t, transformation, ctx=ctx)
+    n_new = i_hi - i_lo
+    if n_new < 8 * PIPELINE_PIECES:
+        return None
+    peer = getattr(ctx, "_pipeline_peer", None)
+    if peer is None:
+        peer = _lib.Context(ctx.device)
+        ctx._pipeline_peer = peer
+    cuts = [i_lo + (n_new * k) // PIPELINE_PIECES for k in range(PIPELINE_PIECES + 1)]
+    out = _lib.pinned_empty((n_new, n_out), np.complex128)
+    t_out = np.empty(n_new, dtype=float)
+    lib = _lib.load()
+    errors = [None, None]
+
+    def run(which, context):
+        try:
+            for k in range(which, PIPELINE_PIECES, 2):
+                a, b = cuts[k], cuts[k + 1]
+                (r0, r1), _ = shard_plan(t, transformation, a, b)
+                piece = bms_wm_input()
+                ctypes.memmove(ctypes.byref(piece), ctypes.byref(inp), ctypes.sizeof(piece))
+                piece.data = data[r0:].ctypes.data
+                sh = bms_shard(int(r0), int(r1 - r0), int(a), int(b))
+                got, first = c_i64(0), c_i64(0)
+                rc = lib.bms_transform_modes_shard(
+                    context.handle, ctypes.byref(piece), ctypes.byref(transformation), ctypes.byref(sh),
+                    dptr(t_out[a - i_lo :]),
+                    vptr(out[a - i_lo :]), ctypes.byref(got), ctypes.byref(first),
+                )
+                context.check(rc, "bms_transform_modes")
+                if got.value != b - a or first.value != a:
+                    raise RuntimeError(f"pipelined shard [{a}, {b}) produced {got.value} rows from {first.value}")
+        except BaseException as e:  # noqa: BLE001 -- re-raised by the caller's thread
+            errors[which] = e
+
+    other = threading.Thread(target=run, args=(1, peer))
+    other.start()
+    run(0, ctx)
+    other.join()
+    for e in errors:
+        if isinstance(e, NotImplementedError):  # a series the engine does not shard: the one-call path handles it
+            return None
+    for e in errors:
+        if e is not None:
+            raise e
+    return t_out, out
+
+
 def transform_modes(
     t,
     data,
@@ -204,6 +268,10 @@ def transform_modes(
         rc = _lib.load().bms_modes_to_grid(ctx.handle, ctypes.byref(inp), ctypes.byref(transformation), dptr(t_out), vptr(out), ctypes.byref(n_new))
         ctx.check(rc, "bms_modes_to_grid")
         return t_out[: n_new.value], out[: n_new.value]
+    if shard is None and not aux and data.nbytes >= PIPELINE_MIN_BYTES and not os.environ.get("SCRI_AMD_NO_PIPELINE"):
+        res = _transform_modes_pipelined(t, data, inp, transformation, n_out, ctx)
+        if res is not None:
+            return res
     out = _lib.pinned_empty((max(n_alloc, 1), n_out), np.complex128)
     rc = _lib.load().bms_transform_modes_shard(
         ctx.handle, ctypes.byref(inp), ctypes.byref(transformation), shp, dptr(t_out), vptr(out), ctypes.byref(n_new),

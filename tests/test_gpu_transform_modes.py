@@ -96,3 +96,48 @@ def test_waveform_grid_from_modes_and_to_modes(ctx):
         scri_amd.WaveformGrid.from_modes(w3, **kw)
     with pytest.raises(TypeError):
         scri_amd.WaveformGrid.from_modes(data, **kw)
+
+
+def test_pipelined_host_path_matches_the_one_call_path(ctx, monkeypatch):
+    """Host arrays above engine.PIPELINE_MIN_BYTES go through time shards on two contexts (upload, kernels and download of
+    neighbouring shards overlapping); the result is the one-call result to rounding, times included, and a series the
+    engine does not shard (graded time steps) quietly takes the one-call path."""
+    import scri_amd
+    from scri_amd import engine
+
+    rng = np.random.default_rng(5)
+    n, ell_max = 6000, 6
+    t = np.sort(rng.uniform(0.0, 600.0, n))
+    t[1:] = np.maximum(t[1:], t[:-1] + 1e-3)
+    nm = (ell_max + 1) ** 2 - 4
+    data = rng.standard_normal((n, nm)) + 1j * rng.standard_normal((n, nm))
+    kw = dict(
+        supertranslation=np.array([0.3, 0.02 - 0.01j, 0.05, -0.02 - 0.01j]), boost_velocity=[0.01, -0.02, 0.015],
+        frame_rotation=[0.9, 0.1, -0.3, 0.2],
+    )
+
+    def run(times):
+        w = scri_amd.WaveformModes(t=times, data=data, ell_min=2, ell_max=ell_max, dataType=scri_amd.h, frameType=scri_amd.Inertial,
+                                   r_is_scaled_out=True, m_is_scaled_out=True, ctx=ctx)
+        return w.transform(**kw)
+
+    monkeypatch.setenv("SCRI_AMD_NO_PIPELINE", "1")
+    plain = run(t)
+    monkeypatch.delenv("SCRI_AMD_NO_PIPELINE")
+    calls = []
+    real = engine._transform_modes_pipelined
+    monkeypatch.setattr(engine, "_transform_modes_pipelined", lambda *a: calls.append(1) or real(*a))
+    monkeypatch.setattr(engine, "PIPELINE_MIN_BYTES", 1 << 16)
+    piped = run(t)
+    assert calls == [1]
+    assert piped.t.shape == plain.t.shape and np.array_equal(piped.t, plain.t)
+    assert np.abs(piped.data - plain.data).max() < 1e-12 * np.abs(plain.data).max()
+    # geometric grading: not shardable -> falls back, same answer as with the pipeline switched off
+    kw = dict(supertranslation=kw["supertranslation"])
+    tg = np.cumsum(np.concatenate([np.full(3000, 0.1), 0.1 * 1.2 ** np.arange(1, 51), np.full(n - 3050, 0.1 * 1.2**50)]))
+    monkeypatch.setenv("SCRI_AMD_NO_PIPELINE", "1")
+    plain_g = run(tg)
+    monkeypatch.delenv("SCRI_AMD_NO_PIPELINE")
+    piped_g = run(tg)
+    assert len(calls) == 2
+    assert np.array_equal(piped_g.data, plain_g.data)
