@@ -282,6 +282,9 @@ class Context:
         return self._h
 
     def close(self):
+        peer = self.__dict__.pop("_pipeline_peer", None)  # second context of engine._transform_modes_pipelined
+        if peer is not None:
+            peer.close()
         if getattr(self, "_h", None):
             load().bms_ctx_destroy(self._h)
             self._h = None
