@@ -183,8 +183,8 @@ def rotation_line(local, ell_max, ctx, cpu_steps):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default="cfg3", choices=["cfg2", "cfg3", "cfg5"])
     ap.add_argument("--n-times", type=int, default=None, help="time steps PER GPU (default: 1e5; cfg5: 2e5 / 8)")
     ap.add_argument("--working-ell-max", type=int, default=None, help="cfg5 only (default 2 ell_max + 1 = 49 -> 99 x 99 grid)")
