@@ -30,9 +30,46 @@ def real_supertranslation(alpha):
 # supertranslation of tests/test_bms_transformations.py:298 of the reference (made real), x 1e-3
 S9 = real_supertranslation(np.array([1, 2 + 4j, 3, -2 + 4j, 7 - 5j, -3 - 2j, 4, 3 - 2j, 7 + 5j]) * 1e-3)
 
+def rotor_series(t, seed, omega=8 * np.pi / 110.0, q0=None):
+    """R(t) = exp(n omega t / 2) [* q0]: rotation about a fixed random axis n (seed) at angular velocity omega -- the
+    `R_basis` series of the reference's rotation tests (tests/conftest.py:84-87) -- as a float array [N, 4] (w, x, y, z)."""
+    rng = np.random.default_rng(seed)
+    axis = rng.normal(size=3)
+    axis /= np.linalg.norm(axis)
+    half = 0.5 * omega * np.asarray(t, dtype=float)
+    R = np.empty((half.shape[0], 4))
+    R[:, 0] = np.cos(half)
+    R[:, 1:] = np.sin(half)[:, None] * axis[None, :]
+    if q0 is not None:  # quaternion product R(t) * q0
+        a, b = R, np.asarray(q0, dtype=float)
+        R = np.stack([
+            a[:, 0] * b[0] - a[:, 1] * b[1] - a[:, 2] * b[2] - a[:, 3] * b[3],
+            a[:, 0] * b[1] + a[:, 1] * b[0] + a[:, 2] * b[3] - a[:, 3] * b[2],
+            a[:, 0] * b[2] - a[:, 1] * b[3] + a[:, 2] * b[0] + a[:, 3] * b[1],
+            a[:, 0] * b[3] + a[:, 1] * b[2] - a[:, 2] * b[1] + a[:, 3] * b[0],
+        ], axis=1)
+    return R
+
+
+Q1234 = np.array([1.0, 2, 3, 4]) / np.sqrt(30)
+
+
+def cfg1():
+    """BASELINE.json configs[0] / SURVEY 8(d) cfg1: h, l = 2..4, t = linspace(-10, 100, 2000),
+    data[t, (l,m)] = a_lm exp(i m 0.3 t) (seed 1); rotations: (i) constant q = (1,2,3,4)/sqrt(30), (ii) the series
+    exp(n omega t / 2), omega = 8 pi / 110 (seed 2).  Returns (t, data, dict(constant=q, series=R[N, 4]))."""
+    t = np.linspace(-10.0, 100.0, 2000)
+    rng = np.random.default_rng(1)
+    LM = LM_range(2, 4)
+    a = rng.normal(size=LM.shape[0]) + 1j * rng.normal(size=LM.shape[0])
+    data = a[None, :] * np.exp(1j * LM[None, :, 1] * 0.3 * t[:, None])
+    return t, data, dict(constant=Q1234.copy(), series=rotor_series(t, 2))
+
+
 CONFIGS = {
     # name: (ell_max, n_times, dt, seed, transformation kwargs)
-    "cfg2": dict(ell_max=8, n_times=100_000, dt=0.1, seed=3, kwargs=dict(supertranslation=S9)),
+    # cfg2: rotation by `rotor_series(t, 4, omega = 8 pi / (t[-1] - t[0]))` first, then the supertranslation
+    "cfg2": dict(ell_max=8, n_times=100_000, dt=0.1, seed=3, rotation_seed=4, kwargs=dict(supertranslation=S9)),
     "cfg3": dict(
         ell_max=16, n_times=100_000, dt=0.1, seed=5,
         kwargs=dict(supertranslation=S9, frame_rotation=np.array([1.0, 2, 3, 4]) / np.sqrt(30), boost_velocity=np.array([1.0, 2, 3]) * 1e-4),

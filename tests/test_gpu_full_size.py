@@ -95,17 +95,33 @@ def test_cfg3_chunks_and_shards_equal_whole(cfg3):
     assert np.abs(np.concatenate(parts) - out.data).max() < 1e-14 * np.abs(out.data).max()
 
 
-def test_cfg2_rotation_round_trip_and_unitarity(ctx):
+def _window_check(out_t, out_data, t_in, data_in, kw, ell_max, windows, margin=60, tol=1e-12):
+    """Windows of a full-size output against the oracle run on slices of the input: `windows` = [(i0, rows)]; the oracle's
+    own first / last `margin` outputs see a truncated spline and are left out."""
+    worst = 0.0
+    for i0, rows in windows:
+        sl = slice(i0, i0 + rows)
+        e = grid_ref.transform(WM(t=t_in[sl], data=data_in[sl], ell_min=2, ell_max=ell_max, dataType=h), **kw)
+        assert e.n_times > 2 * margin + 50, (i0, e.n_times)
+        keep = e.t[margin:-margin]
+        gi = np.searchsorted(out_t, keep - 1e-9)
+        assert np.abs(out_t[gi] - keep).max() < 1e-13 * max(1.0, abs(keep[-1])), i0
+        err = np.abs(out_data[gi] - e.data[margin:-margin]).max()
+        assert err < tol * max(1.0, np.abs(e.data).max()), (i0, err)
+        worst = max(worst, err)
+    return worst
+
+
+def test_cfg2_full_size_rotation_then_supertranslation(ctx):
+    """BASELINE.json configs[1] at full size (l <= 8, 1e5 steps): the series rotation (seed 4), then the supertranslation.
+    Size-independent properties of the rotation (unitarity per l block, R then R^-1), and WINDOWS of both full-size
+    results against the oracle chain (rotations_ref.rotate_by_series, then grid_ref.transform) run on input slices."""
+    from oracle import rotations_ref
     from scri_amd import synthetic
 
     t, data, spec = synthetic.workload("cfg2")
     assert data.shape == (N, 77)
-    rng = np.random.default_rng(4)
-    axis = rng.normal(size=3)
-    axis /= np.linalg.norm(axis)
-    half = np.zeros((N, 4))
-    half[:, 1:] = axis[None, :] * (8 * np.pi / (t[-1] - t[0]) * t / 2)[:, None]
-    R = quat.qmul(quat.qexp(half), (np.array([1.0, 2, 3, 4]) / np.sqrt(30))[None, :])
+    R = synthetic.rotor_series(t, spec["rotation_seed"], omega=8 * np.pi / (t[-1] - t[0]), q0=synthetic.Q1234)
     w = _gpu_wm(t, data.copy(), 8, h, ctx)
     w.rotate_decomposition_basis(R)
     for ell in range(2, 9):  # |f_l|^2 is invariant under rotations
@@ -114,11 +130,132 @@ def test_cfg2_rotation_round_trip_and_unitarity(ctx):
         n1 = (np.abs(w.data[:, blk]) ** 2).sum(axis=1)
         assert np.abs(n1 - n0).max() < 1e-13 * n0.max()
     assert np.abs(w.data - data).max() > 1e-3
-    # the second half of cfg2: supertranslate the rotated series; then undo the rotation of the untransformed copy
+    rotated = w.data.copy()
     out = w.transform(**spec["kwargs"])
-    assert out.n_times > N - 10
+    assert N - 10 < out.n_times <= N and np.all(np.diff(out.t) > 0)
+    for i0 in (0, 31_000, N - 400):
+        sl = slice(i0, i0 + 400)
+        rot_o = rotations_ref.rotate_by_series(data[sl], quat.as_spinor_array(R[sl]), 2, 8)
+        assert np.abs(rotated[sl] - rot_o).max() < 8e-13 * np.abs(data).max()  # the suite's 1e-13 l_max bar
+        _window_check(out.t, out.data, t[sl], rot_o, spec["kwargs"], 8, [(0, 400)])
     w.rotate_decomposition_basis(quat.qconj(R))
     assert np.abs(w.data - data).max() < 2e-13 * np.abs(data).max()
+
+
+def test_cfg1_rotations_match_oracle(ctx):
+    """BASELINE.json configs[0]: l = 2..4, 2000 steps, constant rotor and rotor series, through
+    bms_rotate_const / bms_rotate_series against the restated numba kernels (scri/rotations.py:346-392)."""
+    from oracle import rotations_ref, wigner
+    from scri_amd import engine, synthetic
+
+    t, data, rot = synthetic.cfg1()
+    assert data.shape == (2000, 21)
+    q = rot["constant"]
+    Ra, Rb = quat.as_spinor_array(q)
+    expect = rotations_ref.rotate_by_constant(data, 2, 4, wigner.wigner_D_matrices(Ra, Rb, 2, 4))
+    got = engine.rotate_const(data.copy(), 2, 4, q, ctx=ctx)
+    assert np.abs(got - expect).max() < 4e-13 * np.abs(data).max()
+    sp = quat.as_spinor_array(rot["series"])
+    expect = rotations_ref.rotate_by_series(data, sp, 2, 4)
+    got = engine.rotate_series(data.copy(), 2, 4, sp, ctx=ctx)
+    assert np.abs(got - expect).max() < 4e-13 * np.abs(data).max()
+    # the same through the scri-compatible class (frame bookkeeping of rotations.py:313-335)
+    w = _gpu_wm(t, data.copy(), 4, h, ctx)
+    w.rotate_decomposition_basis(rot["series"])
+    assert np.array_equal(w.data, got) and np.abs(w.frame - rot["series"]).max() == 0.0
+
+
+@pytest.fixture(scope="module")
+def cfg4(ctx):
+    """BASELINE.json configs[3] on ONE GPU: l <= 16, 1e6 steps (4.56 GB of modes), walked in chunks of the work space."""
+    from scri_amd import synthetic
+
+    t, data, spec = synthetic.workload("cfg4")
+    assert data.shape == (1_000_000, 285)
+    out = _gpu_wm(t, data, 16, h, ctx).transform(**spec["kwargs"])
+    return t, data, spec["kwargs"], out
+
+
+def test_cfg4_windows_match_oracle(cfg4):
+    """Start / middle / end of the 1e6-step output against the oracle on input slices.  The boost skews the time axis of a
+    direction by up to beta |u| / dt = 374 rows at the end of the series, which the oracle's window trims from each side of
+    its slice: the late slices are longer."""
+    t, data, kw, out = cfg4
+    assert 999_500 < out.n_times <= 1_000_000 and np.all(np.diff(out.t) > 0)
+    _window_check(out.t, out.data, t, data, kw, 16, [(0, 400), (500_000, 900), (1_000_000 - 1300, 1300)])
+
+
+def test_cfg4_eight_shards_equal_whole(cfg4, ctx):
+    """The 8 time shards of sharding.plan (each with its own halo rows only), run one after the other on this GPU,
+    reassemble to the one-GPU result."""
+    from scri_amd import engine, sharding
+
+    t, data, kw, out = cfg4
+    tr = engine.make_transformation(kw["supertranslation"], kw["frame_rotation"], kw["boost_velocity"], 37, 37, 16)
+    have, need, window = sharding.plan(t, tr, 8)
+    assert window[1] - window[0] == out.n_times
+    scale = np.abs(out.data).max()
+    row = 0
+    for r in range(8):
+        ext = data[need[r][0] : need[r][1]]
+        tp, dp, first = engine.transform_modes(t, ext, 2, 16, -2, -1, engine.BMS_TERM_H, tr, ctx=ctx,
+                                               shard=(need[r][0], ext.shape[0], have[r][0], have[r][1]))
+        assert first == window[0] + row
+        assert np.array_equal(tp, out.t[row : row + tp.shape[0]])
+        assert np.abs(dp - out.data[row : row + dp.shape[0]]).max() < 1e-14 * scale
+        row += dp.shape[0]
+    assert row == out.n_times
+
+
+def _abd_window_check(got_u, got_raw, kw, ell_max, windows, margin=60):
+    """As _window_check for the six ABD fields of cfg5.  The oracle's input rows are generated on their own from the
+    definition of the global series, so a window may straddle the shard's edge: the comparison then covers the rows the
+    shard produced (those are the ones that needed its halo)."""
+    from oracle import abd_ref
+    from oracle.containers import ABD
+    from scri_amd import synthetic
+
+    for i0, rows in windows:
+        u_in, raw_in, _ = synthetic.abd_workload("cfg5", rows=(i0, i0 + rows))
+        e = abd_ref.transform(ABD(u_in[i0 : i0 + rows], raw_in, ell_max), **kw)
+        sel = np.zeros(e.n_times, dtype=bool)
+        sel[margin:-margin] = True
+        sel &= (e.u >= got_u[0] - 1e-9) & (e.u <= got_u[-1] + 1e-9)
+        assert sel.sum() > 100, (i0, e.n_times, int(sel.sum()))
+        keep = e.u[sel]
+        gi = np.searchsorted(got_u, keep - 1e-9)
+        assert np.abs(got_u[gi] - keep).max() < 1e-13 * max(1.0, abs(keep[-1])), i0
+        scale = max(1.0, np.abs(e.raw).max())
+        for f, name in enumerate(("psi0", "psi1", "psi2", "psi3", "psi4", "sigma")):
+            err = np.abs(got_raw[f][gi] - e.raw[f][sel]).max()
+            assert err < 1e-12 * scale, (i0, name, err)
+
+
+@pytest.mark.parametrize("rank", [0, 7])
+def test_cfg5_shard_six_fields_match_oracle(ctx, rank):
+    """BASELINE.json configs[4]: AsymptoticBondiData, all six fields non-zero, l <= 24, 2e5 steps, working_ell_max = 49 ->
+    99 x 99 grid; the 25 000-step time shard of rank 0 and of rank 7 (largest time skew) of the 8-GPU plan, each from its
+    own rows + halo, against the oracle (scri/asymptotic_bondi_data/transformations.py:199-431 restated) on input slices."""
+    from scri_amd import engine, sharding, synthetic
+
+    spec = synthetic.CONFIGS["cfg5"]
+    kw = spec["kwargs"]
+    n, L = spec["n_times"], spec["ell_max"]
+    u = np.arange(n) * spec["dt"]
+    tr = engine.make_transformation(kw["supertranslation"], kw["frame_rotation"], kw["boost_velocity"], 99, 99, L)
+    have, need, window = sharding.plan(u, tr, 8)
+    assert have[rank][1] - have[rank][0] == 25_000
+    _, raw, _ = synthetic.abd_workload("cfg5", rows=need[rank])
+    assert all(np.abs(raw[f]).max() > 0.01 for f in range(6))
+    got_u, got_raw, first = engine.transform_abd(u, raw, L, tr, ctx=ctx,
+                                                 shard=(need[rank][0], raw.shape[1], have[rank][0], have[rank][1]))
+    lo, hi = max(have[rank][0], window[0]), min(have[rank][1], window[1])
+    assert abs(first - lo) <= 1 and abs(got_u.shape[0] - (hi - lo)) <= 1 and got_raw.shape == (6, got_u.shape[0], 625)
+    if rank == 0:
+        windows = [(0, 300), (have[0][1] - 380, 480)]  # start of the series; across the shard's last row
+    else:
+        windows = [(have[7][0] - 100, 480), (n - 480, 480)]  # across the shard's first row; end of the series
+    _abd_window_check(got_u, got_raw, kw, L, windows)
 
 
 def test_cfg5_grid_boosted_schwarzschild_every_time_step(ctx):
