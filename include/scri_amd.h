@@ -202,7 +202,8 @@ int bms_rotor_grid(bms_ctx* ctx, const double frame_rotation[4], const double bo
  * transformations run per direction on the GPU (pixel_math.h); ctx may be NULL. */
 int bms_conformal_factors(bms_ctx* ctx, const double boost_velocity[3], const double* rotors_host, int64_t n_rotors,
                           double* k, void* ethk_over_k, double* one_over_k, double* one_over_k_cubed);
-/* sf.SWSH_grid(R, s, ell_max)[..., ell_min^2:] : host c16[n_rotors][(ell_max+1)^2 - ell_min^2] */
+/* sf.SWSH_grid(R, s, ell_max)[..., ell_min^2:] : host c16[n_rotors][(ell_max+1)^2 - ell_min^2].  ctx = NULL: host
+ * evaluation of the header the kernel compiles (wigner.h; double-double recurrence, correctly rounded values). */
 int bms_swsh_grid(bms_ctx* ctx, const double* rotors_host /* f8[n][4] */, int64_t n_rotors, int spin, int ell_min,
                   int ell_max, void* Y_host);
 /* spinsfast.map2salm(grid[n_maps][n_theta][n_phi], s, ell_max)[..., ell_min^2:] (waveform_grid.py:303-307) */

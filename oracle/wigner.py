@@ -16,9 +16,13 @@ Published definition (spherical_functions documentation, "Wigner D matrices"):
 
 Two evaluators are provided:
   * ``wigner_D_exact``  -- the literal sum in 60-digit mpmath arithmetic (ground truth, slow);
-  * ``wigner_d_column`` / ``wigner_D_matrices`` / ``swsh_grid`` -- float64, vectorised, via
-    the standard three-term recurrence in l (exactly the same function; checked against the
-    exact evaluator in tests/test_oracle_wigner.py).
+  * ``wigner_d_column`` / ``wigner_D_matrices`` / ``swsh_grid`` -- vectorised, via the standard
+    three-term recurrence in l (exactly the same function; checked against the exact evaluator in
+    tests/test_oracle_wigner.py).  The recurrence is carried in numpy's extended precision
+    (``np.longdouble``: 64-bit mantissa on x86) and rounded to float64 at the end: in plain float64
+    it loses ~l ulp, which is what kept two of the reference's hand-tuned tolerances
+    (tests/test_waveform_grid.py: 4e-14, 5e-14) out of reach of the restatement; with the rounded
+    extended values the oracle passes them as they stand.  ``EXTENDED = False`` restores float64.
 """
 import math
 import numpy as np
@@ -156,19 +160,35 @@ def wigner_D_matrices_exact(Ra, Rb, ell_min, ell_max, dps=60):
     return out
 
 
-# ----------------------------------------------------------------------------- float64 D via l-recurrence
+# ----------------------------------------------------------------------------- D via l-recurrence
+
+EXTENDED = True  # carry the recurrences in np.longdouble, round to float64 at the end
+
+
+def _real_t():
+    return np.longdouble if EXTENDED else np.float64
+
+
+def _cplx_t():
+    return np.clongdouble if EXTENDED else np.complex128
+
+
+
+def _sqrt_int(n):
+    """sqrt of a non-negative integer in the working precision."""
+    return np.sqrt(_real_t()(n))
 
 
 def _d_start(ell0, mp, m, ra, rb):
     """d^{l0}_{mp,m}(ra=cos(b/2), rb=sin(b/2)) for l0 = max(|mp|,|m|): single-term closed forms."""
     if ell0 == mp:
-        return (-1.0) ** (ell0 - m) * math.sqrt(math.comb(2 * ell0, ell0 - m)) * ra ** (ell0 + m) * rb ** (ell0 - m)
+        return (-1.0) ** (ell0 - m) * _sqrt_int(math.comb(2 * ell0, ell0 - m)) * ra ** (ell0 + m) * rb ** (ell0 - m)
     if ell0 == -mp:
-        return math.sqrt(math.comb(2 * ell0, ell0 + m)) * ra ** (ell0 - m) * rb ** (ell0 + m)
+        return _sqrt_int(math.comb(2 * ell0, ell0 + m)) * ra ** (ell0 - m) * rb ** (ell0 + m)
     if ell0 == m:
-        return math.sqrt(math.comb(2 * ell0, ell0 - mp)) * ra ** (ell0 + mp) * rb ** (ell0 - mp)
+        return _sqrt_int(math.comb(2 * ell0, ell0 - mp)) * ra ** (ell0 + mp) * rb ** (ell0 - mp)
     # ell0 == -m
-    return (-1.0) ** (ell0 + mp) * math.sqrt(math.comb(2 * ell0, ell0 + mp)) * ra ** (ell0 - mp) * rb ** (ell0 + mp)
+    return (-1.0) ** (ell0 + mp) * _sqrt_int(math.comb(2 * ell0, ell0 + mp)) * ra ** (ell0 - mp) * rb ** (ell0 + mp)
 
 
 def wigner_d_chain(mp, m, ra, rb, ell_max):
@@ -179,18 +199,18 @@ def wigner_d_chain(mp, m, ra, rb, ell_max):
       l sqrt((l+1)^2-mp^2) sqrt((l+1)^2-m^2) d^{l+1}
          = (2l+1) [l(l+1) cos(b) - mp m] d^l - (l+1) sqrt(l^2-mp^2) sqrt(l^2-m^2) d^{l-1}
     """
-    ra = np.asarray(ra, dtype=float)
-    rb = np.asarray(rb, dtype=float)
-    out = np.zeros(ra.shape + (ell_max + 1,))
+    ra = np.asarray(ra, dtype=_real_t())
+    rb = np.asarray(rb, dtype=_real_t())
+    out = np.zeros(ra.shape + (ell_max + 1,), dtype=_real_t())
     ell0 = max(abs(mp), abs(m))
     if ell0 > ell_max:
         return out
     # Well-conditioned form of cos(b): cos(b) = sigma (1 - 2 t), t = min(ra, rb)^2, so that
     # l(l+1) cos(b) - mp m = sigma [(l(l+1) - sigma mp m) - 2 l(l+1) t] keeps full relative accuracy
     # near the poles (forming ra^2 - rb^2 loses l^2 eps / 2 there).
-    sig = np.where(ra >= rb, 1.0, -1.0)
+    sig = np.where(ra >= rb, 1.0, -1.0).astype(_real_t())
     t = np.where(ra >= rb, rb * rb, ra * ra)
-    dm1 = np.zeros(ra.shape)
+    dm1 = np.zeros(ra.shape, dtype=_real_t())
     d0 = _d_start(ell0, mp, m, ra, rb)
     out[..., ell0] = d0
     for ell in range(ell0, ell_max):
@@ -198,8 +218,8 @@ def wigner_d_chain(mp, m, ra, rb, ell_max):
             d1 = sig * (1.0 - 2.0 * t) * d0
         else:
             c1 = (2 * ell + 1) * sig * ((ell * (ell + 1) - sig * (mp * m)) - (2 * ell * (ell + 1)) * t)
-            c2 = (ell + 1) * math.sqrt((ell * ell - mp * mp) * (ell * ell - m * m))
-            den = ell * math.sqrt(((ell + 1) ** 2 - mp * mp) * ((ell + 1) ** 2 - m * m))
+            c2 = (ell + 1) * _sqrt_int((ell * ell - mp * mp) * (ell * ell - m * m))
+            den = ell * _sqrt_int(((ell + 1) ** 2 - mp * mp) * ((ell + 1) ** 2 - m * m))
             d1 = (c1 * d0 - c2 * dm1) / den
         out[..., ell + 1] = d1
         dm1, d0 = d0, d1
@@ -207,8 +227,8 @@ def wigner_d_chain(mp, m, ra, rb, ell_max):
 
 
 def _polar(Ra, Rb):
-    Ra = np.asarray(Ra, dtype=complex)
-    Rb = np.asarray(Rb, dtype=complex)
+    Ra = np.asarray(Ra, dtype=complex).astype(_cplx_t())
+    Rb = np.asarray(Rb, dtype=complex).astype(_cplx_t())
     ra, rb = np.abs(Ra), np.abs(Rb)
     n = np.sqrt(ra * ra + rb * rb)
     # unit phases, with the convention phase(0) = 1
@@ -230,8 +250,11 @@ def wigner_D_matrices(Ra, Rb, ell_min, ell_max):
             d = wigner_d_chain(mp, m, ra, rb, ell_max)
             phase = ea ** (mp + m) * eb ** (m - mp)
             for ell in range(max(ell_min, abs(mp), abs(m)), ell_max + 1):
-                out[..., LMpM_index(ell, mp, m, ell_min)] = phase * d[..., ell]
+                out[..., LMpM_index(ell, mp, m, ell_min)] = (phase * d[..., ell]).astype(complex)
     return out
+
+
+_PI = np.longdouble("3.14159265358979323846264338327950288")
 
 
 def swsh_grid(R, s, ell_max):
@@ -247,7 +270,8 @@ def swsh_grid(R, s, ell_max):
         d = wigner_d_chain(m, -s, ra, rb, ell_max)  # D^l_{m,-s}
         phase = ea ** (m - s) * eb ** (-s - m)
         for ell in range(max(abs(m), abs(s)), ell_max + 1):
-            out[..., LM_index(ell, m, 0)] = sign * math.sqrt((2 * ell + 1) / (4 * math.pi)) * phase * d[..., ell]
+            norm = np.sqrt(_real_t()(2 * ell + 1) / (4 * _PI))
+            out[..., LM_index(ell, m, 0)] = (sign * norm * phase * d[..., ell]).astype(complex)
     return out
 
 

@@ -1441,7 +1441,23 @@ extern "C" int bms_conformal_factors(bms_ctx* c, const double v[3], const double
 }
 
 extern "C" int bms_swsh_grid(bms_ctx* c, const double* rotors, int64_t n, int spin, int ell_min, int ell_max, void* Y) {
-  if (!c || !rotors || !Y) return BMS_ERR_INVALID;
+  if (!rotors || !Y) return BMS_ERR_INVALID;
+  if (!c) {  // host evaluation of the same header the kernel compiles (wigner.h: SwshChain), as bms_rotor_grid(ctx = NULL)
+    const int nm = LM_total_size(ell_min, ell_max);
+    cplx* out = (cplx*)Y;
+    for (int64_t p = 0; p < n; ++p) {
+      for (int k = 0; k < nm; ++k) out[p * nm + k] = {0.0, 0.0};
+      for (int m = -ell_max; m <= ell_max; ++m) {
+        SwshChain ch;
+        ch.init(m, spin, rotors[4 * p], rotors[4 * p + 1], rotors[4 * p + 2], rotors[4 * p + 3]);
+        for (int ell = ch.ell; ell <= ell_max; ++ell) {
+          if (ell >= ell_min) out[p * nm + LM_index(ell, m, ell_min)] = ch.value();
+          if (ell < ell_max) ch.next();
+        }
+      }
+    }
+    return BMS_OK;
+  }
   HIP_TRY(c, hipSetDevice(c->device));
   if (n <= 0) return BMS_OK;
   const size_t nm = LM_total_size(ell_min, ell_max);

@@ -162,12 +162,17 @@ __global__ __launch_bounds__(256, 2) void dgemm_mfma_kernel(const double* __rest
 // 3 x 4 accumulator tiles (96 VGPRs), three workgroups per CU.  Fragments are (re, im) pairs read with ds_read_b128:
 // A rows at a pitch of 10 complex and B rows at 64 complex make every 16-lane group of a read hit 16 distinct slots.
 constexpr int Z_BM = 64, Z_BN = 64, Z_KC = 8;
+constexpr double ZGEMM_4M_BELOW = 4.0e8;  // M N K (complex multiply-adds) below which the 4-product form is used
 constexpr int Z_PA = 10;  // LDS pitch of an A row (complex)
 constexpr int Z_PB = 64;  // LDS pitch of a B row (complex)
 constexpr int Z_ASZ = Z_BM * Z_PA;
 constexpr int Z_BSZ = Z_KC * Z_PB;
 
-__global__ __launch_bounds__(256, 3) void zgemm3m_mfma_kernel(const double* __restrict__ A, long long lda,
+// FOUR = true: the plain 4-product form (Re = Ar.Br - Ai.Bi, Im = Ar.Bi + Ai.Br), componentwise-accurate imaginary parts
+// at 4/3 of the matrix work and 2 workgroups per CU: launch_zgemm3m picks it for small problems (the reference's own
+// analytic tests sit at a few ulp of the data; tests/test_gpu_reference_suite.py), SCRI_AMD_ZGEMM_4M=0/1 forces either.
+template <bool FOUR>
+__global__ __launch_bounds__(256, FOUR ? 2 : 3) void zgemm3m_mfma_kernel(const double* __restrict__ A, long long lda,
                                                               const double* __restrict__ B, long long ldb,
                                                               double* __restrict__ C, long long ldc, long long M, int N,
                                                               int K, int nbm, int nbn, int st_rows_log2,
@@ -196,11 +201,17 @@ __global__ __launch_bounds__(256, 3) void zgemm3m_mfma_kernel(const double* __re
   const int wm = wave >> 1, wn = wave & 1;
   const int fi = lane & 15, fk = lane >> 4;
 
-  v4d p1[2][2], p2[2][2], p3[2][2];
+  v4d p1[2][2], p2[2][2], p3[2][2], p4[FOUR ? 2 : 1][FOUR ? 2 : 1];
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j) p1[i][j] = p2[i][j] = p3[i][j] = v4d{0.0, 0.0, 0.0, 0.0};
+  if constexpr (FOUR) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) p4[i][j] = v4d{0.0, 0.0, 0.0, 0.0};
+  }
 
   // staging maps: A tile 64 rows x 8 complex (thread -> row = tid>>3 (+32), k = tid&7);
   //               B tile 8 rows x 64 complex (thread -> row = tid>>6 (+4), column = tid&63)
@@ -249,7 +260,6 @@ __global__ __launch_bounds__(256, 3) void zgemm3m_mfma_kernel(const double* __re
     for (int kk = 0; wave_has_columns && kk < Z_KC / 4; ++kk) {
       const double2 a0 = as[kk * 4], a1 = as[16 * Z_PA + kk * 4];
       const double2 b0 = bs[kk * 4 * Z_PB], b1 = bs[kk * 4 * Z_PB + 16];
-      const double sa0 = a0.x + a0.y, sa1 = a1.x + a1.y, sb0 = b0.x + b0.y, sb1 = b1.x + b1.y;
       p1[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0.x, b0.x, p1[0][0], 0, 0, 0);
       p1[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0.x, b1.x, p1[0][1], 0, 0, 0);
       p1[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1.x, b0.x, p1[1][0], 0, 0, 0);
@@ -258,10 +268,22 @@ __global__ __launch_bounds__(256, 3) void zgemm3m_mfma_kernel(const double* __re
       p2[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0.y, b1.y, p2[0][1], 0, 0, 0);
       p2[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1.y, b0.y, p2[1][0], 0, 0, 0);
       p2[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1.y, b1.y, p2[1][1], 0, 0, 0);
-      p3[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(sa0, sb0, p3[0][0], 0, 0, 0);
-      p3[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(sa0, sb1, p3[0][1], 0, 0, 0);
-      p3[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(sa1, sb0, p3[1][0], 0, 0, 0);
-      p3[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(sa1, sb1, p3[1][1], 0, 0, 0);
+      if constexpr (FOUR) {
+        p3[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0.x, b0.y, p3[0][0], 0, 0, 0);
+        p3[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0.x, b1.y, p3[0][1], 0, 0, 0);
+        p3[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1.x, b0.y, p3[1][0], 0, 0, 0);
+        p3[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1.x, b1.y, p3[1][1], 0, 0, 0);
+        p4[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0.y, b0.x, p4[0][0], 0, 0, 0);
+        p4[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0.y, b1.x, p4[0][1], 0, 0, 0);
+        p4[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1.y, b0.x, p4[1][0], 0, 0, 0);
+        p4[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1.y, b1.x, p4[1][1], 0, 0, 0);
+      } else {
+        const double sa0 = a0.x + a0.y, sa1 = a1.x + a1.y, sb0 = b0.x + b0.y, sb1 = b1.x + b1.y;
+        p3[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(sa0, sb0, p3[0][0], 0, 0, 0);
+        p3[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(sa0, sb1, p3[0][1], 0, 0, 0);
+        p3[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(sa1, sb0, p3[1][0], 0, 0, 0);
+        p3[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(sa1, sb1, p3[1][1], 0, 0, 0);
+      }
     }
     if (kt + 1 < nk) Z_STORE_LDS(buf ^ 1);
     __syncthreads();
@@ -282,7 +304,9 @@ __global__ __launch_bounds__(256, 3) void zgemm3m_mfma_kernel(const double* __re
         const long long row = m0 + wm * 32 + i * 16 + fk + 4 * rr;
         if (row < M) {
           const double re = p1[i][j][rr] - p2[i][j][rr];
-          const double im = (p3[i][j][rr] - p1[i][j][rr]) - p2[i][j][rr];
+          double im;
+          if constexpr (FOUR) im = p3[i][j][rr] + p4[i][j][rr];
+          else im = (p3[i][j][rr] - p1[i][j][rr]) - p2[i][j][rr];
           double2 v;
           v.x = (re - off_r) * sc_r;
           v.y = (im - off_i) * sc_i;
@@ -310,8 +334,15 @@ hipError_t launch_zgemm3m(hipStream_t stream, const double* A, long long lda, co
   const int sr = 1 << st_rows_log2, sc = 64 >> st_rows_log2;
   const long long n_super = (long long)((nbm + sr - 1) / sr) * ((nbn + sc - 1) / sc);
   const long long grid = ((n_super + 7) / 8) * 8 * 64;
-  hipLaunchKernelGGL(zgemm3m_mfma_kernel, dim3((unsigned)grid), dim3(256), 0, stream, A, lda, B, ldb, C, ldc, M, N, K,
-                     nbm, nbn, st_rows_log2, col_off, col_scale);
+  // 3 products where the matrix pipe is the bound; the plain 4 below ~60 us of matrix work, where nothing is
+  static const int four_env = getenv("SCRI_AMD_ZGEMM_4M") ? atoi(getenv("SCRI_AMD_ZGEMM_4M")) : -1;
+  const bool four = four_env >= 0 ? four_env != 0 : (double)M * (double)N * (double)K < ZGEMM_4M_BELOW;
+  if (four)
+    hipLaunchKernelGGL(zgemm3m_mfma_kernel<true>, dim3((unsigned)grid), dim3(256), 0, stream, A, lda, B, ldb, C, ldc, M, N,
+                       K, nbm, nbn, st_rows_log2, col_off, col_scale);
+  else
+    hipLaunchKernelGGL(zgemm3m_mfma_kernel<false>, dim3((unsigned)grid), dim3(256), 0, stream, A, lda, B, ldb, C, ldc, M, N,
+                       K, nbm, nbn, st_rows_log2, col_off, col_scale);
   return hipGetLastError();
 }
 

@@ -3,7 +3,8 @@
 // scri/asymptotic_bondi_data/transformations.py:324-334).
 //
 // One thread per (pixel, m): a single l-chain of the Wigner small-d recurrence gives
-// sYlm(R_p) = (-1)^s sqrt((2l+1)/4pi) ea^(m-s) eb^(-s-m) d^l_{m,-s}(ra, rb) for every l at once.
+// sYlm(R_p) = (-1)^s sqrt((2l+1)/4pi) ea^(m-s) eb^(-s-m) d^l_{m,-s}(ra, rb) for every l at once (SwshChain: the
+// recurrence runs in double-double, the matrix entries are correctly rounded fp64).
 // The matrix is written directly in the *real* layout the fp64 MFMA GEMM consumes: the complex product
 // (ar + i ai)(yr + i yi) over interleaved (re, im) data is the real product of the row [ar ai] with
 //   | yr  yi |
@@ -28,19 +29,13 @@ __global__ __launch_bounds__(256) void swsh_kernel(const double* __restrict__ ro
   const int p = (int)(gid % n_pix);
   const int m = (int)(gid / n_pix) - ell_max;
   const double* q = rotors + 4LL * p;
-  cplx Ra = {q[0], q[3]}, Rb = {q[2], q[1]};
-  double ra, rb;
-  cplx ea, eb;
-  spinor_polar(Ra, Rb, ra, rb, ea, eb);
-  const cplx phase = cmul(cpow_unit(ea, m - spin), cpow_unit(eb, -spin - m));
-  const double sgn = (spin & 1) ? -1.0 : 1.0;
-  DChain ch;
-  ch.init(m, -spin, ra, rb);
+  SwshChain ch;
+  ch.init(m, spin, q[0], q[1], q[2], q[3]);
   const int n_modes = LM_total_size(ell_min, ell_max);
   for (int ell = ch.ell; ell <= ell_max; ++ell) {
     if (ell >= ell_min) {
-      const double a = sgn * sqrt((2.0 * ell + 1.0) / (4.0 * M_PI)) * ch.value();
-      const double yr = a * phase.re, yi = a * phase.im;
+      const cplx y = ch.value();
+      const double yr = y.re, yi = y.im;
       const long long k = LM_index(ell, m, ell_min);
       if (MODE == 1) {
         double* r0 = out + (2 * k) * ldb + 2LL * p;

@@ -78,29 +78,29 @@ BMS_HD Quat pixel_rotor(const Quat& frq, const BoostSpec& bs, int j, int k, int 
 
 // sum_k coef[k] sYlm_k(R) for modes l = 0..lmax
 BMS_HD cplx eval_modes(const cplx* coef, int lmax, int spin, const Quat& q) {
-  cplx Ra = {q.w, q.z}, Rb = {q.y, q.x};
-  double ra, rb;
-  cplx ea, eb;
-  spinor_polar(Ra, Rb, ra, rb, ea, eb);
-  const double sgn = (spin & 1) ? -1.0 : 1.0;
-  cplx sum = {0.0, 0.0};
+  // terms are summed in double-double too: alpha enters the results as a time shift (u - alpha), unattenuated
+  ddc sum = {{0.0, 0.0}, {0.0, 0.0}};
   for (int m = -lmax; m <= lmax; ++m) {
-    const cplx phase = cmul(cpow_unit(ea, m - spin), cpow_unit(eb, -spin - m));
-    DChain ch;
-    ch.init(m, -spin, ra, rb);
+    const int am = m < 0 ? -m : m, as = spin < 0 ? -spin : spin;
+    bool any = false;
+    for (int ell = am > as ? am : as; ell <= lmax && !any; ++ell) {
+      const cplx c = coef[LM_index(ell, m, 0)];
+      any = c.re != 0.0 || c.im != 0.0;
+    }
+    if (!any) continue;
+    SwshChain ch;
+    ch.init(m, spin, q.w, q.x, q.y, q.z);
     for (int ell = ch.ell; ell <= lmax; ++ell) {
       const cplx c = coef[LM_index(ell, m, 0)];
       if (c.re != 0.0 || c.im != 0.0) {
-        const double a = sgn * sqrt((2.0 * ell + 1.0) / (4.0 * M_PI)) * ch.value();
-        const cplx y = {a * phase.re, a * phase.im};
-        const cplx t = cmul(c, y);
-        sum.re += t.re;
-        sum.im += t.im;
+        const cplx y = ch.value();
+        sum.re = dd_add(sum.re, dd_sub(two_prod(c.re, y.re), two_prod(c.im, y.im)));
+        sum.im = dd_add(sum.im, dd_add(two_prod(c.re, y.im), two_prod(c.im, y.re)));
       }
       if (ell < lmax) ch.next();
     }
   }
-  return sum;
+  return cplx{dd_to_double(sum.re), dd_to_double(sum.im)};
 }
 
 // What the engine needs per pixel; evaluated identically on host and device.

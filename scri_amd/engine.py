@@ -387,13 +387,19 @@ def conformal_factors(boost_velocity, rotors):
     return k.reshape(shape), e.reshape(shape), ik.reshape(shape), ik3.reshape(shape)
 
 
-def swsh_grid(rotors, spin, ell_min, ell_max, ctx=None):
-    ctx = _ctx(ctx)
+def swsh_grid(rotors, spin, ell_min, ell_max, ctx=None, host=False):
+    """sf.SWSH_grid(R, s, ell_max)[..., ell_min^2:].  host=True: the set-up header evaluated on the host (no GPU)."""
     R = np.ascontiguousarray(rotors, dtype=float)
     shape = R.shape[:-1]
     R2 = R.reshape(-1, 4)
     out = np.zeros((R2.shape[0], LM_total_size(ell_min, ell_max)), dtype=np.complex128)
-    ctx.check(_lib.load().bms_swsh_grid(ctx.handle, dptr(R2), R2.shape[0], spin, ell_min, ell_max, vptr(out)), "bms_swsh_grid")
+    if host:
+        rc = _lib.load().bms_swsh_grid(None, dptr(R2), R2.shape[0], spin, ell_min, ell_max, vptr(out))
+        if rc != 0:
+            _lib._raise(rc, None, "bms_swsh_grid")
+    else:
+        ctx = _ctx(ctx)
+        ctx.check(_lib.load().bms_swsh_grid(ctx.handle, dptr(R2), R2.shape[0], spin, ell_min, ell_max, vptr(out)), "bms_swsh_grid")
     return out.reshape(shape + (out.shape[1],))
 
 
