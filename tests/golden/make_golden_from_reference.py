@@ -1,0 +1,109 @@
+"""Golden vectors computed by the reference's OWN source files (run in the build container only: needs /root/reference).
+
+    python tests/golden/make_golden_from_reference.py
+
+imports /root/reference/scri/*.py unmodified on top of the stand-ins of reference_standins.py (the image has no numba,
+quaternion, spherical_functions, spinsfast) and writes
+
+  g8_ref_wm_transform.npz   scri.WaveformModes.transform (scri/waveform_grid.py:331-630): h, sigma, psi2 (with psi3/psi4
+                            companions), l = 2..6 / 0..6, N = 240, supertranslation + frame rotation + boost
+  g9_ref_abd_transform.npz  scri.AsymptoticBondiData.transform (scri/asymptotic_bondi_data/transformations.py:199-431):
+                            six fields, l <= 4, N = 120
+  g10_ref_rotations.npz     scri.WaveformModes.rotate_decomposition_basis (scri/rotations.py:284-392): constant rotor and
+                            rotor series, data and frame
+
+Only the .npz files travel; tests/test_golden.py checks the oracle (CPU) and the HIP path (GPU) against them.
+"""
+import os
+import sys
+import warnings
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import reference_standins as standins  # noqa: E402
+
+scri = standins.install()
+
+from scri_amd import synthetic  # noqa: E402  (seeded smooth inputs; plain numpy)
+
+
+def _wm(t, data, ell_min, ell_max, dataType):
+    return scri.WaveformModes(t=t, data=data, ell_min=ell_min, ell_max=ell_max, frameType=scri.Inertial, dataType=dataType,
+                              r_is_scaled_out=True, m_is_scaled_out=True)
+
+
+def _real_supertranslation(ell_max, seed, scale):
+    rng = np.random.default_rng(seed)
+    a = scale * (rng.normal(size=(ell_max + 1) ** 2) + 1j * rng.normal(size=(ell_max + 1) ** 2))
+    return synthetic.real_supertranslation(a)
+
+
+def g8():
+    n, L = 240, 6
+    t = np.linspace(-12.0, 36.0, n)
+    kw = dict(supertranslation=_real_supertranslation(3, 81, 0.05), frame_rotation=np.array([0.4, 1.0, -2.0, 0.3]) / np.linalg.norm([0.4, 1.0, -2.0, 0.3]),
+              boost_velocity=np.array([0.012, -0.02, 0.015]))
+    out = dict(t=t, ell_max=L, **kw)
+    # h (spin -2, l = 2..6) and sigma (spin 2): the inhomogeneous-term branches (waveform_grid.py:485-503)
+    for name, dt, seed in (("h", scri.h, 82), ("sigma", scri.sigma, 83)):
+        data = synthetic.chirp_modes(t, 2, L, seed) * (1 + 0.01 * t[:, None])
+        w = _wm(t, data, 2, L, dt).transform(**kw)
+        out[f"{name}_in"], out[f"{name}_t_out"], out[f"{name}_out"] = data, w.t, w.data
+        assert w.ell_min == 2 and w.ell_max == L
+    # psi2 (spin 0, l = 0..6) with psi3 / psi4 companions: the mixing branch (waveform_grid.py:504-550)
+    d2 = synthetic.chirp_modes(t, 0, L, 84)
+    d3 = synthetic.chirp_modes(t, 1, 5, 85)
+    d4 = synthetic.chirp_modes(t, 2, 4, 86)
+    w = _wm(t, d2, 0, L, scri.psi2).transform(psi3_modes=_wm(t, d3, 1, 5, scri.psi3), psi4_modes=_wm(t, d4, 2, 4, scri.psi4), **kw)
+    out.update(psi2_in=d2, psi3_in=d3, psi4_in=d4, psi2_t_out=w.t, psi2_out=w.data)
+    # a pure supertranslation through explicit n_theta / n_phi / ell_max kwargs (waveform_grid.py:89-110, 615-630)
+    w = _wm(t, out["h_in"], 2, L, scri.h).transform(supertranslation=kw["supertranslation"], n_theta=23, n_phi=25, ell_max=5)
+    out.update(h_st_t_out=w.t, h_st_out=w.data)
+    np.savez_compressed(os.path.join(HERE, "g8_ref_wm_transform.npz"), source="/root/reference/scri (unmodified) on stand-ins", **out)
+
+
+def g9():
+    n, L = 120, 4
+    u = np.linspace(-8.0, 16.0, n)
+    abd = scri.AsymptoticBondiData(u, L)
+    raw = np.zeros((6, n, (L + 1) ** 2), dtype=complex)
+    for f, s in enumerate(synthetic.ABD_SPINS):
+        raw[f] = synthetic.chirp_modes(u, 0, L, 90 + f) * (1 + 0.02 * u[:, None])
+        raw[f, :, : s * s] = 0
+    abd.psi0, abd.psi1, abd.psi2, abd.psi3, abd.psi4, abd.sigma = raw
+    kw = dict(supertranslation=_real_supertranslation(2, 97, 0.04), frame_rotation=np.array([1.0, 0.5, -0.2, 0.1]) / np.linalg.norm([1.0, 0.5, -0.2, 0.1]),
+              boost_velocity=np.array([0.01, 0.02, -0.015]))
+    new = abd.transform(**kw)
+    out = dict(u=u, raw=raw, ell_max=L, u_out=np.array(new.t), raw_out=np.array(new._raw_data), **kw)
+    new = abd.transform(space_translation=np.array([0.2, -0.1, 0.3]), working_ell_max=7, output_ell_max=3)
+    out.update(u_out_b=np.array(new.t), raw_out_b=np.array(new._raw_data), space_translation_b=np.array([0.2, -0.1, 0.3]))
+    np.savez_compressed(os.path.join(HERE, "g9_ref_abd_transform.npz"), source="/root/reference/scri (unmodified) on stand-ins", **out)
+
+
+def g10():
+    t, data, rot = synthetic.cfg1()
+    t, data = t[::8], data[::8]  # 250 steps of cfg1
+    R = rot["series"][::8]
+    q = rot["constant"]
+    w = _wm(t, data.copy(), 2, 4, scri.h)
+    w.rotate_decomposition_basis(np.quaternion(*q))
+    out = dict(t=t, data=data, constant=q, series=R, const_out=w.data.copy(), const_frame=standins.as_float_array(w.frame))
+    w.rotate_decomposition_basis(standins.as_quat_array(R))  # a series on top: frame right-multiplied (rotations.py:313-323)
+    out.update(series_after_const_out=w.data.copy(), series_after_const_frame=standins.as_float_array(w.frame))
+    w = _wm(t, data.copy(), 2, 4, scri.h)
+    w.rotate_decomposition_basis(standins.as_quat_array(R))
+    out.update(series_out=w.data.copy(), series_frame=standins.as_float_array(w.frame))
+    w = _wm(t, data.copy(), 2, 4, scri.h)
+    w.rotate_physical_system(np.quaternion(*q))
+    out.update(physical_out=w.data.copy(), physical_frame=standins.as_float_array(w.frame))
+    np.savez_compressed(os.path.join(HERE, "g10_ref_rotations.npz"), source="/root/reference/scri (unmodified) on stand-ins", **out)
+
+
+if __name__ == "__main__":
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for f in (g10, g8, g9):
+            f()
+            print("wrote", f.__name__)

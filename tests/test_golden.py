@@ -1,5 +1,8 @@
-"""Golden vectors (tests/golden/, generated by tests/golden/make_golden.py): the oracle reproduces them on the CPU;
-the GPU engine reproduces them through the C ABI (-m gpu).  Nothing here reads the reference checkout."""
+"""Golden vectors (tests/golden/): the oracle reproduces them on the CPU; the GPU engine reproduces them through the C ABI
+(-m gpu).  g1-g7 come from tests/golden/make_golden.py (mpmath / sympy / the oracle); g8-g10 were computed by the
+reference's OWN source files (/root/reference/scri/*.py imported unmodified on stand-ins for the third-party packages the
+image lacks: tests/golden/make_golden_from_reference.py) -- they pin the scri layer of the oracle and of the HIP path:
+kwarg handling, mixing signs and term order, trimming, frame bookkeeping.  Nothing here reads the reference checkout."""
 import os
 
 import numpy as np
@@ -8,7 +11,7 @@ import pytest
 from oracle import quat, wigner, spinsfast_ref, abd_ref
 from oracle import waveform_grid_ref as grid_ref
 from oracle import sample_waveforms_ref as samples
-from oracle.containers import ABD, WM, h
+from oracle.containers import ABD, WM, h, psi2, psi3, psi4, sigma
 
 G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
@@ -79,6 +82,61 @@ def test_g7_oracle_wm_transform():
     assert np.array_equal(out.t, g["t_out"]) and np.abs(out.data - g["data_out"]).max() < 1e-14
 
 
+# ------------------------------------------------------------------------------------- CPU: oracle vs the reference's code
+
+
+def _g8_kw(g):
+    return dict(supertranslation=g["supertranslation"], frame_rotation=g["frame_rotation"], boost_velocity=g["boost_velocity"])
+
+
+def test_g8_oracle_vs_reference_wm_transform():
+    """oracle/waveform_grid_ref.py against scri/waveform_grid.py:331-630 run from the reference checkout (h and sigma
+    inhomogeneous terms, psi2 mixing with psi3 / psi4 companions, explicit n_theta / n_phi / ell_max)."""
+    g = load("g8_ref_wm_transform.npz")
+    t, kw = g["t"], _g8_kw(g)
+    for name, dt in (("h", h), ("sigma", sigma)):
+        o = grid_ref.transform(WM(t=t, data=g[f"{name}_in"], ell_min=2, ell_max=6, dataType=dt), **kw)
+        assert np.array_equal(o.t, g[f"{name}_t_out"])
+        assert np.abs(o.data - g[f"{name}_out"]).max() < 2e-14 * max(1.0, np.abs(g[f"{name}_out"]).max())
+    o = grid_ref.transform(WM(t=t, data=g["psi2_in"], ell_min=0, ell_max=6, dataType=psi2),
+                           psi3_modes=WM(t=t, data=g["psi3_in"], ell_min=1, ell_max=5, dataType=psi3),
+                           psi4_modes=WM(t=t, data=g["psi4_in"], ell_min=2, ell_max=4, dataType=psi4), **kw)
+    assert np.array_equal(o.t, g["psi2_t_out"]) and np.abs(o.data - g["psi2_out"]).max() < 2e-14 * max(1.0, np.abs(g["psi2_out"]).max())
+    o = grid_ref.transform(WM(t=t, data=g["h_in"], ell_min=2, ell_max=6, dataType=h), supertranslation=g["supertranslation"],
+                           n_theta=23, n_phi=25, ell_max=5)
+    assert o.ell_max == 5 and np.array_equal(o.t, g["h_st_t_out"]) and np.abs(o.data - g["h_st_out"]).max() < 2e-14
+
+
+def test_g9_oracle_vs_reference_abd_transform():
+    """oracle/abd_ref.py against scri/asymptotic_bondi_data/transformations.py:199-431 run from the reference checkout."""
+    g = load("g9_ref_abd_transform.npz")
+    a = ABD(g["u"], g["raw"], int(g["ell_max"]))
+    o = abd_ref.transform(a, **_g8_kw(g))
+    assert np.array_equal(o.u, g["u_out"]) and np.abs(o.raw - g["raw_out"]).max() < 2e-14 * np.abs(g["raw_out"]).max()
+    o = abd_ref.transform(a, space_translation=g["space_translation_b"], working_ell_max=7, output_ell_max=3)
+    assert o.ell_max == 3 and np.array_equal(o.u, g["u_out_b"])
+    assert np.abs(o.raw - g["raw_out_b"]).max() < 2e-14 * np.abs(g["raw_out_b"]).max()
+
+
+def test_g10_oracle_vs_reference_rotations():
+    """oracle/rotations_ref.py against scri/rotations.py:268-392 run from the reference checkout (its numba kernels as
+    plain Python loops).  The reference leaves the frame of "series after a constant rotor" as an [N, 1] quaternion array
+    (rotations.py:316-318: `np.array([W.frame * R for R in R_basis])` with a length-1 frame); the values are compared."""
+    from oracle import rotations_ref
+
+    g = load("g10_ref_rotations.npz")
+    w = WM(t=g["t"], data=g["data"], ell_min=2, ell_max=4, dataType=h)
+    a = rotations_ref.rotate_decomposition_basis(w, g["constant"])
+    assert np.abs(a.data - g["const_out"]).max() < 1e-14 and np.abs(a.frame - g["const_frame"]).max() < 1e-15
+    b = rotations_ref.rotate_decomposition_basis(a, g["series"])
+    assert np.abs(b.data - g["series_after_const_out"]).max() < 1e-14
+    assert np.abs(b.frame - g["series_after_const_frame"].reshape(-1, 4)).max() < 1e-15
+    c = rotations_ref.rotate_decomposition_basis(w, g["series"])
+    assert np.abs(c.data - g["series_out"]).max() < 1e-14 and np.abs(c.frame - g["series_frame"]).max() == 0.0
+    d = rotations_ref.rotate_decomposition_basis(w, quat.qconj(g["constant"]))  # rotate_physical_system(R) = basis by ~R
+    assert np.abs(d.data - g["physical_out"]).max() < 1e-14 and np.abs(d.frame - g["physical_frame"]).max() < 1e-15
+
+
 # ------------------------------------------------------------------------------------------------ GPU: engine
 
 
@@ -126,3 +184,61 @@ def test_g6_g7_gpu_transforms(ctx):
                                frameType=scri_amd.Inertial, r_is_scaled_out=True, m_is_scaled_out=True, ctx=ctx)
     o = w.transform(supertranslation=g["supertranslation"], frame_rotation=g["frame_rotation"], boost_velocity=g["boost_velocity"])
     assert np.abs(o.t - g["t_out"]).max() < 1e-14 and np.abs(o.data - g["data_out"]).max() < 1e-13
+
+
+def _gpu_wm(t, data, ell_min, ell_max, dataType, ctx):
+    import scri_amd
+
+    return scri_amd.WaveformModes(t=t, data=data, ell_min=ell_min, ell_max=ell_max, dataType=dataType, frameType=scri_amd.Inertial,
+                                  r_is_scaled_out=True, m_is_scaled_out=True, ctx=ctx)
+
+
+@pytest.mark.gpu
+def test_g8_gpu_vs_reference_wm_transform(ctx):
+    import scri_amd
+
+    g = load("g8_ref_wm_transform.npz")
+    t, kw = g["t"], _g8_kw(g)
+    for name, dt in (("h", scri_amd.h), ("sigma", scri_amd.sigma)):
+        o = _gpu_wm(t, g[f"{name}_in"], 2, 6, dt, ctx).transform(**kw)
+        assert o.t.shape == g[f"{name}_t_out"].shape and np.abs(o.t - g[f"{name}_t_out"]).max() < 1e-13
+        assert np.abs(o.data - g[f"{name}_out"]).max() < 1e-13 * max(1.0, np.abs(g[f"{name}_out"]).max())
+    o = _gpu_wm(t, g["psi2_in"], 0, 6, scri_amd.psi2, ctx).transform(
+        psi3_modes=_gpu_wm(t, g["psi3_in"], 1, 5, scri_amd.psi3, ctx), psi4_modes=_gpu_wm(t, g["psi4_in"], 2, 4, scri_amd.psi4, ctx), **kw)
+    assert o.t.shape == g["psi2_t_out"].shape and np.abs(o.data - g["psi2_out"]).max() < 1e-13 * max(1.0, np.abs(g["psi2_out"]).max())
+    o = _gpu_wm(t, g["h_in"], 2, 6, scri_amd.h, ctx).transform(supertranslation=g["supertranslation"], n_theta=23, n_phi=25, ell_max=5)
+    assert o.ell_max == 5 and o.t.shape == g["h_st_t_out"].shape and np.abs(o.data - g["h_st_out"]).max() < 1e-13
+
+
+@pytest.mark.gpu
+def test_g9_gpu_vs_reference_abd_transform(ctx):
+    import scri_amd
+
+    g = load("g9_ref_abd_transform.npz")
+    a = scri_amd.AsymptoticBondiData(g["u"], int(g["ell_max"]), ctx=ctx)
+    a._raw_data[:] = g["raw"]
+    o = a.transform(**_g8_kw(g))
+    assert o.n_times == g["u_out"].shape[0] and np.abs(o.u - g["u_out"]).max() < 1e-13
+    assert np.abs(o._raw_data - g["raw_out"]).max() < 1e-13 * np.abs(g["raw_out"]).max()
+    o = a.transform(space_translation=g["space_translation_b"], working_ell_max=7, output_ell_max=3)
+    assert o.ell_max == 3 and o.n_times == g["u_out_b"].shape[0]
+    assert np.abs(o._raw_data - g["raw_out_b"]).max() < 1e-13 * np.abs(g["raw_out_b"]).max()
+
+
+@pytest.mark.gpu
+def test_g10_gpu_vs_reference_rotations(ctx):
+    import scri_amd
+
+    g = load("g10_ref_rotations.npz")
+    w = _gpu_wm(g["t"], g["data"].copy(), 2, 4, scri_amd.h, ctx)
+    w.rotate_decomposition_basis(g["constant"])
+    assert np.abs(w.data - g["const_out"]).max() < 4e-13 and np.abs(w.frame - g["const_frame"]).max() < 1e-15
+    w.rotate_decomposition_basis(g["series"])
+    assert np.abs(w.data - g["series_after_const_out"]).max() < 4e-13
+    assert np.abs(w.frame - g["series_after_const_frame"].reshape(-1, 4)).max() < 1e-15
+    w = _gpu_wm(g["t"], g["data"].copy(), 2, 4, scri_amd.h, ctx)
+    w.rotate_decomposition_basis(g["series"])
+    assert np.abs(w.data - g["series_out"]).max() < 4e-13 and np.abs(w.frame - g["series_frame"]).max() == 0.0
+    w = _gpu_wm(g["t"], g["data"].copy(), 2, 4, scri_amd.h, ctx)
+    w.rotate_physical_system(g["constant"])
+    assert np.abs(w.data - g["physical_out"]).max() < 4e-13 and np.abs(w.frame - g["physical_frame"]).max() < 1e-15
