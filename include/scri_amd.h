@@ -91,6 +91,11 @@ int bms_rotate_const(bms_ctx* ctx, void* data, int mem, int64_t n_times, int64_t
                      const double quaternion[4] /* w,x,y,z */);
 int bms_rotate_series(bms_ctx* ctx, void* data, int mem, int64_t n_times, int64_t ld, int ell_min, int ell_max,
                       const void* spinors /* c16[n_times][2] = (w + i z, y + i x), same memory space as data */);
+/* _rotate_decomposition_basis_by_constant at its own seam (scri/rotations.py:346-367): the caller hands the packed Wigner
+ * matrices D (host c16, block l row-major (m', m) at sf._linear_matrix_offset(l, ell_min); rotations.py:327 fills it with
+ * sf._Wigner_D_matrices), not the rotor.  data[t, l, m] <- sum_m' data[t, l, m'] D^l[m', m], in place. */
+int bms_rotate_const_D(bms_ctx* ctx, void* data, int mem, int64_t n_times, int64_t ld, int ell_min, int ell_max,
+                       const void* D_host);
 /* packed Wigner-D matrices of one rotor, layout of sf.Wigner_D_matrices (tests/test_rotations.py:163-165):
  * host c16[(4 L^3 - L)/3 ...], block l at sf._linear_matrix_offset(l, ell_min), row-major (m', m) */
 int bms_wigner_D(bms_ctx* ctx, const double quaternion[4], int ell_min, int ell_max, void* D_host);

@@ -45,8 +45,9 @@ WaveformModes.to_corotating_frame = to_corotating_frame
 WaveformModes.to_coprecessing_frame = to_coprecessing_frame
 
 
-def patch_scri():
-    """Graft the GPU implementations onto an installed `scri` (opt-in drop-in)."""
+def patch_scri(scri=None, ctx=None):
+    """Graft the GPU implementations onto an installed `scri` (opt-in drop-in): the two rotation
+    kernels, `WaveformModes.transform` and `AsymptoticBondiData.transform`.  Returns the patched attribute names."""
     from .integration import patch_scri as _patch
 
-    return _patch()
+    return _patch(scri, ctx=ctx)

@@ -93,6 +93,7 @@ SIGNATURES = {
     ),
     "bms_rotate_const": (c_int, [c_vp, c_vp, c_int, c_i64, c_i64, c_int, c_int, c_dp]),
     "bms_rotate_series": (c_int, [c_vp, c_vp, c_int, c_i64, c_i64, c_int, c_int, c_vp]),
+    "bms_rotate_const_D": (c_int, [c_vp, c_vp, c_int, c_i64, c_i64, c_int, c_int, c_vp]),
     "bms_wigner_D": (c_int, [c_vp, c_dp, c_int, c_int, c_vp]),
     "bms_transform_modes": (
         c_int,

@@ -129,7 +129,9 @@ class AsymptoticBondiData:
         n_theta = 2 * working_ell_max + 1
         tr = engine.make_transformation(supertranslation, frame_rotation, boost_velocity, n_theta, n_theta, output_ell_max)
         u_new, raw_new = engine.transform_abd(self._time, self._raw_data, self.ell_max, tr, ctx=self._ctx)
-        return type(self)(u_new, output_ell_max, multiplication_truncator=self._truncator, frameType=self.frameType, ctx=self._ctx, _raw=raw_new)
+        # `type(self)(timeprime, output_ell_max)` in the reference (transformations.py:417): the result starts from the
+        # constructor's defaults (multiplication_truncator = sum, frameType = Inertial), whatever the input carried
+        return type(self)(u_new, output_ell_max, ctx=self._ctx, _raw=raw_new)
 
 
 def boosted_grid(frame_rotation, boost_velocity, n_theta, n_phi):

@@ -473,7 +473,7 @@ static int rotate_impl(bms_ctx* c, void* data, int mem, int64_t n_times, int64_t
   if (rc) return rc;
   double* d_data = (double*)data;
   const double* d_rot = (const double*)spinors;
-  const size_t data_bytes = (size_t)n_times * ld * 16;
+  const size_t data_bytes = ((size_t)(n_times - 1) * ld + n_modes) * 16;  // a strided view ends with its last row's modes
   const size_t rot_bytes = (series ? (size_t)n_times : 1) * 32;
   if (mem == BMS_HOST || !series) {
     double* r = nullptr;
@@ -511,6 +511,63 @@ extern "C" int bms_rotate_series(bms_ctx* c, void* data, int mem, int64_t n_time
                                  int ell_max, const void* spinors) {
   if (!c || !spinors) return BMS_ERR_INVALID;
   return rotate_impl(c, data, mem, n_times, ld, ell_min, ell_max, spinors, true);
+}
+
+// The reference's numba kernel takes the packed Wigner matrices it is handed, not a rotor (scri/rotations.py:346-367:
+// `_rotate_decomposition_basis_by_constant(data, ell_min, ell_max, D, tmp)` with D from sf._Wigner_D_matrices, :327):
+//     data[t, l, m] <- sum_m' data[t, l, m'] D^l[m', m],   D block l row-major (m', m) at _linear_matrix_offset(l, ell_min).
+// One complex GEMM per l on the synthesis kernel ([N x (2l+1)] . [(2l+1) x (2l+1)], operands zero padded to its 8 x 64
+// panels), out of place into a work buffer, then copied over the input.  This is the seam a binding replaces the numba
+// kernel at; callers that have the rotor use bms_rotate_const, which never forms D.
+static int upload(bms_ctx* c, const char* name, const void* host, size_t bytes, void** dev);
+extern "C" int bms_rotate_const_D(bms_ctx* c, void* data, int mem, int64_t n_times, int64_t ld, int ell_min, int ell_max,
+                                  const void* D_host) {
+  if (!c || !data || !D_host) return BMS_ERR_INVALID;
+  HIP_TRY(c, hipSetDevice(c->device));
+  if (n_times < 0 || ell_min < 0 || ell_max < ell_min) return fail(c, BMS_ERR_INVALID, "bad sizes");
+  const int64_t n_modes = LM_total_size(ell_min, ell_max);
+  if (ld < n_modes) return fail(c, BMS_ERR_INVALID, "row stride %lld smaller than %lld modes", (long long)ld, (long long)n_modes);
+  if (n_times == 0) return BMS_OK;
+  // padded B operands, one after the other
+  auto round_up = [](long long a, long long b) { return (a + b - 1) / b * b; };
+  std::vector<size_t> boff(ell_max + 2, 0);
+  for (int l = ell_min; l <= ell_max; ++l)
+    boff[l + 1] = boff[l] + (size_t)round_up(2 * l + 1, 8) * (size_t)round_up(2 * l + 1, 64) * 2;
+  std::vector<double> B(boff[ell_max + 1], 0.0);
+  const double* D = (const double*)D_host;
+  for (int l = ell_min; l <= ell_max; ++l) {
+    const int n = 2 * l + 1;
+    const size_t pitch = (size_t)round_up(n, 64) * 2;
+    const long long off = linear_matrix_offset(l, ell_min);
+    for (int r = 0; r < n; ++r)
+      for (int q = 0; q < n; ++q) {
+        B[boff[l] + r * pitch + 2 * q] = D[2 * (off + (long long)r * n + q)];
+        B[boff[l] + r * pitch + 2 * q + 1] = D[2 * (off + (long long)r * n + q) + 1];
+      }
+  }
+  void* vp;
+  int rc = upload(c, "rotD_B", B.data(), 8 * B.size(), &vp);
+  if (rc) return rc;
+  const double* d_B = (const double*)vp;
+  const size_t data_bytes = ((size_t)(n_times - 1) * ld + n_modes) * 16;  // a strided view ends with its last row's modes
+  double* d_data = (double*)data;
+  if (mem == BMS_HOST) {
+    if ((rc = dev_buf_t(c, "rot_data", data_bytes / 8, &d_data))) return rc;
+    HIP_TRY(c, hipMemcpyAsync(d_data, data, data_bytes, hipMemcpyHostToDevice, c->stream));
+  }
+  double* d_tmp;
+  if ((rc = dev_buf_t(c, "rotD_out", (size_t)n_times * n_modes * 2, &d_tmp))) return rc;
+  for (int l = ell_min; l <= ell_max; ++l) {
+    const int n = 2 * l + 1;
+    const long long col = (long long)l * l - (long long)ell_min * ell_min;
+    TIMED(c, BMS_TAG_ROTATE, launch_zgemm3m(c->stream, d_data + 2 * col, 2 * ld, d_B + boff[l], round_up(n, 64) * 2,
+                                            d_tmp + 2 * col, 2 * n_modes, n_times, n, n, nullptr, nullptr));
+  }
+  HIP_TRY(c, hipMemcpy2DAsync(d_data, (size_t)ld * 16, d_tmp, (size_t)n_modes * 16, (size_t)n_modes * 16, (size_t)n_times,
+                              hipMemcpyDeviceToDevice, c->stream));
+  if (mem == BMS_HOST) HIP_TRY(c, hipMemcpyAsync(data, d_data, data_bytes, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));  // B was staged from a host vector
+  return BMS_OK;
 }
 
 // D matrices through the rotation kernel itself: rotate the identity blocks (row (l, m') = delta_{m'})

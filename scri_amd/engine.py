@@ -59,6 +59,21 @@ def rotate_const(data, ell_min, ell_max, quaternion, ctx=None):
     return data
 
 
+def rotate_const_D(data, ell_min, ell_max, D, ctx=None):
+    """In place with the packed Wigner matrices handed over, the signature of the reference's numba kernel
+    (scri/rotations.py:346-367; D block l row-major (m', m) at sf._linear_matrix_offset(l, ell_min))."""
+    ctx = _ctx(ctx)
+    assert data.dtype == np.complex128 and data.ndim == 2 and data.strides[1] == 16
+    D = np.ascontiguousarray(D, dtype=np.complex128)
+    if D.shape != (total_size_D_matrices(ell_min, ell_max),):
+        raise ValueError(f"D must hold {total_size_D_matrices(ell_min, ell_max)} elements, got shape {D.shape}")
+    rc = _lib.load().bms_rotate_const_D(
+        ctx.handle, vptr(data), BMS_HOST, data.shape[0], data.strides[0] // 16, ell_min, ell_max, vptr(D)
+    )
+    ctx.check(rc, "bms_rotate_const_D")
+    return data
+
+
 def rotate_series(data, ell_min, ell_max, spinors, ctx=None):
     """In place, one rotor per time step; spinors complex128 [N, 2] = (w + i z, y + i x)
     (scri/rotations.py:370-392)."""

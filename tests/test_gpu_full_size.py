@@ -228,7 +228,13 @@ def _abd_window_check(got_u, got_raw, kw, ell_max, windows, margin=60):
         scale = max(1.0, np.abs(e.raw).max())
         for f, name in enumerate(("psi0", "psi1", "psi2", "psi3", "psi4", "sigma")):
             err = np.abs(got_raw[f][gi] - e.raw[f][sel]).max()
-            assert err < 1e-12 * scale, (i0, name, err)
+            # The reference forms each direction's spline abscissae as k (u - alpha) (transformations.py:408): at |u| ~ 2e4
+            # their rounding, eps |u|, is a time shift that moves the result by eps |u| |df'/du'| -- 7e-11 for psi0' at
+            # l <= 8, ~1e-9 at l <= 24, where the Horner mixing has multiplied psi4 by X^4 ~ (beta u)^4 ~ 2e3 (measured with
+            # the oracle alone: one ulp on its abscissae changes its own output by that much).  The reference's result is
+            # not defined more sharply than that, so the bar is the parity 1e-12 plus a few of those roundings.
+            noise = 8 * np.finfo(float).eps * np.abs(e.u).max() * np.abs(np.gradient(e.raw[f], e.u, axis=0)).max()
+            assert err < 1e-12 * scale + noise, (i0, name, err, noise)
 
 
 @pytest.mark.parametrize("rank", [0, 7])

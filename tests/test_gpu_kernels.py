@@ -100,3 +100,29 @@ def test_cubic_spline_matches_scipy(ctx):
         got = engine.cubic_spline(x, y, xn, ctx=ctx)
         expect = CubicSpline(x, y)(xn)
         assert np.abs(got - expect).max() < 2e-13, n
+
+
+@pytest.mark.parametrize("ell_min,ell_max,n", [(2, 8, 333), (0, 16, 70), (3, 40, 19)])
+def test_rotate_const_D_matches_oracle(ctx, ell_min, ell_max, n):
+    """bms_rotate_const_D: the reference's numba kernel at its own signature (scri/rotations.py:346-367), the packed D
+    matrices handed over by the caller; l = 40 spans two 64-column panels of the GEMM."""
+    from oracle import rotations_ref
+    from scri_amd import engine
+
+    rng = np.random.default_rng(ell_max)
+    data = rng.normal(size=(n, wigner.LM_total_size(ell_min, ell_max))) + 1j * rng.normal(size=(n, wigner.LM_total_size(ell_min, ell_max)))
+    q = rng.normal(size=4)
+    q /= np.linalg.norm(q)
+    Ra, Rb = quat.as_spinor_array(q)
+    D = wigner.wigner_D_matrices(Ra, Rb, ell_min, ell_max)
+    expect = rotations_ref.rotate_by_constant(data, ell_min, ell_max, D)
+    got = engine.rotate_const_D(data.copy(), ell_min, ell_max, D, ctx=ctx)
+    assert np.abs(got - expect).max() < 1e-13 * ell_max
+    # a strided view: only the mode columns change
+    wide = np.zeros((n, data.shape[1] + 7), dtype=complex)
+    wide[:, 2 : 2 + data.shape[1]] = data
+    engine.rotate_const_D(wide[:, 2 : 2 + data.shape[1]], ell_min, ell_max, D, ctx=ctx)
+    assert np.abs(wide[:, 2 : 2 + data.shape[1]] - expect).max() < 1e-13 * ell_max
+    assert np.all(wide[:, :2] == 0) and np.all(wide[:, 2 + data.shape[1] :] == 0)
+    with pytest.raises(ValueError):
+        engine.rotate_const_D(data.copy(), ell_min, ell_max, D[:-1], ctx=ctx)
