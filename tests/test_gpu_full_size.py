@@ -245,10 +245,13 @@ def test_cfg5_shard_six_fields_match_oracle(ctx, rank):
     from scri_amd import engine, sharding, synthetic
 
     spec = synthetic.CONFIGS["cfg5"]
-    kw = spec["kwargs"]
+    # working_ell_max = 49 -> the 99 x 99 grid (the default would be 2 l_max + l_max of the
+    # supertranslation = 50); passed explicitly to the oracle, built into `tr` for the engine
+    kw = dict(spec["kwargs"], working_ell_max=49)
     n, L = spec["n_times"], spec["ell_max"]
     u = np.arange(n) * spec["dt"]
-    tr = engine.make_transformation(kw["supertranslation"], kw["frame_rotation"], kw["boost_velocity"], 99, 99, L)
+    n_theta = 2 * kw["working_ell_max"] + 1
+    tr = engine.make_transformation(kw["supertranslation"], kw["frame_rotation"], kw["boost_velocity"], n_theta, n_theta, L)
     have, need, window = sharding.plan(u, tr, 8)
     assert have[rank][1] - have[rank][0] == 25_000
     _, raw, _ = synthetic.abd_workload("cfg5", rows=need[rank])
