@@ -63,6 +63,8 @@ struct bms_ctx {
   std::map<std::string, DevBuf> bufs;  // grow-only named work space
   int delta_lmax = -1;                 // Delta tables cached up to this l
   int delta_mfma_lmax = -1;            // ... in the MFMA B-image packing
+  std::map<std::pair<int, int>, RotResPlan> rot_res_plans;  // LDS-resident table images built so far, by (ell_min, ell_max)
+  int n_cu = 0;
   // analysis tables depend on the grid, the spin and the l range only: kept per tag until a call asks for other ones
   std::map<std::string, std::pair<std::array<int, 6>, AnalysisPlan>> plans;
   // optional per-kernel timing with HIP events on the context's stream (bms_ctx_enable_timing)
@@ -454,6 +456,35 @@ static int ensure_delta_mfma(bms_ctx* c, int lmax, const double** d_tab, const l
   return BMS_OK;
 }
 
+// LDS image of Delta^l for l = ell_min..ell_max (kernels_rotate_resident.hip); false if the range does not fit the LDS
+static int ensure_delta_resident(bms_ctx* c, int ell_min, int ell_max, bool* ok, RotResPlan* P, size_t* lds_bytes,
+                                 const double** d_tab, unsigned int** d_counter) {
+  *ok = rotate_resident_plan(ell_min, ell_max, P, lds_bytes);
+  if (!*ok) return BMS_OK;
+  char name[64];
+  snprintf(name, sizeof name, "rot_res_tab_%d_%d", ell_min, ell_max);
+  int rc = dev_buf_t(c, "rot_res_counter", 4, d_counter);
+  if (rc) return rc;
+  if (!c->n_cu) {
+    hipDeviceProp_t prop;
+    HIP_TRY(c, hipGetDeviceProperties(&prop, c->device));
+    c->n_cu = prop.multiProcessorCount;
+  }
+  double* dt = nullptr;
+  if ((rc = dev_buf_t(c, name, (size_t)P->tab_doubles, &dt))) return rc;
+  *d_tab = dt;
+  if (c->rot_res_plans.count({ell_min, ell_max})) return BMS_OK;
+  std::vector<double> image((size_t)P->tab_doubles, 0.0), D;
+  for (int l = ell_min; l <= ell_max; ++l) {
+    delta_matrix<long double>(l, D);
+    rotate_resident_pack(*P, l, D.data(), image.data());
+  }
+  HIP_TRY(c, hipMemcpyAsync(dt, image.data(), sizeof(double) * image.size(), hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));  // the host vector goes out of scope
+  c->rot_res_plans[{ell_min, ell_max}] = *P;
+  return BMS_OK;
+}
+
 // ====================================================================================================== rotation
 
 static int rotate_impl(bms_ctx* c, void* data, int mem, int64_t n_times, int64_t ld, int ell_min, int ell_max,
@@ -464,13 +495,25 @@ static int rotate_impl(bms_ctx* c, void* data, int mem, int64_t n_times, int64_t
   const int64_t n_modes = LM_total_size(ell_min, ell_max);
   if (ld < n_modes) return fail(c, BMS_ERR_INVALID, "row stride %lld smaller than %lld modes", (long long)ld, (long long)n_modes);
   if (n_times == 0) return BMS_OK;
-  const bool use_mfma = rotate_mfma_supported(ell_max) && !getenv("SCRI_AMD_ROTATE_VALU");
-  if (!use_mfma && rotate_waves_per_block(ell_max) < 1)
+  // three kernels: tables resident in the LDS (the l ranges of the headline configurations), tables staged per l
+  // (l <= 33), VALU beyond
+  bool use_res = false;
+  RotResPlan res_plan;
+  size_t res_lds = 0;
+  const double* d_res_tab = nullptr;
+  unsigned int* d_res_counter = nullptr;
+  int rc = BMS_OK;
+  if (!getenv("SCRI_AMD_ROTATE_VALU") && !getenv("SCRI_AMD_ROTATE_STAGED"))
+    if ((rc = ensure_delta_resident(c, ell_min, ell_max, &use_res, &res_plan, &res_lds, &d_res_tab, &d_res_counter))) return rc;
+  const bool use_mfma = !use_res && rotate_mfma_supported(ell_max) && !getenv("SCRI_AMD_ROTATE_VALU");
+  if (!use_res && !use_mfma && rotate_waves_per_block(ell_max) < 1)
     return fail(c, BMS_ERR_UNSUPPORTED, "ell_max=%d too large for the rotation kernels", ell_max);
-  const double* d_delta;
-  const long long* d_off;
-  int rc = use_mfma ? ensure_delta_mfma(c, ell_max, &d_delta, &d_off) : ensure_delta(c, ell_max, &d_delta, &d_off);
-  if (rc) return rc;
+  const double* d_delta = nullptr;
+  const long long* d_off = nullptr;
+  if (!use_res) {
+    rc = use_mfma ? ensure_delta_mfma(c, ell_max, &d_delta, &d_off) : ensure_delta(c, ell_max, &d_delta, &d_off);
+    if (rc) return rc;
+  }
   double* d_data = (double*)data;
   const double* d_rot = (const double*)spinors;
   const size_t data_bytes = ((size_t)(n_times - 1) * ld + n_modes) * 16;  // a strided view ends with its last row's modes
@@ -487,7 +530,10 @@ static int rotate_impl(bms_ctx* c, void* data, int mem, int64_t n_times, int64_t
     if (rc) return rc;
     HIP_TRY(c, hipMemcpyAsync(d_data, data, data_bytes, hipMemcpyHostToDevice, c->stream));
   }
-  if (use_mfma)
+  if (use_res)
+    TIMED(c, BMS_TAG_ROTATE, launch_rotate_modes_resident(c->stream, d_data, n_times, ld, d_rot, series ? 4 : 0, d_res_tab, res_plan, res_lds,
+                                                          d_res_counter, c->n_cu));
+  else if (use_mfma)
     TIMED(c, BMS_TAG_ROTATE, launch_rotate_modes_mfma(c->stream, d_data, n_times, ld, ell_min, ell_max, d_rot, series ? 4 : 0, d_delta, d_off));
   else
     TIMED(c, BMS_TAG_ROTATE, launch_rotate_modes(c->stream, d_data, n_times, ld, ell_min, ell_max, d_rot, series ? 4 : 0, d_delta, d_off));

@@ -21,6 +21,19 @@ hipError_t launch_rotate_modes_mfma(hipStream_t stream, double* data, long long 
                                     int ell_max, const double* RaRb, long long rotor_stride, const double* btab,
                                     const long long* boff);
 
+// Wave-autonomous formulation with all tables of the l range resident in the LDS (kernels_rotate_resident.hip)
+constexpr int RR_THREADS = 512, RR_WAVES = 8, RR_MAXL = 24;
+struct RotResPlan {
+  int ell_min, ell_max, n_groups, kpad_max, tab_doubles;
+  int grp_lo[4], grp_hi[4];
+  int tab_off[RR_MAXL];  // doubles, per l - ell_min
+};
+bool rotate_resident_plan(int ell_min, int ell_max, RotResPlan* P, size_t* lds_bytes);
+void rotate_resident_pack(const RotResPlan& P, int ell, const double* Delta, double* image);
+hipError_t launch_rotate_modes_resident(hipStream_t stream, double* data, long long n_times, long long ld, const double* RaRb,
+                                        long long rotor_stride, const double* tab_global, const RotResPlan& P, size_t lds_bytes,
+                                        unsigned int* counter, int n_cu);
+
 // ---- SWSH matrices (sf.SWSH_grid, waveform_grid.py:470-484)
 // Bmat[2k][2p] = Re Y_k(R_p), [2k][2p+1] = Im, [2k+1][2p] = -Im, [2k+1][2p+1] = Re;  k = LM_index(l,m,ell_min)
 hipError_t launch_swsh_matrix(hipStream_t stream, const double* rotors /* f8[n_pix][4] */, int n_pix, int spin,

@@ -194,7 +194,11 @@ def test_rotation_bookkeeping_and_inversion(ctx):
             assert not np.array_equal(w.data, w0.data)
             w.rotate_decomposition_basis(quat.qconj(R))
             assert np.max(np.abs(w.frame - w0.frame)) < 1e-15
-            assert np.allclose(w.data, w0.data, atol=1e-12, rtol=w.ell_max**4 * 4e-14)
+            # the reference writes atol=ell_max ** 4 ** 4e-14 (tests/test_rotations.py:112), which Python reads as
+            # ell_max ** (4 ** 4e-14) = 8.0; its evident intent, ell_max**4 * 4e-14 = 1.6e-10 like the rtol beside it, is
+            # the bar here.  (Zero modes next to |data| ~ 1e3 come back at 1-2e-12 from two rotations: fp64 noise of two
+            # 17-term sums per rotation, tools/rotation_roundtrip_probe.py.)
+            assert np.allclose(w.data, w0.data, atol=w.ell_max**4 * 4e-14, rtol=w.ell_max**4 * 4e-14)
     with pytest.raises(ValueError, match="Input dimension mismatch"):
         to_gpu(samples.linear_waveform(n_times=20), ctx).rotate_decomposition_basis(np.ones((7, 4)))
 
