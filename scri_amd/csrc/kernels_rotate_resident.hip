@@ -26,6 +26,7 @@
 //     of its current one.
 // Every mode is still read and written exactly once from HBM (2 x 16 n_modes + 32 B per step).
 // Rotors with |Rb| ~ 0 / |Ra| ~ 0 take exact diagonal / anti-diagonal branches (identity stays bit-exact).
+#include <cstdlib>
 #include "wigner.h"
 #include "kernels.h"
 
@@ -365,7 +366,10 @@ bool rotate_resident_plan(int ell_min, int ell_max, RotResPlan* P, size_t* lds_b
   int total = 0;
   for (int l = ell_min; l <= ell_max; ++l) total += cost(l);
   const int nl = ell_max - ell_min + 1;
-  int G = nl >= 8 ? 4 : (nl >= 4 ? 2 : 1);
+  // two groups from 4 l on: measured on l = 2..16 and 2..8 (tools/bench_rotation.py, 1e5 and 1e6 steps), 1 / 2 / 3 / 4 groups
+  // are within 5 % of each other; 2 is best at 1e5 steps, where the number of rounds per wave is small
+  int G = nl >= 4 ? 2 : 1;
+  if (const char* e = getenv("SCRI_AMD_ROTATE_GROUPS")) G = atoi(e) < 1 ? 1 : (atoi(e) > 4 ? 4 : atoi(e));
   P->n_groups = 0;
   int l = ell_min, used = 0;
   for (int gidx = 0; gidx < G && l <= ell_max; ++gidx) {
