@@ -4,10 +4,13 @@
   python bench.py --gpus N --steps K --warmup W        (N > 1: launched under torch.distributed.run)
 
 A "step" is one full BMS transformation (supertranslation + frame rotation + boost) of one synthetic
-WaveformModes series that is already resident in HBM: workload cfg3 of BASELINE.json / SURVEY section 8(d)
-(h, ell = 2..16, 285 modes, 1e5 time steps, 37 x 37 grid).  With N > 1 the time axis is sharded (weak scaling:
-every rank owns 1e5 steps of an N x 1e5 series), the input-mode halos are exchanged over RCCL inside the timed
-region, and `value` is the whole-job rate.  Rank 0 prints ONE JSON line.
+WaveformModes series that is already resident in HBM.  N = 1: workload cfg3 of BASELINE.json / SURVEY section 8(d)
+(h, ell = 2..16, 285 modes, 1e5 time steps, 37 x 37 grid).  N > 1: workload cfg4, the SAME transformation of a
+1e6-step series whose time axis is sharded over the N ranks (STRONG scaling: total work fixed; BASELINE.json
+configs[3] / north star): the input-mode halos are exchanged over RCCL point-to-point inside the timed region, `value`
+is the whole-job rate, and before the sharded loop rank 0 transforms the whole 1e6-step series on its own GPU so that
+the line carries its own single-GPU reference (`strong_scaling`).  `--workload` overrides (cfg3 with N > 1 = the weak
+scaling of round 1: 1e5 steps per rank).  Rank 0 prints ONE JSON line.
 """
 import argparse
 import json
@@ -185,8 +188,14 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--workload", default="cfg3", choices=["cfg2", "cfg3", "cfg5"])
-    ap.add_argument("--n-times", type=int, default=None, help="time steps PER GPU (default: 1e5; cfg5: 2e5 / 8)")
+    ap.add_argument("--workload", default=None, choices=["cfg2", "cfg3", "cfg4", "cfg5"],
+                    help="default: cfg3 on one GPU, cfg4 (1e6 steps in all, strong scaling) on several")
+    ap.add_argument("--n-times", type=int, default=None,
+                    help="time steps PER GPU (default: 1e5; cfg5: 2e5 / 8); cfg4: time steps IN ALL (default 1e6)")
+    ap.add_argument("--overlap-halo", action="store_true",
+                    help="N > 1, time shards: transform the outputs that need own rows only while the halos travel, then the "
+                    "two edges (three engine calls per step instead of one)")
+    ap.add_argument("--no-n1-reference", action="store_true", help="cfg4: skip the single-GPU pass of the whole series on rank 0")
     ap.add_argument("--working-ell-max", type=int, default=None, help="cfg5 only (default 2 ell_max + 1 = 49 -> 99 x 99 grid)")
     ap.add_argument("--cpu-sample", type=int, default=30000, help="time steps of the CPU-baseline sample (0: skip)")
     ap.add_argument("--partition", default="auto", choices=["auto", "rows", "columns"],
@@ -194,6 +203,8 @@ def main():
                     "boosts); auto = sharding.choose_partition (rows for the BASELINE.json workloads)")
     ap.add_argument("--boost-scale", type=float, default=1.0, help="multiplies the workload's boost velocity (stress variants)")
     args = ap.parse_args()
+    if args.workload is None:
+        args.workload = "cfg3" if args.gpus == 1 else "cfg4"
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -227,8 +238,13 @@ def main():
     spec = dict(synthetic.CONFIGS[args.workload])
     spec["name"] = args.workload
     abd = args.workload == "cfg5"
-    per_gpu = int(args.n_times or (spec["n_times"] // 8 if abd else spec["n_times"]))
-    n_global = per_gpu * world
+    strong = args.workload == "cfg4"  # total work fixed, sharded `world` ways
+    if strong:
+        n_global = int(args.n_times or spec["n_times"])
+        per_gpu = -(-n_global // world)
+    else:
+        per_gpu = int(args.n_times or (spec["n_times"] // 8 if abd else 100_000))
+        n_global = per_gpu * world
     kw = dict(spec["kwargs"])
     if args.boost_scale != 1.0:
         kw["boost_velocity"] = np.asarray(kw["boost_velocity"], dtype=float) * args.boost_scale
@@ -275,6 +291,64 @@ def main():
         local = ext_buf[lo : lo + own]
     ctx = _lib.Context(dev_index)
     ctx.enable_timing(True)
+    halo_rows = (have[rank][0] - need[rank][0], need[rank][1] - have[rank][1]) if world > 1 else (0, 0)
+
+    # ---- cfg4: the whole series on ONE GPU (rank 0's), in the same run: the reference of the strong-scaling line
+    n1 = None
+    if strong and world > 1 and not args.no_n1_reference:
+        if rank == 0:
+            _, whole_host, _ = synthetic.workload(args.workload, n_times=n_global)
+            whole = torch.from_numpy(whole_host).to(dev)
+            del whole_host
+            whole_out = torch.empty((n_global, n_modes), dtype=torch.complex128, device=dev)
+            reps = 3
+            for i in range(reps + 1):
+                if i == 1:
+                    ctx.synchronize()
+                    t1 = time.perf_counter()
+                engine.transform_modes(t_global, whole.data_ptr(), 2, ell_max, -2, -1, engine.BMS_TERM_H, tr, ctx=ctx, device=True,
+                                       ld=n_modes, out_ptr=whole_out.data_ptr())
+            ctx.synchronize()
+            n1 = {"ms_per_step": 1e3 * (time.perf_counter() - t1) / reps, "steps": reps, "where": "rank 0's GPU, before the sharded loop"}
+            del whole, whole_out
+            torch.cuda.empty_cache()
+            ctx.get_timing(reset=True)
+        dist.barrier()
+
+    # N > 1 on RCCL: the engine runs on torch's current stream, so the halo rows (received on RCCL's stream, which the
+    # current stream waits for in req.wait()) are ordered before the kernels that read them without a host-side
+    # synchronisation of the device
+    stream_ordered = world > 1 and backend == "nccl"
+    if stream_ordered:
+        ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+
+    # --overlap-halo: outputs [a, b) of this rank need its own rows only (bms_shard_plan says so); they are transformed
+    # while the halos travel, the edges [i0, a) and [b, i1) afterwards
+    interior = None
+    if args.overlap_halo and world > 1 and not abd and not columns:
+        i0, i1 = have[rank]
+        a, b = i0 + 2 * halo_rows[0] + 8, i1 - 2 * halo_rows[1] - 8
+        if rank == 0:
+            a = i0
+        if rank == world - 1:
+            b = i1
+        while b - a > 64:
+            (n0, n1_), _ = engine.shard_plan(t_global, tr, a, b)
+            if n0 >= i0 and n1_ <= i1:
+                break
+            a, b = (a + 16 if n0 < i0 else a), (b - 16 if n1_ > i1 else b)
+        if b - a > 64:
+            interior = (a, b)
+
+    def transform_rows(src_ptr, src_row0, src_rows, o0, o1):
+        """outputs with global index in [o0, o1) from the rows [src_row0, src_row0 + src_rows) at src_ptr -> their place in `out`"""
+        if o1 <= o0:
+            return 0
+        first_out = max(o0, window[0]) - max(have[rank][0], window[0])
+        return engine.transform_modes(
+            t_global, src_ptr, 2, ell_max, -2, -1, engine.BMS_TERM_H, tr, ctx=ctx, device=True, ld=n_modes,
+            out_ptr=out.data_ptr() + 16 * n_modes * max(first_out, 0), shard=(src_row0, src_rows, o0, o1),
+        )[1]
 
     def step():
         if columns:
@@ -287,9 +361,20 @@ def main():
             )
             rows, _ = sharding.reduce_scatter_rows(part_buf, n_new_all)
             return rows.shape[0]
+        if world > 1 and interior is not None:
+            i0, i1 = have[rank]
+            pending = sharding.exchange_halos(local, have[rank], need[rank], have, need, out=ext_buf, wait=False)
+            n_new = transform_rows(local.data_ptr(), i0, own, interior[0], interior[1])  # own rows only: runs under the exchange
+            ext = pending()
+            if not stream_ordered:
+                torch.cuda.synchronize()
+            n_new += transform_rows(ext.data_ptr(), need[rank][0], ext.shape[0], i0, interior[0])
+            n_new += transform_rows(ext.data_ptr(), need[rank][0], ext.shape[0], interior[1], i1)
+            return n_new
         if world > 1:
             ext = sharding.exchange_halos(local, have[rank], need[rank], have, need, dim=1 if abd else 0, out=ext_buf)
-            torch.cuda.synchronize()
+            if not stream_ordered:
+                torch.cuda.synchronize()
         else:
             ext = local
         row0 = need[rank][0] if world > 1 else 0
@@ -341,6 +426,7 @@ def main():
         line = {
             "metric": {
                 "cfg3": "timesteps/sec for full BMS transform, l_max=16, 1e5 steps; fp64",
+                "cfg4": "timesteps/sec for full BMS transform, l_max=16, 1e6 steps sharded over the GPUs; fp64",
                 "cfg2": "timesteps/sec for BMS transform (cfg2)",
                 "cfg5": "timesteps/sec for AsymptoticBondiData BMS transform (cfg5: psi0..psi4 + sigma, l_max=24)",
             }[args.workload],
@@ -351,7 +437,7 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": ms_per_step,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong" if strong else "weak",
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
@@ -362,6 +448,7 @@ def main():
                 )
                 + f"{per_gpu} time steps per GPU ({n_global} total), supertranslation(l<=2) + frame_rotation + boost |v|={3.7417e-4 * args.boost_scale:.3g}, "
                 f"{n_theta}x{n_theta} grid, {n_out} output steps on rank 0",
+                "ranks": {"world_size": dist.get_world_size() if world > 1 else 1, "backend": dist.get_backend() if world > 1 else None},
                 "sharding": "none" if world == 1 else (
                     f"grid columns x{world}: all-gather of input modes, reduce-scatter of output modes (RCCL)" if columns
                     else f"time axis x{world}, RCCL point-to-point halo exchange of input modes"),
@@ -384,6 +471,23 @@ def main():
             },
             "kernels": kernels,
         }
+        if world > 1 and not columns:
+            all_halo = [(have[r][0] - need[r][0], need[r][1] - have[r][1]) for r in range(world)]
+            row_bytes = 16 * n_modes * n_fields
+            line["halo"] = {
+                "rows_per_rank_before_after": all_halo,
+                "bytes_received_per_rank": [row_bytes * (a + b) for a, b in all_halo],
+                "exchange": "RCCL point-to-point (batch_isend_irecv) of input-mode rows, ordered on the engine's stream" if stream_ordered
+                else "gloo dry run through host memory",
+                "overlap": (f"interior outputs [{interior[0]}, {interior[1]}) of rank 0 transformed under the exchange, edges after it"
+                            if interior is not None else "none (one engine call per step after the exchange)"),
+            }
+        if strong:
+            line["strong_scaling"] = {
+                "n_times_total": n_global,
+                "n1_same_run": n1,
+                "speedup_vs_n1_same_run": (n1["ms_per_step"] / ms_per_step) if n1 else None,
+            }
         if not abd:
             # the HBM-bound stages against the 8 TB/s peak, with the algorithmic bytes of SURVEY 8(d) (grid = the columns
             # actually stored, n_cols) over the HIP-event kernel times; and the whole transform against the same table

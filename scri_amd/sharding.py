@@ -16,7 +16,7 @@ def shard_bounds(n_times, world_size, rank):
     return i0, i0 + base + (1 if rank < rem else 0)
 
 
-def exchange_halos(local, have, need, all_have, all_need, group=None, dim=0, out=None):
+def exchange_halos(local, have, need, all_have, all_need, group=None, dim=0, out=None, wait=True):
     """Return rows [need[0], need[1]) of the global array, given this rank's rows `local` = [have[0], have[1]).
 
     local: torch tensor [rows, cols] float64/complex128 (CPU for gloo, GPU for nccl); `dim` names the time axis
@@ -24,7 +24,9 @@ def exchange_halos(local, have, need, all_have, all_need, group=None, dim=0, out
     all_have / all_need: per-rank (start, stop) lists known to every rank (static plan, no communication).
     Rows outside every rank's range are never requested.
     out: optional preallocated result (time axis first, shape of the return value) whose own-row block already holds
-    `local` (e.g. `local` is a view of it): then only the halo rows move."""
+    `local` (e.g. `local` is a view of it): then only the halo rows move.
+    wait=False: start the transfers and return a function that completes them and returns the rows -- the caller works on
+    its own rows in between (bench.py --overlap-halo)."""
     import torch
     import torch.distributed as dist
 
@@ -68,17 +70,22 @@ def exchange_halos(local, have, need, all_have, all_need, group=None, dim=0, out
         a, b = max(all_need[peer][0], have[0]), min(all_need[peer][1], have[1])
         if b > a:
             ops.append(dist.P2POp(dist.isend, loc[a - have[0] : b - have[0]].contiguous(), peer, group))
-    if ops:
-        for req in dist.batch_isend_irecv(ops):
+    reqs = dist.batch_isend_irecv(ops) if ops else []
+
+    def finish():
+        for req in reqs:
             req.wait()
-    for a, b, buf in recv_bufs:
-        out[a - need[0] : b - need[0]] = buf
-    if prefilled:
-        return result
-    out = torch.view_as_complex(out) if is_complex else out
-    if out.device != device:
-        out = out.to(device)
-    return out.movedim(0, dim).contiguous() if dim != 0 else out
+        o = out
+        for a, b, buf in recv_bufs:
+            o[a - need[0] : b - need[0]] = buf
+        if prefilled:
+            return result
+        o = torch.view_as_complex(o) if is_complex else o
+        if o.device != device:
+            o = o.to(device)
+        return o.movedim(0, dim).contiguous() if dim != 0 else o
+
+    return finish() if wait else finish
 
 
 def plan(t_global, transformation, world_size):

@@ -248,3 +248,33 @@ print("ok")
 ''' % __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__)))
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and "ok" in out.stdout.split(), out.stderr[-2000:]  # (RCCL prints its banner at exit)
+
+
+def test_interior_and_edges_equal_the_one_call_shard(ctx):
+    """bench.py --overlap-halo: a rank's outputs as three engine calls -- the interior from its own rows only (what runs
+    while the halos travel), then the two edges from the completed rows -- equal the one-call shard bit for bit in the
+    times and to rounding in the data."""
+    from scri_amd import engine, sharding, synthetic
+
+    t, data, spec = synthetic.workload("cfg3", n_times=6000)
+    kw = dict(spec["kwargs"])
+    kw["boost_velocity"] = np.array([1.0, 2.0, 3.0]) * 1e-3
+    data = data[:, : 9 * 9 - 4]
+    tr = engine.make_transformation(kw["supertranslation"], kw["frame_rotation"], kw["boost_velocity"], 21, 21, 8)
+    have, need, window = sharding.plan(t, tr, 3)
+    r = 1
+    i0, i1 = have[r]
+    ext = data[need[r][0] : need[r][1]]
+    t_ref, d_ref, first = engine.transform_modes(t, ext, 2, 8, -2, -1, engine.BMS_TERM_H, tr, ctx=ctx, shard=(need[r][0], ext.shape[0], i0, i1))
+    a, b = i0 + 2 * (i0 - need[r][0]) + 8, i1 - 2 * (need[r][1] - i1) - 8
+    (n0, n1), _ = engine.shard_plan(t, tr, a, b)
+    assert i0 <= n0 and n1 <= i1 and b - a > 1000
+    own = data[i0:i1]
+    pieces = [
+        engine.transform_modes(t, ext, 2, 8, -2, -1, engine.BMS_TERM_H, tr, ctx=ctx, shard=(need[r][0], ext.shape[0], i0, a)),
+        engine.transform_modes(t, own, 2, 8, -2, -1, engine.BMS_TERM_H, tr, ctx=ctx, shard=(i0, own.shape[0], a, b)),
+        engine.transform_modes(t, ext, 2, 8, -2, -1, engine.BMS_TERM_H, tr, ctx=ctx, shard=(need[r][0], ext.shape[0], b, i1)),
+    ]
+    assert [p[2] for p in pieces] == [first, a, b]
+    assert np.array_equal(np.concatenate([p[0] for p in pieces]), t_ref)
+    assert np.abs(np.concatenate([p[1] for p in pieces]) - d_ref).max() < 1e-14 * np.abs(d_ref).max()

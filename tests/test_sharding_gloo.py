@@ -68,7 +68,23 @@ def _worker(rank, world, port, n_times, ell_max, tmpdir):
         buf[lo : lo + local.shape[0]] = local
         ext2 = sharding.exchange_halos(buf[lo : lo + local.shape[0]], have[rank], need[rank], have, need, out=buf)
         assert ext2 is buf and np.array_equal(buf.numpy(), ref_rows[:, :nm])
+        # deferred completion (bench.py --overlap-halo): the interior outputs need own rows only and are computed while
+        # the halos travel; the edges use the completed buffer; the three pieces are the shard's outputs, in order
+        buf[:] = np.nan + 0j
+        buf[lo : lo + local.shape[0]] = local
+        pending = sharding.exchange_halos(buf[lo : lo + local.shape[0]], have[rank], need[rank], have, need, out=buf, wait=False)
+        i0, i1 = have[rank]
+        a = i0 if rank == 0 else i0 + 2 * (i0 - need[rank][0]) + 8
+        b = i1 if rank == world - 1 else i1 - 2 * (need[rank][1] - i1) - 8
+        (n0, n1), _ = engine.shard_plan(t, tr, a, b)
+        assert i0 <= n0 and n1 <= i1 and b - a > 50  # the interior really needs no halo row
+        mid = _oracle_shard(t, local.numpy(), i0, a, b, kw, ell_max)
+        assert pending() is buf and np.array_equal(buf.numpy(), ref_rows[:, :nm])
+        left = _oracle_shard(t, buf.numpy(), need[rank][0], i0, a, kw, ell_max)
+        right = _oracle_shard(t, buf.numpy(), need[rank][0], b, i1, kw, ell_max)
         idx, t_out, data = _oracle_shard(t, ext.numpy(), need[rank][0], have[rank][0], have[rank][1], kw, ell_max)
+        assert np.array_equal(np.concatenate([left[0], mid[0], right[0]]), idx)
+        assert np.abs(np.concatenate([left[2], mid[2], right[2]]) - data).max() < 1e-13 * max(1.0, np.abs(data).max())
         np.savez(os.path.join(tmpdir, f"rank{rank}.npz"), idx=idx, t=t_out, data=data, window=np.array(window))
     finally:
         dist.destroy_process_group()
