@@ -3,6 +3,7 @@
 There is no CPU fallback: importing this module needs the built shared library, and creating a
 context needs an MI355X (gfx950).  Both failures raise immediately with the library's message.
 """
+import collections
 import ctypes
 import os
 import threading
@@ -178,20 +179,49 @@ def load():
 
 class _PinnedBlock:
     """A page-locked host allocation that numpy arrays can sit on (their .base keeps it alive).  Freed blocks of the sizes
-    in recent use are kept for the next result of that size: pinning hundreds of MB costs as much as copying them."""
+    in recent use are kept for the next result of that size: pinning hundreds of MB costs as much as copying them.
+    The pool holds at most `pool_limit()` bytes -- SCRI_AMD_PINNED_POOL_BYTES, default twice the largest block of the last
+    few requests (so a workflow that alternates two result sizes keeps both) -- and gives back the least recently used
+    blocks beyond that; `trim()` (also called by Context.close) releases everything."""
 
-    _pool = {}  # nbytes -> [ptr, ...]
+    _pool = collections.OrderedDict()  # nbytes -> [ptr, ...], least recently used size first
     _pool_lock = threading.RLock()  # re-entrant: a collection inside the critical section may finalise another block
     _pooled_bytes = 0
-    POOL_LIMIT = 8 << 30
+    _recent = collections.deque(maxlen=8)  # sizes of the last requests
+
+    @classmethod
+    def pool_limit(cls):
+        env = os.environ.get("SCRI_AMD_PINNED_POOL_BYTES")
+        if env is not None:
+            return int(env)
+        return 2 * max(cls._recent, default=0)
+
+    @classmethod
+    def _evict(cls, limit):
+        """Release least recently used blocks until the pool holds at most `limit` bytes (lock held by the caller)."""
+        while cls._pooled_bytes > limit and cls._pool:
+            size, ptrs = next(iter(cls._pool.items()))
+            ptr = ptrs.pop()
+            if not ptrs:
+                del cls._pool[size]
+            cls._pooled_bytes -= size
+            load().bms_host_free(ptr)
+
+    @classmethod
+    def trim(cls):
+        with cls._pool_lock:
+            cls._evict(0)
 
     def __init__(self, nbytes):
         self.nbytes = int(nbytes)
         with _PinnedBlock._pool_lock:
+            _PinnedBlock._recent.append(self.nbytes)
             free = _PinnedBlock._pool.get(self.nbytes)
             self.ptr = free.pop() if free else None
             if self.ptr is not None:
                 _PinnedBlock._pooled_bytes -= self.nbytes
+                if not free:
+                    del _PinnedBlock._pool[self.nbytes]
         if self.ptr is None:
             self.ptr = load().bms_host_alloc(self.nbytes)
         if not self.ptr:
@@ -204,9 +234,12 @@ class _PinnedBlock:
             return
         try:
             with _PinnedBlock._pool_lock:
-                if _PinnedBlock._pooled_bytes + self.nbytes <= _PinnedBlock.POOL_LIMIT:
+                limit = _PinnedBlock.pool_limit()
+                if self.nbytes <= limit:
                     _PinnedBlock._pool.setdefault(self.nbytes, []).append(ptr)
+                    _PinnedBlock._pool.move_to_end(self.nbytes)
                     _PinnedBlock._pooled_bytes += self.nbytes
+                    _PinnedBlock._evict(limit)
                     return
             load().bms_host_free(ptr)
         except Exception:  # interpreter shutdown
@@ -289,6 +322,7 @@ class Context:
         if getattr(self, "_h", None):
             load().bms_ctx_destroy(self._h)
             self._h = None
+            _PinnedBlock.trim()  # page-locked result blocks kept for reuse go back to the OS with the context
 
     def __del__(self):
         try:

@@ -104,6 +104,24 @@ struct ScopedTimer {  // brackets one kernel launch with two events when timing 
     if (c->timing) {
       (void)hipEventRecord(b, c->stream);
       c->timed.push_back({tag, a, b});
+      // a context that never asks for its timings must not collect events for ever: pairs that have completed are folded
+      // into the totals once a few thousand are pending (no synchronisation: unfinished pairs stay)
+      if (c->timed.size() > 4096) {
+        size_t keep = 0;
+        for (auto& t : c->timed) {
+          float f = 0.f;
+          if (hipEventQuery(t.b) == hipSuccess && hipEventElapsedTime(&f, t.a, t.b) == hipSuccess) {
+            c->tag_ms[t.tag] += f;
+            c->tag_calls[t.tag] += 1;
+            c->event_pool.push_back(t.a);
+            c->event_pool.push_back(t.b);
+          } else {
+            c->timed[keep++] = t;
+          }
+        }
+        c->timed.resize(keep);
+        (void)hipGetLastError();
+      }
     }
   }
 };
@@ -1284,7 +1302,8 @@ static int transform_modes_impl(bms_ctx* c, const bms_wm_input* in, const bms_tr
   // once, by the back substitution + evaluation.
   const bool bsg = n >= 8 && regular_mesh && !getenv("SCRI_AMD_NO_BSPLINE");  // B-spline form (else: the slope form, kernels_spline.hip)
   const bool bs = bsg && !psi;                                                 // ... with the elimination commuted onto the modes
-  if (!regular_mesh && (sh != nullptr))
+  // (a "shard" that holds every row of every column is the whole series: only its output range is restricted)
+  if (!regular_mesh && sh != nullptr && !(sh->data_row0 == 0 && sh->data_rows == n && sh->col_parts <= 1))
     return fail(c, BMS_ERR_UNSUPPORTED,
                 "the time steps vary by more than 1e3 within 48 samples: such a series is transformed with exact untiled spline "
                 "recurrences, which a time shard cannot provide");
@@ -1408,7 +1427,12 @@ static int transform_modes_impl(bms_ctx* c, const bms_wm_input* in, const bms_tr
   const int margin = SPLINE_HALO + 2;
   // bytes per output row ~ (Y + R + G [+ Yaux]) * ldg * 8
   const double bytes_per_row = (4.0 + (psi ? 1.0 : 0.0)) * ldg * 8.0;  // Y, R, G, F (+ Yaux)
-  int64_t chunk = (int64_t)std::max(1024.0, (double)c->ws_limit / bytes_per_row - 4.0 * margin);
+  // rows the work space limit allows; a chunk shorter than a few spline halos would spend its time re-synthesising them,
+  // so below that the limit is reported as too small rather than silently exceeded
+  int64_t chunk = (int64_t)((double)c->ws_limit / bytes_per_row - 4.0 * margin);
+  if (chunk < 4 * margin && chunk < n_new)
+    return fail(c, BMS_ERR_NOMEM, "work space limit of %llu bytes holds fewer than %d rows of the %d-column grids (%.0f bytes each); raise it with bms_ctx_set_workspace_limit",
+                (unsigned long long)c->ws_limit, 8 * margin, n_cols, bytes_per_row);
   chunk = std::min<int64_t>(chunk, n_new);
   if (!regular_mesh && chunk < n_new)
     return fail(c, BMS_ERR_UNSUPPORTED, "irregular time axis (steps vary by more than 1e3 within 48 samples): the series does not fit the work space in one piece");
@@ -1991,7 +2015,7 @@ extern "C" int bms_transform_abd_shard(bms_ctx* c, const double* u, const void* 
   bool regular_mesh = true;
   int rc = validate_common(c, n, u, tr, t_lo, t_hi, &regular_mesh);
   if (rc) return rc;
-  if (!regular_mesh && sh)
+  if (!regular_mesh && sh && !(sh->data_row0 == 0 && sh->data_rows == n && sh->col_parts <= 1))
     return fail(c, BMS_ERR_UNSUPPORTED,
                 "the time steps vary by more than 1e3 within 48 samples: such a series is transformed with exact untiled spline "
                 "recurrences, which a time shard cannot provide");
@@ -2101,7 +2125,10 @@ extern "C" int bms_transform_abd_shard(bms_ctx* c, const double* u, const void* 
   // ---- chunk loop: 6 fields x (Y, R, G)
   const int margin = SPLINE_HALO + 2;
   const double bytes_per_row = 19.0 * ldg * 8.0;  // 6 x (Y, R, G) + F
-  int64_t chunk = (int64_t)std::max(256.0, (double)c->ws_limit / bytes_per_row - 4.0 * margin);
+  int64_t chunk = (int64_t)((double)c->ws_limit / bytes_per_row - 4.0 * margin);
+  if (chunk < 4 * margin && chunk < n_new)
+    return fail(c, BMS_ERR_NOMEM, "work space limit of %llu bytes holds fewer than %d rows of the six %d-column grids (%.0f bytes each); raise it with bms_ctx_set_workspace_limit",
+                (unsigned long long)c->ws_limit, 8 * margin, n_cols, bytes_per_row);
   chunk = std::min<int64_t>(chunk, n_new);
   if (!regular_mesh && chunk < n_new)
     return fail(c, BMS_ERR_UNSUPPORTED, "irregular time axis (steps vary by more than 1e3 within 48 samples): the series does not fit the work space in one piece");

@@ -144,6 +144,10 @@ def _transform_modes_pipelined(t, data, inp, transformation, n_out, ctx):
     import threading
 
     n = t.shape[0]
+    # each shard only validates its own time window; a series that is not increasing everywhere goes to the one-call path,
+    # whose full check raises the ValueError the reference's callers expect
+    if not np.all(np.diff(t) > 0):
+        return None
     i_lo, i_hi = output_window(t, transformation, ctx=ctx)
     n_new = i_hi - i_lo
     if n_new < 8 * PIPELINE_PIECES:

@@ -263,5 +263,57 @@ def test_geometrically_graded_time_axis_takes_the_exact_path(ctx, ratio):
     assert got.t.size == expect.t.size and got.t.size > 100
     assert np.abs(got.data - expect.data).max() < 2e-12 * max(1.0, np.abs(expect.data).max())
     tr = engine.make_transformation(st, [1, 0, 0, 0], kw["boost_velocity"], 11, 11, ell_max)
+    # a "shard" that holds every row is the whole series with a restricted output range: same exact path
+    t_w, d_w, first = engine.transform_modes(t, data, 2, ell_max, -2, -1, engine.BMS_TERM_H, tr, ctx=ctx, shard=(0, n, 0, n))
+    assert np.array_equal(t_w, got.t) and np.abs(d_w - got.data).max() < 1e-14 * max(1.0, np.abs(got.data).max())
     with pytest.raises(NotImplementedError, match="time steps vary"):
-        engine.transform_modes(t, data, 2, ell_max, -2, -1, engine.BMS_TERM_H, tr, ctx=ctx, shard=(0, n, 0, n))
+        engine.transform_modes(t, data[50:650], 2, ell_max, -2, -1, engine.BMS_TERM_H, tr, ctx=ctx, shard=(50, 600, 200, 500))
+
+
+def test_geometrically_graded_time_axis_abd(ctx):
+    """The same axis through AsymptoticBondiData.transform (whose host path always names the whole series as a shard to
+    size its result exactly): exact single-tile recurrences, against the oracle."""
+    import scri_amd
+    from oracle import abd_ref
+    from oracle.containers import ABD
+
+    rng = np.random.default_rng(18)
+    n, ell_max = 500, 3
+    dt = np.concatenate([np.full(200, 1.0), 1.5 ** np.arange(1, 41), np.full(260, 1.5**40)])
+    dt /= dt.mean()
+    u = np.cumsum(dt)
+    nm = (ell_max + 1) ** 2
+    raw = np.zeros((6, n, nm), dtype=complex)
+    for f, s in enumerate(ABD.spins):
+        phase = np.outer(np.log(u + 1.0), rng.uniform(0.5, 3.0, size=nm))
+        raw[f] = (np.sin(phase) + 1j * np.cos(phase)) * rng.normal(size=nm)
+        raw[f, :, : s * s] = 0
+    kw = dict(supertranslation=np.array([0.05, 0, 0.02, 0, 0, 0, -0.01, 0, 0], dtype=complex), boost_velocity=np.array([0.01, -0.02, 0.015]))
+    expect = abd_ref.transform(ABD(u, raw, ell_max), **kw)
+    a = scri_amd.AsymptoticBondiData(u, ell_max, ctx=ctx)
+    a._raw_data[:] = raw
+    got = a.transform(**kw)
+    assert got.n_times == expect.n_times and got.n_times > 100
+    assert np.abs(got._raw_data - expect.raw).max() < 2e-12 * max(1.0, np.abs(expect.raw).max())
+
+
+def test_workspace_limit_too_small_is_reported(ctx):
+    """A work space limit that cannot hold a few spline halos of grid rows is an error (MemoryError), not silently exceeded."""
+    import scri_amd
+    from scri_amd import engine, synthetic
+
+    t, data, spec = synthetic.workload("cfg3", n_times=4000)
+    tr = engine.make_transformation(spec["kwargs"]["supertranslation"], spec["kwargs"]["frame_rotation"], spec["kwargs"]["boost_velocity"], 37, 37, 16)
+    tiny = scri_amd.Context(0, workspace_limit=4 << 20)  # 4 MiB: ~48 rows of the 1297-column grids
+    try:
+        with pytest.raises(MemoryError, match="work space limit"):
+            engine.transform_modes(t, data, 2, 16, -2, -1, engine.BMS_TERM_H, tr, ctx=tiny)
+    finally:
+        tiny.close()
+    ok = scri_amd.Context(0, workspace_limit=64 << 20)  # several chunks
+    try:
+        t1, d1 = engine.transform_modes(t, data, 2, 16, -2, -1, engine.BMS_TERM_H, tr, ctx=ok)
+    finally:
+        ok.close()
+    t0, d0 = engine.transform_modes(t, data, 2, 16, -2, -1, engine.BMS_TERM_H, tr, ctx=ctx)
+    assert np.array_equal(t0, t1) and np.abs(d0 - d1).max() < 1e-14 * np.abs(d0).max()
