@@ -228,6 +228,16 @@ int bms_cubic_spline(bms_ctx* ctx, const double* x, int64_t n, const void* y, in
  * .dot / .ddot / .int / .iint (scri/modes_time_series.py:72-126).  y: c16[n][ld], out: c16[n_new][n_cols], both in `mem`. */
 int bms_spline_derivative(bms_ctx* ctx, const double* x, int64_t n, const void* y, int64_t ld, int64_t n_cols, int mem,
                           const double* x_new, int64_t n_new, int order, void* out);
+/* The mode-space operators of spherical_functions.Modes / scri.ModesTimeSeries (scri/modes_time_series.py:7-139 and the
+ * algebra it inherits: eth, ethbar, bar, real, imag, +, -, scalar factors, truncate_ell) as ONE map along the mode axis,
+ *     out[t][j] = r_t ( ca_j op_a(a[t][ia_j]) + cb_j op_b(b[t][ib_j]) ),   op = identity or complex conjugation,
+ * with per-column tables the caller derives from (l, m, s) (scri_amd/device_series.py): idx_* int32[n_cols] (-1: zero),
+ * coef_* c16[n_cols], host arrays.  a c16[n_rows][ld_a], b (may be NULL) and out c16[n_rows][ld_out] live in `mem`;
+ * row_scale f8[n_rows] (may be NULL) too.  This is what keeps the charge and frame-fixing loops of
+ * scri/asymptotic_bondi_data/bms_charges.py:14-286 resident in HBM between transformations. */
+int bms_mode_map(bms_ctx* ctx, void* out, int64_t ld_out, int64_t n_rows, int n_cols, const void* a, int64_t ld_a,
+                 const int32_t* idx_a, const void* coef_a, int conj_a, const void* b, int64_t ld_b, const int32_t* idx_b,
+                 const void* coef_b, int conj_b, const double* row_scale, int mem);
 /* ModesTimeSeries.grid_multiply (scri/modes_time_series.py:142-202): modes a (spin_a, l = 0..ell_max_a,
  * c16[n_times][(ell_max_a+1)^2]) and b likewise are evaluated on the (2 working_ell_max + 1)^2 equiangular grid
  * (spinsfast.salm2map), multiplied there, and the product is analysed (map2salm, spin spin_a + spin_b) into

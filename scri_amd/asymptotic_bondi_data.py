@@ -32,7 +32,11 @@ class AsymptoticBondiData:
     psi0, psi1, psi2, psi3, psi4, sigma as complex mode weights [n_times, (ell_max+1)^2]
     (l from 0; modes with l < |s| are zero), stored contiguously as `_raw_data[6, n_times, n_modes]`."""
 
-    def __init__(self, time, ell_max, multiplication_truncator=sum, frameType=None, ctx=None, _raw=None):
+    def __init__(self, time, ell_max, multiplication_truncator=sum, frameType=None, ctx=None, _raw=None, device=False):
+        """device=True: the six fields live in HBM (`_raw_dev`, a torch complex128 tensor [6, n_times, n_modes]); `transform`,
+        the field operators (DeviceModesTimeSeries), the BMS charges and the frame-fixing iterations then run without the
+        fields crossing PCIe.  `_raw_data` of such an object is a host COPY made on access (assign fields through the
+        psi0 ... sigma setters or `to_device`)."""
         from . import Inertial
 
         self._time = np.array(time, dtype=float)
@@ -40,8 +44,20 @@ class AsymptoticBondiData:
             raise ValueError(f"Input `time` parameter must be a 1-d array of floats; it has shape {self._time.shape}")
         self._ell_max = int(ell_max)
         self._truncator = multiplication_truncator
+        self._ctx = ctx
+        self._device = bool(device)
         shape = (6, self._time.size, (self._ell_max + 1) ** 2)
-        if _raw is None:
+        if self._device:
+            from . import _lib, device_series
+
+            self._ctx = ctx if ctx is not None else _lib.default_context()
+            if _raw is None:
+                self._raw_dev = device_series.empty(self._ctx, shape).zero_()
+            else:
+                if tuple(_raw.shape) != shape or not _raw.is_contiguous():
+                    raise ValueError(f"device storage of shape {tuple(_raw.shape)} does not fit {shape}")
+                self._raw_dev = _raw
+        elif _raw is None:
             self._raw_data = np.zeros(shape, dtype=complex)
         else:  # adopt freshly computed storage instead of zero-filling and copying (hundreds of MB per transformation)
             if _raw.shape != shape or _raw.dtype != np.complex128 or not _raw.flags.c_contiguous:
@@ -49,7 +65,39 @@ class AsymptoticBondiData:
             self._raw_data = _raw
         self.frameType = Inertial if frameType is None else frameType
         self.frame = np.zeros((0, 4))
-        self._ctx = ctx
+
+    def __getattr__(self, name):
+        # device-resident objects have no host storage: `_raw_data` is a copy made on demand
+        if name == "_raw_data" and self.__dict__.get("_device"):
+            from . import device_series
+
+            return device_series.to_host(self._raw_dev)
+        raise AttributeError(name)
+
+    @property
+    def is_device_resident(self):
+        return self._device
+
+    def to_device(self, ctx=None):
+        """A device-resident copy of this object (itself if it already is one)."""
+        if self._device:
+            return self
+        from . import _lib, device_series
+
+        ctx = ctx if ctx is not None else (self._ctx if self._ctx is not None else _lib.default_context())
+        new = type(self)(self._time, self._ell_max, multiplication_truncator=self._truncator, frameType=self.frameType, ctx=ctx,
+                         _raw=device_series.to_device(ctx, self._raw_data), device=True)
+        new.frame = self.frame
+        return new
+
+    def to_host(self):
+        """A host-resident copy (itself if it already is one)."""
+        if not self._device:
+            return self
+        new = type(self)(self._time, self._ell_max, multiplication_truncator=self._truncator, frameType=self.frameType, ctx=self._ctx,
+                         _raw=np.ascontiguousarray(self._raw_data))
+        new.frame = self.frame
+        return new
 
     @property
     def time(self):
@@ -92,9 +140,12 @@ class AsymptoticBondiData:
 
     @property
     def n_modes(self):
-        return self._raw_data.shape[-1]
+        return (self._ell_max + 1) ** 2
 
     def copy(self):
+        if self._device:
+            return type(self)(self._time.copy(), self._ell_max, multiplication_truncator=self._truncator, frameType=self.frameType,
+                              ctx=self._ctx, _raw=self._raw_dev.clone(), device=True)
         new = type(self)(self._time.copy(), self._ell_max, multiplication_truncator=self._truncator, frameType=self.frameType, ctx=self._ctx)
         new._raw_data[:] = self._raw_data
         return new
@@ -105,6 +156,9 @@ class AsymptoticBondiData:
             key = slice(key, key + 1 if key != -1 else None)  # one time step, kept as a series of length 1
         if not isinstance(key, slice):
             raise ValueError(f"Invalid key `{key}` of type `{type(key)}`.")
+        if self._device:
+            return type(self)(self._time[key], self._ell_max, multiplication_truncator=self._truncator, frameType=self.frameType,
+                              ctx=self._ctx, _raw=self._raw_dev[:, key].contiguous(), device=True)
         new = type(self)(self._time[key], self._ell_max, multiplication_truncator=self._truncator, frameType=self.frameType, ctx=self._ctx)
         new._raw_data[:] = self._raw_data[:, key]
         return new
@@ -112,6 +166,12 @@ class AsymptoticBondiData:
     def interpolate(self, new_times):
         """scri/asymptotic_bondi_data/__init__.py:218-233: cubic-spline all six fields to `new_times`."""
         new_times = np.asarray(new_times, dtype=float)
+        if self._device:
+            new = type(self)(new_times, self._ell_max, multiplication_truncator=self._truncator, frameType=self.frameType, ctx=self._ctx,
+                             device=True)
+            for name in _FIELDS:
+                getattr(new, name).buf.copy_(getattr(self, name).interpolate(new_times).buf)
+            return new
         new = type(self)(new_times, self._ell_max, multiplication_truncator=self._truncator, frameType=self.frameType, ctx=self._ctx)
         y = np.ascontiguousarray(np.moveaxis(self._raw_data, 0, 1)).reshape(self.n_times, -1)
         out = engine.cubic_spline(self._time, y, new_times, ctx=self._ctx)
@@ -128,6 +188,17 @@ class AsymptoticBondiData:
         )
         n_theta = 2 * working_ell_max + 1
         tr = engine.make_transformation(supertranslation, frame_rotation, boost_velocity, n_theta, n_theta, output_ell_max)
+        if self._device:
+            # HBM to HBM: the output window is known before anything moves, so the result is allocated at its exact size
+            from . import device_series
+
+            i_lo, i_hi = engine.output_window(self._time, tr, abd=True, ctx=self._ctx)
+            out = device_series.empty(self._ctx, (6, max(i_hi - i_lo, 0), (output_ell_max + 1) ** 2))
+            u_new, n_new, _ = engine.transform_abd(self._time, self._raw_dev.data_ptr(), self.ell_max, tr, ctx=self._ctx, device=True,
+                                                   out_ptr=out.data_ptr(), shard=(0, self.n_times, i_lo, i_hi))
+            if n_new != out.shape[1]:
+                out = out[:, :n_new].contiguous()
+            return type(self)(np.array(u_new), output_ell_max, ctx=self._ctx, _raw=out, device=True)
         u_new, raw_new = engine.transform_abd(self._time, self._raw_data, self.ell_max, tr, ctx=self._ctx)
         # `type(self)(timeprime, output_ell_max)` in the reference (transformations.py:417): the result starts from the
         # constructor's defaults (multiplication_truncator = sum, frameType = Inertial), whatever the input carried
@@ -157,12 +228,25 @@ _SPINS = (2, 1, 0, -1, -2, 2)  # psi0..psi4, sigma
 def _field_property(i):
     def get(self):
         # a ModesTimeSeries VIEW of the field (scri/asymptotic_bondi_data/__init__.py:117-216): writes go to _raw_data
+        if self._device:
+            from .device_series import DeviceModesTimeSeries
+
+            return DeviceModesTimeSeries(self._raw_dev[i], self._time, _SPINS[i], 0, self._ell_max, ctx=self._ctx,
+                                         multiplication_truncator=self._truncator)
         from .modes_time_series import ModesTimeSeries
 
         return ModesTimeSeries(self._raw_data[i], self._time, spin_weight=_SPINS[i], ell_min=0, ell_max=self._ell_max,
                                multiplication_truncator=self._truncator)
 
     def set(self, value):
+        if self._device:
+            from . import device_series
+
+            if isinstance(value, device_series.DeviceModesTimeSeries):
+                self._raw_dev[i].copy_(value.buf)
+            else:
+                self._raw_dev[i].copy_(device_series.to_device(self._ctx, np.broadcast_to(np.asarray(value), self._raw_dev[i].shape)))
+            return
         self._raw_data[i] = value
 
     return property(get, set)

@@ -108,8 +108,11 @@ def CWWY_angular_momentum(self):
     from .modes_time_series import ModesTimeSeries
 
     ell_max = 1
-    potential = D_inverse((self.sigma.ethbar_GHP.ethbar_GHP + self.sigma.bar.eth_GHP.eth_GHP).ndarray, self.ell_max)
-    potential = ModesTimeSeries(potential, self.t, spin_weight=0, ell_min=0, ell_max=self.ell_max)
+    potential = self.sigma.ethbar_GHP.ethbar_GHP + self.sigma.bar.eth_GHP.eth_GHP
+    if hasattr(potential, "scale_by_ell"):  # device-resident series: the diagonal D^-1 as one more mode map
+        potential = potential.scale_by_ell(lambda l: 0.0 if l < 2 else 4.0 / ((l + 2) * (l + 1) * l * (l - 1)))
+    else:
+        potential = ModesTimeSeries(D_inverse(potential.ndarray, self.ell_max), self.t, spin_weight=0, ell_min=0, ell_max=self.ell_max)
     charge_aspect = (
         1j * (_psi1_sigma_term(self, ell_max) + potential.multiply(self.mass_aspect().eth_GHP, truncator=lambda tup: ell_max))
     ).ndarray

@@ -1858,6 +1858,69 @@ extern "C" int bms_salm2map(bms_ctx* c, const void* modes, int mem, int64_t n_ma
   return BMS_OK;
 }
 
+// Mode-space operators of sf.Modes / ModesTimeSeries (eth, ethbar, bar, real, sums of different l ranges, scalar and per-row
+// factors) as one map along the mode axis, see kernels_modes.hip.  Tables idx_* / coef_* are host arrays of n_cols entries;
+// a, b, out and row_scale live in `mem`.  b may be NULL (one-sided map); out may alias neither input unless every idx is
+// the identity.
+extern "C" int bms_mode_map(bms_ctx* c, void* out, int64_t ld_out, int64_t n_rows, int n_cols, const void* a, int64_t ld_a,
+                            const int32_t* idx_a, const void* coef_a, int conj_a, const void* b, int64_t ld_b,
+                            const int32_t* idx_b, const void* coef_b, int conj_b, const double* row_scale, int mem) {
+  if (!c || !out || !a || !idx_a || !coef_a) return BMS_ERR_INVALID;
+  if (b && (!idx_b || !coef_b)) return BMS_ERR_INVALID;
+  HIP_TRY(c, hipSetDevice(c->device));
+  if (n_rows < 0 || n_cols <= 0 || ld_out < n_cols || ld_a <= 0 || (b && ld_b <= 0)) return fail(c, BMS_ERR_INVALID, "bad sizes");
+  if (n_rows == 0) return BMS_OK;
+  int max_a = -1, max_b = -1;
+  for (int j = 0; j < n_cols; ++j) {
+    max_a = std::max(max_a, (int)idx_a[j]);
+    if (b) max_b = std::max(max_b, (int)idx_b[j]);
+  }
+  if (max_a >= ld_a || (b && max_b >= ld_b)) return fail(c, BMS_ERR_INVALID, "a source column lies beyond the row stride");
+  hipStream_t S = c->stream;
+  int rc;
+  void* vp;
+  ModeMapSide A{}, B{};
+  if ((rc = upload(c, "mm_idx_a", idx_a, sizeof(int32_t) * n_cols, &vp))) return rc;
+  A.idx = (const int*)vp;
+  if ((rc = upload(c, "mm_coef_a", coef_a, 16 * (size_t)n_cols, &vp))) return rc;
+  A.coef = (const double*)vp;
+  A.ld = ld_a;
+  A.conj = conj_a;
+  if (b) {
+    if ((rc = upload(c, "mm_idx_b", idx_b, sizeof(int32_t) * n_cols, &vp))) return rc;
+    B.idx = (const int*)vp;
+    if ((rc = upload(c, "mm_coef_b", coef_b, 16 * (size_t)n_cols, &vp))) return rc;
+    B.coef = (const double*)vp;
+    B.ld = ld_b;
+    B.conj = conj_b;
+  }
+  const double* d_rs = row_scale;
+  double* d_out = (double*)out;
+  if (mem == BMS_HOST) {
+    const double* d;
+    if ((rc = stage_in(c, "in_data", a, mem, ((size_t)(n_rows - 1) * ld_a + max_a + 1) * 16, &d))) return rc;
+    A.data = d;
+    if (b) {
+      if ((rc = stage_in(c, "in_aux0", b, mem, ((size_t)(n_rows - 1) * ld_b + max_b + 1) * 16, &d))) return rc;
+      B.data = d;
+    }
+    if (row_scale) {
+      if ((rc = upload(c, "mm_rows", row_scale, 8 * (size_t)n_rows, &vp))) return rc;
+      d_rs = (const double*)vp;
+    }
+    if ((rc = dev_buf_t(c, "out_data", (size_t)n_rows * n_cols * 2, &d_out))) return rc;
+  } else {
+    A.data = (const double*)a;
+    B.data = (const double*)b;
+  }
+  TIMED(c, BMS_TAG_POINTWISE, launch_mode_map(S, d_out, mem == BMS_HOST ? n_cols : ld_out, n_rows, n_cols, A, B, d_rs));
+  if (mem == BMS_HOST)
+    HIP_TRY(c, hipMemcpy2DAsync(out, (size_t)ld_out * 16, d_out, (size_t)n_cols * 16, (size_t)n_cols * 16, (size_t)n_rows,
+                                hipMemcpyDeviceToHost, S));
+  HIP_TRY(c, hipStreamSynchronize(S));  // the tables were staged from caller memory
+  return BMS_OK;
+}
+
 // ModesTimeSeries.grid_multiply (scri/modes_time_series.py:142-202): both mode sets (l_min = 0) are synthesised on the
 // (2W+1) x (2W+1) equiangular grid, multiplied there, and the product (spin s_a + s_b) is analysed up to output_ell_max.
 extern "C" int bms_grid_multiply(bms_ctx* c, const void* a, int spin_a, int ell_max_a, const void* b, int spin_b, int ell_max_b,

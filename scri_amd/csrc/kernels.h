@@ -34,6 +34,17 @@ hipError_t launch_rotate_modes_resident(hipStream_t stream, double* data, long l
                                         long long rotor_stride, const double* tab_global, const RotResPlan& P, size_t lds_bytes,
                                         unsigned int* counter, int n_cu);
 
+// ---- mode-space operators on resident series (kernels_modes.hip)
+struct ModeMapSide {
+  const double* data;  // c16[n_rows][ld]; nullptr: side absent
+  long long ld;        // row stride (complex)
+  const int* idx;      // source column per output column, -1: zero
+  const double* coef;  // c16 per output column
+  int conj;            // conjugate the source
+};
+hipError_t launch_mode_map(hipStream_t stream, double* out, long long ld_out, long long n_rows, int n_cols, const ModeMapSide& A,
+                           const ModeMapSide& B, const double* row_scale);
+
 // ---- SWSH matrices (sf.SWSH_grid, waveform_grid.py:470-484)
 // Bmat[2k][2p] = Re Y_k(R_p), [2k][2p+1] = Im, [2k+1][2p] = -Im, [2k+1][2p+1] = Re;  k = LM_index(l,m,ell_min)
 hipError_t launch_swsh_matrix(hipStream_t stream, const double* rotors /* f8[n_pix][4] */, int n_pix, int spin,

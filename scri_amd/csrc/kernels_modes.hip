@@ -1,0 +1,54 @@
+// Mode-space operators of spherical_functions.Modes / scri.ModesTimeSeries on series resident in HBM
+// (scri/modes_time_series.py:7-139 and the sf.Modes algebra it inherits: eth, ethbar, bar, real, imag, +, -, scalar
+// products, truncate_ell; used by scri/asymptotic_bondi_data/bms_charges.py:14-286 and map_to_superrest_frame.py).
+// All of them are the same map along the mode axis,
+//     out[t][j] = r_t ( ca_j op_a(A[t][ia_j]) + cb_j op_b(B[t][ib_j]) ),      op = identity or complex conjugation,
+// with per-column tables (ia, ca, ib, cb) the host derives from (l, m, s): eth = diagonal factor, bar = the permutation
+// (l, m) -> (l, -m) with a sign and a conjugation, real = (a + bar a) / 2, a sum of series with different l ranges = two
+// index maps with -1 for the modes one side lacks.  One pass over the data, lanes along the mode axis (16-byte accesses;
+// the gathers stay inside the row a wave is reading anyway), r_t an optional per-row real factor (the `t *` of the boost
+// charge, bms_charges.py:163-182).  HBM-bound: 16 (1 or 2) n_cols bytes read + 16 n_cols written per row.
+#include "wigner.h"
+#include "kernels.h"
+
+namespace bms {
+
+__global__ __launch_bounds__(256) void mode_map_kernel(double* __restrict__ out, long long ld_out, long long n_rows, int n_cols,
+                                                       ModeMapSide A, ModeMapSide B, const double* __restrict__ row_scale) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n_cols) return;
+  const int ia = A.idx[j];
+  const cplx ca = {A.coef[2 * j], A.coef[2 * j + 1]};
+  const bool has_b = B.data != nullptr;
+  const int ib = has_b ? B.idx[j] : -1;
+  const cplx cb = has_b ? cplx{B.coef[2 * j], B.coef[2 * j + 1]} : cplx{0.0, 0.0};
+  for (long long t = blockIdx.y; t < n_rows; t += gridDim.y) {
+    cplx v = {0.0, 0.0};
+    if (ia >= 0) {
+      const double2 a = *reinterpret_cast<const double2*>(A.data + (t * A.ld + ia) * 2);
+      v = cmul(ca, cplx{a.x, A.conj ? -a.y : a.y});
+    }
+    if (ib >= 0) {
+      const double2 b = *reinterpret_cast<const double2*>(B.data + (t * B.ld + ib) * 2);
+      const cplx w = cmul(cb, cplx{b.x, B.conj ? -b.y : b.y});
+      v.re += w.re;
+      v.im += w.im;
+    }
+    if (row_scale) {
+      const double r = row_scale[t];
+      v.re *= r;
+      v.im *= r;
+    }
+    *reinterpret_cast<double2*>(out + (t * ld_out + j) * 2) = double2{v.re, v.im};
+  }
+}
+
+hipError_t launch_mode_map(hipStream_t stream, double* out, long long ld_out, long long n_rows, int n_cols, const ModeMapSide& A,
+                           const ModeMapSide& B, const double* row_scale) {
+  if (n_rows <= 0 || n_cols <= 0) return hipSuccess;
+  dim3 grid((n_cols + 255) / 256, (unsigned)(n_rows < 8192 ? n_rows : 8192));
+  hipLaunchKernelGGL(mode_map_kernel, grid, dim3(256), 0, stream, out, ld_out, n_rows, n_cols, A, B, row_scale);
+  return hipGetLastError();
+}
+
+}  // namespace bms

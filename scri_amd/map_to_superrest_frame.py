@@ -95,10 +95,11 @@ def _rows_near(t, times, reach=SPLINE_REACH):
 def compute_Moreschi_supermomentum(PsiM, alpha, ell_max, ctx=None):
     """Moreschi supermomentum in the frame supertranslated by alpha (a real grid function): Eq. (9) of
     doi:10.1063/1.532646 (map_to_superrest_frame.py:155-197)."""
-    data = np.asarray(PsiM.ndarray if hasattr(PsiM, "ndarray") else PsiM)
     t = PsiM.t
     lo, hi = _rows_near(t, alpha)
-    data, t = data[lo:hi], t[lo:hi]
+    # (a device-resident series hands over the rows around u = 0 only)
+    data = PsiM.rows(lo, hi) if hasattr(PsiM, "rows") else np.asarray(PsiM.ndarray if hasattr(PsiM, "ndarray") else PsiM)[lo:hi]
+    t = t[lo:hi]
     M_Grid, K_Grid = compute_bondi_rest_mass_and_conformal_factor(data, ell_max, ctx)
     PsiM_Grid = _to_grid(data, ell_max, ctx).real
     PsiM_at_alpha = _interpolate_each_pixel(t, PsiM_Grid, alpha, ctx)
@@ -369,7 +370,9 @@ def rel_err_for_abd_in_superrest(abd, target_PsiM, target_strain):
         rel_err_rot = _time_average(np.linalg.norm(omega - _target_omega_spline(target_strain)(abd.t), axis=-1), abd.t, ctx)
     else:
         rel_err_rot = _time_average(np.linalg.norm(_unit_spin(abd) - np.array([0.0, 0, 1])[None, :], axis=-1), abd.t, ctx)
-    PsiM0 = abd.supermomentum("Moreschi").ndarray[np.argmin(abs(abd.t - 0)), 4:]
+    PsiM = abd.supermomentum("Moreschi")
+    i0 = int(np.argmin(abs(abd.t - 0)))
+    PsiM0 = (PsiM.rows(i0, i0 + 1)[0] if hasattr(PsiM, "rows") else PsiM.ndarray[i0])[4:]
     if target_PsiM is not None:
         PsiM0 = PsiM0 - np.asarray(target_PsiM.data)[np.argmin(abs(target_PsiM.t - 0)), 4:]
     return rel_err_CoM, rel_err_rot, np.linalg.norm(PsiM0)
@@ -419,7 +422,9 @@ def map_to_superrest_frame(
         ell_max = abd.ell_max
     i1 = np.abs(abd.t - (t_0 - (padding_time + 200))).argmin()
     i2 = np.abs(abd.t - (t_0 + (padding_time + 200))).argmin() + 1
-    abd_sliced = abd[i1:i2]
+    # the window the iterations work on stays in HBM across their transformations and charge evaluations (a dozen of each):
+    # nothing but l <= 1 charge vectors and a few rows around u = 0 comes back to the host
+    abd_sliced = abd[i1:i2].to_device(ctx)
 
     # a time translation first, so that the frame is fixed at u = 0
     time_translation = BMSTransformation(supertranslation=[constant_as_ell_0_mode(t_0)], ell_max=ell_max, ctx=ctx)
