@@ -155,6 +155,13 @@ typedef struct {
 } bms_shard;
 int bms_shard_plan(bms_ctx* ctx, const double* t, int64_t n_times, const bms_transformation* tr, int64_t out_i0,
                    int64_t out_i1, int64_t need_rows[2], int64_t window[2]);
+/* bms_transform_modes for HOST arrays as a three-stage pipeline over `pieces` time shards of the output range: upload of
+ * shard k + 1, kernels of shard k and download of shard k - 1 run side by side on three streams (a long series in host memory
+ * waits for PCIe, not for the kernels).  in->mem must be BMS_HOST, no auxiliary fields.  data_out: host
+ * c16[window rows][n_out], t_out f8[window rows] (size them with bms_output_window); full rate needs page-locked arrays
+ * (bms_host_alloc for the result, bms_host_register for a caller's input).  Same results as the sharded path. */
+int bms_transform_modes_pipelined(bms_ctx* ctx, const bms_wm_input* in, const bms_transformation* tr, int pieces, double* t_out,
+                                  void* data_out, int64_t* n_times_out);
 /* WaveformGrid.from_modes on its own (scri/waveform_grid.py:331-613): the first half of bms_transform_modes -- the field on the
  * boost-distorted grid at the new time slices, grid_out c16[n_times][n_theta * n_phi] (only the first *n_times_out rows are
  * written; grid order, theta-major), in the memory space in->mem.  bms_map2salm of it is WaveformGrid.to_modes (:274-329). */
@@ -178,6 +185,11 @@ int bms_transform_modes_shard(bms_ctx* ctx, const bms_wm_input* in, const bms_tr
  * NULL on failure. */
 void* bms_host_alloc(uint64_t bytes);
 void bms_host_free(void* p);
+/* The other direction: page-lock a caller's INPUT array in place (and release it), so that repeated transformations of
+ * the same host array upload at PCIe rate instead of through the runtime's staging copy.  Registration costs about one
+ * upload; scri_amd/engine.py registers an array the second time it sees it and unregisters when it is freed. */
+int bms_host_register(void* p, uint64_t bytes);
+int bms_host_unregister(void* p);
 
 /* ---- BMS transformation of AsymptoticBondiData ---------------------------------------------------------
  * replaces AsymptoticBondiData.transform (scri/asymptotic_bondi_data/transformations.py:199-431) after

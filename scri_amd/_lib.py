@@ -82,6 +82,8 @@ SIGNATURES = {
     ),
     "bms_host_alloc": (c_vp, [ctypes.c_uint64]),
     "bms_host_free": (None, [c_vp]),
+    "bms_host_register": (c_int, [c_vp, ctypes.c_uint64]),
+    "bms_host_unregister": (c_int, [c_vp]),
     "bms_modes_to_grid": (
         c_int,
         [c_vp, ctypes.POINTER(bms_wm_input), ctypes.POINTER(bms_transformation), c_dp, c_vp, ctypes.POINTER(c_i64)],
@@ -91,6 +93,10 @@ SIGNATURES = {
         c_int,
         [c_vp, ctypes.POINTER(bms_wm_input), ctypes.POINTER(bms_transformation), ctypes.POINTER(bms_shard), c_dp, c_vp,
          ctypes.POINTER(c_i64), ctypes.POINTER(c_i64)],
+    ),
+    "bms_transform_modes_pipelined": (
+        c_int,
+        [c_vp, ctypes.POINTER(bms_wm_input), ctypes.POINTER(bms_transformation), c_int, c_dp, c_vp, ctypes.POINTER(c_i64)],
     ),
     "bms_rotate_const": (c_int, [c_vp, c_vp, c_int, c_i64, c_i64, c_int, c_int, c_dp]),
     "bms_rotate_series": (c_int, [c_vp, c_vp, c_int, c_i64, c_i64, c_int, c_int, c_vp]),
@@ -246,6 +252,51 @@ class _PinnedBlock:
             load().bms_host_free(ptr)
         except Exception:  # interpreter shutdown
             pass
+
+
+# ---- page-locking of caller-owned input arrays that are transformed repeatedly
+_seen_inputs = collections.OrderedDict()  # (address, nbytes) -> sightings (small LRU)
+_registered = {}  # (address, nbytes) -> weakref.finalize handle
+REGISTER_MIN_BYTES = 32 << 20
+
+
+def register_if_reused(a):
+    """Page-lock the host array `a` in place the SECOND time it is handed in (a one-off array would pay the registration for
+    nothing: it costs about one upload); released when the array is garbage collected.  Returns True when `a` is page-locked
+    after the call.  SCRI_AMD_NO_REGISTER disables."""
+    import weakref
+
+    if os.environ.get("SCRI_AMD_NO_REGISTER") or a.nbytes < REGISTER_MIN_BYTES or not a.flags.c_contiguous:
+        return False
+    owner = a if a.base is None else a.base  # the object whose lifetime covers the memory
+    while isinstance(owner, np.ndarray) and owner.base is not None:
+        owner = owner.base
+    key = (a.ctypes.data, a.nbytes)
+    if key in _registered:
+        return True
+    n = _seen_inputs.pop(key, 0) + 1
+    _seen_inputs[key] = n
+    while len(_seen_inputs) > 16:
+        _seen_inputs.popitem(last=False)
+    if n < 2:
+        return False
+    if load().bms_host_register(c_vp(key[0]), key[1]) != 0:
+        return False
+
+    def _release(k=key):
+        _registered.pop(k, None)
+        _seen_inputs.pop(k, None)
+        try:
+            load().bms_host_unregister(c_vp(k[0]))
+        except Exception:  # interpreter shutdown
+            pass
+
+    try:
+        _registered[key] = weakref.finalize(owner, _release)
+    except TypeError:  # the owner cannot be weakly referenced: do not keep a registration we could never release
+        _release()
+        return False
+    return True
 
 
 def pinned_empty(shape, dtype):

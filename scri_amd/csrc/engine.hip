@@ -63,6 +63,12 @@ struct bms_ctx {
   std::map<std::string, DevBuf> bufs;  // grow-only named work space
   int delta_lmax = -1;                 // Delta tables cached up to this l
   int delta_mfma_lmax = -1;            // ... in the MFMA B-image packing
+  hipStream_t pipe_up = nullptr, pipe_down = nullptr;  // bms_transform_modes_pipelined: uploads and downloads beside the kernels
+  // set by bms_transform_modes_pipelined around its per-piece calls: the pieces share one transformation, so the
+  // per-direction tables are computed (and read back) once, and a piece returns without waiting for its kernels
+  bool async_pieces = false;
+  bool piece_tables_valid = false;
+  void* piece_tables = nullptr;  // PieceTables*
   std::map<std::pair<int, int>, RotResPlan> rot_res_plans;  // LDS-resident table images built so far, by (ell_min, ell_max)
   int n_cu = 0;
   // analysis tables depend on the grid, the spin and the l range only: kept per tag until a call asks for other ones
@@ -246,6 +252,8 @@ extern "C" void bms_ctx_destroy(bms_ctx* c) {
   for (auto e : c->event_pool) (void)hipEventDestroy(e);
   if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
   if (c->aux) (void)hipStreamDestroy(c->aux);
+  if (c->pipe_up) (void)hipStreamDestroy(c->pipe_up);
+  if (c->pipe_down) (void)hipStreamDestroy(c->pipe_down);
   delete c;
 }
 
@@ -258,6 +266,25 @@ extern "C" void* bms_host_alloc(uint64_t bytes) {
 }
 extern "C" void bms_host_free(void* p) {
   if (p) (void)hipHostFree(p);
+}
+// Page-lock a caller's array in place: uploads from it then run at PCIe rate without the runtime's staging copy.  Costs about
+// what one upload of the array costs, so it pays for arrays that are transformed more than once (scri_amd/engine.py does it
+// on the second sighting of an array and undoes it when the array is freed).
+extern "C" int bms_host_register(void* p, uint64_t bytes) {
+  if (!p || !bytes) return BMS_ERR_INVALID;
+  if (hipHostRegister(p, bytes, hipHostRegisterDefault) != hipSuccess) {
+    (void)hipGetLastError();
+    return BMS_ERR_HIP;
+  }
+  return BMS_OK;
+}
+extern "C" int bms_host_unregister(void* p) {
+  if (!p) return BMS_ERR_INVALID;
+  if (hipHostUnregister(p) != hipSuccess) {
+    (void)hipGetLastError();
+    return BMS_ERR_HIP;
+  }
+  return BMS_OK;
 }
 
 extern "C" int bms_ctx_set_stream(bms_ctx* c, void* s) {
@@ -1039,6 +1066,11 @@ struct DevPixel {
   double *rotors, *k, *alpha, *skew_a, *skew_b, *col_off, *col_scale, *xa, *xb, *ethk, *etha, *ethetha, *ik, *ik3;
   const int* col_of_pixel = nullptr;  // set when the grid is stored as a column plan (kernels_swsh.hip, pixel_sort_kernel)
 };
+
+struct PieceTables {  // per-direction tables shared by the pieces of one pipelined call
+  PixelTables T;
+  DevPixel DP;
+};
 // Column plan of the grids: 0 = one column per grid pixel, in grid order.  When the analysis can read the columns in any
 // order (the fused kernel) the two pole rings are stored once each (1) and, with a boost, whose time skew grows with |u|,
 // the columns are also sorted by the skew rate (2).
@@ -1219,6 +1251,142 @@ extern "C" int bms_transform_modes_shard(bms_ctx* c, const bms_wm_input* in, con
   return transform_modes_impl(c, in, tr, sh, t_out, data_out, n_times_out, first_index_out, nullptr);
 }
 
+// Host arrays in, host arrays out, as a three-stage pipeline over time shards of the OUTPUT range: the upload of shard k + 1
+// (its rows + halo, bms_shard_plan), the kernels of shard k and the download of shard k - 1 run on three streams, ordered by
+// events; the host thread only enqueues.  A long series in host memory waits for PCIe, not for the kernels (cfg3: 456 MB each
+// way at 57 GB/s = 8 ms per direction against 6 ms of kernels): one call does upload -> kernels -> download one after the
+// other (26 ms), this does them side by side.  Uploads run at full rate from page-locked memory (bms_host_register /
+// bms_host_alloc); from pageable memory the runtime stages them.  data_out: host c16[i_hi - i_lo][n_out] (best page-locked).
+// Results are those of the sharded path (equal to the one-call path to rounding).  No psi companions (aux) here.
+extern "C" int bms_transform_modes_pipelined(bms_ctx* c, const bms_wm_input* in, const bms_transformation* tr, int pieces,
+                                             double* t_out, void* data_out, int64_t* n_times_out) {
+  if (!c) return BMS_ERR_INVALID;
+  if (!in || !tr || !t_out || !data_out || !n_times_out) return fail(c, BMS_ERR_INVALID, "NULL argument");
+  if (in->mem != BMS_HOST || in->n_aux != 0) return fail(c, BMS_ERR_INVALID, "the pipelined path takes host data without auxiliary fields");
+  HIP_TRY(c, hipSetDevice(c->device));
+  const int64_t n = in->n_times;
+  bool regular = true;
+  int rc = validate_common(c, n, in->t, tr, 0, n, &regular);
+  if (rc) return rc;
+  if (!regular) return fail(c, BMS_ERR_UNSUPPORTED, "the time steps vary by more than 1e3 within 48 samples: not sharded");
+  // per-direction tables once (on the device, read back), for the window and for every piece's row range
+  PixelTables T;
+  {
+    DevPixel DP;
+    const cplx cv0[4] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}};
+    if ((rc = device_pixel_tables(c, tr, T, 0, 0, 0, nullptr, nullptr, cv0, DP, 0))) return rc;
+  }
+  int64_t i_lo, i_hi;
+  output_window(T, in->t, n, i_lo, i_hi);
+  const int64_t n_new = i_hi - i_lo;
+  *n_times_out = n_new;
+  if (n_new <= 0) return BMS_OK;
+  if (pieces < 1) pieces = 1;
+  if (pieces > n_new / 8) pieces = (int)std::max<int64_t>(1, n_new / 8);
+  const int n_modes = LM_total_size(in->ell_min, in->ell_max);
+  const int s_abs = std::abs(in->spin_weight);
+  const int n_out = LM_total_size(s_abs, tr->ell_max_out);
+  // plan: output cuts and the input rows each piece needs
+  std::vector<int64_t> cut(pieces + 1), r0(pieces), r1(pieces);
+  int64_t max_rows = 0, max_out = 0;
+  for (int k = 0; k <= pieces; ++k) cut[k] = i_lo + (n_new * k) / pieces;
+  for (int k = 0; k < pieces; ++k) {
+    int64_t ja, jb;
+    needed_knots(T, in->t, n, cut[k], cut[k + 1], ja, jb);
+    const int margin = SPLINE_HALO + 2;  // as bms_shard_plan
+    r0[k] = std::max<int64_t>(0, ja - margin);
+    r1[k] = std::min<int64_t>(n, jb + margin + 1);
+    max_rows = std::max(max_rows, r1[k] - r0[k]);
+    max_out = std::max(max_out, cut[k + 1] - cut[k]);
+  }
+  double *d_in[2], *d_out[2];
+  if ((rc = dev_buf_t(c, "pipe_in0", (size_t)max_rows * n_modes * 2, &d_in[0]))) return rc;
+  if ((rc = dev_buf_t(c, "pipe_in1", (size_t)max_rows * n_modes * 2, &d_in[1]))) return rc;
+  if ((rc = dev_buf_t(c, "pipe_out0", (size_t)max_out * n_out * 2, &d_out[0]))) return rc;
+  if ((rc = dev_buf_t(c, "pipe_out1", (size_t)max_out * n_out * 2, &d_out[1]))) return rc;
+  if (!c->pipe_up) {
+    HIP_TRY(c, hipStreamCreateWithFlags(&c->pipe_up, hipStreamNonBlocking));
+    HIP_TRY(c, hipStreamCreateWithFlags(&c->pipe_down, hipStreamNonBlocking));
+  }
+  std::vector<hipEvent_t> ev_up(pieces), ev_c(pieces), ev_dn(pieces);
+  for (int k = 0; k < pieces; ++k) {
+    ev_up[k] = ScopedTimer::get(c);
+    ev_c[k] = ScopedTimer::get(c);
+    ev_dn[k] = ScopedTimer::get(c);
+  }
+  auto give_back = [&]() {
+    for (int k = 0; k < pieces; ++k) {
+      c->event_pool.push_back(ev_up[k]);
+      c->event_pool.push_back(ev_c[k]);
+      c->event_pool.push_back(ev_dn[k]);
+    }
+  };
+  const char* host_in = (const char*)in->data;
+  char* host_out = (char*)data_out;
+  auto upload_piece = [&](int k) -> hipError_t {
+    // (the buffer is free: the host has waited for the kernels of piece k - 2 before it gets here)
+    const int64_t rows = r1[k] - r0[k];
+    hipError_t e = in->ld == n_modes
+                       ? hipMemcpyAsync(d_in[k & 1], host_in + (size_t)r0[k] * in->ld * 16, (size_t)rows * n_modes * 16, hipMemcpyHostToDevice, c->pipe_up)
+                       : hipMemcpy2DAsync(d_in[k & 1], (size_t)n_modes * 16, host_in + (size_t)r0[k] * in->ld * 16, (size_t)in->ld * 16,
+                                          (size_t)n_modes * 16, (size_t)rows, hipMemcpyHostToDevice, c->pipe_up);
+    if (e != hipSuccess) return e;
+    return hipEventRecord(ev_up[k], c->pipe_up);
+  };
+  PieceTables shared_tables;
+  struct AsyncScope {
+    bms_ctx* c;
+    ~AsyncScope() {
+      c->async_pieces = false;
+      c->piece_tables_valid = false;
+      c->piece_tables = nullptr;
+    }
+  } scope{c};
+  c->piece_tables = &shared_tables;
+  c->piece_tables_valid = false;
+  c->async_pieces = true;
+  hipError_t he = upload_piece(0);
+  if (he != hipSuccess) {
+    give_back();
+    return fail(c, BMS_ERR_HIP, "pipelined upload: %s", hipGetErrorString(he));
+  }
+  for (int k = 0; k < pieces && rc == BMS_OK; ++k) {
+    if (k + 1 < pieces && (he = upload_piece(k + 1)) != hipSuccess) break;  // travels while piece k is transformed
+    if ((he = hipStreamWaitEvent(c->stream, ev_up[k], 0)) != hipSuccess) break;
+    if (k >= 2 && (he = hipStreamWaitEvent(c->stream, ev_dn[k - 2], 0)) != hipSuccess) break;  // its output buffer has left
+    bms_wm_input piece = *in;
+    piece.data = d_in[k & 1];
+    piece.ld = n_modes;
+    piece.mem = BMS_DEVICE;
+    const bms_shard sh = {r0[k], r1[k] - r0[k], cut[k], cut[k + 1], 0, 0};
+    int64_t got = 0, first = 0;
+    rc = transform_modes_impl(c, &piece, tr, &sh, t_out + (cut[k] - i_lo), d_out[k & 1], &got, &first, nullptr);
+    if (rc) break;
+    if (got != cut[k + 1] - cut[k] || first != cut[k]) {
+      rc = fail(c, BMS_ERR_HIP, "pipelined shard [%lld, %lld) produced %lld rows from %lld", (long long)cut[k], (long long)cut[k + 1],
+                (long long)got, (long long)first);
+      break;
+    }
+    if ((he = hipEventRecord(ev_c[k], c->stream)) != hipSuccess) break;
+    // The host waits for the piece's kernels and then issues the download (it has nothing else to do here: the next upload
+    // is already on its way).  In the rocprofv3 trace of this loop the uploads run on a DMA engine beside the kernels; the
+    // downloads are executed by the runtime as shader copies (__amd_rocclr_copyBuffer) that take turns with the compute
+    // kernels -- with or without a cross-stream event in front of them -- which is what keeps a piece at 2.8 ms instead of 1.4.
+    if ((he = hipEventSynchronize(ev_c[k])) != hipSuccess) break;
+    if ((he = hipMemcpyAsync(host_out + (size_t)(cut[k] - i_lo) * n_out * 16, d_out[k & 1], (size_t)got * n_out * 16,
+                             hipMemcpyDeviceToHost, c->pipe_down)) != hipSuccess)
+      break;
+    if ((he = hipEventRecord(ev_dn[k], c->pipe_down)) != hipSuccess) break;
+  }
+  (void)hipStreamSynchronize(c->pipe_up);
+  (void)hipStreamSynchronize(c->stream);
+  (void)hipStreamSynchronize(c->pipe_down);
+  give_back();
+  if (rc) return rc;
+  if (he != hipSuccess) return fail(c, BMS_ERR_HIP, "pipelined transfer: %s", hipGetErrorString(he));
+  return BMS_OK;
+}
+
 // WaveformGrid.from_modes on its own (scri/waveform_grid.py:331-613): the field on the distorted grid at the new time slices,
 // c16[N'][n_theta * n_phi] in grid order (no column plan), without the analysis back to modes
 extern "C" int bms_modes_to_grid(bms_ctx* c, const bms_wm_input* in, const bms_transformation* tr, double* t_out, void* grid_out,
@@ -1311,8 +1479,11 @@ static int transform_modes_impl(bms_ctx* c, const bms_wm_input* in, const bms_tr
   // tables, whose window the host has to wait for, are computed beside it on the auxiliary stream.
   struct DrainOnExit {  // whatever path leaves this call, nothing enqueued here still reads the caller's buffers
     hipStream_t s;
-    ~DrainOnExit() { (void)hipStreamSynchronize(s); }
-  } drain{S};
+    bool skip;  // pieces of the pipelined path: its own buffers, drained by the pipeline
+    ~DrainOnExit() {
+      if (!skip) (void)hipStreamSynchronize(s);
+    }
+  } drain{S, c->async_pieces};
   FieldPlan F[5];
   F[0].ell_min = in->ell_min;
   F[0].ell_max = in->ell_max;
@@ -1338,9 +1509,20 @@ static int transform_modes_impl(bms_ctx* c, const bms_wm_input* in, const bms_tr
   trace.mark("input staging, time upload, spline factors, elimination on the modes (enqueue)");
   PixelTables T;
   DevPixel DP;
-  if ((rc = device_pixel_tables(c, tr, T, psi ? 1 : 0, s, in->conformal_weight, coef0.empty() ? nullptr : &coef0, nullptr, cv, DP, grid_out ? 0 : column_plan(tr, n_out),
-                                c->aux)))
-    return rc;
+  PieceTables* shared = c->async_pieces ? static_cast<PieceTables*>(c->piece_tables) : nullptr;
+  if (shared && c->piece_tables_valid) {
+    T = shared->T;
+    DP = shared->DP;
+  } else {
+    if ((rc = device_pixel_tables(c, tr, T, psi ? 1 : 0, s, in->conformal_weight, coef0.empty() ? nullptr : &coef0, nullptr, cv, DP,
+                                  grid_out ? 0 : column_plan(tr, n_out), c->aux)))
+      return rc;
+    if (shared) {
+      shared->T = T;
+      shared->DP = DP;
+      c->piece_tables_valid = true;
+    }
+  }
   trace.mark("pixel tables (GPU, auxiliary stream) + copy back");
   const int n_cols = T.n_pix;
   const bool col_split = sh && sh->col_parts > 1;
@@ -1506,7 +1688,7 @@ static int transform_modes_impl(bms_ctx* c, const bms_wm_input* in, const bms_tr
   // the new time axis is host work: done while the GPU runs
   for (int64_t i = 0; i < n_new; ++i) t_out[i] = (1 / T.gamma) * (in->t[i_lo + i] - T.tt);
   // host tables above are stack/vector memory: wait for the uploads (and results) before returning
-  HIP_TRY(c, hipStreamSynchronize(S));
+  if (!c->async_pieces) HIP_TRY(c, hipStreamSynchronize(S));
   trace.mark("final synchronize");
   return BMS_OK;
 }

@@ -136,11 +136,29 @@ PIPELINE_PIECES = int(os.environ.get("SCRI_AMD_PIPELINE_PIECES", "6"))  # one bo
 
 def _transform_modes_pipelined(t, data, inp, transformation, n_out, ctx):
     """Host-memory callers of a long series wait for PCIe, not for the kernels (cfg3: 456 MB each way against 6 ms of
-    kernels), and one call does upload -> kernels -> download one after the other.  Here the output range is cut into
-    PIPELINE_PIECES time shards (bms_shard_plan names the input rows each one needs, exactly as for the multi-GPU split),
-    which run alternately on two contexts from two threads: the upload of one shard, the kernels of the next and the
-    download of a third overlap (PCIe is full duplex).  Results are those of the sharded path (equal to the one-call path
-    to rounding; tests/test_gpu_sharding.py).  Returns None when the series cannot be sharded (graded time steps)."""
+    kernels), and one call does upload -> kernels -> download one after the other.  bms_transform_modes_pipelined cuts the
+    output range into PIPELINE_PIECES time shards (bms_shard_plan names the input rows each one needs, exactly as for the
+    multi-GPU split) and runs upload, kernels and download of neighbouring shards side by side on three streams.  Results
+    are those of the sharded path (equal to the one-call path to rounding; tests/test_gpu_sharding.py).  Returns None when
+    the series cannot be sharded (graded time steps).  SCRI_AMD_PIPELINE_THREADS=1: round 1's version of the same idea
+    (two contexts fed by two host threads)."""
+    if not os.environ.get("SCRI_AMD_PIPELINE_THREADS"):
+        if not np.all(np.diff(t) > 0):
+            return None  # the one-call path raises the ValueError the reference's callers expect
+        i_lo, i_hi = output_window(t, transformation, ctx=ctx)
+        n_new = i_hi - i_lo
+        if n_new < 8 * PIPELINE_PIECES:
+            return None
+        out = _lib.pinned_empty((n_new, n_out), np.complex128)
+        t_out = np.empty(n_new, dtype=float)
+        got = c_i64(0)
+        rc = _lib.load().bms_transform_modes_pipelined(ctx.handle, ctypes.byref(inp), ctypes.byref(transformation), PIPELINE_PIECES,
+                                                       dptr(t_out), vptr(out), ctypes.byref(got))
+        try:
+            ctx.check(rc, "bms_transform_modes_pipelined")
+        except NotImplementedError:
+            return None
+        return t_out[: got.value], out[: got.value]
     import threading
 
     n = t.shape[0]
@@ -287,6 +305,8 @@ def transform_modes(
         rc = _lib.load().bms_modes_to_grid(ctx.handle, ctypes.byref(inp), ctypes.byref(transformation), dptr(t_out), vptr(out), ctypes.byref(n_new))
         ctx.check(rc, "bms_modes_to_grid")
         return t_out[: n_new.value], out[: n_new.value]
+    if not device:
+        _lib.register_if_reused(data)  # an input array seen for the second time is page-locked in place: uploads at PCIe rate
     if shard is None and not aux and data.nbytes >= PIPELINE_MIN_BYTES and not os.environ.get("SCRI_AMD_NO_PIPELINE"):
         res = _transform_modes_pipelined(t, data, inp, transformation, n_out, ctx)
         if res is not None:
@@ -356,6 +376,7 @@ def transform_abd(u, raw, ell_max, transformation, ctx=None, shard=None, device=
     raw = _lib.as_c16(raw)
     if raw.shape != (6, n_rows, (ell_max + 1) ** 2):
         raise ValueError(f"raw shape {raw.shape} inconsistent")
+    _lib.register_if_reused(raw)
     if shard is None:
         # size the result exactly (the window is known before the data move): no trimming copy of hundreds of MB afterwards
         i_lo, i_hi = output_window(u, transformation, abd=True, ctx=ctx)

@@ -317,3 +317,25 @@ def test_workspace_limit_too_small_is_reported(ctx):
         ok.close()
     t0, d0 = engine.transform_modes(t, data, 2, 16, -2, -1, engine.BMS_TERM_H, tr, ctx=ctx)
     assert np.array_equal(t0, t1) and np.abs(d0 - d1).max() < 1e-14 * np.abs(d0).max()
+
+
+def test_reused_host_input_is_page_locked_and_released(ctx):
+    """An input array handed in for the second time is page-locked in place (uploads at PCIe rate), the results do not change,
+    and the registration goes away with the array."""
+    import gc
+
+    from scri_amd import _lib, engine, synthetic
+
+    t, data, spec = synthetic.workload("cfg3", n_times=120_000)  # 547 MB: above the registration threshold
+    data = np.ascontiguousarray(data[:, :77])  # l <= 8: 148 MB
+    kw = synthetic.CONFIGS["cfg2"]["kwargs"]
+    tr = engine.make_transformation(kw["supertranslation"], [1, 0, 0, 0], [0, 0, 0], 21, 21, 8)
+    key = (data.ctypes.data, data.nbytes)
+    outs = []
+    for i in range(3):
+        outs.append(engine.transform_modes(t, data, 2, 8, -2, -1, engine.BMS_TERM_H, tr, ctx=ctx)[1].copy())
+        assert (key in _lib._registered) == (i >= 1)
+    assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[1], outs[2])
+    del data
+    gc.collect()
+    assert key not in _lib._registered

@@ -9,11 +9,11 @@ kw, L = spec["kwargs"], spec["ell_max"]
 nth = 2 * (L + 2) + 1
 tr = engine.make_transformation(kw["supertranslation"], kw["frame_rotation"], kw["boost_velocity"], nth, nth, L)
 ctx = _lib.Context(0)
-for _ in range(2):
+for _ in range(3):
     engine.transform_modes(t, data, 2, L, -2, -1, engine.BMS_TERM_H, tr, ctx=ctx)
 t0 = time.perf_counter()
-k = 5
+k = 8
 for _ in range(k):
     t_new, d_new = engine.transform_modes(t, data, 2, L, -2, -1, engine.BMS_TERM_H, tr, ctx=ctx)
 dt = (time.perf_counter() - t0) / k
-print(f"host in / host out: {dt * 1e3:.1f} ms per transform = {t.size / dt:.3g} timesteps/s ({data.nbytes / 1e6:.0f} MB in, {d_new.nbytes / 1e6:.0f} MB out, pageable numpy memory)")
+print(f"host in / host out: {dt * 1e3:.1f} ms per transform = {t.size / dt:.3g} timesteps/s ({data.nbytes / 1e6:.0f} MB in, {d_new.nbytes / 1e6:.0f} MB out, numpy memory, page-locked in place from its second use; SCRI_AMD_NO_REGISTER=1 for pageable)")
