@@ -11,7 +11,7 @@ import threading
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libscri_amd.so")
+LIB_PATH = os.environ.get("SCRI_AMD_LIB_PATH") or os.path.join(_HERE, "libscri_amd.so")  # (the override: A/B builds of one kernel)
 
 BMS_HOST, BMS_DEVICE = 0, 1
 BMS_TERM_NONE, BMS_TERM_H, BMS_TERM_SIGMA, BMS_TERM_PSI = 0, 1, 2, 3
