@@ -428,6 +428,251 @@ hipError_t launch_dft_cs_matrix(hipStream_t stream, int n_phi, int L, double* D)
   return hipGetLastError();
 }
 
+// =====================================================================================================================
+// The same analysis with the two halves of the work on different waves of one workgroup (one workgroup per CU, two time
+// rows per trip), because the one-role kernel above is bound by its own chain -- fold, barrier, MFMA, barrier,
+// quadrature -- not by memory (with its phases switched off one at a time: loads alone 0.37 ms at cfg3, the chain without
+// loads 0.80 ms, together 0.82 ms).
+//
+//   front waves: wave w owns 16 rings of the 2 n_rings of a row pair as the 16 A-rows of its MFMA tile.  Lane (i, c) loads
+//                the sample pair (ring i, k = 4 s + c | n_phi - k) itself, 16 bytes each, so the folded operands
+//                e = x_k + x_{n-k}, o = x_k - x_{n-k} exist in registers in exactly the A-fragment layout: no LDS
+//                operands, no barrier before the products.  Re and Im go through separate products (A = Re e, Im e,
+//                Re o, Im o against the cos | sin twiddles, which the lane keeps in registers), 4 KS MFMAs per wave and
+//                trip, no padding but the last tile's.  m = 0 is the lane sum of e reduced over c.  Results are combined
+//                to F_{+-m} in registers and written to LDS.  A pair's samples are requested during the fold of the pair
+//                before it.
+//   back waves:  one thread per output mode, its T row in registers, both rows of the pair: the theta quadrature reading
+//                F as 16-byte pairs, while the front waves already work on the next pair (F is double buffered; one
+//                barrier per trip); they also prefetch into L2 for the front waves (see there).
+//   pole rings of the de-duplicated grids (col_of_pixel) have a closed form, F_m = n_phi x value at m = -+spin, and take no
+//   part in the products.
+// =====================================================================================================================
+struct SplitGeom {
+  int n_theta, n_phi, L, n_out, nk, spin;
+  int nf, nb;     // front and back waves
+  int rings;      // rings per row that go through the products (n_theta, or n_theta - 2 with closed-form poles)
+  int poles;      // 1: rings 0 and n_theta - 1 are stored as one value each
+  int ahead;      // 1: the back waves prefetch into L2
+};
+constexpr int SPLIT_MAX_WAVES = 10;
+
+template <int NT, int KS>
+__global__ __launch_bounds__(640, 1) void analysis_split_kernel(
+    const double* __restrict__ G, long long ldg, long long n_rows, SplitGeom g, const int* __restrict__ m_index,
+    const double* __restrict__ T, double* __restrict__ out, long long ldo, const int* __restrict__ col_of_pixel) {
+  constexpr int PJ = NT + 1;  // odd pitch (complex) of an F_m row
+  extern __shared__ double lds[];
+  // [1 KB per wave: landing area of the prefetch requests, never read][2 buffers][2 rows][2L+1][PJ]
+  double2* Fs = reinterpret_cast<double2*>(lds) + 64 * SPLIT_MAX_WAVES;
+  const int fsz = (2 * g.L + 1) * PJ;
+  const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  for (int e = tid; e < 4 * fsz; e += blockDim.x) Fs[e] = double2{0.0, 0.0};
+  __syncthreads();
+  const long long n_pairs = (n_rows + 1) / 2;
+  const long long stride = gridDim.x;
+  long long p = blockIdx.x;
+  // Roles.  A workgroup's waves go to the SIMDs round robin, so waves w, w + 4, w + 8 share one.  The front waves carry
+  // the MFMA work (one tile of 4 KS products each): waves 0..3 first, one per SIMD, and a fifth and sixth on the SIMDs
+  // that hold only two waves (6 and 7) -- with waves 0..4 in front, waves 0 and 4 made one SIMD the bottleneck.
+  const int n_waves = g.nf + g.nb;
+  const auto front_of = [&](int w) {  // tile of wave w, or -1
+    const int extra = n_waves >= 8 ? 6 : 4;  // where the fifth and sixth front waves sit
+    const int f = w < 4 ? w : (w >= extra && w < extra + 2 ? 4 + w - extra : -1);
+    return f < g.nf ? f : -1;
+  };
+  const int front = front_of(wave);
+  const bool is_front = front >= 0;
+  int back = wave;  // rank among the waves that are not front
+  for (int w = 0; w < wave; ++w)
+    if (front_of(w) >= 0) --back;
+
+  if (is_front) {
+    const int fi = lane & 15, fk = lane >> 4;
+    // A-row of this lane: ring slot q of the pair's 2 x rings regular rings
+    const int q = 16 * front + fi;
+    const bool okr = q < 2 * g.rings;
+    const int r = okr ? q / g.rings : 0;
+    const int j = (okr ? q - r * g.rings : 0) + g.poles;
+    int offa[KS], offb[KS];
+    double cs[KS], sn[KS];
+    unsigned va = 0, vb = 0;  // bit s: sample k = 4 s + fk exists / has a partner other than itself
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      const int k = 4 * s + fk;
+      const bool ok = okr && k < g.nk;
+      const int k2 = k == 0 ? 0 : g.n_phi - k;
+      const int g1 = ok ? j * g.n_phi + k : 0, g2 = ok ? j * g.n_phi + k2 : 0;
+      offa[s] = 8 * (2 * (col_of_pixel ? col_of_pixel[g1] : g1) + r * (int)ldg);  // bytes from the pair's first row
+      offb[s] = 8 * (2 * (col_of_pixel ? col_of_pixel[g2] : g2) + r * (int)ldg);
+      if (ok) va |= 1u << s;
+      if (ok && k2 != k) vb |= 1u << s;
+      // B fragment: column m = fi + 1 of the cos | sin matrices, row k
+      const int m = fi + 1;
+      const long long rr = ((long long)m * k) % g.n_phi;
+      double sv, cv;
+      sincospi(2.0 * (double)rr / (double)g.n_phi, &sv, &cv);
+      const bool okb = k < g.nk && m <= g.L;
+      cs[s] = okb ? cv : 0.0;
+      sn[s] = okb ? sv : 0.0;
+    }
+    // where the four results of a lane go: D rows fk + 4 v = ring slots 16 front + fk + 4 v, column m = fi + 1
+    int fo[4];
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      const int qv = 16 * front + fk + 4 * v;
+      const bool ok = qv < 2 * g.rings && fi + 1 <= g.L;
+      const int rv = ok ? qv / g.rings : 0;
+      fo[v] = ok ? rv * fsz + (qv - rv * g.rings) + g.poles : -1;
+    }
+    const int f0 = okr ? r * fsz + g.L * PJ + j : -1;  // m = 0 of this lane's own ring (written by the lanes fk = 0)
+    // closed-form poles: lanes 0..3 of the first front wave take (row, pole) = (lane >> 1, lane & 1)
+    const bool pole_lane = g.poles && front == 0 && lane < 4;
+    const int pole_m = (lane & 1) ? g.spin : -g.spin;
+    const int pole_ring = (lane & 1) ? g.n_theta - 1 : 0;
+    const int pole_off = pole_lane ? 8 * (2 * col_of_pixel[pole_ring * g.n_phi] + (lane >> 1) * (int)ldg) : 0;
+    const int pole_fo = (pole_lane && pole_m >= -g.L && pole_m <= g.L) ? (lane >> 1) * fsz + (g.L + pole_m) * PJ + pole_ring : -1;
+    // Buffer loads: the pair's two rows (t0, t0 + 1 with t0 = min(2 pp, n_rows - 2): the last pair of an odd series
+    // overlaps the one before it) behind a wave-uniform descriptor, 32-bit lane offsets.  Flat loads made the compiler
+    // carry a 64-bit address per load through the loop and spill; a spill reload inside the loop waits with vmcnt(0),
+    // i.e. for every sample in flight.
+    auto descriptor = [&](long long pp) {
+      if (pp >= n_pairs) pp = n_pairs - 1;  // (past the end: any valid pair, the samples are never used)
+      long long t = 2 * pp;
+      if (t > n_rows - 2) t = n_rows - 2;
+      return __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(G + t * ldg), 0, (int)(16 * ldg), 0x00020000);
+    };
+    double2 xa[KS], xb[KS], xp;
+    {
+      const auto rsrc = descriptor(p);
+#pragma unroll
+      for (int s = 0; s < KS; ++s) {
+        xa[s] = __builtin_bit_cast(double2, __builtin_amdgcn_raw_buffer_load_b128(rsrc, offa[s], 0, 0));
+        xb[s] = __builtin_bit_cast(double2, __builtin_amdgcn_raw_buffer_load_b128(rsrc, offb[s], 0, 0));
+      }
+      xp = __builtin_bit_cast(double2, __builtin_amdgcn_raw_buffer_load_b128(rsrc, pole_off, 0, 0));
+    }
+    for (int it = 0; p < n_pairs; p += stride, it ^= 1) {
+      double2* Fb = Fs + it * 2 * fsz;
+      // k-step by k-step: fold, ask for the same samples of the next pair (their registers are free from here on, and
+      // the request is in flight under everything up to the next trip's fold), four products
+      const auto next = descriptor(p + stride);
+      const double2 pole_value = xp;
+      xp = __builtin_bit_cast(double2, __builtin_amdgcn_raw_buffer_load_b128(next, pole_off, 0, 0));
+      v4d_t cr{0.0, 0.0, 0.0, 0.0}, ci = cr, sr = cr, si = cr;
+      double e0x = 0.0, e0y = 0.0;
+#pragma unroll
+      for (int s = 0; s < KS; ++s) {
+        const double wa = (va >> s) & 1u ? 1.0 : 0.0, wb = (vb >> s) & 1u ? 1.0 : 0.0;
+        const double ex = wa * xa[s].x + wb * xb[s].x, ey = wa * xa[s].y + wb * xb[s].y;
+        const double ox = wb * (xa[s].x - xb[s].x), oy = wb * (xa[s].y - xb[s].y);
+        xa[s] = __builtin_bit_cast(double2, __builtin_amdgcn_raw_buffer_load_b128(next, offa[s], 0, 0));
+        xb[s] = __builtin_bit_cast(double2, __builtin_amdgcn_raw_buffer_load_b128(next, offb[s], 0, 0));
+        e0x += ex;
+        e0y += ey;
+        cr = __builtin_amdgcn_mfma_f64_16x16x4f64(ex, cs[s], cr, 0, 0, 0);
+        ci = __builtin_amdgcn_mfma_f64_16x16x4f64(ey, cs[s], ci, 0, 0, 0);
+        sr = __builtin_amdgcn_mfma_f64_16x16x4f64(ox, sn[s], sr, 0, 0, 0);
+        si = __builtin_amdgcn_mfma_f64_16x16x4f64(oy, sn[s], si, 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      // m = 0: sum over the four k-lanes of a ring
+      e0x += __shfl_xor(e0x, 16);
+      e0y += __shfl_xor(e0y, 16);
+      e0x += __shfl_xor(e0x, 32);
+      e0y += __shfl_xor(e0y, 32);
+      if (fk == 0 && f0 >= 0) Fb[f0] = double2{e0x, e0y};
+      const int m = fi + 1;
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        if (fo[v] >= 0) {
+          Fb[fo[v] + (g.L + m) * PJ] = double2{cr[v] + si[v], ci[v] - sr[v]};
+          Fb[fo[v] + (g.L - m) * PJ] = double2{cr[v] - si[v], ci[v] + sr[v]};
+        }
+      }
+      if (pole_fo >= 0) Fb[pole_fo] = double2{(double)g.n_phi * pole_value.x, (double)g.n_phi * pole_value.y};
+      __syncthreads();  // F of this pair complete; the back waves have finished with the other buffer
+    }
+  } else {
+    const int o = 64 * back + lane;
+    const bool live = o < g.n_out;
+    double tj[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) tj[j] = (live && j < g.n_theta) ? T[(long long)o * g.n_theta + j] : 0.0;
+    const int fbase = (live ? m_index[o] : 0) * PJ;
+    // Prefetch (g.ahead > 0).  The front waves' requests are 16-byte pieces, 16 to 64 different lines per instruction, in
+    // an order the MFMA fragment dictates; the memory system serves whole rows requested in order much better.  The back
+    // waves have the time and need no registers for it: LDS-DMA requests for the rows the front waves will ask for in
+    // their next trip but one, 1 KB per instruction, into a landing area nobody reads -- a prefetch into this XCD's L2
+    // that no s_waitcnt of the compiler knows about.  It only pays while three pairs of rows of every CU of the XCD fit
+    // the L2 (the launcher decides): beyond that it evicts what it fetched.
+    const unsigned landing = (unsigned)wave * 1024u;  // LDS byte address (the dynamic segment starts at 0)
+    const int pair_bytes = (int)(16 * ldg);
+    auto prefetch = [&](long long pp) {
+      if (pp >= n_pairs) return;
+      long long t = 2 * pp;
+      if (t > n_rows - 2) t = n_rows - 2;
+      const char* base = reinterpret_cast<const char*>(G + t * ldg);
+      for (int c = 16 * o; c < pair_bytes; c += 1024 * g.nb) {
+        unsigned keep;
+        asm volatile(
+            "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+            : "=&s"(keep)
+            : "v"(base + c), "s"(landing)
+            : "memory");
+      }
+    };
+    if (g.ahead) {
+      prefetch(p + stride);
+      prefetch(p + 2 * stride);
+    }
+    for (int it = 0; p < n_pairs; p += stride, it ^= 1) {
+      __syncthreads();
+      const double2* fa = Fs + it * 2 * fsz + fbase;
+      const double2* fb = fa + fsz;
+      double ar = 0.0, ai = 0.0, br = 0.0, bi = 0.0;
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        const double2 u = fa[j], w = fb[j];
+        ar = fma(tj[j], u.x, ar);
+        ai = fma(tj[j], u.y, ai);
+        br = fma(tj[j], w.x, br);
+        bi = fma(tj[j], w.y, bi);
+      }
+      if (live) {
+        long long t = 2 * p;
+        if (t > n_rows - 2) t = n_rows - 2;
+        *reinterpret_cast<double2*>(out + t * ldo + 2LL * o) = double2{ar, ai};
+        *reinterpret_cast<double2*>(out + (t + 1) * ldo + 2LL * o) = double2{br, bi};
+      }
+      // (the front waves are in their next trip and have asked for pair p + 2 stride at its start)
+      if (g.ahead) prefetch(p + 3 * stride);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // no request may outlive the workgroup's LDS
+  }
+}
+
+int split_analysis_supported(int n_theta, int n_phi, int L, int n_out, bool dedup_poles, SplitGeom& g, size_t& lds_bytes, int& nt) {
+  if (getenv("SCRI_AMD_NO_SPLIT_ANALYSIS")) return 0;
+  if (n_theta < 3 || n_theta > 40 || n_phi < 2 || L < 1 || L > 16) return 0;
+  // (n_rows >= 2 and 16 ldg < 2^31 are checked by the caller)
+  g.n_theta = n_theta;
+  g.n_phi = n_phi;
+  g.L = L;
+  g.n_out = n_out;
+  g.nk = n_phi / 2 + 1;
+  if (g.nk > 20) return 0;  // five k-steps: with six the kernel no longer fits the 168 registers of 10 waves per CU
+  g.poles = dedup_poles ? 1 : 0;
+  g.rings = n_theta - 2 * g.poles;
+  g.nf = (2 * g.rings + 15) / 16;
+  g.nb = (n_out + 63) / 64;
+  if (g.nf > 6 || g.nf + g.nb > SPLIT_MAX_WAVES) return 0;
+  nt = n_theta <= 24 ? 24 : (n_theta <= 38 ? 38 : 40);
+  lds_bytes = sizeof(double2) * ((size_t)4 * (2 * L + 1) * (nt + 1) + 64 * SPLIT_MAX_WAVES);
+  return 1;
+}
+
 template <typename K>
 static hipError_t launch_fused_t(K kernel, hipStream_t stream, dim3 grid, dim3 block, size_t lds, const double* G, long long ldg,
                                  long long n_rows, const FusedGeom& g, const int* m_index, const double* T, const double* D,
@@ -446,6 +691,51 @@ hipError_t launch_analysis_fused(hipStream_t stream, const double* G, long long 
   size_t lds;
   int pj;
   fused_geometry(n_theta, n_phi, L, n_out, g, lds, pj);
+  {
+    SplitGeom sg;
+    size_t slds;
+    int nt;
+    if (n_rows >= 2 && ldg < (1LL << 26) && split_analysis_supported(n_theta, n_phi, L, n_out, col_of_pixel != nullptr, sg, slds, nt)) {
+      sg.spin = spin;
+      // Prefetch: measured at cfg3 it takes the gathered grid of the transformation from 0.67 to 0.52 ms per 1e5 rows (its
+      // 16-byte pieces land on 64 different lines per request and are expensive as L2 misses), costs the same shape in
+      // natural order 0.51 -> 0.58 ms (64-byte pieces: nothing to gain) and the small rows of cfg2 0.22 -> 0.27 ms.  So:
+      // gathered grids whose rows are long, while three pairs of rows of each of the XCD's 32 CUs fit its 4 MiB L2.
+      const long long pair_bytes = 16 * ldg;
+      sg.ahead = getenv("SCRI_AMD_SPLIT_PREFETCH") ? atoi(getenv("SCRI_AMD_SPLIT_PREFETCH"))
+                                                   : (col_of_pixel && pair_bytes >= (32 << 10) && 96 * pair_bytes <= (4LL << 20) ? 1 : 0);
+      static const long long cus = [] {
+        int dev = 0, n = 256;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 256;
+        return (long long)n;
+      }();
+      const long long n_pairs = (n_rows + 1) / 2;
+      // one workgroup per CU at cfg3 (10 waves); small shapes need fewer waves and get two or three
+      const long long per_cu = 10 / (sg.nf + sg.nb) < 3 ? 10 / (sg.nf + sg.nb) : 3;
+      const long long max_blocks = cus * per_cu;
+      const dim3 sgrid((unsigned)(n_pairs < max_blocks ? n_pairs : max_blocks)), sblock(64 * (sg.nf + sg.nb));
+      const int ks = (sg.nk + 3) / 4;
+#define SPLIT_GO(NT, KS)                                                                                                   \
+  {                                                                                                                        \
+    hipError_t e = hipFuncSetAttribute((const void*)analysis_split_kernel<NT, KS>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                       (int)slds);                                                                         \
+    if (e != hipSuccess) return e;                                                                                         \
+    hipLaunchKernelGGL((analysis_split_kernel<NT, KS>), sgrid, sblock, slds, stream, G, ldg, n_rows, sg, m_index, T, out, ldo, \
+                       col_of_pixel);                                                                                      \
+    return hipGetLastError();                                                                                              \
+  }
+#define SPLIT_KS(NT)              \
+  {                               \
+    if (ks <= 3) SPLIT_GO(NT, 3)  \
+    SPLIT_GO(NT, 5)               \
+  }
+      if (nt == 24) SPLIT_KS(24)
+      if (nt == 38) SPLIT_KS(38)
+      SPLIT_KS(40)
+#undef SPLIT_KS
+#undef SPLIT_GO
+    }
+  }
   g.spin = spin;
   // one thread per output mode (up to 64 modes beyond 256 ride along as second modes), never fewer than 4 waves
   int threads = g.n_sec ? 256 : ((n_out + 63) / 64) * 64;

@@ -84,6 +84,37 @@ def test_large_grid_analysis_variants(ctx, monkeypatch, n_theta, n_phi, spin, el
     assert np.abs(old - ref).max() < 2e-13 * max(1.0, np.abs(ref).max())
 
 
+@pytest.mark.parametrize(
+    "n_theta,n_phi,spin,ell_max,ell_min,n_rows",
+    [
+        (37, 37, -2, 16, 2, 11),  # cfg3's grid: 5 front + 5 back waves
+        (37, 37, -2, 4, 2, 6),    # 5 front waves, ONE back wave (fewer than 8 waves in the workgroup)
+        (40, 39, 0, 3, 0, 5),     # 5 front waves, one back wave, n_theta at the limit
+        (33, 33, 0, 16, 0, 4),    # spin 0: 289 modes
+        (21, 21, -2, 8, 2, 9),    # cfg2's grid: 3 + 2 waves, several workgroups per CU
+        (17, 20, -1, 8, 1, 3),    # even n_phi (a Nyquist sample that is its own partner), odd number of rows
+        (9, 9, 2, 4, 2, 2),       # two rows: one pair
+        (25, 27, 1, 12, 1, 1001),
+        (3, 5, 0, 1, 0, 7),       # the smallest grid the kernel takes
+    ],
+)
+def test_fused_analysis_two_role_kernel_shapes(ctx, monkeypatch, n_theta, n_phi, spin, ell_max, ell_min, n_rows):
+    """n_theta <= 40, l_max <= 16: `analysis_split_kernel` (front waves: fold + MFMA, back waves: theta quadrature) for
+    every combination of wave counts; the one-role kernel (SCRI_AMD_NO_SPLIT_ANALYSIS) stays reachable and must agree;
+    repeated calls are bitwise equal."""
+    from scri_amd import engine
+
+    rng = np.random.default_rng(n_theta * n_phi + n_rows)
+    f = rng.normal(size=(n_rows, n_theta, n_phi)) + 1j * rng.normal(size=(n_rows, n_theta, n_phi))
+    ref = spinsfast_ref.map2salm(f, spin, ell_max)[..., ell_min**2 :]
+    got = engine.map2salm(f, spin, ell_max, ell_min=ell_min, ctx=ctx)
+    assert np.abs(got - ref).max() < 2e-13 * max(1.0, np.abs(ref).max())
+    assert np.array_equal(got, engine.map2salm(f, spin, ell_max, ell_min=ell_min, ctx=ctx))
+    monkeypatch.setenv("SCRI_AMD_NO_SPLIT_ANALYSIS", "1")
+    old = engine.map2salm(f, spin, ell_max, ell_min=ell_min, ctx=ctx)
+    assert np.abs(old - ref).max() < 2e-13 * max(1.0, np.abs(ref).max())
+
+
 def test_large_boost_wide_skew_and_chunks(ctx):
     import scri_amd
 
