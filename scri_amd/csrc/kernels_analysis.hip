@@ -456,6 +456,9 @@ struct SplitGeom {
   int ahead;      // 1: the back waves prefetch into L2
 };
 constexpr int SPLIT_MAX_WAVES = 10;
+#ifndef SPLIT_AUX
+#define SPLIT_AUX 0  // cache policy bits of the sample requests (2 = non-temporal)
+#endif
 
 template <int NT, int KS>
 __global__ __launch_bounds__(640, 1) void analysis_split_kernel(
@@ -567,8 +570,8 @@ __global__ __launch_bounds__(640, 1) void analysis_split_kernel(
         const double wa = (va >> s) & 1u ? 1.0 : 0.0, wb = (vb >> s) & 1u ? 1.0 : 0.0;
         const double ex = wa * xa[s].x + wb * xb[s].x, ey = wa * xa[s].y + wb * xb[s].y;
         const double ox = wb * (xa[s].x - xb[s].x), oy = wb * (xa[s].y - xb[s].y);
-        xa[s] = __builtin_bit_cast(double2, __builtin_amdgcn_raw_buffer_load_b128(next, offa[s], 0, 0));
-        xb[s] = __builtin_bit_cast(double2, __builtin_amdgcn_raw_buffer_load_b128(next, offb[s], 0, 0));
+        xa[s] = __builtin_bit_cast(double2, __builtin_amdgcn_raw_buffer_load_b128(next, offa[s], 0, SPLIT_AUX));
+        xb[s] = __builtin_bit_cast(double2, __builtin_amdgcn_raw_buffer_load_b128(next, offb[s], 0, SPLIT_AUX));
         e0x += ex;
         e0y += ey;
         cr = __builtin_amdgcn_mfma_f64_16x16x4f64(ex, cs[s], cr, 0, 0, 0);

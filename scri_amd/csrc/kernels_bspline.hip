@@ -347,17 +347,26 @@ hipError_t launch_negated_row(hipStream_t stream, const double* off, double* row
 constexpr int BS_WORDS = sizeof(BsplineTable) / sizeof(double);  // 20
 constexpr int BS_W_G = 16, BS_W_D = 17, BS_W_X = 18;
 
+// maximum over the wave, on the cross-lane data path of the VALU (six LDS round trips as ds_bpermute, several times per group
+// of knots in the dependent chain of the march)
 __device__ __forceinline__ int bs_wave_max_i32(int v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) {
-    const int o = __shfl_xor(v, off, 64);
-    v = o > v ? o : v;
+#define BS_DPP_MAX(ctrl, rows)                                                      \
+  {                                                                                 \
+    const int o = __builtin_amdgcn_update_dpp(v, v, ctrl, rows, 0xf, false);        \
+    v = o > v ? o : v;                                                              \
   }
-  return v;
+  BS_DPP_MAX(0x111, 0xf)  // row_shr:1
+  BS_DPP_MAX(0x112, 0xf)  // row_shr:2
+  BS_DPP_MAX(0x114, 0xf)  // row_shr:4
+  BS_DPP_MAX(0x118, 0xf)  // row_shr:8   -> lane 15 of every row of 16 holds the row's maximum
+  BS_DPP_MAX(0x142, 0xa)  // row_bcast:15 into rows 1 and 3
+  BS_DPP_MAX(0x143, 0xc)  // row_bcast:31 into rows 2 and 3 -> lane 63 holds the wave's
+#undef BS_DPP_MAX
+  return __builtin_amdgcn_readlane(v, 63);
 }
 
-template <int RING, int GS, int DEFER>
-__global__ __launch_bounds__(64) void bspline_backward_eval_kernel(
+template <int RING, int GS, int DEFER, int SLOTS, bool NT_IO>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void bspline_backward_eval_kernel(
     const double* __restrict__ C, long long ld, int n_cols, long long g0, long long n_rows, long long n,
     const double* __restrict__ x, const BsplineTable* __restrict__ table, int tile, int halo, const double* __restrict__ base,
     const double* __restrict__ skew_a, const double* __restrict__ skew_b, double tt, long long i_lo, long long i_hi,
@@ -412,42 +421,67 @@ __global__ __launch_bounds__(64) void bspline_backward_eval_kernel(
                                // keeps every output sample away from there)
   long long jE = jI + halo;
   if (jE > jend - 1) jE = jend - 1;
-  auto ld2 = [&](long long j) { return *reinterpret_cast<const double2*>(cp + (j >= k_min ? j : k_min) * ld); };
+  // rows of C are read once and rows of `out` written once (2 GB each at cfg3): non-temporal, they need not stay in the caches
+  typedef double v2d_t __attribute__((ext_vector_type(2)));
+  auto ld2 = [&](long long j) {
+    const v2d_t v = NT_IO ? __builtin_nontemporal_load(reinterpret_cast<const v2d_t*>(cp + (j >= k_min ? j : k_min) * ld))
+                          : *reinterpret_cast<const v2d_t*>(cp + (j >= k_min ? j : k_min) * ld);
+    return double2{v.x, v.y};
+  };
+  auto st2 = [&](double* q, double2 v) {
+    if (NT_IO)
+      __builtin_nontemporal_store(v2d_t{v.x, v.y}, reinterpret_cast<v2d_t*>(q));
+    else
+      *reinterpret_cast<double2*>(q) = v;
+  };
 
-  // this lane's share of a group's table words: word (lane + 64 u) of the block = word tw of entry k_top - te
+  // this lane's share of a group's table words: word (lane + 64 u) of the block = word tw of entry k_top - te.  The words
+  // of the block that the table leaves free (TN .. 64 TU) carry a window of the output abscissae, base[w_top - WIN + 1 ..
+  // w_top]: the march needs base[i - 1] after every sample, and as a load from global memory that value queues up behind
+  // the rows just requested for the next group (loads return in order), i.e. it costs the full latency of HBM once per
+  // group, in the dependent chain.
+  constexpr int WIN = 64 * TU - TN;
+  static_assert(WIN >= 16, "no room for the abscissa window");
   int te[TU], tw[TU];
 #pragma unroll
   for (int u = 0; u < TU; ++u) {
     const int idx = lane + 64 * u;
     te[u] = idx < TN ? idx / BS_WORDS : -1;
-    tw[u] = idx % BS_WORDS;
+    tw[u] = idx < TN ? idx % BS_WORDS : idx - TN;
   }
-  auto tfetch = [&](long long k_top, double* tl) {
+  auto tfetch = [&](long long k_top, int w_top, double* tl) {
 #pragma unroll
     for (int u = 0; u < TU; ++u)
       if (te[u] >= 0) {
         long long kk = k_top - te[u];
         kk = kk < k_min ? k_min : (kk > jE ? jE : kk);
         tl[u] = reinterpret_cast<const double*>(table + kk)[tw[u]];
+      } else {
+        int wi = w_top - (WIN - 1) + tw[u];
+        wi = wi < 0 ? 0 : (wi > n_i - 1 ? n_i - 1 : wi);
+        tl[u] = bp[wi];
       }
   };
 
   // the output abscissa of the sample in hand and of the one after it: the gather of base[i - 1] is in flight while sample i
   // is evaluated (it sits in the dependent chain of the march otherwise)
   double xi_cur = alive ? bp[i] : 0.0, xi_nxt = (alive && i > 0) ? bp[i - 1] : 0.0;
-  double ue = xi_cur + (sa * (xi_cur - tt) + sb);
+  double sk = sa * (xi_cur - tt) + sb;  // time skew of this column at the sample in hand
+  const double* wv = nullptr;  // the abscissa window of the group in hand (LDS) and the index of its first entry
+  int w_lo = 0;
+  double ue = xi_cur + sk;
   int fl = i;
   int ftop = bs_wave_max_i32(i);
   auto park = [&](double2 v) {
     if (fl - i >= RING) {  // ring full (output much denser than the knots): let the oldest row go
-      *reinterpret_cast<double2*>(op + fl * ldo) = ring[fl & (RING - 1)][lane];
+      st2(op + fl * ldo, ring[fl & (RING - 1)][lane]);
       --fl;
     }
     ring[i & (RING - 1)][lane] = v;
   };
   auto flush = [&](int bot) {
     for (int row = ftop; row > bot; --row)
-      if (row <= fl && row > i) *reinterpret_cast<double2*>(op + row * ldo) = ring[row & (RING - 1)][lane];
+      if (row <= fl && row > i) st2(op + row * ldo, ring[row & (RING - 1)][lane]);
     const int keep = bot > i ? bot : i;
     if (fl > keep) fl = keep;
     if (ftop > bot) ftop = bot;
@@ -456,25 +490,33 @@ __global__ __launch_bounds__(64) void bspline_backward_eval_kernel(
   auto interval = [&](long long jj, const double* tb, double2 q0, double2 q1, double2 q2, double2 q3) {
     const double xj = tb[BS_W_X];
     const bool last_interval = (jj == 0);  // only the tile with jA = 0 gets here: claims everything below
-    if (i >= 0 && (ue >= xj || last_interval)) {
-      const double p0x = tb[0] * q0.x + tb[1] * q1.x + tb[2] * q2.x + tb[3] * q3.x, p0y = tb[0] * q0.y + tb[1] * q1.y + tb[2] * q2.y + tb[3] * q3.y;
-      const double p1x = tb[4] * q0.x + tb[5] * q1.x + tb[6] * q2.x + tb[7] * q3.x, p1y = tb[4] * q0.y + tb[5] * q1.y + tb[6] * q2.y + tb[7] * q3.y;
-      const double p2x = tb[8] * q0.x + tb[9] * q1.x + tb[10] * q2.x + tb[11] * q3.x,
-                   p2y = tb[8] * q0.y + tb[9] * q1.y + tb[10] * q2.y + tb[11] * q3.y;
-      const double p3x = tb[12] * q0.x + tb[13] * q1.x + tb[14] * q2.x + tb[15] * q3.x,
-                   p3y = tb[12] * q0.y + tb[13] * q1.y + tb[14] * q2.y + tb[15] * q3.y;
-      while (i >= 0 && (ue >= xj || last_interval)) {
-        // t = u_eval - x_j, formed as (x_i - x_j) + skew to keep the small difference exact
-        const double t = (xi_cur - xj) + (sa * (xi_cur - tt) + sb);
-        double2 v;
-        v.x = ((p3x * t + p2x) * t + p1x) * t + p0x;
-        v.y = ((p3y * t + p2y) * t + p1y) * t + p0y;
-        park(v);
-        --i;
-        xi_cur = xi_nxt;
-        if (i > 0) xi_nxt = bp[i - 1];
-        ue = xi_cur + (sa * (xi_cur - tt) + sb);
+    // B-spline form: the four basis values at t (cubic each, 12 multiply-adds for the wave), then 8 for the sample --
+    // the power form of the interval (32 to build + 6 per sample) loses when an interval holds about one sample
+    while (i >= 0 && (ue >= xj || last_interval)) {
+      // t = u_eval - x_j, formed as (x_i - x_j) + skew to keep the small difference exact
+      const double t = (xi_cur - xj) + sk;
+      const double b0 = fma(fma(fma(tb[12], t, tb[8]), t, tb[4]), t, tb[0]);
+      const double b1 = fma(fma(fma(tb[13], t, tb[9]), t, tb[5]), t, tb[1]);
+      const double b2 = fma(fma(fma(tb[14], t, tb[10]), t, tb[6]), t, tb[2]);
+      const double b3 = fma(fma(fma(tb[15], t, tb[11]), t, tb[7]), t, tb[3]);
+      double2 v;
+      v.x = fma(b3, q3.x, fma(b2, q2.x, fma(b1, q1.x, b0 * q0.x)));
+      v.y = fma(b3, q3.y, fma(b2, q2.y, fma(b1, q1.y, b0 * q0.y)));
+      park(v);
+      --i;
+      xi_cur = xi_nxt;
+      if (i > 0) {
+        const int rel = (i - 1) - w_lo;  // position in the staged window
+        if (rel >= 0 && rel < WIN) {
+          xi_nxt = wv[rel];
+        } else {  // (output much denser than the knots, or columns of very different skew in one wave)
+          double far = bp[i - 1];
+          asm volatile("" : "+v"(far));  // the wait for it stays on this path
+          xi_nxt = far;
+        }
       }
+      sk = sa * (xi_cur - tt) + sb;
+      ue = xi_cur + sk;
     }
   };
   const bool has_top_extra = (n - 2 >= jA) && (n - 2 < jI);
@@ -491,39 +533,60 @@ __global__ __launch_bounds__(64) void bspline_backward_eval_kernel(
     w2 = w1, w1 = w0, w0 = c;
   };
 
-  // march: knots jE-1 .. k_min in groups of GS; above the tile only the recurrence runs (its start decays as 0.268^halo)
+  // march: knots jE-1 .. k_min in groups of GS; above the tile only the recurrence runs (its start decays as 0.268^halo).
+  // SLOTS register sets hold the groups in hand and in flight: the group computed in a trip was requested SLOTS - 1 trips
+  // earlier (one trip ~ 900 cycles of dependent arithmetic, a load from HBM under load 2-3 us).
   long long k = jE - 1;
-  double2 r[GS], nx[GS];
-  double tl[TU];
+  double2 rr[SLOTS][GS];
+  double tl[SLOTS][TU];
+  int wtop[SLOTS];  // last index of the abscissa window that travels with the slot's table words
 #pragma unroll
-  for (int g = 0; g < GS; ++g) r[g] = ld2(k - g);
-  tfetch(k + 2, tl);
+  for (int d = 0; d < SLOTS - 1; ++d) {
+    const long long kd = k - (long long)d * GS;
+    wtop[d] = ftop - 1;
+    if (kd >= k_min) {
+#pragma unroll
+      for (int g = 0; g < GS; ++g) rr[d][g] = ld2(kd - g);
+      tfetch(kd + 2, wtop[d], tl[d]);
+    }
+  }
   int buf = 0;
   int pending_bot = 0x7fffffff;  // rows above it are complete but not yet written (DEFER: written one group late)
-  for (; k >= k_min; k -= GS) {
-    double* tb = tbuf[buf];
+  bool done = false;
+  while (!done) {
 #pragma unroll
-    for (int u = 0; u < TU; ++u) tb[lane + 64 * u] = tl[u];
-    // (the wait for this group's loads has just drained the memory pipe: the stores of the previous group go out now, a
-    // whole group ahead of the next wait, instead of right in front of it)
-    if (DEFER && pending_bot != 0x7fffffff) flush(pending_bot);
-    // the NEXT group's rows and table entries are requested before the dependent chain of this group starts
-    const long long kn = k - GS;
-    if (kn >= k_min) {
+    for (int ph = 0; ph < SLOTS; ++ph) {
+      if (done || k < k_min) {
+        done = true;
+        continue;
+      }
+      double* tb = tbuf[buf];
 #pragma unroll
-      for (int g = 0; g < GS; ++g) nx[g] = ld2(kn - g);
-      tfetch(kn + 2, tl);
+      for (int u = 0; u < TU; ++u) tb[lane + 64 * u] = tl[ph][u];
+      wv = tb + TN;
+      w_lo = wtop[ph] - (WIN - 1);
+      // (the wait for this group's loads has just drained the memory pipe: the stores of the previous group go out now, a
+      // whole group ahead of the next wait, instead of right in front of it)
+      if (DEFER && pending_bot != 0x7fffffff) flush(pending_bot);
+      // the group SLOTS - 1 trips ahead is requested into the set that became free in the previous trip
+      const int nslot = (ph + SLOTS - 1) % SLOTS;  // (a constant once the loop is unrolled)
+      const long long kn = k - (long long)(SLOTS - 1) * GS;
+      if (kn >= k_min) {
+#pragma unroll
+        for (int g = 0; g < GS; ++g) rr[nslot][g] = ld2(kn - g);
+        wtop[nslot] = bs_wave_max_i32(i) - 1;  // nobody will ask for an entry above where the first lane stands now
+        tfetch(kn + 2, wtop[nslot], tl[nslot]);
+      }
+#pragma unroll
+      for (int g = 0; g < GS; ++g) {
+        if (k - g >= k_min) stepk(k - g, rr[ph][g], tb + (2 + g) * BS_WORDS);
+        if (!DEFER && ((g & 3) == 3 || g == GS - 1)) flush(bs_wave_max_i32(i));  // rows every lane has left behind
+      }
+      if (DEFER) pending_bot = bs_wave_max_i32(i);
+      if (!__any(i >= 0)) done = true;
+      buf ^= 1;
+      k -= GS;
     }
-#pragma unroll
-    for (int g = 0; g < GS; ++g) {
-      if (k - g >= k_min) stepk(k - g, r[g], tb + (2 + g) * BS_WORDS);
-      if (!DEFER && ((g & 3) == 3 || g == GS - 1)) flush(bs_wave_max_i32(i));  // rows every lane has left behind
-    }
-    if (DEFER) pending_bot = bs_wave_max_i32(i);
-    if (!__any(i >= 0)) break;
-#pragma unroll
-    for (int g = 0; g < GS; ++g) r[g] = nx[g];
-    buf ^= 1;
   }
   if (DEFER && pending_bot != 0x7fffffff) flush(pending_bot);
   // lanes stop at different rows at the bottom of the tile: whatever is still parked goes out now
@@ -559,14 +622,18 @@ hipError_t launch_bspline_backward_eval(hipStream_t stream, const double* C, lon
   const long long n_tiles = (n_rows + tile - 1) / tile;
   dim3 grid((n_cols + 63) / 64, (unsigned)n_tiles);
   static const int xp = getenv("SCRI_AMD_BS_XP") ? atoi(getenv("SCRI_AMD_BS_XP")) : 0;
-#define BS_GO(R, G_, X_)                                                                                                        \
-  hipLaunchKernelGGL((bspline_backward_eval_kernel<R, G_, X_>), grid, dim3(64), 0, stream, C, ld, n_cols, g0, n_rows, n_knots, x, table, \
+#define BS_GO(R, G_, X_, S_, N_)                                                                                                      \
+  hipLaunchKernelGGL((bspline_backward_eval_kernel<R, G_, X_, S_, N_>), grid, dim3(64), 0, stream, C, ld, n_cols, g0, n_rows, n_knots, x, table, \
                      tile, halo, base, skew_a, skew_b, tt, i_lo, i_hi, out, ldo)
   switch (xp) {  // (ring rows, knots per group, deferred stores): measured 1.21 / 1.12 / 1.06 ms at cfg3 for the first three
-    case 1: BS_GO(8, 4, 0); break;
-    case 2: BS_GO(8, 4, 1); break;
-    case 3: BS_GO(16, 4, 1); break;
-    default: BS_GO(8, 3, 1);
+    case 1: BS_GO(8, 3, 0, 2, false); break;
+    case 3: BS_GO(16, 3, 1, 2, false); break;
+    case 4: BS_GO(8, 3, 1, 2, false); break;
+    case 5: BS_GO(8, 3, 1, 4, false); break;
+    case 6: BS_GO(8, 2, 1, 4, false); break;
+    case 7: BS_GO(8, 2, 1, 3, false); break;
+    case 8: BS_GO(8, 3, 1, 2, false); break;
+    default: BS_GO(8, 3, 1, 2, true);  // non-temporal rows: 0.96 -> 0.91 ms at cfg3
   }
 #undef BS_GO
   return hipGetLastError();
