@@ -53,6 +53,15 @@ struct AnalysisPlan {
   long long ldw = 0;
 };
 
+// separable synthesis of boost-free transformations (kernels_synthesis.hip)
+struct SynthesisPlan {
+  SynGeom g;
+  int nt = 0;
+  size_t lds = 0;
+  double* d_T = nullptr;  // [n_modes][n_theta] sLambda_lm(theta_j)
+  int* d_meta = nullptr;
+};
+
 struct bms_ctx {
   int device = 0;
   hipStream_t own_stream = nullptr;
@@ -73,6 +82,7 @@ struct bms_ctx {
   int n_cu = 0;
   // analysis tables depend on the grid, the spin and the l range only: kept per tag until a call asks for other ones
   std::map<std::string, std::pair<std::array<int, 6>, AnalysisPlan>> plans;
+  std::map<std::array<int, 5>, SynthesisPlan> syn_plans;  // by (n_theta, n_phi, spin, ell_min, ell_max)
   // optional per-kernel timing with HIP events on the context's stream (bms_ctx_enable_timing)
   bool timing = false;
   struct Timed {
@@ -1071,6 +1081,58 @@ struct PieceTables {  // per-direction tables shared by the pieces of one pipeli
   PixelTables T;
   DevPixel DP;
 };
+// Tables of the separable synthesis, built once per (grid, spin, l range) and kept in the context.  Returns with P.nt = 0
+// when the shape is not one the kernel takes.
+static int build_synthesis(bms_ctx* c, int n_theta, int n_phi, int spin, int ell_min, int ell_max, SynthesisPlan& P) {
+  const std::array<int, 5> key = {n_theta, n_phi, spin, ell_min, ell_max};
+  auto it = c->syn_plans.find(key);
+  if (it != c->syn_plans.end()) {
+    P = it->second;
+    return BMS_OK;
+  }
+  P = SynthesisPlan();
+  if (!c->n_cu) {
+    hipDeviceProp_t prop;
+    HIP_TRY(c, hipGetDeviceProperties(&prop, c->device));
+    c->n_cu = prop.multiProcessorCount;
+  }
+  std::vector<int> meta;
+  int len = 0;
+  if (!synthesis_split_plan(n_theta, n_phi, ell_min, ell_max, P.g, meta, P.lds, P.nt, len)) {
+    P.nt = 0;
+    return BMS_OK;
+  }
+  hipStream_t S = c->stream;
+  int rc;
+  void* vp;
+  char nm_[96];
+  const int n_modes = LM_total_size(ell_min, ell_max);
+  std::vector<double> rot(4 * (size_t)n_theta), one(n_theta, 1.0);
+  for (int j = 0; j < n_theta; ++j) {
+    const Quat q = from_spherical_coords(M_PI * j / (n_theta - 1), 0.0);
+    rot[4 * j] = q.w, rot[4 * j + 1] = q.x, rot[4 * j + 2] = q.y, rot[4 * j + 3] = q.z;
+  }
+  snprintf(nm_, sizeof nm_, "syn_rot_%d", n_theta);
+  if ((rc = upload(c, nm_, rot.data(), 8 * rot.size(), &vp))) return rc;
+  const double* d_rot = (const double*)vp;
+  snprintf(nm_, sizeof nm_, "syn_one_%d", n_theta);
+  if ((rc = upload(c, nm_, one.data(), 8 * one.size(), &vp))) return rc;
+  const double* d_one = (const double*)vp;
+  snprintf(nm_, sizeof nm_, "syn_meta_%d_%d_%d_%d_%d", n_theta, n_phi, spin, ell_min, ell_max);
+  if ((rc = upload(c, nm_, meta.data(), sizeof(int) * meta.size(), &vp))) return rc;
+  P.d_meta = (int*)vp;
+  double* d_Y;
+  if ((rc = dev_buf_t(c, "syn_Y", (size_t)n_theta * n_modes * 2, &d_Y))) return rc;
+  HIP_TRY(c, hipMemsetAsync(d_Y, 0, 16 * (size_t)n_theta * n_modes, S));
+  TIMED(c, BMS_TAG_SETUP, launch_swsh_values(S, d_rot, n_theta, spin, ell_min, ell_max, d_Y));
+  snprintf(nm_, sizeof nm_, "syn_T_%d_%d_%d_%d", n_theta, spin, ell_min, ell_max);
+  if ((rc = dev_buf_t(c, nm_, (size_t)n_theta * n_modes, &P.d_T))) return rc;
+  TIMED(c, BMS_TAG_SETUP, launch_theta_table(S, d_Y, d_one, n_theta, n_modes, P.d_T));  // weights 1: the plain sLambda values
+  HIP_TRY(c, hipStreamSynchronize(S));  // host vectors above go out of scope
+  c->syn_plans[key] = P;
+  return BMS_OK;
+}
+
 // Column plan of the grids: 0 = one column per grid pixel, in grid order.  When the analysis can read the columns in any
 // order (the fused kernel) the two pole rings are stored once each (1) and, with a boost, whose time skew grows with |u|,
 // the columns are also sorted by the skew rate (2).
@@ -1507,6 +1569,22 @@ static int transform_modes_impl(bms_ctx* c, const bms_wm_input* in, const bms_tr
                                                                   SPLINE_TILE, SPLINE_HALO, 1));
   }
   trace.mark("input staging, time upload, spline factors, elimination on the modes (enqueue)");
+  // Without a boost the grid is the equiangular grid seen through the constant frame rotation: rotate the (eliminated) modes
+  // once and synthesise ring by ring (kernels_synthesis.hip) instead of multiplying with the dense sYlm matrix.  The grid
+  // keeps its natural column order for that.
+  SynthesisPlan syn;
+  const bool no_boost = tr->boost_velocity[0] == 0 && tr->boost_velocity[1] == 0 && tr->boost_velocity[2] == 0;
+  if (bs && no_boost && rows_avail >= 2 && !(sh && sh->col_parts > 1) && tr->n_theta >= 3 && !getenv("SCRI_AMD_NO_SEPARABLE_SYNTHESIS"))
+    if ((rc = build_synthesis(c, tr->n_theta, tr->n_phi, s, in->ell_min, in->ell_max, syn))) return rc;
+  const bool sep = syn.nt != 0;
+  if (sep) {
+    const double* q = tr->frame_rotation;
+    if (!(q[0] == 1.0 && q[1] == 0.0 && q[2] == 0.0 && q[3] == 0.0)) {
+      // sYlm(F G) = sum_m' D_{m m'}(F) sYlm'(G): the modes as seen from the rotated frame (the constant column stays)
+      const double sp[4] = {q[0], q[3], q[2], q[1]};  // (w + i z, y + i x)
+      if ((rc = rotate_impl(c, d_Af, BMS_DEVICE, rows_avail, ld_af / 2, in->ell_min, in->ell_max, sp, false))) return rc;
+    }
+  }
   PixelTables T;
   DevPixel DP;
   PieceTables* shared = c->async_pieces ? static_cast<PieceTables*>(c->piece_tables) : nullptr;
@@ -1515,7 +1593,7 @@ static int transform_modes_impl(bms_ctx* c, const bms_wm_input* in, const bms_tr
     DP = shared->DP;
   } else {
     if ((rc = device_pixel_tables(c, tr, T, psi ? 1 : 0, s, in->conformal_weight, coef0.empty() ? nullptr : &coef0, nullptr, cv, DP,
-                                  grid_out ? 0 : column_plan(tr, n_out), c->aux)))
+                                  (grid_out || sep) ? 0 : column_plan(tr, n_out), c->aux)))
       return rc;
     if (shared) {
       shared->T = T;
@@ -1570,12 +1648,13 @@ static int transform_modes_impl(bms_ctx* c, const bms_wm_input* in, const bms_tr
     const long long rows = round_up(f.K, 16);
     char nm[32];
     snprintf(nm, sizeof nm, "Bsyn%d", fi);
+    if (sep) continue;  // (no dense sYlm matrix)
     if ((rc = dev_buf_t(c, nm, (size_t)rows * ldb, &f.d_B))) return rc;
     HIP_TRY(c, hipMemsetAsync(f.d_B, 0, sizeof(double) * rows * ldb, S));
     TIMED(c, BMS_TAG_SETUP, launch_swsh_matrix_complex(S, d_rot, n_cols, f.spin, f.ell_min, f.ell_max, f.d_B, ldb));
   }
   const int n_modes_in = F[0].K / 2;
-  if (bs)  // row n_modes of B multiplies the eliminated constant series: it carries the per-column offset
+  if (bs && !sep)  // row n_modes of B multiplies the eliminated constant series: it carries the per-column offset
     TIMED(c, BMS_TAG_SETUP, launch_negated_row(S, DP.col_off, F[0].d_B + (size_t)n_modes_in * ldb, 2 * n_cols));
   trace.mark("uploads + synthesis matrices");
   AnalysisPlan ana;
@@ -1640,6 +1719,12 @@ static int transform_modes_impl(bms_ctx* c, const bms_wm_input* in, const bms_tr
     else if ((rc = dev_buf_t(c, "G", (size_t)rows_out * ldG, &d_G)))
       return rc;
     if (bs) {
+      if (sep && rows_in >= 2)  // (k = 1 without a boost: no column scale)
+        TIMED(c, BMS_TAG_GEMM_SYNTHESIS, launch_synthesis_split(S, d_Af + (g0 - row0) * ld_af, ld_af, rows_in, syn.g, syn.nt, syn.d_T, syn.d_meta,
+                                                                coef0.empty() ? nullptr : DP.col_off, d_Y, ldg, syn.lds, c->n_cu));
+      else if (sep)
+        return fail(c, BMS_ERR_UNSUPPORTED, "a chunk of one row");
+      else
       TIMED(c, BMS_TAG_GEMM_SYNTHESIS, launch_zgemm3m(S, d_Af + (g0 - row0) * ld_af, ld_af, F[0].d_B + 2 * cA, ldb, d_Y, ldg, rows_in, n_pix,
                                                       n_modes_in + 1, nullptr, d_scale));
       TIMED(c, BMS_TAG_SPLINE_BACKWARD, launch_bspline_backward_eval(S, d_Y, ldg, n_pix, g0, rows_in, n, d_x, d_bstab, SPLINE_TILE, SPLINE_HALO, d_x, d_skewa,

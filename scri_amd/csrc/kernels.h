@@ -1,5 +1,6 @@
 // Launchers of the gfx950 kernels (C++ internal interface between the engine and the kernels).
 #pragma once
+#include <vector>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -93,6 +94,20 @@ hipError_t launch_dft_cs_matrix(hipStream_t stream, int n_phi, int L, double* D)
 hipError_t launch_analysis_fused(hipStream_t stream, const double* G, long long ldg, long long n_rows, int n_theta, int n_phi,
                                  int L, int n_out, const int* m_index, const double* T, const double* D, double* out,
                                  long long ldo, const int* col_of_pixel, int spin);
+
+// ---- separable synthesis for boost-free transformations (kernels_synthesis.hip)
+struct SynGeom {
+  int n_theta, n_phi, L, n_modes, nk;
+  int nth, nph;      // theta and phi waves
+  int n_lists, len;  // lists of mode entries the theta threads walk, entries per list (8 .. 20)
+};
+int synthesis_split_plan(int n_theta, int n_phi, int ell_min, int ell_max, SynGeom& g, std::vector<int>& meta, size_t& lds_bytes,
+                         int& nt, int& len);
+// A: [n_rows][lda] modes (complex, n_modes + 1 per row: the last one multiplies `off`), Tsyn[n_modes][n_theta] = sLambda_lm(theta_j),
+// off: complex per grid pixel or null; Y[n_rows][ldy] = grid rows in grid order
+hipError_t launch_synthesis_split(hipStream_t stream, const double* A, long long lda, long long n_rows, const SynGeom& g, int nt,
+                                  const double* Tsyn, const int* meta, const double* off, double* Y, long long ldy, size_t lds_bytes,
+                                  int n_cu);
 
 // ---- dense fp64 GEMM on MFMA: C[M x N] = (A[M x K] * B[K x N] - col_off[N]) * col_scale[N]
 // A row-major (lda), B row-major (ldb, zero padded to a multiple of 128 columns and 16 rows), C row-major (ldc).

@@ -115,6 +115,42 @@ def test_fused_analysis_two_role_kernel_shapes(ctx, monkeypatch, n_theta, n_phi,
     assert np.abs(old - ref).max() < 2e-13 * max(1.0, np.abs(ref).max())
 
 
+@pytest.mark.parametrize("ell_max,n,data_type", [(8, 1501, "h"), (8, 700, "psi4"), (16, 901, "h"), (12, 333, "sigma"), (5, 64, "psi4")])
+@pytest.mark.parametrize("rotated", [False, True])
+def test_boost_free_transformations_take_the_separable_synthesis(ctx, monkeypatch, ell_max, n, data_type, rotated):
+    """Without a boost the modes are rotated by the frame rotor and synthesised ring by ring (`synthesis_split_kernel`:
+    theta stage on the VALU, folded phi stage on MFMA) instead of through the dense sYlm matrix; both routes must agree to
+    rounding, with and without a frame rotation and with and without the inhomogeneous term of h / sigma."""
+    import scri_amd
+    from scri_amd import synthetic
+    from oracle import containers
+
+    t = np.linspace(-50.0, 60.0, n)
+    data = synthetic.chirp_modes(t, 2, ell_max, 17 + ell_max)
+    rng = np.random.default_rng(ell_max + n)
+    lst = 3
+    st = synthetic.real_supertranslation(0.3 * (rng.normal(size=(lst + 1) ** 2) + 1j * rng.normal(size=(lst + 1) ** 2)))
+    kw = dict(supertranslation=st)
+    if rotated:
+        kw["frame_rotation"] = np.array([0.3, -0.5, 0.7, 0.41]) / np.linalg.norm([0.3, -0.5, 0.7, 0.41])
+    dt = getattr(containers, data_type)
+
+    def run():
+        w = scri_amd.WaveformModes(t=t, data=data, ell_min=2, ell_max=ell_max, dataType=dt, frameType=scri_amd.Inertial,
+                                   r_is_scaled_out=True, m_is_scaled_out=True, ctx=ctx)
+        return w.transform(**kw)
+
+    ctx.enable_timing(True)
+    ctx.get_timing(reset=True)
+    got = run()
+    assert rotated == ("rotate" in {k for k, v in ctx.get_timing(reset=True).items() if v[1]})  # the route was the separable one
+    monkeypatch.setenv("SCRI_AMD_NO_SEPARABLE_SYNTHESIS", "1")
+    ref = run()
+    ctx.enable_timing(False)
+    assert got.n_times == ref.n_times and np.array_equal(got.t, ref.t)
+    assert np.abs(got.data - ref.data).max() < 2e-13 * max(1.0, np.abs(ref.data).max())
+
+
 def test_large_boost_wide_skew_and_chunks(ctx):
     import scri_amd
 
