@@ -1023,8 +1023,8 @@ static void time_window(int64_t n, const bms_shard* sh, int64_t& lo, int64_t& hi
 static int spline_tile_for(const double* x, int64_t n);
 
 static int validate_common(bms_ctx* c, int64_t n, const double* t, const bms_transformation* tr, int64_t lo = 0, int64_t hi = -1,
-                           bool* regular = nullptr) {
-  if (n < 4) return fail(c, BMS_ERR_INVALID, "need at least 4 time steps for the cubic spline, got %lld", (long long)n);
+                           bool* regular = nullptr, int64_t n_min = 4) {
+  if (n < n_min) return fail(c, BMS_ERR_INVALID, "need at least %lld time steps, got %lld", (long long)n_min, (long long)n);
   if (hi < 0) hi = n;
   if (!(t[n - 1] > t[0])) return fail(c, BMS_ERR_INVALID, "time array must be strictly increasing (first/last)");
   double bmin[3] = {INFINITY, INFINITY, INFINITY}, bmax[3] = {0.0, 0.0, 0.0};  // step range of the last three 16-step blocks
@@ -1289,7 +1289,7 @@ extern "C" int bms_output_window(bms_ctx* c, const double* t, int64_t n, const b
   if (!c) return BMS_ERR_INVALID;
   if (!t || !tr || !window) return fail(c, BMS_ERR_INVALID, "NULL argument");
   HIP_TRY(c, hipSetDevice(c->device));
-  int rc = validate_common(c, n, t, tr, 0, 0);
+  int rc = validate_common(c, n, t, tr, 0, 0, nullptr, abd ? 2 : 4);
   if (rc) return rc;
   PixelTables T;
   DevPixel DP;
@@ -2343,8 +2343,12 @@ extern "C" int bms_transform_abd_shard(bms_ctx* c, const double* u, const void* 
   int64_t t_lo, t_hi;
   time_window(n, sh, t_lo, t_hi);
   bool regular_mesh = true;
-  int rc = validate_common(c, n, u, tr, t_lo, t_hi, &regular_mesh);
+  // (scipy's CubicSpline, the interpolant of this flavour, takes 2 and 3 samples too: line and parabola)
+  int rc = validate_common(c, n, u, tr, t_lo, t_hi, &regular_mesh, 2);
   if (rc) return rc;
+  const bool short_series = n < 4;
+  if (short_series && sh && !(sh->data_row0 == 0 && sh->data_rows == n && sh->col_parts <= 1))
+    return fail(c, BMS_ERR_UNSUPPORTED, "a series of %lld samples cannot be sharded", (long long)n);
   if (!regular_mesh && sh && !(sh->data_row0 == 0 && sh->data_rows == n && sh->col_parts <= 1))
     return fail(c, BMS_ERR_UNSUPPORTED,
                 "the time steps vary by more than 1e3 within 48 samples: such a series is transformed with exact untiled spline "
@@ -2407,7 +2411,11 @@ extern "C" int bms_transform_abd_shard(bms_ctx* c, const double* u, const void* 
   SplineTable* d_tab = nullptr;
   BsplineTable* d_bstab = nullptr;
   BsplineForward* d_bsfwd = nullptr;
-  if (bsg)
+  if (short_series) {
+    void* vp;
+    if ((rc = upload(c, "times", u, 8 * (size_t)n, &vp))) return rc;
+    d_x = (double*)vp;
+  } else if (bsg)
     rc = upload_times_bspline(c, u, n, t_lo, t_hi, row0, row0 + rows_avail, &d_x, &d_bstab, &d_bsfwd);
   else
     rc = upload_times(c, u, n, t_lo, t_hi, row0, row0 + rows_avail, &d_x, &d_tab);
@@ -2497,7 +2505,9 @@ extern "C" int bms_transform_abd_shard(bms_ctx* c, const double* u, const void* 
     for (int f = 0; f < 6; ++f) {
       double* Rf = d_R + (size_t)f * rows_in * ldg;
       double* Gf = d_G + (size_t)f * rows_out * ldG;
-      if (bsg) {
+      if (short_series) {
+        TIMED(c, BMS_TAG_SPLINE_BACKWARD, launch_short_series_eval(S, grids.y[f], ldg, n_pix, (int)n, d_x, d_x, d_skewa, d_skewb, T.tt, c0, c1_, Gf, ldG));
+      } else if (bsg) {
         TIMED(c, BMS_TAG_SPLINE_BACKWARD, launch_bspline_backward_eval(S, Rf, ldg, n_pix, g0, rows_in, n, d_x, d_bstab, SPLINE_TILE, SPLINE_HALO,
                                                                        d_x, d_skewa, d_skewb, T.tt, c0, c1_, Gf, ldG));
       } else {

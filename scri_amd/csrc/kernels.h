@@ -95,6 +95,11 @@ hipError_t launch_analysis_fused(hipStream_t stream, const double* G, long long 
                                  int L, int n_out, const int* m_index, const double* T, const double* D, double* out,
                                  long long ldo, const int* col_of_pixel, int spin);
 
+// series of 2 or 3 samples (ABD flavour): line / parabola through the samples, rows 0..n-1 of Y
+hipError_t launch_short_series_eval(hipStream_t stream, const double* Y, long long ld, int n_cols, int n, const double* x,
+                                    const double* base, const double* skew_a, const double* skew_b, double tt, long long i_lo,
+                                    long long i_hi, double* out, long long ldo);
+
 // ---- separable synthesis for boost-free transformations (kernels_synthesis.hip)
 struct SynGeom {
   int n_theta, n_phi, L, n_modes, nk;

@@ -372,4 +372,45 @@ hipError_t launch_spline_backward_eval(hipStream_t stream, const double* Y, cons
   return hipGetLastError();
 }
 
+// ------------------------------------------------------------------------------------------------ 2 or 3 samples
+// scipy's CubicSpline (the ABD flavour's interpolant, scri/asymptotic_bondi_data/transformations.py:398-411) degenerates
+// to the straight line through 2 samples and to the parabola through 3 (not-a-knot with no interior knot to spare): the
+// Lagrange form, one thread per (output sample, column).
+__global__ __launch_bounds__(256) void short_series_eval_kernel(const double* __restrict__ Y, long long ld, int n_cols, int n,
+                                                                const double* __restrict__ x, const double* __restrict__ base,
+                                                                const double* __restrict__ skew_a, const double* __restrict__ skew_b,
+                                                                double tt, long long i_lo, long long i_hi, double* __restrict__ out,
+                                                                long long ldo) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  const long long i = i_lo + blockIdx.y;
+  if (p >= n_cols || i >= i_hi) return;
+  const double xi = base[i];
+  const double u = xi + ((skew_a ? skew_a[p] : 0.0) * (xi - tt) + (skew_b ? skew_b[p] : 0.0));
+  const double2 y0 = *reinterpret_cast<const double2*>(Y + 2LL * p), y1 = *reinterpret_cast<const double2*>(Y + ld + 2LL * p);
+  double2 v;
+  if (n == 2) {
+    const double w = (u - x[0]) / (x[1] - x[0]);
+    v.x = y0.x + w * (y1.x - y0.x);
+    v.y = y0.y + w * (y1.y - y0.y);
+  } else {
+    const double2 y2 = *reinterpret_cast<const double2*>(Y + 2 * ld + 2LL * p);
+    const double l0 = (u - x[1]) * (u - x[2]) / ((x[0] - x[1]) * (x[0] - x[2]));
+    const double l1 = (u - x[0]) * (u - x[2]) / ((x[1] - x[0]) * (x[1] - x[2]));
+    const double l2 = (u - x[0]) * (u - x[1]) / ((x[2] - x[0]) * (x[2] - x[1]));
+    v.x = l0 * y0.x + l1 * y1.x + l2 * y2.x;
+    v.y = l0 * y0.y + l1 * y1.y + l2 * y2.y;
+  }
+  *reinterpret_cast<double2*>(out + (i - i_lo) * ldo + 2LL * p) = v;
+}
+
+hipError_t launch_short_series_eval(hipStream_t stream, const double* Y, long long ld, int n_cols, int n, const double* x,
+                                    const double* base, const double* skew_a, const double* skew_b, double tt, long long i_lo,
+                                    long long i_hi, double* out, long long ldo) {
+  if (n < 2 || n > 3) return hipErrorInvalidValue;
+  if (n_cols <= 0 || i_hi <= i_lo) return hipSuccess;
+  hipLaunchKernelGGL(short_series_eval_kernel, dim3((n_cols + 255) / 256, (unsigned)(i_hi - i_lo)), dim3(256), 0, stream, Y, ld, n_cols, n, x,
+                     base, skew_a, skew_b, tt, i_lo, i_hi, out, ldo);
+  return hipGetLastError();
+}
+
 }  // namespace bms
