@@ -187,6 +187,48 @@ def rotation_line(local, ell_max, ctx, cpu_steps):
     return out
 
 
+def boost_free_line(local, t_global, kw, n_theta, ell_max, ctx):
+    """Secondary measurement: the same resident series through a transformation WITHOUT a boost (the workload's
+    supertranslation and frame rotation): the modes are rotated once and synthesised ring by ring (synthesis_split_kernel)
+    instead of through the dense sYlm product.  HIP-event time of the synthesis kernel against the HBM roofline
+    (read the modes once, write the grid once: 16 (n_modes + 1 + n_pix) B per step)."""
+    import torch
+
+    from scri_amd import engine
+
+    n, nm = local.shape
+    tr = engine.make_transformation(kw["supertranslation"], kw.get("frame_rotation", [1, 0, 0, 0]), [0, 0, 0], n_theta, n_theta, ell_max)
+    out = torch.empty_like(local)
+
+    def go():
+        return engine.transform_modes(t_global, local.data_ptr(), 2, ell_max, -2, -1, engine.BMS_TERM_H, tr, ctx=ctx, device=True,
+                                      ld=nm, out_ptr=out.data_ptr())[1]
+
+    for _ in range(3):
+        go()
+    ctx.synchronize()
+    ctx.get_timing(reset=True)
+    reps = 10
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        n_new = go()
+    ctx.synchronize()
+    wall = (time.perf_counter() - t0) / reps
+    tm = ctx.get_timing(reset=True)
+    ms = tm["gemm_synthesis"][0] / max(tm["gemm_synthesis"][1], 1)
+    bytes_per_step = 16 * (nm + 1 + n_theta * n_theta)
+    return {
+        "metric": "timesteps/s, transformation without a boost (supertranslation + frame rotation), separable synthesis",
+        "value": n / wall,
+        "ms_per_step": wall * 1e3,
+        "n_out": int(n_new),
+        "kernels": {k: v[0] / reps for k, v in tm.items() if v[1]},
+        "synthesis_roofline": {"bound": "hbm", "kernel": "synthesis_split_kernel", "achieved": n * bytes_per_step / (ms * 1e-3) / 1e9,
+                               "peak": 8000.0, "unit": "GB/s", "frac": n * bytes_per_step / (ms * 1e-3) / 8e12,
+                               "bytes_per_step": bytes_per_step, "ms_per_launch": ms},
+    }
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -523,6 +565,7 @@ def main():
             line["cpu_baseline_all_cores"] = cpu_baseline_all_cores(spec, args.cpu_sample)
         if world == 1 and not abd:
             line["rotation"] = rotation_line(local, ell_max, ctx, 3000 if args.cpu_sample > 0 else 0)
+            line["boost_free"] = boost_free_line(local, t_global, kw, n_theta, ell_max, ctx)
         print(json.dumps(line))
     if world > 1:
         dist.barrier()
