@@ -1077,9 +1077,13 @@ struct DevPixel {
   const int* col_of_pixel = nullptr;  // set when the grid is stored as a column plan (kernels_swsh.hip, pixel_sort_kernel)
 };
 
-struct PieceTables {  // per-direction tables shared by the pieces of one pipelined call
+struct PieceTables {  // tables shared by the pieces of one pipelined call: per direction, and per knot of the WHOLE series
   PixelTables T;
   DevPixel DP;
+  bool times_valid = false;
+  double* d_x = nullptr;
+  BsplineTable* d_bstab = nullptr;
+  BsplineForward* d_bsfwd = nullptr;
 };
 // Tables of the separable synthesis, built once per (grid, spin, l range) and kept in the context.  Returns with P.nt = 0
 // when the shape is not one the kernel takes.
@@ -1413,7 +1417,13 @@ extern "C" int bms_transform_modes_pipelined(bms_ctx* c, const bms_wm_input* in,
     return fail(c, BMS_ERR_HIP, "pipelined upload: %s", hipGetErrorString(he));
   }
   for (int k = 0; k < pieces && rc == BMS_OK; ++k) {
-    if (k + 1 < pieces && (he = upload_piece(k + 1)) != hipSuccess) break;  // travels while piece k is transformed
+    // piece k + 1 travels while piece k is transformed; its buffer was read by the kernels of piece k - 1.  (Piece 0 reads
+    // its per-direction tables back with a blocking copy, which waits for every upload under way: piece 1 is sent after it.)
+    auto send_next = [&]() -> hipError_t {
+      if (k + 1 >= pieces) return hipSuccess;
+      return upload_piece(k + 1);
+    };
+    if (k > 0 && (he = send_next()) != hipSuccess) break;
     if ((he = hipStreamWaitEvent(c->stream, ev_up[k], 0)) != hipSuccess) break;
     if (k >= 2 && (he = hipStreamWaitEvent(c->stream, ev_dn[k - 2], 0)) != hipSuccess) break;  // its output buffer has left
     bms_wm_input piece = *in;
@@ -1424,16 +1434,18 @@ extern "C" int bms_transform_modes_pipelined(bms_ctx* c, const bms_wm_input* in,
     int64_t got = 0, first = 0;
     rc = transform_modes_impl(c, &piece, tr, &sh, t_out + (cut[k] - i_lo), d_out[k & 1], &got, &first, nullptr);
     if (rc) break;
+    if (k == 0 && (he = send_next()) != hipSuccess) break;
     if (got != cut[k + 1] - cut[k] || first != cut[k]) {
       rc = fail(c, BMS_ERR_HIP, "pipelined shard [%lld, %lld) produced %lld rows from %lld", (long long)cut[k], (long long)cut[k + 1],
                 (long long)got, (long long)first);
       break;
     }
     if ((he = hipEventRecord(ev_c[k], c->stream)) != hipSuccess) break;
-    // The host waits for the piece's kernels and then issues the download (it has nothing else to do here: the next upload
-    // is already on its way).  In the rocprofv3 trace of this loop the uploads run on a DMA engine beside the kernels; the
-    // downloads are executed by the runtime as shader copies (__amd_rocclr_copyBuffer) that take turns with the compute
-    // kernels -- with or without a cross-stream event in front of them -- which is what keeps a piece at 2.8 ms instead of 1.4.
+    // The host waits for the piece's kernels and then issues the download (the next upload is already on its way).  In the
+    // rocprofv3 trace of this loop the uploads run on a DMA engine beside the kernels; the downloads are executed by the runtime
+    // as shader copies (__amd_rocclr_copyBuffer) that take turns with the compute kernels.  Storing the results straight into the
+    // page-locked array from the analysis kernel (on a side stream, with a small grid) was tried: the stores leave at 42 GB/s
+    // instead of 57 and every memory-bound kernel running beside them crawls -- 19.8 ms against 15.7 ms per cfg3 transform.
     if ((he = hipEventSynchronize(ev_c[k])) != hipSuccess) break;
     if ((he = hipMemcpyAsync(host_out + (size_t)(cut[k] - i_lo) * n_out * 16, d_out[k & 1], (size_t)got * n_out * 16,
                              hipMemcpyDeviceToHost, c->pipe_down)) != hipSuccess)
@@ -1556,7 +1568,16 @@ static int transform_modes_impl(bms_ctx* c, const bms_wm_input* in, const bms_tr
   SplineTable* d_tab = nullptr;
   BsplineTable* d_bstab = nullptr;
   BsplineForward* d_bsfwd = nullptr;
-  if (bsg)
+  // (pieces of a pipelined call: the knot tables depend on the time axis only and are built once, for the whole series --
+  // per piece they cost a blocking upload from pageable memory and two kernels that crawl while results leave over PCIe)
+  PieceTables* shared = c->async_pieces ? static_cast<PieceTables*>(c->piece_tables) : nullptr;
+  if (bsg && shared && shared->times_valid) {
+    d_x = shared->d_x, d_bstab = shared->d_bstab, d_bsfwd = shared->d_bsfwd;
+  } else if (bsg && shared) {
+    rc = upload_times_bspline(c, in->t, n, 0, n, 0, n, &d_x, &d_bstab, &d_bsfwd);
+    shared->d_x = d_x, shared->d_bstab = d_bstab, shared->d_bsfwd = d_bsfwd;
+    shared->times_valid = rc == BMS_OK;
+  } else if (bsg)
     rc = upload_times_bspline(c, in->t, n, t_lo, t_hi, row0, row0 + rows_avail, &d_x, &d_bstab, &d_bsfwd);
   else
     rc = upload_times(c, in->t, n, t_lo, t_hi, row0, row0 + rows_avail, &d_x, &d_tab);
@@ -1587,7 +1608,6 @@ static int transform_modes_impl(bms_ctx* c, const bms_wm_input* in, const bms_tr
   }
   PixelTables T;
   DevPixel DP;
-  PieceTables* shared = c->async_pieces ? static_cast<PieceTables*>(c->piece_tables) : nullptr;
   if (shared && c->piece_tables_valid) {
     T = shared->T;
     DP = shared->DP;

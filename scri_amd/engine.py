@@ -131,7 +131,7 @@ def make_transformation(supertranslation, frame_rotation, boost_velocity, n_thet
 
 # Host arrays in and out: below this size one call moves the data and computes; above it the time axis is pipelined
 PIPELINE_MIN_BYTES = 64 << 20
-PIPELINE_PIECES = int(os.environ.get("SCRI_AMD_PIPELINE_PIECES", "6"))  # one box: 26.9 ms as one call, 22.5-24.8 at 4 pieces, 21.5 at 6, 25 at 8 (cfg3)
+PIPELINE_PIECES = int(os.environ.get("SCRI_AMD_PIPELINE_PIECES", "10"))  # cfg3, round 2: 15.5 ms at 4 pieces, 15.0 at 6, 13.9 at 8, 13.6 at 10 (26.9 as one call)
 
 
 def _transform_modes_pipelined(t, data, inp, transformation, n_out, ctx):
