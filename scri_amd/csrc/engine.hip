@@ -1085,6 +1085,26 @@ struct PieceTables {  // tables shared by the pieces of one pipelined call: per 
   BsplineTable* d_bstab = nullptr;
   BsplineForward* d_bsfwd = nullptr;
 };
+// How far apart the lanes of a back-substitution wave can stand: ranges of the skew rate and offset within any block of 64
+// columns [cA + 64 b, ...) of the launch (host copies of the per-column tables).
+static BsplineSpread skew_spread(const PixelTables& T, int cA, int cB, const double* x_host) {
+  BsplineSpread sp = {0.0, 0.0, x_host};
+  if ((int)T.skew_a.size() < cB || (int)T.skew_b.size() < cB) {
+    sp.x = nullptr;  // (no host copy: the kernel gathers)
+    return sp;
+  }
+  for (int c0 = cA; c0 < cB; c0 += 64) {
+    double a0 = T.skew_a[c0], a1 = a0, b0 = T.skew_b[c0], b1 = b0;
+    for (int p = c0; p < std::min(cB, c0 + 64); ++p) {
+      a0 = std::min(a0, T.skew_a[p]), a1 = std::max(a1, T.skew_a[p]);
+      b0 = std::min(b0, T.skew_b[p]), b1 = std::max(b1, T.skew_b[p]);
+    }
+    sp.skew_rate_range = std::max(sp.skew_rate_range, a1 - a0);
+    sp.skew_offset_range = std::max(sp.skew_offset_range, b1 - b0);
+  }
+  return sp;
+}
+
 // Tables of the separable synthesis, built once per (grid, spin, l range) and kept in the context.  Returns with P.nt = 0
 // when the shape is not one the kernel takes.
 static int build_synthesis(bms_ctx* c, int n_theta, int n_phi, int spin, int ell_min, int ell_max, SynthesisPlan& P) {
@@ -1705,6 +1725,7 @@ static int transform_modes_impl(bms_ctx* c, const bms_wm_input* in, const bms_tr
   }
 
   // ---------------------------------------------------------------- chunk loop over output samples
+  const BsplineSpread spread = skew_spread(T, cA, cB, in->t);
   const int margin = SPLINE_HALO + 2;
   // bytes per output row ~ (Y + R + G [+ Yaux]) * ldg * 8
   const double bytes_per_row = (4.0 + (psi ? 1.0 : 0.0)) * ldg * 8.0;  // Y, R, G, F (+ Yaux)
@@ -1748,7 +1769,7 @@ static int transform_modes_impl(bms_ctx* c, const bms_wm_input* in, const bms_tr
       TIMED(c, BMS_TAG_GEMM_SYNTHESIS, launch_zgemm3m(S, d_Af + (g0 - row0) * ld_af, ld_af, F[0].d_B + 2 * cA, ldb, d_Y, ldg, rows_in, n_pix,
                                                       n_modes_in + 1, nullptr, d_scale));
       TIMED(c, BMS_TAG_SPLINE_BACKWARD, launch_bspline_backward_eval(S, d_Y, ldg, n_pix, g0, rows_in, n, d_x, d_bstab, SPLINE_TILE, SPLINE_HALO, d_x, d_skewa,
-                                                                     d_skewb, T.tt, c0, c1, d_G, ldG));
+                                                                     d_skewb, T.tt, c0, c1, d_G, ldG, &spread));
     } else {
     if (psi)
       if ((rc = dev_buf_t(c, "Yaux", (size_t)rows_in * ldg, &d_Yaux))) return rc;
@@ -1769,7 +1790,7 @@ static int transform_modes_impl(bms_ctx* c, const bms_wm_input* in, const bms_tr
     if (bsg) {  // mixing is time dependent: eliminate on the grid, then the coefficient-only back substitution
       TIMED(c, BMS_TAG_SPLINE_FORWARD, launch_bspline_forward_modes(S, d_Y, ldg, n_pix, d_R, ldg, g0, rows_in, n, d_bsfwd, SPLINE_TILE, SPLINE_HALO, 0));
       TIMED(c, BMS_TAG_SPLINE_BACKWARD, launch_bspline_backward_eval(S, d_R, ldg, n_pix, g0, rows_in, n, d_x, d_bstab, SPLINE_TILE, SPLINE_HALO, d_x, d_skewa,
-                                                                     d_skewb, T.tt, c0, c1, d_G, ldG));
+                                                                     d_skewb, T.tt, c0, c1, d_G, ldG, &spread));
     } else {
     TIMED(c, BMS_TAG_SPLINE_FORWARD, launch_spline_forward(S, d_Y, d_R, ldg, n_pix, g0, rows_in, n, d_x, d_tab, spline_tile, SPLINE_HALO));
     TIMED(c, BMS_TAG_SPLINE_BACKWARD, launch_spline_backward_eval(S, d_Y, d_R, ldg, n_pix, g0, rows_in, n, d_x, d_tab, spline_tile, SPLINE_HALO,
@@ -2481,6 +2502,7 @@ extern "C" int bms_transform_abd_shard(bms_ctx* c, const double* u, const void* 
   }
 
   // ---- chunk loop: 6 fields x (Y, R, G)
+  const BsplineSpread spread = skew_spread(T, cA, cB, u);
   const int margin = SPLINE_HALO + 2;
   const double bytes_per_row = 19.0 * ldg * 8.0;  // 6 x (Y, R, G) + F
   int64_t chunk = (int64_t)((double)c->ws_limit / bytes_per_row - 4.0 * margin);
@@ -2529,7 +2551,7 @@ extern "C" int bms_transform_abd_shard(bms_ctx* c, const double* u, const void* 
         TIMED(c, BMS_TAG_SPLINE_BACKWARD, launch_short_series_eval(S, grids.y[f], ldg, n_pix, (int)n, d_x, d_x, d_skewa, d_skewb, T.tt, c0, c1_, Gf, ldG));
       } else if (bsg) {
         TIMED(c, BMS_TAG_SPLINE_BACKWARD, launch_bspline_backward_eval(S, Rf, ldg, n_pix, g0, rows_in, n, d_x, d_bstab, SPLINE_TILE, SPLINE_HALO,
-                                                                       d_x, d_skewa, d_skewb, T.tt, c0, c1_, Gf, ldG));
+                                                                       d_x, d_skewa, d_skewb, T.tt, c0, c1_, Gf, ldG, &spread));
       } else {
         TIMED(c, BMS_TAG_SPLINE_FORWARD,
               launch_spline_forward(S, grids.y[f], Rf, ldg, n_pix, g0, rows_in, n, d_x, d_tab, spline_tile, SPLINE_HALO));

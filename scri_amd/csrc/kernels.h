@@ -173,10 +173,16 @@ hipError_t launch_abd_mix_forward(hipStream_t stream, const AbdGrids& Y, const A
 // B[row][0 .. 2 n_cols) = -off[0 .. 2 n_cols): the synthesis-matrix row that multiplies the constant column
 hipError_t launch_negated_row(hipStream_t stream, const double* off, double* row, int n);
 // back substitution + evaluation (arguments as launch_spline_backward_eval, C = eliminated grid coefficients)
+// how far apart the lanes of a wave can stand (host side, optional): ranges of skew_a / skew_b within any block of 64 columns of the
+// launch, and the time axis indexed by global knot number
+struct BsplineSpread {
+  double skew_rate_range, skew_offset_range;
+  const double* x;
+};
 hipError_t launch_bspline_backward_eval(hipStream_t stream, const double* C, long long ld, int n_cols, long long g0,
                                         long long n_rows, long long n_knots, const double* x, const BsplineTable* table,
                                         int tile, int halo, const double* base, const double* skew_a, const double* skew_b,
-                                        double tt, long long i_lo, long long i_hi, double* out, long long ldo);
+                                        double tt, long long i_lo, long long i_hi, double* out, long long ldo, const BsplineSpread* spread = nullptr);
 
 // ---- time-series calculus and grid products (kernels_series.hip; scri/modes_time_series.py:72-202)
 // spline slopes s_j at all knots from the forward-pass result R (S != R)

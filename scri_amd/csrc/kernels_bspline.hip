@@ -21,6 +21,9 @@
 // is stable, and the factors decay like 0.268^n on average for any mesh (same tiling + halo as the slope form).
 #include <cstdlib>
 #include "wigner.h"
+#include <algorithm>
+#include <cmath>
+
 #include "kernels.h"
 
 namespace bms {
@@ -365,12 +368,12 @@ __device__ __forceinline__ int bs_wave_max_i32(int v) {
   return __builtin_amdgcn_readlane(v, 63);
 }
 
-template <int RING, int GS, int DEFER, int SLOTS, bool NT_IO>
+template <int RING, int GS, int DEFER, int SLOTS, bool NT_IO, bool USEWIN>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void bspline_backward_eval_kernel(
     const double* __restrict__ C, long long ld, int n_cols, long long g0, long long n_rows, long long n,
     const double* __restrict__ x, const BsplineTable* __restrict__ table, int tile, int halo, const double* __restrict__ base,
     const double* __restrict__ skew_a, const double* __restrict__ skew_b, double tt, long long i_lo, long long i_hi,
-    double* __restrict__ out, long long ldo) {
+    double* __restrict__ out, long long ldo, int tile_first) {
   constexpr int TN = (GS + 2) * BS_WORDS;  // staged words per group: entries k+2 .. k-GS+1
   constexpr int TU = (TN + 63) / 64;
   __shared__ double2 ring[RING][64];
@@ -380,7 +383,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
   bool alive = p < n_cols;
   if (!alive) p = n_cols - 1;
   const long long jend = g0 + n_rows;
-  const long long jA = g0 + (long long)blockIdx.y * tile;
+  const long long jA = g0 + (long long)(blockIdx.y + tile_first) * tile;
   long long jB = jA + tile;
   if (jB > jend) jB = jend;
   const long long jI = jB < n - 1 ? jB : n - 1;  // intervals handled: [jA, jI)
@@ -507,7 +510,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
       xi_cur = xi_nxt;
       if (i > 0) {
         const int rel = (i - 1) - w_lo;  // position in the staged window
-        if (rel >= 0 && rel < WIN) {
+        if constexpr (!USEWIN) {
+          // Tiles in which the lanes of a wave stand too far apart for the window (their columns' time skew differs, and the
+          // difference grows with |u|: hundreds of rows across the grid at the end of a 1e6-step series) gather base[i - 1] one
+          // sample ahead, as round 1 did; the launcher decides tile by tile.
+          xi_nxt = bp[i - 1];
+        } else if (rel >= 0 && rel < WIN) {
           xi_nxt = wv[rel];
         } else {  // (output much denser than the knots, or columns of very different skew in one wave)
           double far = bp[i - 1];
@@ -597,7 +605,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void
 hipError_t launch_bspline_backward_eval(hipStream_t stream, const double* C, long long ld, int n_cols, long long g0,
                                         long long n_rows, long long n_knots, const double* x, const BsplineTable* table,
                                         int tile, int halo, const double* base, const double* skew_a, const double* skew_b,
-                                        double tt, long long i_lo, long long i_hi, double* out, long long ldo) {
+                                        double tt, long long i_lo, long long i_hi, double* out, long long ldo, const BsplineSpread* spread) {
   static const int tile_env = getenv("SCRI_AMD_SPLINE_TILE_BWD") ? atoi(getenv("SCRI_AMD_SPLINE_TILE_BWD")) : 0;
   if (n_rows <= 0 || n_cols <= 0 || i_hi <= i_lo) return hipSuccess;
   if (tile_env > 0) {
@@ -620,20 +628,38 @@ hipError_t launch_bspline_backward_eval(hipStream_t stream, const double* C, lon
     }
   }
   const long long n_tiles = (n_rows + tile - 1) / tile;
-  dim3 grid((n_cols + 63) / 64, (unsigned)n_tiles);
   static const int xp = getenv("SCRI_AMD_BS_XP") ? atoi(getenv("SCRI_AMD_BS_XP")) : 0;
-#define BS_GO(R, G_, X_, S_, N_)                                                                                                      \
-  hipLaunchKernelGGL((bspline_backward_eval_kernel<R, G_, X_, S_, N_>), grid, dim3(64), 0, stream, C, ld, n_cols, g0, n_rows, n_knots, x, table, \
-                     tile, halo, base, skew_a, skew_b, tt, i_lo, i_hi, out, ldo)
-  switch (xp) {  // (ring rows, knots per group, deferred stores): measured 1.21 / 1.12 / 1.06 ms at cfg3 for the first three
-    case 1: BS_GO(8, 3, 0, 2, false); break;
-    case 3: BS_GO(16, 3, 1, 2, false); break;
-    case 4: BS_GO(8, 3, 1, 2, false); break;
-    case 5: BS_GO(8, 3, 1, 4, false); break;
-    case 6: BS_GO(8, 2, 1, 4, false); break;
-    case 7: BS_GO(8, 2, 1, 3, false); break;
-    case 8: BS_GO(8, 3, 1, 2, false); break;
-    default: BS_GO(8, 3, 1, 2, true);  // non-temporal rows: 0.96 -> 0.91 ms at cfg3
+  // Tile by tile: may the march read the output abscissae from the window staged with the table words?  Only while the lanes
+  // of a wave stay within a few samples of each other, i.e. while (range of the skew rate within 64 columns) x |x - tt| + (range
+  // of the skew offset) is a few time steps; elsewhere (and when the caller gives no bound) the lanes gather them.
+  auto fits = [&](long long y) {
+    if (!spread || !spread->x || xp == 8) return false;
+    const long long jA = g0 + y * tile, jB = std::min(g0 + n_rows, jA + tile);
+    if (jB - jA < 2) return false;
+    const double xm = std::max(std::fabs(spread->x[jA] - tt), std::fabs(spread->x[jB - 1] - tt));
+    const double dx = (spread->x[jB - 1] - spread->x[jA]) / (double)(jB - 1 - jA);
+    return dx > 0 && (spread->skew_rate_range * xm + spread->skew_offset_range) <= 10.0 * dx;
+  };
+#define BS_GO(R, G_, X_, S_, N_, W_)                                                                                                  \
+  hipLaunchKernelGGL((bspline_backward_eval_kernel<R, G_, X_, S_, N_, W_>), grid, dim3(64), 0, stream, C, ld, n_cols, g0, n_rows, n_knots, x, table, \
+                     tile, halo, base, skew_a, skew_b, tt, i_lo, i_hi, out, ldo, (int)y0)
+  for (long long y0 = 0; y0 < n_tiles;) {
+    const bool w = fits(y0);
+    long long y1 = y0 + 1;
+    while (y1 < n_tiles && fits(y1) == w) ++y1;
+    dim3 grid((n_cols + 63) / 64, (unsigned)(y1 - y0));
+    if (xp == 1) {  // (ring rows, knots per group, deferred stores, register sets, non-temporal rows, abscissa window)
+      BS_GO(8, 3, 0, 2, false, false);
+    } else if (xp == 3) {
+      BS_GO(16, 3, 1, 2, false, false);
+    } else if (xp == 4) {
+      BS_GO(8, 3, 1, 2, false, false);
+    } else if (w) {
+      BS_GO(8, 3, 1, 2, true, true);
+    } else {  // (lanes spread over many samples write their rows in pieces: non-temporal stores of pieces cost 12.7 -> 20 ms at cfg4)
+      BS_GO(8, 3, 1, 2, false, false);
+    }
+    y0 = y1;
   }
 #undef BS_GO
   return hipGetLastError();
