@@ -1,5 +1,5 @@
 """DIAGNOSIS: time of the fused analysis at cfg3's shape with phases of the kernel switched off (results are wrong then;
-only the time matters).  SCRI_AMD_FUSED_KNOCK bits: 1 MFMA step, 2 quadrature, 4 fold's LDS writes, 8 global fetch."""
+only the time matters).  (the switches this probe drove were removed from the kernel after the diagnosis; it now times the kernel as it is)"""
 import os, sys
 import numpy as np
 from scri_amd import _lib, engine
