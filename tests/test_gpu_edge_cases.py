@@ -84,6 +84,16 @@ def test_large_grid_analysis_variants(ctx, monkeypatch, n_theta, n_phi, spin, el
     assert np.abs(old - ref).max() < 2e-13 * max(1.0, np.abs(ref).max())
 
 
+@pytest.mark.parametrize("n_theta,n_phi", [(20, 24), (31, 38), (19, 18), (39, 39), (17, 34)])
+def test_separable_synthesis_on_user_grids(ctx, n_theta, n_phi):
+    """Boost-free transformations on caller-chosen grids, even n_phi included (a Nyquist column that is its own mirror image,
+    side columns k = 17..19 of the 4x4x4 product) against the oracle."""
+    t = np.linspace(-5, 25, 180)
+    _check(_wm(t, 6, 13), ctx, n_theta=n_theta, n_phi=n_phi, supertranslation=np.array([0.3, 0.1 - 0.2j, 0.15, -0.1 - 0.2j]),
+           frame_rotation=np.array([0.8, -0.3, 0.4, 0.2]))
+    _check(_wm(t, 8, 14, dataType=psi4), ctx, n_theta=n_theta, n_phi=n_phi, time_translation=0.7)
+
+
 @pytest.mark.parametrize(
     "n_theta,n_phi,spin,ell_max,ell_min,n_rows",
     [
