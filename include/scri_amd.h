@@ -162,6 +162,13 @@ int bms_shard_plan(bms_ctx* ctx, const double* t, int64_t n_times, const bms_tra
  * (bms_host_alloc for the result, bms_host_register for a caller's input).  Same results as the sharded path. */
 int bms_transform_modes_pipelined(bms_ctx* ctx, const bms_wm_input* in, const bms_transformation* tr, int pieces, double* t_out,
                                   void* data_out, int64_t* n_times_out);
+
+/* The same pipeline for AsymptoticBondiData.transform (scri/asymptotic_bondi_data/transformations.py:205-423): host arrays in and
+ * out, raw = c16[6][n_times][(ell_max+1)^2], raw_out = c16[6][n_times_out][(ell_max_out+1)^2] (best page-locked: bms_host_alloc /
+ * bms_host_register); the rows of the six fields of one time shard travel up while the previous shard is transformed and the one
+ * before it travels down.  u_out must hold n_times doubles.  Results equal bms_transform_abd's to rounding. */
+int bms_transform_abd_pipelined(bms_ctx* ctx, const double* u, const void* raw, int64_t n_times, int ell_max,
+                                const bms_transformation* tr, int pieces, double* u_out, void* raw_out, int64_t* n_times_out);
 /* WaveformGrid.from_modes on its own (scri/waveform_grid.py:331-613): the first half of bms_transform_modes -- the field on the
  * boost-distorted grid at the new time slices, grid_out c16[n_times][n_theta * n_phi] (only the first *n_times_out rows are
  * written; grid order, theta-major), in the memory space in->mem.  bms_map2salm of it is WaveformGrid.to_modes (:274-329). */

@@ -2374,10 +2374,20 @@ extern "C" int bms_fletcher32(bms_ctx* c, const void* data, int mem, int64_t n_b
 }
 
 // ====================================================================================================== ABD flavour
+static int transform_abd_impl(bms_ctx* c, const double* u, const void* raw, int mem, int64_t n_times, int ell_max,
+                              const bms_transformation* tr, const bms_shard* sh, double* u_out, void* raw_out, int64_t* n_times_out,
+                              int64_t* first_index_out);
+
 extern "C" int bms_transform_abd_shard(bms_ctx* c, const double* u, const void* raw, int mem, int64_t n_times, int ell_max,
                                        const bms_transformation* tr, const bms_shard* sh, double* u_out, void* raw_out,
                                        int64_t* n_times_out, int64_t* first_index_out) {
   if (!c) return BMS_ERR_INVALID;
+  return transform_abd_impl(c, u, raw, mem, n_times, ell_max, tr, sh, u_out, raw_out, n_times_out, first_index_out);
+}
+
+static int transform_abd_impl(bms_ctx* c, const double* u, const void* raw, int mem, int64_t n_times, int ell_max,
+                              const bms_transformation* tr, const bms_shard* sh, double* u_out, void* raw_out, int64_t* n_times_out,
+                              int64_t* first_index_out) {
   if (!u || !raw || !tr || !u_out || !raw_out || !n_times_out) return fail(c, BMS_ERR_INVALID, "NULL argument");
   HIP_TRY(c, hipSetDevice(c->device));
   const int64_t n = n_times;
@@ -2419,7 +2429,19 @@ extern "C" int bms_transform_abd_shard(bms_ctx* c, const double* u, const void* 
                       {-v[0] * std::sqrt(2 * M_PI / 3), v[1] * std::sqrt(2 * M_PI / 3)}};
   PixelTables T;
   DevPixel DP;
-  if ((rc = device_pixel_tables(c, tr, T, 2, 0, 0, &c1, &c2, cv, DP, column_plan(tr, n_out)))) return rc;
+  // (pieces of a pipelined call share the per-direction tables and the knot tables of the whole series)
+  PieceTables* shared = c->async_pieces ? static_cast<PieceTables*>(c->piece_tables) : nullptr;
+  if (shared && c->piece_tables_valid) {
+    T = shared->T;
+    DP = shared->DP;
+  } else {
+    if ((rc = device_pixel_tables(c, tr, T, 2, 0, 0, &c1, &c2, cv, DP, column_plan(tr, n_out)))) return rc;
+    if (shared) {
+      shared->T = T;
+      shared->DP = DP;
+      c->piece_tables_valid = true;
+    }
+  }
   const int n_cols = T.n_pix;
   const bool col_split = sh && sh->col_parts > 1;
   int cA, cB;
@@ -2456,6 +2478,12 @@ extern "C" int bms_transform_abd_shard(bms_ctx* c, const double* u, const void* 
     void* vp;
     if ((rc = upload(c, "times", u, 8 * (size_t)n, &vp))) return rc;
     d_x = (double*)vp;
+  } else if (bsg && shared && shared->times_valid) {
+    d_x = shared->d_x, d_bstab = shared->d_bstab, d_bsfwd = shared->d_bsfwd;
+  } else if (bsg && shared) {
+    rc = upload_times_bspline(c, u, n, 0, n, 0, n, &d_x, &d_bstab, &d_bsfwd);
+    shared->d_x = d_x, shared->d_bstab = d_bstab, shared->d_bsfwd = d_bsfwd;
+    shared->times_valid = rc == BMS_OK;
   } else if (bsg)
     rc = upload_times_bspline(c, u, n, t_lo, t_hi, row0, row0 + rows_avail, &d_x, &d_bstab, &d_bsfwd);
   else
@@ -2572,7 +2600,119 @@ extern "C" int bms_transform_abd_shard(bms_ctx* c, const double* u, const void* 
       HIP_TRY(c, hipMemcpyAsync((char*)raw_out + (size_t)f * fs_out * n_out * 16, d_out + (size_t)f * fs_out * n_out * 2,
                                 (size_t)n_new * n_out * 16, hipMemcpyDeviceToHost, S));
   }
-  HIP_TRY(c, hipStreamSynchronize(S));
+  if (!c->async_pieces) HIP_TRY(c, hipStreamSynchronize(S));  // (a piece of a pipelined call returns without waiting)
+  return BMS_OK;
+}
+
+// AsymptoticBondiData.transform with host arrays in and out, as the three-stage pipeline of bms_transform_modes_pipelined: the
+// rows (+ halo) of the six fields of shard k + 1 travel up, the kernels of shard k run and the results of shard k - 1 travel
+// down at the same time.  raw: host c16[6][n][(ell_max+1)^2]; raw_out: host c16[6][i_hi - i_lo][n_out] (best page-locked).
+extern "C" int bms_transform_abd_pipelined(bms_ctx* c, const double* u, const void* raw, int64_t n, int ell_max,
+                                           const bms_transformation* tr, int pieces, double* u_out, void* raw_out, int64_t* n_times_out) {
+  if (!c) return BMS_ERR_INVALID;
+  if (!u || !raw || !tr || !u_out || !raw_out || !n_times_out) return fail(c, BMS_ERR_INVALID, "NULL argument");
+  HIP_TRY(c, hipSetDevice(c->device));
+  bool regular = true;
+  int rc = validate_common(c, n, u, tr, 0, n, &regular);
+  if (rc) return rc;
+  if (!regular) return fail(c, BMS_ERR_UNSUPPORTED, "the time steps vary by more than 1e3 within 48 samples: not sharded");
+  if (ell_max < 0 || tr->ell_max_out < 0) return fail(c, BMS_ERR_INVALID, "bad ell_max");
+  PixelTables T;
+  {
+    DevPixel DP;
+    const cplx cv0[4] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}};
+    if ((rc = device_pixel_tables(c, tr, T, 0, 0, 0, nullptr, nullptr, cv0, DP, 0))) return rc;
+  }
+  int64_t i_lo, i_hi;
+  output_window_abd(T, u, n, i_lo, i_hi);
+  const int64_t n_new = i_hi - i_lo;
+  *n_times_out = n_new;
+  if (n_new <= 0) return BMS_OK;
+  if (pieces < 1) pieces = 1;
+  if (pieces > n_new / 8) pieces = (int)std::max<int64_t>(1, n_new / 8);
+  const int64_t nm = (int64_t)(ell_max + 1) * (ell_max + 1), n_out = (int64_t)(tr->ell_max_out + 1) * (tr->ell_max_out + 1);
+  std::vector<int64_t> cut(pieces + 1), r0(pieces), r1(pieces);
+  int64_t max_rows = 0, max_out = 0;
+  for (int k = 0; k <= pieces; ++k) cut[k] = i_lo + (n_new * k) / pieces;
+  for (int k = 0; k < pieces; ++k) {
+    int64_t ja, jb;
+    needed_knots(T, u, n, cut[k], cut[k + 1], ja, jb);
+    const int margin = SPLINE_HALO + 2;  // as bms_shard_plan
+    r0[k] = std::max<int64_t>(0, ja - margin);
+    r1[k] = std::min<int64_t>(n, jb + margin + 1);
+    max_rows = std::max(max_rows, r1[k] - r0[k]);
+    max_out = std::max(max_out, cut[k + 1] - cut[k]);
+  }
+  double *d_in[2], *d_out[2];
+  if ((rc = dev_buf_t(c, "pipe_in0", (size_t)6 * max_rows * nm * 2, &d_in[0]))) return rc;
+  if ((rc = dev_buf_t(c, "pipe_in1", (size_t)6 * max_rows * nm * 2, &d_in[1]))) return rc;
+  if ((rc = dev_buf_t(c, "pipe_out0", (size_t)6 * max_out * n_out * 2, &d_out[0]))) return rc;
+  if ((rc = dev_buf_t(c, "pipe_out1", (size_t)6 * max_out * n_out * 2, &d_out[1]))) return rc;
+  if (!c->pipe_up) {
+    HIP_TRY(c, hipStreamCreateWithFlags(&c->pipe_up, hipStreamNonBlocking));
+    HIP_TRY(c, hipStreamCreateWithFlags(&c->pipe_down, hipStreamNonBlocking));
+  }
+  std::vector<hipEvent_t> ev_up(pieces), ev_c(pieces), ev_dn(pieces);
+  for (int k = 0; k < pieces; ++k) ev_up[k] = ScopedTimer::get(c), ev_c[k] = ScopedTimer::get(c), ev_dn[k] = ScopedTimer::get(c);
+  auto give_back = [&]() {
+    for (int k = 0; k < pieces; ++k) c->event_pool.push_back(ev_up[k]), c->event_pool.push_back(ev_c[k]), c->event_pool.push_back(ev_dn[k]);
+  };
+  const char* host_in = (const char*)raw;
+  char* host_out = (char*)raw_out;
+  auto upload_piece = [&](int k) -> hipError_t {  // the six fields' rows [r0, r1) -> c16[6][rows][nm]
+    const int64_t rows = r1[k] - r0[k];
+    for (int f = 0; f < 6; ++f) {
+      const hipError_t e = hipMemcpyAsync(d_in[k & 1] + (size_t)f * rows * nm * 2, host_in + ((size_t)f * n + r0[k]) * nm * 16, (size_t)rows * nm * 16,
+                                          hipMemcpyHostToDevice, c->pipe_up);
+      if (e != hipSuccess) return e;
+    }
+    return hipEventRecord(ev_up[k], c->pipe_up);
+  };
+  PieceTables shared_tables;
+  struct AsyncScope {
+    bms_ctx* c;
+    ~AsyncScope() {
+      c->async_pieces = false;
+      c->piece_tables_valid = false;
+      c->piece_tables = nullptr;
+    }
+  } scope{c};
+  c->piece_tables = &shared_tables;
+  c->piece_tables_valid = false;
+  c->async_pieces = true;
+  hipError_t he = upload_piece(0);
+  if (he != hipSuccess) {
+    give_back();
+    return fail(c, BMS_ERR_HIP, "pipelined upload: %s", hipGetErrorString(he));
+  }
+  for (int k = 0; k < pieces && rc == BMS_OK; ++k) {
+    if (k > 0 && k + 1 < pieces && (he = upload_piece(k + 1)) != hipSuccess) break;
+    if ((he = hipStreamWaitEvent(c->stream, ev_up[k], 0)) != hipSuccess) break;
+    if (k >= 2 && (he = hipStreamWaitEvent(c->stream, ev_dn[k - 2], 0)) != hipSuccess) break;  // its output buffer has left
+    const bms_shard sh = {r0[k], r1[k] - r0[k], cut[k], cut[k + 1], 0, 0};
+    int64_t got = 0, first = 0;
+    rc = transform_abd_impl(c, u, d_in[k & 1], BMS_DEVICE, n, ell_max, tr, &sh, u_out + (cut[k] - i_lo), d_out[k & 1], &got, &first);
+    if (rc) break;
+    if (k == 0 && pieces > 1 && (he = upload_piece(1)) != hipSuccess) break;  // (after piece 0's blocking table read-back)
+    if (got != cut[k + 1] - cut[k] || first != cut[k]) {
+      rc = fail(c, BMS_ERR_HIP, "pipelined shard [%lld, %lld) produced %lld rows from %lld", (long long)cut[k], (long long)cut[k + 1],
+                (long long)got, (long long)first);
+      break;
+    }
+    if ((he = hipEventRecord(ev_c[k], c->stream)) != hipSuccess) break;
+    if ((he = hipEventSynchronize(ev_c[k])) != hipSuccess) break;
+    for (int f = 0; f < 6 && he == hipSuccess; ++f)
+      he = hipMemcpyAsync(host_out + ((size_t)f * n_new + (cut[k] - i_lo)) * n_out * 16, d_out[k & 1] + (size_t)f * got * n_out * 2,
+                          (size_t)got * n_out * 16, hipMemcpyDeviceToHost, c->pipe_down);
+    if (he != hipSuccess) break;
+    if ((he = hipEventRecord(ev_dn[k], c->pipe_down)) != hipSuccess) break;
+  }
+  (void)hipStreamSynchronize(c->pipe_up);
+  (void)hipStreamSynchronize(c->stream);
+  (void)hipStreamSynchronize(c->pipe_down);
+  give_back();
+  if (rc) return rc;
+  if (he != hipSuccess) return fail(c, BMS_ERR_HIP, "pipelined transfer: %s", hipGetErrorString(he));
   return BMS_OK;
 }
 

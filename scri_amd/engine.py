@@ -385,6 +385,16 @@ def transform_abd(u, raw, ell_max, transformation, ctx=None, shard=None, device=
         fs_out = i_hi - i_lo
         u_out = np.empty(max(fs_out, 1), dtype=float)
     out = _lib.pinned_empty((6, max(fs_out, 1), n_out), np.complex128)
+    if (shard is None and raw.nbytes >= PIPELINE_MIN_BYTES and fs_out >= 8 * PIPELINE_PIECES and not os.environ.get("SCRI_AMD_NO_PIPELINE")):
+        # a long series in host memory: uploads, kernels and downloads of consecutive time shards side by side
+        rc = _lib.load().bms_transform_abd_pipelined(
+            ctx.handle, dptr(u), vptr(raw), n, int(ell_max), ctypes.byref(transformation), PIPELINE_PIECES, dptr(u_out), vptr(out),
+            ctypes.byref(n_new),
+        )
+        ctx.check(rc, "bms_transform_abd_pipelined")
+        if n_new.value != out.shape[1]:
+            raise RuntimeError(f"pipelined ABD transform produced {n_new.value} rows, expected {out.shape[1]}")
+        return u_out, out
     rc = _lib.load().bms_transform_abd_shard(
         ctx.handle, dptr(u), vptr(raw), BMS_HOST, n, int(ell_max), ctypes.byref(transformation), shp, dptr(u_out), vptr(out),
         ctypes.byref(n_new), ctypes.byref(first),
