@@ -223,8 +223,10 @@ __global__ __launch_bounds__(640, 1) void synthesis_split_kernel(const double* _
       asm volatile("" : "+v"(opaque));  // trip instead of being carried, and spilled, across the loop)
       v4d_t ure{0.0, 0.0, 0.0, 0.0}, uim = ure, vre = ure, vim = ure;
       double xur = 0.0, xui = 0.0, xvr = 0.0, xvi = 0.0;
+      const int ksm = (g.L + 3) / 4;  // k steps that carry an m <= L at all (two of the four at l_max = 8)
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
+        if (s >= ksm) break;
         const int m = 4 * s + fk + 1;
         const int mm = m <= g.L ? m : 0;  // (rows beyond L: their twiddles are zero)
         const double2 fp = Fb[fa + (g.L + mm) * PJ], fm = Fb[fa + (g.L - mm) * PJ];
