@@ -372,6 +372,15 @@ def test_geometrically_graded_time_axis_abd(ctx):
     got = a.transform(**kw)
     assert got.n_times == expect.n_times and got.n_times > 100
     assert np.abs(got._raw_data - expect.raw).max() < 2e-12 * max(1.0, np.abs(expect.raw).max())
+    # a series long enough for the host pipeline: bms_transform_abd_pipelined refuses the graded axis and the call falls back
+    from scri_amd import engine
+
+    old_min, engine.PIPELINE_MIN_BYTES = engine.PIPELINE_MIN_BYTES, 1
+    try:
+        again = a.transform(**kw)
+    finally:
+        engine.PIPELINE_MIN_BYTES = old_min
+    assert np.array_equal(again._raw_data, got._raw_data)
 
 
 def test_workspace_limit_too_small_is_reported(ctx):
