@@ -650,8 +650,6 @@ hipError_t launch_bspline_backward_eval(hipStream_t stream, const double* C, lon
     dim3 grid((n_cols + 63) / 64, (unsigned)(y1 - y0));
     if (xp == 1) {  // (ring rows, knots per group, deferred stores, register sets, non-temporal rows, abscissa window)
       BS_GO(8, 3, 0, 2, false, false);
-    } else if (xp == 3) {
-      BS_GO(16, 3, 1, 2, false, false);
     } else if (xp == 4) {
       BS_GO(8, 3, 1, 2, false, false);
     } else if (w) {
