@@ -57,6 +57,26 @@ def test_cfg3_windows_match_oracle(cfg3):
         assert err < 1e-12 * max(1.0, np.abs(e.data).max()), (i0, err)
 
 
+def test_cfg3_size_without_boost_separable_equals_dense(cfg3, ctx, monkeypatch):
+    """The cfg3 series (1e5 steps, l <= 16) through a boost-free transformation -- rotated modes + `synthesis_split_kernel` --
+    against the dense sYlm product on the same grid, and a window of it against the oracle."""
+    t, data, kw, _ = cfg3
+    kw0 = {k: v for k, v in kw.items() if k != "boost_velocity"}
+    got = _gpu_wm(t, data, 16, h, ctx).transform(**kw0)
+    monkeypatch.setenv("SCRI_AMD_NO_SEPARABLE_SYNTHESIS", "1")
+    ref = _gpu_wm(t, data, 16, h, ctx).transform(**kw0)
+    monkeypatch.delenv("SCRI_AMD_NO_SEPARABLE_SYNTHESIS")
+    assert got.n_times == ref.n_times and np.array_equal(got.t, ref.t)
+    assert np.abs(got.data - ref.data).max() < 1e-13 * max(1.0, np.abs(ref.data).max())
+    i0 = 61_000
+    sl = slice(i0, i0 + 400)
+    e = grid_ref.transform(WM(t=t[sl], data=data[sl], ell_min=2, ell_max=16, dataType=h), **kw0)
+    keep = e.t[60:-60]
+    gi = np.searchsorted(got.t, keep - 1e-9)
+    assert np.abs(got.t[gi] - keep).max() < 1e-10
+    assert np.abs(got.data[gi] - e.data[60:-60]).max() < 1e-12 * max(1.0, np.abs(e.data).max())
+
+
 def test_cfg3_linearity_and_affinity(cfg3, ctx):
     from scri_amd import synthetic
 
