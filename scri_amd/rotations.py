@@ -32,21 +32,32 @@ def rotate_decomposition_basis(W, R_basis):
         R = R[0]
     if R.ndim > 2:
         raise ValueError("Input dimension mismatch.  R_basis.shape={}".format(R.shape[:-1]))
-    if not W.data.flags.c_contiguous:
+    on_device = getattr(W, "is_device_resident", False)  # weights in HBM (WaveformModes.to_device): rotated there, in place
+    if not on_device and not W.data.flags.c_contiguous:
         W.data = np.ascontiguousarray(W.data)
     if R.ndim == 2:
         if W.n_times != R.shape[0]:
             raise ValueError(
                 "Input dimension mismatch.  (W.n_times={}) != (len(R_basis)={})".format(W.n_times, R.shape[0])
             )
-        engine.rotate_series(W.data, W.ell_min, W.ell_max, quaternions.as_spinor_array(R), ctx=W._ctx)
+        if on_device:
+            from . import device_series
+
+            sp = device_series.to_device(W._ctx, quaternions.as_spinor_array(R))
+            engine.rotate_device(W._dev.data_ptr(), W.n_times, W.n_modes, W.ell_min, W.ell_max, spinors_ptr=sp.data_ptr(), ctx=W._ctx)
+            W._ctx.synchronize()  # (the rotor tensor goes out of scope)
+        else:
+            engine.rotate_series(W.data, W.ell_min, W.ell_max, quaternions.as_spinor_array(R), ctx=W._ctx)
         # right-multiplication (rotations.py:313-321)
         if W.frame.size:
             W.frame = quaternions.multiply(W.frame, R)  # broadcasts a single frame element
         else:
             W.frame = np.copy(R)
     else:
-        engine.rotate_const(W.data, W.ell_min, W.ell_max, R, ctx=W._ctx)
+        if on_device:
+            engine.rotate_device(W._dev.data_ptr(), W.n_times, W.n_modes, W.ell_min, W.ell_max, quaternion=R, ctx=W._ctx)
+        else:
+            engine.rotate_const(W.data, W.ell_min, W.ell_max, R, ctx=W._ctx)
         if W.frame.size:
             W.frame = quaternions.multiply(W.frame, R)
         else:

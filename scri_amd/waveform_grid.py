@@ -185,7 +185,7 @@ def _prepare(w_modes, kwargs):
                 "of dataType '{}'. Proceeding with the transformation as if it "
                 "were dataType 'Psi4'.".format(w_modes.data_type_string)
             )
-    if w_modes.data.ndim != 2:
+    if len(w_modes._data_shape() if hasattr(w_modes, "_data_shape") else np.shape(w_modes.data)) != 2:
         raise NotImplementedError("extra trailing data dimensions are not supported by the GPU engine")
     return supertranslation, frame_rotation, boost_velocity, n_theta, n_phi, type_term, aux
 
@@ -216,14 +216,28 @@ def transform(w_modes, **kwargs):
         raise ValueError(f"Input `ell_min` should be an integer between 0 and {ell_max_out}; got `{ell_min_out}`.")
 
     tr = engine.make_transformation(supertranslation, frame_rotation, boost_velocity, n_theta, n_phi, ell_max_out)
-    t_new, data_new = engine.transform_modes(
-        w_modes.t, w_modes.data, w_modes.ell_min, w_modes.ell_max, s, w_modes.conformal_weight, type_term, tr,
-        aux=aux, ctx=w_modes._ctx,
-    )
+    dev_out = None
+    if getattr(w_modes, "is_device_resident", False) and not aux:
+        # weights in HBM (WaveformModes.to_device): the transformation reads and writes them there
+        from . import device_series
+        from .mode_algebra import LM_total_size
+
+        n_out = LM_total_size(ell_min_out, int(ell_max_out))
+        out = device_series.empty(w_modes._ctx, (w_modes.n_times, n_out))
+        t_new, n_new = engine.transform_modes(
+            w_modes.t, w_modes._dev.data_ptr(), w_modes.ell_min, w_modes.ell_max, s, w_modes.conformal_weight, type_term, tr,
+            ctx=w_modes._ctx, device=True, ld=w_modes.n_modes, out_ptr=out.data_ptr(),
+        )
+        dev_out, data_new = out[:n_new], np.empty((0, 0))
+    else:
+        t_new, data_new = engine.transform_modes(
+            w_modes.t, w_modes.data, w_modes.ell_min, w_modes.ell_max, s, w_modes.conformal_weight, type_term, tr,
+            aux=aux, ctx=w_modes._ctx,
+        )
     if kwargs:
         warnings.warn("\nUnused kwargs passed to this function:\n{}".format(pprint.pformat(kwargs, width=1)))
 
-    return WaveformModes(
+    return _with_device_data(dev_out, WaveformModes, dict(
         t=t_new,
         data=data_new,
         history=w_modes.history,
@@ -235,7 +249,17 @@ def transform(w_modes, **kwargs):
         m_is_scaled_out=w_modes.m_is_scaled_out,
         constructor_statement=f"WaveformGrid.from_modes({w_modes}, **{original_kwargs}).to_modes({ell_max_out})",
         ctx=w_modes._ctx,
-    )
+    ))
+
+
+def _with_device_data(dev, cls, kw):
+    """cls(**kw), with the mode weights a device tensor when `dev` is given (the shape check of the constructor sees them)."""
+    if dev is None:
+        return cls(**kw)
+    kw = dict(kw, data=np.empty((0, dev.shape[1]), dtype=complex))
+    w = cls(**kw)
+    w._host, w._dev = None, dev
+    return w
 
 
 class WaveformGrid:

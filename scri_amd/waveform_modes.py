@@ -20,10 +20,16 @@ class WaveformModes:
     """
 
     def __init__(self, *args, **kwargs):
+        self._host = None
+        self._dev = None  # device-resident weights (torch tensor used as memory only), see to_device()
+        dev_copy = None
         if len(args) == 1 and isinstance(args[0], WaveformModes) and not kwargs:
             o = args[0]
+            if o._dev is not None:  # a copy of a device-resident object stays on the device (and does not pull the source off it)
+                dev_copy = o._dev.clone()
             kwargs = dict(
-                t=o.t.copy(), data=o.data.copy(), ell_min=o.ell_min, ell_max=o.ell_max, frame=np.array(o.frame, copy=True),
+                t=o.t.copy(), data=(np.empty((0, 0)) if dev_copy is not None else o.data.copy()), ell_min=o.ell_min, ell_max=o.ell_max,
+                frame=np.array(o.frame, copy=True),
                 frameType=o.frameType, dataType=o.dataType, r_is_scaled_out=o.r_is_scaled_out,
                 m_is_scaled_out=o.m_is_scaled_out, history=list(o.history), ctx=o._ctx,
             )
@@ -35,6 +41,8 @@ class WaveformModes:
         frame = kwargs.pop("frame", None)
         self.frame = np.zeros((0, 4)) if frame is None or np.size(frame) == 0 else np.atleast_2d(quaternions.as_float_array(frame)).copy()
         self.data = np.array(kwargs.pop("data", np.empty((0, 0))), dtype=complex)
+        if dev_copy is not None:
+            self._host, self._dev = None, dev_copy
         self.ell_min = int(kwargs.pop("ell_min", 0))
         self.ell_max = int(kwargs.pop("ell_max", -1))
         self.frameType = int(kwargs.pop("frameType", UnknownFrameType))
@@ -50,10 +58,48 @@ class WaveformModes:
         _next_num[0] += 1
         self.num = _next_num[0]
         self.history.append(f"{self} = {constructor_statement or 'WaveformModes(...)'}")
-        if self.ell_max >= self.ell_min and self.data.ndim >= 2 and self.data.shape[1] != LM_total_size(self.ell_min, self.ell_max):
+        shape = self._data_shape()
+        if self.ell_max >= self.ell_min and len(shape) >= 2 and shape[1] != LM_total_size(self.ell_min, self.ell_max):
             raise ValueError(
-                f"data.shape[1]={self.data.shape[1]} inconsistent with ell_min={self.ell_min}, ell_max={self.ell_max}"
+                f"data.shape[1]={shape[1]} inconsistent with ell_min={self.ell_min}, ell_max={self.ell_max}"
             )
+
+    # ---- where the mode weights live.  `data` is the host array of the reference's interface; an object moved to the GPU with
+    # to_device() keeps its weights in HBM, and transform / rotate_decomposition_basis / copy work on them there (results
+    # stay there too).  Reading `data` brings them back and makes the host array authoritative again (the caller may write to it).
+    @property
+    def data(self):
+        if self._host is None and self._dev is not None:
+            self._host, self._dev = self._dev.cpu().numpy(), None
+        return self._host
+
+    @data.setter
+    def data(self, value):
+        self._host, self._dev = value, None
+
+    def _data_shape(self):
+        return tuple(self._dev.shape) if self._dev is not None else np.shape(self._host)
+
+    @property
+    def is_device_resident(self):
+        return self._dev is not None
+
+    def to_device(self):
+        """Move the mode weights to the GPU (in place; returns self).  Chains of rotations and BMS transformations then run
+        without crossing PCIe; `to_host()` or reading `.data` brings the result back."""
+        from . import device_series, _lib
+
+        if self._dev is None:
+            if self._host is None or self._host.ndim != 2:
+                raise ValueError("to_device() takes data of shape [n_times, n_modes]")
+            ctx = self._ctx if self._ctx is not None else _lib.default_context()
+            self._ctx = ctx
+            self._dev, self._host = device_series.to_device(ctx, self._host), None
+        return self
+
+    def to_host(self):
+        _ = self.data
+        return self
 
     def __str__(self):
         return f"{type(self).__name__}_{self.num}"
@@ -65,7 +111,7 @@ class WaveformModes:
 
     @property
     def n_modes(self):
-        return self.data.shape[1]
+        return self._data_shape()[1]
 
     @property
     def LM(self):
