@@ -558,7 +558,8 @@ static int rotate_impl(bms_ctx* c, void* data, int mem, int64_t n_times, int64_t
   const double* d_res_tab = nullptr;
   unsigned int* d_res_counter = nullptr;
   int rc = BMS_OK;
-  if (!getenv("SCRI_AMD_ROTATE_VALU") && !getenv("SCRI_AMD_ROTATE_STAGED"))
+  // (the resident kernel addresses a 16-row tile with 32-bit byte offsets)
+  if (!getenv("SCRI_AMD_ROTATE_VALU") && !getenv("SCRI_AMD_ROTATE_STAGED") && ld * 256 <= 0x7ffe0000LL)
     if ((rc = ensure_delta_resident(c, ell_min, ell_max, &use_res, &res_plan, &res_lds, &d_res_tab, &d_res_counter))) return rc;
   const bool use_mfma = !use_res && rotate_mfma_supported(ell_max) && !getenv("SCRI_AMD_ROTATE_VALU");
   if (!use_res && !use_mfma && rotate_waves_per_block(ell_max) < 1)

@@ -23,9 +23,9 @@ hipError_t launch_rotate_modes_mfma(hipStream_t stream, double* data, long long 
                                     const long long* boff);
 
 // Wave-autonomous formulation with all tables of the l range resident in the LDS (kernels_rotate_resident.hip)
-constexpr int RR_THREADS = 512, RR_WAVES = 8, RR_MAXL = 24;
+constexpr int RR_MAXL = 24;
 struct RotResPlan {
-  int ell_min, ell_max, n_groups, kpad_max, tab_doubles;
+  int ell_min, ell_max, n_groups, kpad_max, tab_doubles, waves;
   int grp_lo[4], grp_hi[4];
   int tab_off[RR_MAXL];  // doubles, per l - ell_min
 };

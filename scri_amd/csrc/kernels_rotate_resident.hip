@@ -1,5 +1,5 @@
 // Time-series / constant Wigner-D rotation of mode weights (scri/rotations.py:346-392), wave-autonomous version for
-// l ranges whose Delta tables fit the LDS (l <= 16 of the headline configurations: 76 KB).
+// l ranges whose Delta tables fit the LDS (l <= 16 of the headline configurations: 47 KB).
 //
 // Same factorisation as kernels_rotate_mfma.hip (the per-step D matrix of the reference is never formed):
 //   out_m = p3^m sum_mu Delta_{mu,m} [ p2^mu sum_m' Delta_{mu,m'} ( p1^m' f_m' ) ],   Delta^l = d^l(pi/2) (real constants)
@@ -7,18 +7,22 @@
 // and with Delta_{mu,m'} = (-1)^(mu-m') Delta_{m',mu} ONE table T[y][x] = Delta_{y,x} serves both products:
 //   stage 1:  c_x = sum_y T[y][x] (-p1)^y f_y ,   h_x = (-p2)^x c_x          (x = mu, y = m')
 //   stage 2:  o_x = p3^x sum_y T[y][x] h_y                                    (x = m,  y = mu)
+// Column symmetry of d(pi/2): T[y][-x] = (-1)^(l+y) T[y][x].  With the rows split by the parity of l + y (= the parity of the
+// 0-based row index iy = y + l: class A even, class B odd),
+//   P_x = sum_{y in A} T[y][x] b_y ,  Q_x = sum_{y in B} T[y][x] b_y ,   c_x = P_x + Q_x ,  c_{-x} = P_x - Q_x      (x >= 0)
+// so only the l + 1 columns x >= 0 are ever multiplied: one 16-column tile up to l = 15 (the full table needed two from l = 8 and
+// three at l = 16), the k steps of the two classes together are those of the full product.  The operand image in the LDS holds
+// the rows of class A, then those of class B (each padded to a multiple of 4 with zero rows); the phases of the outputs
+// x and -x are conjugates of each other and start at power g whatever l, so they are four constants per lane and work unit.
 // Both are MFMA products with the TABLE as the A operand (rows = output index x) and the DATA as the B operand (columns =
-// 16 time steps), so the accumulators of a lane belong to ONE time step (lane & 15): every phase is a running product of
+// 16 time steps), so the accumulators of a lane belong to ONE time step (lane & 15): every phase is a product of
 // that time step's rotor, in registers, with no cross-lane traffic; Re and Im parts are two independent accumulators
 // sharing the table operand.
 //
-// What the previous kernel lost its time on (0.21 of the HBM roofline: 37 % of the wave cycles waiting, two workgroup
-// barriers and a re-staging of both table images per l, quarter-row fetches of 16 bytes per lane) is gone by construction:
-//   * all tables of the l range are loaded into the LDS once per workgroup (no swizzle needed for odd tile counts; an XOR of
-//     the column tile with the row parity keeps ds_read_b64 conflict free for 32-column tables without padding them to 48);
-//   * a wave owns its 16 time steps and a private 256 B x kpad LDS image [y][time] (complex, 16 B slots, XOR-swizzled so
-//     that the transposing write from the load layout, the operand reads and the accumulator write-back are all conflict
-//     free) -- there is NO workgroup barrier after the table load;
+//   * all tables of the l range are loaded into the LDS once per workgroup;
+//   * a wave owns its 16 time steps and a private 256 B x kpad LDS image [row][time] (complex, 16 B slots, XOR-swizzled so
+//     that the transposing write from the load layout and the operand reads are conflict free) -- there is NO workgroup
+//     barrier after the table load;
 //   * rows are fetched with 4 adjacent lanes covering 64 contiguous bytes of a row (16 rows per instruction) and the fetch
 //     of the next l is in flight under the two products of the current one;
 //   * work units are (16-step tile, l group), dealt round-robin to the waves with the group rotating from round to round:
@@ -33,62 +37,113 @@
 namespace bms {
 
 typedef double v4dq __attribute__((ext_vector_type(4)));
+typedef int v4iq __attribute__((ext_vector_type(4)));
 
-// table geometry of one l: rows kpad = 4 ceil(n / 4), column tiles ntl = ceil(n / 16), pitch 16 ntl
-static inline void rr_shape(int ell, int* kpad, int* ntl) {
-  const int n = 2 * ell + 1;
-  *kpad = 4 * ((n + 3) / 4);
-  *ntl = (n + 15) / 16;
+constexpr int RR_OOB = 0x7fff0000;  // byte offset beyond every descriptor: loads return zero, stores are dropped
+
+// geometry of one l: rows of class A (l + 1 of them) and of class B (l) padded to multiples of 4; columns x' = 0..15 in the
+// 16-column table, x' = 16..19 (l >= 16) in a 4-column side table
+BMS_HD void rr_shape(int ell, int* ka, int* kb) {
+  *ka = 4 * ((ell + 4) / 4);
+  *kb = ell > 4 ? 4 * ((ell + 3) / 4) : 4;
+}
+BMS_HD int rr_table_doubles(int ell) {
+  int ka, kb;
+  rr_shape(ell, &ka, &kb);
+  return (ka + kb) * (ell >= 16 ? 20 : 16);
 }
 
-// One product: acc[x][t] (+)= sum_y T[y][x] b_y(t) over the kpad rows of the image, operands of k step s + 1 requested
-// before the MFMAs of step s are issued.  PHASE: multiply the operand by w (advanced by w4 per step) as it is read.
-template <int NT, bool PHASE>
-__device__ __forceinline__ void rr_product(const double2* __restrict__ bp, const double* __restrict__ ap, int cq, int pd, int swz,
-                                           cplx w, cplx w4, v4dq (&acc_re)[NT], v4dq (&acc_im)[NT]) {
-#pragma unroll
-  for (int nt = 0; nt < NT; ++nt) {
-    acc_re[nt] = v4dq{0, 0, 0, 0};
-    acc_im[nt] = v4dq{0, 0, 0, 0};
-  }
-  auto fetch = [&](int s, double2& b, double (&a)[NT]) {
-    b = bp[s * 64];
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) a[nt] = ap[4 * s * pd + 16 * (nt ^ swz)];
+// Both partial products of one stage: P[x][t] = sum over the class A rows, Q[x][t] = sum over the class B rows of
+// T[row][x] b_row(t); the rows of B follow those of A in the image and in the table (k steps 0..cqA-1, cqA..cqT-1), the
+// operands of k step j + 1 are requested before the MFMAs of step j are issued, across the class boundary too.
+// PHASE: multiply the operand by w (advanced by w8 per step: rows of a class are 2 apart in y) as it is read.
+// X16: columns x' = 16..19 through the 4-block 4x4x4 MFMA (same data operand; output lane (t, g) = column 16 + g).
+struct RRAcc {
+  v4dq P_re, P_im, Q_re, Q_im;
+  double p_re, p_im, q_re, q_im;  // X16
+};
+template <bool PHASE, bool X16>
+__device__ __forceinline__ void rr_products(const double2* __restrict__ bpA, const double2* __restrict__ bpB,
+                                            const double* __restrict__ ap, const double* __restrict__ ax, int cqA, int cqT, cplx wA,
+                                            cplx wB, cplx w8, RRAcc& C) {
+  C.P_re = C.P_im = C.Q_re = C.Q_im = v4dq{0, 0, 0, 0};
+  C.p_re = C.p_im = C.q_re = C.q_im = 0.0;
+  auto fetch = [&](int j, double2& b, double& a, double& x) {
+    b = (j < cqA ? bpA : bpB)[j * 64];
+    a = ap[64 * j];
+    if (X16) x = ax[16 * j];
   };
-  auto step = [&](double2 b, const double (&a)[NT]) {
+  cplx w = wA;
+  auto stepP = [&](double2 b, double a, double x) {
     if (PHASE) {
       const double br = b.x * w.re - b.y * w.im, bi = b.x * w.im + b.y * w.re;
       b.x = br;
       b.y = bi;
-      w = cmul(w, w4);
+      w = cmul(w, w8);
     }
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-      acc_re[nt] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[nt], b.x, acc_re[nt], 0, 0, 0);
-      acc_im[nt] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[nt], b.y, acc_im[nt], 0, 0, 0);
+    C.P_re = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b.x, C.P_re, 0, 0, 0);
+    C.P_im = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b.y, C.P_im, 0, 0, 0);
+    if (X16) {
+      C.p_re = __builtin_amdgcn_mfma_f64_4x4x4f64(x, b.x, C.p_re, 0, 0, 0);
+      C.p_im = __builtin_amdgcn_mfma_f64_4x4x4f64(x, b.y, C.p_im, 0, 0, 0);
     }
   };
-  // two register sets: the operands of step s + 1 are on their way while the MFMAs of step s issue
+  auto stepQ = [&](double2 b, double a, double x) {
+    if (PHASE) {
+      const double br = b.x * w.re - b.y * w.im, bi = b.x * w.im + b.y * w.re;
+      b.x = br;
+      b.y = bi;
+      w = cmul(w, w8);
+    }
+    C.Q_re = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b.x, C.Q_re, 0, 0, 0);
+    C.Q_im = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b.y, C.Q_im, 0, 0, 0);
+    if (X16) {
+      C.q_re = __builtin_amdgcn_mfma_f64_4x4x4f64(x, b.x, C.q_re, 0, 0, 0);
+      C.q_im = __builtin_amdgcn_mfma_f64_4x4x4f64(x, b.y, C.q_im, 0, 0, 0);
+    }
+  };
+  // two register sets; which of them holds the first step of class B depends on the parity of cqA
   double2 b0, b1;
-  double a0[NT], a1[NT];
-  fetch(0, b0, a0);
-  int s = 0;
-  for (; s + 2 <= cq; s += 2) {
-    fetch(s + 1, b1, a1);
-    step(b0, a0);
-    if (s + 2 < cq) fetch(s + 2, b0, a0);
-    step(b1, a1);
+  double a0, a1, x0 = 0.0, x1 = 0.0;
+  fetch(0, b0, a0, x0);
+  int j = 0;
+  for (; j + 2 <= cqA; j += 2) {
+    fetch(j + 1, b1, a1, x1);
+    stepP(b0, a0, x0);
+    fetch(j + 2, b0, a0, x0);  // j + 2 <= cqA < cqT: always a valid step
+    stepP(b1, a1, x1);
   }
-  if (s < cq) step(b0, a0);
+  if (j < cqA) {
+    fetch(j + 1, b1, a1, x1);
+    stepP(b0, a0, x0);
+    ++j;
+    w = wB;
+    for (; j + 2 <= cqT; j += 2) {
+      fetch(j + 1, b0, a0, x0);
+      stepQ(b1, a1, x1);
+      if (j + 2 < cqT) fetch(j + 2, b1, a1, x1);
+      stepQ(b0, a0, x0);
+    }
+    if (j < cqT) stepQ(b1, a1, x1);
+  } else {
+    w = wB;
+    for (; j + 2 <= cqT; j += 2) {
+      fetch(j + 1, b1, a1, x1);
+      stepQ(b0, a0, x0);
+      if (j + 2 < cqT) fetch(j + 2, b0, a0, x0);
+      stepQ(b1, a1, x1);
+    }
+    if (j < cqT) stepQ(b0, a0, x0);
+  }
 }
 
 struct RRLane {       // per-lane state of a work unit (MFMA orientation: time step l15, row block g)
-  cplx q1, q2, p3;    // unit phases of the rotor: q1 = -i ea conj(eb), q2 = -exp(-i beta), p3 = -i ea eb
-  cplx q1_4, q2_4, p3_4;
-  cplx s1, s2, s3;    // q1^(g - l), q2^(g - l), p3^(g - l) of the current l (one factor conj(q) per l)
+  cplx q1, q1_8;      // q1 = -i ea conj(eb) and its 8th power (one k step of a class = 4 rows = 8 in y)
+  cplx s1;            // q1^(2 g - l) of the current l (one factor conj(q1) per l)
+  cplx v2, q2_4;      // q2^g and q2^4, q2 = -exp(-i beta): the outputs x' = 4 r + g start at power g whatever l
+  cplx v3, p3_4;      // p3^g and p3^4, p3 = -i ea eb
   bool live, z_only, flip, any_special;
-  int g, slot_m;
+  int g, l15;
 };
 
 BMS_HD cplx rr_pow4(cplx z) {
@@ -104,124 +159,110 @@ __device__ __forceinline__ void rr_setup(RRLane& L, cplx Ra, cplx Rb, int ell) {
   L.z_only = rb <= 1e-15;
   L.flip = ra <= 1e-15;
   L.q1 = cmul(cplx{0.0, -1.0}, cmul(ea, cconj(eb)));
-  L.q2 = {-(ra * ra - rb * rb), 2.0 * ra * rb};
-  L.p3 = cmul(cplx{0.0, -1.0}, cmul(ea, eb));
-  L.q1_4 = rr_pow4(L.q1);
-  L.q2_4 = rr_pow4(L.q2);
-  L.p3_4 = rr_pow4(L.p3);
-  L.s1 = cpow_unit(L.q1, L.g - ell);
-  L.s2 = cpow_unit(L.q2, L.g - ell);
-  L.s3 = cpow_unit(L.p3, L.g - ell);
+  const cplx q2 = {-(ra * ra - rb * rb), 2.0 * ra * rb};
+  const cplx p3 = cmul(cplx{0.0, -1.0}, cmul(ea, eb));
+  const cplx q1_4 = rr_pow4(L.q1);
+  L.q1_8 = cmul(q1_4, q1_4);
+  L.q2_4 = rr_pow4(q2);
+  L.p3_4 = rr_pow4(p3);
+  L.s1 = cpow_unit(L.q1, 2 * L.g - ell);
+  L.v2 = cpow_unit(q2, L.g);
+  L.v3 = cpow_unit(p3, L.g);
   L.any_special = __any(L.live && (L.z_only || L.flip));
 }
 
-// Both products, the phase between them and the store of one l with NT column tiles
-template <int NT, int MAXNT>
-__device__ __forceinline__ void rr_one_ell(double2* __restrict__ S2, const double* __restrict__ Tl, int ell, double* __restrict__ dst,
-                                           const double* __restrict__ rotor, const RRLane& L, double2 (&O)[4 * MAXNT]) {
-  const int n = 2 * ell + 1, cq = (n + 3) / 4, pd = 16 * NT;
-  const int swz = (NT & 1) ? 0 : (L.g & 1);  // even tile counts: column tile XOR row parity (pitch = 0 mod 32 doubles)
-  const int l15 = L.slot_m ^ (L.g << 1);
-  const double2* bp = S2 + L.g * 16 + L.slot_m;
-  const double* ap = Tl + L.g * pd + l15;
-  v4dq acc_re[NT], acc_im[NT];
-  // stage 1: c_x = sum_y T[y][x] (-p1)^(y - l) f_y
-  rr_product<NT, true>(bp, ap, cq, pd, swz, L.s1, L.q1_4, acc_re, acc_im);
+// Both stages, the phase between them and the stores of one l.  A lane's outputs are x = x' and -x', x' = 4 r + g (slots
+// r = 0..3) and 16 + g (slot 4, X16: l = 16..19).  `rsrc` covers the 16 rows of the tile; `col0` = byte offset of this l's first
+// mode in the lane's row.
+template <bool X16>
+__device__ __forceinline__ void rr_one_ell(double2* __restrict__ S2, int dump, const double* __restrict__ Tl, int ell, int ka, int kb,
+                                           __amdgpu_buffer_rsrc_t rsrc, int col0, const double* __restrict__ row,
+                                           const double* __restrict__ rotor, const RRLane& L) {
+  constexpr int NJ = X16 ? 5 : 4;
+  const int cqA = ka >> 2, cqT = (ka + kb) >> 2;
+  const double2* bpA = S2 + L.g * 16 + (L.l15 ^ (L.g << 1));
+  const double2* bpB = S2 + L.g * 16 + (L.l15 ^ ((L.g ^ 2) << 1));
+  const double* ap = Tl + L.g * 16 + L.l15;
+  const double* ax = Tl + (ka + kb) * 16 + L.g * 4 + (L.l15 & 3);
+  RRAcc C;
+  // stage 1: c_x = sum_y T[y][x] q1^y f_y
+  rr_products<true, X16>(bpA, bpB, ap, ax, cqA, cqT, L.s1, cmul(L.s1, L.q1), L.q1_8, C);
   {
-    // h_x = (-p2)^(x - l) c_x back into the image (rows n <= x < kpad are zero: the table's columns beyond n are)
-    cplx v = L.s2;
+    // h_{+-x'} = q2^(+-x') (P +- Q) back into the image: rows iy = l +- x' are of one class c (x' = g mod 2), at position
+    // iy >> 1 of it; positions 4 apart share the swizzle key, so two addresses per sign serve all slots.  Outputs beyond l
+    // go to the dump row.
+    const int c = (ell + L.g) & 1, base = c ? ka : 0;
+    const int hp = (ell + L.g) >> 1, hm = (ell - L.g) >> 1;
+    auto at = [&](int half) { return (base + half) * 16 + (L.l15 ^ ((((half & 3) ^ (c << 1))) << 1)); };
+    const int ap0 = at(hp), ap1 = at(hp + 2), am0 = at(hm), am1 = at(hm - 2);
+    cplx v = L.v2;
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int x = 16 * nt + 4 * r + L.g;
-        const double xr = acc_re[nt][r], xi = acc_im[nt][r];
-        if (x < 4 * cq) S2[x * 16 + L.slot_m] = double2{xr * v.re - xi * v.im, xr * v.im + xi * v.re};
-        v = cmul(v, L.q2_4);
-      }
+    for (int j = 0; j < NJ; ++j) {
+      const int r = j & 3, xp = 4 * j + L.g;
+      const double pr = j < 4 ? C.P_re[r] : C.p_re, pi = j < 4 ? C.P_im[r] : C.p_im;
+      const double qr = j < 4 ? C.Q_re[r] : C.q_re, qi = j < 4 ? C.Q_im[r] : C.q_im;
+      const double sr = pr + qr, si = pi + qi, dr = pr - qr, di = pi - qi;
+      const int step = 64 * (j >> 1);
+      const bool ok = xp <= ell;
+      S2[ok ? ((j & 1) ? ap1 : ap0) + step : dump] = double2{sr * v.re - si * v.im, sr * v.im + si * v.re};
+      S2[ok && xp > 0 ? ((j & 1) ? am1 : am0) - step : dump] = double2{dr * v.re + di * v.im, di * v.re - dr * v.im};
+      if (j + 1 < NJ) v = cmul(v, L.q2_4);
     }
   }
-  // stage 2: o_x = p3^(x - l) sum_y T[y][x] h_y
-  rr_product<NT, false>(bp, ap, cq, pd, swz, cplx{1.0, 0.0}, cplx{1.0, 0.0}, acc_re, acc_im);
-  {
-    cplx v = L.s3;
+  // stage 2: o_x = p3^x sum_y T[y][x] h_y
+  rr_products<false, X16>(bpA, bpB, ap, ax, cqA, cqT, cplx{1.0, 0.0}, cplx{1.0, 0.0}, cplx{1.0, 0.0}, C);
+  cplx e2 = {1.0, 0.0};
+  const bool special = L.live && (L.z_only || L.flip);
+  if (L.any_special && special) {
+    // exact branches re-read the input (still in HBM: a lane stores the two modes of a slot after it has read both) and the rotor
+    const cplx Ra = {rotor[0], rotor[1]}, Rb = {rotor[2], rotor[3]};
+    double ra, rb;
+    cplx ea, eb;
+    spinor_polar(Ra, Rb, ra, rb, ea, eb);
+    e2 = L.z_only ? cmul(ea, ea) : cmul(eb, eb);
+  }
+  cplx v = L.v3;
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const double xr = acc_re[nt][r], xi = acc_im[nt][r];
-        acc_re[nt][r] = xr * v.re - xi * v.im;
-        acc_im[nt][r] = xr * v.im + xi * v.re;
-        v = cmul(v, L.p3_4);
+  for (int j = 0; j < NJ; ++j) {
+    const int r = j & 3, xp = 4 * j + L.g;
+    const double pr = j < 4 ? C.P_re[r] : C.p_re, pi = j < 4 ? C.P_im[r] : C.p_im;
+    const double qr = j < 4 ? C.Q_re[r] : C.q_re, qi = j < 4 ? C.Q_im[r] : C.q_im;
+    const double sr = pr + qr, si = pi + qi, dr = pr - qr, di = pi - qi;
+    double2 op = double2{sr * v.re - si * v.im, sr * v.im + si * v.re};
+    double2 om = double2{dr * v.re + di * v.im, di * v.re - dr * v.im};
+    if (j + 1 < NJ) v = cmul(v, L.p3_4);
+    const bool ok = xp <= ell;
+    if (L.any_special) {
+      if (special && ok) {
+        // z_only: D_mm = ea^(2m);  flip: D_{-m,m} = (-1)^(l-m) eb^(2m), out_m = f_{-m} D_{-m,m}
+        const double2 fa = *reinterpret_cast<const double2*>(row + 2 * (ell + xp));
+        const double2 fb = *reinterpret_cast<const double2*>(row + 2 * (ell - xp));
+        const double2 fp = L.z_only ? fa : fb, fm = L.z_only ? fb : fa;
+        cplx wv = cpow_unit(e2, xp);
+        if (!L.z_only && ((ell - xp) & 1)) wv = {-wv.re, -wv.im};
+        const cplx vp = cmul(cplx{fp.x, fp.y}, wv), vm = cmul(cplx{fm.x, fm.y}, cconj(wv));
+        op = double2{vp.re, vp.im};
+        om = double2{vm.re, vm.im};
       }
     }
-  }
-  if (L.any_special) {
-    // exact branches re-read the input (still in HBM: nothing of this l has been stored yet) and the rotor
-    if (L.live && (L.z_only || L.flip)) {
-      const cplx Ra = {rotor[0], rotor[1]}, Rb = {rotor[2], rotor[3]};
-      double ra, rb;
-      cplx ea, eb;
-      spinor_polar(Ra, Rb, ra, rb, ea, eb);
-      const cplx e2 = L.z_only ? cmul(ea, ea) : cmul(eb, eb);
-#pragma unroll
-      for (int nt = 0; nt < NT; ++nt) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int x = 16 * nt + 4 * r + L.g;
-          if (x < n) {
-            const int m = x - ell;
-            // z_only: D_mm = ea^(2m);  flip: D_{-m,m} = (-1)^(l-m) eb^(2m), out_m = f_{-m} D_{-m,m}
-            const double2 f = *reinterpret_cast<const double2*>(dst + 2 * (L.z_only ? x : n - 1 - x));
-            cplx wv = cpow_unit(e2, m);
-            if (!L.z_only && ((ell - m) & 1)) wv = {-wv.re, -wv.im};
-            const cplx val = cmul(cplx{f.x, f.y}, wv);
-            acc_re[nt][r] = val.re;
-            acc_im[nt][r] = val.im;
-          }
-        }
-      }
-    }
-    __builtin_amdgcn_s_waitcnt(0);  // every re-read of the wave has returned before any of its stores
-    __builtin_amdgcn_wave_barrier();
-  }
-  // the rotated row leaves through O: element 4 nt + r = column x = 16 nt + 4 r + g of time step l15.  The caller stores it
-  // one step later, after the rows of the next l have been consumed: a wait for those rows then never waits for stores.
-#pragma unroll
-  for (int nt = 0; nt < NT; ++nt) {
-#pragma unroll
-    for (int r = 0; r < 4; ++r) O[4 * nt + r] = double2{acc_re[nt][r], acc_im[nt][r]};
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4iq, op), rsrc, ok ? col0 + 16 * (ell + xp) : RR_OOB, 0, 0);
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4iq, om), rsrc, ok && xp > 0 ? col0 + 16 * (ell - xp) : RR_OOB, 0, 0);
   }
 }
 
-// Row fetch of one l in load orientation (time step lane >> 2, columns 4 u + (lane & 3)): 4 adjacent lanes cover 64
-// contiguous bytes of a row, 16 rows per instruction; columns beyond n and rows beyond the series read as zero.
-template <int MAXNT>
-__device__ __forceinline__ void rr_fetch(double2 (&F)[4 * MAXNT], const double* __restrict__ data, long long ld, long long n_times,
-                                         long long t0, int ell, int ell_min, int lrow, int lk) {
-  const long long tl = t0 + lrow;
-  const bool live = tl < n_times;
-  const int n = 2 * ell + 1, cq = (n + 3) / 4;
-  const double2* src = reinterpret_cast<const double2*>(data + (tl * ld + ((long long)ell * ell - (long long)ell_min * ell_min) + lk) * 2);
-#pragma unroll
-  for (int u = 0; u < 4 * MAXNT; ++u) {
-    double2 v = double2{0.0, 0.0};
-    if (live && u < cq && 4 * u + lk < n) v = src[4 * u];
-    F[u] = v;
-  }
-}
-
-template <int MAXNT>
-__global__ __launch_bounds__(RR_THREADS, 1) void rotate_modes_resident_kernel(double* __restrict__ data, long long n_times,
+// NU = row slots of a lane in load orientation = KA(l_max) / 2: 4 (l <= 7), 6 (l <= 11), 8 (l <= 15), 10 (l <= 19)
+template <int NU, int W>
+__global__ __launch_bounds__(64 * W, 1) void rotate_modes_resident_kernel(double* __restrict__ data, long long n_times,
                                                                               long long ld, const double* __restrict__ RaRb,
                                                                               long long rotor_stride,
-                                                                              const double* __restrict__ tab_global, RotResPlan P,
-                                                                              unsigned int* __restrict__ counter) {
+                                                                              const double* __restrict__ tab_global, RotResPlan P) {
+  constexpr bool ANYX = NU > 8;
+  const long long n_modes = (long long)(P.ell_max + 1) * (P.ell_max + 1) - (long long)P.ell_min * P.ell_min;
   extern __shared__ double lds[];
   {
     const double2* src = reinterpret_cast<const double2*>(tab_global);
     double2* dst = reinterpret_cast<double2*>(lds);
-    for (int e = threadIdx.x; e < P.tab_doubles / 2; e += RR_THREADS) dst[e] = src[e];
+    for (int e = threadIdx.x; e < P.tab_doubles / 2; e += 64 * W) dst[e] = src[e];
   }
   __syncthreads();  // the only workgroup barrier of the kernel
 
@@ -229,19 +270,37 @@ __global__ __launch_bounds__(RR_THREADS, 1) void rotate_modes_resident_kernel(do
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   const int l15 = lane & 15, g = lane >> 4;  // MFMA orientation: time step l15, k / row block g
   const int lrow = lane >> 2, lk = lane & 3; // load orientation: time step lrow, column 4 u + lk
-  double2* S2 = reinterpret_cast<double2*>(lds + P.tab_doubles + (size_t)wave * P.kpad_max * 32);
-  const int slot_l = lrow ^ (lk << 1);       // swizzled time slot in load orientation (row y of an element has y & 3 = lk)
+  // per wave: image of kpad_max rows of 16 complex slots + one dump row for the writes of lanes without an output
+  double2* S2 = reinterpret_cast<double2*>(lds + P.tab_doubles + (size_t)wave * (P.kpad_max + 1) * 32);
+  const int dump = P.kpad_max * 16 + l15;
+  // load orientation -> image: column iy = 4 u + lk is row 2 u + (lk >> 1) of class lk & 1; swizzle key = (that row & 3),
+  // XOR 2 for class B, so the four lanes of a time step write four different keys
+  const int half0 = lk >> 1, cls = lk & 1;
+  const int slot_e = lrow ^ ((half0 ^ (cls << 1)) << 1);  // u even; u odd: key ^ 2 = slot ^ 4
   const long long n_tiles = (n_times + 15) / 16;
   const unsigned int n_units = (unsigned int)(n_tiles * P.n_groups);
+  const int ld_b = (int)(ld * 16);
+  const int off_load = lrow * ld_b + lk * 16, off_store = l15 * ld_b;  // byte offsets of a lane's row within its tile
 
   // work units (16-step tile, l group) are dealt round-robin to the waves of the launch; the group a wave gets rotates
   // from round to round so that every wave sees every group (their costs differ)
-  const unsigned int n_waves = gridDim.x * RR_WAVES;
+  const unsigned int n_waves = gridDim.x * W;
   unsigned int round = 0;
-  unsigned int unit = blockIdx.x * RR_WAVES + wave;
+  unsigned int unit = blockIdx.x * W + wave;
   auto unit_tile = [&](unsigned int u) { return (long long)(u / P.n_groups) * 16; };
   auto unit_group = [&](unsigned int u, unsigned int rnd) { return (int)((u % P.n_groups + rnd) % P.n_groups); };
-  double2 F[4 * MAXNT];  // rows of the (unit, l) to come, requested one step ahead
+  // descriptor of the rows of a tile: rows beyond the series are out of range (loads give zero, stores are dropped)
+  auto tile_rsrc = [&](long long t0) {
+    const long long rows = n_times - t0 < 16 ? n_times - t0 : 16;
+    return __builtin_amdgcn_make_buffer_rsrc(data + t0 * ld * 2, 0, (int)(((rows - 1) * ld + n_modes) * 16), 0x00020000);
+  };
+  double2 F[NU];  // rows of the (unit, l) to come, requested one step ahead; columns beyond 2 l + 1 read as zero
+  auto fetch = [&](__amdgpu_buffer_rsrc_t rs, int ell) {
+    const int n = 2 * ell + 1, col = (ell * ell - P.ell_min * P.ell_min) * 16 + off_load;
+#pragma unroll
+    for (int u = 0; u < NU; ++u)
+      F[u] = __builtin_bit_cast(double2, __builtin_amdgcn_raw_buffer_load_b128(rs, 4 * u + lk < n ? col + 64 * u : RR_OOB, 0, 0));
+  };
   // rotor of time step t0 + l15 (the last step's for lanes beyond the series: their results are never stored)
   auto load_rotor = [&](long long t0, double2& a, double2& b) {
     long long tm = t0 + l15;
@@ -257,40 +316,35 @@ __global__ __launch_bounds__(RR_THREADS, 1) void rotate_modes_resident_kernel(do
   int ell = P.grp_lo[grp], ell_hi = P.grp_hi[grp];
   double2 Ra_n, Rb_n;
   load_rotor(t0, Ra_n, Rb_n);
-  rr_fetch<MAXNT>(F, data, ld, n_times, t0, ell, P.ell_min, lrow, lk);
+  __amdgpu_buffer_rsrc_t rs_next = tile_rsrc(t0);
+  fetch(rs_next, ell);
+  // The wait for these rows at the top of the loop must let the (younger) stores of the previous l stay in flight.  The
+  // compiler merges the loop entry with the back edge and takes the smaller vmcnt; with as many (out-of-range, dropped)
+  // stores behind the first fetch as an iteration issues behind the others, both agree.
+#pragma unroll
+  for (int j = 0; j < 8; ++j) __builtin_amdgcn_raw_buffer_store_b128(v4iq{j, 0, 0, 0}, rs_next, RR_OOB + 256 * j + 16 * lane, 0, 0);
   RRLane L;
   L.g = g;
-  L.slot_m = l15 ^ (g << 1);  // swizzled time slot of this lane's accesses in MFMA orientation
+  L.l15 = l15;
   L.live = t0 + l15 < n_times;
   rr_setup(L, cplx{Ra_n.x, Ra_n.y}, cplx{Rb_n.x, Rb_n.y}, ell);
 
-  double2 O[4 * MAXNT];   // rotated row of the previous step, stored one step late
-  double* dst_prev = nullptr;
-  int n_prev = 0;
-  bool live_prev = false;
-  auto store_prev = [&]() {
-    if (live_prev) {
-#pragma unroll
-      for (int j = 0; j < 4 * MAXNT; ++j) {
-        const int x = 4 * j + g;
-        if (x < n_prev) *reinterpret_cast<double2*>(dst_prev + 2 * x) = O[j];
-      }
-    }
-  };
-
   for (;;) {
-    const int n = 2 * ell + 1;
-    const int cq = (n + 3) / 4;  // k steps = kpad / 4
-    // ---- rows of this l -> LDS image [y][time]
+    int ka, kb;
+    rr_shape(ell, &ka, &kb);
+    // ---- rows of this l -> LDS image [class A rows | class B rows][time]; the padding rows of both classes are written
+    // too (F holds zeros there)
+    {
+      const int rb = half0 + (cls ? ka : 0);
 #pragma unroll
-    for (int u = 0; u < 4 * MAXNT; ++u)
-      if (u < cq) S2[(4 * u + lk) * 16 + slot_l] = F[u];
-    // ---- the previous step's row goes out now
-    store_prev();
+      for (int u = 0; u < NU; ++u)
+        if (2 * u < ka) S2[!cls || 2 * u + half0 < kb ? (rb + 2 * u) * 16 + (slot_e ^ ((u & 1) << 2)) : dump] = F[u];
+    }
     // ---- what comes next: the next l of this unit, or the first l of the next unit (its rows and rotor are requested now
     // and arrive under the products below)
     const long long t0_cur = t0;
     const int ell_cur = ell;
+    const __amdgpu_buffer_rsrc_t rs_cur = rs_next;
     bool new_unit = false, done = false;
     if (ell < ell_hi) {
       ++ell;
@@ -306,34 +360,28 @@ __global__ __launch_bounds__(RR_THREADS, 1) void rotate_modes_resident_kernel(do
         ell = P.grp_lo[grp];
         ell_hi = P.grp_hi[grp];
         load_rotor(t0, Ra_n, Rb_n);
+        rs_next = tile_rsrc(t0);
       }
     }
-    if (!done) rr_fetch<MAXNT>(F, data, ld, n_times, t0, ell, P.ell_min, lrow, lk);
+    if (!done) fetch(rs_next, ell);
 
     const double* Tl = lds + P.tab_off[ell_cur - P.ell_min];
     const long long tm = t0_cur + l15;
-    double* dst = data + (tm * ld + ((long long)ell_cur * ell_cur - (long long)P.ell_min * P.ell_min)) * 2;
+    const int col0 = (ell_cur * ell_cur - P.ell_min * P.ell_min) * 16 + off_store;
+    const double* row = data + (tm * ld + ((long long)ell_cur * ell_cur - (long long)P.ell_min * P.ell_min)) * 2;
     const double* rot = RaRb + tm * rotor_stride;
-    if (MAXNT >= 3 && n > 32)
-      rr_one_ell<3, MAXNT>(S2, Tl, ell_cur, dst, rot, L, O);
-    else if (MAXNT >= 2 && n > 16)
-      rr_one_ell<2, MAXNT>(S2, Tl, ell_cur, dst, rot, L, O);
+    if (ANYX && ell_cur >= 16)
+      rr_one_ell<true>(S2, dump, Tl, ell_cur, ka, kb, rs_cur, col0, row, rot, L);
     else
-      rr_one_ell<1, MAXNT>(S2, Tl, ell_cur, dst, rot, L, O);
-    dst_prev = dst;
-    n_prev = n;
-    live_prev = L.live;
+      rr_one_ell<false>(S2, dump, Tl, ell_cur, ka, kb, rs_cur, col0, row, rot, L);
     if (done) break;
     if (new_unit) {
       L.live = t0 + l15 < n_times;
       rr_setup(L, cplx{Ra_n.x, Ra_n.y}, cplx{Rb_n.x, Rb_n.y}, ell);
     } else {
       L.s1 = cmul(L.s1, cconj(L.q1));
-      L.s2 = cmul(L.s2, cconj(L.q2));
-      L.s3 = cmul(L.s3, cconj(L.p3));
     }
   }
-  store_prev();
 }
 
 // ---------------------------------------------------------------------------------------------------- host side
@@ -341,27 +389,29 @@ __global__ __launch_bounds__(RR_THREADS, 1) void rotate_modes_resident_kernel(do
 // Plan for an l range: table offsets, l groups of similar cost, LDS size.  Returns false if the range does not fit.
 bool rotate_resident_plan(int ell_min, int ell_max, RotResPlan* P, size_t* lds_bytes) {
   if (ell_max - ell_min + 1 > RR_MAXL) return false;
-  int kpad, ntl, tab = 0, kmax = 0, nt_max = 0;
+  if (ell_max > 19) return false;  // output slots of a lane: x' = 4 r + g and 16 + g
+  int ka, kb, tab = 0, kmax = 0;
   for (int l = ell_min; l <= ell_max; ++l) {
-    rr_shape(l, &kpad, &ntl);
+    rr_shape(l, &ka, &kb);
     P->tab_off[l - ell_min] = tab;
-    tab += kpad * 16 * ntl;
-    kmax = kpad > kmax ? kpad : kmax;
-    nt_max = ntl > nt_max ? ntl : nt_max;
+    tab += rr_table_doubles(l);
+    kmax = ka + kb > kmax ? ka + kb : kmax;
   }
-  if (nt_max > 3) return false;
   P->ell_min = ell_min;
   P->ell_max = ell_max;
   P->tab_doubles = tab;
   P->kpad_max = kmax;
-  const size_t bytes = sizeof(double) * ((size_t)tab + (size_t)RR_WAVES * kmax * 32);
+  // 12 waves (three per SIMD, 168 registers each) where the row slots of a lane leave room for them, else 8
+  P->waves = ell_max <= 11 ? 12 : 8;
+  if (const char* e = getenv("SCRI_AMD_ROTATE_WAVES")) P->waves = atoi(e) == 12 ? 12 : 8;
+  const size_t bytes = sizeof(double) * ((size_t)tab + (size_t)P->waves * (kmax + 1) * 32);  // + the dump row of a wave
   if (bytes > 160u * 1024u) return false;
   *lds_bytes = bytes;
-  // l groups: contiguous, similar MFMA cost (ntl * kpad / 4 products per stage + a constant per l)
+  // l groups: contiguous, similar MFMA cost ((ka + kb) / 4 products per stage + a constant per l)
   auto cost = [](int l) {
-    int k, t;
-    rr_shape(l, &k, &t);
-    return t * (k / 4) + 3;
+    int a, b;
+    rr_shape(l, &a, &b);
+    return (a + b) / 4 + 3;
   };
   int total = 0;
   for (int l = ell_min; l <= ell_max; ++l) total += cost(l);
@@ -387,19 +437,26 @@ bool rotate_resident_plan(int ell_min, int ell_max, RotResPlan* P, size_t* lds_b
   return true;
 }
 
-// LDS image of the tables: per l, T[y][16 (nt ^ swz(y)) + i] = Delta[y][x = 16 nt + i], zero padded
+// LDS image of the tables: per l, rows R = class A (iy = 0, 2, ..) then class B (iy = 1, 3, ..), each padded with zero rows,
+// columns x' = 0..l (m = x' >= 0):  T[R][x'] = Delta[iy(R)][l + x'] for x' < 16, then the side table [R][x' - 16] (l >= 16)
 void rotate_resident_pack(const RotResPlan& P, int ell, const double* Delta /* (2l+1)^2 row-major */, double* image) {
-  int kpad, ntl;
-  rr_shape(ell, &kpad, &ntl);
-  const int n = 2 * ell + 1, pd = 16 * ntl;
+  int ka, kb;
+  rr_shape(ell, &ka, &kb);
+  const int n = 2 * ell + 1;
   double* T = image + P.tab_off[ell - P.ell_min];
-  for (int e = 0; e < kpad * pd; ++e) T[e] = 0.0;
-  for (int y = 0; y < n; ++y)
-    for (int x = 0; x < n; ++x) {
-      const int nt = x / 16, i = x % 16;
-      const int pt = (ntl & 1) ? nt : (nt ^ (y & 1));
-      T[(size_t)y * pd + 16 * pt + i] = Delta[(size_t)y * n + x];
+  double* X = T + (ka + kb) * 16;
+  for (int e = 0; e < rr_table_doubles(ell); ++e) T[e] = 0.0;
+  for (int R = 0; R < ka + kb; ++R) {
+    const int iy = R < ka ? 2 * R : 2 * (R - ka) + 1;
+    if (iy >= n) continue;
+    for (int xp = 0; xp <= ell; ++xp) {
+      const double d = Delta[(size_t)iy * n + ell + xp];
+      if (xp < 16)
+        T[R * 16 + xp] = d;
+      else
+        X[R * 4 + xp - 16] = d;
     }
+  }
 }
 
 hipError_t launch_rotate_modes_resident(hipStream_t stream, double* data, long long n_times, long long ld, const double* RaRb,
@@ -409,23 +466,35 @@ hipError_t launch_rotate_modes_resident(hipStream_t stream, double* data, long l
   hipError_t e;
   (void)counter;
   const long long n_units = ((n_times + 15) / 16) * P.n_groups;
-  long long blocks = (n_units + RR_WAVES - 1) / RR_WAVES;
+  long long blocks = (n_units + P.waves - 1) / P.waves;
   if (blocks > n_cu) blocks = n_cu;
-  int nt_max = (2 * P.ell_max + 1 + 15) / 16;
-#define RR_LAUNCH(NT)                                                                                                        \
+  if (ld * 256 > 0x7ffe0000LL) return hipErrorInvalidValue;  // 32-bit byte offsets within a 16-row tile
+  int ka, kb;
+  rr_shape(P.ell_max, &ka, &kb);
+  const int nu = ka / 2;
+#define RR_LAUNCH(NU, W)                                                                                                     \
   {                                                                                                                          \
-    e = hipFuncSetAttribute((const void*)rotate_modes_resident_kernel<NT>, hipFuncAttributeMaxDynamicSharedMemorySize,        \
+    e = hipFuncSetAttribute((const void*)rotate_modes_resident_kernel<NU, W>, hipFuncAttributeMaxDynamicSharedMemorySize,     \
                             (int)lds_bytes);                                                                                 \
     if (e != hipSuccess) return e;                                                                                           \
-    hipLaunchKernelGGL(rotate_modes_resident_kernel<NT>, dim3((unsigned)blocks), dim3(RR_THREADS), lds_bytes, stream, data,  \
-                       n_times, ld, RaRb, rotor_stride, tab_global, P, counter);                                             \
+    hipLaunchKernelGGL((rotate_modes_resident_kernel<NU, W>), dim3((unsigned)blocks), dim3(64 * W), lds_bytes, stream, data, \
+                       n_times, ld, RaRb, rotor_stride, tab_global, P);                                                      \
   }
-  if (nt_max <= 1)
-    RR_LAUNCH(1)
-  else if (nt_max <= 2)
-    RR_LAUNCH(2)
-  else
-    RR_LAUNCH(3)
+#define RR_LAUNCH_W(NU)  \
+  if (P.waves == 12)     \
+    RR_LAUNCH(NU, 12)    \
+  else                   \
+    RR_LAUNCH(NU, 8)
+  if (nu <= 4) {
+    RR_LAUNCH_W(4)
+  } else if (nu <= 6) {
+    RR_LAUNCH_W(6)
+  } else if (nu <= 8) {
+    RR_LAUNCH_W(8)
+  } else {
+    RR_LAUNCH_W(10)
+  }
+#undef RR_LAUNCH_W
 #undef RR_LAUNCH
   return hipGetLastError();
 }
