@@ -62,78 +62,66 @@ struct RRAcc {
   v4dq P_re, P_im, Q_re, Q_im;
   double p_re, p_im, q_re, q_im;  // X16
 };
-template <bool PHASE, bool X16>
+template <bool PHASE, bool X16, int MAXQ>
 __device__ __forceinline__ void rr_products(const double2* __restrict__ bpA, const double2* __restrict__ bpB,
                                             const double* __restrict__ ap, const double* __restrict__ ax, int cqA, int cqT, cplx wA,
                                             cplx wB, cplx w8, RRAcc& C) {
-  C.P_re = C.P_im = C.Q_re = C.Q_im = v4dq{0, 0, 0, 0};
-  C.p_re = C.p_im = C.q_re = C.q_im = 0.0;
-  auto fetch = [&](int j, double2& b, double& a, double& x) {
-    b = (j < cqA ? bpA : bpB)[j * 64];
-    a = ap[64 * j];
-    if (X16) x = ax[16 * j];
+  // k steps unrolled up to the largest count of the l range (every bound is wave-uniform: scalar branches); two operand
+  // sets, the first step of a class starts its accumulators from the zero operand
+  double2 b[2];
+  double a[2], x[2] = {0.0, 0.0};
+  auto fetch = [&](int j, int s) {
+    b[s] = (j < cqA ? bpA : bpB)[j * 64];
+    a[s] = ap[64 * j];
+    if (X16) x[s] = ax[16 * j];
   };
+  fetch(0, 0);
   cplx w = wA;
-  auto stepP = [&](double2 b, double a, double x) {
-    if (PHASE) {
-      const double br = b.x * w.re - b.y * w.im, bi = b.x * w.im + b.y * w.re;
-      b.x = br;
-      b.y = bi;
-      w = cmul(w, w8);
+  const v4dq Z = {0.0, 0.0, 0.0, 0.0};
+  if (X16) C.p_re = C.p_im = C.q_re = C.q_im = 0.0;
+#pragma unroll
+  for (int j = 0; j < MAXQ; ++j) {
+    if (j < cqT) {
+      if (j + 1 < MAXQ && j + 1 < cqT) fetch(j + 1, (j + 1) & 1);
+      double2 bb = b[j & 1];
+      const double aa = a[j & 1], xx = x[j & 1];
+      if (PHASE) {
+        if (j == cqA) w = wB;
+        const double br = bb.x * w.re - bb.y * w.im, bi = bb.x * w.im + bb.y * w.re;
+        bb.x = br;
+        bb.y = bi;
+        w = cmul(w, w8);
+      }
+      if (j == 0) {
+        C.P_re = __builtin_amdgcn_mfma_f64_16x16x4f64(aa, bb.x, Z, 0, 0, 0);
+        C.P_im = __builtin_amdgcn_mfma_f64_16x16x4f64(aa, bb.y, Z, 0, 0, 0);
+        if (X16) {
+          C.p_re = __builtin_amdgcn_mfma_f64_4x4x4f64(xx, bb.x, 0.0, 0, 0, 0);
+          C.p_im = __builtin_amdgcn_mfma_f64_4x4x4f64(xx, bb.y, 0.0, 0, 0, 0);
+        }
+      } else if (j < cqA) {
+        C.P_re = __builtin_amdgcn_mfma_f64_16x16x4f64(aa, bb.x, C.P_re, 0, 0, 0);
+        C.P_im = __builtin_amdgcn_mfma_f64_16x16x4f64(aa, bb.y, C.P_im, 0, 0, 0);
+        if (X16) {
+          C.p_re = __builtin_amdgcn_mfma_f64_4x4x4f64(xx, bb.x, C.p_re, 0, 0, 0);
+          C.p_im = __builtin_amdgcn_mfma_f64_4x4x4f64(xx, bb.y, C.p_im, 0, 0, 0);
+        }
+      } else if (j == cqA) {
+        C.Q_re = __builtin_amdgcn_mfma_f64_16x16x4f64(aa, bb.x, Z, 0, 0, 0);
+        C.Q_im = __builtin_amdgcn_mfma_f64_16x16x4f64(aa, bb.y, Z, 0, 0, 0);
+        if (X16) {
+          C.q_re = __builtin_amdgcn_mfma_f64_4x4x4f64(xx, bb.x, 0.0, 0, 0, 0);
+          C.q_im = __builtin_amdgcn_mfma_f64_4x4x4f64(xx, bb.y, 0.0, 0, 0, 0);
+        }
+      } else {
+        C.Q_re = __builtin_amdgcn_mfma_f64_16x16x4f64(aa, bb.x, C.Q_re, 0, 0, 0);
+        C.Q_im = __builtin_amdgcn_mfma_f64_16x16x4f64(aa, bb.y, C.Q_im, 0, 0, 0);
+        if (X16) {
+          C.q_re = __builtin_amdgcn_mfma_f64_4x4x4f64(xx, bb.x, C.q_re, 0, 0, 0);
+          C.q_im = __builtin_amdgcn_mfma_f64_4x4x4f64(xx, bb.y, C.q_im, 0, 0, 0);
+        }
+      }
     }
-    C.P_re = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b.x, C.P_re, 0, 0, 0);
-    C.P_im = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b.y, C.P_im, 0, 0, 0);
-    if (X16) {
-      C.p_re = __builtin_amdgcn_mfma_f64_4x4x4f64(x, b.x, C.p_re, 0, 0, 0);
-      C.p_im = __builtin_amdgcn_mfma_f64_4x4x4f64(x, b.y, C.p_im, 0, 0, 0);
-    }
-  };
-  auto stepQ = [&](double2 b, double a, double x) {
-    if (PHASE) {
-      const double br = b.x * w.re - b.y * w.im, bi = b.x * w.im + b.y * w.re;
-      b.x = br;
-      b.y = bi;
-      w = cmul(w, w8);
-    }
-    C.Q_re = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b.x, C.Q_re, 0, 0, 0);
-    C.Q_im = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b.y, C.Q_im, 0, 0, 0);
-    if (X16) {
-      C.q_re = __builtin_amdgcn_mfma_f64_4x4x4f64(x, b.x, C.q_re, 0, 0, 0);
-      C.q_im = __builtin_amdgcn_mfma_f64_4x4x4f64(x, b.y, C.q_im, 0, 0, 0);
-    }
-  };
-  // two register sets; which of them holds the first step of class B depends on the parity of cqA
-  double2 b0, b1;
-  double a0, a1, x0 = 0.0, x1 = 0.0;
-  fetch(0, b0, a0, x0);
-  int j = 0;
-  for (; j + 2 <= cqA; j += 2) {
-    fetch(j + 1, b1, a1, x1);
-    stepP(b0, a0, x0);
-    fetch(j + 2, b0, a0, x0);  // j + 2 <= cqA < cqT: always a valid step
-    stepP(b1, a1, x1);
-  }
-  if (j < cqA) {
-    fetch(j + 1, b1, a1, x1);
-    stepP(b0, a0, x0);
-    ++j;
-    w = wB;
-    for (; j + 2 <= cqT; j += 2) {
-      fetch(j + 1, b0, a0, x0);
-      stepQ(b1, a1, x1);
-      if (j + 2 < cqT) fetch(j + 2, b1, a1, x1);
-      stepQ(b0, a0, x0);
-    }
-    if (j < cqT) stepQ(b1, a1, x1);
-  } else {
-    w = wB;
-    for (; j + 2 <= cqT; j += 2) {
-      fetch(j + 1, b1, a1, x1);
-      stepQ(b0, a0, x0);
-      if (j + 2 < cqT) fetch(j + 2, b0, a0, x0);
-      stepQ(b1, a1, x1);
-    }
-    if (j < cqT) stepQ(b0, a0, x0);
   }
 }
 
@@ -174,7 +162,7 @@ __device__ __forceinline__ void rr_setup(RRLane& L, cplx Ra, cplx Rb, int ell) {
 // Both stages, the phase between them and the stores of one l.  A lane's outputs are x = x' and -x', x' = 4 r + g (slots
 // r = 0..3) and 16 + g (slot 4, X16: l = 16..19).  `rsrc` covers the 16 rows of the tile; `col0` = byte offset of this l's first
 // mode in the lane's row.
-template <bool X16>
+template <bool X16, int MAXQ>
 __device__ __forceinline__ void rr_one_ell(double2* __restrict__ S2, int dump, const double* __restrict__ Tl, int ell, int ka, int kb,
                                            __amdgpu_buffer_rsrc_t rsrc, int col0, const double* __restrict__ row,
                                            const double* __restrict__ rotor, const RRLane& L) {
@@ -186,7 +174,7 @@ __device__ __forceinline__ void rr_one_ell(double2* __restrict__ S2, int dump, c
   const double* ax = Tl + (ka + kb) * 16 + L.g * 4 + (L.l15 & 3);
   RRAcc C;
   // stage 1: c_x = sum_y T[y][x] q1^y f_y
-  rr_products<true, X16>(bpA, bpB, ap, ax, cqA, cqT, L.s1, cmul(L.s1, L.q1), L.q1_8, C);
+  rr_products<true, X16, MAXQ>(bpA, bpB, ap, ax, cqA, cqT, L.s1, cmul(L.s1, L.q1), L.q1_8, C);
   {
     // h_{+-x'} = q2^(+-x') (P +- Q) back into the image: rows iy = l +- x' are of one class c (x' = g mod 2), at position
     // iy >> 1 of it; positions 4 apart share the swizzle key, so two addresses per sign serve all slots.  Outputs beyond l
@@ -198,19 +186,21 @@ __device__ __forceinline__ void rr_one_ell(double2* __restrict__ S2, int dump, c
     cplx v = L.v2;
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
-      const int r = j & 3, xp = 4 * j + L.g;
-      const double pr = j < 4 ? C.P_re[r] : C.p_re, pi = j < 4 ? C.P_im[r] : C.p_im;
-      const double qr = j < 4 ? C.Q_re[r] : C.q_re, qi = j < 4 ? C.Q_im[r] : C.q_im;
-      const double sr = pr + qr, si = pi + qi, dr = pr - qr, di = pi - qi;
-      const int step = 64 * (j >> 1);
-      const bool ok = xp <= ell;
-      S2[ok ? ((j & 1) ? ap1 : ap0) + step : dump] = double2{sr * v.re - si * v.im, sr * v.im + si * v.re};
-      S2[ok && xp > 0 ? ((j & 1) ? am1 : am0) - step : dump] = double2{dr * v.re + di * v.im, di * v.re - dr * v.im};
-      if (j + 1 < NJ) v = cmul(v, L.q2_4);
+      if (4 * j <= ell) {  // (wave-uniform: slots whose columns all lie beyond l are skipped)
+        const int r = j & 3, xp = 4 * j + L.g;
+        const double pr = j < 4 ? C.P_re[r] : C.p_re, pi = j < 4 ? C.P_im[r] : C.p_im;
+        const double qr = j < 4 ? C.Q_re[r] : C.q_re, qi = j < 4 ? C.Q_im[r] : C.q_im;
+        const double sr = pr + qr, si = pi + qi, dr = pr - qr, di = pi - qi;
+        const int step = 64 * (j >> 1);
+        const bool ok = xp <= ell;
+        S2[ok ? ((j & 1) ? ap1 : ap0) + step : dump] = double2{sr * v.re - si * v.im, sr * v.im + si * v.re};
+        S2[ok && xp > 0 ? ((j & 1) ? am1 : am0) - step : dump] = double2{dr * v.re + di * v.im, di * v.re - dr * v.im};
+        if (j + 1 < NJ && 4 * (j + 1) <= ell) v = cmul(v, L.q2_4);
+      }
     }
   }
   // stage 2: o_x = p3^x sum_y T[y][x] h_y
-  rr_products<false, X16>(bpA, bpB, ap, ax, cqA, cqT, cplx{1.0, 0.0}, cplx{1.0, 0.0}, cplx{1.0, 0.0}, C);
+  rr_products<false, X16, MAXQ>(bpA, bpB, ap, ax, cqA, cqT, cplx{1.0, 0.0}, cplx{1.0, 0.0}, cplx{1.0, 0.0}, C);
   cplx e2 = {1.0, 0.0};
   const bool special = L.live && (L.z_only || L.flip);
   if (L.any_special && special) {
@@ -224,29 +214,37 @@ __device__ __forceinline__ void rr_one_ell(double2* __restrict__ S2, int dump, c
   cplx v = L.v3;
 #pragma unroll
   for (int j = 0; j < NJ; ++j) {
-    const int r = j & 3, xp = 4 * j + L.g;
-    const double pr = j < 4 ? C.P_re[r] : C.p_re, pi = j < 4 ? C.P_im[r] : C.p_im;
-    const double qr = j < 4 ? C.Q_re[r] : C.q_re, qi = j < 4 ? C.Q_im[r] : C.q_im;
-    const double sr = pr + qr, si = pi + qi, dr = pr - qr, di = pi - qi;
-    double2 op = double2{sr * v.re - si * v.im, sr * v.im + si * v.re};
-    double2 om = double2{dr * v.re + di * v.im, di * v.re - dr * v.im};
-    if (j + 1 < NJ) v = cmul(v, L.p3_4);
-    const bool ok = xp <= ell;
-    if (L.any_special) {
-      if (special && ok) {
-        // z_only: D_mm = ea^(2m);  flip: D_{-m,m} = (-1)^(l-m) eb^(2m), out_m = f_{-m} D_{-m,m}
-        const double2 fa = *reinterpret_cast<const double2*>(row + 2 * (ell + xp));
-        const double2 fb = *reinterpret_cast<const double2*>(row + 2 * (ell - xp));
-        const double2 fp = L.z_only ? fa : fb, fm = L.z_only ? fb : fa;
-        cplx wv = cpow_unit(e2, xp);
-        if (!L.z_only && ((ell - xp) & 1)) wv = {-wv.re, -wv.im};
-        const cplx vp = cmul(cplx{fp.x, fp.y}, wv), vm = cmul(cplx{fm.x, fm.y}, cconj(wv));
-        op = double2{vp.re, vp.im};
-        om = double2{vm.re, vm.im};
+    // every slot issues its two stores (the number of stores of an iteration is what the wait for the next rows counts on);
+    // slots whose columns all lie beyond l (wave-uniform) store nothing: offsets out of range, no arithmetic
+    double2 op = double2{0.0, 0.0}, om = double2{0.0, 0.0};
+    int offp = RR_OOB, offm = RR_OOB;
+    if (4 * j <= ell) {
+      const int r = j & 3, xp = 4 * j + L.g;
+      const double pr = j < 4 ? C.P_re[r] : C.p_re, pi = j < 4 ? C.P_im[r] : C.p_im;
+      const double qr = j < 4 ? C.Q_re[r] : C.q_re, qi = j < 4 ? C.Q_im[r] : C.q_im;
+      const double sr = pr + qr, si = pi + qi, dr = pr - qr, di = pi - qi;
+      op = double2{sr * v.re - si * v.im, sr * v.im + si * v.re};
+      om = double2{dr * v.re + di * v.im, di * v.re - dr * v.im};
+      if (j + 1 < NJ && 4 * (j + 1) <= ell) v = cmul(v, L.p3_4);
+      const bool ok = xp <= ell;
+      if (L.any_special) {
+        if (special && ok) {
+          // z_only: D_mm = ea^(2m);  flip: D_{-m,m} = (-1)^(l-m) eb^(2m), out_m = f_{-m} D_{-m,m}
+          const double2 fa = *reinterpret_cast<const double2*>(row + 2 * (ell + xp));
+          const double2 fb = *reinterpret_cast<const double2*>(row + 2 * (ell - xp));
+          const double2 fp = L.z_only ? fa : fb, fm = L.z_only ? fb : fa;
+          cplx wv = cpow_unit(e2, xp);
+          if (!L.z_only && ((ell - xp) & 1)) wv = {-wv.re, -wv.im};
+          const cplx vp = cmul(cplx{fp.x, fp.y}, wv), vm = cmul(cplx{fm.x, fm.y}, cconj(wv));
+          op = double2{vp.re, vp.im};
+          om = double2{vm.re, vm.im};
+        }
       }
+      offp = ok ? col0 + 16 * (ell + xp) : RR_OOB;
+      offm = ok && xp > 0 ? col0 + 16 * (ell - xp) : RR_OOB;
     }
-    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4iq, op), rsrc, ok ? col0 + 16 * (ell + xp) : RR_OOB, 0, 0);
-    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4iq, om), rsrc, ok && xp > 0 ? col0 + 16 * (ell - xp) : RR_OOB, 0, 0);
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4iq, op), rsrc, offp, 0, 0);
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4iq, om), rsrc, offm, 0, 0);
   }
 }
 
@@ -285,8 +283,6 @@ __global__ __launch_bounds__(64 * W, 1) void rotate_modes_resident_kernel(double
   // work units (16-step tile, l group) are dealt round-robin to the waves of the launch; the group a wave gets rotates
   // from round to round so that every wave sees every group (their costs differ)
   const unsigned int n_waves = gridDim.x * W;
-  unsigned int round = 0;
-  unsigned int unit = blockIdx.x * W + wave;
   auto unit_tile = [&](unsigned int u) { return (long long)(u / P.n_groups) * 16; };
   auto unit_group = [&](unsigned int u, unsigned int rnd) { return (int)((u % P.n_groups + rnd) % P.n_groups); };
   // descriptor of the rows of a tile: rows beyond the series are out of range (loads give zero, stores are dropped)
@@ -298,8 +294,11 @@ __global__ __launch_bounds__(64 * W, 1) void rotate_modes_resident_kernel(double
   auto fetch = [&](__amdgpu_buffer_rsrc_t rs, int ell) {
     const int n = 2 * ell + 1, col = (ell * ell - P.ell_min * P.ell_min) * 16 + off_load;
 #pragma unroll
-    for (int u = 0; u < NU; ++u)
-      F[u] = __builtin_bit_cast(double2, __builtin_amdgcn_raw_buffer_load_b128(rs, 4 * u + lk < n ? col + 64 * u : RR_OOB, 0, 0));
+    for (int u = 0; u < NU; ++u) {
+      int off = RR_OOB;  // (slots wholly beyond the row, wave-uniform, skip the arithmetic but still issue their load)
+      if (4 * u < n) off = 4 * u + lk < n ? col + 64 * u : RR_OOB;
+      F[u] = __builtin_bit_cast(double2, __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0));
+    }
   };
   // rotor of time step t0 + l15 (the last step's for lanes beyond the series: their results are never stored)
   auto load_rotor = [&](long long t0, double2& a, double2& b) {
@@ -310,28 +309,57 @@ __global__ __launch_bounds__(64 * W, 1) void rotate_modes_resident_kernel(double
     b = r[1];
   };
 
-  if (unit >= n_units) return;
-  long long t0 = unit_tile(unit);
-  int grp = unit_group(unit, round);
-  int ell = P.grp_lo[grp], ell_hi = P.grp_hi[grp];
+  // position in a wave's sequence of (unit, l) steps
+  struct Step {
+    unsigned int unit, round;
+    long long t0;
+    int ell, ell_hi;
+    bool done;
+  };
+  auto enter_unit = [&](Step& s) {
+    s.done = s.unit >= n_units;
+    if (!s.done) {
+      s.t0 = unit_tile(s.unit);
+      const int grp = unit_group(s.unit, s.round);
+      s.ell = P.grp_lo[grp];
+      s.ell_hi = P.grp_hi[grp];
+    }
+  };
+  auto advance = [&](Step& s) {
+    if (s.ell < s.ell_hi) {
+      ++s.ell;
+    } else {
+      s.unit += n_waves;
+      ++s.round;
+      enter_unit(s);
+    }
+  };
+  Step cur;
+  cur.unit = blockIdx.x * W + wave;
+  cur.round = 0;
+  enter_unit(cur);
+  if (cur.done) return;
   double2 Ra_n, Rb_n;
-  load_rotor(t0, Ra_n, Rb_n);
-  __amdgpu_buffer_rsrc_t rs_next = tile_rsrc(t0);
-  fetch(rs_next, ell);
-  // The wait for these rows at the top of the loop must let the (younger) stores of the previous l stay in flight.  The
+  load_rotor(cur.t0, Ra_n, Rb_n);
+  __amdgpu_buffer_rsrc_t rs_cur = tile_rsrc(cur.t0);
+  fetch(rs_cur, cur.ell);
+  Step n1 = cur;
+  advance(n1);
+  // The wait for the rows at the top of the loop must let the (younger) stores of the previous l stay in flight.  The
   // compiler merges the loop entry with the back edge and takes the smaller vmcnt; with as many (out-of-range, dropped)
   // stores behind the first fetch as an iteration issues behind the others, both agree.
 #pragma unroll
-  for (int j = 0; j < 8; ++j) __builtin_amdgcn_raw_buffer_store_b128(v4iq{j, 0, 0, 0}, rs_next, RR_OOB + 256 * j + 16 * lane, 0, 0);
+  for (int j = 0; j < 8; ++j)
+    __builtin_amdgcn_raw_buffer_store_b128(v4iq{j, 0, 0, 0}, rs_cur, RR_OOB + 256 * j + 16 * lane, 0, 0);
   RRLane L;
   L.g = g;
   L.l15 = l15;
-  L.live = t0 + l15 < n_times;
-  rr_setup(L, cplx{Ra_n.x, Ra_n.y}, cplx{Rb_n.x, Rb_n.y}, ell);
+  L.live = cur.t0 + l15 < n_times;
+  rr_setup(L, cplx{Ra_n.x, Ra_n.y}, cplx{Rb_n.x, Rb_n.y}, cur.ell);
 
   for (;;) {
     int ka, kb;
-    rr_shape(ell, &ka, &kb);
+    rr_shape(cur.ell, &ka, &kb);
     // ---- rows of this l -> LDS image [class A rows | class B rows][time]; the padding rows of both classes are written
     // too (F holds zeros there)
     {
@@ -340,47 +368,39 @@ __global__ __launch_bounds__(64 * W, 1) void rotate_modes_resident_kernel(double
       for (int u = 0; u < NU; ++u)
         if (2 * u < ka) S2[!cls || 2 * u + half0 < kb ? (rb + 2 * u) * 16 + (slot_e ^ ((u & 1) << 2)) : dump] = F[u];
     }
-    // ---- what comes next: the next l of this unit, or the first l of the next unit (its rows and rotor are requested now
-    // and arrive under the products below)
-    const long long t0_cur = t0;
-    const int ell_cur = ell;
-    const __amdgpu_buffer_rsrc_t rs_cur = rs_next;
-    bool new_unit = false, done = false;
-    if (ell < ell_hi) {
-      ++ell;
-    } else {
-      unit += n_waves;
-      ++round;
-      if (unit >= n_units) {
-        done = true;
-      } else {
-        new_unit = true;
-        t0 = unit_tile(unit);
-        grp = unit_group(unit, round);
-        ell = P.grp_lo[grp];
-        ell_hi = P.grp_hi[grp];
-        load_rotor(t0, Ra_n, Rb_n);
-        rs_next = tile_rsrc(t0);
-      }
-    }
-    if (!done) fetch(rs_next, ell);
-
-    const double* Tl = lds + P.tab_off[ell_cur - P.ell_min];
-    const long long tm = t0_cur + l15;
-    const int col0 = (ell_cur * ell_cur - P.ell_min * P.ell_min) * 16 + off_store;
-    const double* row = data + (tm * ld + ((long long)ell_cur * ell_cur - (long long)P.ell_min * P.ell_min)) * 2;
-    const double* rot = RaRb + tm * rotor_stride;
-    if (ANYX && ell_cur >= 16)
-      rr_one_ell<true>(S2, dump, Tl, ell_cur, ka, kb, rs_cur, col0, row, rot, L);
-    else
-      rr_one_ell<false>(S2, dump, Tl, ell_cur, ka, kb, rs_cur, col0, row, rot, L);
-    if (done) break;
+    // ---- what comes next: the next l of this unit, or the first l of the next unit -- its rows (and rotor) are requested now
+    // and arrive under the products below
+    const bool new_unit = !n1.done && n1.unit != cur.unit;
+    __amdgpu_buffer_rsrc_t rs_next = rs_cur;
     if (new_unit) {
-      L.live = t0 + l15 < n_times;
-      rr_setup(L, cplx{Ra_n.x, Ra_n.y}, cplx{Rb_n.x, Rb_n.y}, ell);
+      load_rotor(n1.t0, Ra_n, Rb_n);
+      rs_next = tile_rsrc(n1.t0);
+    }
+    if (!n1.done) fetch(rs_next, n1.ell);
+
+    const double* Tl = lds + P.tab_off[cur.ell - P.ell_min];
+    const long long tm = cur.t0 + l15;
+    const int col0 = (cur.ell * cur.ell - P.ell_min * P.ell_min) * 16 + off_store;
+    const double* row = data + (tm * ld + ((long long)cur.ell * cur.ell - (long long)P.ell_min * P.ell_min)) * 2;
+    const double* rot = RaRb + tm * rotor_stride;
+    // (with the two instances in one kernel the compiler's vmcnt bookkeeping at their join forgets that the stores are younger
+    // than the rows in flight: an iteration of these kernels starts by draining its predecessor's stores.  Measured, that
+    // costs less than running the side products of l >= 16 behind a run-time flag in a single instance: 2.45 vs 2.55 ms per
+    // 1e6 steps at l <= 16)
+    if (ANYX && cur.ell >= 16)
+      rr_one_ell<true, NU>(S2, dump, Tl, cur.ell, ka, kb, rs_cur, col0, row, rot, L);
+    else
+      rr_one_ell<false, NU>(S2, dump, Tl, cur.ell, ka, kb, rs_cur, col0, row, rot, L);
+    if (n1.done) break;
+    if (new_unit) {
+      L.live = n1.t0 + l15 < n_times;
+      rr_setup(L, cplx{Ra_n.x, Ra_n.y}, cplx{Rb_n.x, Rb_n.y}, n1.ell);
     } else {
       L.s1 = cmul(L.s1, cconj(L.q1));
     }
+    cur = n1;
+    rs_cur = rs_next;
+    advance(n1);
   }
 }
 
@@ -472,7 +492,7 @@ hipError_t launch_rotate_modes_resident(hipStream_t stream, double* data, long l
   int ka, kb;
   rr_shape(P.ell_max, &ka, &kb);
   const int nu = ka / 2;
-#define RR_LAUNCH(NU, W)                                                                                                     \
+#define RR_LAUNCH(NU, W)                                                                                                       \
   {                                                                                                                          \
     e = hipFuncSetAttribute((const void*)rotate_modes_resident_kernel<NU, W>, hipFuncAttributeMaxDynamicSharedMemorySize,     \
                             (int)lds_bytes);                                                                                 \
