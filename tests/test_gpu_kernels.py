@@ -62,6 +62,26 @@ def test_rotate_series_matches_oracle(ctx, ell_min, ell_max):
     assert np.abs(got - expect).max() < 1e-13 * ell_max
 
 
+@pytest.mark.parametrize("ell_min,ell_max,n", [(0, 0, 50), (1, 1, 17), (0, 3, 37), (3, 7, 16), (5, 11, 1), (7, 12, 100), (12, 15, 33),
+                                               (14, 19, 41), (16, 19, 64), (15, 16, 23), (2, 16, 1600)])
+def test_rotate_series_resident_kernel_shapes(ctx, ell_min, ell_max, n):
+    """Every shape the LDS-resident rotation kernel distinguishes (kernels_rotate_resident.hip): row slots 4 / 6 / 8 / 10 per lane,
+    12- and 8-wave builds, the side columns 16..19 of l >= 16, single-l ranges (every step a new work unit), l from 0 (class B of
+    padding rows only), series shorter than / not a multiple of the 16-step tile; special rotors mixed in."""
+    from scri_amd import engine
+
+    rng = np.random.default_rng(100 * ell_min + ell_max)
+    nm = wigner.LM_total_size(ell_min, ell_max)
+    data = rng.normal(size=(n, nm)) + 1j * rng.normal(size=(n, nm))
+    R = _rotors(11, n)
+    k = min(n, 100)
+    R[:k:3] = samples.Rs()[:k:3][: len(R[:k:3])]
+    sp = quat.as_spinor_array(R)
+    expect = rotations_ref.rotate_by_series(data, sp, ell_min, ell_max)
+    got = engine.rotate_series(data.copy(), ell_min, ell_max, sp, ctx=ctx)
+    assert np.abs(got - expect).max() < 1e-13 * max(ell_max, 1)
+
+
 def test_rotate_const_and_identity_bit_exact(ctx):
     from scri_amd import engine
 
