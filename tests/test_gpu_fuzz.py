@@ -105,3 +105,42 @@ def test_random_abd_transform(ctx, seed):
     if expect.n_times:
         assert np.abs(got.u - expect.u).max() < 1e-12, info
         assert np.abs(got._raw_data - expect.raw).max() < 2e-12 * max(1.0, np.abs(expect.raw).max()), info
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_random_rotation(ctx, seed):
+    """Time-series and constant rotations (scri/rotations.py:346-392) over random l ranges (all three kernels: tables resident in
+    the LDS, staged per l, VALU), series lengths around the 16-step tile, row strides larger than the mode count (a view into
+    a wider array: the padding columns must come back untouched), special rotors mixed into the series."""
+    import torch
+    from oracle import quat, rotations_ref, wigner, sample_waveforms_ref as samples
+    from scri_amd import engine
+
+    rng = np.random.default_rng(9000 + seed)
+    top = [8, 16, 19, 24, 33, 36][int(rng.integers(6))]
+    ell_min = int(rng.integers(0, min(top, 15) + 1))
+    ell_max = int(rng.integers(ell_min, top + 1))
+    n = int(rng.choice([1, 2, 15, 16, 17, 31, 33, 100, 257, 700]))
+    nm = wigner.LM_total_size(ell_min, ell_max)
+    ld = nm + int(rng.choice([0, 0, 1, 3, 16]))
+    wide = rng.normal(size=(n, ld)) + 1j * rng.normal(size=(n, ld))
+    q = rng.normal(size=(n, 4))
+    q /= np.linalg.norm(q, axis=1)[:, None]
+    sp_rot = samples.Rs()
+    pick = rng.random(n) < 0.2
+    q[pick] = sp_rot[rng.integers(0, len(sp_rot), pick.sum())]
+    dev = torch.from_numpy(wide.copy()).cuda()
+    tol = 1e-13 * max(ell_max, 1)
+    if seed % 4 == 3:
+        engine.rotate_device(dev.data_ptr(), n, ld, ell_min, ell_max, quaternion=q[0], ctx=ctx)
+        Ra, Rb = quat.as_spinor_array(q[0])
+        expect = rotations_ref.rotate_by_constant(wide[:, :nm].copy(), ell_min, ell_max, wigner.wigner_D_matrices(Ra, Rb, ell_min, ell_max))
+    else:
+        sp = np.ascontiguousarray(quat.as_spinor_array(q))
+        sp_dev = torch.from_numpy(sp).cuda()
+        engine.rotate_device(dev.data_ptr(), n, ld, ell_min, ell_max, spinors_ptr=sp_dev.data_ptr(), ctx=ctx)
+        expect = rotations_ref.rotate_by_series(wide[:, :nm].copy(), sp, ell_min, ell_max)
+    ctx.synchronize()
+    got = dev.cpu().numpy()
+    assert np.abs(got[:, :nm] - expect).max() < tol, (seed, ell_min, ell_max, n, ld)
+    assert np.array_equal(got[:, nm:], wide[:, nm:]), (seed, "padding columns changed")
