@@ -550,24 +550,53 @@ static int rotate_impl(bms_ctx* c, void* data, int mem, int64_t n_times, int64_t
   const int64_t n_modes = LM_total_size(ell_min, ell_max);
   if (ld < n_modes) return fail(c, BMS_ERR_INVALID, "row stride %lld smaller than %lld modes", (long long)ld, (long long)n_modes);
   if (n_times == 0) return BMS_OK;
-  // three kernels: tables resident in the LDS (the l ranges of the headline configurations), tables staged per l
-  // (l <= 33), VALU beyond
-  bool use_res = false;
-  RotResPlan res_plan;
-  size_t res_lds = 0;
-  const double* d_res_tab = nullptr;
-  unsigned int* d_res_counter = nullptr;
+  // three kernels: tables resident in the LDS, tables staged per l (l <= 33), VALU beyond.  The l range is walked in
+  // segments: as many leading l as fit the LDS-resident kernel (l <= 27 and 160 KB: 2..16 of the headline configurations in
+  // one launch, 2..19 and 20..24 of an l <= 24 series), the rest through the staged / VALU kernel -- a segment is a column range of the
+  // same rows, so each launch gets the pointer of its first mode and the common row stride.
+  struct Segment {
+    int lo, hi, kind;  // 0 resident, 1 staged MFMA, 2 VALU
+    RotResPlan plan;
+    size_t lds;
+    const double* tab;
+  };
+  std::vector<Segment> segs;
   int rc = BMS_OK;
-  // (the resident kernel addresses a 16-row tile with 32-bit byte offsets)
-  if (!getenv("SCRI_AMD_ROTATE_VALU") && !getenv("SCRI_AMD_ROTATE_STAGED") && ld * 256 <= 0x7ffe0000LL)
-    if ((rc = ensure_delta_resident(c, ell_min, ell_max, &use_res, &res_plan, &res_lds, &d_res_tab, &d_res_counter))) return rc;
-  const bool use_mfma = !use_res && rotate_mfma_supported(ell_max) && !getenv("SCRI_AMD_ROTATE_VALU");
-  if (!use_res && !use_mfma && rotate_waves_per_block(ell_max) < 1)
-    return fail(c, BMS_ERR_UNSUPPORTED, "ell_max=%d too large for the rotation kernels", ell_max);
+  {
+    const bool allow_res = !getenv("SCRI_AMD_ROTATE_VALU") && !getenv("SCRI_AMD_ROTATE_STAGED") && ld * 256 <= 0x7ffe0000LL;
+    int l = ell_min;
+    while (l <= ell_max) {
+      Segment sg{};
+      bool placed = false;
+      if (allow_res) {
+        for (int hi = std::min(ell_max, 27); hi >= l && !placed; --hi) {
+          size_t lds = 0;
+          if (!rotate_resident_plan(l, hi, &sg.plan, &lds)) continue;
+          bool ok = false;
+          unsigned int* d_counter = nullptr;
+          if ((rc = ensure_delta_resident(c, l, hi, &ok, &sg.plan, &sg.lds, &sg.tab, &d_counter))) return rc;
+          if (!ok) continue;
+          sg.lo = l;
+          sg.hi = hi;
+          sg.kind = 0;
+          placed = true;
+        }
+      }
+      if (!placed) {
+        sg.lo = l;
+        sg.hi = ell_max;
+        sg.kind = (rotate_mfma_supported(ell_max) && !getenv("SCRI_AMD_ROTATE_VALU")) ? 1 : 2;
+        if (sg.kind == 2 && rotate_waves_per_block(ell_max) < 1)
+          return fail(c, BMS_ERR_UNSUPPORTED, "ell_max=%d too large for the rotation kernels", ell_max);
+      }
+      segs.push_back(sg);
+      l = sg.hi + 1;
+    }
+  }
   const double* d_delta = nullptr;
   const long long* d_off = nullptr;
-  if (!use_res) {
-    rc = use_mfma ? ensure_delta_mfma(c, ell_max, &d_delta, &d_off) : ensure_delta(c, ell_max, &d_delta, &d_off);
+  if (segs.back().kind != 0) {
+    rc = segs.back().kind == 1 ? ensure_delta_mfma(c, ell_max, &d_delta, &d_off) : ensure_delta(c, ell_max, &d_delta, &d_off);
     if (rc) return rc;
   }
   double* d_data = (double*)data;
@@ -586,13 +615,16 @@ static int rotate_impl(bms_ctx* c, void* data, int mem, int64_t n_times, int64_t
     if (rc) return rc;
     HIP_TRY(c, hipMemcpyAsync(d_data, data, data_bytes, hipMemcpyHostToDevice, c->stream));
   }
-  if (use_res)
-    TIMED(c, BMS_TAG_ROTATE, launch_rotate_modes_resident(c->stream, d_data, n_times, ld, d_rot, series ? 4 : 0, d_res_tab, res_plan, res_lds,
-                                                          d_res_counter, c->n_cu));
-  else if (use_mfma)
-    TIMED(c, BMS_TAG_ROTATE, launch_rotate_modes_mfma(c->stream, d_data, n_times, ld, ell_min, ell_max, d_rot, series ? 4 : 0, d_delta, d_off));
-  else
-    TIMED(c, BMS_TAG_ROTATE, launch_rotate_modes(c->stream, d_data, n_times, ld, ell_min, ell_max, d_rot, series ? 4 : 0, d_delta, d_off));
+  for (const Segment& sg : segs) {
+    double* seg_data = d_data + 2 * ((long long)sg.lo * sg.lo - (long long)ell_min * ell_min);
+    if (sg.kind == 0)
+      TIMED(c, BMS_TAG_ROTATE, launch_rotate_modes_resident(c->stream, seg_data, n_times, ld, d_rot, series ? 4 : 0, sg.tab, sg.plan, sg.lds,
+                                                            nullptr, c->n_cu));
+    else if (sg.kind == 1)
+      TIMED(c, BMS_TAG_ROTATE, launch_rotate_modes_mfma(c->stream, seg_data, n_times, ld, sg.lo, sg.hi, d_rot, series ? 4 : 0, d_delta, d_off));
+    else
+      TIMED(c, BMS_TAG_ROTATE, launch_rotate_modes(c->stream, seg_data, n_times, ld, sg.lo, sg.hi, d_rot, series ? 4 : 0, d_delta, d_off));
+  }
   if (mem == BMS_HOST) {
     HIP_TRY(c, hipMemcpyAsync(data, d_data, data_bytes, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));

@@ -47,44 +47,52 @@ BMS_HD void rr_shape(int ell, int* ka, int* kb) {
   *ka = 4 * ((ell + 4) / 4);
   *kb = ell > 4 ? 4 * ((ell + 3) / 4) : 4;
 }
-BMS_HD int rr_table_doubles(int ell) {
+// side columns of a kernel whose l range ends at l_max: 4 NX, NX = 0 (l_max <= 15), 1 (<= 19), 2 (<= 23), 3 (<= 27); every
+// l >= 16 of the range carries a side table of that width (zero beyond its own l)
+BMS_HD int rr_side_tiles(int ell_max) { return ell_max < 16 ? 0 : (ell_max - 16) / 4 + 1; }
+BMS_HD int rr_table_doubles(int ell, int nx) {
   int ka, kb;
   rr_shape(ell, &ka, &kb);
-  return (ka + kb) * (ell >= 16 ? 20 : 16);
+  return (ka + kb) * (ell >= 16 ? 16 + 4 * nx : 16);
 }
 
 // Both partial products of one stage: P[x][t] = sum over the class A rows, Q[x][t] = sum over the class B rows of
 // T[row][x] b_row(t); the rows of B follow those of A in the image and in the table (k steps 0..cqA-1, cqA..cqT-1), the
 // operands of k step j + 1 are requested before the MFMAs of step j are issued, across the class boundary too.
 // PHASE: multiply the operand by w (advanced by w8 per step: rows of a class are 2 apart in y) as it is read.
-// X16: columns x' = 16..19 through the 4-block 4x4x4 MFMA (same data operand; output lane (t, g) = column 16 + g).
+// NX > 0: columns x' = 16 + 4 i + (0..3), i < NX, through the 4-block 4x4x4 MFMA (same data operand; output lane (t, g) =
+// column 16 + 4 i + g).
+template <int NX>
 struct RRAcc {
   v4dq P_re, P_im, Q_re, Q_im;
-  double p_re, p_im, q_re, q_im;  // X16
+  double p_re[NX ? NX : 1], p_im[NX ? NX : 1], q_re[NX ? NX : 1], q_im[NX ? NX : 1];
 };
-template <bool PHASE, bool X16, int MAXQ>
+template <bool PHASE, int NX, int MAXQ>
 __device__ __forceinline__ void rr_products(const double2* __restrict__ bpA, const double2* __restrict__ bpB,
                                             const double* __restrict__ ap, const double* __restrict__ ax, int cqA, int cqT, cplx wA,
-                                            cplx wB, cplx w8, RRAcc& C) {
+                                            cplx wB, cplx w8, RRAcc<NX>& C) {
   // k steps unrolled up to the largest count of the l range (every bound is wave-uniform: scalar branches); two operand
   // sets, the first step of a class starts its accumulators from the zero operand
+  constexpr int NXA = NX ? NX : 1;
   double2 b[2];
-  double a[2], x[2] = {0.0, 0.0};
+  double a[2], x[2][NXA];
   auto fetch = [&](int j, int s) {
     b[s] = (j < cqA ? bpA : bpB)[j * 64];
     a[s] = ap[64 * j];
-    if (X16) x[s] = ax[16 * j];
+#pragma unroll
+    for (int i = 0; i < NX; ++i) x[s][i] = ax[16 * NX * j + 4 * i];
   };
   fetch(0, 0);
   cplx w = wA;
   const v4dq Z = {0.0, 0.0, 0.0, 0.0};
-  if (X16) C.p_re = C.p_im = C.q_re = C.q_im = 0.0;
+#pragma unroll
+  for (int i = 0; i < NX; ++i) C.p_re[i] = C.p_im[i] = C.q_re[i] = C.q_im[i] = 0.0;
 #pragma unroll
   for (int j = 0; j < MAXQ; ++j) {
     if (j < cqT) {
       if (j + 1 < MAXQ && j + 1 < cqT) fetch(j + 1, (j + 1) & 1);
       double2 bb = b[j & 1];
-      const double aa = a[j & 1], xx = x[j & 1];
+      const double aa = a[j & 1];
       if (PHASE) {
         if (j == cqA) w = wB;
         const double br = bb.x * w.re - bb.y * w.im, bi = bb.x * w.im + bb.y * w.re;
@@ -95,30 +103,34 @@ __device__ __forceinline__ void rr_products(const double2* __restrict__ bpA, con
       if (j == 0) {
         C.P_re = __builtin_amdgcn_mfma_f64_16x16x4f64(aa, bb.x, Z, 0, 0, 0);
         C.P_im = __builtin_amdgcn_mfma_f64_16x16x4f64(aa, bb.y, Z, 0, 0, 0);
-        if (X16) {
-          C.p_re = __builtin_amdgcn_mfma_f64_4x4x4f64(xx, bb.x, 0.0, 0, 0, 0);
-          C.p_im = __builtin_amdgcn_mfma_f64_4x4x4f64(xx, bb.y, 0.0, 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < NX; ++i) {
+          C.p_re[i] = __builtin_amdgcn_mfma_f64_4x4x4f64(x[j & 1][i], bb.x, 0.0, 0, 0, 0);
+          C.p_im[i] = __builtin_amdgcn_mfma_f64_4x4x4f64(x[j & 1][i], bb.y, 0.0, 0, 0, 0);
         }
       } else if (j < cqA) {
         C.P_re = __builtin_amdgcn_mfma_f64_16x16x4f64(aa, bb.x, C.P_re, 0, 0, 0);
         C.P_im = __builtin_amdgcn_mfma_f64_16x16x4f64(aa, bb.y, C.P_im, 0, 0, 0);
-        if (X16) {
-          C.p_re = __builtin_amdgcn_mfma_f64_4x4x4f64(xx, bb.x, C.p_re, 0, 0, 0);
-          C.p_im = __builtin_amdgcn_mfma_f64_4x4x4f64(xx, bb.y, C.p_im, 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < NX; ++i) {
+          C.p_re[i] = __builtin_amdgcn_mfma_f64_4x4x4f64(x[j & 1][i], bb.x, C.p_re[i], 0, 0, 0);
+          C.p_im[i] = __builtin_amdgcn_mfma_f64_4x4x4f64(x[j & 1][i], bb.y, C.p_im[i], 0, 0, 0);
         }
       } else if (j == cqA) {
         C.Q_re = __builtin_amdgcn_mfma_f64_16x16x4f64(aa, bb.x, Z, 0, 0, 0);
         C.Q_im = __builtin_amdgcn_mfma_f64_16x16x4f64(aa, bb.y, Z, 0, 0, 0);
-        if (X16) {
-          C.q_re = __builtin_amdgcn_mfma_f64_4x4x4f64(xx, bb.x, 0.0, 0, 0, 0);
-          C.q_im = __builtin_amdgcn_mfma_f64_4x4x4f64(xx, bb.y, 0.0, 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < NX; ++i) {
+          C.q_re[i] = __builtin_amdgcn_mfma_f64_4x4x4f64(x[j & 1][i], bb.x, 0.0, 0, 0, 0);
+          C.q_im[i] = __builtin_amdgcn_mfma_f64_4x4x4f64(x[j & 1][i], bb.y, 0.0, 0, 0, 0);
         }
       } else {
         C.Q_re = __builtin_amdgcn_mfma_f64_16x16x4f64(aa, bb.x, C.Q_re, 0, 0, 0);
         C.Q_im = __builtin_amdgcn_mfma_f64_16x16x4f64(aa, bb.y, C.Q_im, 0, 0, 0);
-        if (X16) {
-          C.q_re = __builtin_amdgcn_mfma_f64_4x4x4f64(xx, bb.x, C.q_re, 0, 0, 0);
-          C.q_im = __builtin_amdgcn_mfma_f64_4x4x4f64(xx, bb.y, C.q_im, 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < NX; ++i) {
+          C.q_re[i] = __builtin_amdgcn_mfma_f64_4x4x4f64(x[j & 1][i], bb.x, C.q_re[i], 0, 0, 0);
+          C.q_im[i] = __builtin_amdgcn_mfma_f64_4x4x4f64(x[j & 1][i], bb.y, C.q_im[i], 0, 0, 0);
         }
       }
     }
@@ -160,21 +172,21 @@ __device__ __forceinline__ void rr_setup(RRLane& L, cplx Ra, cplx Rb, int ell) {
 }
 
 // Both stages, the phase between them and the stores of one l.  A lane's outputs are x = x' and -x', x' = 4 r + g (slots
-// r = 0..3) and 16 + g (slot 4, X16: l = 16..19).  `rsrc` covers the 16 rows of the tile; `col0` = byte offset of this l's first
+// r = 0..3) and 16 + 4 i + g (slots 4 + i, i < NX: l >= 16).  `rsrc` covers the 16 rows of the tile; `col0` = byte offset of this l's first
 // mode in the lane's row.
-template <bool X16, int MAXQ>
+template <int NX, int MAXQ>
 __device__ __forceinline__ void rr_one_ell(double2* __restrict__ S2, int dump, const double* __restrict__ Tl, int ell, int ka, int kb,
                                            __amdgpu_buffer_rsrc_t rsrc, int col0, const double* __restrict__ row,
                                            const double* __restrict__ rotor, const RRLane& L) {
-  constexpr int NJ = X16 ? 5 : 4;
+  constexpr int NJ = 4 + NX;
   const int cqA = ka >> 2, cqT = (ka + kb) >> 2;
   const double2* bpA = S2 + L.g * 16 + (L.l15 ^ (L.g << 1));
   const double2* bpB = S2 + L.g * 16 + (L.l15 ^ ((L.g ^ 2) << 1));
   const double* ap = Tl + L.g * 16 + L.l15;
-  const double* ax = Tl + (ka + kb) * 16 + L.g * 4 + (L.l15 & 3);
-  RRAcc C;
+  const double* ax = Tl + (ka + kb) * 16 + L.g * 4 * NX + (L.l15 & 3);
+  RRAcc<NX> C;
   // stage 1: c_x = sum_y T[y][x] q1^y f_y
-  rr_products<true, X16, MAXQ>(bpA, bpB, ap, ax, cqA, cqT, L.s1, cmul(L.s1, L.q1), L.q1_8, C);
+  rr_products<true, NX, MAXQ>(bpA, bpB, ap, ax, cqA, cqT, L.s1, cmul(L.s1, L.q1), L.q1_8, C);
   {
     // h_{+-x'} = q2^(+-x') (P +- Q) back into the image: rows iy = l +- x' are of one class c (x' = g mod 2), at position
     // iy >> 1 of it; positions 4 apart share the swizzle key, so two addresses per sign serve all slots.  Outputs beyond l
@@ -188,8 +200,9 @@ __device__ __forceinline__ void rr_one_ell(double2* __restrict__ S2, int dump, c
     for (int j = 0; j < NJ; ++j) {
       if (4 * j <= ell) {  // (wave-uniform: slots whose columns all lie beyond l are skipped)
         const int r = j & 3, xp = 4 * j + L.g;
-        const double pr = j < 4 ? C.P_re[r] : C.p_re, pi = j < 4 ? C.P_im[r] : C.p_im;
-        const double qr = j < 4 ? C.Q_re[r] : C.q_re, qi = j < 4 ? C.Q_im[r] : C.q_im;
+        const int i = j < 4 ? 0 : j - 4;
+        const double pr = j < 4 ? C.P_re[r] : C.p_re[i], pi = j < 4 ? C.P_im[r] : C.p_im[i];
+        const double qr = j < 4 ? C.Q_re[r] : C.q_re[i], qi = j < 4 ? C.Q_im[r] : C.q_im[i];
         const double sr = pr + qr, si = pi + qi, dr = pr - qr, di = pi - qi;
         const int step = 64 * (j >> 1);
         const bool ok = xp <= ell;
@@ -200,7 +213,7 @@ __device__ __forceinline__ void rr_one_ell(double2* __restrict__ S2, int dump, c
     }
   }
   // stage 2: o_x = p3^x sum_y T[y][x] h_y
-  rr_products<false, X16, MAXQ>(bpA, bpB, ap, ax, cqA, cqT, cplx{1.0, 0.0}, cplx{1.0, 0.0}, cplx{1.0, 0.0}, C);
+  rr_products<false, NX, MAXQ>(bpA, bpB, ap, ax, cqA, cqT, cplx{1.0, 0.0}, cplx{1.0, 0.0}, cplx{1.0, 0.0}, C);
   cplx e2 = {1.0, 0.0};
   const bool special = L.live && (L.z_only || L.flip);
   if (L.any_special && special) {
@@ -220,8 +233,9 @@ __device__ __forceinline__ void rr_one_ell(double2* __restrict__ S2, int dump, c
     int offp = RR_OOB, offm = RR_OOB;
     if (4 * j <= ell) {
       const int r = j & 3, xp = 4 * j + L.g;
-      const double pr = j < 4 ? C.P_re[r] : C.p_re, pi = j < 4 ? C.P_im[r] : C.p_im;
-      const double qr = j < 4 ? C.Q_re[r] : C.q_re, qi = j < 4 ? C.Q_im[r] : C.q_im;
+      const int i = j < 4 ? 0 : j - 4;
+      const double pr = j < 4 ? C.P_re[r] : C.p_re[i], pi = j < 4 ? C.P_im[r] : C.p_im[i];
+      const double qr = j < 4 ? C.Q_re[r] : C.q_re[i], qi = j < 4 ? C.Q_im[r] : C.q_im[i];
       const double sr = pr + qr, si = pi + qi, dr = pr - qr, di = pi - qi;
       op = double2{sr * v.re - si * v.im, sr * v.im + si * v.re};
       om = double2{dr * v.re + di * v.im, di * v.re - dr * v.im};
@@ -248,13 +262,14 @@ __device__ __forceinline__ void rr_one_ell(double2* __restrict__ S2, int dump, c
   }
 }
 
-// NU = row slots of a lane in load orientation = KA(l_max) / 2: 4 (l <= 7), 6 (l <= 11), 8 (l <= 15), 10 (l <= 19)
+// NU = row slots of a lane in load orientation = KA(l_max) / 2: 4 (l <= 7), 6 (l <= 11), 8 (l <= 15), 10 (l <= 19), 12 (l <= 23),
+// 14 (l <= 27)
 template <int NU, int W>
 __global__ __launch_bounds__(64 * W, 1) void rotate_modes_resident_kernel(double* __restrict__ data, long long n_times,
                                                                               long long ld, const double* __restrict__ RaRb,
                                                                               long long rotor_stride,
                                                                               const double* __restrict__ tab_global, RotResPlan P) {
-  constexpr bool ANYX = NU > 8;
+  constexpr int NXK = NU > 8 ? (NU - 8) / 2 : 0;  // side tiles of the kernel (rr_side_tiles of its largest l)
   const long long n_modes = (long long)(P.ell_max + 1) * (P.ell_max + 1) - (long long)P.ell_min * P.ell_min;
   extern __shared__ double lds[];
   {
@@ -387,10 +402,10 @@ __global__ __launch_bounds__(64 * W, 1) void rotate_modes_resident_kernel(double
     // than the rows in flight: an iteration of these kernels starts by draining its predecessor's stores.  Measured, that
     // costs less than running the side products of l >= 16 behind a run-time flag in a single instance: 2.45 vs 2.55 ms per
     // 1e6 steps at l <= 16)
-    if (ANYX && cur.ell >= 16)
-      rr_one_ell<true, NU>(S2, dump, Tl, cur.ell, ka, kb, rs_cur, col0, row, rot, L);
+    if (NXK > 0 && cur.ell >= 16)
+      rr_one_ell<NXK, NU>(S2, dump, Tl, cur.ell, ka, kb, rs_cur, col0, row, rot, L);
     else
-      rr_one_ell<false, NU>(S2, dump, Tl, cur.ell, ka, kb, rs_cur, col0, row, rot, L);
+      rr_one_ell<0, NU>(S2, dump, Tl, cur.ell, ka, kb, rs_cur, col0, row, rot, L);
     if (n1.done) break;
     if (new_unit) {
       L.live = n1.t0 + l15 < n_times;
@@ -409,12 +424,12 @@ __global__ __launch_bounds__(64 * W, 1) void rotate_modes_resident_kernel(double
 // Plan for an l range: table offsets, l groups of similar cost, LDS size.  Returns false if the range does not fit.
 bool rotate_resident_plan(int ell_min, int ell_max, RotResPlan* P, size_t* lds_bytes) {
   if (ell_max - ell_min + 1 > RR_MAXL) return false;
-  if (ell_max > 19) return false;  // output slots of a lane: x' = 4 r + g and 16 + g
+  if (ell_max > 27) return false;  // output slots of a lane: x' = 4 r + g and 16 + 4 i + g, i < 3
   int ka, kb, tab = 0, kmax = 0;
   for (int l = ell_min; l <= ell_max; ++l) {
     rr_shape(l, &ka, &kb);
     P->tab_off[l - ell_min] = tab;
-    tab += rr_table_doubles(l);
+    tab += rr_table_doubles(l, rr_side_tiles(ell_max));
     kmax = ka + kb > kmax ? ka + kb : kmax;
   }
   P->ell_min = ell_min;
@@ -423,7 +438,7 @@ bool rotate_resident_plan(int ell_min, int ell_max, RotResPlan* P, size_t* lds_b
   P->kpad_max = kmax;
   // 12 waves (three per SIMD, 168 registers each) where the row slots of a lane leave room for them, else 8
   P->waves = ell_max <= 11 ? 12 : 8;
-  if (const char* e = getenv("SCRI_AMD_ROTATE_WAVES")) P->waves = atoi(e) == 12 ? 12 : 8;
+  if (const char* e = getenv("SCRI_AMD_ROTATE_WAVES")) P->waves = atoi(e) == 12 && ell_max <= 11 ? 12 : 8;
   const size_t bytes = sizeof(double) * ((size_t)tab + (size_t)P->waves * (kmax + 1) * 32);  // + the dump row of a wave
   if (bytes > 160u * 1024u) return false;
   *lds_bytes = bytes;
@@ -465,7 +480,8 @@ void rotate_resident_pack(const RotResPlan& P, int ell, const double* Delta /* (
   const int n = 2 * ell + 1;
   double* T = image + P.tab_off[ell - P.ell_min];
   double* X = T + (ka + kb) * 16;
-  for (int e = 0; e < rr_table_doubles(ell); ++e) T[e] = 0.0;
+  const int nx = rr_side_tiles(P.ell_max);
+  for (int e = 0; e < rr_table_doubles(ell, nx); ++e) T[e] = 0.0;
   for (int R = 0; R < ka + kb; ++R) {
     const int iy = R < ka ? 2 * R : 2 * (R - ka) + 1;
     if (iy >= n) continue;
@@ -474,7 +490,7 @@ void rotate_resident_pack(const RotResPlan& P, int ell, const double* Delta /* (
       if (xp < 16)
         T[R * 16 + xp] = d;
       else
-        X[R * 4 + xp - 16] = d;
+        X[R * 4 * nx + xp - 16] = d;
     }
   }
 }
@@ -510,9 +526,13 @@ hipError_t launch_rotate_modes_resident(hipStream_t stream, double* data, long l
   } else if (nu <= 6) {
     RR_LAUNCH_W(6)
   } else if (nu <= 8) {
-    RR_LAUNCH_W(8)
+    RR_LAUNCH(8, 8)
+  } else if (nu <= 10) {
+    RR_LAUNCH(10, 8)
+  } else if (nu <= 12) {
+    RR_LAUNCH(12, 8)
   } else {
-    RR_LAUNCH_W(10)
+    RR_LAUNCH(14, 8)
   }
 #undef RR_LAUNCH_W
 #undef RR_LAUNCH

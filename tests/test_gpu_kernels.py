@@ -63,10 +63,12 @@ def test_rotate_series_matches_oracle(ctx, ell_min, ell_max):
 
 
 @pytest.mark.parametrize("ell_min,ell_max,n", [(0, 0, 50), (1, 1, 17), (0, 3, 37), (3, 7, 16), (5, 11, 1), (7, 12, 100), (12, 15, 33),
-                                               (14, 19, 41), (16, 19, 64), (15, 16, 23), (2, 16, 1600)])
+                                               (14, 19, 41), (16, 19, 64), (15, 16, 23), (2, 16, 1600), (20, 24, 40), (22, 27, 19), (2, 24, 70),
+                                               (26, 30, 21)])
 def test_rotate_series_resident_kernel_shapes(ctx, ell_min, ell_max, n):
     """Every shape the LDS-resident rotation kernel distinguishes (kernels_rotate_resident.hip): row slots 4 / 6 / 8 / 10 per lane,
-    12- and 8-wave builds, the side columns 16..19 of l >= 16, single-l ranges (every step a new work unit), l from 0 (class B of
+    12- and 8-wave builds, the side columns 16..27 of l >= 16 (one to three 4-column side products), ranges walked in several
+    segments (2..19 | 20..24; 26..27 resident | 28..30 staged), single-l ranges (every step a new work unit), l from 0 (class B of
     padding rows only), series shorter than / not a multiple of the 16-step tile; special rotors mixed in."""
     from scri_amd import engine
 
