@@ -174,11 +174,19 @@ __device__ __forceinline__ void rr_setup(RRLane& L, cplx Ra, cplx Rb, int ell) {
 // Both stages, the phase between them and the stores of one l.  A lane's outputs are x = x' and -x', x' = 4 r + g (slots
 // r = 0..3) and 16 + 4 i + g (slots 4 + i, i < NX: l >= 16).  `rsrc` covers the 16 rows of the tile; `col0` = byte offset of this l's first
 // mode in the lane's row.
-template <int NX, int MAXQ>
+template <int NX, int MAXQ, int ELLC = -1, int CQA = 0, int CQB = 0>
 __device__ __forceinline__ void rr_one_ell(double2* __restrict__ S2, int dump, const double* __restrict__ Tl, int ell, int ka, int kb,
                                            __amdgpu_buffer_rsrc_t rsrc, int col0, const double* __restrict__ row,
                                            const double* __restrict__ rotor, const RRLane& L) {
   constexpr int NJ = 4 + NX;
+  // (ELLC >= 0: l as a compile-time constant -- the k loops become straight-line code, the idle output slots disappear)
+  // (CQA, CQB: only the k-step counts of the two classes -- the l ranges with too many l for one instance each)
+  if (ELLC >= 0) {
+    ell = ELLC;
+    rr_shape(ELLC, &ka, &kb);
+  } else if (CQA) {
+    ka = 4 * CQA, kb = 4 * CQB;
+  }
   const int cqA = ka >> 2, cqT = (ka + kb) >> 2;
   const double2* bpA = S2 + L.g * 16 + (L.l15 ^ (L.g << 1));
   const double2* bpB = S2 + L.g * 16 + (L.l15 ^ ((L.g ^ 2) << 1));
@@ -269,6 +277,7 @@ __global__ __launch_bounds__(64 * W, 1) void rotate_modes_resident_kernel(double
                                                                               long long ld, const double* __restrict__ RaRb,
                                                                               long long rotor_stride,
                                                                               const double* __restrict__ tab_global, RotResPlan P) {
+  constexpr bool SPEC = true;
   constexpr int NXK = NU > 8 ? (NU - 8) / 2 : 0;  // side tiles of the kernel (rr_side_tiles of its largest l)
   const long long n_modes = (long long)(P.ell_max + 1) * (P.ell_max + 1) - (long long)P.ell_min * P.ell_min;
   extern __shared__ double lds[];
@@ -402,9 +411,45 @@ __global__ __launch_bounds__(64 * W, 1) void rotate_modes_resident_kernel(double
     // than the rows in flight: an iteration of these kernels starts by draining its predecessor's stores.  Measured, that
     // costs less than running the side products of l >= 16 behind a run-time flag in a single instance: 2.45 vs 2.55 ms per
     // 1e6 steps at l <= 16)
-    if (NXK > 0 && cur.ell >= 16)
+    if (SPEC && NU >= 8 && NU <= 10) {
+#define RR_CASE(E) \
+  case E: rr_one_ell<0, NU, E>(S2, dump, Tl, cur.ell, ka, kb, rs_cur, col0, row, rot, L); break;
+#define RR_PAIR(A, B, X) \
+  case 4 * A + B: rr_one_ell<X, NU, -1, A, B>(S2, dump, Tl, cur.ell, ka, kb, rs_cur, col0, row, rot, L); break;
+      // one instance per l up to 7 (the idle output slots and every loop bound disappear), one per pair of k-step counts above:
+      // l = 8, 9..11, 12, 13..15, 16, 17..19
+      switch (cur.ell) {
+        RR_CASE(0) RR_CASE(1) RR_CASE(2) RR_CASE(3) RR_CASE(4) RR_CASE(5) RR_CASE(6) RR_CASE(7)
+        default:
+          switch (ka + (kb >> 2)) {
+            RR_PAIR(3, 2, 0) RR_PAIR(3, 3, 0) RR_PAIR(4, 3, 0) RR_PAIR(4, 4, 0)
+            default:
+              if (NXK > 0) switch (ka + (kb >> 2)) {
+                  RR_PAIR(5, 4, NXK)
+                  default: rr_one_ell<NXK, NU, -1, 5, 5>(S2, dump, Tl, cur.ell, ka, kb, rs_cur, col0, row, rot, L); break;
+                }
+              break;
+          }
+          break;
+      }
+#undef RR_PAIR
+#undef RR_CASE
+    } else if (NXK > 0 && cur.ell >= 16)
       rr_one_ell<NXK, NU>(S2, dump, Tl, cur.ell, ka, kb, rs_cur, col0, row, rot, L);
-    else
+    else if (SPEC && NU <= 6) {
+#define RR_CASE(E) \
+  case E: rr_one_ell<0, NU, E>(S2, dump, Tl, cur.ell, ka, kb, rs_cur, col0, row, rot, L); break;
+      switch (cur.ell) {
+        RR_CASE(0) RR_CASE(1) RR_CASE(2) RR_CASE(3) RR_CASE(4) RR_CASE(5) RR_CASE(6) RR_CASE(7)
+        default:
+          if (NU > 4) switch (cur.ell) {
+              RR_CASE(8) RR_CASE(9) RR_CASE(10)
+              default: rr_one_ell<0, NU, 11>(S2, dump, Tl, cur.ell, ka, kb, rs_cur, col0, row, rot, L); break;
+            }
+          break;
+      }
+#undef RR_CASE
+    } else
       rr_one_ell<0, NU>(S2, dump, Tl, cur.ell, ka, kb, rs_cur, col0, row, rot, L);
     if (n1.done) break;
     if (new_unit) {
@@ -436,8 +481,8 @@ bool rotate_resident_plan(int ell_min, int ell_max, RotResPlan* P, size_t* lds_b
   P->ell_max = ell_max;
   P->tab_doubles = tab;
   P->kpad_max = kmax;
-  // 12 waves (three per SIMD, 168 registers each) where the row slots of a lane leave room for them, else 8
-  P->waves = ell_max <= 11 ? 12 : 8;
+  // 8 waves (two per SIMD, 256 registers each); 12 (168 registers: spills in the per-l instances) on request for l_max <= 11
+  P->waves = 8;
   if (const char* e = getenv("SCRI_AMD_ROTATE_WAVES")) P->waves = atoi(e) == 12 && ell_max <= 11 ? 12 : 8;
   const size_t bytes = sizeof(double) * ((size_t)tab + (size_t)P->waves * (kmax + 1) * 32);  // + the dump row of a wave
   if (bytes > 160u * 1024u) return false;
