@@ -27,7 +27,7 @@ FP64_MATRIX_PEAK_TFLOPS = 78.6  # MI355X fp64 matrix (= vector) peak, AMD public
 # HBM traffic of the dominant kernel comes from separate rocprofv3 --pmc passes of this same command
 # (tools/run_profiles.sh -> tools/pmc_summary.py; 2 x FETCH_SIZE + WRITE_SIZE as MI355X_MICROARCH.md prescribes for
 # gfx950); the committed summary is read back here so the bench line carries it.
-PMC_SUMMARY = os.path.join(ROOT, "profiles", "r02_h_pmc_cfg3.json")
+PMC_SUMMARY = os.path.join(ROOT, "profiles", "r02_j_pmc_cfg3.json")
 DOMINANT_KERNEL = "bms::zgemm3m_mfma_kernel"
 
 
@@ -507,7 +507,7 @@ def main():
                 "unit": "TFLOP/s",
                 "frac": (achieved / FP64_MATRIX_PEAK_TFLOPS) if achieved else None,
                 "traffic": pmc_traffic(args.workload, world, per_gpu),
-                "traffic_unit": "bytes per launch from the PMC passes, 2 x FETCH_SIZE + WRITE_SIZE (profiles/r02_h_pmc_cfg3.json); the reads are "
+                "traffic_unit": "bytes per launch from the PMC passes, 2 x FETCH_SIZE + WRITE_SIZE (profiles/r02_j_pmc_cfg3.json); the reads are "
                 "L2 misses, Infinity-Cache hits included: the A operand passes each of the 21 column panels (DESIGN.md section 4)",
                 "flops_per_launch": flops_per_launch,
                 "ms_per_launch": g_ms / max(g_calls, 1),
