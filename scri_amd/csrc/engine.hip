@@ -2273,6 +2273,15 @@ extern "C" int bms_grid_multiply(bms_ctx* c, const void* a, int spin_a, int ell_
   if (std::abs(spin_a) > 2 || std::abs(spin_b) > 2 || std::abs(spin_a + spin_b) > 4)
     return fail(c, BMS_ERR_UNSUPPORTED, "spin weights beyond +-2 are not supported");
   if (n_times <= 0) return BMS_OK;
+  // A grid that resolves the product (band limit B = l_a + l_b <= working_ell_max) gives the modes l <= output_ell_max exactly
+  // (up to rounding) as soon as 2 W + 1 > B + output_ell_max and 2 W - 1 >= B -- phi sampling and the extended theta transform of
+  // map2salm -- so the smallest such W serves: the reference's default (W = B, output l_a) needs 2.3 times fewer pixels, and for
+  // l_a + l_b <= 25 it is a grid the separable synthesis and the fused analysis take (n_theta <= 40).  A caller's smaller W
+  // (aliasing, as in the reference) is kept as given.
+  if (working_ell_max >= ell_max_a + ell_max_b && !getenv("SCRI_AMD_GRID_MULTIPLY_FULL_GRID")) {
+    const int B = ell_max_a + ell_max_b;
+    working_ell_max = std::max({(B + output_ell_max + 1) / 2, (B + 2) / 2, output_ell_max, 1});
+  }
   const int n_theta = 2 * working_ell_max + 1, n_phi = n_theta, n_pix = n_theta * n_phi;
   const int nma = (ell_max_a + 1) * (ell_max_a + 1), nmb = (ell_max_b + 1) * (ell_max_b + 1);
   const int n_out = (output_ell_max + 1) * (output_ell_max + 1);
@@ -2286,17 +2295,27 @@ extern "C" int bms_grid_multiply(bms_ctx* c, const void* a, int spin_a, int ell_
       double* r = &rot[4 * ((size_t)j * n_phi + k)];
       r[0] = q.w, r[1] = q.x, r[2] = q.y, r[3] = q.z;
     }
+  // the equiangular grid itself: both syntheses are separable where the kernel takes the shape (kernels_synthesis.hip)
+  SynthesisPlan syn_a, syn_b;
+  bool sep = n_times >= 2 && ell_max_a >= 1 && ell_max_b >= 1 && !getenv("SCRI_AMD_NO_SEPARABLE_SYNTHESIS");
+  if (sep) {
+    if ((rc = build_synthesis(c, n_theta, n_phi, spin_a, 0, ell_max_a, syn_a))) return rc;
+    if ((rc = build_synthesis(c, n_theta, n_phi, spin_b, 0, ell_max_b, syn_b))) return rc;
+    sep = syn_a.nt != 0 && syn_b.nt != 0;
+  }
   void* vp;
-  if ((rc = upload(c, "gm_rotors", rot.data(), 8 * rot.size(), &vp))) return rc;
-  const double* d_rot = (const double*)vp;
   const long long P2 = 2LL * n_pix, ldb = round_up(P2, 128);
-  double *d_Ba, *d_Bb;
-  if ((rc = dev_buf_t(c, "gm_Ba", (size_t)round_up(nma, 8) * ldb, &d_Ba))) return rc;
-  if ((rc = dev_buf_t(c, "gm_Bb", (size_t)round_up(nmb, 8) * ldb, &d_Bb))) return rc;
-  HIP_TRY(c, hipMemsetAsync(d_Ba, 0, sizeof(double) * round_up(nma, 8) * ldb, S));
-  HIP_TRY(c, hipMemsetAsync(d_Bb, 0, sizeof(double) * round_up(nmb, 8) * ldb, S));
-  TIMED(c, BMS_TAG_SETUP, launch_swsh_matrix_complex(S, d_rot, n_pix, spin_a, 0, ell_max_a, d_Ba, ldb));
-  TIMED(c, BMS_TAG_SETUP, launch_swsh_matrix_complex(S, d_rot, n_pix, spin_b, 0, ell_max_b, d_Bb, ldb));
+  double *d_Ba = nullptr, *d_Bb = nullptr;
+  if (!sep) {
+    if ((rc = upload(c, "gm_rotors", rot.data(), 8 * rot.size(), &vp))) return rc;
+    const double* d_rot = (const double*)vp;
+    if ((rc = dev_buf_t(c, "gm_Ba", (size_t)round_up(nma, 8) * ldb, &d_Ba))) return rc;
+    if ((rc = dev_buf_t(c, "gm_Bb", (size_t)round_up(nmb, 8) * ldb, &d_Bb))) return rc;
+    HIP_TRY(c, hipMemsetAsync(d_Ba, 0, sizeof(double) * round_up(nma, 8) * ldb, S));
+    HIP_TRY(c, hipMemsetAsync(d_Bb, 0, sizeof(double) * round_up(nmb, 8) * ldb, S));
+    TIMED(c, BMS_TAG_SETUP, launch_swsh_matrix_complex(S, d_rot, n_pix, spin_a, 0, ell_max_a, d_Ba, ldb));
+    TIMED(c, BMS_TAG_SETUP, launch_swsh_matrix_complex(S, d_rot, n_pix, spin_b, 0, ell_max_b, d_Bb, ldb));
+  }
   AnalysisPlan ana;
   if ((rc = build_analysis(c, "gm", n_theta, n_phi, spin_a + spin_b, 0, output_ell_max, ana))) return rc;
   const double *d_a, *d_b;
@@ -2305,16 +2324,37 @@ extern "C" int bms_grid_multiply(bms_ctx* c, const void* a, int spin_a, int ell_
   double* d_out = (double*)out;
   if (mem == BMS_HOST)
     if ((rc = dev_buf_t(c, "out_data", (size_t)n_times * n_out * 2, &d_out))) return rc;
+  // (the separable kernel reads one more complex number per row -- the eliminated constant of the transformation's series: the
+  // operands are copied to rows with a zero there)
+  double *d_ap = nullptr, *d_bp = nullptr;
+  if (sep) {
+    if ((rc = dev_buf_t(c, "gm_a_pad", (size_t)n_times * (nma + 1) * 2, &d_ap))) return rc;
+    if ((rc = dev_buf_t(c, "gm_b_pad", (size_t)n_times * (nmb + 1) * 2, &d_bp))) return rc;
+    HIP_TRY(c, hipMemset2DAsync(d_ap + 2 * nma, (size_t)(nma + 1) * 16, 0, 16, (size_t)n_times, S));
+    HIP_TRY(c, hipMemset2DAsync(d_bp + 2 * nmb, (size_t)(nmb + 1) * 16, 0, 16, (size_t)n_times, S));
+    HIP_TRY(c, hipMemcpy2DAsync(d_ap, (size_t)(nma + 1) * 16, d_a, (size_t)nma * 16, (size_t)nma * 16, (size_t)n_times, hipMemcpyDeviceToDevice, S));
+    HIP_TRY(c, hipMemcpy2DAsync(d_bp, (size_t)(nmb + 1) * 16, d_b, (size_t)nmb * 16, (size_t)nmb * 16, (size_t)n_times, hipMemcpyDeviceToDevice, S));
+  }
   // chunks of time rows: two grids of 16 n_pix bytes per row
   int64_t chunk = (int64_t)std::max(64.0, (double)c->ws_limit / (2.0 * P2 * 8.0));
   chunk = std::min<int64_t>(chunk, n_times);
-  for (int64_t r0 = 0; r0 < n_times; r0 += chunk) {
-    const int64_t rows = std::min<int64_t>(chunk, n_times - r0);
+  for (int64_t r0 = 0, rows; r0 < n_times; r0 += rows) {
+    rows = std::min<int64_t>(chunk, n_times - r0);
+    if (n_times - (r0 + rows) == 1) --rows;  // (never a last chunk of one row: the separable kernel walks rows in pairs)
     double *d_Ga, *d_Gb;
     if ((rc = dev_buf_t(c, "Y", (size_t)rows * P2, &d_Ga))) return rc;
     if ((rc = dev_buf_t(c, "R", (size_t)rows * P2, &d_Gb))) return rc;
-    TIMED(c, BMS_TAG_GEMM_SYNTHESIS, launch_zgemm3m(S, d_a + r0 * nma * 2, 2LL * nma, d_Ba, ldb, d_Ga, P2, rows, n_pix, nma, nullptr, nullptr));
-    TIMED(c, BMS_TAG_GEMM_SYNTHESIS, launch_zgemm3m(S, d_b + r0 * nmb * 2, 2LL * nmb, d_Bb, ldb, d_Gb, P2, rows, n_pix, nmb, nullptr, nullptr));
+    if (sep && rows >= 2) {
+      TIMED(c, BMS_TAG_GEMM_SYNTHESIS, launch_synthesis_split(S, d_ap + r0 * (nma + 1) * 2, 2LL * (nma + 1), rows, syn_a.g, syn_a.nt, syn_a.d_T, syn_a.d_meta,
+                                                              nullptr, d_Ga, P2, syn_a.lds, c->n_cu));
+      TIMED(c, BMS_TAG_GEMM_SYNTHESIS, launch_synthesis_split(S, d_bp + r0 * (nmb + 1) * 2, 2LL * (nmb + 1), rows, syn_b.g, syn_b.nt, syn_b.d_T, syn_b.d_meta,
+                                                              nullptr, d_Gb, P2, syn_b.lds, c->n_cu));
+    } else if (sep) {
+      return fail(c, BMS_ERR_UNSUPPORTED, "a chunk of one row");
+    } else {
+      TIMED(c, BMS_TAG_GEMM_SYNTHESIS, launch_zgemm3m(S, d_a + r0 * nma * 2, 2LL * nma, d_Ba, ldb, d_Ga, P2, rows, n_pix, nma, nullptr, nullptr));
+      TIMED(c, BMS_TAG_GEMM_SYNTHESIS, launch_zgemm3m(S, d_b + r0 * nmb * 2, 2LL * nmb, d_Bb, ldb, d_Gb, P2, rows, n_pix, nmb, nullptr, nullptr));
+    }
     TIMED(c, BMS_TAG_POINTWISE, launch_cmul(S, d_Ga, d_Gb, d_Ga, rows * (long long)n_pix));
     if ((rc = run_analysis(c, ana, d_Ga, rows, d_out + r0 * n_out * 2, 2LL * n_out))) return rc;
   }
