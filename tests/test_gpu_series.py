@@ -70,7 +70,8 @@ def test_modes_time_series_calculus(ctx):
     assert np.abs(back.ndarray[5:-5] - y[5:-5]).max() < 5e-3  # and it undoes the integral up to the spline error
 
 
-@pytest.mark.parametrize("sa,sb,la,lb", [(0, 0, 3, 4), (2, -2, 4, 4), (-1, 2, 3, 5), (1, 1, 2, 2), (-2, 0, 6, 3)])
+@pytest.mark.parametrize("sa,sb,la,lb", [(0, 0, 3, 4), (2, -2, 4, 4), (-1, 2, 3, 5), (1, 1, 2, 2), (-2, 0, 6, 3), (-2, 1, 12, 12), (0, 2, 16, 9),
+                                         (1, -1, 1, 8)])
 def test_grid_multiply_matches_oracle(ctx, sa, sb, la, lb):
     from scri_amd import engine
 
@@ -80,7 +81,9 @@ def test_grid_multiply_matches_oracle(ctx, sa, sb, la, lb):
     b = rng.normal(size=(n, (lb + 1) ** 2)) + 1j * rng.normal(size=(n, (lb + 1) ** 2))
     a[:, : sa * sa] = 0
     b[:, : sb * sb] = 0
-    for W, Lout in ((la + lb, la + lb), (la + lb, la), (max(la, lb), 2)):  # exact, truncated, aliased working grid
+    # exact, truncated (the engine then works on the smallest exact grid: separable synthesis + fused analysis up to 39 x 39, dense
+    # beyond), aliased working grid (kept as given)
+    for W, Lout in ((la + lb, la + lb), (la + lb, la), (max(la, lb), 2)):
         got = engine.grid_multiply(a, sa, la, b, sb, lb, W, Lout, ctx=ctx)
         ref = mref.grid_multiply(a, sa, la, b, sb, lb, W, Lout)
         assert got.shape == ref.shape
