@@ -274,10 +274,30 @@ def main():
     dev_index = local_rank if backend == "nccl" else local_rank % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
+    backend_note = None
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+            # RCCL, one rank per GPU.  If the process group cannot be set up or its first collective fails (every rank sees
+            # that: missing peer access, IPC handles), the run falls back to gloo with the halos staged through the host
+            # rather than produce no line at all; the line then says so (`config.ranks.backend`).
+            try:
+                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+                probe = torch.ones(1, device=dev)
+                dist.all_reduce(probe)
+                torch.cuda.synchronize()
+                if int(probe.item()) != world:
+                    raise RuntimeError(f"all_reduce probe returned {probe.item()} on {world} ranks")
+            except Exception as e:  # noqa: BLE001 -- any failure of the RCCL bring-up
+                backend_note = f"nccl bring-up failed ({type(e).__name__}: {str(e)[:200]}); halos through the host"
+                if dist.is_initialized():
+                    try:
+                        dist.destroy_process_group()
+                    except Exception:  # noqa: BLE001
+                        pass
+                backend = "gloo"
+                os.environ["MASTER_PORT"] = str(int(os.environ.get("MASTER_PORT", "29500")) + 17)
+                dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
 
@@ -494,7 +514,8 @@ def main():
                 )
                 + f"{per_gpu} time steps per GPU ({n_global} total), supertranslation(l<=2) + frame_rotation + boost |v|={3.7417e-4 * args.boost_scale:.3g}, "
                 f"{n_theta}x{n_theta} grid, {n_out} output steps on rank 0",
-                "ranks": {"world_size": dist.get_world_size() if world > 1 else 1, "backend": dist.get_backend() if world > 1 else None},
+                "ranks": dict({"world_size": dist.get_world_size() if world > 1 else 1, "backend": dist.get_backend() if world > 1 else None},
+                              **({"note": backend_note} if backend_note else {})),
                 "sharding": "none" if world == 1 else (
                     f"grid columns x{world}: all-gather of input modes, reduce-scatter of output modes (RCCL)" if columns
                     else f"time axis x{world}, RCCL point-to-point halo exchange of input modes"),
