@@ -75,8 +75,9 @@ enum bms_kernel_tag {
   BMS_TAG_GEMM_ANALYSIS = 5,   /* dgemm_mfma_kernel, grid -> modes: phi-DFT (or dense quadrature) */
   BMS_TAG_POINTWISE = 6,       /* psi mixing / affine / Horner kernels */
   BMS_TAG_THETA_QUADRATURE = 7, /* theta_quadrature_kernel (second step of the separable analysis) */
-  BMS_TAG_ANALYSIS_FUSED = 8,   /* analysis_fused_kernel (phi-DFT on MFMA + theta quadrature, one kernel) */
-  BMS_TAG_COUNT = 9
+  BMS_TAG_ANALYSIS_FUSED = 8,   /* analysis_split_kernel / analysis_fused_kernel (phi-DFT on MFMA + theta quadrature, one kernel) */
+  BMS_TAG_ANALYSIS_LARGE = 9,   /* phi_dft_folded_kernel + theta_quadrature_mfma_kernel (grids with n_theta > 40) */
+  BMS_TAG_COUNT = 10
 };
 int bms_ctx_enable_timing(bms_ctx* ctx, int on);
 int bms_ctx_get_timing(bms_ctx* ctx, double ms[BMS_TAG_COUNT], int64_t calls[BMS_TAG_COUNT], int reset);

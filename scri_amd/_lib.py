@@ -63,7 +63,7 @@ class bms_shard(ctypes.Structure):
                 ("col_parts", ctypes.c_int32)]
 
 
-KERNEL_TAGS = ("rotate", "setup", "gemm_synthesis", "spline_forward", "spline_backward", "gemm_analysis", "pointwise", "theta_quadrature", "analysis_fused")
+KERNEL_TAGS = ("rotate", "setup", "gemm_synthesis", "spline_forward", "spline_backward", "gemm_analysis", "pointwise", "theta_quadrature", "analysis_fused", "analysis_large")
 
 # every symbol include/scri_amd.h declares: (restype, argtypes)
 SIGNATURES = {

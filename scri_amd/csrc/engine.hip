@@ -968,7 +968,7 @@ static int run_analysis(bms_ctx* c, const AnalysisPlan& A, const double* d_G, lo
     double* d_F;
     int rc = dev_buf_t(c, "Fphi", (size_t)rows * A.nm * large_analysis_jp(A.n_theta) * 2, &d_F);
     if (rc) return rc;
-    TIMED(c, BMS_TAG_GEMM_ANALYSIS, launch_analysis_large(S, d_G, ld, rows, A.n_theta, A.n_phi, A.L, A.ell_min_out, A.d_T, d_F, d_out, ldo));
+    TIMED(c, BMS_TAG_ANALYSIS_LARGE, launch_analysis_large(S, d_G, ld, rows, A.n_theta, A.n_phi, A.L, A.ell_min_out, A.d_T, d_F, d_out, ldo));
   } else if (A.separable) {
     if (col_of_pixel) return fail(c, BMS_ERR_UNSUPPORTED, "internal: sorted columns need the fused analysis");
     if (ld != P2) return fail(c, BMS_ERR_UNSUPPORTED, "internal: the separable analysis reads contiguous rows");
