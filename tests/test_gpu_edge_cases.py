@@ -150,6 +150,7 @@ def test_boost_free_transformations_take_the_separable_synthesis(ctx, monkeypatc
                                    r_is_scaled_out=True, m_is_scaled_out=True, ctx=ctx)
         return w.transform(**kw)
 
+    monkeypatch.delenv("SCRI_AMD_NO_SEPARABLE_SYNTHESIS", raising=False)  # (the suite may be run with the switch set)
     ctx.enable_timing(True)
     ctx.get_timing(reset=True)
     got = run()
