@@ -1,7 +1,10 @@
 #!/usr/bin/env python
 """Benchmark of the BMS-transformation hot path on MI355X (contract: see the task description).
 
-  python bench.py --gpus N --steps K --warmup W        (N > 1: launched under torch.distributed.run)
+  python bench.py --gpus N --steps K --warmup W
+
+N > 1 without WORLD_SIZE in the environment: this process starts its own N ranks (a child `python -m torch.distributed.run`,
+spawned before anything here touches the GPU) and returns their exit code; under a launcher (WORLD_SIZE set) it is one rank.
 
 A "step" is one full BMS transformation (supertranslation + frame rotation + boost) of one synthetic
 WaveformModes series that is already resident in HBM.  N = 1: workload cfg3 of BASELINE.json / SURVEY section 8(d)
@@ -24,23 +27,118 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 FP64_MATRIX_PEAK_TFLOPS = 78.6  # MI355X fp64 matrix (= vector) peak, AMD public spec
-# HBM traffic of the dominant kernel comes from separate rocprofv3 --pmc passes of this same command
-# (tools/run_profiles.sh -> tools/pmc_summary.py; 2 x FETCH_SIZE + WRITE_SIZE as MI355X_MICROARCH.md prescribes for
-# gfx950); the committed summary is read back here so the bench line carries it.
-PMC_SUMMARY = os.path.join(ROOT, "profiles", "r02_j_pmc_cfg3.json")
 DOMINANT_KERNEL = "bms::zgemm3m_mfma_kernel"
+# HBM traffic of the dominant kernel: measured BY THIS RUN where rocprofv3 is on the PATH -- before the parent process touches
+# the GPU it runs two short child passes of this same script under `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` (separate
+# passes, as MI355X_MICROARCH.md prescribes; traffic = 2 x FETCH_SIZE + WRITE_SIZE KiB on gfx950) and reads their counter CSVs.
+# Fallback: the committed summary of tools/run_profiles.sh, used only if it was taken on the same kernel sources.
+PMC_SUMMARY = os.path.join(ROOT, "profiles", "r03_pmc_cfg3.json")
 
 
-def pmc_traffic(workload, world, per_gpu):
-    """HBM bytes per launch of the dominant kernel from the committed PMC summary (cfg3, 1 GPU, 1e5 steps only)."""
-    if workload != "cfg3" or world != 1 or per_gpu != 100_000 or not os.path.exists(PMC_SUMMARY):
-        return None
+def csrc_hash():
+    """sha256 over the kernel sources and the ABI header: identifies the build a profile was taken on (the GPU box has no .git)"""
+    import glob
+    import hashlib
+
+    h = hashlib.sha256()
+    files = sorted(glob.glob(os.path.join(ROOT, "scri_amd", "csrc", "*.hip")) + glob.glob(os.path.join(ROOT, "scri_amd", "csrc", "*.h"))
+                   + [os.path.join(ROOT, "scri_amd", "csrc", "Makefile"), os.path.join(ROOT, "include", "scri_amd.h")])
+    for f in files:
+        h.update(os.path.basename(f).encode())
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
+def _pmc_counter_mean(directory, counter):
+    """mean of `counter` over the launches of the dominant kernel in a rocprofv3 counter_collection.csv (first launch dropped)"""
+    import csv
+    import glob
+
+    vals = []
+    for f in glob.glob(os.path.join(directory, "**", "*counter_collection.csv"), recursive=True):
+        with open(f) as fh:
+            for row in csv.DictReader(fh):
+                if DOMINANT_KERNEL.split("::")[1] in row["Kernel_Name"] and row["Counter_Name"] == counter:
+                    vals.append(float(row["Counter_Value"]))
+    vals = vals[1:] if len(vals) > 1 else vals
+    return sum(vals) / len(vals) if vals else None
+
+
+def live_pmc_traffic(argv):
+    """Two child passes of this script under rocprofv3 --pmc (never combined with a trace option); called before this process
+    initialises the GPU.  Returns (bytes per launch or None, note)."""
+    import shutil
+    import subprocess
+    import tempfile
+
+    prof = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if prof is None:
+        return None, "rocprofv3 not found"
+    keep = [a for a in argv if a not in ("--live-pmc",)]
+    got = {}
+    with tempfile.TemporaryDirectory(dir="/tmp") as tmp:
+        env = dict(os.environ, TMPDIR="/tmp", SCRI_AMD_BENCH_PMC_CHILD="1")
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            out_dir = os.path.join(tmp, counter)
+            cmd = [prof, "--pmc", counter, "--output-format", "csv", "-d", out_dir, "--", sys.executable, os.path.abspath(__file__)] + keep
+            try:
+                r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=420)
+            except (subprocess.TimeoutExpired, OSError) as e:
+                return None, f"rocprofv3 --pmc {counter} pass failed: {type(e).__name__}"
+            if r.returncode != 0:
+                return None, f"rocprofv3 --pmc {counter} pass exited with {r.returncode}: {r.stdout.decode(errors='replace')[-200:]}"
+            got[counter] = _pmc_counter_mean(out_dir, counter)
+            if got[counter] is None:
+                return None, f"no {counter} rows for {DOMINANT_KERNEL} in the pass's counter_collection.csv"
+    traffic = (2.0 * got["FETCH_SIZE"] + got["WRITE_SIZE"]) * 1024.0
+    return traffic, ("measured by this run: two child passes of the same command (3 timed steps) under rocprofv3 --pmc FETCH_SIZE / --pmc "
+                     "WRITE_SIZE, mean over the kernel's launches; bytes = (2 x FETCH_SIZE + WRITE_SIZE) KiB (gfx950 correction of "
+                     "MI355X_MICROARCH.md); reads are L2 misses, Infinity-Cache hits included")
+
+
+def committed_pmc_traffic(workload, world, per_gpu):
+    """HBM bytes per launch of the dominant kernel from the committed PMC summary -- only if that summary was taken on the kernel
+    sources of the running build (its `csrc_hash` stamp) and for this very workload.  Returns (bytes or None, note)."""
+    if workload != "cfg3" or world != 1 or per_gpu != 100_000:
+        return None, "no PMC pass for this workload"
+    if not os.path.exists(PMC_SUMMARY):
+        return None, "no committed PMC summary"
     with open(PMC_SUMMARY) as f:
         summary = json.load(f)
-    for name, counters in summary.items():  # (the kernel is a template: its name carries "<false>")
-        if name.startswith(DOMINANT_KERNEL) and "traffic_bytes" in counters:
-            return counters["traffic_bytes"]
-    return None
+    stamp = summary.get("_meta", {}).get("csrc_hash")
+    name = os.path.relpath(PMC_SUMMARY, ROOT)
+    if stamp != csrc_hash():
+        return None, f"{name} was taken on kernel sources {stamp}, this build is {csrc_hash()}: not reported"
+    for kname, counters in summary.items():  # (the kernel is a template: its name carries "<false>")
+        if kname.startswith(DOMINANT_KERNEL) and "traffic_bytes" in counters:
+            return counters["traffic_bytes"], f"{name} (tools/run_profiles.sh on kernel sources {stamp} = this build), 2 x FETCH_SIZE + WRITE_SIZE"
+    return None, f"{name} has no row for {DOMINANT_KERNEL}"
+
+
+def launch_ranks(n, argv):
+    """`python bench.py --gpus N` outside a launcher: start N ranks as a CHILD process group (torch.distributed.run) before this
+    process has touched the GPU, wait, hand back the exit code.  With fewer GPUs than ranks the run is a gloo dry run (ranks share
+    devices, halos through the host: plumbing only, the line says so)."""
+    import socket
+    import subprocess
+
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if "SCRI_AMD_BENCH_BACKEND" not in env:
+        try:
+            import torch  # (device_count() does not initialise the GPU)
+
+            if torch.cuda.device_count() < n:
+                env["SCRI_AMD_BENCH_BACKEND"] = "gloo"
+        except Exception:  # noqa: BLE001
+            pass
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    return subprocess.call(cmd, env=env)
 
 
 def cpu_baseline(spec, n_sample):
@@ -229,6 +327,36 @@ def boost_free_line(local, t_global, kw, n_theta, ell_max, ctx):
     }
 
 
+def plumbing_only(args, rank, world):
+    """The N > 1 path minus the kernels, for a box without GPUs (CPU test of the launcher): shard plan from the library's host
+    planner, one halo exchange of the synthetic input rows over the process group, every rank's rows checked."""
+    import torch
+    import torch.distributed as dist
+
+    from scri_amd import engine, sharding, synthetic
+
+    spec = dict(synthetic.CONFIGS[args.workload])
+    kw = spec["kwargs"]
+    ell_max = spec["ell_max"]
+    lst = int(round(np.sqrt(len(kw["supertranslation"])))) - 1
+    n_theta = 2 * (ell_max + lst) + 1
+    n_global = int(args.n_times or 8000)
+    tr = engine.make_transformation(kw["supertranslation"], kw.get("frame_rotation", [1, 0, 0, 0]), kw.get("boost_velocity", [0, 0, 0]),
+                                    n_theta, n_theta, ell_max)
+    have, need, window = sharding.plan(np.arange(n_global) * spec["dt"], tr, world)
+    _, mine, _ = synthetic.workload(args.workload, n_times=n_global, rows=have[rank])
+    ext = sharding.exchange_halos(torch.from_numpy(mine), have[rank], need[rank], have, need)
+    _, expect, _ = synthetic.workload(args.workload, n_times=n_global, rows=need[rank])
+    ok = torch.tensor([1 if np.array_equal(ext.numpy(), expect) else 0])
+    dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+    if rank == 0:
+        print(json.dumps({"plumbing_only": True, "n_gpus": world, "backend": dist.get_backend(), "halo_rows_exact": bool(int(ok)),
+                          "have": have, "need": need, "window": list(window), "workload": args.workload, "n_times_total": n_global}))
+    dist.barrier()
+    dist.destroy_process_group()
+    return 0 if int(ok) else 1
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -248,20 +376,36 @@ def main():
                     help="N > 1: time shards + halo exchange (rows) or grid-column parts + reduce-scatter (columns, for strong "
                     "boosts); auto = sharding.choose_partition (rows for the BASELINE.json workloads)")
     ap.add_argument("--boost-scale", type=float, default=1.0, help="multiplies the workload's boost velocity (stress variants)")
+    ap.add_argument("--no-live-pmc", action="store_true",
+                    help="N = 1: do not run the two rocprofv3 --pmc child passes that measure roofline.traffic (the committed summary "
+                    "is reported instead if it was taken on this build's kernel sources, otherwise null)")
+    ap.add_argument("--plumbing-only", action="store_true",
+                    help="N > 1 without any GPU: launcher, rendezvous, backend agreement, shard plan and one halo exchange on host "
+                    "tensors, checked against the synthetic series; prints a line with \"plumbing_only\": true and no measurement")
+    ap.add_argument("--no-parity", action="store_true", help="cfg4, N > 1: skip the comparison of the reassembled shard outputs with "
+                    "rank 0's single-GPU result of the same run")
     args = ap.parse_args()
     if args.workload is None:
         args.workload = "cfg3" if args.gpus == 1 else "cfg4"
+    pmc_child = os.environ.get("SCRI_AMD_BENCH_PMC_CHILD") == "1"
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # no launcher around us: be the launcher (child processes; nothing in this process has touched the GPU)
+        raise SystemExit(launch_ranks(args.gpus, sys.argv[1:]))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit(
-                "launch multi-GPU runs with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N "
-                "--master-addr 127.0.0.1 --master-port P bench.py --gpus N ..."
-            )
         raise SystemExit(f"--gpus {args.gpus} does not match WORLD_SIZE {world}")
+
+    # roofline.traffic of the dominant kernel, measured by this run: PMC child passes BEFORE this process initialises the GPU
+    traffic, traffic_note = None, "not measured"
+    if world == 1 and not pmc_child and not args.no_live_pmc and args.workload == "cfg3":
+        child = ["--gpus", "1", "--steps", "3", "--warmup", "1", "--cpu-sample", "0", "--no-live-pmc", "--workload", args.workload,
+                 "--boost-scale", str(args.boost_scale)] + (["--n-times", str(args.n_times)] if args.n_times else [])
+        traffic, traffic_note = live_pmc_traffic(child)
+
+    import datetime
 
     import torch
     import torch.distributed as dist
@@ -271,35 +415,59 @@ def main():
     # SCRI_AMD_BENCH_BACKEND=gloo: dry run of the multi-rank path on a box with fewer GPUs than ranks (ranks share
     # devices, halos travel through the host); the measured configuration is nccl = RCCL, one rank per GPU
     backend = os.environ.get("SCRI_AMD_BENCH_BACKEND", "nccl")
-    dev_index = local_rank if backend == "nccl" else local_rank % max(torch.cuda.device_count(), 1)
-    torch.cuda.set_device(dev_index)
+    if args.plumbing_only:
+        backend = "gloo"
+    n_dev = max(torch.cuda.device_count(), 1)
+    dev_index = local_rank % n_dev
+    if not args.plumbing_only:
+        torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
     backend_note = None
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
-            # RCCL, one rank per GPU.  If the process group cannot be set up or its first collective fails (every rank sees
-            # that: missing peer access, IPC handles), the run falls back to gloo with the halos staged through the host
-            # rather than produce no line at all; the line then says so (`config.ranks.backend`).
+            # RCCL, one rank per GPU.  The ranks AGREE on the outcome of the bring-up through a key-value store of their own
+            # (a failure seen by a subset of the ranks must not leave the others waiting in a collective): every rank
+            # publishes ok / failed after its init + first all_reduce, reads everybody's flag, and only a unanimous ok keeps
+            # RCCL; otherwise all of them fall back to gloo with the halos staged through the host rather than produce no
+            # line at all, and the line says so (`config.ranks`).
+            port = int(os.environ.get("MASTER_PORT", "29500"))
+            store = dist.TCPStore(os.environ["MASTER_ADDR"], port + 23, world, is_master=(rank == 0), timeout=datetime.timedelta(seconds=300),
+                                  wait_for_workers=False)
+            err = None
             try:
-                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+                if n_dev < world:
+                    raise RuntimeError(f"{world} ranks on {n_dev} visible GPU(s)")
+                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev, timeout=datetime.timedelta(seconds=240))
                 probe = torch.ones(1, device=dev)
                 dist.all_reduce(probe)
                 torch.cuda.synchronize()
                 if int(probe.item()) != world:
                     raise RuntimeError(f"all_reduce probe returned {probe.item()} on {world} ranks")
             except Exception as e:  # noqa: BLE001 -- any failure of the RCCL bring-up
-                backend_note = f"nccl bring-up failed ({type(e).__name__}: {str(e)[:200]}); halos through the host"
+                err = f"{type(e).__name__}: {str(e)[:200]}"
+            store.set(f"nccl_{rank}", "ok" if err is None else err)
+            flags = [store.get(f"nccl_{r}").decode(errors="replace") for r in range(world)]
+            if any(f != "ok" for f in flags):
+                bad = next(r for r, f in enumerate(flags) if f != "ok")
+                backend_note = f"nccl bring-up failed on rank {bad} ({flags[bad]}); all ranks on gloo, halos through the host"
                 if dist.is_initialized():
                     try:
                         dist.destroy_process_group()
                     except Exception:  # noqa: BLE001
                         pass
                 backend = "gloo"
-                os.environ["MASTER_PORT"] = str(int(os.environ.get("MASTER_PORT", "29500")) + 17)
+                os.environ["MASTER_PORT"] = str(port + 17)
                 dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
+    # One stream for torch's work (allocations, copies, RCCL's completion waits) AND the engine's kernels: a side stream
+    # of torch's made current for the whole run, handed to the context.  (torch's default stream has the handle 0; engine
+    # kernels on the context's own non-blocking stream would not be ordered behind copies queued there.)
+    if args.plumbing_only:
+        return plumbing_only(args, rank, world)
+    run_stream = torch.cuda.Stream(device=dev)
+    torch.cuda.set_stream(run_stream)
 
     spec = dict(synthetic.CONFIGS[args.workload])
     spec["name"] = args.workload
@@ -350,17 +518,18 @@ def main():
         # every rank's contribution covers all output rows; equal blocks for the reduce-scatter
         n_new_all = window[1] - window[0]
         part_buf = torch.zeros((sharding.padded_rows(n_new_all, world)[0], n_modes), dtype=torch.complex128, device=dev)
-    if world > 1 and not abd and backend == "nccl" and not columns:
+    if world > 1 and not abd and not columns:
         ext_buf = torch.empty((need[rank][1] - need[rank][0], n_modes), dtype=torch.complex128, device=dev)
         lo = have[rank][0] - need[rank][0]
         ext_buf[lo : lo + own] = local
         local = ext_buf[lo : lo + own]
-    ctx = _lib.Context(dev_index)
+    ctx = _lib.Context(dev_index, stream=run_stream.cuda_stream)
     ctx.enable_timing(True)
     halo_rows = (have[rank][0] - need[rank][0], need[rank][1] - have[rank][1]) if world > 1 else (0, 0)
 
     # ---- cfg4: the whole series on ONE GPU (rank 0's), in the same run: the reference of the strong-scaling line
     n1 = None
+    whole_out = None
     if strong and world > 1 and not args.no_n1_reference:
         if rank == 0:
             _, whole_host, _ = synthetic.workload(args.workload, n_times=n_global)
@@ -372,21 +541,21 @@ def main():
                 if i == 1:
                     ctx.synchronize()
                     t1 = time.perf_counter()
-                engine.transform_modes(t_global, whole.data_ptr(), 2, ell_max, -2, -1, engine.BMS_TERM_H, tr, ctx=ctx, device=True,
-                                       ld=n_modes, out_ptr=whole_out.data_ptr())
+                n1_rows = engine.transform_modes(t_global, whole.data_ptr(), 2, ell_max, -2, -1, engine.BMS_TERM_H, tr, ctx=ctx, device=True,
+                                                 ld=n_modes, out_ptr=whole_out.data_ptr())[1]
             ctx.synchronize()
             n1 = {"ms_per_step": 1e3 * (time.perf_counter() - t1) / reps, "steps": reps, "where": "rank 0's GPU, before the sharded loop"}
-            del whole, whole_out
+            del whole
+            if args.no_parity or columns:
+                whole_out = None
             torch.cuda.empty_cache()
             ctx.get_timing(reset=True)
         dist.barrier()
 
-    # N > 1 on RCCL: the engine runs on torch's current stream, so the halo rows (received on RCCL's stream, which the
-    # current stream waits for in req.wait()) are ordered before the kernels that read them without a host-side
-    # synchronisation of the device
+    # N > 1 on RCCL: the engine runs on torch's current stream (`run_stream`), so the halo rows (received on RCCL's stream,
+    # which the current stream waits for in req.wait(); copied into place on the current stream) are ordered before the
+    # kernels that read them without a host-side synchronisation of the device
     stream_ordered = world > 1 and backend == "nccl"
-    if stream_ordered:
-        ctx.set_stream(torch.cuda.current_stream().cuda_stream)
 
     # --overlap-halo: outputs [a, b) of this rank need its own rows only (bms_shard_plan says so); they are transformed
     # while the halos travel, the edges [i0, a) and [b, i1) afterwards
@@ -420,7 +589,6 @@ def main():
         if columns:
             # plan B: gather the whole input series, transform this rank's grid columns over all times, reduce-scatter the sum
             full = sharding.replicate_rows(local, have)
-            torch.cuda.synchronize()
             engine.transform_modes(
                 t_global, full.data_ptr(), 2, ell_max, -2, -1, engine.BMS_TERM_H, tr, ctx=ctx, device=True, ld=n_modes,
                 out_ptr=part_buf.data_ptr(), shard=(0, n_global, 0, n_global, rank, world),
@@ -476,6 +644,39 @@ def main():
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
     elapsed = float(el.item())
 
+    # ---- cfg4, N > 1: the shards' outputs of the LAST timed step, reassembled on rank 0, against rank 0's own single-GPU
+    # transform of the whole series from the same run (the check of the RCCL path that only hardware can give; the same
+    # comparison on one device is tests/test_gpu_full_size.py::test_cfg4_eight_shards_equal_whole, bar 1e-14 x scale)
+    parity = None
+    if strong and world > 1 and not columns and not args.no_parity and not args.no_n1_reference:
+        comm_dev = dev if backend == "nccl" else torch.device("cpu")
+        counts = torch.zeros(world, dtype=torch.int64, device=comm_dev)
+        counts[rank] = int(n_out)
+        dist.all_reduce(counts)
+        counts = [int(c) for c in counts.cpu()]
+        worst, scale, offset = 0.0, 0.0, 0
+        for r in range(world):
+            if counts[r] == 0:
+                continue
+            if r == rank:
+                piece = out[: counts[r]].to(comm_dev)
+            else:
+                piece = torch.empty((counts[r], n_modes), dtype=torch.complex128, device=comm_dev)
+            piece_real = torch.view_as_real(piece)
+            dist.broadcast(piece_real, src=r)
+            if rank == 0:
+                ref = whole_out[offset : offset + counts[r]]
+                got = piece.to(dev)
+                worst = max(worst, float((got - ref).abs().max()))
+                scale = max(scale, float(ref.abs().max()))
+                del got
+            offset += counts[r]
+            del piece, piece_real
+        if rank == 0:
+            parity = {"sharded_vs_n1_max_abs_diff": worst, "scale_max_abs": scale, "rows_compared": offset,
+                      "rows_of_n1_result": int(n1_rows),
+                      "bar": 1e-14 * scale, "within_bar": bool(worst <= 1e-14 * scale and offset == int(n1_rows))}
+
     if rank == 0:
         ms_per_step = 1e3 * elapsed / args.steps
         value = n_global * args.steps / elapsed
@@ -489,6 +690,10 @@ def main():
         flops_per_launch = 8.0 * n_modes * n_pix * rows_in * n_fields / launches_per_step / (world if columns else 1)
         achieved = flops_per_launch / (g_ms / max(g_calls, 1) * 1e-3) / 1e12 if g_ms > 0 else None
         kernels = {k: {"ms_per_step": v[0] / args.steps, "launches_per_step": v[1] / args.steps} for k, v in timing.items() if v[1]}
+        executed = 0.75 * achieved * ((n_pix - 2 * (n_theta - 1)) / n_pix if n_theta <= 40 else 1.0) if achieved else None
+        if traffic is None and not pmc_child:
+            traffic, fallback_note = committed_pmc_traffic(args.workload, world, per_gpu)
+            traffic_note = fallback_note if traffic_note == "not measured" else f"{traffic_note}; {fallback_note}"
         line = {
             "metric": {
                 "cfg3": "timesteps/sec for full BMS transform, l_max=16, 1e5 steps; fp64",
@@ -503,7 +708,7 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": ms_per_step,
             "higher_is_better": True,
-            "scaling": "strong" if strong else "weak",
+            "scaling": None if world == 1 else ("strong" if strong else "weak"),
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
@@ -527,14 +732,17 @@ def main():
                 "peak": FP64_MATRIX_PEAK_TFLOPS,
                 "unit": "TFLOP/s",
                 "frac": (achieved / FP64_MATRIX_PEAK_TFLOPS) if achieved else None,
-                "traffic": pmc_traffic(args.workload, world, per_gpu),
-                "traffic_unit": "bytes per launch from the PMC passes, 2 x FETCH_SIZE + WRITE_SIZE (profiles/r02_j_pmc_cfg3.json); the reads are "
-                "L2 misses, Infinity-Cache hits included: the A operand passes each of the 21 column panels (DESIGN.md section 4)",
+                "traffic": traffic,
+                "traffic_source": traffic_note,
+                "traffic_unit": "HBM-side bytes per launch of the kernel (L2 misses: Infinity-Cache hits included); the A operand passes "
+                "each of the column panels (DESIGN.md section 4)",
+                "csrc_hash": csrc_hash(),
                 "flops_per_launch": flops_per_launch,
                 "ms_per_launch": g_ms / max(g_calls, 1),
                 # what the MFMA pipe actually executes: 3 real products per complex one (not 4), and, when the fused analysis
                 # is in use (grids up to 40 x 40), one column per pole ring instead of n_phi
-                "executed_tflops": 0.75 * achieved * ((n_pix - 2 * (n_theta - 1)) / n_pix if n_theta <= 40 else 1.0) if achieved else None,
+                "executed_tflops": executed,
+                "frac_executed": (executed / FP64_MATRIX_PEAK_TFLOPS) if executed else None,
             },
             "kernels": kernels,
         }
@@ -544,7 +752,8 @@ def main():
             line["halo"] = {
                 "rows_per_rank_before_after": all_halo,
                 "bytes_received_per_rank": [row_bytes * (a + b) for a, b in all_halo],
-                "exchange": "RCCL point-to-point (batch_isend_irecv) of input-mode rows, ordered on the engine's stream" if stream_ordered
+                "exchange": "RCCL point-to-point (batch_isend_irecv) of input-mode rows; torch and the engine share one side stream, "
+                "so the rows are ordered before the kernels without a device synchronisation" if stream_ordered
                 else "gloo dry run through host memory",
                 "overlap": (f"interior outputs [{interior[0]}, {interior[1]}) of rank 0 transformed under the exchange, edges after it"
                             if interior is not None else "none (one engine call per step after the exchange)"),
@@ -554,6 +763,8 @@ def main():
                 "n_times_total": n_global,
                 "n1_same_run": n1,
                 "speedup_vs_n1_same_run": (n1["ms_per_step"] / ms_per_step) if n1 else None,
+                "parity": parity,
+                "sharded_vs_n1_max_abs_diff": parity["sharded_vs_n1_max_abs_diff"] if parity else None,
             }
         if not abd:
             # the HBM-bound stages against the 8 TB/s peak, with the algorithmic bytes of SURVEY 8(d) (grid = the columns
@@ -584,14 +795,14 @@ def main():
         if world == 1 and args.cpu_sample > 0 and not abd:
             line["cpu_baseline"] = cpu_baseline(spec, args.cpu_sample)
             line["cpu_baseline_all_cores"] = cpu_baseline_all_cores(spec, args.cpu_sample)
-        if world == 1 and not abd:
+        if world == 1 and not abd and not pmc_child:
             line["rotation"] = rotation_line(local, ell_max, ctx, 3000 if args.cpu_sample > 0 else 0)
             line["boost_free"] = boost_free_line(local, t_global, kw, n_theta, ell_max, ctx)
-        print(json.dumps(line))
+        print("\n" + json.dumps(line), flush=True)  # (on a line of its own whatever a backend wrote to stdout before)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

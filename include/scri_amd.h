@@ -58,6 +58,9 @@ void bms_ctx_destroy(bms_ctx* ctx);
 const char* bms_last_error(const bms_ctx* ctx); /* ctx may be NULL: error of the last failed bms_ctx_create */
 /* run on a caller-provided hipStream_t (NULL: the context's own stream) */
 int bms_ctx_set_stream(bms_ctx* ctx, void* hip_stream);
+/* run on the device's default (null) stream -- handle 0, which bms_ctx_set_stream takes as "own stream" -- so that work a
+ * caller queued there (torch's default stream: allocations, copies, memsets) is ordered before the engine's kernels */
+int bms_ctx_use_default_stream(bms_ctx* ctx);
 /* cap on the grid work space in bytes (time axis is processed in chunks that fit); 0 = default */
 int bms_ctx_set_workspace_limit(bms_ctx* ctx, uint64_t bytes);
 /* block until all work queued by this context has finished */

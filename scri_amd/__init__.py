@@ -48,6 +48,17 @@ WaveformModes.to_coprecessing_frame = to_coprecessing_frame
 def patch_scri(scri=None, ctx=None):
     """Graft the GPU implementations onto an installed `scri` (opt-in drop-in): the two rotation
     kernels, `WaveformModes.transform` and `AsymptoticBondiData.transform`.  Returns the patched attribute names."""
-    from .integration import patch_scri as _patch
+    if scri is None:
+        import scri  # only available where the reference is installed
+    from . import adapters
 
-    return _patch(scri, ctx=ctx)
+    return adapters.install(scri, ctx=ctx)
+
+
+def unpatch_scri(scri=None):
+    """Undo `patch_scri`: put the reference's own functions back (kept as `_reference` aliases)."""
+    if scri is None:
+        import scri
+    from . import adapters
+
+    adapters.uninstall(scri)

@@ -72,6 +72,7 @@ SIGNATURES = {
     "bms_ctx_destroy": (None, [c_vp]),
     "bms_last_error": (ctypes.c_char_p, [c_vp]),
     "bms_ctx_set_stream": (c_int, [c_vp, c_vp]),
+    "bms_ctx_use_default_stream": (c_int, [c_vp]),
     "bms_ctx_set_workspace_limit": (c_int, [c_vp, ctypes.c_uint64]),
     "bms_ctx_synchronize": (c_int, [c_vp]),
     "bms_ctx_enable_timing": (c_int, [c_vp, c_int]),
@@ -352,7 +353,14 @@ class Context:
             _raise(rc, self._h, what)
 
     def set_stream(self, stream):
-        self.check(load().bms_ctx_set_stream(self._h, c_vp(int(stream) if stream else 0)), "bms_ctx_set_stream")
+        """stream: a hipStream_t handle; None = the context's own stream; 0 = the device's default (null) stream, which is what
+        torch.cuda.current_stream().cuda_stream reports unless the caller switched streams"""
+        if stream is None:
+            self.check(load().bms_ctx_set_stream(self._h, c_vp(0)), "bms_ctx_set_stream")
+        elif int(stream) == 0:
+            self.check(load().bms_ctx_use_default_stream(self._h), "bms_ctx_use_default_stream")
+        else:
+            self.check(load().bms_ctx_set_stream(self._h, c_vp(int(stream))), "bms_ctx_set_stream")
 
     def synchronize(self):
         self.check(load().bms_ctx_synchronize(self._h), "bms_ctx_synchronize")

@@ -303,6 +303,15 @@ extern "C" int bms_ctx_set_stream(bms_ctx* c, void* s) {
   return BMS_OK;
 }
 
+// The device's default (null) stream has the handle 0, which bms_ctx_set_stream reads as "back to the context's own
+// stream"; a caller whose allocations, copies and memsets are queued on the null stream (torch's default stream) names it
+// here, so that the engine's kernels are ordered behind them instead of racing them on a non-blocking stream.
+extern "C" int bms_ctx_use_default_stream(bms_ctx* c) {
+  if (!c) return BMS_ERR_INVALID;
+  c->stream = nullptr;
+  return BMS_OK;
+}
+
 extern "C" int bms_ctx_set_workspace_limit(bms_ctx* c, uint64_t bytes) {
   if (!c) return BMS_ERR_INVALID;
   c->ws_limit = bytes ? bytes : (32ull << 30);

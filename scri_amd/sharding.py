@@ -35,11 +35,11 @@ def exchange_halos(local, have, need, all_have, all_need, group=None, dim=0, out
     is_complex = local.is_complex()
     if dim != 0:
         local = local.movedim(dim, 0)
-    # gloo moves host memory only: device tensors take a round trip through the host (dry runs of the multi-rank
-    # path on a box without RCCL peers; the production backend is nccl = RCCL, device to device)
+    # gloo moves host memory only: there the halo rows (not the whole shard) take a round trip through the host (dry runs of
+    # the multi-rank path on a box without RCCL peers; the production backend is nccl = RCCL, device to device)
     device = local.device
-    if device.type != "cpu" and dist.get_backend(group) == "gloo":
-        local = local.cpu()
+    via_host = device.type != "cpu" and dist.get_backend(group) == "gloo"
+    wire = torch.device("cpu") if via_host else device
     loc = torch.view_as_real(local) if is_complex else local
     out_shape = (need[1] - need[0],) + tuple(loc.shape[1:])
     prefilled = out is not None
@@ -63,13 +63,13 @@ def exchange_halos(local, have, need, all_have, all_need, group=None, dim=0, out
         # rows I need that the peer owns
         a, b = max(need[0], all_have[peer][0]), min(need[1], all_have[peer][1])
         if b > a:
-            buf = torch.empty((b - a,) + tuple(loc.shape[1:]), dtype=loc.dtype, device=loc.device)
+            buf = torch.empty((b - a,) + tuple(loc.shape[1:]), dtype=loc.dtype, device=wire)
             recv_bufs.append((a, b, buf))
             ops.append(dist.P2POp(dist.irecv, buf, peer, group))
         # rows the peer needs that I own
         a, b = max(all_need[peer][0], have[0]), min(all_need[peer][1], have[1])
         if b > a:
-            ops.append(dist.P2POp(dist.isend, loc[a - have[0] : b - have[0]].contiguous(), peer, group))
+            ops.append(dist.P2POp(dist.isend, loc[a - have[0] : b - have[0]].contiguous().to(wire), peer, group))
     reqs = dist.batch_isend_irecv(ops) if ops else []
 
     def finish():
@@ -77,12 +77,10 @@ def exchange_halos(local, have, need, all_have, all_need, group=None, dim=0, out
             req.wait()
         o = out
         for a, b, buf in recv_bufs:
-            o[a - need[0] : b - need[0]] = buf
+            o[a - need[0] : b - need[0]] = buf.to(o.device)
         if prefilled:
             return result
         o = torch.view_as_complex(o) if is_complex else o
-        if o.device != device:
-            o = o.to(device)
         return o.movedim(0, dim).contiguous() if dim != 0 else o
 
     return finish() if wait else finish

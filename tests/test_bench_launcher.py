@@ -1,0 +1,66 @@
+"""`python bench.py --gpus N` with no launcher around it starts its own N ranks (child processes, before anything touches
+the GPU) and returns their exit code -- the form in which the driver's scaling run calls it.  Here on CPU: the launcher,
+the rendezvous, the backend agreement, the shard plan of the library's host planner and one halo exchange (`--plumbing-only`:
+everything of the N > 1 path except the kernels); on the GPU box (`-m gpu`): the real cfg4 strong-scaling line from two
+ranks that share the box's one GPU (gloo dry run), with the reassembled shard outputs compared with rank 0's single-GPU
+result of the same run."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(args, timeout=600, **env):
+    e = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    e.update(env)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, cwd=ROOT, env=e, stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, timeout=timeout)
+    lines = [ln for ln in r.stdout.decode().splitlines() if ln.startswith("{")]
+    return r.returncode, (json.loads(lines[-1]) if lines else None), r.stderr.decode()[-2000:]
+
+
+def test_bench_starts_its_own_ranks_and_exchanges_halos():
+    rc, line, err = _run(["--gpus", "2", "--plumbing-only", "--n-times", "6000"])
+    assert rc == 0, err
+    assert line["plumbing_only"] and line["n_gpus"] == 2 and line["backend"] == "gloo"
+    assert line["halo_rows_exact"]
+    (a0, a1), (b0, b1) = line["need"]
+    assert a1 > 3000 and b0 < 3000  # both ranks fetched rows of the other
+
+
+def test_launcher_hands_back_a_failing_rank_exit_code():
+    rc, line, err = _run(["--gpus", "2", "--plumbing-only", "--n-times", "3"])  # a 3-sample series has no cubic spline: the ranks raise
+    assert rc != 0 and line is None
+
+
+def test_committed_pmc_summary_is_reported_only_for_the_build_it_was_taken_on(tmp_path, monkeypatch):
+    sys.path.insert(0, ROOT)
+    import bench
+
+    stamp = bench.csrc_hash()
+    assert len(stamp) == 16 and stamp == bench.csrc_hash()
+    good = tmp_path / "good.json"
+    good.write_text(json.dumps({"_meta": {"csrc_hash": stamp}, "bms::zgemm3m_mfma_kernel<false>": {"traffic_bytes": 123.0}}))
+    stale = tmp_path / "stale.json"
+    stale.write_text(json.dumps({"_meta": {"csrc_hash": "0" * 16}, "bms::zgemm3m_mfma_kernel<false>": {"traffic_bytes": 123.0}}))
+    monkeypatch.setattr(bench, "PMC_SUMMARY", str(good))
+    assert bench.committed_pmc_traffic("cfg3", 1, 100_000)[0] == 123.0
+    assert bench.committed_pmc_traffic("cfg3", 2, 100_000)[0] is None
+    monkeypatch.setattr(bench, "PMC_SUMMARY", str(stale))
+    value, note = bench.committed_pmc_traffic("cfg3", 1, 100_000)
+    assert value is None and "not reported" in note
+
+
+@pytest.mark.gpu
+def test_two_rank_cfg4_line_carries_its_own_parity_check():
+    rc, line, err = _run(["--gpus", "2", "--steps", "2", "--warmup", "1", "--n-times", "60000"], timeout=900)
+    assert rc == 0, err
+    assert line["n_gpus"] == 2 and line["scaling"] == "strong" and line["config"]["ranks"]["world_size"] == 2
+    par = line["strong_scaling"]["parity"]
+    assert par["rows_compared"] == par["rows_of_n1_result"] > 59000
+    assert par["within_bar"], par
+    assert line["strong_scaling"]["sharded_vs_n1_max_abs_diff"] <= 1e-14 * par["scale_max_abs"]

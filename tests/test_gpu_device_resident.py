@@ -119,3 +119,28 @@ def test_map_to_superrest_frame_from_a_device_resident_object(ctx):
     assert np.allclose(tr_d.boost_velocity, tr_h.boost_velocity, atol=1e-13)
     assert np.allclose(np.asarray(err_d), np.asarray(err_h), atol=1e-13)
     assert np.abs(rec_d._raw_data - rec_h._raw_data).max() < 1e-12 * max(1.0, np.abs(rec_h._raw_data).max())
+
+
+def test_engine_reads_are_ordered_behind_torch_copies(ctx):
+    """torch's default stream has the handle 0, which `bms_ctx_set_stream` used to read as "the context's own (non-blocking) stream": the
+    kernels of a device-resident series then raced the asynchronous clone / zero_ / copy_ that produced their input.  `attach` now names the
+    null stream (`bms_ctx_use_default_stream`); the stress case: multi-GB copies queued on torch's stream with an engine read right behind
+    each of them, and the reverse order (an engine write read back by torch at once)."""
+    import torch
+
+    from scri_amd import device_series
+
+    dev = device_series.attach(ctx)
+    n, ell_max = 1_500_000, 9  # 100 modes x 1.5e6 rows x 16 B = 2.4 GB per buffer
+    nm = (ell_max + 1) ** 2
+    src = torch.view_as_complex(torch.randn((n, nm, 2), dtype=torch.float64, device=dev))
+    t = np.arange(n, dtype=float)
+    for rep in range(4):
+        dst = torch.empty_like(src)
+        dst.zero_()
+        dst.copy_(src if rep % 2 == 0 else src.clone())  # asynchronous on torch's stream
+        series = device_series.DeviceModesTimeSeries(dst, t, 0, 0, ell_max, ctx=ctx)
+        doubled = series * 2.0  # bms_mode_map reads dst at once
+        back = (doubled.buf - 2.0 * src).abs().max()  # torch reads the engine's output at once
+        assert float(back) == 0.0, rep
+        del dst, series, doubled

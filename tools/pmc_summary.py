@@ -2,7 +2,10 @@
 FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE counts half the bytes of wide coalesced streaming reads, so
 hbm_read_bytes = 2 * FETCH_SIZE * 1024 (MI355X_MICROARCH.md, HBM section).  Mean over the launches of each kernel, first
 (warm-up) launch dropped."""
-import collections, csv, glob, json, sys
+import collections, csv, glob, json, os, sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from bench import csrc_hash  # noqa: E402  (stamp: the kernel sources the passes ran on; bench.py reports the summary only for that build)
 
 root = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out"
 out = collections.defaultdict(dict)
@@ -22,4 +25,5 @@ for k, v in out.items():
         v["hbm_read_bytes_corrected"] = 2 * v["FETCH_SIZE"] * 1024
         v["hbm_write_bytes"] = v["WRITE_SIZE"] * 1024
         v["traffic_bytes"] = v["hbm_read_bytes_corrected"] + v["hbm_write_bytes"]
+out["_meta"] = {"csrc_hash": csrc_hash()}
 json.dump(out, sys.stdout, indent=1, sort_keys=True)
