@@ -56,7 +56,9 @@ struct AnalysisPlan {
 // separable synthesis of boost-free transformations (kernels_synthesis.hip)
 struct SynthesisPlan {
   SynGeom g;
-  int nt = 0;
+  int nt = 0;          // != 0: the one-kernel form takes the shape (synthesis_split_kernel)
+  bool large = false;  // the two-kernel form does (kernels_synthesis_large.hip)
+  int n_theta = 0, n_phi = 0, ell_min = 0, ell_max = 0;
   size_t lds = 0;
   double* d_T = nullptr;  // [n_modes][n_theta] sLambda_lm(theta_j)
   int* d_meta = nullptr;
@@ -78,6 +80,11 @@ struct bms_ctx {
   bool async_pieces = false;
   bool piece_tables_valid = false;
   void* piece_tables = nullptr;  // PieceTables*
+  // constant rotors of internal rotations travel through a page-locked ring (a truly asynchronous copy: no stream
+  // synchronisation to protect a stack copy); the ring is drained once per lap
+  double* rot_ring_host = nullptr;
+  double* rot_ring_dev = nullptr;
+  int rot_ring_next = 0;
   std::map<std::pair<int, int>, RotResPlan> rot_res_plans;  // LDS-resident table images built so far, by (ell_min, ell_max)
   int n_cu = 0;
   // analysis tables depend on the grid, the spin and the l range only: kept per tag until a call asks for other ones
@@ -189,6 +196,9 @@ static int dev_buf(bms_ctx* c, const char* name, size_t bytes, void** out) {
   if (b.cap < bytes) {
     if (b.p) {
       HIP_TRY(c, hipStreamSynchronize(c->stream));
+      // (a pipelined call's uploads and downloads run on their own streams and may still use the old block)
+      if (c->pipe_up) HIP_TRY(c, hipStreamSynchronize(c->pipe_up));
+      if (c->pipe_down) HIP_TRY(c, hipStreamSynchronize(c->pipe_down));
       HIP_TRY(c, hipFree(b.p));
       b.p = nullptr;
       b.cap = 0;
@@ -260,6 +270,8 @@ extern "C" void bms_ctx_destroy(bms_ctx* c) {
     (void)hipEventDestroy(t.b);
   }
   for (auto e : c->event_pool) (void)hipEventDestroy(e);
+  if (c->rot_ring_host) (void)hipHostFree(c->rot_ring_host);
+  if (c->rot_ring_dev) (void)hipFree(c->rot_ring_dev);
   if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
   if (c->aux) (void)hipStreamDestroy(c->aux);
   if (c->pipe_up) (void)hipStreamDestroy(c->pipe_up);
@@ -551,8 +563,10 @@ static int ensure_delta_resident(bms_ctx* c, int ell_min, int ell_max, bool* ok,
 
 // ====================================================================================================== rotation
 
+constexpr int ROT_RING = 64;
+// sync_after = false (internal callers, device data, constant rotor): the call returns with the work enqueued
 static int rotate_impl(bms_ctx* c, void* data, int mem, int64_t n_times, int64_t ld, int ell_min, int ell_max,
-                       const void* spinors, bool series) {
+                       const void* spinors, bool series, bool sync_after = true) {
   if (!c) return BMS_ERR_INVALID;
   HIP_TRY(c, hipSetDevice(c->device));
   if (n_times < 0 || ell_min < 0 || ell_max < ell_min) return fail(c, BMS_ERR_INVALID, "bad sizes");
@@ -612,7 +626,20 @@ static int rotate_impl(bms_ctx* c, void* data, int mem, int64_t n_times, int64_t
   const double* d_rot = (const double*)spinors;
   const size_t data_bytes = ((size_t)(n_times - 1) * ld + n_modes) * 16;  // a strided view ends with its last row's modes
   const size_t rot_bytes = (series ? (size_t)n_times : 1) * 32;
-  if (mem == BMS_HOST || !series) {
+  if (!series && mem == BMS_DEVICE && !sync_after) {
+    if (!c->rot_ring_host) {
+      HIP_TRY(c, hipHostMalloc((void**)&c->rot_ring_host, 32 * ROT_RING, hipHostMallocDefault));
+      HIP_TRY(c, hipMalloc((void**)&c->rot_ring_dev, 32 * ROT_RING));
+    }
+    if (c->rot_ring_next == ROT_RING) {  // a lap: the slots are free again once the stream has passed them
+      HIP_TRY(c, hipStreamSynchronize(c->stream));
+      c->rot_ring_next = 0;
+    }
+    const int slot = c->rot_ring_next++;
+    std::memcpy(c->rot_ring_host + 4 * slot, spinors, 32);
+    HIP_TRY(c, hipMemcpyAsync(c->rot_ring_dev + 4 * slot, c->rot_ring_host + 4 * slot, 32, hipMemcpyHostToDevice, c->stream));
+    d_rot = c->rot_ring_dev + 4 * slot;
+  } else if (mem == BMS_HOST || !series) {
     double* r = nullptr;
     rc = dev_buf_t(c, "rot_spinors", rot_bytes / 8, &r);
     if (rc) return rc;
@@ -637,7 +664,7 @@ static int rotate_impl(bms_ctx* c, void* data, int mem, int64_t n_times, int64_t
   if (mem == BMS_HOST) {
     HIP_TRY(c, hipMemcpyAsync(data, d_data, data_bytes, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
-  } else if (!series) {
+  } else if (!series && sync_after) {
     HIP_TRY(c, hipStreamSynchronize(c->stream));  // the constant rotor was staged from a host stack copy
   }
   return BMS_OK;
@@ -1148,7 +1175,9 @@ static BsplineSpread skew_spread(const PixelTables& T, int cA, int cB, const dou
 }
 
 // Tables of the separable synthesis, built once per (grid, spin, l range) and kept in the context.  Returns with P.nt = 0
-// when the shape is not one the kernel takes.
+// and P.large = false when the shape is one neither kernel takes.
+static int run_synthesis(bms_ctx* c, const SynthesisPlan& P, const double* A, long long lda, long long rows, const double* off, double* Y,
+                         long long ldy);
 static int build_synthesis(bms_ctx* c, int n_theta, int n_phi, int spin, int ell_min, int ell_max, SynthesisPlan& P) {
   const std::array<int, 5> key = {n_theta, n_phi, spin, ell_min, ell_max};
   auto it = c->syn_plans.find(key);
@@ -1164,10 +1193,10 @@ static int build_synthesis(bms_ctx* c, int n_theta, int n_phi, int spin, int ell
   }
   std::vector<int> meta;
   int len = 0;
-  if (!synthesis_split_plan(n_theta, n_phi, ell_min, ell_max, P.g, meta, P.lds, P.nt, len)) {
-    P.nt = 0;
-    return BMS_OK;
-  }
+  if (!synthesis_split_plan(n_theta, n_phi, ell_min, ell_max, P.g, meta, P.lds, P.nt, len)) P.nt = 0;
+  P.large = large_synthesis_supported(n_theta, n_phi, ell_min, ell_max) != 0;
+  P.n_theta = n_theta, P.n_phi = n_phi, P.ell_min = ell_min, P.ell_max = ell_max;
+  if (!P.nt && !P.large) return BMS_OK;
   hipStream_t S = c->stream;
   int rc;
   void* vp;
@@ -1184,9 +1213,11 @@ static int build_synthesis(bms_ctx* c, int n_theta, int n_phi, int spin, int ell
   snprintf(nm_, sizeof nm_, "syn_one_%d", n_theta);
   if ((rc = upload(c, nm_, one.data(), 8 * one.size(), &vp))) return rc;
   const double* d_one = (const double*)vp;
-  snprintf(nm_, sizeof nm_, "syn_meta_%d_%d_%d_%d_%d", n_theta, n_phi, spin, ell_min, ell_max);
-  if ((rc = upload(c, nm_, meta.data(), sizeof(int) * meta.size(), &vp))) return rc;
-  P.d_meta = (int*)vp;
+  if (P.nt) {
+    snprintf(nm_, sizeof nm_, "syn_meta_%d_%d_%d_%d_%d", n_theta, n_phi, spin, ell_min, ell_max);
+    if ((rc = upload(c, nm_, meta.data(), sizeof(int) * meta.size(), &vp))) return rc;
+    P.d_meta = (int*)vp;
+  }
   double* d_Y;
   if ((rc = dev_buf_t(c, "syn_Y", (size_t)n_theta * n_modes * 2, &d_Y))) return rc;
   HIP_TRY(c, hipMemsetAsync(d_Y, 0, 16 * (size_t)n_theta * n_modes, S));
@@ -1196,6 +1227,23 @@ static int build_synthesis(bms_ctx* c, int n_theta, int n_phi, int spin, int ell
   TIMED(c, BMS_TAG_SETUP, launch_theta_table(S, d_Y, d_one, n_theta, n_modes, P.d_T));  // weights 1: the plain sLambda values
   HIP_TRY(c, hipStreamSynchronize(S));  // host vectors above go out of scope
   c->syn_plans[key] = P;
+  return BMS_OK;
+}
+
+// One separable synthesis: A[rows][lda] (complex; n_modes (+ 1 with `off`, always for the one-kernel form) per row) -> Y[rows][ldy]
+static int run_synthesis(bms_ctx* c, const SynthesisPlan& P, const double* A, long long lda, long long rows, const double* off, double* Y,
+                         long long ldy) {
+  hipStream_t S = c->stream;
+  if (rows <= 0) return BMS_OK;
+  if (P.nt && rows >= 2 && !getenv("SCRI_AMD_NO_SPLIT_SYNTHESIS")) {
+    TIMED(c, BMS_TAG_GEMM_SYNTHESIS, launch_synthesis_split(S, A, lda, rows, P.g, P.nt, P.d_T, P.d_meta, off, Y, ldy, P.lds, c->n_cu));
+  } else if (P.large) {
+    double* d_F;
+    int rc = dev_buf_t(c, "Fphi", (size_t)rows * (2 * P.ell_max + 1) * large_analysis_jp(P.n_theta) * 2, &d_F);
+    if (rc) return rc;
+    TIMED(c, BMS_TAG_GEMM_SYNTHESIS, launch_synthesis_large(S, A, lda, rows, P.n_theta, P.n_phi, P.ell_min, P.ell_max, P.d_T, off, d_F, Y, ldy));
+  } else
+    return fail(c, BMS_ERR_UNSUPPORTED, "internal: no separable synthesis for a chunk of %lld row(s) of this shape", rows);
   return BMS_OK;
 }
 
@@ -1659,13 +1707,30 @@ static int transform_modes_impl(bms_ctx* c, const bms_wm_input* in, const bms_tr
   const bool no_boost = tr->boost_velocity[0] == 0 && tr->boost_velocity[1] == 0 && tr->boost_velocity[2] == 0;
   if (bs && no_boost && rows_avail >= 2 && !(sh && sh->col_parts > 1) && tr->n_theta >= 3 && !getenv("SCRI_AMD_NO_SEPARABLE_SYNTHESIS"))
     if ((rc = build_synthesis(c, tr->n_theta, tr->n_phi, s, in->ell_min, in->ell_max, syn))) return rc;
-  const bool sep = syn.nt != 0;
+  const bool sep = syn.nt != 0 || syn.large;
   if (sep) {
     const double* q = tr->frame_rotation;
     if (!(q[0] == 1.0 && q[1] == 0.0 && q[2] == 0.0 && q[3] == 0.0)) {
       // sYlm(F G) = sum_m' D_{m m'}(F) sYlm'(G): the modes as seen from the rotated frame (the constant column stays)
       const double sp[4] = {q[0], q[3], q[2], q[1]};  // (w + i z, y + i x)
-      if ((rc = rotate_impl(c, d_Af, BMS_DEVICE, rows_avail, ld_af / 2, in->ell_min, in->ell_max, sp, false))) return rc;
+      if ((rc = rotate_impl(c, d_Af, BMS_DEVICE, rows_avail, ld_af / 2, in->ell_min, in->ell_max, sp, false, false))) return rc;
+    }
+  }
+  // The psi-mixing types (whose elimination stays on the grid) and the slope-form fallback of the others: without a boost every
+  // field goes through the two-kernel separable synthesis of its own spin; mixing, offset and scale follow on the grid exactly
+  // as they do behind the dense product.
+  SynthesisPlan syn_f[5];
+  bool sep_fields = false;
+  if (!bs && no_boost && rows_avail >= 1 && !(sh && sh->col_parts > 1) && tr->n_theta >= 3 && !getenv("SCRI_AMD_NO_SEPARABLE_SYNTHESIS")) {
+    sep_fields = true;
+    for (int fi = 0; fi < 1 + (psi ? in->n_aux : 0) && sep_fields; ++fi) {
+      const int f_spin = fi ? in->aux_spin[fi - 1] : s, f_lo = fi ? in->aux_ell_min[fi - 1] : in->ell_min, f_hi = fi ? in->aux_ell_max[fi - 1] : in->ell_max;
+      if (f_lo < 0 || f_hi < f_lo) {
+        sep_fields = false;  // (reported below, where the auxiliary fields are checked)
+        break;
+      }
+      if ((rc = build_synthesis(c, tr->n_theta, tr->n_phi, f_spin, f_lo, f_hi, syn_f[fi]))) return rc;
+      sep_fields = syn_f[fi].large;
     }
   }
   PixelTables T;
@@ -1675,7 +1740,7 @@ static int transform_modes_impl(bms_ctx* c, const bms_wm_input* in, const bms_tr
     DP = shared->DP;
   } else {
     if ((rc = device_pixel_tables(c, tr, T, psi ? 1 : 0, s, in->conformal_weight, coef0.empty() ? nullptr : &coef0, nullptr, cv, DP,
-                                  (grid_out || sep) ? 0 : column_plan(tr, n_out), c->aux)))
+                                  (grid_out || sep || sep_fields) ? 0 : column_plan(tr, n_out), c->aux)))
       return rc;
     if (shared) {
       shared->T = T;
@@ -1731,6 +1796,22 @@ static int transform_modes_impl(bms_ctx* c, const bms_wm_input* in, const bms_tr
     char nm[32];
     snprintf(nm, sizeof nm, "Bsyn%d", fi);
     if (sep) continue;  // (no dense sYlm matrix)
+    if (sep_fields) {
+      // the field as seen from the rotated frame: rotated in place in the staging copy (host callers), in a copy otherwise
+      const double* q = tr->frame_rotation;
+      if (!(q[0] == 1.0 && q[1] == 0.0 && q[2] == 0.0 && q[3] == 0.0)) {
+        const double sp[4] = {q[0], q[3], q[2], q[1]};  // (w + i z, y + i x)
+        double* d_copy = const_cast<double*>(f.d_data);
+        if (in->mem == BMS_DEVICE) {
+          snprintf(nm, sizeof nm, "rot_in%d", fi);
+          if ((rc = dev_buf_t(c, nm, (size_t)rows_avail * f.ld * 2, &d_copy))) return rc;
+          HIP_TRY(c, hipMemcpyAsync(d_copy, f.d_data, (size_t)rows_avail * f.ld * 16, hipMemcpyDeviceToDevice, S));
+          f.d_data = d_copy;
+        }
+        if ((rc = rotate_impl(c, d_copy, BMS_DEVICE, rows_avail, f.ld, f.ell_min, f.ell_max, sp, false, false))) return rc;
+      }
+      continue;
+    }
     if ((rc = dev_buf_t(c, nm, (size_t)rows * ldb, &f.d_B))) return rc;
     HIP_TRY(c, hipMemsetAsync(f.d_B, 0, sizeof(double) * rows * ldb, S));
     TIMED(c, BMS_TAG_SETUP, launch_swsh_matrix_complex(S, d_rot, n_cols, f.spin, f.ell_min, f.ell_max, f.d_B, ldb));
@@ -1802,12 +1883,9 @@ static int transform_modes_impl(bms_ctx* c, const bms_wm_input* in, const bms_tr
     else if ((rc = dev_buf_t(c, "G", (size_t)rows_out * ldG, &d_G)))
       return rc;
     if (bs) {
-      if (sep && rows_in >= 2)  // (k = 1 without a boost: no column scale)
-        TIMED(c, BMS_TAG_GEMM_SYNTHESIS, launch_synthesis_split(S, d_Af + (g0 - row0) * ld_af, ld_af, rows_in, syn.g, syn.nt, syn.d_T, syn.d_meta,
-                                                                coef0.empty() ? nullptr : DP.col_off, d_Y, ldg, syn.lds, c->n_cu));
-      else if (sep)
-        return fail(c, BMS_ERR_UNSUPPORTED, "a chunk of one row");
-      else
+      if (sep) {  // (k = 1 without a boost: no column scale)
+        if ((rc = run_synthesis(c, syn, d_Af + (g0 - row0) * ld_af, ld_af, rows_in, coef0.empty() ? nullptr : DP.col_off, d_Y, ldg))) return rc;
+      } else
       TIMED(c, BMS_TAG_GEMM_SYNTHESIS, launch_zgemm3m(S, d_Af + (g0 - row0) * ld_af, ld_af, F[0].d_B + 2 * cA, ldb, d_Y, ldg, rows_in, n_pix,
                                                       n_modes_in + 1, nullptr, d_scale));
       TIMED(c, BMS_TAG_SPLINE_BACKWARD, launch_bspline_backward_eval(S, d_Y, ldg, n_pix, g0, rows_in, n, d_x, d_bstab, SPLINE_TILE, SPLINE_HALO, d_x, d_skewa,
@@ -1816,11 +1894,18 @@ static int transform_modes_impl(bms_ctx* c, const bms_wm_input* in, const bms_tr
     if (psi)
       if ((rc = dev_buf_t(c, "Yaux", (size_t)rows_in * ldg, &d_Yaux))) return rc;
     // synthesis (+ fused affine map when there is no psi mixing)
+    if (sep_fields) {
+      if ((rc = run_synthesis(c, syn_f[0], F[0].d_data + (g0 - row0) * F[0].ld * 2, F[0].ld * 2, rows_in, nullptr, d_Y, ldg))) return rc;
+      if (!psi) TIMED(c, BMS_TAG_POINTWISE, launch_affine_cols(S, d_Y, ldg, (int)P2, rows_in, d_off, d_scale));
+    } else
     TIMED(c, BMS_TAG_GEMM_SYNTHESIS, launch_zgemm3m(S, F[0].d_data + (g0 - row0) * F[0].ld * 2, F[0].ld * 2, F[0].d_B + 2 * cA, ldb, d_Y, ldg, rows_in, n_pix,
                             F[0].K / 2, psi ? nullptr : d_off, psi ? nullptr : d_scale));
     if (psi) {
       for (int a = 0; a < in->n_aux; ++a) {
         const FieldPlan& f = F[1 + a];
+        if (sep_fields) {
+          if ((rc = run_synthesis(c, syn_f[1 + a], f.d_data + (g0 - row0) * f.ld * 2, f.ld * 2, rows_in, nullptr, d_Yaux, ldg))) return rc;
+        } else
         TIMED(c, BMS_TAG_GEMM_SYNTHESIS, launch_zgemm3m(S, f.d_data + (g0 - row0) * f.ld * 2, f.ld * 2, f.d_B + 2 * cA, ldb, d_Yaux, ldg, rows_in, n_pix, f.K / 2,
                                 nullptr, nullptr));
         TIMED(c, BMS_TAG_POINTWISE, launch_psi_mix(S, d_Y, d_Yaux, ldg, n_pix, rows_in, d_x + g0, d_alpha, d_xa, d_xb, in->aux_coeff[a],
@@ -2183,25 +2268,36 @@ extern "C" int bms_salm2map(bms_ctx* c, const void* modes, int mem, int64_t n_ma
   const int n_pix = n_theta * n_phi, nm = (ell_max + 1) * (ell_max + 1);
   hipStream_t S = c->stream;
   int rc;
-  std::vector<double> rot(4 * (size_t)n_pix);
-  for (int j = 0; j < n_theta; ++j)
-    for (int k = 0; k < n_phi; ++k) {
-      const Quat q = from_spherical_coords(M_PI * j / (n_theta - 1), (2 * M_PI) * k / n_phi);
-      double* r = &rot[4 * ((size_t)j * n_phi + k)];
-      r[0] = q.w, r[1] = q.x, r[2] = q.y, r[3] = q.z;
-    }
-  void* vp;
-  if ((rc = upload(c, "gm_rotors", rot.data(), 8 * rot.size(), &vp))) return rc;
   const long long P2 = 2LL * n_pix, ldb = round_up(P2, 128);
-  double* d_B;
-  if ((rc = dev_buf_t(c, "gm_Ba", (size_t)round_up(nm, 8) * ldb, &d_B))) return rc;
-  HIP_TRY(c, hipMemsetAsync(d_B, 0, sizeof(double) * round_up(nm, 8) * ldb, S));
-  TIMED(c, BMS_TAG_SETUP, launch_swsh_matrix_complex(S, (const double*)vp, n_pix, spin, 0, ell_max, d_B, ldb));
+  // the equiangular grid itself: separable (kernels_synthesis_large.hip) wherever that kernel takes the shape
+  SynthesisPlan syn;
+  if (n_theta >= 3 && ell_max >= 1 && !getenv("SCRI_AMD_NO_SEPARABLE_SYNTHESIS"))
+    if ((rc = build_synthesis(c, n_theta, n_phi, spin, 0, ell_max, syn))) return rc;
+  double* d_B = nullptr;
+  if (!syn.large) {
+    std::vector<double> rot(4 * (size_t)n_pix);
+    for (int j = 0; j < n_theta; ++j)
+      for (int k = 0; k < n_phi; ++k) {
+        const Quat q = from_spherical_coords(M_PI * j / (n_theta - 1), (2 * M_PI) * k / n_phi);
+        double* r = &rot[4 * ((size_t)j * n_phi + k)];
+        r[0] = q.w, r[1] = q.x, r[2] = q.y, r[3] = q.z;
+      }
+    void* vp;
+    if ((rc = upload(c, "gm_rotors", rot.data(), 8 * rot.size(), &vp))) return rc;
+    if ((rc = dev_buf_t(c, "gm_Ba", (size_t)round_up(nm, 8) * ldb, &d_B))) return rc;
+    HIP_TRY(c, hipMemsetAsync(d_B, 0, sizeof(double) * round_up(nm, 8) * ldb, S));
+    TIMED(c, BMS_TAG_SETUP, launch_swsh_matrix_complex(S, (const double*)vp, n_pix, spin, 0, ell_max, d_B, ldb));
+  }
   const double* d_a;
   if ((rc = stage_in(c, "in_data", modes, mem, (size_t)n_maps * nm * 16, &d_a))) return rc;
   double* d_G = (double*)grid_out;
   if (mem == BMS_HOST)
     if ((rc = dev_buf_t(c, "out_data", (size_t)n_maps * P2, &d_G))) return rc;
+  if (syn.large) {
+    SynthesisPlan two = syn;
+    two.nt = 0;  // (the one-kernel form wants padded rows)
+    if ((rc = run_synthesis(c, two, d_a, 2LL * nm, n_maps, nullptr, d_G, P2))) return rc;
+  } else
   TIMED(c, BMS_TAG_GEMM_SYNTHESIS, launch_zgemm3m(S, d_a, 2LL * nm, d_B, ldb, d_G, P2, n_maps, n_pix, nm, nullptr, nullptr));
   if (mem == BMS_HOST) HIP_TRY(c, hipMemcpyAsync(grid_out, d_G, (size_t)n_maps * n_pix * 16, hipMemcpyDeviceToHost, S));
   HIP_TRY(c, hipStreamSynchronize(S));
@@ -2310,7 +2406,7 @@ extern "C" int bms_grid_multiply(bms_ctx* c, const void* a, int spin_a, int ell_
   if (sep) {
     if ((rc = build_synthesis(c, n_theta, n_phi, spin_a, 0, ell_max_a, syn_a))) return rc;
     if ((rc = build_synthesis(c, n_theta, n_phi, spin_b, 0, ell_max_b, syn_b))) return rc;
-    sep = syn_a.nt != 0 && syn_b.nt != 0;
+    sep = (syn_a.nt != 0 || syn_a.large) && (syn_b.nt != 0 || syn_b.large);
   }
   void* vp;
   const long long P2 = 2LL * n_pix, ldb = round_up(P2, 128);
@@ -2335,13 +2431,16 @@ extern "C" int bms_grid_multiply(bms_ctx* c, const void* a, int spin_a, int ell_
     if ((rc = dev_buf_t(c, "out_data", (size_t)n_times * n_out * 2, &d_out))) return rc;
   // (the separable kernel reads one more complex number per row -- the eliminated constant of the transformation's series: the
   // operands are copied to rows with a zero there)
+  // (the two-kernel form reads the plain rows)
   double *d_ap = nullptr, *d_bp = nullptr;
-  if (sep) {
+  if (sep && syn_a.nt) {
     if ((rc = dev_buf_t(c, "gm_a_pad", (size_t)n_times * (nma + 1) * 2, &d_ap))) return rc;
-    if ((rc = dev_buf_t(c, "gm_b_pad", (size_t)n_times * (nmb + 1) * 2, &d_bp))) return rc;
     HIP_TRY(c, hipMemset2DAsync(d_ap + 2 * nma, (size_t)(nma + 1) * 16, 0, 16, (size_t)n_times, S));
-    HIP_TRY(c, hipMemset2DAsync(d_bp + 2 * nmb, (size_t)(nmb + 1) * 16, 0, 16, (size_t)n_times, S));
     HIP_TRY(c, hipMemcpy2DAsync(d_ap, (size_t)(nma + 1) * 16, d_a, (size_t)nma * 16, (size_t)nma * 16, (size_t)n_times, hipMemcpyDeviceToDevice, S));
+  }
+  if (sep && syn_b.nt) {
+    if ((rc = dev_buf_t(c, "gm_b_pad", (size_t)n_times * (nmb + 1) * 2, &d_bp))) return rc;
+    HIP_TRY(c, hipMemset2DAsync(d_bp + 2 * nmb, (size_t)(nmb + 1) * 16, 0, 16, (size_t)n_times, S));
     HIP_TRY(c, hipMemcpy2DAsync(d_bp, (size_t)(nmb + 1) * 16, d_b, (size_t)nmb * 16, (size_t)nmb * 16, (size_t)n_times, hipMemcpyDeviceToDevice, S));
   }
   // chunks of time rows: two grids of 16 n_pix bytes per row
@@ -2353,13 +2452,13 @@ extern "C" int bms_grid_multiply(bms_ctx* c, const void* a, int spin_a, int ell_
     double *d_Ga, *d_Gb;
     if ((rc = dev_buf_t(c, "Y", (size_t)rows * P2, &d_Ga))) return rc;
     if ((rc = dev_buf_t(c, "R", (size_t)rows * P2, &d_Gb))) return rc;
-    if (sep && rows >= 2) {
-      TIMED(c, BMS_TAG_GEMM_SYNTHESIS, launch_synthesis_split(S, d_ap + r0 * (nma + 1) * 2, 2LL * (nma + 1), rows, syn_a.g, syn_a.nt, syn_a.d_T, syn_a.d_meta,
-                                                              nullptr, d_Ga, P2, syn_a.lds, c->n_cu));
-      TIMED(c, BMS_TAG_GEMM_SYNTHESIS, launch_synthesis_split(S, d_bp + r0 * (nmb + 1) * 2, 2LL * (nmb + 1), rows, syn_b.g, syn_b.nt, syn_b.d_T, syn_b.d_meta,
-                                                              nullptr, d_Gb, P2, syn_b.lds, c->n_cu));
-    } else if (sep) {
-      return fail(c, BMS_ERR_UNSUPPORTED, "a chunk of one row");
+    if (sep) {
+      if ((rc = syn_a.nt ? run_synthesis(c, syn_a, d_ap + r0 * (nma + 1) * 2, 2LL * (nma + 1), rows, nullptr, d_Ga, P2)
+                         : run_synthesis(c, syn_a, d_a + r0 * nma * 2, 2LL * nma, rows, nullptr, d_Ga, P2)))
+        return rc;
+      if ((rc = syn_b.nt ? run_synthesis(c, syn_b, d_bp + r0 * (nmb + 1) * 2, 2LL * (nmb + 1), rows, nullptr, d_Gb, P2)
+                         : run_synthesis(c, syn_b, d_b + r0 * nmb * 2, 2LL * nmb, rows, nullptr, d_Gb, P2)))
+        return rc;
     } else {
       TIMED(c, BMS_TAG_GEMM_SYNTHESIS, launch_zgemm3m(S, d_a + r0 * nma * 2, 2LL * nma, d_Ba, ldb, d_Ga, P2, rows, n_pix, nma, nullptr, nullptr));
       TIMED(c, BMS_TAG_GEMM_SYNTHESIS, launch_zgemm3m(S, d_b + r0 * nmb * 2, 2LL * nmb, d_Bb, ldb, d_Gb, P2, rows, n_pix, nmb, nullptr, nullptr));
@@ -2509,6 +2608,14 @@ static int transform_abd_impl(bms_ctx* c, const double* u, const void* raw, int 
                       {v[0] * std::sqrt(2 * M_PI / 3), v[1] * std::sqrt(2 * M_PI / 3)},
                       {v[2] * std::sqrt(4 * M_PI / 3), 0},
                       {-v[0] * std::sqrt(2 * M_PI / 3), v[1] * std::sqrt(2 * M_PI / 3)}};
+  // Without a boost (every supertranslation and rotation step of map_to_superrest_frame, map_to_superrest_frame.py:443,610,641)
+  // the six dense products give way to the separable synthesis on the rotated modes (kernels_synthesis_large.hip).
+  SynthesisPlan syn5[5];
+  bool sep = v[0] == 0 && v[1] == 0 && v[2] == 0 && !(sh && sh->col_parts > 1) && tr->n_theta >= 3 && !getenv("SCRI_AMD_NO_SEPARABLE_SYNTHESIS");
+  for (int si = 0; si < 5 && sep; ++si) {
+    if ((rc = build_synthesis(c, tr->n_theta, tr->n_phi, si - 2, 0, ell_max, syn5[si]))) return rc;
+    sep = syn5[si].large;
+  }
   PixelTables T;
   DevPixel DP;
   // (pieces of a pipelined call share the per-direction tables and the knot tables of the whole series)
@@ -2517,7 +2624,7 @@ static int transform_abd_impl(bms_ctx* c, const double* u, const void* raw, int 
     T = shared->T;
     DP = shared->DP;
   } else {
-    if ((rc = device_pixel_tables(c, tr, T, 2, 0, 0, &c1, &c2, cv, DP, column_plan(tr, n_out)))) return rc;
+    if ((rc = device_pixel_tables(c, tr, T, 2, 0, 0, &c1, &c2, cv, DP, sep ? 0 : column_plan(tr, n_out)))) return rc;
     if (shared) {
       shared->T = T;
       shared->DP = DP;
@@ -2583,9 +2690,11 @@ static int transform_abd_impl(bms_ctx* c, const double* u, const void* raw, int 
     char nm1[32], tag[16];
     snprintf(nm1, sizeof nm1, "abd_B%d", si);
     snprintf(tag, sizeof tag, "abd%d", si);
-    if ((rc = dev_buf_t(c, nm1, (size_t)brows * ldb, &d_B[si]))) return rc;
-    HIP_TRY(c, hipMemsetAsync(d_B[si], 0, sizeof(double) * brows * ldb, S));
-    TIMED(c, BMS_TAG_SETUP, launch_swsh_matrix_complex(S, d_rot, n_cols, si - 2, 0, ell_max, d_B[si], ldb));
+    if (!sep) {
+      if ((rc = dev_buf_t(c, nm1, (size_t)brows * ldb, &d_B[si]))) return rc;
+      HIP_TRY(c, hipMemsetAsync(d_B[si], 0, sizeof(double) * brows * ldb, S));
+      TIMED(c, BMS_TAG_SETUP, launch_swsh_matrix_complex(S, d_rot, n_cols, si - 2, 0, ell_max, d_B[si], ldb));
+    }
     if ((rc = build_analysis(c, tag, T.n_theta, T.n_phi, si - 2, 0, tr->ell_max_out, ana[si]))) return rc;
     if (col_split && n_pix > 0) {
       snprintf(nm1, sizeof nm1, "abd_At%d", si);
@@ -2599,6 +2708,21 @@ static int transform_abd_impl(bms_ctx* c, const double* u, const void* raw, int 
   double* d_out = (double*)raw_out;
   if (mem == BMS_HOST)
     if ((rc = dev_buf_t(c, "out_data", (size_t)6 * fs_out * n_out * 2, &d_out))) return rc;
+  if (sep) {
+    // the six fields as seen from the rotated frame, sYlm(F G) = sum_m' D_{m m'}(F) sYlm'(G): [6][rows][nm] is one series of
+    // 6 x rows steps for the rotation kernel -- in place in the staging copy of a host caller, in a copy of device data
+    const double* q = tr->frame_rotation;
+    if (!(q[0] == 1.0 && q[1] == 0.0 && q[2] == 0.0 && q[3] == 0.0)) {
+      const double sp[4] = {q[0], q[3], q[2], q[1]};  // (w + i z, y + i x)
+      double* d_copy = const_cast<double*>(d_raw);
+      if (mem == BMS_DEVICE) {
+        if ((rc = dev_buf_t(c, "abd_rot_in", (size_t)6 * rows_avail * nm * 2, &d_copy))) return rc;
+        HIP_TRY(c, hipMemcpyAsync(d_copy, d_raw, (size_t)6 * rows_avail * nm * 16, hipMemcpyDeviceToDevice, S));
+        d_raw = d_copy;
+      }
+      if ((rc = rotate_impl(c, d_copy, BMS_DEVICE, 6 * rows_avail, nm, 0, ell_max, sp, false, false))) return rc;
+    }
+  }
 
   if (n_pix == 0) {  // more parts than column tiles: this part contributes nothing
     for (int f = 0; f < 6; ++f) {
@@ -2641,6 +2765,10 @@ static int transform_abd_impl(bms_ctx* c, const double* u, const void* raw, int 
     AbdGrids grids;
     for (int f = 0; f < 6; ++f) {
       grids.y[f] = d_Y + (size_t)f * rows_in * ldg;
+      if (sep) {
+        if ((rc = run_synthesis(c, syn5[spins[f] + 2], d_raw + ((size_t)f * rows_avail + (g0 - row0)) * nm * 2, 2LL * nm, rows_in, nullptr, grids.y[f], ldg)))
+          return rc;
+      } else
       TIMED(c, BMS_TAG_GEMM_SYNTHESIS,
             launch_zgemm3m(S, d_raw + ((size_t)f * rows_avail + (g0 - row0)) * nm * 2, 2LL * nm, d_B[spins[f] + 2] + 2 * cA, ldb, grids.y[f], ldg, rows_in,
                            n_pix, K / 2, nullptr, nullptr));

@@ -114,6 +114,14 @@ hipError_t launch_synthesis_split(hipStream_t stream, const double* A, long long
                                   const double* Tsyn, const int* meta, const double* off, double* Y, long long ldy, size_t lds_bytes,
                                   int n_cu);
 
+// two-kernel form for the grids the one-kernel form does not take (kernels_synthesis_large.hip): n_theta <= 104, n_phi <= 127,
+// l_max <= 33, any l_min; F = n_rows x (2 l_max + 1) x large_analysis_jp(n_theta) complex of work space.  With `off` the row has
+// one more complex number at column n_modes (the eliminated constant series), which multiplies -off[pixel].
+int large_synthesis_supported(int n_theta, int n_phi, int ell_min, int ell_max);
+hipError_t launch_synthesis_large(hipStream_t stream, const double* A, long long lda, long long n_rows, int n_theta, int n_phi,
+                                  int ell_min, int ell_max, const double* Tsyn, const double* off, double* F, double* Y,
+                                  long long ldy);
+
 // ---- dense fp64 GEMM on MFMA: C[M x N] = (A[M x K] * B[K x N] - col_off[N]) * col_scale[N]
 // A row-major (lda), B row-major (ldb, zero padded to a multiple of 128 columns and 16 rows), C row-major (ldc).
 hipError_t launch_dgemm(hipStream_t stream, const double* A, long long lda, const double* B, long long ldb, double* C,

@@ -303,3 +303,53 @@ def test_cfg5_grid_boosted_schwarzschild_every_time_step(ctx):
     P = ap.bondi_four_momentum()
     assert np.abs(P - mass * gamma * np.array([1, *-v])[None, :]).max() < 1e-13
     assert np.abs(ap._raw_data[[3, 4, 5]]).max() < 1e-13  # no shear, no radiation (psi1', psi0' pick up u eth psi2 terms)
+
+
+def test_cfg5_whole_series_equals_its_eight_shards_and_oracle_at_interior_seams(ctx):
+    """BASELINE.json configs[4] as a whole: the full 2e5-step series of the six fields (12 GB of modes, l <= 24, 99 x 99 grid) on ONE
+    GPU, resident in HBM, against (i) the 8 time shards of `sharding.plan`, each transformed from its own rows + halo only -- what the
+    8 ranks of the sharded run compute -- to 1e-14 of the data's scale, every seam included, and (ii) the oracle
+    (scri/asymptotic_bondi_data/transformations.py:199-431 restated) on windows across two interior seams, ranks 3|4 and 5|6."""
+    import torch
+
+    from scri_amd import engine, sharding, synthetic
+
+    spec = synthetic.CONFIGS["cfg5"]
+    kw = dict(spec["kwargs"], working_ell_max=49)
+    n, L = spec["n_times"], spec["ell_max"]
+    nm = (L + 1) ** 2
+    u = np.arange(n) * spec["dt"]
+    n_theta = 2 * kw["working_ell_max"] + 1
+    tr = engine.make_transformation(kw["supertranslation"], kw["frame_rotation"], kw["boost_velocity"], n_theta, n_theta, L)
+    have, need, window = sharding.plan(u, tr, 8)
+    dev = torch.device("cuda", ctx.device)
+    d_in = torch.empty((6, n, nm), dtype=torch.complex128, device=dev)
+    for r in range(8):  # the series is generated and uploaded shard by shard: 1.5 GB of host memory at a time
+        _, rows, _ = synthetic.abd_workload("cfg5", rows=have[r])
+        d_in[:, have[r][0] : have[r][1]] = torch.from_numpy(rows).to(dev)
+        del rows
+    d_out = torch.empty((6, n, nm), dtype=torch.complex128, device=dev)
+    torch.cuda.synchronize()
+    u_out, n_new = engine.transform_abd(u, d_in.data_ptr(), L, tr, ctx=ctx, device=True, out_ptr=d_out.data_ptr())
+    assert n_new == window[1] - window[0] and n_new > n - 1000
+    scale = float(d_out[:, :n_new].abs().max())
+    assert scale > 0.1
+    # (i) the eight shards
+    row = 0
+    d_part = torch.empty((6, have[0][1] - have[0][0], nm), dtype=torch.complex128, device=dev)
+    for r in range(8):
+        ext = d_in[:, need[r][0] : need[r][1]].contiguous()
+        torch.cuda.synchronize()
+        up, nr, first = engine.transform_abd(u, ext.data_ptr(), L, tr, ctx=ctx, device=True, out_ptr=d_part.data_ptr(),
+                                             shard=(need[r][0], ext.shape[1], have[r][0], have[r][1]))
+        assert first == window[0] + row and np.array_equal(up, u_out[row : row + nr])
+        worst = float((d_part[:, :nr] - d_out[:, row : row + nr]).abs().max())
+        assert worst <= 1e-14 * scale, (r, worst)
+        row += nr
+        del ext
+    assert row == n_new
+    # (ii) the oracle across the seams 3|4 and 5|6 (a slice of the whole result around each seam)
+    for seam in (have[4][0], have[6][0]):
+        lo, hi = seam - 700 - window[0], seam + 700 - window[0]
+        got_raw = d_out[:, lo:hi].cpu().numpy()
+        _abd_window_check(u_out[lo:hi], got_raw, kw, L, [(seam - 240, 480)])
