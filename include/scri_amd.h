@@ -246,7 +246,7 @@ int bms_cubic_spline(bms_ctx* ctx, const double* x, int64_t n, const void* y, in
                      const double* x_new, int64_t n_new, void* out);
 
 /* ---- "next" rows of the scope table: time-series calculus and grid products ------------- */
-/* scipy CubicSpline(x, y).derivative(order) (order 1..3), the spline itself (0) or .antiderivative(-order) (order -1, -2;
+/* scipy CubicSpline(x, y).derivative(order) (order 1..3), the spline itself (0) or .antiderivative(-order) (order -1 .. -16;
  * zero at x[0]) evaluated at x_new (any order of samples): ModesTimeSeries.interpolate(new_time, derivative_order) and
  * .dot / .ddot / .int / .iint (scri/modes_time_series.py:72-126).  y: c16[n][ld], out: c16[n_new][n_cols], both in `mem`. */
 int bms_spline_derivative(bms_ctx* ctx, const double* x, int64_t n, const void* y, int64_t ld, int64_t n_cols, int mem,

@@ -2097,7 +2097,7 @@ extern "C" int bms_spline_derivative(bms_ctx* c, const double* x, int64_t n, con
   HIP_TRY(c, hipSetDevice(c->device));
   if (n < 4) return fail(c, BMS_ERR_UNSUPPORTED, "cubic spline needs at least 4 knots, got %lld", (long long)n);
   if (ld < n_cols || n_cols <= 0) return fail(c, BMS_ERR_INVALID, "bad column count / stride");
-  if (order < -2 || order > 3) return fail(c, BMS_ERR_INVALID, "derivative order %d outside [-2, 3]", order);
+  if (order < -16 || order > 3) return fail(c, BMS_ERR_INVALID, "derivative order %d outside [-16, 3]", order);
   for (int64_t i = 1; i < n; ++i)
     if (!(x[i] > x[i - 1])) return fail(c, BMS_ERR_INVALID, "knots must be strictly increasing");
   if (n_new <= 0) return BMS_OK;
@@ -2116,6 +2116,22 @@ extern "C" int bms_spline_derivative(bms_ctx* c, const double* x, int64_t n, con
   const int tile = spline_tile_for(x, n);
   TIMED(c, BMS_TAG_SPLINE_FORWARD, launch_spline_forward(S, d_y, d_R, 2 * ld, (int)n_cols, 0, n, n, d_x, d_tab, tile, SPLINE_HALO));
   TIMED(c, BMS_TAG_SPLINE_BACKWARD, launch_spline_slopes(S, d_R, d_S, 2 * ld, (int)n_cols, n, d_tab, tile, SPLINE_HALO));
+  double* d_out = (double*)out;
+  if (mem == BMS_HOST)
+    if ((rc = dev_buf_t(c, "out_data", (size_t)n_new * n_cols * 2, &d_out))) return rc;
+  if (order < -2) {  // any antiderivative order (scri/modes_time_series.py:88-89): one array of knot values per level
+    const int k = -order;
+    double* d_Pall;
+    const long long level_stride = (long long)n * ld * 2;
+    if ((rc = dev_buf_t(c, "P_levels", (size_t)k * level_stride, &d_Pall))) return rc;
+    if ((rc = dev_buf_t(c, "P_carry", (size_t)spline_prefix_carry_size(n, (int)n_cols), &d_carry))) return rc;
+    TIMED(c, BMS_TAG_POINTWISE, launch_spline_prefix_levels(S, d_y, d_S, 2 * ld, (int)n_cols, n, d_x, d_Pall, level_stride, d_carry, k));
+    TIMED(c, BMS_TAG_POINTWISE, launch_spline_antiderivative_eval(S, d_y, d_S, d_Pall, level_stride, 2 * ld, (int)n_cols, n, d_x,
+                                                                  (const double*)d_xn, n_new, k, d_out, 2 * n_cols));
+    if (mem == BMS_HOST) HIP_TRY(c, hipMemcpyAsync(out, d_out, (size_t)n_new * n_cols * 16, hipMemcpyDeviceToHost, S));
+    HIP_TRY(c, hipStreamSynchronize(S));
+    return BMS_OK;
+  }
   if (order < 0) {
     if ((rc = dev_buf_t(c, "P1", (size_t)n * ld * 2, &d_P1))) return rc;
     if (order < -1)
@@ -2123,9 +2139,6 @@ extern "C" int bms_spline_derivative(bms_ctx* c, const double* x, int64_t n, con
     if ((rc = dev_buf_t(c, "P_carry", (size_t)spline_prefix_carry_size(n, (int)n_cols), &d_carry))) return rc;
     TIMED(c, BMS_TAG_POINTWISE, launch_spline_prefix(S, d_y, d_S, 2 * ld, (int)n_cols, n, d_x, d_P1, d_P2, d_carry, -order));
   }
-  double* d_out = (double*)out;
-  if (mem == BMS_HOST)
-    if ((rc = dev_buf_t(c, "out_data", (size_t)n_new * n_cols * 2, &d_out))) return rc;
   TIMED(c, BMS_TAG_POINTWISE, launch_spline_hermite_eval(S, d_y, d_S, d_P1, d_P2, 2 * ld, (int)n_cols, n, d_x, (const double*)d_xn,
                                                          n_new, order, d_out, 2 * n_cols));
   if (mem == BMS_HOST) HIP_TRY(c, hipMemcpyAsync(out, d_out, (size_t)n_new * n_cols * 16, hipMemcpyDeviceToHost, S));

@@ -198,6 +198,12 @@ hipError_t launch_spline_slopes(hipStream_t stream, const double* R, double* S, 
                                 const SplineTable* table, int tile, int halo);
 // running integrals at the knots: P1 = int f (order >= 1), P2 = int P1 (order 2); carry: spline_prefix_carry_size doubles
 long long spline_prefix_carry_size(long long n, int n_cols);
+// antiderivatives of order k >= 3: knot values of the levels 1..k in Pall + (r - 1) level_stride (doubles), then the evaluation
+hipError_t launch_spline_prefix_levels(hipStream_t stream, const double* Y, const double* S, long long ld, int n_cols, long long n,
+                                       const double* x, double* Pall, long long level_stride, double* carry, int levels);
+hipError_t launch_spline_antiderivative_eval(hipStream_t stream, const double* Y, const double* S, const double* Pall, long long level_stride,
+                                             long long ld, int n_cols, long long n, const double* x, const double* x_new, long long n_new,
+                                             int k, double* out, long long ldo);
 hipError_t launch_spline_prefix(hipStream_t stream, const double* Y, const double* S, long long ld, int n_cols, long long n,
                                 const double* x, double* P1, double* P2, double* carry, int order);
 // out[i][c] = (d/du)^order spline_c(x_new[i]), order in [-2, 3] (negative: antiderivatives vanishing at x[0])

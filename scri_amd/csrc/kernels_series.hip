@@ -133,6 +133,126 @@ hipError_t launch_spline_prefix(hipStream_t stream, const double* Y, const doubl
 }
 long long spline_prefix_carry_size(long long n, int n_cols) { return ((n + 511) / 512) * 2LL * n_cols; }
 
+// ---- antiderivatives of any order k >= 3 (scipy's PPoly.antiderivative(k): k integrations, each vanishing at the first knot).
+// Level r = 1..k keeps its knot values A_r(x_j) in Pall + (r - 1) level_stride; with the interval's cubic c_0..c_3 (c_0 = y_j,
+// c_1 = s_j) and h = x_{j+1} - x_j the Taylor shift is
+//     A_r(x_j + t) = sum_{q=0}^{r-1} A_{r-q}(x_j) t^q / q!  +  t^r sum_{n=0}^{3} c_n n! / (n + r)! t^n ,
+// so level r needs the levels below it at the same knot: the levels run one after the other, each as the three phases of
+// spline_prefix_kernel (tile totals, running sum over tiles, prefix within the tile).
+__device__ __forceinline__ double2 antiderivative_shift(const double* __restrict__ lower /* level 1 at knot j, column p */, long long level_stride,
+                                                        int r, bool with_own, double2 y0, double2 s0, const Hermite& H, double t) {
+  // sum_{q = (with_own ? 0 : 1)}^{r-1} A_{r-q}(x_j) t^q / q!   (A_r itself is the caller's running value when !with_own)
+  double2 acc{0.0, 0.0};
+  double tq = with_own ? 1.0 : t;  // t^q / q!
+  for (int q = with_own ? 0 : 1; q < r; ++q) {
+    const double2 a = *reinterpret_cast<const double2*>(lower + (long long)(r - q - 1) * level_stride);
+    acc.x = fma(a.x, tq, acc.x);
+    acc.y = fma(a.y, tq, acc.y);
+    tq *= t / (double)(q + 1);
+  }
+  // t^r / r! (c_0 + t (c_1 / (r+1) + t (2 c_2 / ((r+1)(r+2)) + t 6 c_3 / ((r+1)(r+2)(r+3)))))
+  double tr = 1.0;
+  for (int q = 1; q <= r; ++q) tr *= t / (double)q;
+  const double f1 = 1.0 / (r + 1.0), f2 = 2.0 * f1 / (r + 2.0), f3 = 3.0 * f2 / (r + 3.0);
+  acc.x = fma(tr, y0.x + t * (s0.x * f1 + t * (H.c2x * f2 + t * H.c3x * f3)), acc.x);
+  acc.y = fma(tr, y0.y + t * (s0.y * f1 + t * (H.c2y * f2 + t * H.c3y * f3)), acc.y);
+  return acc;
+}
+
+__global__ __launch_bounds__(64) void spline_prefix_level_kernel(const double* __restrict__ Y, const double* __restrict__ S, long long ld,
+                                                                 int n_cols, long long n, const double* __restrict__ x, int tile,
+                                                                 double* __restrict__ Pall, long long level_stride,
+                                                                 double* __restrict__ carry, int phase, int r) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n_cols) return;
+  const long long n_tiles = (n + tile - 1) / tile;
+  if (phase == 2) {
+    if (blockIdx.y != 0) return;
+    double2 run = {0.0, 0.0};
+    for (long long t = 0; t < n_tiles; ++t) {
+      double2* cp = reinterpret_cast<double2*>(carry + t * 2LL * n_cols + 2LL * p);
+      const double2 v = *cp;
+      *cp = run;
+      run.x += v.x, run.y += v.y;
+    }
+    return;
+  }
+  const long long jA = (long long)blockIdx.y * tile;
+  long long jB = jA + tile;
+  if (jB > n) jB = n;
+  if (jA >= n) return;
+  const double* yp = Y + 2LL * p;
+  const double* sp = S + 2LL * p;
+  double* out = Pall + (long long)(r - 1) * level_stride + 2LL * p;
+  double2* cp = reinterpret_cast<double2*>(carry + (long long)blockIdx.y * 2LL * n_cols + 2LL * p);
+  double2 run = phase == 3 ? *cp : double2{0.0, 0.0};
+  double2 y0 = *reinterpret_cast<const double2*>(yp + jA * ld), s0 = *reinterpret_cast<const double2*>(sp + jA * ld);
+  for (long long j = jA; j < jB; ++j) {
+    if (phase == 3) *reinterpret_cast<double2*>(out + j * ld) = run;
+    if (j + 1 >= n) break;
+    const double2 y1 = *reinterpret_cast<const double2*>(yp + (j + 1) * ld);
+    const double2 s1 = *reinterpret_cast<const double2*>(sp + (j + 1) * ld);
+    const double h = x[j + 1] - x[j];
+    const Hermite H = hermite(y0, y1, s0, s1, h);
+    const double2 inc = antiderivative_shift(Pall + 2LL * p + j * ld, level_stride, r, false, y0, s0, H, h);
+    run.x += inc.x, run.y += inc.y;
+    y0 = y1, s0 = s1;
+  }
+  if (phase == 1) *cp = run;
+}
+
+hipError_t launch_spline_prefix_levels(hipStream_t stream, const double* Y, const double* S, long long ld, int n_cols, long long n,
+                                       const double* x, double* Pall, long long level_stride, double* carry, int levels) {
+  if (n <= 0 || n_cols <= 0) return hipSuccess;
+  const int tile = 512;
+  const long long n_tiles = (n + tile - 1) / tile;
+  dim3 grid((n_cols + 63) / 64, (unsigned)n_tiles), one((n_cols + 63) / 64, 1);
+  for (int r = 1; r <= levels; ++r)
+    for (int phase = 1; phase <= 3; ++phase)
+      hipLaunchKernelGGL(spline_prefix_level_kernel, phase == 2 ? one : grid, dim3(64), 0, stream, Y, S, ld, n_cols, n, x, tile, Pall,
+                         level_stride, carry, phase, r);
+  return hipGetLastError();
+}
+
+__global__ __launch_bounds__(256) void spline_antiderivative_eval_kernel(const double* __restrict__ Y, const double* __restrict__ S,
+                                                                         const double* __restrict__ Pall, long long level_stride,
+                                                                         long long ld, int n_cols, long long n, const double* __restrict__ x,
+                                                                         const double* __restrict__ x_new, long long n_new, int k,
+                                                                         double* __restrict__ out, long long ldo) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  for (long long i = blockIdx.y; i < n_new; i += gridDim.y) {
+    const double u = x_new[i];
+    long long lo = 0, hi = n - 1;
+    while (hi - lo > 1) {
+      const long long mid = (lo + hi) >> 1;
+      if (x[mid] <= u)
+        lo = mid;
+      else
+        hi = mid;
+    }
+    const long long j = lo;
+    if (p >= n_cols) continue;
+    const double xj = x[j], h = x[j + 1] - xj, t = u - xj;
+    const double2 y0 = *reinterpret_cast<const double2*>(Y + 2LL * p + j * ld);
+    const double2 y1 = *reinterpret_cast<const double2*>(Y + 2LL * p + (j + 1) * ld);
+    const double2 s0 = *reinterpret_cast<const double2*>(S + 2LL * p + j * ld);
+    const double2 s1 = *reinterpret_cast<const double2*>(S + 2LL * p + (j + 1) * ld);
+    const Hermite H = hermite(y0, y1, s0, s1, h);
+    *reinterpret_cast<double2*>(out + 2LL * p + i * ldo) = antiderivative_shift(Pall + 2LL * p + j * ld, level_stride, k, true, y0, s0, H, t);
+  }
+}
+
+hipError_t launch_spline_antiderivative_eval(hipStream_t stream, const double* Y, const double* S, const double* Pall, long long level_stride,
+                                             long long ld, int n_cols, long long n, const double* x, const double* x_new, long long n_new,
+                                             int k, double* out, long long ldo) {
+  if (n_new <= 0 || n_cols <= 0) return hipSuccess;
+  const int threads = n_cols >= 256 ? 256 : ((n_cols + 63) / 64) * 64;
+  dim3 grid((n_cols + threads - 1) / threads, (unsigned)(n_new < 32768 ? n_new : 32768));
+  hipLaunchKernelGGL(spline_antiderivative_eval_kernel, grid, dim3(threads), 0, stream, Y, S, Pall, level_stride, ld, n_cols, n, x, x_new,
+                     n_new, k, out, ldo);
+  return hipGetLastError();
+}
+
 // ------------------------------------------------------------------------------------------------ evaluation
 // out[i][c] = d^k/du^k spline_c (x_new[i]), k = order in [-2, 3]; interval found by binary search (the same for every
 // column of a block row), end intervals extrapolate (scipy's default).  Lanes across columns.

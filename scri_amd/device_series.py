@@ -304,8 +304,8 @@ class DeviceModesTimeSeries:
             raise ValueError(f"New time array must have exactly 1 dimension; it has {new_time.ndim}.")
         if derivative_order > 3:
             raise ValueError(f"{type(self)} interpolation uses CubicSpline, and cannot take a derivative of order {derivative_order}")
-        if derivative_order < -2:
-            raise NotImplementedError("antiderivatives beyond the second are not provided")
+        if derivative_order < -16:
+            raise NotImplementedError("antiderivatives beyond the sixteenth are not provided")
         n_cols = self.buf.shape[1]
         res = empty(self._ctx, (new_time.size, n_cols))
         x = np.ascontiguousarray(self._time)

@@ -487,7 +487,7 @@ def cubic_spline(x, y, x_new, ctx=None):
 
 
 def spline_derivative(x, y, x_new, order=0, ctx=None):
-    """scipy CubicSpline(x, y, axis=0) differentiated (`order` 1..3) or integrated (`order` -1, -2; zero at x[0]) and
+    """scipy CubicSpline(x, y, axis=0) differentiated (`order` 1..3) or integrated (`order` -1 .. -16; zero at x[0]) and
     evaluated at x_new, for complex y[N, ...]."""
     ctx = _ctx(ctx)
     x = np.ascontiguousarray(x, dtype=float)

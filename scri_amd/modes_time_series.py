@@ -126,8 +126,8 @@ class ModesTimeSeries(np.ndarray):
             raise ValueError(
                 f"{type(self)} interpolation uses CubicSpline, and cannot take a derivative of order {derivative_order}"
             )
-        if derivative_order < -2:
-            raise NotImplementedError("antiderivatives beyond the second are not provided")
+        if derivative_order < -16:
+            raise NotImplementedError("antiderivatives beyond the sixteenth are not provided")
         data = self.ndarray
         if data.shape[-2] != self.n_times:
             raise ValueError("cannot interpolate a time-independent series")
