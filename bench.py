@@ -327,7 +327,7 @@ def boost_free_line(local, t_global, kw, n_theta, ell_max, ctx):
     }
 
 
-def plumbing_only(args, rank, world):
+def plumbing_only(args, rank, world, backend_note=None):
     """The N > 1 path minus the kernels, for a box without GPUs (CPU test of the launcher): shard plan from the library's host
     planner, one halo exchange of the synthetic input rows over the process group, every rank's rows checked."""
     import torch
@@ -350,7 +350,8 @@ def plumbing_only(args, rank, world):
     ok = torch.tensor([1 if np.array_equal(ext.numpy(), expect) else 0])
     dist.all_reduce(ok, op=dist.ReduceOp.MIN)
     if rank == 0:
-        print(json.dumps({"plumbing_only": True, "n_gpus": world, "backend": dist.get_backend(), "halo_rows_exact": bool(int(ok)),
+        print(json.dumps({"plumbing_only": True, "n_gpus": world, "backend": dist.get_backend(), "backend_note": backend_note,
+                          "halo_rows_exact": bool(int(ok)),
                           "have": have, "need": need, "window": list(window), "workload": args.workload, "n_times_total": n_global}))
     dist.barrier()
     dist.destroy_process_group()
@@ -415,8 +416,8 @@ def main():
     # SCRI_AMD_BENCH_BACKEND=gloo: dry run of the multi-rank path on a box with fewer GPUs than ranks (ranks share
     # devices, halos travel through the host); the measured configuration is nccl = RCCL, one rank per GPU
     backend = os.environ.get("SCRI_AMD_BENCH_BACKEND", "nccl")
-    if args.plumbing_only:
-        backend = "gloo"
+    if args.plumbing_only and os.environ.get("SCRI_AMD_BENCH_BACKEND") != "nccl":
+        backend = "gloo"  # (with nccl asked for explicitly the bring-up below is attempted, fails without GPUs and falls back: its test)
     n_dev = max(torch.cuda.device_count(), 1)
     dev_index = local_rank % n_dev
     if not args.plumbing_only:
@@ -432,8 +433,12 @@ def main():
             # RCCL; otherwise all of them fall back to gloo with the halos staged through the host rather than produce no
             # line at all, and the line says so (`config.ranks`).
             port = int(os.environ.get("MASTER_PORT", "29500"))
-            store = dist.TCPStore(os.environ["MASTER_ADDR"], port + 23, world, is_master=(rank == 0), timeout=datetime.timedelta(seconds=300),
-                                  wait_for_workers=False)
+            if os.environ.get("TORCHELASTIC_USE_AGENT_STORE") == "True":  # under torchrun: the agent's store at MASTER_PORT, as a client
+                store = dist.PrefixStore("bench_agree", dist.TCPStore(os.environ["MASTER_ADDR"], port, world, is_master=False,
+                                                                      timeout=datetime.timedelta(seconds=300)))
+            else:
+                store = dist.TCPStore(os.environ["MASTER_ADDR"], port + 23, world, is_master=(rank == 0), timeout=datetime.timedelta(seconds=300),
+                                      wait_for_workers=False)
             err = None
             try:
                 if n_dev < world:
@@ -457,15 +462,16 @@ def main():
                     except Exception:  # noqa: BLE001
                         pass
                 backend = "gloo"
-                os.environ["MASTER_PORT"] = str(port + 17)
-                dist.init_process_group("gloo", rank=rank, world_size=world)
+                # (rendezvous through the ranks' own store: under torchrun the env:// store lives in the launcher's agent at
+                # MASTER_PORT and must stay where it is)
+                dist.init_process_group("gloo", store=dist.PrefixStore("gloo_fallback", store), rank=rank, world_size=world)
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
     # One stream for torch's work (allocations, copies, RCCL's completion waits) AND the engine's kernels: a side stream
     # of torch's made current for the whole run, handed to the context.  (torch's default stream has the handle 0; engine
     # kernels on the context's own non-blocking stream would not be ordered behind copies queued there.)
     if args.plumbing_only:
-        return plumbing_only(args, rank, world)
+        return plumbing_only(args, rank, world, backend_note)
     run_stream = torch.cuda.Stream(device=dev)
     torch.cuda.set_stream(run_stream)
 

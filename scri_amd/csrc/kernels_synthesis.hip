@@ -40,7 +40,10 @@ __global__ __launch_bounds__(640, 1) void synthesis_split_kernel(const double* _
                                                                  SynGeom g, const double* __restrict__ Tsyn,
                                                                  const int* __restrict__ meta, const double* __restrict__ off,
                                                                  double* __restrict__ Y, long long ldy) {
-  constexpr int PJ = NT + 1;  // odd pitch (complex) of an F_m row; its last slot of the m = 0 row carries the row's constant
+  // pitch (complex) of an F_m row, a multiple of 16: the phi waves' ds_read_b128 of (ring fi, m fk) then hit 16 distinct 16-byte
+  // slots in each of the instruction's four lane groups {0-3, 12-15, 20-27}, ... (with the odd pitch NT + 1 every group was 2-way);
+  // the last slot of the m = 0 row carries the row's constant
+  constexpr int PJ = NT + 8;
   extern __shared__ double lds[];
   const int fsz = (2 * g.L + 1) * PJ;
   const int na = g.n_modes + 1;
@@ -88,8 +91,9 @@ __global__ __launch_bounds__(640, 1) void synthesis_split_kernel(const double* _
     const int tt = 64 * th + lane;
     const int npair = (g.n_theta + 1) / 2;
     const bool active = tt < g.n_lists * npair;
-    const int li = active ? tt / npair : 0, j = active ? 2 * (tt - li * npair) : 0;
-    const bool second = active && j + 1 < g.n_theta;
+    // rings j and j + npair: neighbouring lanes write neighbouring 16-byte slots of an F row (2 j, 2 j + 1 made every store 2-way)
+    const int li = active ? tt / npair : 0, j = active ? tt - li * npair : 0;
+    const bool second = active && j + npair < g.n_theta;
     // sLambda_lm(theta_j), sLambda_lm(theta_j+1) of this thread's list in registers; the list itself (LDS byte offset of a_lm |
     // m slot << 16 | flush << 24 per entry) stays in LDS and is read two pairs of entries ahead of its use
     double treg[LEN], tre2[LEN];
@@ -98,7 +102,7 @@ __global__ __launch_bounds__(640, 1) void synthesis_split_kernel(const double* _
       const int mt = meta[li * LEN + e];
       const bool ok = active && (mt & SYN_META_VALID);
       treg[e] = ok ? Tsyn[(long long)(mt & 1023) * g.n_theta + j] : 0.0;
-      tre2[e] = (ok && second) ? Tsyn[(long long)(mt & 1023) * g.n_theta + j + 1] : 0.0;
+      tre2[e] = (ok && second) ? Tsyn[(long long)(mt & 1023) * g.n_theta + j + npair] : 0.0;
     }
     const int2* ml = reinterpret_cast<const int2*>(metal) + li * (LEN / 2);
     // this thread's share of a pair's mode rows: elements tt and tt + 64 nth of the 2 (n_modes + 1)
@@ -145,8 +149,8 @@ __global__ __launch_bounds__(640, 1) void synthesis_split_kernel(const double* _
             Fb[fsz + at] = double2{r1, i1};
           }
           if (second) {
-            Fb[at + 1] = double2{s0, k0};
-            Fb[fsz + at + 1] = double2{s1, k1};
+            Fb[at + npair] = double2{s0, k0};
+            Fb[fsz + at + npair] = double2{s1, k1};
           }
           r0 = i0 = r1 = i1 = s0 = k0 = s1 = k1 = 0.0;
         }
@@ -323,7 +327,7 @@ int synthesis_split_plan(int n_theta, int n_phi, int ell_min, int ell_max, SynGe
           }
       }
       nt = n_theta <= 24 ? 24 : 40;
-      lds_bytes = sizeof(double2) * ((size_t)4 * (2 * ell_max + 1) * (nt + 1) + 4 * (size_t)(n_modes + 1) + (size_t)n_theta * n_phi) +
+      lds_bytes = sizeof(double2) * ((size_t)4 * (2 * ell_max + 1) * (nt + 8) + 4 * (size_t)(n_modes + 1) + (size_t)n_theta * n_phi) +
                   sizeof(int) * meta.size();
       return lds_bytes <= 160 * 1024 ? 1 : 0;
     }

@@ -32,6 +32,14 @@ def test_bench_starts_its_own_ranks_and_exchanges_halos():
     assert a1 > 3000 and b0 < 3000  # both ranks fetched rows of the other
 
 
+def test_failed_rccl_bring_up_is_agreed_on_by_all_ranks_and_falls_back_to_gloo():
+    """RCCL asked for where it cannot come up (no GPUs here): every rank publishes its outcome in the ranks' own key-value store,
+    reads everybody's, and all of them switch to gloo together -- no rank is left waiting in a collective."""
+    rc, line, err = _run(["--gpus", "2", "--plumbing-only", "--n-times", "6000"], SCRI_AMD_BENCH_BACKEND="nccl")
+    assert rc == 0, err
+    assert line["backend"] == "gloo" and "nccl bring-up failed on rank 0" in line["backend_note"] and line["halo_rows_exact"]
+
+
 def test_launcher_hands_back_a_failing_rank_exit_code():
     rc, line, err = _run(["--gpus", "2", "--plumbing-only", "--n-times", "3"])  # a 3-sample series has no cubic spline: the ranks raise
     assert rc != 0 and line is None
