@@ -190,6 +190,29 @@ static int fail(bms_ctx* c, int code, const char* fmt, ...) {
                   hipGetErrorString(e__), __FILE__, __LINE__);                                               \
   } while (0)
 
+// The stream the results of a pipelined call leave on.  The runtime executes device-to-host copies as shader copies
+// (__amd_rocclr_copyBuffer) that take turns with the compute kernels on every CU; the stream is therefore confined to 8 CUs spread
+// over the chip (hipExtStreamCreateWithCUMask): the blit kernels still fill the link and leave the other CUs to the transform.
+// Measured (tools/host_mode_rate.py, cfg3 from and to host memory): 14.8 ms unconfined, 14.9 / 13.7 / 13.6 / 13.8 / 13.9 ms on
+// 2 / 4 / 8 / 16 / 32 CUs.  SCRI_AMD_DOWN_CUS = n overrides (0: unconfined).
+static hipError_t create_download_stream(bms_ctx* c) {
+  const char* e = getenv("SCRI_AMD_DOWN_CUS");
+  const int want = e ? atoi(e) : 8;
+  if (want > 0) {
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, c->device) == hipSuccess) {
+      const int n_cu = prop.multiProcessorCount, words = (n_cu + 31) / 32;
+      std::vector<uint32_t> mask(words, 0u);
+      const int stride = std::max(1, n_cu / want);
+      int set = 0;
+      for (int i = 0; i < n_cu && set < want; i += stride, ++set) mask[i / 32] |= 1u << (i % 32);
+      if (hipExtStreamCreateWithCUMask(&c->pipe_down, (uint32_t)words, mask.data()) == hipSuccess) return hipSuccess;
+      (void)hipGetLastError();
+    }
+  }
+  return hipStreamCreateWithFlags(&c->pipe_down, hipStreamNonBlocking);
+}
+
 // grow-only device buffer by name
 static int dev_buf(bms_ctx* c, const char* name, size_t bytes, void** out) {
   DevBuf& b = c->bufs[name];
@@ -1482,7 +1505,7 @@ extern "C" int bms_transform_modes_pipelined(bms_ctx* c, const bms_wm_input* in,
   if ((rc = dev_buf_t(c, "pipe_out1", (size_t)max_out * n_out * 2, &d_out[1]))) return rc;
   if (!c->pipe_up) {
     HIP_TRY(c, hipStreamCreateWithFlags(&c->pipe_up, hipStreamNonBlocking));
-    HIP_TRY(c, hipStreamCreateWithFlags(&c->pipe_down, hipStreamNonBlocking));
+    HIP_TRY(c, create_download_stream(c));
   }
   std::vector<hipEvent_t> ev_up(pieces), ev_c(pieces), ev_dn(pieces);
   for (int k = 0; k < pieces; ++k) {
@@ -2873,7 +2896,7 @@ extern "C" int bms_transform_abd_pipelined(bms_ctx* c, const double* u, const vo
   if ((rc = dev_buf_t(c, "pipe_out1", (size_t)6 * max_out * n_out * 2, &d_out[1]))) return rc;
   if (!c->pipe_up) {
     HIP_TRY(c, hipStreamCreateWithFlags(&c->pipe_up, hipStreamNonBlocking));
-    HIP_TRY(c, hipStreamCreateWithFlags(&c->pipe_down, hipStreamNonBlocking));
+    HIP_TRY(c, create_download_stream(c));
   }
   std::vector<hipEvent_t> ev_up(pieces), ev_c(pieces), ev_dn(pieces);
   for (int k = 0; k < pieces; ++k) ev_up[k] = ScopedTimer::get(c), ev_c[k] = ScopedTimer::get(c), ev_dn[k] = ScopedTimer::get(c);

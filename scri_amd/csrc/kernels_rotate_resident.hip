@@ -308,7 +308,22 @@ __global__ __launch_bounds__(64 * W, 1) void rotate_modes_resident_kernel(double
   // from round to round so that every wave sees every group (their costs differ)
   const unsigned int n_waves = gridDim.x * W;
   auto unit_tile = [&](unsigned int u) { return (long long)(u / P.n_groups) * 16; };
-  auto unit_group = [&](unsigned int u, unsigned int rnd) { return (int)((u % P.n_groups + rnd) % P.n_groups); };
+  // (the rotation by the round keeps a wave from meeting the same group every time; when the number of waves is no multiple of
+  // the number of groups u % n_groups changes from round to round by itself -- and a rotation would map two units of a tile that
+  // straddles a round boundary onto the same group)
+  const bool rotate_groups = n_waves % P.n_groups == 0;
+  auto unit_group = [&](unsigned int u, unsigned int rnd) { return (int)((u % P.n_groups + (rotate_groups ? rnd : 0u)) % P.n_groups); };
+  // The deal ends with a partial round: `tail_units` < n_waves units for n_waves waves -- at 1e5 steps, l <= 16 that is 212 units
+  // of 12 500 whose round costs as much as each of the six full ones.  Those units are cut into `tail_split` pieces of
+  // consecutive l (equal shares of the group's cost), one piece per wave, so that the last round takes 1 / tail_split of a full one.
+  const unsigned int full_rounds = n_units / n_waves, tail_first = full_rounds * n_waves, tail_units = n_units - tail_first;
+  unsigned int tail_split = tail_units ? n_waves / tail_units : 1u;
+  if (tail_split > (unsigned int)RR_MAXL) tail_split = RR_MAXL;
+  auto ell_cost = [](int ell) {
+    int a, b;
+    rr_shape(ell, &a, &b);
+    return (a + b) / 4 + 3;  // k steps of a stage + the fixed part of an l (as the host's grouping)
+  };
   // descriptor of the rows of a tile: rows beyond the series are out of range (loads give zero, stores are dropped)
   auto tile_rsrc = [&](long long t0) {
     const long long rows = n_times - t0 < 16 ? n_times - t0 : 16;
@@ -341,13 +356,38 @@ __global__ __launch_bounds__(64 * W, 1) void rotate_modes_resident_kernel(double
     bool done;
   };
   auto enter_unit = [&](Step& s) {
-    s.done = s.unit >= n_units;
-    if (!s.done) {
+    if (s.unit < tail_first) {
+      s.done = false;
       s.t0 = unit_tile(s.unit);
       const int grp = unit_group(s.unit, s.round);
       s.ell = P.grp_lo[grp];
       s.ell_hi = P.grp_hi[grp];
+      return;
     }
+    // the partial last round: wave w takes piece w % tail_split of unit tail_first + w / tail_split
+    const unsigned int w = s.unit - tail_first;
+    s.done = w >= tail_units * tail_split;
+    if (s.done) return;
+    const unsigned int u = tail_first + w / tail_split, piece = w % tail_split;
+    s.t0 = unit_tile(u);
+    const int grp = unit_group(u, full_rounds);
+    const int lo = P.grp_lo[grp], hi = P.grp_hi[grp];
+    int total = 0;
+    for (int l = lo; l <= hi; ++l) total += ell_cost(l);
+    // piece k = the l whose running cost (midpoint) falls into [k, k + 1) total / tail_split: contiguous, possibly empty
+    int first = hi + 1, last = lo - 1, run = 0;
+    for (int l = lo; l <= hi; ++l) {
+      const int cst = ell_cost(l);
+      const unsigned int k = (unsigned int)(((2 * run + cst) * (int)tail_split) / (2 * total));
+      run += cst;
+      if (k == piece) {
+        first = l < first ? l : first;
+        last = l;
+      }
+    }
+    s.done = first > last;
+    s.ell = first;
+    s.ell_hi = last;
   };
   auto advance = [&](Step& s) {
     if (s.ell < s.ell_hi) {
@@ -496,9 +536,10 @@ bool rotate_resident_plan(int ell_min, int ell_max, RotResPlan* P, size_t* lds_b
   int total = 0;
   for (int l = ell_min; l <= ell_max; ++l) total += cost(l);
   const int nl = ell_max - ell_min + 1;
-  // two groups from 4 l on: measured on l = 2..16 and 2..8 (tools/bench_rotation.py, 1e5 and 1e6 steps), 1 / 2 / 3 / 4 groups
-  // are within 5 % of each other; 2 is best at 1e5 steps, where the number of rounds per wave is small
-  int G = nl >= 4 ? 2 : 1;
+  // one group up to 9 l, two beyond: measured on l = 2..16 and 2..8 (tools/rotation_sweep.sh, 1e5 and 1e6 steps) with the partial
+  // last round of the deal cut into per-l pieces (kernel): l <= 16: 0.265 / 0.259 / 0.264 / 0.265 ms per 1e5 steps for 1 / 2 / 3 / 4
+  // groups, l <= 8: 0.0665 / 0.0709 / 0.0761 / 0.0804 (every unit pays one rotor set-up)
+  int G = nl >= 10 ? 2 : 1;
   if (const char* e = getenv("SCRI_AMD_ROTATE_GROUPS")) G = atoi(e) < 1 ? 1 : (atoi(e) > 4 ? 4 : atoi(e));
   P->n_groups = 0;
   int l = ell_min, used = 0;
