@@ -70,14 +70,16 @@ int bms_ctx_synchronize(bms_ctx* ctx);
  * context's stream; bms_ctx_get_timing synchronises and returns the accumulated milliseconds and launch
  * counts per kernel class since the last reset. */
 enum bms_kernel_tag {
-  BMS_TAG_ROTATE = 0,          /* rotate_modes_kernel */
-  BMS_TAG_SETUP = 1,           /* swsh_kernel (synthesis + quadrature matrices), spline_table_kernel */
-  BMS_TAG_GEMM_SYNTHESIS = 2,  /* dgemm_mfma_kernel, modes -> grid */
-  BMS_TAG_SPLINE_FORWARD = 3,  /* spline_forward_kernel */
-  BMS_TAG_SPLINE_BACKWARD = 4, /* spline_backward_eval_kernel */
-  BMS_TAG_GEMM_ANALYSIS = 5,   /* dgemm_mfma_kernel, grid -> modes: phi-DFT (or dense quadrature) */
-  BMS_TAG_POINTWISE = 6,       /* psi mixing / affine / Horner kernels */
-  BMS_TAG_THETA_QUADRATURE = 7, /* theta_quadrature_kernel (second step of the separable analysis) */
+  BMS_TAG_ROTATE = 0,          /* rotate_modes_resident_kernel (l <= 27), rotate_modes_mfma_kernel (l <= 33), rotate_modes_kernel */
+  BMS_TAG_SETUP = 1,           /* pixel_sort_kernel, pixel_tables_kernel, swsh_kernel (synthesis matrix), bspline table kernels */
+  BMS_TAG_GEMM_SYNTHESIS = 2,  /* modes -> grid: zgemm3m_mfma_kernel (with a boost), synthesis_split_kernel or
+                                  theta_synthesis_mfma_kernel + phi_synthesis_folded_kernel (without one) */
+  BMS_TAG_SPLINE_FORWARD = 3,  /* bspline_forward_modes_kernel, abd_mix_forward_kernel (slope form: spline_forward_kernel) */
+  BMS_TAG_SPLINE_BACKWARD = 4, /* bspline_backward_eval_kernel (slope form: spline_backward_eval_kernel, spline_slopes_kernel) */
+  BMS_TAG_GEMM_ANALYSIS = 5,   /* dgemm_mfma_kernel / zgemm3m_mfma_kernel, grid -> modes: phi-DFT of the unfused analysis, dense
+                                  quadrature beyond n_theta = 104, a column part's analysis */
+  BMS_TAG_POINTWISE = 6,       /* psi mixing / affine / Horner kernels, grid products, spline prefix sums and evaluation */
+  BMS_TAG_THETA_QUADRATURE = 7, /* theta_quadrature_kernel (second step of the unfused separable analysis) */
   BMS_TAG_ANALYSIS_FUSED = 8,   /* analysis_split_kernel / analysis_fused_kernel (phi-DFT on MFMA + theta quadrature, one kernel) */
   BMS_TAG_ANALYSIS_LARGE = 9,   /* phi_dft_folded_kernel + theta_quadrature_mfma_kernel (grids with n_theta > 40) */
   BMS_TAG_COUNT = 10
