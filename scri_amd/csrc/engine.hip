@@ -2744,7 +2744,23 @@ static int transform_abd_impl(bms_ctx* c, const double* u, const void* raw, int 
   double* d_out = (double*)raw_out;
   if (mem == BMS_HOST)
     if ((rc = dev_buf_t(c, "out_data", (size_t)6 * fs_out * n_out * 2, &d_out))) return rc;
-  if (sep) {
+  // Without a boost the Horner mixing has time-independent coefficients (k = 1, eth k = 0: X = -eth alpha), so it commutes with the
+  // spline's forward elimination: that runs on the MODES (6 x (l_max+1)^2 columns + the constant series, instead of six grids), the
+  // fields are synthesised as eliminated coefficients and mixed on their way out of the phi stage (phi_synthesis_mix6_kernel)
+  const bool fused_mix = sep && bsg && !short_series && abd_mix6_supported(tr->n_theta, tr->n_phi, ell_max);
+  const long long ld_af = round_up(2LL * (nm + 1), 16);
+  double* d_Af = nullptr;
+  if (fused_mix) {
+    if ((rc = dev_buf_t(c, "abd_Af", (size_t)6 * rows_avail * ld_af, &d_Af))) return rc;
+    for (int f = 0; f < 6; ++f)
+      TIMED(c, BMS_TAG_SPLINE_FORWARD, launch_bspline_forward_modes(S, d_raw + (size_t)f * rows_avail * nm * 2, 2LL * nm, nm, d_Af + (size_t)f * rows_avail * ld_af,
+                                                                    ld_af, row0, rows_avail, n, d_bsfwd, SPLINE_TILE, SPLINE_HALO, 1));
+    const double* q = tr->frame_rotation;
+    if (!(q[0] == 1.0 && q[1] == 0.0 && q[2] == 0.0 && q[3] == 0.0)) {
+      const double sp[4] = {q[0], q[3], q[2], q[1]};  // (w + i z, y + i x); the constant column stays
+      if ((rc = rotate_impl(c, d_Af, BMS_DEVICE, 6 * rows_avail, ld_af / 2, 0, ell_max, sp, false, false))) return rc;
+    }
+  } else if (sep) {
     // the six fields as seen from the rotated frame, sYlm(F G) = sum_m' D_{m m'}(F) sYlm'(G): [6][rows][nm] is one series of
     // 6 x rows steps for the rotation kernel -- in place in the staging copy of a host caller, in a copy of device data
     const double* q = tr->frame_rotation;
@@ -2794,12 +2810,28 @@ static int transform_abd_impl(bms_ctx* c, const double* u, const void* raw, int 
                   "shard holds rows [%lld, %lld) but outputs [%lld, %lld) need rows [%lld, %lld): halo too small "
                   "(use bms_shard_plan)",
                   (long long)row0, (long long)(row0 + rows_avail), (long long)c0, (long long)c1_, (long long)g0, (long long)g1);
-    double *d_Y, *d_R, *d_G;
-    if ((rc = dev_buf_t(c, "Y", (size_t)6 * rows_in * ldg, &d_Y))) return rc;
+    double *d_Y = nullptr, *d_R, *d_G;
+    if (!fused_mix)
+      if ((rc = dev_buf_t(c, "Y", (size_t)6 * rows_in * ldg, &d_Y))) return rc;
     if ((rc = dev_buf_t(c, "R", (size_t)6 * rows_in * ldg, &d_R))) return rc;
     if ((rc = dev_buf_t(c, "G", (size_t)6 * rows_out * ldG, &d_G))) return rc;
     AbdGrids grids;
-    for (int f = 0; f < 6; ++f) {
+    if (fused_mix) {
+      const size_t f_stride = (size_t)rows_in * (2 * ell_max + 1) * large_analysis_jp(T.n_theta) * 2;
+      double* d_F6;
+      if ((rc = dev_buf_t(c, "Fsyn6", 6 * f_stride, &d_F6))) return rc;
+      const double* F6[6];
+      double* out6[6];
+      for (int f = 0; f < 6; ++f) {
+        F6[f] = d_F6 + f * f_stride;
+        out6[f] = d_R + (size_t)f * rows_in * ldg;
+        TIMED(c, BMS_TAG_GEMM_SYNTHESIS, launch_theta_synthesis(S, d_Af + ((size_t)f * rows_avail + (g0 - row0)) * ld_af, ld_af, rows_in, T.n_theta, 0, ell_max,
+                                                                syn5[spins[f] + 2].d_T, d_F6 + f * f_stride));
+      }
+      TIMED(c, BMS_TAG_GEMM_SYNTHESIS, launch_phi_synthesis_mix6(S, F6, rows_in, T.n_theta, T.n_phi, ell_max, d_etha, d_ethetha, d_ik, d_ik3,
+                                                                 d_Af + (size_t)(g0 - row0) * ld_af + 2LL * nm, ld_af, out6, ldg));
+    }
+    for (int f = 0; f < 6 && !fused_mix; ++f) {
       grids.y[f] = d_Y + (size_t)f * rows_in * ldg;
       if (sep) {
         if ((rc = run_synthesis(c, syn5[spins[f] + 2], d_raw + ((size_t)f * rows_avail + (g0 - row0)) * nm * 2, 2LL * nm, rows_in, nullptr, grids.y[f], ldg)))
@@ -2809,7 +2841,9 @@ static int transform_abd_impl(bms_ctx* c, const double* u, const void* raw, int 
             launch_zgemm3m(S, d_raw + ((size_t)f * rows_avail + (g0 - row0)) * nm * 2, 2LL * nm, d_B[spins[f] + 2] + 2 * cA, ldb, grids.y[f], ldg, rows_in,
                            n_pix, K / 2, nullptr, nullptr));
     }
-    if (bsg) {  // mixing and elimination of the six fields in one pass over the grids
+    if (fused_mix) {
+      // (synthesised, mixed and eliminated above)
+    } else if (bsg) {  // mixing and elimination of the six fields in one pass over the grids
       AbdGrids elim;
       for (int f = 0; f < 6; ++f) elim.y[f] = d_R + (size_t)f * rows_in * ldg;
       TIMED(c, BMS_TAG_SPLINE_FORWARD, launch_abd_mix_forward(S, grids, elim, ldg, n_pix, g0, rows_in, d_bsfwd, SPLINE_TILE, SPLINE_HALO, d_alpha, d_ethk,

@@ -122,6 +122,15 @@ hipError_t launch_synthesis_large(hipStream_t stream, const double* A, long long
                                   int ell_min, int ell_max, const double* Tsyn, const double* off, double* F, double* Y,
                                   long long ldy);
 
+// AsymptoticBondiData without a boost: theta stage per field, then the phi stage of all six fields fused with their Horner mixing
+// (time-independent without a boost: the elimination has moved onto the modes); per-pixel tables in grid order
+hipError_t launch_theta_synthesis(hipStream_t stream, const double* A, long long lda, long long n_rows, int n_theta, int ell_min,
+                                  int ell_max, const double* Tsyn, double* F);
+int abd_mix6_supported(int n_theta, int n_phi, int ell_max);
+hipError_t launch_phi_synthesis_mix6(hipStream_t stream, const double* const F6[6], long long n_rows, int n_theta, int n_phi,
+                                     int ell_max, const double* eth_alpha, const double* etheth_alpha, const double* inv_k,
+                                     const double* inv_k3, const double* cst, long long ldc, double* const out6[6], long long ldo);
+
 // ---- dense fp64 GEMM on MFMA: C[M x N] = (A[M x K] * B[K x N] - col_off[N]) * col_scale[N]
 // A row-major (lda), B row-major (ldb, zero padded to a multiple of 128 columns and 16 rows), C row-major (ldc).
 hipError_t launch_dgemm(hipStream_t stream, const double* A, long long lda, const double* B, long long ldb, double* C,

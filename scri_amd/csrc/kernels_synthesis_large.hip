@@ -24,6 +24,7 @@
 #include <cstdlib>
 
 #include "kernels.h"
+#include "wigner.h"
 
 namespace bms {
 
@@ -94,10 +95,11 @@ __global__ __launch_bounds__(256) void theta_synthesis_mfma_kernel(const double*
     for (int n = 0; n < NTJ; ++n) acc[n] = v4d_t{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
     for (int s = 0; s < KL; ++s) {
-      if (s >= ks) break;  // (wave-uniform: the high |m| have few l)
-      const double a = Aw[fi * PQ + 4 * s + fk];
+      if (s < ks) {  // (wave-uniform: the high |m| have few l; a `break` here keeps the loop from being unrolled at KL = 9)
+        const double a = Aw[fi * PQ + 4 * s + fk];
 #pragma unroll
-      for (int n = 0; n < NTJ; ++n) acc[n] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bq[s][n], acc[n], 0, 0, 0);
+        for (int n = 0; n < NTJ; ++n) acc[n] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bq[s][n], acc[n], 0, 0, 0);
+      }
     }
     // results r = 2h (re), 2h+1 (im) of time step t0 + fk + 4 h, ring j = 16 n + fi (the padding rings j >= n_theta get zeros)
 #pragma unroll
@@ -175,16 +177,17 @@ __global__ __launch_bounds__(64) void phi_synthesis_folded_kernel(const double* 
     for (int n = 0; n < NTC; ++n) u[n] = v[n] = v4d_t{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
     for (int s = 0; s < KM; ++s) {
-      if (s >= km) break;
-      const int m = 4 * s + fk + 1;
-      const int mm = m <= L ? m : 0;  // (rows beyond L: their twiddles are zero)
-      const double2 fp = Ft[(L + mm) * 8 + ag], fm = Ft[(L - mm) * 8 + ag];
-      const double ap = part ? fp.y + fm.y : fp.x + fm.x;  // P_m = F_m + F_-m
-      const double aq = part ? fp.x - fm.x : fm.y - fp.y;  // Q_m = i (F_m - F_-m)
+      if (s < km) {
+        const int m = 4 * s + fk + 1;
+        const int mm = m <= L ? m : 0;  // (rows beyond L: their twiddles are zero)
+        const double2 fp = Ft[(L + mm) * 8 + ag], fm = Ft[(L - mm) * 8 + ag];
+        const double ap = part ? fp.y + fm.y : fp.x + fm.x;  // P_m = F_m + F_-m
+        const double aq = part ? fp.x - fm.x : fm.y - fp.y;  // Q_m = i (F_m - F_-m)
 #pragma unroll
-      for (int n = 0; n < NTC; ++n) {
-        u[n] = __builtin_amdgcn_mfma_f64_16x16x4f64(ap, bc[s][n], u[n], 0, 0, 0);
-        v[n] = __builtin_amdgcn_mfma_f64_16x16x4f64(aq, bs[s][n], v[n], 0, 0, 0);
+        for (int n = 0; n < NTC; ++n) {
+          u[n] = __builtin_amdgcn_mfma_f64_16x16x4f64(ap, bc[s][n], u[n], 0, 0, 0);
+          v[n] = __builtin_amdgcn_mfma_f64_16x16x4f64(aq, bs[s][n], v[n], 0, 0, 0);
+        }
       }
     }
     // results: rows fk + 4 r = (Re, Im) of ring fk, (Re, Im) of ring fk + 4; column k = 16 n + fi
@@ -223,6 +226,170 @@ __global__ __launch_bounds__(64) void phi_synthesis_folded_kernel(const double* 
     for (int e = lane; e < n_el; e += 64) *reinterpret_cast<double2*>(y + 2LL * e) = Gt[e];
   }
 #undef PS_LOAD
+}
+
+// ---- AsymptoticBondiData without a boost: phi stage of all SIX fields + their Horner mixing in one pass.
+// Without a boost k = 1 and eth k = 0, so the mixing variable X = (eth k / k)(u - alpha) - eth alpha of
+// scri/asymptotic_bondi_data/transformations.py:322-385 is -eth alpha: constant in time.  A per-pixel linear map with
+// time-independent coefficients commutes with the spline's forward elimination (linear along time with per-knot coefficients), so
+// the elimination runs on the MODES (bspline_forward_modes_kernel, 6 x 625 columns instead of 6 x 9801), the six fields are
+// synthesised as eliminated coefficients and mixed on their way out of this kernel -- the separate mixing + elimination pass over
+// the six grids (47 GB at l <= 24, 25 000 steps) is gone.  sigma' = sigma - eth^2 alpha becomes F[sigma] - eth^2 alpha F[1] with
+// the eliminated constant series F[1] (the extra column of the eliminated modes), as for h and sigma of the WaveformModes flavour.
+//
+// One wave per (time step, 4 rings).  The 16 rows of an MFMA are 2 fields x 4 rings x (Re, Im): three passes (fields 0|1, 2|3, 4|5)
+// with the cos | sin twiddles in registers throughout; the F tile of a pass sits in the LDS area its own results will overwrite (all
+// of it is in registers or accumulators by then); after the third pass the area holds the six fields on the tile's 4 n_phi pixels,
+// which are mixed pixel by pixel and leave as whole wave stores (4 n_phi contiguous complex numbers per field).
+struct Mix6Args {
+  const double* F[6];   // F[f][t][m][jp]
+  double* out[6];       // eliminated coefficients of the mixed fields, [rows][ldo]
+  const double* eth_alpha;     // c16[n_pix]  (eth alpha / sqrt 2 of the reference)
+  const double* etheth_alpha;  // c16[n_pix]
+  const double* inv_k;         // [n_pix] (= 1 without a boost; kept so that the arithmetic is the dense route's)
+  const double* inv_k3;
+  const double* cst;    // eliminated constant series: cst[t * ldc]
+  long long ldc, ldo;
+};
+
+template <int KM, int NTC>
+__global__ __launch_bounds__(64) void phi_synthesis_mix6_kernel(Mix6Args a, long long n_rows, int n_theta, int n_phi, int L, int jp) {
+  extern __shared__ double2 sm[];  // [6][4 n_phi]
+  const int nm = 2 * L + 1, tile = 4 * n_phi;
+  const int lane = threadIdx.x, fi = lane & 15, fk = lane >> 4;
+  const int nk = n_phi / 2 + 1, mt = (n_theta + 3) / 4;
+  double bc[KM][NTC], bs[KM][NTC];
+#pragma unroll
+  for (int s = 0; s < KM; ++s)
+#pragma unroll
+    for (int n = 0; n < NTC; ++n) {
+      const int m = 4 * s + fk + 1, k = 16 * n + fi;
+      double sn = 0.0, co = 0.0;
+      if (k < nk && m <= L) sincospi(2.0 * (double)(((long long)m * k) % n_phi) / (double)n_phi, &sn, &co);
+      bc[s][n] = co, bs[s][n] = sn;
+    }
+  const int km = (L + 3) / 4;
+  // This lane's pieces of a pass's two F tiles ((2L+1) x 4 rings each, 64-byte pieces): element e = lane + 64 i is ring e & 3 of
+  // row (e >> 2) % nm of field e / (4 nm) of the pair
+  constexpr int NPRE = ((2 * 4 * KM + 1) * 8 + 63) / 64;
+  double2 pre[NPRE];
+#define M6_LOAD(ITEM, PASS)                                                                                             \
+  {                                                                                                                     \
+    const long long item_ = (ITEM);                                                                                     \
+    const long long t_ = item_ / mt;                                                                                    \
+    const int rt_ = (int)(item_ - t_ * mt);                                                                             \
+    const int rings_ = n_theta - 4 * rt_ < 4 ? n_theta - 4 * rt_ : 4;                                                   \
+    const long long o_ = ((t_ * nm) * (long long)jp + 4 * rt_) * 2;                                                     \
+    const double *fa_ = a.F[2 * (PASS)] + o_, *fb_ = a.F[2 * (PASS) + 1] + o_;                                          \
+    _Pragma("unroll") for (int i = 0; i < NPRE; ++i) {                                                                  \
+      const int e_ = lane + 64 * i;                                                                                     \
+      const int fld_ = e_ >= 4 * nm ? 1 : 0, rem_ = e_ - fld_ * 4 * nm;                                                 \
+      const double* f_ = fld_ ? fb_ : fa_;                                                                              \
+      pre[i] = (e_ < 8 * nm && (rem_ & 3) < rings_) ? *reinterpret_cast<const double2*>(f_ + ((long long)(rem_ >> 2) * jp + (rem_ & 3)) * 2) \
+                                                    : double2{0.0, 0.0};                                               \
+    }                                                                                                                   \
+  }
+  // operand row fi: field fi >> 3 of the pair, ring fi & 3, Re (part 0) or Im (part 1)
+  const int ab = fi >> 3, ag = fi & 3, part = (fi >> 2) & 1;
+  const long long n_items = n_rows * mt;
+  if (blockIdx.x < n_items) M6_LOAD((long long)blockIdx.x, 0)
+  for (long long item = blockIdx.x; item < n_items; item += gridDim.x) {
+    const long long t = item / mt;
+    const int rt = (int)(item - t * mt);
+    const int rings = n_theta - 4 * rt < 4 ? n_theta - 4 * rt : 4;
+#pragma unroll
+    for (int pass = 0; pass < 3; ++pass) {  // (unrolled: the field pointers of a pass are then scalars, not a private array)
+      // the pass's F tiles go where its results will: fields 2 pass, 2 pass + 1
+      double2* Ft = sm + (size_t)(2 * pass) * tile;  // [2][nm][4]  (2 x 4 nm <= 2 x 4 n_phi: nm <= n_phi for every grid that resolves L)
+#pragma unroll
+      for (int i = 0; i < NPRE; ++i) {
+        const int e = lane + 64 * i;
+        if (e < 8 * nm) Ft[e] = pre[i];
+      }
+      if (pass == 0) M6_LOAD(item, 1)
+      if (pass == 1) M6_LOAD(item, 2)
+      if (pass == 2 && item + gridDim.x < n_items) M6_LOAD(item + gridDim.x, 0)
+      v4d_t u[NTC], v[NTC];
+#pragma unroll
+      for (int n = 0; n < NTC; ++n) u[n] = v[n] = v4d_t{0.0, 0.0, 0.0, 0.0};
+      const double2* Fb = Ft + ab * 4 * nm;
+#pragma unroll
+      for (int s = 0; s < KM; ++s) {
+        if (s < km) {
+          const int m = 4 * s + fk + 1;
+          const int mm = m <= L ? m : 0;
+          const double2 fp = Fb[(L + mm) * 4 + ag], fm = Fb[(L - mm) * 4 + ag];
+          const double ap = part ? fp.y + fm.y : fp.x + fm.x;
+          const double aq = part ? fp.x - fm.x : fm.y - fp.y;
+#pragma unroll
+          for (int n = 0; n < NTC; ++n) {
+            u[n] = __builtin_amdgcn_mfma_f64_16x16x4f64(ap, bc[s][n], u[n], 0, 0, 0);
+            v[n] = __builtin_amdgcn_mfma_f64_16x16x4f64(aq, bs[s][n], v[n], 0, 0, 0);
+          }
+        }
+      }
+      // results: rows fk + 4 r = (Re, Im) of ring fk of the pair's first field, (Re, Im) of ring fk of its second; column k = 16 n + fi
+      const double2 f0a = Ft[L * 4 + fk], f0b = Ft[4 * nm + L * 4 + fk];
+      // (every read of the F tiles is done: their area now takes the results)
+      __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0)
+      double2* Ga = sm + (size_t)(2 * pass) * tile + fk * n_phi;
+      double2* Gb = Ga + tile;
+#pragma unroll
+      for (int n = 0; n < NTC; ++n) {
+        const int k = 16 * n + fi;
+        if (k < nk) {
+          const double uax = f0a.x + u[n][0], uay = f0a.y + u[n][1], ubx = f0b.x + u[n][2], uby = f0b.y + u[n][3];
+          Ga[k] = double2{uax + v[n][0], uay + v[n][1]};
+          Gb[k] = double2{ubx + v[n][2], uby + v[n][3]};
+          const int k2 = n_phi - k;
+          if (k >= 1 && k2 != k) {
+            Ga[k2] = double2{uax - v[n][0], uay - v[n][1]};
+            Gb[k2] = double2{ubx - v[n][2], uby - v[n][3]};
+          }
+        }
+      }
+    }
+    // ---- mixing (transformations.py:340-385 with X = -eth alpha) and the way out
+    const double cv = a.cst[t * a.ldc];
+    const long long pix0 = (long long)(4 * rt) * n_phi;
+    const int n_el = rings * n_phi;
+    for (int e = lane; e < n_el; e += 64) {
+      const long long p = pix0 + e;
+      cplx f[6];
+#pragma unroll
+      for (int i = 0; i < 6; ++i) {
+        const double2 w = sm[(size_t)i * tile + e];
+        f[i] = {w.x, w.y};
+      }
+      const double2 B = *reinterpret_cast<const double2*>(a.eth_alpha + 2 * p), EE = *reinterpret_cast<const double2*>(a.etheth_alpha + 2 * p);
+      const double ik = a.inv_k[p], ik3 = a.inv_k3[p];
+      const cplx X = {-B.x, -B.y};
+      auto axpy = [](cplx tt, cplx X, double c, cplx ff) {  // tt X + c ff
+        cplx r = cmul(tt, X);
+        return cplx{r.re + c * ff.re, r.im + c * ff.im};
+      };
+      cplx t0 = f[4];
+      t0 = axpy(t0, X, -4.0, f[3]);
+      t0 = axpy(t0, X, 6.0, f[2]);
+      t0 = axpy(t0, X, -4.0, f[1]);
+      t0 = axpy(t0, X, 1.0, f[0]);
+      cplx t1 = {-f[4].re, -f[4].im};
+      t1 = axpy(t1, X, 3.0, f[3]);
+      t1 = axpy(t1, X, -3.0, f[2]);
+      t1 = axpy(t1, X, 1.0, f[1]);
+      cplx t2 = f[4];
+      t2 = axpy(t2, X, -2.0, f[3]);
+      t2 = axpy(t2, X, 1.0, f[2]);
+      cplx t3 = {-f[4].re, -f[4].im};
+      t3 = axpy(t3, X, 1.0, f[3]);
+      const cplx mixed[6] = {{t0.re * ik3, t0.im * ik3}, {t1.re * ik3, t1.im * ik3}, {t2.re * ik3, t2.im * ik3},
+                             {t3.re * ik3, t3.im * ik3}, {f[4].re * ik3, f[4].im * ik3},
+                             {(f[5].re - EE.x * cv) * ik, (f[5].im - EE.y * cv) * ik}};
+#pragma unroll
+      for (int i = 0; i < 6; ++i) *reinterpret_cast<double2*>(a.out[i] + t * a.ldo + 2 * p) = double2{mixed[i].re, mixed[i].im};
+    }
+  }
+#undef M6_LOAD
 }
 
 int large_synthesis_supported(int n_theta, int n_phi, int ell_min, int ell_max) {
@@ -287,6 +454,81 @@ hipError_t launch_synthesis_large(hipStream_t stream, const double* A, long long
   }
 #undef PS_KM
 #undef PS_GO
+  return hipGetLastError();
+}
+
+// theta stage alone (the six fields of the fused ABD route: one launch per field into its own F)
+hipError_t launch_theta_synthesis(hipStream_t stream, const double* A, long long lda, long long n_rows, int n_theta, int ell_min,
+                                  int ell_max, const double* Tsyn, double* F) {
+  if (n_rows <= 0) return hipSuccess;
+  const int L = ell_max, nm = 2 * L + 1, jp = large_analysis_jp(n_theta);
+  static const int rows_per_block = getenv("SCRI_AMD_TS_ROWS") ? atoi(getenv("SCRI_AMD_TS_ROWS")) : 256;
+  const dim3 grid1(nm, (unsigned)((n_rows + rows_per_block - 1) / rows_per_block));
+  const int kl = (L + 1 - ell_min + 3) / 4, ntj = (n_theta + 15) / 16;
+#define TS_GO(KL, NTJ)                                                                                                      \
+  hipLaunchKernelGGL((theta_synthesis_mfma_kernel<KL, NTJ>), grid1, dim3(256), 0, stream, A, lda, n_rows, n_theta, L, ell_min, jp, \
+                     rows_per_block, Tsyn, F)
+#define TS_KL(NTJ)  \
+  if (kl <= 5)      \
+    TS_GO(5, NTJ);  \
+  else if (kl <= 7) \
+    TS_GO(7, NTJ);  \
+  else              \
+    TS_GO(9, NTJ);
+  if (ntj <= 3) {
+    TS_KL(3)
+  } else if (ntj <= 5) {
+    TS_KL(5)
+  } else {
+    TS_KL(7)
+  }
+#undef TS_KL
+#undef TS_GO
+  return hipGetLastError();
+}
+
+int abd_mix6_supported(int n_theta, int n_phi, int ell_max) {
+  if (getenv("SCRI_AMD_NO_FUSED_ABD_MIX")) return 0;
+  // (the F tiles of a pass borrow the LDS area of its results: 2 L + 1 <= n_phi; three workgroups or more per CU)
+  return large_synthesis_supported(n_theta, n_phi, 0, ell_max) && 2 * ell_max + 1 <= n_phi && (size_t)6 * 4 * n_phi * 16 <= 53 * 1024;
+}
+
+// F6: six F buffers (each n_rows x (2 L + 1) x jp complex); out6: six grids [n_rows][ldo]; per-pixel tables in grid order
+hipError_t launch_phi_synthesis_mix6(hipStream_t stream, const double* const F6[6], long long n_rows, int n_theta, int n_phi,
+                                     int ell_max, const double* eth_alpha, const double* etheth_alpha, const double* inv_k,
+                                     const double* inv_k3, const double* cst, long long ldc, double* const out6[6], long long ldo) {
+  if (n_rows <= 0) return hipSuccess;
+  Mix6Args a;
+  for (int f = 0; f < 6; ++f) a.F[f] = F6[f], a.out[f] = out6[f];
+  a.eth_alpha = eth_alpha, a.etheth_alpha = etheth_alpha, a.inv_k = inv_k, a.inv_k3 = inv_k3, a.cst = cst, a.ldc = ldc, a.ldo = ldo;
+  const int L = ell_max, jp = large_analysis_jp(n_theta);
+  const int nk = n_phi / 2 + 1, mt = (n_theta + 3) / 4;
+  const int km = (L + 3) / 4, ntc = (nk + 15) / 16;
+  const size_t lds = sizeof(double2) * (size_t)6 * 4 * n_phi;
+  const long long items = n_rows * mt;
+  const unsigned grid = (unsigned)(items < 256 * 4 ? items : 256 * 4);
+#define M6_GO(KM, NTC)                                                                                                    \
+  {                                                                                                                       \
+    hipError_t e_ = hipFuncSetAttribute((const void*)phi_synthesis_mix6_kernel<KM, NTC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+    if (e_ != hipSuccess) return e_;                                                                                      \
+    hipLaunchKernelGGL((phi_synthesis_mix6_kernel<KM, NTC>), dim3(grid), dim3(64), lds, stream, a, n_rows, n_theta, n_phi, L, jp);  \
+  }
+#define M6_KM(NTC)  \
+  if (km <= 5)      \
+    M6_GO(5, NTC)   \
+  else if (km <= 7) \
+    M6_GO(7, NTC)   \
+  else              \
+    M6_GO(9, NTC)
+  if (ntc <= 2) {
+    M6_KM(2)
+  } else if (ntc == 3) {
+    M6_KM(3)
+  } else {
+    M6_KM(4)
+  }
+#undef M6_KM
+#undef M6_GO
   return hipGetLastError();
 }
 
