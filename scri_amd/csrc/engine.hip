@@ -2828,7 +2828,7 @@ static int transform_abd_impl(bms_ctx* c, const double* u, const void* raw, int 
         TIMED(c, BMS_TAG_GEMM_SYNTHESIS, launch_theta_synthesis(S, d_Af + ((size_t)f * rows_avail + (g0 - row0)) * ld_af, ld_af, rows_in, T.n_theta, 0, ell_max,
                                                                 syn5[spins[f] + 2].d_T, d_F6 + f * f_stride));
       }
-      TIMED(c, BMS_TAG_GEMM_SYNTHESIS, launch_phi_synthesis_mix6(S, F6, rows_in, T.n_theta, T.n_phi, ell_max, d_etha, d_ethetha, d_ik, d_ik3,
+      TIMED(c, BMS_TAG_GEMM_SYNTHESIS, launch_phi_synthesis_mix6(S, F6, rows_in, T.n_theta, T.n_phi, ell_max, d_etha, d_ethetha,
                                                                  d_Af + (size_t)(g0 - row0) * ld_af + 2LL * nm, ld_af, out6, ldg));
     }
     for (int f = 0; f < 6 && !fused_mix; ++f) {

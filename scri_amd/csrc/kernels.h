@@ -128,8 +128,8 @@ hipError_t launch_theta_synthesis(hipStream_t stream, const double* A, long long
                                   int ell_max, const double* Tsyn, double* F);
 int abd_mix6_supported(int n_theta, int n_phi, int ell_max);
 hipError_t launch_phi_synthesis_mix6(hipStream_t stream, const double* const F6[6], long long n_rows, int n_theta, int n_phi,
-                                     int ell_max, const double* eth_alpha, const double* etheth_alpha, const double* inv_k,
-                                     const double* inv_k3, const double* cst, long long ldc, double* const out6[6], long long ldo);
+                                     int ell_max, const double* eth_alpha, const double* etheth_alpha, const double* cst, long long ldc,
+                                     double* const out6[6], long long ldo);
 
 // ---- dense fp64 GEMM on MFMA: C[M x N] = (A[M x K] * B[K x N] - col_off[N]) * col_scale[N]
 // A row-major (lda), B row-major (ldb, zero padded to a multiple of 128 columns and 16 rows), C row-major (ldc).

@@ -246,8 +246,6 @@ struct Mix6Args {
   double* out[6];       // eliminated coefficients of the mixed fields, [rows][ldo]
   const double* eth_alpha;     // c16[n_pix]  (eth alpha / sqrt 2 of the reference)
   const double* etheth_alpha;  // c16[n_pix]
-  const double* inv_k;         // [n_pix] (= 1 without a boost; kept so that the arithmetic is the dense route's)
-  const double* inv_k3;
   const double* cst;    // eliminated constant series: cst[t * ldc]
   long long ldc, ldo;
 };
@@ -291,12 +289,25 @@ __global__ __launch_bounds__(64) void phi_synthesis_mix6_kernel(Mix6Args a, long
   }
   // operand row fi: field fi >> 3 of the pair, ring fi & 3, Re (part 0) or Im (part 1)
   const int ab = fi >> 3, ag = fi & 3, part = (fi >> 2) & 1;
+  constexpr int MAXIT = 8;  // 64-lane sweeps over the tile's 4 n_phi pixels (n_phi <= 127)
+  double2 tB[MAXIT], tE[MAXIT];
   const long long n_items = n_rows * mt;
   if (blockIdx.x < n_items) M6_LOAD((long long)blockIdx.x, 0)
   for (long long item = blockIdx.x; item < n_items; item += gridDim.x) {
     const long long t = item / mt;
     const int rt = (int)(item - t * mt);
     const int rings = n_theta - 4 * rt < 4 ? n_theta - 4 * rt : 4;
+    const long long pix0 = (long long)(4 * rt) * n_phi;
+    const int n_el = rings * n_phi;
+    // the per-pixel constants of the mixing are requested now and arrive under the three passes (asked for inside the mixing loop
+    // each sweep waited out an L2 round trip)
+#pragma unroll
+    for (int it = 0; it < MAXIT; ++it) {
+      const int e = lane + 64 * it;
+      const long long p = pix0 + (e < n_el ? e : 0);
+      tB[it] = *reinterpret_cast<const double2*>(a.eth_alpha + 2 * p);
+      tE[it] = *reinterpret_cast<const double2*>(a.etheth_alpha + 2 * p);
+    }
 #pragma unroll
     for (int pass = 0; pass < 3; ++pass) {  // (unrolled: the field pointers of a pass are then scalars, not a private array)
       // the pass's F tiles go where its results will: fields 2 pass, 2 pass + 1
@@ -349,44 +360,43 @@ __global__ __launch_bounds__(64) void phi_synthesis_mix6_kernel(Mix6Args a, long
         }
       }
     }
-    // ---- mixing (transformations.py:340-385 with X = -eth alpha) and the way out
+    // ---- mixing (transformations.py:340-385 with X = -eth alpha, 1 / k = 1 / k^3 = 1) and the way out
     const double cv = a.cst[t * a.ldc];
-    const long long pix0 = (long long)(4 * rt) * n_phi;
-    const int n_el = rings * n_phi;
-    for (int e = lane; e < n_el; e += 64) {
-      const long long p = pix0 + e;
-      cplx f[6];
 #pragma unroll
-      for (int i = 0; i < 6; ++i) {
-        const double2 w = sm[(size_t)i * tile + e];
-        f[i] = {w.x, w.y};
+    for (int it = 0; it < MAXIT; ++it) {
+      const int e = lane + 64 * it;
+      if (e < n_el) {
+        const long long p = pix0 + e;
+        cplx f[6];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+          const double2 w = sm[(size_t)i * tile + e];
+          f[i] = {w.x, w.y};
+        }
+        const double2 EE = tE[it];
+        const cplx X = {-tB[it].x, -tB[it].y};
+        auto axpy = [](cplx tt, cplx X, double c, cplx ff) {  // tt X + c ff
+          cplx r = cmul(tt, X);
+          return cplx{r.re + c * ff.re, r.im + c * ff.im};
+        };
+        cplx t0 = f[4];
+        t0 = axpy(t0, X, -4.0, f[3]);
+        t0 = axpy(t0, X, 6.0, f[2]);
+        t0 = axpy(t0, X, -4.0, f[1]);
+        t0 = axpy(t0, X, 1.0, f[0]);
+        cplx t1 = {-f[4].re, -f[4].im};
+        t1 = axpy(t1, X, 3.0, f[3]);
+        t1 = axpy(t1, X, -3.0, f[2]);
+        t1 = axpy(t1, X, 1.0, f[1]);
+        cplx t2 = f[4];
+        t2 = axpy(t2, X, -2.0, f[3]);
+        t2 = axpy(t2, X, 1.0, f[2]);
+        cplx t3 = {-f[4].re, -f[4].im};
+        t3 = axpy(t3, X, 1.0, f[3]);
+        const cplx mixed[6] = {t0, t1, t2, t3, f[4], {f[5].re - EE.x * cv, f[5].im - EE.y * cv}};
+#pragma unroll
+        for (int i = 0; i < 6; ++i) *reinterpret_cast<double2*>(a.out[i] + t * a.ldo + 2 * p) = double2{mixed[i].re, mixed[i].im};
       }
-      const double2 B = *reinterpret_cast<const double2*>(a.eth_alpha + 2 * p), EE = *reinterpret_cast<const double2*>(a.etheth_alpha + 2 * p);
-      const double ik = a.inv_k[p], ik3 = a.inv_k3[p];
-      const cplx X = {-B.x, -B.y};
-      auto axpy = [](cplx tt, cplx X, double c, cplx ff) {  // tt X + c ff
-        cplx r = cmul(tt, X);
-        return cplx{r.re + c * ff.re, r.im + c * ff.im};
-      };
-      cplx t0 = f[4];
-      t0 = axpy(t0, X, -4.0, f[3]);
-      t0 = axpy(t0, X, 6.0, f[2]);
-      t0 = axpy(t0, X, -4.0, f[1]);
-      t0 = axpy(t0, X, 1.0, f[0]);
-      cplx t1 = {-f[4].re, -f[4].im};
-      t1 = axpy(t1, X, 3.0, f[3]);
-      t1 = axpy(t1, X, -3.0, f[2]);
-      t1 = axpy(t1, X, 1.0, f[1]);
-      cplx t2 = f[4];
-      t2 = axpy(t2, X, -2.0, f[3]);
-      t2 = axpy(t2, X, 1.0, f[2]);
-      cplx t3 = {-f[4].re, -f[4].im};
-      t3 = axpy(t3, X, 1.0, f[3]);
-      const cplx mixed[6] = {{t0.re * ik3, t0.im * ik3}, {t1.re * ik3, t1.im * ik3}, {t2.re * ik3, t2.im * ik3},
-                             {t3.re * ik3, t3.im * ik3}, {f[4].re * ik3, f[4].im * ik3},
-                             {(f[5].re - EE.x * cv) * ik, (f[5].im - EE.y * cv) * ik}};
-#pragma unroll
-      for (int i = 0; i < 6; ++i) *reinterpret_cast<double2*>(a.out[i] + t * a.ldo + 2 * p) = double2{mixed[i].re, mixed[i].im};
     }
   }
 #undef M6_LOAD
@@ -495,12 +505,12 @@ int abd_mix6_supported(int n_theta, int n_phi, int ell_max) {
 
 // F6: six F buffers (each n_rows x (2 L + 1) x jp complex); out6: six grids [n_rows][ldo]; per-pixel tables in grid order
 hipError_t launch_phi_synthesis_mix6(hipStream_t stream, const double* const F6[6], long long n_rows, int n_theta, int n_phi,
-                                     int ell_max, const double* eth_alpha, const double* etheth_alpha, const double* inv_k,
-                                     const double* inv_k3, const double* cst, long long ldc, double* const out6[6], long long ldo) {
+                                     int ell_max, const double* eth_alpha, const double* etheth_alpha, const double* cst, long long ldc,
+                                     double* const out6[6], long long ldo) {
   if (n_rows <= 0) return hipSuccess;
   Mix6Args a;
   for (int f = 0; f < 6; ++f) a.F[f] = F6[f], a.out[f] = out6[f];
-  a.eth_alpha = eth_alpha, a.etheth_alpha = etheth_alpha, a.inv_k = inv_k, a.inv_k3 = inv_k3, a.cst = cst, a.ldc = ldc, a.ldo = ldo;
+  a.eth_alpha = eth_alpha, a.etheth_alpha = etheth_alpha, a.cst = cst, a.ldc = ldc, a.ldo = ldo;
   const int L = ell_max, jp = large_analysis_jp(n_theta);
   const int nk = n_phi / 2 + 1, mt = (n_theta + 3) / 4;
   const int km = (L + 3) / 4, ntc = (nk + 15) / 16;
