@@ -260,15 +260,27 @@ class _PinnedBlock:
 
 
 # ---- page-locking of caller-owned input arrays that are transformed repeatedly
-_seen_inputs = collections.OrderedDict()  # (address, nbytes) -> sightings (small LRU)
-_registered = {}  # (address, nbytes) -> weakref.finalize handle
+# An input is "the same array again" only if it is the same live OBJECT (identity of the array that owns the memory, held by a weak
+# reference) with the same address and size: a temporary whose freed block malloc hands out again at the same address is a new
+# object and starts from zero, so one-off arrays (copies made by the shim, the fresh copy an adapter builds per call) are never
+# page-locked, and a range that moved (ndarray.resize) is released before anything else happens.
+_reg_lock = threading.Lock()
+_seen_inputs = collections.OrderedDict()  # id(owner) -> [weakref to owner, address, nbytes, sightings] (small LRU)
+_registered = {}  # id(owner) -> (address, nbytes, weakref.finalize handle)
 REGISTER_MIN_BYTES = 32 << 20
 
 
+def _unregister_range(address):
+    try:
+        load().bms_host_unregister(c_vp(address))
+    except Exception:  # interpreter shutdown
+        pass
+
+
 def register_if_reused(a):
-    """Page-lock the host array `a` in place the SECOND time it is handed in (a one-off array would pay the registration for
-    nothing: it costs about one upload); released when the array is garbage collected.  Returns True when `a` is page-locked
-    after the call.  SCRI_AMD_NO_REGISTER disables."""
+    """Page-lock the host array `a` in place the SECOND time the same array object is handed in (a one-off array would pay the
+    registration for nothing: it costs about one upload); released when the array is garbage collected or found resized.  Returns
+    True when `a` is page-locked after the call.  SCRI_AMD_NO_REGISTER disables."""
     import weakref
 
     if os.environ.get("SCRI_AMD_NO_REGISTER") or a.nbytes < REGISTER_MIN_BYTES or not a.flags.c_contiguous:
@@ -276,32 +288,45 @@ def register_if_reused(a):
     owner = a if a.base is None else a.base  # the object whose lifetime covers the memory
     while isinstance(owner, np.ndarray) and owner.base is not None:
         owner = owner.base
-    key = (a.ctypes.data, a.nbytes)
-    if key in _registered:
+    oid, address, nbytes = id(owner), a.ctypes.data, a.nbytes
+    with _reg_lock:
+        reg = _registered.get(oid)
+        if reg is not None:
+            if reg[0] == address and reg[1] == nbytes:
+                return True
+            # the object's memory moved or changed size since it was page-locked: that registration is stale
+            _registered.pop(oid, None)
+            reg[2].detach()
+            _unregister_range(reg[0])
+            _seen_inputs.pop(oid, None)
+        seen = _seen_inputs.pop(oid, None)
+        if seen is not None and (seen[0]() is not owner or seen[1] != address or seen[2] != nbytes):
+            seen = None  # a recycled id, or the same object with other memory: not a second sighting
+        if seen is None:
+            try:
+                seen = [weakref.ref(owner), address, nbytes, 0]
+            except TypeError:  # the owner cannot be weakly referenced: its release could never be observed
+                return False
+        seen[3] += 1
+        _seen_inputs[oid] = seen
+        while len(_seen_inputs) > 16:
+            _seen_inputs.popitem(last=False)
+        if seen[3] < 2:
+            return False
+        if load().bms_host_register(c_vp(address), nbytes) != 0:
+            return False
+
+        def _release(k=oid, addr=address):
+            with _reg_lock:
+                cur = _registered.get(k)
+                if cur is not None and cur[0] == addr:
+                    _registered.pop(k, None)
+                _seen_inputs.pop(k, None)
+            _unregister_range(addr)
+
+        _registered[oid] = (address, nbytes, weakref.finalize(owner, _release))
+        _seen_inputs.pop(oid, None)
         return True
-    n = _seen_inputs.pop(key, 0) + 1
-    _seen_inputs[key] = n
-    while len(_seen_inputs) > 16:
-        _seen_inputs.popitem(last=False)
-    if n < 2:
-        return False
-    if load().bms_host_register(c_vp(key[0]), key[1]) != 0:
-        return False
-
-    def _release(k=key):
-        _registered.pop(k, None)
-        _seen_inputs.pop(k, None)
-        try:
-            load().bms_host_unregister(c_vp(k[0]))
-        except Exception:  # interpreter shutdown
-            pass
-
-    try:
-        _registered[key] = weakref.finalize(owner, _release)
-    except TypeError:  # the owner cannot be weakly referenced: do not keep a registration we could never release
-        _release()
-        return False
-    return True
 
 
 def pinned_empty(shape, dtype):

@@ -417,12 +417,20 @@ def test_reused_host_input_is_page_locked_and_released(ctx):
     data = np.ascontiguousarray(data[:, :77])  # l <= 8: 148 MB
     kw = synthetic.CONFIGS["cfg2"]["kwargs"]
     tr = engine.make_transformation(kw["supertranslation"], [1, 0, 0, 0], [0, 0, 0], 21, 21, 8)
-    key = (data.ctypes.data, data.nbytes)
+    key = id(data)
     outs = []
     for i in range(3):
         outs.append(engine.transform_modes(t, data, 2, 8, -2, -1, engine.BMS_TERM_H, tr, ctx=ctx)[1].copy())
         assert (key in _lib._registered) == (i >= 1)
     assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[1], outs[2])
+    # a one-off array -- a fresh copy per call, as an adapter builds it -- is never page-locked, even when malloc hands out the
+    # block of its predecessor again (same address, same size: another object)
+    before = set(_lib._registered)
+    for i in range(3):
+        tmp = data.copy()
+        engine.transform_modes(t, tmp, 2, 8, -2, -1, engine.BMS_TERM_H, tr, ctx=ctx)
+        assert set(_lib._registered) == before
+        del tmp
     del data
     gc.collect()
     assert key not in _lib._registered

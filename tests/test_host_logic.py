@@ -133,3 +133,48 @@ def test_boosted_grid_and_conformal_factors_match_the_oracle():
     assert R.shape == (11, 13, 4) and np.abs(R - R_ref).max() < 1e-14
     for got, expect in zip(A.conformal_factors(v, R), abd_ref.conformal_factors(v, R_ref)):
         assert got.shape == (1, 11, 13) and np.abs(got - expect).max() < 1e-14
+
+
+def test_register_if_reused_counts_objects_not_addresses(monkeypatch):
+    """Sightings of an input array are counted per live OBJECT (scri_amd/_lib.py): a recycled address, a recycled id() or the
+    same object with other memory do not add up to "seen twice"; the library calls are replaced by recorders here."""
+    import gc
+
+    from scri_amd import _lib
+
+    calls = []
+
+    class FakeLib:
+        def bms_host_register(self, p, n):
+            calls.append(("reg", p.value, n))
+            return 0
+
+        def bms_host_unregister(self, p):
+            calls.append(("unreg", p.value))
+            return 0
+
+    monkeypatch.setattr(_lib, "load", lambda: FakeLib())
+    monkeypatch.setattr(_lib, "REGISTER_MIN_BYTES", 1024)
+    monkeypatch.delenv("SCRI_AMD_NO_REGISTER", raising=False)
+    _lib._seen_inputs.clear()
+    a = np.zeros(4096)
+    assert _lib.register_if_reused(a) is False and calls == []
+    assert _lib.register_if_reused(a) is True and calls == [("reg", a.ctypes.data, a.nbytes)]
+    assert _lib.register_if_reused(a) is True and len(calls) == 1  # already page-locked
+    assert _lib.register_if_reused(a[:2048]) is False  # a view with another extent of a registered owner: stale range released
+    assert calls[-1] == ("unreg", a.ctypes.data)
+    # fresh objects every time: never registered, whatever addresses they get
+    n_before = len(calls)
+    for _ in range(4):
+        b = np.zeros(4096)
+        assert _lib.register_if_reused(b) is False
+        del b
+    assert len(calls) == n_before
+    # release with the owner
+    c = np.ones(4096)
+    _lib.register_if_reused(c)
+    _lib.register_if_reused(c)
+    addr = c.ctypes.data
+    del c
+    gc.collect()
+    assert calls[-1] == ("unreg", addr) and not _lib._registered
