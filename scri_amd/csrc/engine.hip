@@ -191,13 +191,14 @@ static int fail(bms_ctx* c, int code, const char* fmt, ...) {
   } while (0)
 
 // The stream the results of a pipelined call leave on.  The runtime executes device-to-host copies as shader copies
-// (__amd_rocclr_copyBuffer) that take turns with the compute kernels on every CU; the stream is therefore confined to 8 CUs spread
-// over the chip (hipExtStreamCreateWithCUMask): the blit kernels still fill the link and leave the other CUs to the transform.
-// Measured (tools/host_mode_rate.py, cfg3 from and to host memory): 14.8 ms unconfined, 14.9 / 13.7 / 13.6 / 13.8 / 13.9 ms on
-// 2 / 4 / 8 / 16 / 32 CUs.  SCRI_AMD_DOWN_CUS = n overrides (0: unconfined).
+// (__amd_rocclr_copyBuffer) that take turns with the compute kernels on every CU.  SCRI_AMD_DOWN_CUS = n (experiment) confines the
+// stream to n CUs spread over the chip (hipExtStreamCreateWithCUMask).  Measured (tools/host_mode_rate.py, cfg3 from and to host
+// memory, three alternating runs on one box): 14.8 / 13.9 / 15.0 ms unconfined, 14.9 / 14.9 / 15.2 ms on 8 CUs -- no difference
+// beyond the run-to-run spread (a first sweep that read 13.6 ms on 8 CUs against 14.8 was that spread), so the default stays
+// unconfined.
 static hipError_t create_download_stream(bms_ctx* c) {
   const char* e = getenv("SCRI_AMD_DOWN_CUS");
-  const int want = e ? atoi(e) : 8;
+  const int want = e ? atoi(e) : 0;
   if (want > 0) {
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, c->device) == hipSuccess) {
