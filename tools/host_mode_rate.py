@@ -9,10 +9,10 @@ kw, L = spec["kwargs"], spec["ell_max"]
 nth = 2 * (L + 2) + 1
 tr = engine.make_transformation(kw["supertranslation"], kw["frame_rotation"], kw["boost_velocity"], nth, nth, L)
 ctx = _lib.Context(0)
-for _ in range(3):
-    engine.transform_modes(t, data, 2, L, -2, -1, engine.BMS_TERM_H, tr, ctx=ctx)
+for _ in range(4):  # (results bound as in the timed loop: the second page-locked result block is allocated here, once)
+    t_new, d_new = engine.transform_modes(t, data, 2, L, -2, -1, engine.BMS_TERM_H, tr, ctx=ctx)
 t0 = time.perf_counter()
-k = 8
+k = 16
 for _ in range(k):
     t_new, d_new = engine.transform_modes(t, data, 2, L, -2, -1, engine.BMS_TERM_H, tr, ctx=ctx)
 dt = (time.perf_counter() - t0) / k
