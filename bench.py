@@ -401,7 +401,10 @@ def main():
 
     # roofline.traffic of the dominant kernel, measured by this run: PMC child passes BEFORE this process initialises the GPU
     traffic, traffic_note = None, "not measured"
-    if world == 1 and not pmc_child and not args.no_live_pmc and args.workload == "cfg3":
+    under_profiler = any("rocprof" in os.environ.get(k, "").lower() for k in ("LD_PRELOAD", "ROCP_TOOL_LIBRARIES", "ROCPROFILER_LIBRARY_CTOR"))
+    if under_profiler:  # (a profiler's preloaded library has initialised the GPU already: no child programs from here)
+        traffic_note = "not measured: this run is itself under a profiler"
+    if world == 1 and not pmc_child and not args.no_live_pmc and args.workload == "cfg3" and not under_profiler:
         child = ["--gpus", "1", "--steps", "3", "--warmup", "1", "--cpu-sample", "0", "--no-live-pmc", "--workload", args.workload,
                  "--boost-scale", str(args.boost_scale)] + (["--n-times", str(args.n_times)] if args.n_times else [])
         traffic, traffic_note = live_pmc_traffic(child)

@@ -7,7 +7,7 @@ cd /tmp && export TMPDIR=/tmp
 for set in "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_LDS_UNALIGNED_STALL" "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" "SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES"; do
   tag=$(echo $set | cut -d' ' -f1)
   rm -rf $OUT/sq_$tag
-  rocprofv3 --pmc $set --output-format csv -d $OUT/sq_$tag -- python3 $REPO/bench.py --steps 2 --warmup 1 --cpu-sample 0 > $OUT/sq_$tag.log 2>&1
+  rocprofv3 --pmc $set --output-format csv -d $OUT/sq_$tag -- python3 $REPO/bench.py --steps 2 --warmup 1 --cpu-sample 0 --no-live-pmc > $OUT/sq_$tag.log 2>&1
 done
 cd $REPO
 python3 - <<'PY'
