@@ -353,3 +353,37 @@ def test_cfg5_whole_series_equals_its_eight_shards_and_oracle_at_interior_seams(
         lo, hi = seam - 700 - window[0], seam + 700 - window[0]
         got_raw = d_out[:, lo:hi].cpu().numpy()
         _abd_window_check(u_out[lo:hi], got_raw, kw, L, [(seam - 240, 480)])
+
+
+def test_cfg5_shard_size_without_boost_fused_route_equals_dense(ctx, monkeypatch):
+    """One GPU's share of cfg5 (25 000 steps, six fields, l <= 24, 99 x 99 grid) under the workload's supertranslation and frame rotation
+    WITHOUT its boost: elimination on the modes + two-kernel separable synthesis + phi stage fused with the mixing
+    (kernels_synthesis_large.hip) against the six dense sYlm products + mixing and elimination on the grid (the route the oracle windows
+    of the boosted tests above pin at this size), and against the unfused separable route."""
+    import torch
+
+    from scri_amd import engine, synthetic
+
+    spec = synthetic.CONFIGS["cfg5"]
+    kw = spec["kwargs"]
+    n, L = 25_000, spec["ell_max"]
+    u, raw, _ = synthetic.abd_workload("cfg5", n_times=n)
+    tr = engine.make_transformation(kw["supertranslation"], kw["frame_rotation"], [0, 0, 0], 99, 99, L)
+    dev = torch.device("cuda", ctx.device)
+    d_in = torch.from_numpy(raw).to(dev)
+    outs = {}
+    for route, env in (("fused", {}), ("separable", {"SCRI_AMD_NO_FUSED_ABD_MIX": "1"}), ("dense", {"SCRI_AMD_NO_SEPARABLE_SYNTHESIS": "1"})):
+        for k in ("SCRI_AMD_NO_FUSED_ABD_MIX", "SCRI_AMD_NO_SEPARABLE_SYNTHESIS"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        d_out = torch.empty_like(d_in)
+        torch.cuda.synchronize()
+        u_out, n_new = engine.transform_abd(u, d_in.data_ptr(), L, tr, ctx=ctx, device=True, out_ptr=d_out.data_ptr())
+        outs[route] = (u_out, d_out[:, :n_new])
+    assert outs["dense"][1].shape[1] > n - 10
+    scale = float(outs["dense"][1].abs().max())
+    for route in ("fused", "separable"):
+        assert np.array_equal(outs[route][0], outs["dense"][0])
+        worst = float((outs[route][1] - outs["dense"][1]).abs().max())
+        assert worst < 2e-13 * scale, (route, worst / scale)
