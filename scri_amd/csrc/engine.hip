@@ -1829,6 +1829,26 @@ static int transform_modes_impl(bms_ctx* c, const bms_wm_input* in, const bms_tr
     char nm[32];
     snprintf(nm, sizeof nm, "Bsyn%d", fi);
     if (sep) continue;  // (no dense sYlm matrix)
+    if (sep_fields && psi && bsg) {
+      // Without a boost the psi mixing is time independent too (X = xa (t - alpha) - xb with xa = 0) and commutes with the spline's
+      // forward elimination, as the offset and scale of the other types do: every field is eliminated as MODES
+      // (bspline_forward_modes_kernel), rotated, synthesised as eliminated coefficients and mixed -- the elimination pass over the
+      // grid is skipped below.
+      const int nmf = f.K / 2;
+      const long long ld_e = round_up(2LL * nmf, 16);
+      double* d_e;
+      snprintf(nm, sizeof nm, "psi_Af%d", fi);
+      if ((rc = dev_buf_t(c, nm, (size_t)rows_avail * ld_e, &d_e))) return rc;
+      TIMED(c, BMS_TAG_SPLINE_FORWARD, launch_bspline_forward_modes(S, f.d_data, f.ld * 2, nmf, d_e, ld_e, row0, rows_avail, n, d_bsfwd, SPLINE_TILE, SPLINE_HALO, 0));
+      f.d_data = d_e;
+      f.ld = ld_e / 2;
+      const double* q = tr->frame_rotation;
+      if (!(q[0] == 1.0 && q[1] == 0.0 && q[2] == 0.0 && q[3] == 0.0)) {
+        const double sp[4] = {q[0], q[3], q[2], q[1]};  // (w + i z, y + i x)
+        if ((rc = rotate_impl(c, d_e, BMS_DEVICE, rows_avail, f.ld, f.ell_min, f.ell_max, sp, false, false))) return rc;
+      }
+      continue;
+    }
     if (sep_fields) {
       // the field as seen from the rotated frame: rotated in place in the staging copy (host callers), in a copy otherwise
       const double* q = tr->frame_rotation;
@@ -1947,7 +1967,10 @@ static int transform_modes_impl(bms_ctx* c, const bms_wm_input* in, const bms_tr
       TIMED(c, BMS_TAG_POINTWISE, launch_affine_cols(S, d_Y, ldg, (int)P2, rows_in, d_off, d_scale));
     }
     // spline along time on the shared knots, evaluated on the distorted slices
-    if (bsg) {  // mixing is time dependent: eliminate on the grid, then the coefficient-only back substitution
+    if (bsg && sep_fields && psi) {  // (eliminated on the modes above: d_Y holds coefficients already)
+      TIMED(c, BMS_TAG_SPLINE_BACKWARD, launch_bspline_backward_eval(S, d_Y, ldg, n_pix, g0, rows_in, n, d_x, d_bstab, SPLINE_TILE, SPLINE_HALO, d_x, d_skewa,
+                                                                     d_skewb, T.tt, c0, c1, d_G, ldG, &spread));
+    } else if (bsg) {  // mixing is time dependent: eliminate on the grid, then the coefficient-only back substitution
       TIMED(c, BMS_TAG_SPLINE_FORWARD, launch_bspline_forward_modes(S, d_Y, ldg, n_pix, d_R, ldg, g0, rows_in, n, d_bsfwd, SPLINE_TILE, SPLINE_HALO, 0));
       TIMED(c, BMS_TAG_SPLINE_BACKWARD, launch_bspline_backward_eval(S, d_R, ldg, n_pix, g0, rows_in, n, d_x, d_bstab, SPLINE_TILE, SPLINE_HALO, d_x, d_skewa,
                                                                      d_skewb, T.tt, c0, c1, d_G, ldG, &spread));
