@@ -132,6 +132,16 @@ def test_pipelined_host_path_matches_the_one_call_path(ctx, monkeypatch):
     assert calls == [1]
     assert piped.t.shape == plain.t.shape and np.array_equal(piped.t, plain.t)
     assert np.abs(piped.data - plain.data).max() < 1e-12 * np.abs(plain.data).max()
+    # without the boost: every piece rotates its eliminated modes (constant rotor through the context's page-locked ring, no stream
+    # synchronisation per piece) and takes the separable synthesis
+    boost = kw.pop("boost_velocity")
+    piped_free = run(t)
+    monkeypatch.setenv("SCRI_AMD_NO_PIPELINE", "1")
+    plain_free = run(t)
+    monkeypatch.delenv("SCRI_AMD_NO_PIPELINE")
+    assert calls == [1, 1] and np.array_equal(piped_free.t, plain_free.t)
+    assert np.abs(piped_free.data - plain_free.data).max() < 1e-12 * np.abs(plain_free.data).max()
+    kw["boost_velocity"] = boost
     # geometric grading: not shardable -> falls back, same answer as with the pipeline switched off
     kw = dict(supertranslation=kw["supertranslation"])
     tg = np.cumsum(np.concatenate([np.full(3000, 0.1), 0.1 * 1.2 ** np.arange(1, 51), np.full(n - 3050, 0.1 * 1.2**50)]))
@@ -139,5 +149,5 @@ def test_pipelined_host_path_matches_the_one_call_path(ctx, monkeypatch):
     plain_g = run(tg)
     monkeypatch.delenv("SCRI_AMD_NO_PIPELINE")
     piped_g = run(tg)
-    assert len(calls) == 2
+    assert len(calls) == 3
     assert np.array_equal(piped_g.data, plain_g.data)
