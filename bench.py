@@ -358,6 +358,55 @@ def plumbing_only(args, rank, world, backend_note=None):
     return 0 if int(ok) else 1
 
 
+def abd_boost_free_line(ctx, n_rows=10_000):
+    """Secondary measurement: AsymptoticBondiData (psi0..psi4 + sigma, l <= 24, 99 x 99 working grid: one GPU's cfg5 rows, here
+    `n_rows` of them) under cfg5's supertranslation + frame rotation WITHOUT its boost -- elimination on the modes, two-kernel
+    separable synthesis (theta stage per field, phi stage of the six fields fused with their mixing) -- and the same through the six
+    dense products.  HIP-event time of the synthesis kernels against the HBM roofline with their algorithmic bytes: modes read,
+    F written and read, grids written."""
+    import torch
+
+    from scri_amd import engine, synthetic
+
+    spec = synthetic.CONFIGS["cfg5"]
+    kw, L = spec["kwargs"], spec["ell_max"]
+    u, raw, _ = synthetic.abd_workload("cfg5", n_times=n_rows)
+    n_theta = 2 * (2 * L + 1) + 1
+    tr = engine.make_transformation(kw["supertranslation"], kw["frame_rotation"], [0, 0, 0], n_theta, n_theta, L)
+    d_in = torch.from_numpy(raw).to(torch.device("cuda", ctx.device))
+    d_out = torch.empty_like(d_in)
+    out = {"metric": "timesteps/s, AsymptoticBondiData transformation without a boost (cfg5 fields and grid)", "n_times": n_rows}
+    saved = os.environ.pop("SCRI_AMD_NO_SEPARABLE_SYNTHESIS", None)
+    try:
+        for route in ("separable", "dense"):
+            if route == "dense":
+                os.environ["SCRI_AMD_NO_SEPARABLE_SYNTHESIS"] = "1"
+            reps = 3 if route == "separable" else 1
+            engine.transform_abd(u, d_in.data_ptr(), L, tr, ctx=ctx, device=True, out_ptr=d_out.data_ptr())
+            ctx.synchronize()
+            ctx.get_timing(reset=True)
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                engine.transform_abd(u, d_in.data_ptr(), L, tr, ctx=ctx, device=True, out_ptr=d_out.data_ptr())
+            ctx.synchronize()
+            wall = (time.perf_counter() - t0) / reps
+            tm = {k: v[0] / reps for k, v in ctx.get_timing(reset=True).items() if v[1]}
+            out[route] = {"ms_per_step": wall * 1e3, "value": n_rows / wall, "kernels": tm}
+    finally:
+        os.environ.pop("SCRI_AMD_NO_SEPARABLE_SYNTHESIS", None)
+        if saved is not None:
+            os.environ["SCRI_AMD_NO_SEPARABLE_SYNTHESIS"] = saved
+    nm, jp = (L + 1) ** 2, (n_theta + 7) // 8 * 8
+    bytes_per_step = 6 * 16 * (nm + 1 + 2 * (2 * L + 1) * jp + n_theta * n_theta)
+    ms = out["separable"]["kernels"].get("gemm_synthesis")
+    if ms:
+        out["synthesis_roofline"] = {"bound": "hbm", "kernel": "theta_synthesis_mfma_kernel x 6 + phi_synthesis_mix6_kernel", "bytes_per_step": bytes_per_step,
+                                     "achieved": n_rows * bytes_per_step / (ms * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
+                                     "frac": n_rows * bytes_per_step / (ms * 1e-3) / 8e12, "ms": ms}
+    out["speedup_vs_dense_products"] = out["dense"]["ms_per_step"] / out["separable"]["ms_per_step"]
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -807,6 +856,10 @@ def main():
         if world == 1 and not abd and not pmc_child:
             line["rotation"] = rotation_line(local, ell_max, ctx, 3000 if args.cpu_sample > 0 else 0)
             line["boost_free"] = boost_free_line(local, t_global, kw, n_theta, ell_max, ctx)
+            if args.workload == "cfg3" and args.cpu_sample > 0:  # (the default run; the profiling commands pass --cpu-sample 0)
+                del local
+                torch.cuda.empty_cache()
+                line["abd_boost_free"] = abd_boost_free_line(ctx)
         print("\n" + json.dumps(line), flush=True)  # (on a line of its own whatever a backend wrote to stdout before)
     if world > 1:
         dist.barrier()
