@@ -109,3 +109,65 @@ def test_waveform_modes_boost_free_psi_types_and_large_ell(ctx, monkeypatch, dat
         expect = grid_ref.transform(ow, **kw, **oaux)
         assert got.n_times == expect.t.size
         assert np.abs(got.data - expect.data).max() < 1e-12 * scale
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_random_boost_free_shapes_equal_the_dense_route(ctx, monkeypatch, seed):
+    """Random shapes for the two-kernel separable synthesis: WaveformModes (h and psi3 with its psi4 companion) on user grids with odd and
+    even n_theta / n_phi up to the kernels' limits, AsymptoticBondiData with random working grids; with and without a frame rotation;
+    every case against the dense products of the same library."""
+    import scri_amd
+    from scri_amd import synthetic
+
+    rng = np.random.default_rng(1000 + seed)
+    rotated = bool(rng.integers(0, 2))
+    rot = rng.normal(size=4)
+    rot /= np.linalg.norm(rot)
+    st = synthetic.real_supertranslation(0.1 * (rng.normal(size=9) + 1j * rng.normal(size=9)))
+    flavour = ("wm_h", "wm_psi3", "abd")[seed % 3]
+    n = int(rng.integers(9, 60))
+    t = np.sort(rng.uniform(-20.0, 30.0, n))
+    t[1:] = np.maximum(t[1:], t[:-1] + 0.05)
+    kw = dict(supertranslation=st)
+    if rotated:
+        kw["frame_rotation"] = rot
+
+    if flavour == "abd":
+        ell_max = int(rng.integers(2, 14))
+        o = smooth_abd(n, ell_max, seed)
+        o = type(o)(t, o.raw, ell_max)
+        kw["working_ell_max"] = int(rng.integers(ell_max + 1, min(51, 3 * ell_max + 4) + 1))
+
+        def run():
+            g = scri_amd.AsymptoticBondiData(t, ell_max, ctx=ctx)
+            g._raw_data[:] = o.raw
+            r = g.transform(**kw)
+            return r.u, r._raw_data
+    else:
+        ell_max = int(rng.integers(3, 30))
+        n_theta = int(rng.integers(2 * ell_max + 1, 105))
+        n_phi = int(rng.integers(2 * ell_max + 1, 128))
+        kw.update(n_theta=n_theta, n_phi=n_phi)
+        name = "h" if flavour == "wm_h" else "psi3"
+        lmin = 2 if name == "h" else 1
+        data = synthetic.chirp_modes(t, lmin, ell_max, seed)
+        extra = {}
+
+        def wrap(nm, d, lo):
+            return scri_amd.WaveformModes(t=t, data=d, ell_min=lo, ell_max=ell_max, dataType=getattr(scri_amd, nm), frameType=scri_amd.Inertial,
+                                          r_is_scaled_out=True, m_is_scaled_out=True, ctx=ctx)
+
+        aux = synthetic.chirp_modes(t, 2, ell_max, seed + 50) if name == "psi3" else None
+
+        def run():
+            if aux is not None:
+                extra["psi4_modes"] = wrap("psi4", aux, 2)
+            r = wrap(name, data, lmin).transform(**kw, **extra)
+            return r.t, r.data
+
+    monkeypatch.delenv("SCRI_AMD_NO_SEPARABLE_SYNTHESIS", raising=False)
+    t_sep, d_sep = run()
+    monkeypatch.setenv("SCRI_AMD_NO_SEPARABLE_SYNTHESIS", "1")
+    t_den, d_den = run()
+    assert np.array_equal(t_sep, t_den) and t_den.size > 0
+    assert np.abs(d_sep - d_den).max() < 3e-13 * max(1.0, np.abs(d_den).max()) * max(1.0, ell_max / 8.0), (flavour, ell_max, kw.get("n_theta"), kw.get("working_ell_max"))
