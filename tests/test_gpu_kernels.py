@@ -148,3 +148,39 @@ def test_rotate_const_D_matches_oracle(ctx, ell_min, ell_max, n):
     assert np.all(wide[:, :2] == 0) and np.all(wide[:, 2 + data.shape[1] :] == 0)
     with pytest.raises(ValueError):
         engine.rotate_const_D(data.copy(), ell_min, ell_max, D[:-1], ctx=ctx)
+
+
+@pytest.mark.parametrize("ell_max,n", [(16, 100_000), (16, 40_007), (8, 100_000), (8, 70_001), (12, 33_333)])
+def test_rotate_series_long_runs_and_the_split_last_round(ctx, ell_max, n):
+    """Long series: the (tile, l group) units of the resident-table rotation kernel fill several rounds of the launch's waves and the
+    partial last round is cut into per-l pieces (kernels_rotate_resident.hip).  Every row is rotated independently, so the oracle
+    (scri/rotations.py:370-392 restated) runs on a sample of rows: the first and last tiles, every row of the tiles dealt in the last
+    round, and 400 rows at random; all other rows are checked through the norm of each l block, which a rotation preserves."""
+    import torch
+
+    from oracle import quat, rotations_ref, wigner
+    from scri_amd import engine
+
+    rng = np.random.default_rng(ell_max + n)
+    nm = wigner.LM_total_size(2, ell_max)
+    data = rng.normal(size=(n, nm)) + 1j * rng.normal(size=(n, nm))
+    q = rng.normal(size=(n, 4))
+    q /= np.linalg.norm(q, axis=1)[:, None]
+    sp = np.ascontiguousarray(quat.as_spinor_array(q))
+    dev = torch.from_numpy(data).cuda()
+    sp_dev = torch.from_numpy(sp).cuda()
+    engine.rotate_device(dev.data_ptr(), n, nm, 2, ell_max, spinors_ptr=sp_dev.data_ptr(), ctx=ctx)
+    ctx.synchronize()
+    got = dev.cpu().numpy()
+    # a rotation preserves the norm of every l block of every row
+    for ell in range(2, ell_max + 1):
+        a = ell * ell - 4
+        before = np.linalg.norm(data[:, a : a + 2 * ell + 1], axis=1)
+        after = np.linalg.norm(got[:, a : a + 2 * ell + 1], axis=1)
+        assert np.abs(after - before).max() < 1e-12 * before.max(), ell
+    n_tiles = (n + 15) // 16
+    tail_tiles = min(n_tiles, 256 * 8)  # (tiles whose units can lie in the partial last round of 2 048 waves)
+    rows = np.unique(np.concatenate([np.arange(0, 48), np.arange(max(0, n - 16 * tail_tiles), n)[:: max(1, tail_tiles // 64)],
+                                     np.arange(n - 48, n), rng.integers(0, n, 400)]))
+    expect = rotations_ref.rotate_by_series(data[rows].copy(), sp[rows], 2, ell_max)
+    assert np.abs(got[rows] - expect).max() < 1e-13 * ell_max * np.abs(expect).max()
