@@ -70,7 +70,7 @@ struct bms_ctx {
   hipStream_t stream = nullptr;
   hipStream_t aux = nullptr;  // set-up kernels whose results the host waits for run here, beside the main stream's work
   std::string err;
-  uint64_t ws_limit = 32ull << 30;
+  uint64_t ws_limit = 96ull << 30;  // a third of the 288 GB: one GPU's cfg5 rows (25 000 steps, six 99 x 99 grids, 76 GB) are ONE chunk
   std::map<std::string, DevBuf> bufs;  // grow-only named work space
   int delta_lmax = -1;                 // Delta tables cached up to this l
   int delta_mfma_lmax = -1;            // ... in the MFMA B-image packing
@@ -350,7 +350,7 @@ extern "C" int bms_ctx_use_default_stream(bms_ctx* c) {
 
 extern "C" int bms_ctx_set_workspace_limit(bms_ctx* c, uint64_t bytes) {
   if (!c) return BMS_ERR_INVALID;
-  c->ws_limit = bytes ? bytes : (32ull << 30);
+  c->ws_limit = bytes ? bytes : (96ull << 30);
   return BMS_OK;
 }
 
