@@ -1198,14 +1198,67 @@ static BsplineSpread skew_spread(const PixelTables& T, int cA, int cB, const dou
   return sp;
 }
 
+// Is the rotor grid of this transformation of the form F R(Theta_j, phi'_k), rings of the rotated equiangular grid at
+// colatitudes Theta_j?  Always without a boost (Theta_j = theta'_j); with one exactly when it points along the polar axis of the
+// rotated grid: the aberration then moves whole rings, B'(r') F R(theta', phi') = F R(Theta(theta'), phi') with no spin phase
+// (scri/waveform_grid.py:141-161: the rotation is about r' x v, which lies in the ring's tangent plane).  SURVEY section 7,
+// step 4(b).  The form is CHECKED on the rotors themselves (pixel_rotor, the code the dense route uses), not assumed.
+// The two-kernel synthesis moves (2 l_max + 1) x n_theta numbers per time step through HBM twice; the dense product it replaces
+// costs n_modes x n_pix multiply-adds per step and overtakes it only from about l_max = 13 on the default grids (measured:
+// tools/axis_boost_probe.py; l <= 8 on 17 x 17: 0.45 ms dense, 0.81 ms separable per 10^5 steps; l <= 16 on 33 x 33: 4.2 and 2.3).
+static bool axis_boost_pays(int n_modes, int n_theta, int n_phi) {
+  const char* e = getenv("SCRI_AMD_AXIS_BOOST_MIN_WORK");  // (read per call, like the other route switches)
+  const long long min_work = e ? atoll(e) : 160000;
+  return (long long)n_modes * n_theta * n_phi >= min_work;
+}
+static bool separable_rotor_grid(const bms_transformation* tr, std::vector<double>& thetas) {
+  const int n_theta = tr->n_theta, n_phi = tr->n_phi;
+  const double* fr = tr->frame_rotation;
+  const Quat F = {fr[0], fr[1], fr[2], fr[3]};
+  const BoostSpec bs = make_boost_spec(tr->boost_velocity);
+  thetas.resize(n_theta);
+  if (!bs.boosted) {
+    for (int j = 0; j < n_theta; ++j) thetas[j] = M_PI * j / (n_theta - 1);
+    return true;
+  }
+  if (getenv("SCRI_AMD_NO_AXIS_BOOST_SEPARABLE")) return false;
+  double zf[3];
+  rotate_z(F, zf);
+  const double cx = bs.vhat[1] * zf[2] - bs.vhat[2] * zf[1], cy = bs.vhat[2] * zf[0] - bs.vhat[0] * zf[2], cz = bs.vhat[0] * zf[1] - bs.vhat[1] * zf[0];
+  if (std::sqrt(cx * cx + cy * cy + cz * cz) > 1e-15) return false;  // (parallel to rounding, nothing looser)
+  const double n2 = F.w * F.w + F.x * F.x + F.y * F.y + F.z * F.z;
+  const Quat Finv = {F.w / n2, -F.x / n2, -F.y / n2, -F.z / n2};
+  // Every pixel of the two rings at either end (acos near 1 turns an ulp of r'.v into 1e-8 rad there, as it does in the reference:
+  // a frame whose axis is parallel to v only to rounding can fail right there and then keeps the dense route), a few per ring
+  // elsewhere.
+  const int ks[4] = {0, 1 % n_phi, n_phi / 3, n_phi - 1};
+  for (int j = 0; j < n_theta; ++j) {
+    double th = 0.0, ph = 0.0;
+    as_spherical_coords(qmul(Finv, pixel_rotor(F, bs, j, 0, n_theta, n_phi)), th, ph);
+    thetas[j] = th;
+    const bool end_ring = j < 2 || j >= n_theta - 2;
+    for (int i = 0; i < (end_ring ? n_phi : 4); ++i) {
+      const int k = end_ring ? i : ks[i];
+      const Quat G = qmul(Finv, pixel_rotor(F, bs, j, k, n_theta, n_phi));
+      const Quat E = from_spherical_coords(th, (2 * M_PI) * k / n_phi);
+      const double sgn = (G.w * E.w + G.x * E.x + G.y * E.y + G.z * E.z) < 0 ? -1.0 : 1.0;
+      const double d = std::fabs(G.w - sgn * E.w) + std::fabs(G.x - sgn * E.x) + std::fabs(G.y - sgn * E.y) + std::fabs(G.z - sgn * E.z);
+      if (!(d <= 1e-13)) return false;
+    }
+  }
+  return true;
+}
+
 // Tables of the separable synthesis, built once per (grid, spin, l range) and kept in the context.  Returns with P.nt = 0
 // and P.large = false when the shape is one neither kernel takes.
 static int run_synthesis(bms_ctx* c, const SynthesisPlan& P, const double* A, long long lda, long long rows, const double* off, double* Y,
-                         long long ldy);
-static int build_synthesis(bms_ctx* c, int n_theta, int n_phi, int spin, int ell_min, int ell_max, SynthesisPlan& P) {
+                         long long ldy, const double* scale = nullptr);
+// thetas != nullptr: the rings' colatitudes (a boost along the grid's polar axis): tables of their own, not kept, two-kernel form only
+static int build_synthesis(bms_ctx* c, int n_theta, int n_phi, int spin, int ell_min, int ell_max, SynthesisPlan& P,
+                           const std::vector<double>* thetas = nullptr) {
   const std::array<int, 5> key = {n_theta, n_phi, spin, ell_min, ell_max};
   auto it = c->syn_plans.find(key);
-  if (it != c->syn_plans.end()) {
+  if (!thetas && it != c->syn_plans.end()) {
     P = it->second;
     return BMS_OK;
   }
@@ -1217,7 +1270,7 @@ static int build_synthesis(bms_ctx* c, int n_theta, int n_phi, int spin, int ell
   }
   std::vector<int> meta;
   int len = 0;
-  if (!synthesis_split_plan(n_theta, n_phi, ell_min, ell_max, P.g, meta, P.lds, P.nt, len)) P.nt = 0;
+  if (thetas || !synthesis_split_plan(n_theta, n_phi, ell_min, ell_max, P.g, meta, P.lds, P.nt, len)) P.nt = 0;
   P.large = large_synthesis_supported(n_theta, n_phi, ell_min, ell_max) != 0;
   P.n_theta = n_theta, P.n_phi = n_phi, P.ell_min = ell_min, P.ell_max = ell_max;
   if (!P.nt && !P.large) return BMS_OK;
@@ -1228,10 +1281,10 @@ static int build_synthesis(bms_ctx* c, int n_theta, int n_phi, int spin, int ell
   const int n_modes = LM_total_size(ell_min, ell_max);
   std::vector<double> rot(4 * (size_t)n_theta), one(n_theta, 1.0);
   for (int j = 0; j < n_theta; ++j) {
-    const Quat q = from_spherical_coords(M_PI * j / (n_theta - 1), 0.0);
+    const Quat q = from_spherical_coords(thetas ? (*thetas)[j] : M_PI * j / (n_theta - 1), 0.0);
     rot[4 * j] = q.w, rot[4 * j + 1] = q.x, rot[4 * j + 2] = q.y, rot[4 * j + 3] = q.z;
   }
-  snprintf(nm_, sizeof nm_, "syn_rot_%d", n_theta);
+  snprintf(nm_, sizeof nm_, thetas ? "syn_rotb_%d" : "syn_rot_%d", n_theta);
   if ((rc = upload(c, nm_, rot.data(), 8 * rot.size(), &vp))) return rc;
   const double* d_rot = (const double*)vp;
   snprintf(nm_, sizeof nm_, "syn_one_%d", n_theta);
@@ -1246,26 +1299,26 @@ static int build_synthesis(bms_ctx* c, int n_theta, int n_phi, int spin, int ell
   if ((rc = dev_buf_t(c, "syn_Y", (size_t)n_theta * n_modes * 2, &d_Y))) return rc;
   HIP_TRY(c, hipMemsetAsync(d_Y, 0, 16 * (size_t)n_theta * n_modes, S));
   TIMED(c, BMS_TAG_SETUP, launch_swsh_values(S, d_rot, n_theta, spin, ell_min, ell_max, d_Y));
-  snprintf(nm_, sizeof nm_, "syn_T_%d_%d_%d_%d", n_theta, spin, ell_min, ell_max);
+  snprintf(nm_, sizeof nm_, thetas ? "syn_Tb_%d_%d_%d_%d" : "syn_T_%d_%d_%d_%d", n_theta, spin, ell_min, ell_max);
   if ((rc = dev_buf_t(c, nm_, (size_t)n_theta * n_modes, &P.d_T))) return rc;
   TIMED(c, BMS_TAG_SETUP, launch_theta_table(S, d_Y, d_one, n_theta, n_modes, P.d_T));  // weights 1: the plain sLambda values
   HIP_TRY(c, hipStreamSynchronize(S));  // host vectors above go out of scope
-  c->syn_plans[key] = P;
+  if (!thetas) c->syn_plans[key] = P;
   return BMS_OK;
 }
 
 // One separable synthesis: A[rows][lda] (complex; n_modes (+ 1 with `off`, always for the one-kernel form) per row) -> Y[rows][ldy]
 static int run_synthesis(bms_ctx* c, const SynthesisPlan& P, const double* A, long long lda, long long rows, const double* off, double* Y,
-                         long long ldy) {
+                         long long ldy, const double* scale) {
   hipStream_t S = c->stream;
   if (rows <= 0) return BMS_OK;
-  if (P.nt && rows >= 2 && !getenv("SCRI_AMD_NO_SPLIT_SYNTHESIS")) {
+  if (P.nt && !scale && rows >= 2 && !getenv("SCRI_AMD_NO_SPLIT_SYNTHESIS")) {
     TIMED(c, BMS_TAG_GEMM_SYNTHESIS, launch_synthesis_split(S, A, lda, rows, P.g, P.nt, P.d_T, P.d_meta, off, Y, ldy, P.lds, c->n_cu));
   } else if (P.large) {
     double* d_F;
     int rc = dev_buf_t(c, "Fphi", (size_t)rows * (2 * P.ell_max + 1) * large_analysis_jp(P.n_theta) * 2, &d_F);
     if (rc) return rc;
-    TIMED(c, BMS_TAG_GEMM_SYNTHESIS, launch_synthesis_large(S, A, lda, rows, P.n_theta, P.n_phi, P.ell_min, P.ell_max, P.d_T, off, d_F, Y, ldy));
+    TIMED(c, BMS_TAG_GEMM_SYNTHESIS, launch_synthesis_large(S, A, lda, rows, P.n_theta, P.n_phi, P.ell_min, P.ell_max, P.d_T, off, d_F, Y, ldy, scale));
   } else
     return fail(c, BMS_ERR_UNSUPPORTED, "internal: no separable synthesis for a chunk of %lld row(s) of this shape", rows);
   return BMS_OK;
@@ -1736,11 +1789,22 @@ static int transform_modes_impl(bms_ctx* c, const bms_wm_input* in, const bms_tr
   // Without a boost the grid is the equiangular grid seen through the constant frame rotation: rotate the (eliminated) modes
   // once and synthesise ring by ring (kernels_synthesis.hip) instead of multiplying with the dense sYlm matrix.  The grid
   // keeps its natural column order for that.
+  // A boost ALONG the polar axis of the rotated grid only moves its rings (separable_rotor_grid): the same route with the tables of
+  // the aberrated colatitudes, and the conformal factor's power applied on the way out of the phi stage.
   SynthesisPlan syn;
   const bool no_boost = tr->boost_velocity[0] == 0 && tr->boost_velocity[1] == 0 && tr->boost_velocity[2] == 0;
-  if (bs && no_boost && rows_avail >= 2 && !(sh && sh->col_parts > 1) && tr->n_theta >= 3 && !getenv("SCRI_AMD_NO_SEPARABLE_SYNTHESIS"))
-    if ((rc = build_synthesis(c, tr->n_theta, tr->n_phi, s, in->ell_min, in->ell_max, syn))) return rc;
-  const bool sep = syn.nt != 0 || syn.large;
+  std::vector<double> ring_theta;
+  bool axis_boost = false;
+  if (bs && rows_avail >= 2 && !(sh && sh->col_parts > 1) && tr->n_theta >= 3 && !getenv("SCRI_AMD_NO_SEPARABLE_SYNTHESIS")) {
+    if (no_boost) {
+      if ((rc = build_synthesis(c, tr->n_theta, tr->n_phi, s, in->ell_min, in->ell_max, syn))) return rc;
+    } else if (axis_boost_pays(n_modes, tr->n_theta, tr->n_phi) && large_synthesis_supported(tr->n_theta, tr->n_phi, in->ell_min, in->ell_max) &&
+               separable_rotor_grid(tr, ring_theta)) {
+      if ((rc = build_synthesis(c, tr->n_theta, tr->n_phi, s, in->ell_min, in->ell_max, syn, &ring_theta))) return rc;
+      axis_boost = syn.large;
+    }
+  }
+  const bool sep = no_boost ? (syn.nt != 0 || syn.large) : axis_boost;
   if (sep) {
     const double* q = tr->frame_rotation;
     if (!(q[0] == 1.0 && q[1] == 0.0 && q[2] == 0.0 && q[3] == 0.0)) {
@@ -1754,7 +1818,8 @@ static int transform_modes_impl(bms_ctx* c, const bms_wm_input* in, const bms_tr
   // as they do behind the dense product.
   SynthesisPlan syn_f[5];
   bool sep_fields = false;
-  if (!bs && no_boost && rows_avail >= 1 && !(sh && sh->col_parts > 1) && tr->n_theta >= 3 && !getenv("SCRI_AMD_NO_SEPARABLE_SYNTHESIS")) {
+  if (!bs && rows_avail >= 1 && !(sh && sh->col_parts > 1) && tr->n_theta >= 3 && !getenv("SCRI_AMD_NO_SEPARABLE_SYNTHESIS") &&
+      (no_boost || (axis_boost_pays(n_modes, tr->n_theta, tr->n_phi) && separable_rotor_grid(tr, ring_theta)))) {
     sep_fields = true;
     for (int fi = 0; fi < 1 + (psi ? in->n_aux : 0) && sep_fields; ++fi) {
       const int f_spin = fi ? in->aux_spin[fi - 1] : s, f_lo = fi ? in->aux_ell_min[fi - 1] : in->ell_min, f_hi = fi ? in->aux_ell_max[fi - 1] : in->ell_max;
@@ -1762,7 +1827,7 @@ static int transform_modes_impl(bms_ctx* c, const bms_wm_input* in, const bms_tr
         sep_fields = false;  // (reported below, where the auxiliary fields are checked)
         break;
       }
-      if ((rc = build_synthesis(c, tr->n_theta, tr->n_phi, f_spin, f_lo, f_hi, syn_f[fi]))) return rc;
+      if ((rc = build_synthesis(c, tr->n_theta, tr->n_phi, f_spin, f_lo, f_hi, syn_f[fi], no_boost ? nullptr : &ring_theta))) return rc;
       sep_fields = syn_f[fi].large;
     }
   }
@@ -1829,7 +1894,7 @@ static int transform_modes_impl(bms_ctx* c, const bms_wm_input* in, const bms_tr
     char nm[32];
     snprintf(nm, sizeof nm, "Bsyn%d", fi);
     if (sep) continue;  // (no dense sYlm matrix)
-    if (sep_fields && psi && bsg) {
+    if (sep_fields && psi && bsg && no_boost) {
       // Without a boost the psi mixing is time independent too (X = xa (t - alpha) - xb with xa = 0) and commutes with the spline's
       // forward elimination, as the offset and scale of the other types do: every field is eliminated as MODES
       // (bspline_forward_modes_kernel), rotated, synthesised as eliminated coefficients and mixed -- the elimination pass over the
@@ -1937,7 +2002,9 @@ static int transform_modes_impl(bms_ctx* c, const bms_wm_input* in, const bms_tr
       return rc;
     if (bs) {
       if (sep) {  // (k = 1 without a boost: no column scale)
-        if ((rc = run_synthesis(c, syn, d_Af + (g0 - row0) * ld_af, ld_af, rows_in, coef0.empty() ? nullptr : DP.col_off, d_Y, ldg))) return rc;
+        if ((rc = run_synthesis(c, syn, d_Af + (g0 - row0) * ld_af, ld_af, rows_in, coef0.empty() ? nullptr : DP.col_off, d_Y, ldg,
+                                axis_boost ? DP.col_scale : nullptr)))
+          return rc;
       } else
       TIMED(c, BMS_TAG_GEMM_SYNTHESIS, launch_zgemm3m(S, d_Af + (g0 - row0) * ld_af, ld_af, F[0].d_B + 2 * cA, ldb, d_Y, ldg, rows_in, n_pix,
                                                       n_modes_in + 1, nullptr, d_scale));
@@ -1967,7 +2034,7 @@ static int transform_modes_impl(bms_ctx* c, const bms_wm_input* in, const bms_tr
       TIMED(c, BMS_TAG_POINTWISE, launch_affine_cols(S, d_Y, ldg, (int)P2, rows_in, d_off, d_scale));
     }
     // spline along time on the shared knots, evaluated on the distorted slices
-    if (bsg && sep_fields && psi) {  // (eliminated on the modes above: d_Y holds coefficients already)
+    if (bsg && sep_fields && psi && no_boost) {  // (eliminated on the modes above: d_Y holds coefficients already)
       TIMED(c, BMS_TAG_SPLINE_BACKWARD, launch_bspline_backward_eval(S, d_Y, ldg, n_pix, g0, rows_in, n, d_x, d_bstab, SPLINE_TILE, SPLINE_HALO, d_x, d_skewa,
                                                                      d_skewb, T.tt, c0, c1, d_G, ldG, &spread));
     } else if (bsg) {  // mixing is time dependent: eliminate on the grid, then the coefficient-only back substitution
@@ -2679,10 +2746,16 @@ static int transform_abd_impl(bms_ctx* c, const double* u, const void* raw, int 
                       {-v[0] * std::sqrt(2 * M_PI / 3), v[1] * std::sqrt(2 * M_PI / 3)}};
   // Without a boost (every supertranslation and rotation step of map_to_superrest_frame, map_to_superrest_frame.py:443,610,641)
   // the six dense products give way to the separable synthesis on the rotated modes (kernels_synthesis_large.hip).
+  // A boost along the polar axis of the rotated grid keeps the rings (separable_rotor_grid): the same synthesis at the aberrated
+  // colatitudes; the mixing is time dependent then and stays on the grid.
   SynthesisPlan syn5[5];
-  bool sep = v[0] == 0 && v[1] == 0 && v[2] == 0 && !(sh && sh->col_parts > 1) && tr->n_theta >= 3 && !getenv("SCRI_AMD_NO_SEPARABLE_SYNTHESIS");
+  const bool no_boost = v[0] == 0 && v[1] == 0 && v[2] == 0;
+  std::vector<double> ring_theta;
+  bool sep = !(sh && sh->col_parts > 1) && tr->n_theta >= 3 && !getenv("SCRI_AMD_NO_SEPARABLE_SYNTHESIS") &&
+             (no_boost || (axis_boost_pays((ell_max + 1) * (ell_max + 1), tr->n_theta, tr->n_phi) &&
+                           large_synthesis_supported(tr->n_theta, tr->n_phi, 0, ell_max) && separable_rotor_grid(tr, ring_theta)));
   for (int si = 0; si < 5 && sep; ++si) {
-    if ((rc = build_synthesis(c, tr->n_theta, tr->n_phi, si - 2, 0, ell_max, syn5[si]))) return rc;
+    if ((rc = build_synthesis(c, tr->n_theta, tr->n_phi, si - 2, 0, ell_max, syn5[si], no_boost ? nullptr : &ring_theta))) return rc;
     sep = syn5[si].large;
   }
   PixelTables T;
@@ -2780,7 +2853,7 @@ static int transform_abd_impl(bms_ctx* c, const double* u, const void* raw, int 
   // Without a boost the Horner mixing has time-independent coefficients (k = 1, eth k = 0: X = -eth alpha), so it commutes with the
   // spline's forward elimination: that runs on the MODES (6 x (l_max+1)^2 columns + the constant series, instead of six grids), the
   // fields are synthesised as eliminated coefficients and mixed on their way out of the phi stage (phi_synthesis_mix6_kernel)
-  const bool fused_mix = sep && bsg && !short_series && abd_mix6_supported(tr->n_theta, tr->n_phi, ell_max);
+  const bool fused_mix = sep && no_boost && bsg && !short_series && abd_mix6_supported(tr->n_theta, tr->n_phi, ell_max);
   const long long ld_af = round_up(2LL * (nm + 1), 16);
   double* d_Af = nullptr;
   if (fused_mix) {

@@ -116,11 +116,12 @@ hipError_t launch_synthesis_split(hipStream_t stream, const double* A, long long
 
 // two-kernel form for the grids the one-kernel form does not take (kernels_synthesis_large.hip): n_theta <= 104, n_phi <= 127,
 // l_max <= 33, any l_min; F = n_rows x (2 l_max + 1) x large_analysis_jp(n_theta) complex of work space.  With `off` the row has
-// one more complex number at column n_modes (the eliminated constant series), which multiplies -off[pixel].
+// one more complex number at column n_modes (the eliminated constant series), which multiplies -off[pixel]; `scale` (2 doubles per
+// pixel, equal) multiplies the result.
 int large_synthesis_supported(int n_theta, int n_phi, int ell_min, int ell_max);
 hipError_t launch_synthesis_large(hipStream_t stream, const double* A, long long lda, long long n_rows, int n_theta, int n_phi,
                                   int ell_min, int ell_max, const double* Tsyn, const double* off, double* F, double* Y,
-                                  long long ldy);
+                                  long long ldy, const double* scale = nullptr);
 
 // AsymptoticBondiData without a boost: theta stage per field, then the phi stage of all six fields fused with their Horner mixing
 // (time-independent without a boost: the elimination has moved onto the modes); per-pixel tables in grid order

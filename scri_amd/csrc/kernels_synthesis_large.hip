@@ -117,13 +117,14 @@ __global__ __launch_bounds__(256) void theta_synthesis_mfma_kernel(const double*
 #undef TS_LOAD
 }
 
-// ---- phi stage: Y[t][ring][k] = sum_m F[t][m][ring] e^{i m phi_k} (- off[pixel] x the row's constant).  One wave per (time step,
-// tile of 8 rings).
+// ---- phi stage: Y[t][ring][k] = (sum_m F[t][m][ring] e^{i m phi_k} (- off[pixel] x the row's constant)) (x scale[pixel], the
+// conformal factor's power behind a boost along the grid's axis).  One wave per (time step, tile of 8 rings).
 template <int KM, int NTC>
 __global__ __launch_bounds__(64) void phi_synthesis_folded_kernel(const double* __restrict__ F, long long n_rows, int n_theta,
                                                                   int n_phi, int L, int jp, const double* __restrict__ off,
                                                                   const double* __restrict__ cst, long long ldc,
-                                                                  double* __restrict__ Y, long long ldy) {
+                                                                  const double* __restrict__ scale, double* __restrict__ Y,
+                                                                  long long ldy) {
   extern __shared__ double2 sm[];  // Ft[(2L+1)][8] tile of F, then Gt[8][n_phi] tile of the grid row
   const int nm = 2 * L + 1;
   double2* Ft = sm;
@@ -223,7 +224,15 @@ __global__ __launch_bounds__(64) void phi_synthesis_folded_kernel(const double* 
     // ---- the tile is rings x n_phi contiguous complex numbers of the grid row
     double* y = Y + t * ldy + 2LL * (8 * rt) * n_phi;
     const int n_el = rings * n_phi;
-    for (int e = lane; e < n_el; e += 64) *reinterpret_cast<double2*>(y + 2LL * e) = Gt[e];
+    if (scale) {
+      const double* sc = scale + 2LL * (8 * rt) * n_phi;  // (stored twice per pixel: engine.hip's col_scale)
+      for (int e = lane; e < n_el; e += 64) {
+        const double2 g = Gt[e];
+        const double w = sc[2 * e];
+        *reinterpret_cast<double2*>(y + 2LL * e) = double2{g.x * w, g.y * w};
+      }
+    } else
+      for (int e = lane; e < n_el; e += 64) *reinterpret_cast<double2*>(y + 2LL * e) = Gt[e];
   }
 #undef PS_LOAD
 }
@@ -409,10 +418,11 @@ int large_synthesis_supported(int n_theta, int n_phi, int ell_min, int ell_max) 
 }
 
 // A: [n_rows][lda] modes (complex; with `off` one more complex number per row at column n_modes: it multiplies `off`);
-// Tsyn[n_modes][n_theta]; F: n_rows x (2 ell_max + 1) x large_analysis_jp(n_theta) complex of work space; Y[n_rows][ldy].
+// Tsyn[n_modes][n_theta]; F: n_rows x (2 ell_max + 1) x large_analysis_jp(n_theta) complex of work space; Y[n_rows][ldy];
+// scale: NULL or 2 doubles per pixel (the first is used) multiplying the result.
 hipError_t launch_synthesis_large(hipStream_t stream, const double* A, long long lda, long long n_rows, int n_theta, int n_phi,
                                   int ell_min, int ell_max, const double* Tsyn, const double* off, double* F, double* Y,
-                                  long long ldy) {
+                                  long long ldy, const double* scale) {
   if (n_rows <= 0) return hipSuccess;
   const int L = ell_max, nm = 2 * L + 1, jp = large_analysis_jp(n_theta);
   const int n_modes = (L + 1) * (L + 1) - ell_min * ell_min;
@@ -447,7 +457,7 @@ hipError_t launch_synthesis_large(hipStream_t stream, const double* A, long long
   const unsigned grid2 = (unsigned)(items < 256 * 8 ? items : 256 * 8);
 #define PS_GO(KM, NTC)                                                                                                          \
   hipLaunchKernelGGL((phi_synthesis_folded_kernel<KM, NTC>), dim3(grid2), dim3(64), lds, stream, F, n_rows, n_theta, n_phi, L, jp, off, \
-                     A + 2LL * n_modes, lda, Y, ldy)
+                     A + 2LL * n_modes, lda, scale, Y, ldy)
 #define PS_KM(NTC)  \
   if (km <= 5)      \
     PS_GO(5, NTC);  \
