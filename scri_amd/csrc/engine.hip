@@ -1253,7 +1253,7 @@ static bool separable_rotor_grid(const bms_transformation* tr, std::vector<doubl
 // and P.large = false when the shape is one neither kernel takes.
 static int run_synthesis(bms_ctx* c, const SynthesisPlan& P, const double* A, long long lda, long long rows, const double* off, double* Y,
                          long long ldy, const double* scale = nullptr);
-// thetas != nullptr: the rings' colatitudes (a boost along the grid's polar axis): tables of their own, not kept, two-kernel form only
+// thetas != nullptr: the rings' colatitudes (a boost along the grid's polar axis): tables of their own, not kept
 static int build_synthesis(bms_ctx* c, int n_theta, int n_phi, int spin, int ell_min, int ell_max, SynthesisPlan& P,
                            const std::vector<double>* thetas = nullptr) {
   const std::array<int, 5> key = {n_theta, n_phi, spin, ell_min, ell_max};
@@ -1270,7 +1270,9 @@ static int build_synthesis(bms_ctx* c, int n_theta, int n_phi, int spin, int ell
   }
   std::vector<int> meta;
   int len = 0;
-  if (thetas || !synthesis_split_plan(n_theta, n_phi, ell_min, ell_max, P.g, meta, P.lds, P.nt, len)) P.nt = 0;
+  if (!synthesis_split_plan(n_theta, n_phi, ell_min, ell_max, P.g, meta, P.lds, P.nt, len)) P.nt = 0;
+  // (behind an axis boost the one-kernel form also keeps the per-pixel scale in LDS)
+  if (thetas && P.nt && P.lds + synthesis_split_scale_bytes(n_theta, n_phi) > 160 * 1024) P.nt = 0;
   P.large = large_synthesis_supported(n_theta, n_phi, ell_min, ell_max) != 0;
   P.n_theta = n_theta, P.n_phi = n_phi, P.ell_min = ell_min, P.ell_max = ell_max;
   if (!P.nt && !P.large) return BMS_OK;
@@ -1312,8 +1314,8 @@ static int run_synthesis(bms_ctx* c, const SynthesisPlan& P, const double* A, lo
                          long long ldy, const double* scale) {
   hipStream_t S = c->stream;
   if (rows <= 0) return BMS_OK;
-  if (P.nt && !scale && rows >= 2 && !getenv("SCRI_AMD_NO_SPLIT_SYNTHESIS")) {
-    TIMED(c, BMS_TAG_GEMM_SYNTHESIS, launch_synthesis_split(S, A, lda, rows, P.g, P.nt, P.d_T, P.d_meta, off, Y, ldy, P.lds, c->n_cu));
+  if (P.nt && rows >= 2 && !getenv("SCRI_AMD_NO_SPLIT_SYNTHESIS")) {
+    TIMED(c, BMS_TAG_GEMM_SYNTHESIS, launch_synthesis_split(S, A, lda, rows, P.g, P.nt, P.d_T, P.d_meta, off, Y, ldy, P.lds, c->n_cu, scale));
   } else if (P.large) {
     double* d_F;
     int rc = dev_buf_t(c, "Fphi", (size_t)rows * (2 * P.ell_max + 1) * large_analysis_jp(P.n_theta) * 2, &d_F);
@@ -1801,7 +1803,7 @@ static int transform_modes_impl(bms_ctx* c, const bms_wm_input* in, const bms_tr
     } else if (axis_boost_pays(n_modes, tr->n_theta, tr->n_phi) && large_synthesis_supported(tr->n_theta, tr->n_phi, in->ell_min, in->ell_max) &&
                separable_rotor_grid(tr, ring_theta)) {
       if ((rc = build_synthesis(c, tr->n_theta, tr->n_phi, s, in->ell_min, in->ell_max, syn, &ring_theta))) return rc;
-      axis_boost = syn.large;
+      axis_boost = syn.large || syn.nt != 0;
     }
   }
   const bool sep = no_boost ? (syn.nt != 0 || syn.large) : axis_boost;

@@ -109,10 +109,12 @@ struct SynGeom {
 int synthesis_split_plan(int n_theta, int n_phi, int ell_min, int ell_max, SynGeom& g, std::vector<int>& meta, size_t& lds_bytes,
                          int& nt, int& len);
 // A: [n_rows][lda] modes (complex, n_modes + 1 per row: the last one multiplies `off`), Tsyn[n_modes][n_theta] = sLambda_lm(theta_j),
-// off: complex per grid pixel or null; Y[n_rows][ldy] = grid rows in grid order
+// off: complex per grid pixel or null; Y[n_rows][ldy] = grid rows in grid order; scale: null or 2 (equal) doubles per pixel
+// multiplying the result -- it takes synthesis_split_scale_bytes more LDS than the plan's lds_bytes
+size_t synthesis_split_scale_bytes(int n_theta, int n_phi);
 hipError_t launch_synthesis_split(hipStream_t stream, const double* A, long long lda, long long n_rows, const SynGeom& g, int nt,
                                   const double* Tsyn, const int* meta, const double* off, double* Y, long long ldy, size_t lds_bytes,
-                                  int n_cu);
+                                  int n_cu, const double* scale = nullptr);
 
 // two-kernel form for the grids the one-kernel form does not take (kernels_synthesis_large.hip): n_theta <= 104, n_phi <= 127,
 // l_max <= 33, any l_min; F = n_rows x (2 l_max + 1) x large_analysis_jp(n_theta) complex of work space.  With `off` the row has

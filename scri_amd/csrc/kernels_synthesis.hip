@@ -35,11 +35,14 @@ constexpr int SYN_MAX_WAVES = 10;
 constexpr int SYN_XCOLS = 3;  // ring columns beyond k = 16: the side product has four, one of them is k = 0 (n_phi <= 39)
 constexpr int SYN_META_FLUSH = 1 << 16, SYN_META_VALID = 1 << 17;
 
-template <int NT, int LEN>
+// SCALED: every result is multiplied by scale[pixel] (2 doubles per pixel, equal: the conformal factor's power behind a boost along
+// the grid's axis, engine.hip::separable_rotor_grid), kept in LDS next to the offsets
+template <int NT, int LEN, bool SCALED>
 __global__ __launch_bounds__(640, 1) void synthesis_split_kernel(const double* __restrict__ A, long long lda, long long n_rows,
                                                                  SynGeom g, const double* __restrict__ Tsyn,
                                                                  const int* __restrict__ meta, const double* __restrict__ off,
-                                                                 double* __restrict__ Y, long long ldy) {
+                                                                 const double* __restrict__ scale, double* __restrict__ Y,
+                                                                 long long ldy) {
   // pitch (complex) of an F_m row, a multiple of 16: the phi waves' ds_read_b128 of (ring fi, m fk) then hit 16 distinct 16-byte
   // slots in each of the instruction's four lane groups {0-3, 12-15, 20-27}, ... (with the odd pitch NT + 1 every group was 2-way);
   // the last slot of the m = 0 row carries the row's constant
@@ -50,7 +53,8 @@ __global__ __launch_bounds__(640, 1) void synthesis_split_kernel(const double* _
   double2* Fs = reinterpret_cast<double2*>(lds);  // [2 buffers][2 rows][2L+1][PJ]
   double2* abuf = Fs + 4 * fsz;                   // [2 buffers][2 rows][n_modes + 1]
   double2* offl = abuf + 4 * na;                  // [n_pix]
-  int* metal = reinterpret_cast<int*>(offl + g.n_theta * g.n_phi);  // [n_lists][LEN]: byte offset of a_lm | m slot << 16 | flush << 24
+  double* scl = reinterpret_cast<double*>(offl + g.n_theta * g.n_phi);  // [n_pix] (SCALED)
+  int* metal = reinterpret_cast<int*>(scl + (SCALED ? g.n_theta * g.n_phi : 0));  // [n_lists][LEN]: byte offset of a_lm | m slot << 16 | flush << 24
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
   const int n_waves = g.nth + g.nph;
@@ -67,6 +71,8 @@ __global__ __launch_bounds__(640, 1) void synthesis_split_kernel(const double* _
   // (no zeroing of F: every slot that is read is written in every trip)
   for (int e = tid; e < g.n_theta * g.n_phi; e += blockDim.x)
     offl[e] = off ? *reinterpret_cast<const double2*>(off + 2LL * e) : double2{0.0, 0.0};
+  if (SCALED)
+    for (int e = tid; e < g.n_theta * g.n_phi; e += blockDim.x) scl[e] = scale[2LL * e];
   for (int e = tid; e < g.n_lists * LEN; e += blockDim.x) {
     const int mt = meta[e];
     metal[e] = ((mt & 1023) * 16) | (((mt >> 10) & 63) << 16) | ((mt & SYN_META_FLUSH) ? 1 << 24 : 0);
@@ -252,12 +258,14 @@ __global__ __launch_bounds__(640, 1) void synthesis_split_kernel(const double* _
         const double ux = f0.x + xur, uy = f0.y + xui;
         {
           const double2 o = has_off ? offl[pix0 + kx] : double2{0.0, 0.0};
-          *reinterpret_cast<double2*>(yr + 2LL * (pix0 + kx)) = double2{ux + xvr - o.x * c, uy + xvi - o.y * c};
+          const double w = SCALED ? scl[pix0 + kx] : 1.0;
+          *reinterpret_cast<double2*>(yr + 2LL * (pix0 + kx)) = double2{(ux + xvr - o.x * c) * w, (uy + xvi - o.y * c) * w};
         }
         if (kx >= 1 && 2 * kx != g.n_phi) {
           const int k2 = g.n_phi - kx;
           const double2 o = has_off ? offl[pix0 + k2] : double2{0.0, 0.0};
-          *reinterpret_cast<double2*>(yr + 2LL * (pix0 + k2)) = double2{ux - xvr - o.x * c, uy - xvi - o.y * c};
+          const double w = SCALED ? scl[pix0 + k2] : 1.0;
+          *reinterpret_cast<double2*>(yr + 2LL * (pix0 + k2)) = double2{(ux - xvr - o.x * c) * w, (uy - xvi - o.y * c) * w};
         }
       }
       const int k = fi + 1;
@@ -272,18 +280,22 @@ __global__ __launch_bounds__(640, 1) void synthesis_split_kernel(const double* _
           const double ux = f0.x + ure[v], uy = f0.y + uim[v];
           {
             const double2 o = has_off ? offl[pix0 + k] : double2{0.0, 0.0};
-            *reinterpret_cast<double2*>(yr + 2LL * (pix0 + k)) = double2{ux + vre[v] - o.x * c, uy + vim[v] - o.y * c};
+            const double w = SCALED ? scl[pix0 + k] : 1.0;
+            *reinterpret_cast<double2*>(yr + 2LL * (pix0 + k)) = double2{(ux + vre[v] - o.x * c) * w, (uy + vim[v] - o.y * c) * w};
           }
           if (2 * k != g.n_phi) {
             const int k2 = g.n_phi - k;
             const double2 o = has_off ? offl[pix0 + k2] : double2{0.0, 0.0};
-            *reinterpret_cast<double2*>(yr + 2LL * (pix0 + k2)) = double2{ux - vre[v] - o.x * c, uy - vim[v] - o.y * c};
+            const double w = SCALED ? scl[pix0 + k2] : 1.0;
+            *reinterpret_cast<double2*>(yr + 2LL * (pix0 + k2)) = double2{(ux - vre[v] - o.x * c) * w, (uy - vim[v] - o.y * c) * w};
           }
         }
       }
     }
   }
 }
+
+size_t synthesis_split_scale_bytes(int n_theta, int n_phi) { return sizeof(double) * (((size_t)n_theta * n_phi + 1) & ~(size_t)1); }
 
 // The m values of the input modes dealt into lists of nearly equal total length (longest first into the shortest list);
 // meta[list][e] = mode index | m slot << 10 | flush << 16 | valid << 17.
@@ -336,21 +348,29 @@ int synthesis_split_plan(int n_theta, int n_phi, int ell_min, int ell_max, SynGe
 
 hipError_t launch_synthesis_split(hipStream_t stream, const double* A, long long lda, long long n_rows, const SynGeom& g, int nt,
                                   const double* Tsyn, const int* meta, const double* off, double* Y, long long ldy, size_t lds_bytes,
-                                  int n_cu) {
+                                  int n_cu, const double* scale) {
   if (n_rows < 2) return hipErrorInvalidValue;
+  if (scale) lds_bytes += synthesis_split_scale_bytes(g.n_theta, g.n_phi);
+  if (lds_bytes > 160 * 1024) return hipErrorInvalidValue;
   const long long n_pairs = (n_rows + 1) / 2;
   // one workgroup per CU at l_max = 16 (10 waves, 124 KB of LDS); small shapes need fewer waves and less LDS and get two or three
   long long per_cu = std::min<long long>(3, std::min<long long>(SYN_MAX_WAVES / (g.nth + g.nph), (160 * 1024) / (long long)lds_bytes));
   if (per_cu < 1) per_cu = 1;
   const long long max_blocks = per_cu * n_cu;
   const dim3 grid((unsigned)(n_pairs < max_blocks ? n_pairs : max_blocks)), block(64 * (g.nth + g.nph));
-#define SYN_GO(NT, LEN)                                                                                                          \
-  {                                                                                                                              \
-    hipError_t e = hipFuncSetAttribute((const void*)synthesis_split_kernel<NT, LEN>, hipFuncAttributeMaxDynamicSharedMemorySize, \
-                                       (int)lds_bytes);                                                                          \
-    if (e != hipSuccess) return e;                                                                                               \
-    hipLaunchKernelGGL((synthesis_split_kernel<NT, LEN>), grid, block, lds_bytes, stream, A, lda, n_rows, g, Tsyn, meta, off, Y, ldy); \
-    return hipGetLastError();                                                                                                    \
+#define SYN_GO_S(NT, LEN, SC)                                                                                                       \
+  {                                                                                                                                  \
+    hipError_t e = hipFuncSetAttribute((const void*)synthesis_split_kernel<NT, LEN, SC>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                       (int)lds_bytes);                                                                              \
+    if (e != hipSuccess) return e;                                                                                                   \
+    hipLaunchKernelGGL((synthesis_split_kernel<NT, LEN, SC>), grid, block, lds_bytes, stream, A, lda, n_rows, g, Tsyn, meta, off, scale, \
+                       Y, ldy);                                                                                                      \
+    return hipGetLastError();                                                                                                        \
+  }
+#define SYN_GO(NT, LEN)            \
+  {                                \
+    if (scale) SYN_GO_S(NT, LEN, true) \
+    SYN_GO_S(NT, LEN, false)       \
   }
 #define SYN_LEN(NT)                  \
   {                                  \
@@ -363,6 +383,7 @@ hipError_t launch_synthesis_split(hipStream_t stream, const double* A, long long
   SYN_LEN(40)
 #undef SYN_LEN
 #undef SYN_GO
+#undef SYN_GO_S
 }
 
 }  // namespace bms
