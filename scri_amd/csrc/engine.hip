@@ -90,6 +90,8 @@ struct bms_ctx {
   // analysis tables depend on the grid, the spin and the l range only: kept per tag until a call asks for other ones
   std::map<std::string, std::pair<std::array<int, 6>, AnalysisPlan>> plans;
   std::map<std::array<int, 5>, SynthesisPlan> syn_plans;  // by (n_theta, n_phi, spin, ell_min, ell_max)
+  // the same behind a boost along the grid's axis: the tables belong to the ring colatitudes of the last such transformation
+  std::map<std::array<int, 5>, std::pair<std::vector<double>, SynthesisPlan>> syn_plans_axis;
   // optional per-kernel timing with HIP events on the context's stream (bms_ctx_enable_timing)
   bool timing = false;
   struct Timed {
@@ -1253,7 +1255,8 @@ static bool separable_rotor_grid(const bms_transformation* tr, std::vector<doubl
 // and P.large = false when the shape is one neither kernel takes.
 static int run_synthesis(bms_ctx* c, const SynthesisPlan& P, const double* A, long long lda, long long rows, const double* off, double* Y,
                          long long ldy, const double* scale = nullptr);
-// thetas != nullptr: the rings' colatitudes (a boost along the grid's polar axis): tables of their own, not kept
+// thetas != nullptr: the rings' colatitudes (a boost along the grid's polar axis): tables of their own, kept until a transformation
+// with other colatitudes asks for the same shape
 static int build_synthesis(bms_ctx* c, int n_theta, int n_phi, int spin, int ell_min, int ell_max, SynthesisPlan& P,
                            const std::vector<double>* thetas = nullptr) {
   const std::array<int, 5> key = {n_theta, n_phi, spin, ell_min, ell_max};
@@ -1261,6 +1264,13 @@ static int build_synthesis(bms_ctx* c, int n_theta, int n_phi, int spin, int ell
   if (!thetas && it != c->syn_plans.end()) {
     P = it->second;
     return BMS_OK;
+  }
+  if (thetas) {
+    auto ia = c->syn_plans_axis.find(key);
+    if (ia != c->syn_plans_axis.end() && ia->second.first == *thetas) {
+      P = ia->second.second;
+      return BMS_OK;
+    }
   }
   P = SynthesisPlan();
   if (!c->n_cu) {
@@ -1301,11 +1311,17 @@ static int build_synthesis(bms_ctx* c, int n_theta, int n_phi, int spin, int ell
   if ((rc = dev_buf_t(c, "syn_Y", (size_t)n_theta * n_modes * 2, &d_Y))) return rc;
   HIP_TRY(c, hipMemsetAsync(d_Y, 0, 16 * (size_t)n_theta * n_modes, S));
   TIMED(c, BMS_TAG_SETUP, launch_swsh_values(S, d_rot, n_theta, spin, ell_min, ell_max, d_Y));
-  snprintf(nm_, sizeof nm_, thetas ? "syn_Tb_%d_%d_%d_%d" : "syn_T_%d_%d_%d_%d", n_theta, spin, ell_min, ell_max);
+  if (thetas)  // (one buffer per cache entry: the key's n_phi is part of the name)
+    snprintf(nm_, sizeof nm_, "syn_Tb_%d_%d_%d_%d_%d", n_theta, n_phi, spin, ell_min, ell_max);
+  else
+    snprintf(nm_, sizeof nm_, "syn_T_%d_%d_%d_%d", n_theta, spin, ell_min, ell_max);
   if ((rc = dev_buf_t(c, nm_, (size_t)n_theta * n_modes, &P.d_T))) return rc;
   TIMED(c, BMS_TAG_SETUP, launch_theta_table(S, d_Y, d_one, n_theta, n_modes, P.d_T));  // weights 1: the plain sLambda values
   HIP_TRY(c, hipStreamSynchronize(S));  // host vectors above go out of scope
-  if (!thetas) c->syn_plans[key] = P;
+  if (!thetas)
+    c->syn_plans[key] = P;
+  else
+    c->syn_plans_axis[key] = std::make_pair(*thetas, P);
   return BMS_OK;
 }
 

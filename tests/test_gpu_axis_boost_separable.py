@@ -285,3 +285,30 @@ def test_random_axis_boost_abd_transform_against_the_oracle(ctx, monkeypatch, se
     monkeypatch.delenv("SCRI_AMD_NO_AXIS_BOOST_SEPARABLE", raising=False)
     monkeypatch.setattr(fuzz, "_random_kwargs", _axis_kwargs)
     fuzz.test_random_abd_transform(ctx, seed)
+
+
+def test_ring_tables_follow_the_transformation(ctx, monkeypatch):
+    """The ring tables are kept per shape together with the colatitudes they were built for: a second boost of another size (or
+    sign) on the same shape must rebuild them, a repeat of the first must find them again."""
+    import scri_amd
+    from scri_amd import synthetic
+
+    monkeypatch.setenv("SCRI_AMD_AXIS_BOOST_MIN_WORK", "0")
+    monkeypatch.delenv("SCRI_AMD_NO_SEPARABLE_SYNTHESIS", raising=False)
+    t = np.linspace(-30.0, 40.0, 120)
+    data = synthetic.chirp_modes(t, 2, 10, 21)
+
+    def run(v):
+        w = scri_amd.WaveformModes(t=t, data=data, ell_min=2, ell_max=10, dataType=scri_amd.h, frameType=scri_amd.Inertial,
+                                   r_is_scaled_out=True, m_is_scaled_out=True, ctx=ctx)
+        return w.transform(boost_velocity=[0.0, 0.0, v], frame_rotation=_zrot(0.2))
+
+    ref = {}
+    monkeypatch.setenv("SCRI_AMD_NO_AXIS_BOOST_SEPARABLE", "1")
+    for v in (0.3, -0.45, 0.05):
+        ref[v] = run(v)
+    monkeypatch.delenv("SCRI_AMD_NO_AXIS_BOOST_SEPARABLE")
+    for v in (0.3, -0.45, 0.3, 0.05, 0.05, -0.45):
+        got = run(v)
+        assert got.n_times == ref[v].n_times > 0
+        assert np.abs(got.data - ref[v].data).max() < 2e-13 * max(1.0, np.abs(ref[v].data).max()), v
