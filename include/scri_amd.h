@@ -227,6 +227,12 @@ int bms_transform_abd_shard(bms_ctx* ctx, const double* u, const void* raw, int 
 /* boosted_grid / R_j_k (transformations.py:100-148, waveform_grid.py:130-174): host f8[n_theta][n_phi][4] */
 int bms_rotor_grid(bms_ctx* ctx, const double frame_rotation[4], const double boost_velocity[3], int n_theta,
                    int n_phi, double* rotors_host);
+/* Does that rotor grid keep its rings?  Returns 1 and the ring colatitudes Theta_j (thetas_out[n_theta]) when every rotor is
+ * frame_rotation * R(Theta_j, phi'_k) -- no boost (Theta_j = theta'_j), or a boost along the polar axis of the rotated grid, whose
+ * aberration (waveform_grid.py:141-161) only moves whole rings -- and 0 otherwise; < 0 on bad arguments.  Host only (no context):
+ * the test the transformations use to pick the separable synthesis, made on the rotors themselves. */
+int bms_ring_colatitudes(const double frame_rotation[4], const double boost_velocity[3], int n_theta, int n_phi,
+                         double* thetas_out);
 /* conformal_factors (transformations.py:151-196) on the given rotors (host f8[n][4]): k = 1 / (gamma (1 - v.r)) with r the
  * direction the rotor takes z to, eth k / k (spin weight 1, c16[n]), 1/k and 1/k^3.  Host evaluation with the code the
  * transformations run per direction on the GPU (pixel_math.h); ctx may be NULL. */

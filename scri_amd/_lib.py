@@ -121,6 +121,7 @@ SIGNATURES = {
          ctypes.POINTER(c_i64), ctypes.POINTER(c_i64)],
     ),
     "bms_rotor_grid": (c_int, [c_vp, c_dp, c_dp, c_int, c_int, c_dp]),
+    "bms_ring_colatitudes": (c_int, [c_dp, c_dp, c_int, c_int, c_dp]),
     "bms_conformal_factors": (c_int, [c_vp, c_dp, c_dp, c_i64, c_dp, c_vp, c_dp, c_dp]),
     "bms_swsh_grid": (c_int, [c_vp, c_dp, c_i64, c_int, c_int, c_int, c_vp]),
     "bms_map2salm": (c_int, [c_vp, c_vp, c_int, c_i64, c_int, c_int, c_int, c_int, c_int, c_vp]),

@@ -2089,6 +2089,19 @@ static int transform_modes_impl(bms_ctx* c, const bms_wm_input* in, const bms_tr
 
 // ====================================================================================================== building blocks
 
+extern "C" int bms_ring_colatitudes(const double fr[4], const double v[3], int n_theta, int n_phi, double* thetas_out) {
+  if (!fr || !v || !thetas_out) return fail(nullptr, BMS_ERR_INVALID, "NULL argument");
+  if (n_theta < 2 || n_phi < 1) return fail(nullptr, BMS_ERR_INVALID, "bad grid size");
+  bms_transformation tr{};
+  for (int i = 0; i < 4; ++i) tr.frame_rotation[i] = fr[i];
+  for (int i = 0; i < 3; ++i) tr.boost_velocity[i] = v[i];
+  tr.n_theta = n_theta, tr.n_phi = n_phi;
+  std::vector<double> thetas;
+  if (!separable_rotor_grid(&tr, thetas)) return 0;
+  std::memcpy(thetas_out, thetas.data(), sizeof(double) * n_theta);
+  return 1;
+}
+
 extern "C" int bms_rotor_grid(bms_ctx* c, const double fr[4], const double v[3], int n_theta, int n_phi, double* out) {
   // ctx == NULL: pure host evaluation; otherwise the GPU kernel the transforms use (same pixel_math.h code)
   if (!fr || !v || !out) return fail(c, BMS_ERR_INVALID, "NULL argument");

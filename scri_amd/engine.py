@@ -427,6 +427,18 @@ def rotor_grid(frame_rotation, boost_velocity, n_theta, n_phi, ctx=None, device=
     return out
 
 
+def ring_colatitudes(frame_rotation, boost_velocity, n_theta, n_phi):
+    """The colatitudes Theta_j of the rotor grid's rings if it is frame_rotation * R(Theta_j, phi'_k) -- no boost, or one along the
+    polar axis of the rotated grid -- else None.  Host only: the test that sends a transformation to the separable synthesis."""
+    fr = np.ascontiguousarray(frame_rotation, dtype=float)
+    v = np.ascontiguousarray(boost_velocity, dtype=float)
+    out = np.empty(n_theta)
+    rc = _lib.load().bms_ring_colatitudes(dptr(fr), dptr(v), n_theta, n_phi, dptr(out))
+    if rc < 0:
+        _lib._raise(rc, None, "bms_ring_colatitudes")
+    return out if rc == 1 else None
+
+
 def conformal_factors(boost_velocity, rotors):
     """bms_conformal_factors: (k, eth k / k, 1/k, 1/k^3) on rotors [..., 4], each shaped like rotors[..., 0]."""
     v = np.ascontiguousarray(boost_velocity, dtype=float)

@@ -178,3 +178,47 @@ def test_register_if_reused_counts_objects_not_addresses(monkeypatch):
     del c
     gc.collect()
     assert calls[-1] == ("unreg", addr) and not _lib._registered
+
+
+def _zrot(a):
+    return np.array([np.cos(a / 2), 0.0, 0.0, np.sin(a / 2)])
+
+
+@pytest.mark.parametrize("fr,v,keeps", [
+    ([1.0, 0, 0, 0], [0, 0, 0], True),
+    ([0.5, -0.5, 0.5, 0.5], [0, 0, 0], True),
+    ([1.0, 0, 0, 0], [0, 0, 0.3], True),
+    ([1.0, 0, 0, 0], [0, 0, -0.45], True),
+    (_zrot(0.7), [0, 0, 0.2], True),
+    ([0.0, 1.0, 0, 0], [0, 0, -0.25], True),      # pi about x: the grid's axis is -z
+    ([1.0, 0, 0, 0], [1e-9, 0, 0.3], False),      # a hair off the axis
+    ([0.5, -0.5, 0.5, 0.5], [0, 0, 0.1], False),  # frame axis = x
+    ([1.0, 0, 0, 0], [0.1, 0, 0], False),
+])
+def test_ring_colatitudes_against_the_oracle_rotor_grid(fr, v, keeps):
+    """bms_ring_colatitudes (host): the rotor grid of scri/waveform_grid.py:130-174 keeps its rings without a boost and with one along
+    the polar axis of the rotated grid; the colatitudes it returns rebuild the oracle's rotors as frame_rotation * R(Theta_j, phi_k)."""
+    from oracle import quat
+    from scri_amd import engine
+
+    n_theta, n_phi = 11, 9
+    fr = np.asarray(fr, dtype=float)
+    th = engine.ring_colatitudes(fr, v, n_theta, n_phi)
+    assert (th is not None) == keeps
+    if not keeps:
+        return
+    R = grid_ref.rotor_grid(fr, np.asarray(v, dtype=float), n_theta, n_phi)
+    for j in range(n_theta):
+        for k in range(n_phi):
+            E = quat.qmul(fr, quat.from_spherical_coords(th[j], 2 * np.pi * k / n_phi))
+            G = np.asarray(R[j, k], dtype=float)
+            assert min(np.abs(G - E).max(), np.abs(G + E).max()) < 1e-14, (j, k)
+    # aberration formula: tan(Theta / 2) = exp(-+rapidity) tan(theta' / 2) along +-z'
+    beta = float(np.linalg.norm(v))
+    if beta:
+        sign = np.sign(np.dot(quat.rotate_z(fr), v))
+        thp = np.linspace(0.0, np.pi, n_theta)
+        expect = 2 * np.arctan(np.exp(-sign * np.arctanh(beta)) * np.tan(thp[1:-1] / 2))
+        assert np.abs(th[1:-1] - expect).max() < 1e-14
+    with pytest.raises(ValueError):
+        engine.ring_colatitudes(fr, v, 1, n_phi)
