@@ -86,8 +86,11 @@ __global__ __launch_bounds__(640, 1) void synthesis_split_kernel(const double* _
     long long t = 2 * pp;
     return t > n_rows - 2 ? n_rows - 2 : t;
   };
+  // (without `off` a row carries no constant column: nothing is read there -- the element after the last row's modes may lie past
+  // the caller's buffer -- and the constant counts as zero)
   for (int e = tid; e < 2 * na; e += blockDim.x)
-    abuf[e] = *reinterpret_cast<const double2*>(A + (first_row(p0) + e / na) * lda + 2LL * (e % na));
+    abuf[e] = (off || e % na != g.n_modes) ? *reinterpret_cast<const double2*>(A + (first_row(p0) + e / na) * lda + 2LL * (e % na))
+                                           : double2{0.0, 0.0};
   __syncthreads();
 
   if (phi < 0) {
@@ -113,7 +116,7 @@ __global__ __launch_bounds__(640, 1) void synthesis_split_kernel(const double* _
     const int2* ml = reinterpret_cast<const int2*>(metal) + li * (LEN / 2);
     // this thread's share of a pair's mode rows: elements tt and tt + 64 nth of the 2 (n_modes + 1)
     const int e1 = tt, e2 = tt + 64 * g.nth;
-    const bool h1 = e1 < 2 * na, h2 = e2 < 2 * na;
+    const bool h1 = e1 < 2 * na && (off || e1 % na != g.n_modes), h2 = e2 < 2 * na && (off || e2 % na != g.n_modes);
     const long long o1 = h1 ? (long long)(e1 / na) * lda + 2LL * (e1 % na) : 0, o2 = h2 ? (long long)(e2 / na) * lda + 2LL * (e2 % na) : 0;
     auto request = [&](long long pp, double2& x1, double2& x2) {
       const double* row = A + first_row(pp) * lda;
@@ -175,7 +178,7 @@ __global__ __launch_bounds__(640, 1) void synthesis_split_kernel(const double* _
       }
       const double2* a0c = reinterpret_cast<const double2*>(a0);
       const double2* a1c = reinterpret_cast<const double2*>(a1);
-      if (tt < 2) Fb[tt * fsz + g.L * PJ + PJ - 1] = (tt ? a1c : a0c)[g.n_modes];  // the row's eliminated-constant value
+      if (tt < 2) Fb[tt * fsz + g.L * PJ + PJ - 1] = off ? (tt ? a1c : a0c)[g.n_modes] : double2{0.0, 0.0};  // the row's eliminated-constant value
       double2* an = abuf + (buf ^ 1) * 2 * na;
       if (h1) an[e1] = x1;
       if (h2) an[e2] = x2;

@@ -434,3 +434,42 @@ def test_reused_host_input_is_page_locked_and_released(ctx):
     del data
     gc.collect()
     assert key not in _lib._registered
+
+
+@pytest.mark.parametrize("n", [6, 40])
+def test_separable_synthesis_reads_nothing_past_the_modes(ctx, monkeypatch, n):
+    """Boost-free psi-type / slope-form transformations hand the one-kernel synthesis rows WITHOUT the constant column the h / sigma
+    route appends: the kernel must not touch the element behind a row's modes (behind the last row: memory past the caller's
+    buffer).  A device-resident series whose buffer is followed by NaNs shows it."""
+    import torch
+    from scri_amd import engine, synthetic
+
+    monkeypatch.delenv("SCRI_AMD_NO_SEPARABLE_SYNTHESIS", raising=False)
+    monkeypatch.setenv("SCRI_AMD_NO_BSPLINE", "1")  # slope form: the synthesis reads the caller's rows directly
+    ell_max = 8
+    t = np.linspace(-3.0, 4.0, n)
+    data = synthetic.chirp_modes(t, 2, ell_max, 17)
+    nm = data.shape[1]
+    st = synthetic.real_supertranslation(0.05 * (np.arange(9) + 1j * np.arange(9)[::-1]))
+    n_theta = 2 * ell_max + 1
+    tr = engine.make_transformation(st, [1.0, 0, 0, 0], [0.0, 0, 0], n_theta, n_theta, ell_max)
+    dev = torch.device("cuda", 0)
+    buf = torch.full((n * nm + 64,), float("nan"), dtype=torch.complex128, device=dev)
+    buf[: n * nm] = torch.from_numpy(data.reshape(-1)).to(dev)
+    out = torch.zeros((n, nm), dtype=torch.complex128, device=dev)
+    torch.cuda.synchronize()
+
+    def run():
+        out.zero_()
+        torch.cuda.synchronize()
+        n_new = engine.transform_modes(t, buf.data_ptr(), 2, ell_max, -2, -1, engine.BMS_TERM_H, tr, ctx=ctx, device=True, ld=nm,
+                                       out_ptr=out.data_ptr(), shard=(0, n, 0, n))[1]
+        ctx.synchronize()
+        return out[:n_new].cpu().numpy()
+
+    got = run()
+    assert got.shape[0] > 0 and np.isfinite(got).all()
+    monkeypatch.setenv("SCRI_AMD_NO_SEPARABLE_SYNTHESIS", "1")  # the dense product reads exactly n_modes columns
+    ref = run()
+    assert got.shape == ref.shape and not np.array_equal(got, ref)
+    assert np.abs(got - ref).max() < 1e-13 * max(1.0, np.abs(ref).max())
