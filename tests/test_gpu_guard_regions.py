@@ -237,3 +237,54 @@ def test_psi_type_with_device_companions_and_a_shard_between_guards(ctx, monkeyp
         assert np.abs(t_ref[i_first : i_first + n_new] - t_out).max() < 1e-12
         assert np.abs(got - d_ref[i_first : i_first + n_new]).max() < 1e-13 * max(1.0, np.abs(d_ref).max())
         _check_guards(dst, (o1 - o0) * n3)
+
+
+def test_abd_shard_and_column_parts_between_guards(ctx, monkeypatch):
+    """An AsymptoticBondiData time shard from the middle of the series (its buffer holds only the planned rows of every field) and
+    the WaveformModes grid-column parts (every part reads the whole series, writes its contribution to all output rows)."""
+    from scri_amd import engine, synthetic
+    from tests.test_gpu_transform_abd import smooth_abd
+
+    for k in ("SCRI_AMD_NO_SEPARABLE_SYNTHESIS", "SCRI_AMD_NO_BSPLINE"):
+        monkeypatch.delenv(k, raising=False)
+    n, ell_max = 1200, 4
+    o = smooth_abd(n, ell_max, 9, t0=0.0, t1=240.0)
+    nm = (ell_max + 1) ** 2
+    n_theta = 2 * (2 * ell_max) + 1
+    for boost in ([1e-3, -2e-3, 2e-3], [0.0, 0.0, 0.0]):
+        tr = engine.make_transformation(np.array([0.05, 0, 0.01, 0], dtype=complex), [0.8, 0.2, -0.5, 0.1], boost, n_theta, n_theta, ell_max)
+        raw = np.ascontiguousarray(o.raw)
+        u_ref, d_ref = engine.transform_abd(o.u, raw, ell_max, tr, ctx=ctx)
+        o0, o1 = 500, 760
+        (r0, r1), _ = engine.shard_plan(o.u, tr, o0, o1)
+        src, sp = _guarded_input(raw[:, r0:r1])
+        dst, dp = _guarded_output(6 * (o1 - o0) * nm)
+        u_out, n_new, first = engine.transform_abd(o.u, sp, ell_max, tr, ctx=ctx, shard=(r0, r1 - r0, o0, o1), device=True, out_ptr=dp)
+        ctx.synchronize()
+        got = dst[GUARD : GUARD + 6 * (o1 - o0) * nm].cpu().numpy().reshape(6, o1 - o0, nm)
+        i_first = int(np.searchsorted(u_ref, u_out[0] - 1e-9))
+        assert n_new > 0 and np.isfinite(got[:, :n_new]).all()
+        assert np.abs(got[:, :n_new] - d_ref[:, i_first : i_first + n_new]).max() < 1e-13 * max(1.0, np.abs(d_ref).max())
+        assert np.all(got[:, n_new:] == SENTINEL)
+        _check_guards(dst, 6 * (o1 - o0) * nm)
+
+    n, ell_max = 900, 8
+    t = np.linspace(0.0, 90.0, n)
+    data = synthetic.chirp_modes(t, 2, ell_max, 6)
+    nmw = data.shape[1]
+    st = synthetic.real_supertranslation(0.1 * (np.arange(9) + 1.0 + 0j))
+    n_theta = 2 * (ell_max + 2) + 1
+    tr = engine.make_transformation(st, [0.9, 0.1, -0.3, 0.2], [0.02, -0.01, 0.03], n_theta, n_theta, ell_max)
+    t_ref, d_ref = engine.transform_modes(t, data, 2, ell_max, -2, -1, engine.BMS_TERM_H, tr, ctx=ctx)
+    total = 0
+    for part in range(3):
+        src, sp = _guarded_input(data)
+        dst, dp = _guarded_output(n * nmw)
+        t_out, n_new, first = engine.transform_modes(t, sp, 2, ell_max, -2, -1, engine.BMS_TERM_H, tr, ctx=ctx, device=True, ld=nmw, out_ptr=dp,
+                                                     shard=(0, n, 0, n, part, 3))
+        ctx.synchronize()
+        got = dst[GUARD : GUARD + n_new * nmw].cpu().numpy().reshape(n_new, nmw)
+        assert n_new == d_ref.shape[0] and np.isfinite(got).all()
+        _check_guards(dst, n * nmw)
+        total = total + got
+    assert np.abs(total - d_ref).max() < 1e-13 * max(1.0, np.abs(d_ref).max())
