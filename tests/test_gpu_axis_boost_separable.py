@@ -312,3 +312,29 @@ def test_ring_tables_follow_the_transformation(ctx, monkeypatch):
         got = run(v)
         assert got.n_times == ref[v].n_times > 0
         assert np.abs(got.data - ref[v].data).max() < 2e-13 * max(1.0, np.abs(ref[v].data).max()), v
+
+
+def test_axis_boost_abd_pipelined_host_path(ctx, monkeypatch):
+    """AsymptoticBondiData from host memory through the three-stream pipeline (bms_transform_abd_pipelined): every piece takes the
+    separable route with the ring tables of the one transformation."""
+    from scri_amd import engine
+
+    monkeypatch.setenv("SCRI_AMD_AXIS_BOOST_MIN_WORK", "0")
+    monkeypatch.delenv("SCRI_AMD_NO_SEPARABLE_SYNTHESIS", raising=False)
+    monkeypatch.delenv("SCRI_AMD_NO_AXIS_BOOST_SEPARABLE", raising=False)
+    n, ell_max = 3000, 4
+    o = smooth_abd(n, ell_max, 77, t0=0.0, t1=600.0)
+    n_theta = 2 * (2 * ell_max) + 1
+    tr = engine.make_transformation(np.array([0.3, 0, 0.02, 0], dtype=complex), _zrot(0.6), [0.0, 0.0, 0.01], n_theta, n_theta, ell_max)
+    raw = np.ascontiguousarray(o.raw)
+    monkeypatch.setenv("SCRI_AMD_NO_PIPELINE", "1")
+    ctx.enable_timing(True)
+    ctx.get_timing(reset=True)
+    u_ref, d_ref = engine.transform_abd(o.u, raw, ell_max, tr, ctx=ctx)
+    assert _rotations(ctx) > 0
+    ctx.enable_timing(False)
+    monkeypatch.delenv("SCRI_AMD_NO_PIPELINE")
+    monkeypatch.setattr(engine, "PIPELINE_MIN_BYTES", 1 << 16)
+    u_got, d_got = engine.transform_abd(o.u, raw, ell_max, tr, ctx=ctx)
+    assert np.array_equal(u_got, u_ref) and d_got.shape == d_ref.shape
+    assert np.abs(d_got - d_ref).max() < 1e-13 * max(1.0, np.abs(d_ref).max())
