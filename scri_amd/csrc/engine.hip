@@ -90,6 +90,10 @@ struct bms_ctx {
   // analysis tables depend on the grid, the spin and the l range only: kept per tag until a call asks for other ones
   std::map<std::string, std::pair<std::array<int, 6>, AnalysisPlan>> plans;
   std::map<std::array<int, 5>, SynthesisPlan> syn_plans;  // by (n_theta, n_phi, spin, ell_min, ell_max)
+  // the last answer of separable_rotor_grid (frame rotation, boost, grid): repeated transformations skip the walk over the rotors
+  double ring_key[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  int ring_verdict = -1;  // -1: nothing kept
+  std::vector<double> ring_thetas;
   // the same behind a boost along the grid's axis: the tables belong to the ring colatitudes of the last such transformation
   std::map<std::array<int, 5>, std::pair<std::vector<double>, SynthesisPlan>> syn_plans_axis;
   // optional per-kernel timing with HIP events on the context's stream (bms_ctx_enable_timing)
@@ -1251,6 +1255,24 @@ static bool separable_rotor_grid(const bms_transformation* tr, std::vector<doubl
   return true;
 }
 
+// ... with the context remembering the last answer
+static bool separable_rotor_grid(bms_ctx* c, const bms_transformation* tr, std::vector<double>& thetas) {
+  const double key[9] = {tr->frame_rotation[0], tr->frame_rotation[1], tr->frame_rotation[2], tr->frame_rotation[3], tr->boost_velocity[0],
+                         tr->boost_velocity[1], tr->boost_velocity[2], (double)tr->n_theta, (double)tr->n_phi};
+  const bool switched_off = getenv("SCRI_AMD_NO_AXIS_BOOST_SEPARABLE") != nullptr;  // (the switch is read per call)
+  if (!switched_off && c->ring_verdict >= 0 && std::memcmp(key, c->ring_key, sizeof key) == 0) {
+    if (c->ring_verdict) thetas = c->ring_thetas;
+    return c->ring_verdict != 0;
+  }
+  const bool yes = separable_rotor_grid(tr, thetas);
+  if (!switched_off) {
+    std::memcpy(c->ring_key, key, sizeof key);
+    c->ring_verdict = yes ? 1 : 0;
+    c->ring_thetas = yes ? thetas : std::vector<double>();
+  }
+  return yes;
+}
+
 // Tables of the separable synthesis, built once per (grid, spin, l range) and kept in the context.  Returns with P.nt = 0
 // and P.large = false when the shape is one neither kernel takes.
 static int run_synthesis(bms_ctx* c, const SynthesisPlan& P, const double* A, long long lda, long long rows, const double* off, double* Y,
@@ -1817,7 +1839,7 @@ static int transform_modes_impl(bms_ctx* c, const bms_wm_input* in, const bms_tr
     if (no_boost) {
       if ((rc = build_synthesis(c, tr->n_theta, tr->n_phi, s, in->ell_min, in->ell_max, syn))) return rc;
     } else if (axis_boost_pays(n_modes, tr->n_theta, tr->n_phi) && large_synthesis_supported(tr->n_theta, tr->n_phi, in->ell_min, in->ell_max) &&
-               separable_rotor_grid(tr, ring_theta)) {
+               separable_rotor_grid(c, tr, ring_theta)) {
       if ((rc = build_synthesis(c, tr->n_theta, tr->n_phi, s, in->ell_min, in->ell_max, syn, &ring_theta))) return rc;
       axis_boost = syn.large || syn.nt != 0;
     }
@@ -1837,7 +1859,7 @@ static int transform_modes_impl(bms_ctx* c, const bms_wm_input* in, const bms_tr
   SynthesisPlan syn_f[5];
   bool sep_fields = false;
   if (!bs && rows_avail >= 1 && !(sh && sh->col_parts > 1) && tr->n_theta >= 3 && !getenv("SCRI_AMD_NO_SEPARABLE_SYNTHESIS") &&
-      (no_boost || (axis_boost_pays(n_modes, tr->n_theta, tr->n_phi) && separable_rotor_grid(tr, ring_theta)))) {
+      (no_boost || (axis_boost_pays(n_modes, tr->n_theta, tr->n_phi) && separable_rotor_grid(c, tr, ring_theta)))) {
     sep_fields = true;
     for (int fi = 0; fi < 1 + (psi ? in->n_aux : 0) && sep_fields; ++fi) {
       const int f_spin = fi ? in->aux_spin[fi - 1] : s, f_lo = fi ? in->aux_ell_min[fi - 1] : in->ell_min, f_hi = fi ? in->aux_ell_max[fi - 1] : in->ell_max;
@@ -2784,7 +2806,7 @@ static int transform_abd_impl(bms_ctx* c, const double* u, const void* raw, int 
   std::vector<double> ring_theta;
   bool sep = !(sh && sh->col_parts > 1) && tr->n_theta >= 3 && !getenv("SCRI_AMD_NO_SEPARABLE_SYNTHESIS") &&
              (no_boost || (axis_boost_pays((ell_max + 1) * (ell_max + 1), tr->n_theta, tr->n_phi) &&
-                           large_synthesis_supported(tr->n_theta, tr->n_phi, 0, ell_max) && separable_rotor_grid(tr, ring_theta)));
+                           large_synthesis_supported(tr->n_theta, tr->n_phi, 0, ell_max) && separable_rotor_grid(c, tr, ring_theta)));
   for (int si = 0; si < 5 && sep; ++si) {
     if ((rc = build_synthesis(c, tr->n_theta, tr->n_phi, si - 2, 0, ell_max, syn5[si], no_boost ? nullptr : &ring_theta))) return rc;
     sep = syn5[si].large;
