@@ -269,6 +269,11 @@ int bms_spline_derivative(bms_ctx* ctx, const double* x, int64_t n, const void* 
 int bms_mode_map(bms_ctx* ctx, void* out, int64_t ld_out, int64_t n_rows, int n_cols, const void* a, int64_t ld_a,
                  const int32_t* idx_a, const void* coef_a, int conj_a, const void* b, int64_t ld_b, const int32_t* idx_b,
                  const void* coef_b, int conj_b, const double* row_scale, int mem);
+/* WaveformBase.norm (scri/waveform_base.py:19-35,535-551): out[t] = sum_j |data[t][j]|^2, or its square root with take_sqrt
+ * (complex_array_norm / complex_array_abs), the terms re^2 + im^2 added one at a time in column order, no fused multiply-adds --
+ * the reference's loop, so the sums agree with it to the bit (and with them the parity-violation measures,
+ * scri/waveform_modes.py:769-778 ...).  data c16[n_rows][ld] and out f8[n_rows] live in `mem`. */
+int bms_row_norm(bms_ctx* ctx, const void* data, int64_t ld, int64_t n_rows, int n_cols, int mem, int take_sqrt, double* out);
 /* ModesTimeSeries.grid_multiply (scri/modes_time_series.py:142-202): modes a (spin_a, l = 0..ell_max_a,
  * c16[n_times][(ell_max_a+1)^2]) and b likewise are evaluated on the (2 working_ell_max + 1)^2 equiangular grid
  * (spinsfast.salm2map), multiplied there, and the product is analysed (map2salm, spin spin_a + spin_b) into

@@ -135,6 +135,7 @@ SIGNATURES = {
     "bms_salm2map": (c_int, [c_vp, c_vp, c_int, c_i64, c_int, c_int, c_int, c_int, c_vp]),
     "bms_mode_map": (c_int, [c_vp, c_vp, c_i64, c_i64, c_int, c_vp, c_i64, ctypes.POINTER(ctypes.c_int32), c_vp, c_int, c_vp, c_i64,
                               ctypes.POINTER(ctypes.c_int32), c_vp, c_int, c_vp, c_int]),
+    "bms_row_norm": (c_int, [c_vp, c_vp, c_i64, c_i64, c_int, c_int, c_int, c_vp]),
     "bms_grid_multiply": (c_int, [c_vp, c_vp, c_int, c_int, c_vp, c_int, c_int, c_int, c_i64, c_int, c_int, c_vp]),
 }
 

@@ -2556,6 +2556,29 @@ extern "C" int bms_mode_map(bms_ctx* c, void* out, int64_t ld_out, int64_t n_row
   return BMS_OK;
 }
 
+extern "C" int bms_row_norm(bms_ctx* c, const void* data, int64_t ld, int64_t n_rows, int n_cols, int mem, int take_sqrt, double* out) {
+  if (!c || !data || !out) return BMS_ERR_INVALID;
+  HIP_TRY(c, hipSetDevice(c->device));
+  if (n_rows < 0 || n_cols < 0 || ld < n_cols) return fail(c, BMS_ERR_INVALID, "bad sizes");
+  if (n_rows == 0) return BMS_OK;
+  hipStream_t S = c->stream;
+  int rc;
+  const double* d_in = (const double*)data;
+  double* d_out = out;
+  if (mem == BMS_HOST) {
+    if (n_cols == 0) {
+      std::memset(out, 0, sizeof(double) * n_rows);
+      return BMS_OK;
+    }
+    if ((rc = stage_in(c, "in_data", data, mem, ((size_t)(n_rows - 1) * ld + n_cols) * 16, &d_in))) return rc;
+    if ((rc = dev_buf_t(c, "norm_out", (size_t)n_rows, &d_out))) return rc;
+  }
+  TIMED(c, BMS_TAG_POINTWISE, launch_row_norm(S, d_in, ld, n_rows, n_cols, take_sqrt, d_out));
+  if (mem == BMS_HOST) HIP_TRY(c, hipMemcpyAsync(out, d_out, sizeof(double) * n_rows, hipMemcpyDeviceToHost, S));
+  HIP_TRY(c, hipStreamSynchronize(S));
+  return BMS_OK;
+}
+
 // ModesTimeSeries.grid_multiply (scri/modes_time_series.py:142-202): both mode sets (l_min = 0) are synthesised on the
 // (2W+1) x (2W+1) equiangular grid, multiplied there, and the product (spin s_a + s_b) is analysed up to output_ell_max.
 extern "C" int bms_grid_multiply(bms_ctx* c, const void* a, int spin_a, int ell_max_a, const void* b, int spin_b, int ell_max_b,

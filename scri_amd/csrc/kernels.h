@@ -43,6 +43,8 @@ struct ModeMapSide {
   const double* coef;  // c16 per output column
   int conj;            // conjugate the source
 };
+// s_t = sum_j |data[t][j]|^2 (or its square root), terms added in column order without contraction (waveform_base.py:19-35)
+hipError_t launch_row_norm(hipStream_t stream, const double* data, long long ld, long long n_rows, int n_cols, int take_sqrt, double* out);
 hipError_t launch_mode_map(hipStream_t stream, double* out, long long ld_out, long long n_rows, int n_cols, const ModeMapSide& A,
                            const ModeMapSide& B, const double* row_scale);
 

@@ -43,6 +43,44 @@ __global__ __launch_bounds__(256) void mode_map_kernel(double* __restrict__ out,
   }
 }
 
+// WaveformBase.norm (scri/waveform_base.py:19-35,535-551): s_t = sum_j (re^2 + im^2) accumulated in column order, one term at a time
+// and without fused multiply-adds -- the reference's loop, so that the sums (and the parity-violation measures built on them)
+// come out to the bit.  One wave per 64 rows: 64 x 16 tiles travel through LDS with 256-byte row segments, every lane then adds the
+// 16 terms of its own row in order.
+__global__ __launch_bounds__(64) void row_norm_kernel(const double* __restrict__ data, long long ld, long long n_rows, int n_cols,
+                                                      int take_sqrt, double* __restrict__ out) {
+#pragma clang fp contract(off)
+  __shared__ double2 tile[64][17];
+  const int lane = threadIdx.x, sub = lane >> 4, col = lane & 15;
+  for (long long r0 = 64LL * blockIdx.x; r0 < n_rows; r0 += 64LL * gridDim.x) {
+    double s = 0.0;
+    for (int c0 = 0; c0 < n_cols; c0 += 16) {
+#pragma unroll
+      for (int k = 0; k < 16; ++k) {
+        const long long r = r0 + 4 * k + sub;
+        tile[4 * k + sub][col] = (r < n_rows && c0 + col < n_cols) ? *reinterpret_cast<const double2*>(data + (r * ld + c0 + col) * 2)
+                                                                   : double2{0.0, 0.0};
+      }
+      __syncthreads();
+      const int nc = n_cols - c0 < 16 ? n_cols - c0 : 16;
+      for (int j = 0; j < nc; ++j) {
+        const double2 v = tile[lane][j];
+        const double a = v.x * v.x, b = v.y * v.y;
+        s += a + b;
+      }
+      __syncthreads();
+    }
+    if (r0 + lane < n_rows) out[r0 + lane] = take_sqrt ? sqrt(s) : s;
+  }
+}
+
+hipError_t launch_row_norm(hipStream_t stream, const double* data, long long ld, long long n_rows, int n_cols, int take_sqrt, double* out) {
+  if (n_rows <= 0) return hipSuccess;
+  const long long blocks = (n_rows + 63) / 64;
+  hipLaunchKernelGGL(row_norm_kernel, dim3((unsigned)(blocks < 65536 ? blocks : 65536)), dim3(64), 0, stream, data, ld, n_rows, n_cols, take_sqrt, out);
+  return hipGetLastError();
+}
+
 hipError_t launch_mode_map(hipStream_t stream, double* out, long long ld_out, long long n_rows, int n_cols, const ModeMapSide& A,
                            const ModeMapSide& B, const double* row_scale) {
   if (n_rows <= 0 || n_cols <= 0) return hipSuccess;

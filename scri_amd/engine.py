@@ -534,6 +534,65 @@ def grid_multiply(a, spin_a, ell_max_a, b, spin_b, ell_max_b, working_ell_max, o
     return out
 
 
+def mode_map(a, idx_a, coef_a, conj_a=False, b=None, idx_b=None, coef_b=None, conj_b=False, row_scale=None, ctx=None):
+    """bms_mode_map on host arrays: out[t, j] = r_t (coef_a[j] op_a(a[t, idx_a[j]]) + coef_b[j] op_b(b[t, idx_b[j]])), op = identity or
+    complex conjugation, idx = -1 for a zero term.  a, b complex128 [N, *]; returns complex128 [N, len(idx_a)]."""
+    ctx = _ctx(ctx)
+    a = _lib.as_c16(a)
+    idx_a = np.ascontiguousarray(idx_a, dtype=np.int32)
+    coef_a = np.ascontiguousarray(coef_a, dtype=np.complex128)
+    n_cols = idx_a.shape[0]
+    if coef_a.shape != (n_cols,) or a.ndim != 2:
+        raise ValueError("mode_map takes a [N, n] array and tables of one length")
+    out = np.empty((a.shape[0], n_cols), dtype=np.complex128)
+    i32 = ctypes.POINTER(ctypes.c_int32)
+    args_b = (None, 0, None, None, 0)
+    if b is not None:
+        b = _lib.as_c16(b)
+        idx_b = np.ascontiguousarray(idx_b, dtype=np.int32)
+        coef_b = np.ascontiguousarray(coef_b, dtype=np.complex128)
+        if b.ndim != 2 or b.shape[0] != a.shape[0] or idx_b.shape != (n_cols,) or coef_b.shape != (n_cols,):
+            raise ValueError("mode_map: the second operand needs the rows of the first and tables of the same length")
+        args_b = (vptr(b), b.shape[1], idx_b.ctypes.data_as(i32), vptr(coef_b), int(bool(conj_b)))
+    rs = None
+    if row_scale is not None:
+        rs = np.ascontiguousarray(row_scale, dtype=float)
+        if rs.shape != (a.shape[0],):
+            raise ValueError("mode_map: one row factor per row")
+    if out.size:
+        rc = _lib.load().bms_mode_map(
+            ctx.handle, vptr(out), n_cols, a.shape[0], n_cols, vptr(a), a.shape[1], idx_a.ctypes.data_as(i32), vptr(coef_a), int(bool(conj_a)),
+            *args_b, vptr(rs) if rs is not None else None, BMS_HOST,
+        )
+        ctx.check(rc, "bms_mode_map")
+    return out
+
+
+def row_norm(data, take_sqrt=False, ctx=None, device_tensor=None):
+    """bms_row_norm: sum over the columns of |data|^2 (its square root with take_sqrt) per row, accumulated in the reference's
+    order (scri/waveform_base.py:19-35).  `data` complex128 [N, n] on the host, or `device_tensor` (torch, [N, n], unit column
+    stride) for data resident on the GPU; returns a host float array [N]."""
+    ctx = _ctx(ctx)
+    if device_tensor is not None:
+        import torch
+
+        n_rows, n_cols = device_tensor.shape
+        out = torch.empty(n_rows, dtype=torch.float64, device=device_tensor.device)
+        if n_rows:
+            rc = _lib.load().bms_row_norm(ctx.handle, c_vp(device_tensor.data_ptr()), device_tensor.stride(0) if n_rows > 1 else max(n_cols, 1), n_rows,
+                                          n_cols, BMS_DEVICE, int(bool(take_sqrt)), c_vp(out.data_ptr()))
+            ctx.check(rc, "bms_row_norm")
+        return out.cpu().numpy()
+    data = _lib.as_c16(data)
+    if data.ndim != 2:
+        raise ValueError("row_norm takes a [N, n] array")
+    out = np.empty(data.shape[0], dtype=float)
+    if data.shape[0]:
+        rc = _lib.load().bms_row_norm(ctx.handle, vptr(data), max(data.shape[1], 1), data.shape[0], data.shape[1], BMS_HOST, int(bool(take_sqrt)), vptr(out))
+        ctx.check(rc, "bms_row_norm")
+    return out
+
+
 def angular_velocity(t, data, ell_min, ell_max, ctx=None, parts=False):
     """omega[N, 3] = -<LL>^-1 <Ldt> of modes data[N, n_modes]; parts=True returns (<Ldt>[N, 3], <LL>[N, 3, 3], omega)."""
     ctx = _ctx(ctx)

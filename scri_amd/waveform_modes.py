@@ -7,11 +7,12 @@ import numpy as np
 from . import engine, quaternions
 from . import UnknownFrameType, UnknownDataType, SpinWeights, ConformalWeights, RScaling, DataNames, FrameNames
 from .mode_algebra import LM_range, LM_total_size
+from .mode_operators import ModeOperators
 
 _next_num = [0]
 
 
-class WaveformModes:
+class WaveformModes(ModeOperators):
     """Object containing time, frame, and SWSH-mode data (subset of scri.WaveformModes).
 
     Parameters (keyword): t, data [n_times, n_modes] complex, ell_min, ell_max, frame (quaternion array or
@@ -220,7 +221,15 @@ class WaveformModes:
     def norm(self, take_sqrt=False, indices=slice(None, None, None)):
         """L2 norm of the waveform at each time: sum over modes of |data|^2 (its square root with take_sqrt), optionally on
         a slice of the times"""
-        n = np.sum(np.abs(self.data_2d[indices]) ** 2, axis=-1)
+        # the reference adds re^2 + im^2 column by column (complex_array_norm / complex_array_abs, waveform_base.py:19-35); the same
+        # order here, so the sums agree to the bit.  Weights resident on the GPU are reduced there (bms_row_norm); a host array is
+        # reduced where it is -- one pass over it, against an upload of the whole series.
+        if self.is_device_resident and indices == slice(None, None, None) and len(self._data_shape()) == 2:
+            return engine.row_norm(None, take_sqrt=take_sqrt, ctx=self._ctx, device_tensor=self._dev)
+        d = self.data_2d[indices]
+        n = np.zeros(d.shape[0], dtype=float)
+        for j in range(d.shape[1]):
+            n += d[:, j].real * d[:, j].real + d[:, j].imag * d[:, j].imag
         return np.sqrt(n) if take_sqrt else n
 
     def max_norm_index(self, skip_fraction_of_data=4):

@@ -12,6 +12,13 @@ quaternion, spherical_functions, spinsfast) and writes
   g10_ref_rotations.npz     scri.WaveformModes.rotate_decomposition_basis (scri/rotations.py:284-392): constant rotor and
                             rotor series, data and frame
 
+  g11_ref_mode_operators.npz  the mode-space operators of scri.WaveformModes (scri/waveform_modes.py:458-943): apply_eth, the
+                            four parity conjugates with their symmetric / antisymmetric parts, the conjugate-pair form, truncate,
+                            inner_product; scri.extrapolation.intersection (scri/extrapolation.py:47-122).  The waveforms carry an
+                            EMPTY frame, so the numpy-quaternion parity ufuncs the reference applies to it (np.x_parity_conjugate
+                            ...: absent here) are the identity on it; inner_product's spline_definite_integral is scipy's
+                            CubicSpline.integrate -- both third-party, everything else is the reference's code.
+
 Only the .npz files travel; tests/test_golden.py checks the oracle (CPU) and the HIP path (GPU) against them.
 """
 import os
@@ -101,9 +108,61 @@ def g10():
     np.savez_compressed(os.path.join(HERE, "g10_ref_rotations.npz"), source="/root/reference/scri (unmodified) on stand-ins", **out)
 
 
+def g11():
+    import types
+
+    from scipy.interpolate import CubicSpline
+
+    # numpy-quaternion's parity ufuncs on an empty frame array: nothing to reflect
+    for d in ("x_", "y_", "z_", ""):
+        for part in ("conjugate", "symmetric_part", "antisymmetric_part"):
+            setattr(np, f"{d}parity_{part}", lambda f: f)
+    calculus = types.ModuleType("quaternion.calculus")
+    calculus.spline_definite_integral = lambda f, t, t1=None, t2=None, axis=-1: CubicSpline(t, f, axis=axis).integrate(
+        t[0] if t1 is None else t1, t[-1] if t2 is None else t2)
+    sys.modules["quaternion.calculus"] = calculus
+    sys.modules["quaternion"].calculus = calculus
+    from scri.extrapolation import intersection
+
+    out = {}
+    n = 24
+    t = np.linspace(0.0, 9.0, n) + 0.05 * np.sin(np.arange(n))
+    out["t"] = t
+    for name, dt, lmin, lmax, seed in (("psi1", scri.psi1, 1, 4, 5), ("psi4", scri.psi4, 2, 5, 6), ("h", scri.h, 2, 4, 7), ("psi2", scri.psi2, 0, 3, 8)):
+        rng = np.random.default_rng(seed)
+        nm = (lmax + 1) ** 2 - lmin**2
+        data = rng.normal(size=(n, nm)) + 1j * rng.normal(size=(n, nm))
+        out[f"{name}_in"], out[f"{name}_ells"] = data, np.array([lmin, lmax])
+        w = _wm(t, data.copy(), lmin, lmax, dt)
+        for d in ("x_", "y_", "z_", ""):
+            for part in ("conjugate", "symmetric_part", "antisymmetric_part"):
+                out[f"{name}_{d}parity_{part}"] = getattr(w, f"{d}parity_{part}").data
+            out[f"{name}_{d}parity_violation_squared"] = getattr(w, f"{d}parity_violation_squared")
+        for k, (ops, conv) in enumerate((("+", "NP"), ("-", "NP"), ("-+", "NP"), ("+-", "GHP"), ([+1, -1, -1], "NP"))):
+            out[f"{name}_eth{k}"] = w.apply_eth(ops, eth_convention=conv)
+        p = _wm(t, data.copy(), lmin, lmax, dt)
+        p.convert_to_conjugate_pairs()
+        out[f"{name}_pairs"] = p.data.copy()
+        p.convert_from_conjugate_pairs()
+        out[f"{name}_pairs_back"] = p.data.copy()
+        for tol in (1e-10, 1e-3):
+            q = _wm(t, data.copy(), lmin, lmax, dt)
+            q.truncate(tol)
+            out[f"{name}_truncate_{tol:g}"] = q.data.copy()
+        other = _wm(t, rng.normal(size=(n, nm)) + 1j * rng.normal(size=(n, nm)), lmin, lmax, dt)
+        out[f"{name}_other"] = other.data
+        out[f"{name}_inner"] = np.array([w.inner_product(other), w.inner_product(other, t1=2.0, t2=7.0)])
+    t2 = np.linspace(0.7, 11.0, 31) + 0.08 * np.cos(np.arange(31))
+    out["t2"] = t2
+    out["intersection"] = intersection(t, t2)
+    out["intersection_min_step"] = intersection(t, t2, min_step=0.25)
+    out["intersection_bounds"] = intersection(t, t2, min_time=1.5, max_time=8.0)
+    np.savez_compressed(os.path.join(HERE, "g11_ref_mode_operators.npz"), source="/root/reference/scri (unmodified) on stand-ins", **out)
+
+
 if __name__ == "__main__":
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
-        for f in (g10, g8, g9):
+        for f in ((g11,) if "--g11" in sys.argv else (g10, g8, g9, g11)):
             f()
             print("wrote", f.__name__)

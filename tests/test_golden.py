@@ -242,3 +242,88 @@ def test_g10_gpu_vs_reference_rotations(ctx):
     w = _gpu_wm(g["t"], g["data"].copy(), 2, 4, scri_amd.h, ctx)
     w.rotate_physical_system(g["constant"])
     assert np.abs(w.data - g["physical_out"]).max() < 4e-13 and np.abs(w.frame - g["physical_frame"]).max() < 1e-15
+
+
+# ---- g11: the mode-space operators of scri.WaveformModes, computed by the reference's own scri/waveform_modes.py:458-943 and
+# scri/extrapolation.py:47-122 (tests/golden/make_golden_from_reference.py::g11)
+G11_TYPES = {"psi1": 2, "psi4": 5, "h": 7, "psi2": 3}  # oracle.containers data type numbers
+G11_ETH = (("+", "NP"), ("-", "NP"), ("-+", "NP"), ("+-", "GHP"), ([+1, -1, -1], "NP"))
+
+
+def _g11_cases(g):
+    for name, dt in G11_TYPES.items():
+        lmin, lmax = (int(x) for x in g[f"{name}_ells"])
+        yield name, dt, lmin, lmax
+
+
+def test_g11_oracle_vs_reference_mode_operators():
+    from oracle import waveform_modes_ref as mref
+
+    g = load("g11_ref_mode_operators.npz")
+    t = g["t"]
+    for name, dt, lmin, lmax in _g11_cases(g):
+        w = WM(t=t, data=g[f"{name}_in"], ell_min=lmin, ell_max=lmax, dataType=dt)
+        for d in ("x_", "y_", "z_", ""):
+            for part, fn in (("conjugate", mref.parity_conjugate), ("symmetric_part", mref.parity_symmetric_part),
+                             ("antisymmetric_part", mref.parity_antisymmetric_part)):
+                assert np.array_equal(fn(w, d.rstrip("_")).data, g[f"{name}_{d}parity_{part}"]), (name, d, part)
+            # (norms: the vectors were made without numba, whose x ** 2 is x * x; CPython's pow differs by an ulp now and then)
+            assert np.allclose(mref.parity_violation_squared(w, d.rstrip("_")), g[f"{name}_{d}parity_violation_squared"], rtol=1e-15, atol=0)
+        for k, (ops, conv) in enumerate(G11_ETH):
+            assert np.array_equal(mref.apply_eth(w, ops, eth_convention=conv), g[f"{name}_eth{k}"]), (name, ops)
+        p = mref.convert_to_conjugate_pairs(w)
+        assert np.array_equal(p.data, g[f"{name}_pairs"])
+        assert np.array_equal(mref.convert_from_conjugate_pairs(p).data, g[f"{name}_pairs_back"])
+        for tol in (1e-10, 1e-3):
+            assert np.array_equal(mref.truncate(w, tol).data, g[f"{name}_truncate_{tol:g}"])
+        other = WM(t=t, data=g[f"{name}_other"], ell_min=lmin, ell_max=lmax, dataType=dt)
+        got = np.array([mref.inner_product(w, other), mref.inner_product(w, other, t1=2.0, t2=7.0)])
+        assert np.abs(got - g[f"{name}_inner"]).max() < 1e-13 * np.abs(g[f"{name}_inner"]).max()
+    assert np.array_equal(mref.intersection(t, g["t2"]), g["intersection"])
+    assert np.array_equal(mref.intersection(t, g["t2"], min_step=0.25), g["intersection_min_step"])
+    assert np.array_equal(mref.intersection(t, g["t2"], min_time=1.5, max_time=8.0), g["intersection_bounds"])
+
+
+def test_g11_time_intersection_vs_reference():
+    from scri_amd.mode_operators import time_intersection
+
+    g = load("g11_ref_mode_operators.npz")
+    assert np.array_equal(time_intersection(g["t"], g["t2"]), g["intersection"])
+    assert np.array_equal(time_intersection(g["t"], g["t2"], min_step=0.25), g["intersection_min_step"])
+    assert np.array_equal(time_intersection(g["t"], g["t2"], min_time=1.5, max_time=8.0), g["intersection_bounds"])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("device", [False, True])
+def test_g11_gpu_vs_reference_mode_operators(ctx, device):
+    import scri_amd
+
+    g = load("g11_ref_mode_operators.npz")
+    t = g["t"]
+
+    def make(name, dt, lmin, lmax, key="in"):
+        w = scri_amd.WaveformModes(t=t, data=g[f"{name}_{key}"].copy(), ell_min=lmin, ell_max=lmax, dataType=dt, frameType=scri_amd.Inertial,
+                                   r_is_scaled_out=True, m_is_scaled_out=True, ctx=ctx)
+        return w.to_device() if device else w
+
+    for name, dt, lmin, lmax in _g11_cases(g):
+        w = make(name, dt, lmin, lmax)
+        for d in ("x_", "y_", "z_", ""):
+            for part in ("conjugate", "symmetric_part", "antisymmetric_part"):
+                assert np.array_equal(getattr(w, f"{d}parity_{part}").data, g[f"{name}_{d}parity_{part}"]), (name, d, part)
+            assert np.allclose(getattr(w, f"{d}parity_violation_squared"), g[f"{name}_{d}parity_violation_squared"], rtol=1e-15, atol=0)
+        for k, (ops, conv) in enumerate(G11_ETH):
+            assert np.array_equal(w.apply_eth(ops, eth_convention=conv), g[f"{name}_eth{k}"]), (name, ops)
+        p = make(name, dt, lmin, lmax)
+        p.convert_to_conjugate_pairs()
+        scale = np.abs(g[f"{name}_in"]).max()
+        assert np.abs(p.data - g[f"{name}_pairs"]).max() < 4e-16 * scale  # (x + y) / sqrt2 here is x / sqrt2 + y / sqrt2
+        p.convert_from_conjugate_pairs()
+        assert np.abs(p.data - g[f"{name}_pairs_back"]).max() < 8e-16 * scale
+        for tol in (1e-10, 1e-3):
+            q = make(name, dt, lmin, lmax)
+            q.truncate(tol)
+            assert np.array_equal(q.data, g[f"{name}_truncate_{tol:g}"])
+        other = make(name, dt, lmin, lmax, "other")
+        got = np.array([w.inner_product(other), w.inner_product(other, t1=2.0, t2=7.0)])
+        assert np.abs(got - g[f"{name}_inner"]).max() < 1e-12 * np.abs(g[f"{name}_inner"]).max()

@@ -222,3 +222,30 @@ def test_ring_colatitudes_against_the_oracle_rotor_grid(fr, v, keeps):
         assert np.abs(th[1:-1] - expect).max() < 1e-14
     with pytest.raises(ValueError):
         engine.ring_colatitudes(fr, v, 1, n_phi)
+
+
+def test_time_intersection_matches_the_oracle():
+    """scri_amd.mode_operators.time_intersection (what inner_product(..., allow_times_differ=True) interpolates to) against the
+    oracle's restatement of scri/extrapolation.py:47-122, on uniform, jittered and offset axes and with the optional bounds."""
+    from oracle import waveform_modes_ref as ref
+    from scri_amd.mode_operators import time_intersection
+
+    rng = np.random.default_rng(11)
+    for case in range(12):
+        n1, n2 = int(rng.integers(5, 80)), int(rng.integers(5, 80))
+        t1 = np.sort(rng.uniform(0.0, 10.0, n1)) if case % 2 else np.linspace(0.0, 10.0, n1)
+        t2 = np.sort(rng.uniform(-1.0, 12.0, n2)) if case % 3 else np.linspace(0.5, 9.0, n2)
+        t1[1:] = np.maximum(t1[1:], t1[:-1] + 1e-3)
+        t2[1:] = np.maximum(t2[1:], t2[:-1] + 1e-3)
+        kw = {}
+        if case % 4 == 1:
+            kw = dict(min_step=0.05)
+        if case % 4 == 2:
+            kw = dict(min_time=1.0, max_time=8.0)
+        got, expect = time_intersection(t1, t2, **kw), ref.intersection(t1, t2, **kw)
+        assert np.array_equal(got, expect), case
+        assert got[0] >= max(t1[0], t2[0]) and got[-1] <= min(t1[-1], t2[-1]) and (np.diff(got) > 0).all()
+    with pytest.raises(ValueError):
+        time_intersection(np.array([]), np.array([0.0, 1.0]))
+    with pytest.raises(ValueError, match="Empty intersection"):
+        time_intersection(np.array([0.0, 1.0]), np.array([2.0, 3.0]))
