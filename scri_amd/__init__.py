@@ -22,6 +22,13 @@ SpinWeights = [sys.maxsize, 2, 1, 0, -1, -2, 2, -2, -2, -2, sys.maxsize, 0]
 ConformalWeights = [sys.maxsize, 2, 1, 0, -1, -2, 1, 0, -1, -1, -3, 0]
 RScaling = [sys.maxsize, 5, 4, 3, 2, 1, 2, 1, 1, 1, 0, 0]
 MScaling = [sys.maxsize, 2, 2, 2, 2, 2, 0, 0, 1, 1, 2, 1]
+DataNamesLaTeX = [r"\mathrm{unknown data type}", r"\psi_0", r"\psi_1", r"\psi_2", r"\psi_3", r"\psi_4", r"\sigma", r"h", r"\dot{h}", r"\mathrm{n}",
+                  r"\psi_n", r"\psi_M"]
+# units (scri/__init__.py:60-76): c exact; G M_sun / c^2 and / c^3 ("2015 Selected Astronomical Constants", TDB); the parsec of IAU 2012 B2
+speed_of_light = 299792458.0  # m/s
+m_sun_in_meters = 1476.62503851  # m
+m_sun_in_seconds = 4.92549094916e-06  # s
+parsec_in_meters = 3.0856775814913672789139379577965e16  # m
 
 from . import _lib  # noqa: E402  (raises ImportError if libscri_amd.so has not been built)
 from ._lib import Context, default_context, BMSError  # noqa: E402,F401

@@ -10,7 +10,7 @@ bit (tests/test_gpu_mode_operators.py mirrors tests/test_parity.py's np.array_eq
 import numpy as np
 
 from . import engine
-from . import UnknownDataType
+from . import UnknownDataType, RScaling, MScaling, DataNamesLaTeX
 from .mode_algebra import LM_range
 
 
@@ -254,3 +254,87 @@ class ModeOperators:
         integrand = np.sum(np.conjugate(A.data) * B.data, axis=1)
         ends = engine.spline_derivative(times, integrand[:, np.newaxis], np.array([t1, t2], dtype=float), order=-1, ctx=self._ctx)
         return complex(ends[1, 0] - ends[0, 0])
+
+    # ------------------------------------------------------------------ what the object says about itself (waveform_base.py:425-516)
+    @property
+    def is_valid(self):
+        return self.ensure_validity(alter=False, assertions=False)
+
+    @property
+    def gamma_weight(self):
+        """Non-conformal effect of a boost: the power of gamma a mass that was scaled out picks up (a monopole cannot depend on
+        the direction the way r and the field do)"""
+        return (MScaling[self.dataType] if self.m_is_scaled_out else 0) + (
+            -RScaling[self.dataType] if (self.r_is_scaled_out and self.m_is_scaled_out) else 0
+        )
+
+    @property
+    def r_scaling(self):
+        return RScaling[self.dataType]
+
+    @property
+    def m_scaling(self):
+        return MScaling[self.dataType]
+
+    @property
+    def data_type_latex(self):
+        return DataNamesLaTeX[self.dataType]
+
+    @property
+    def descriptor_string(self):
+        """A name for the content suitable for file names, e.g. 'rMpsi4' or 'rhOverM', from what the object knows of itself"""
+        if self.dataType == UnknownDataType:
+            return self.data_type_string
+        r_power, name = RScaling[self.dataType], self.data_type_string
+        text = ""
+        if self.r_is_scaled_out and r_power >= 1:
+            text = "r" if r_power == 1 else "r" + str(r_power)
+        if not self.m_is_scaled_out:
+            return text + name
+        m_power = MScaling[self.dataType] - (r_power if self.r_is_scaled_out else 0)
+        if m_power < -1:
+            return text + name + "OverM" + str(-m_power)
+        if m_power == -1:
+            return text + name + "OverM"
+        if m_power == 0:
+            return text + name
+        return text + ("M" if m_power == 1 else "M" + str(m_power)) + name
+
+    def deepcopy(self):
+        """an alias of copy(), which is deep anyway"""
+        W = self.copy()
+        W._append_history(f"{W} = {self}.deepcopy()")
+        return W
+
+    def SI_units(self, current_unit_mass_in_solar_masses, distance_from_source_in_megaparsecs=100):
+        """The waveform a source of the given total mass shows at the given distance, in SI units (times in s; curvature
+        scalars in s^-2), assuming the data are in geometric units as `dataType`, `r_is_scaled_out` and `m_is_scaled_out` say
+        (waveform_base.py:970-1045)."""
+        import warnings
+
+        from . import m_sun_in_meters, speed_of_light, parsec_in_meters
+
+        if not self.r_is_scaled_out:
+            warnings.warn("\nTrying to convert to SI units, the radius is supposedly not scaled out.\n"
+                          "This seems to suggest that the data may already be in some units...")
+        if not self.m_is_scaled_out:
+            warnings.warn("\nTrying to convert to SI units, the mass is supposedly not scaled out.\n"
+                          "This seems to suggest that the data may already be in some units...")
+        M_in_meters = current_unit_mass_in_solar_masses * m_sun_in_meters
+        M_in_seconds = M_in_meters / speed_of_light
+        R_over_M = distance_from_source_in_megaparsecs * (1e6 * parsec_in_meters) / M_in_meters
+        scale = 1.0
+        if self.r_is_scaled_out:
+            scale = R_over_M ** -self.r_scaling
+        if self.m_is_scaled_out:
+            scale = scale * M_in_meters ** -self.m_scaling if self.r_is_scaled_out else M_in_meters ** -self.m_scaling
+        W = self.copy_without_data()
+        W.t = M_in_seconds * self.t if self.m_is_scaled_out else np.copy(self.t)
+        W.frame = np.copy(self.frame)
+        W.data = scale * self.data
+        W.m_is_scaled_out = False
+        W.r_is_scaled_out = False
+        W._append_history(
+            "{} = {}.SI_units(current_unit_mass_in_solar_masses={}, distance_from_source_in_megaparsecs={})".format(
+                W, self, current_unit_mass_in_solar_masses, distance_from_source_in_megaparsecs))
+        return W

@@ -129,3 +129,48 @@ def test_squad_rotor_interpolation():
     # a single rotor or no output times
     assert Q.squad(w.frame[:1], w.t[:1], t_out[:5]).shape == (5, 4)
     assert Q.squad(w.frame, w.t, np.array([])).shape == (0, 4)
+
+
+def test_SI_units():
+    """the reference's tests/test_waveform.py:350-370 on the same linear waveform"""
+    import scri_amd
+
+    units_precision = 4.5e-16
+    total_mass, distance = 1.1, 3.7
+    mass_in_seconds = total_mass * 4.92549094916e-06
+    distance_in_meters = distance * 3.0856775814913672789e22
+    W_in = linear_waveform()
+    W_out = W_in.SI_units(total_mass, distance)
+    assert W_in.ensure_validity(alter=False) and W_out.ensure_validity(alter=False)
+    assert W_out.history[:1] == ["# Called from linear_waveform"]
+    assert W_out.frameType == scri_amd.Corotating and W_out.dataType == scri_amd.h
+    assert not W_out.r_is_scaled_out and not W_out.m_is_scaled_out
+    assert W_out.num != W_in.num
+    assert np.allclose(W_out.t, W_in.t * mass_in_seconds, rtol=units_precision)
+    assert np.allclose(W_out.data, W_in.data * mass_in_seconds * 299792458 / distance_in_meters, rtol=units_precision)
+    with pytest.warns(UserWarning, match="radius is supposedly not scaled out"):
+        W_out.SI_units(total_mass, distance)
+
+
+def test_descriptors_and_weights():
+    """waveform_base.py:440-516: the weights and the file-name descriptor for the combinations of what is scaled out"""
+    import scri_amd
+
+    def make(dataType, r, m):
+        return scri_amd.WaveformModes(t=np.zeros(1), data=np.zeros((1, 5), dtype=complex), ell_min=2, ell_max=2, dataType=dataType,
+                                      r_is_scaled_out=r, m_is_scaled_out=m)
+
+    assert make(scri_amd.psi4, True, True).descriptor_string == "rMPsi4"
+    assert make(scri_amd.h, True, True).descriptor_string == "rhOverM"
+    assert make(scri_amd.h, False, True).descriptor_string == "h"
+    assert make(scri_amd.h, True, False).descriptor_string == "rh"
+    assert make(scri_amd.psi0, True, True).descriptor_string == "r5Psi0OverM3"
+    assert make(scri_amd.psi2, False, True).descriptor_string == "M2Psi2"
+    assert make(scri_amd.news, False, True).descriptor_string == "Mnews"
+    assert scri_amd.WaveformModes(t=np.zeros(1), data=np.zeros((1, 5), dtype=complex), ell_min=2, ell_max=2).descriptor_string == "UnknownDataType"
+    w = make(scri_amd.psi4, True, True)
+    assert (w.r_scaling, w.m_scaling, w.gamma_weight, w.data_type_latex) == (1, 2, 1, r"\psi_4")
+    assert make(scri_amd.psi4, True, False).gamma_weight == 0 and make(scri_amd.psi4, False, True).gamma_weight == 2
+    assert w.is_valid
+    c = w.deepcopy()
+    assert c.num != w.num and np.array_equal(c.data, w.data) and c.data is not w.data and c.history[-1].endswith(".deepcopy()")
