@@ -19,6 +19,15 @@ quaternion, spherical_functions, spinsfast) and writes
                             ...: absent here) are the identity on it; inner_product's spline_definite_integral is scipy's
                             CubicSpline.integrate -- both third-party, everything else is the reference's code.
 
+  g12_ref_bms_charges.npz   the Bondi charges of scri/asymptotic_bondi_data/bms_charges.py:14-192 on generic smooth data (l <= 4, N = 90):
+                            mass aspect, four-momentum, rest mass, angular momentum, boost and centre-of-mass charge,
+                            dimensionless spin.  The formulas are the reference's; the sf.Modes algebra underneath (multiply,
+                            eth, bar, real, truncate_ell) and scipy's spline are the stand-ins' / third party.
+
+  g13_ref_mode_calculations.npz  scri/mode_calculations.py:14-141,320-372 on a chirp (l = 2..6 and 0..4, N = 120): LdtVector,
+                            LLMatrix, angular_velocity, LLDominantEigenvector -- the reference's loops; the ladder coefficient
+                            sqrt(l(l+1) - m(m+1)) and scipy's spline (data_dot) are third party.
+
 Only the .npz files travel; tests/test_golden.py checks the oracle (CPU) and the HIP path (GPU) against them.
 """
 import os
@@ -160,9 +169,44 @@ def g11():
     np.savez_compressed(os.path.join(HERE, "g11_ref_mode_operators.npz"), source="/root/reference/scri (unmodified) on stand-ins", **out)
 
 
+def g12():
+    n, L = 90, 4
+    u = np.linspace(-5.0, 20.0, n)
+    raw = np.zeros((6, n, (L + 1) ** 2), dtype=complex)
+    for f, s in enumerate(synthetic.ABD_SPINS):
+        raw[f] = 0.3 * synthetic.chirp_modes(u, 0, L, 120 + f) * (1 + 0.02 * u[:, None])
+        raw[f, :, : s * s] = 0
+    raw[2, :, 0] -= 5.0 * np.sqrt(4 * np.pi)  # a dominant mass monopole keeps the four-momentum timelike
+    abd = scri.AsymptoticBondiData(u, L)
+    abd.psi0, abd.psi1, abd.psi2, abd.psi3, abd.psi4, abd.sigma = raw
+    out = dict(u=u, raw=raw, ell_max=L)
+    out["mass_aspect"] = np.asarray(abd.mass_aspect()).view(np.ndarray)
+    out["mass_aspect_ell2"] = np.asarray(abd.mass_aspect(truncate_ell=2)).view(np.ndarray)
+    for name in ("bondi_rest_mass", "bondi_four_momentum", "bondi_angular_momentum", "bondi_boost_charge", "bondi_CoM_charge",
+                 "bondi_dimensionless_spin"):
+        out[name] = np.asarray(getattr(abd, name)())
+    np.savez_compressed(os.path.join(HERE, "g12_ref_bms_charges.npz"), source="/root/reference/scri (unmodified) on stand-ins", **out)
+
+
+def g13():
+    out = {}
+    for tag, lmin, lmax, dt, seed in (("a", 2, 6, scri.h, 131), ("b", 0, 4, scri.psi2, 132)):
+        n = 120
+        t = np.linspace(0.0, 30.0, n) + 0.04 * np.sin(np.arange(n))
+        data = synthetic.chirp_modes(t, lmin, lmax, seed) * (1 + 0.01 * t[:, None])
+        w = _wm(t, data, lmin, lmax, dt)
+        out[f"{tag}_t"], out[f"{tag}_data"], out[f"{tag}_ells"] = t, data, np.array([lmin, lmax])
+        out[f"{tag}_LdtVector"] = np.asarray(w.LdtVector())
+        out[f"{tag}_LLMatrix"] = np.asarray(w.LLMatrix())
+        out[f"{tag}_angular_velocity"] = np.asarray(w.angular_velocity())
+        out[f"{tag}_LLDominantEigenvector"] = np.asarray(w.LLDominantEigenvector())
+    np.savez_compressed(os.path.join(HERE, "g13_ref_mode_calculations.npz"), source="/root/reference/scri (unmodified) on stand-ins", **out)
+
+
 if __name__ == "__main__":
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
-        for f in ((g11,) if "--g11" in sys.argv else (g10, g8, g9, g11)):
+        only = [f for f in (g10, g8, g9, g11, g12, g13) if "--" + f.__name__ in sys.argv]
+        for f in only or (g10, g8, g9, g11, g12, g13):
             f()
             print("wrote", f.__name__)

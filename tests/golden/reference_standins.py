@@ -423,6 +423,65 @@ class Modes(np.ndarray):
                 out[..., self.index(ell, m)] = (-1.0) ** (self.s + m) * np.conj(a[..., self.index(ell, -m)])
         return self._with(out, -self.s)
 
+    # ---- what scri/asymptotic_bondi_data/bms_charges.py asks of sf.Modes beyond the above (third-party behaviour, restated)
+    @property
+    def eth_GHP(self):
+        return self._with(wigner.eth_GHP(self.view(np.ndarray), self.s, self.ell_min), self.s + 1)
+
+    @property
+    def ethbar_GHP(self):
+        return self._with(wigner.ethbar_GHP(self.view(np.ndarray), self.s, self.ell_min), self.s - 1)
+
+    def truncate_ell(self, new_ell_max):
+        """the modes l <= new_ell_max (a copy; more modes than present is an error in sf)"""
+        if new_ell_max >= self.ell_max:
+            return self
+        md = dict(self._metadata)
+        md["ell_max"] = int(new_ell_max)
+        out = np.array(self.view(np.ndarray)[..., : (new_ell_max + 1) ** 2 - self.ell_min**2]).view(type(self))
+        out._metadata = md
+        return out
+
+    def norm(self):
+        return np.linalg.norm(self.view(np.ndarray), axis=-1)
+
+    def multiply(self, other, truncator=None):
+        """sf.Modes.multiply: the exact product of two band-limited functions (Wigner-3j sums there; here both are put on a grid
+        that resolves the product, multiplied and analysed -- the same modes to rounding), truncated at truncator((l_a, l_b))."""
+        from oracle import modes_time_series_ref as mts_ref
+
+        if truncator is None:
+            truncator = self.multiplication_truncator
+        if self.ell_min != 0 or other.ell_min != 0:
+            raise NotImplementedError
+        out_ell = int(truncator((self.ell_max, other.ell_max)))
+        prod = mts_ref.grid_multiply(self.view(np.ndarray), self.s, self.ell_max, np.asarray(other).view(np.ndarray), other.s, other.ell_max,
+                                     working_ell_max=self.ell_max + other.ell_max, output_ell_max=min(out_ell, self.ell_max + other.ell_max))
+        md = dict(self._metadata)
+        md["spin_weight"] = self.s + other.s
+        md["ell_max"] = min(out_ell, self.ell_max + other.ell_max)
+        out = np.asarray(prod).view(type(self))
+        out._metadata = md
+        return out
+
+    def __mul__(self, other):
+        if isinstance(other, Modes):
+            return self.multiply(other)
+        return self._scaled_by(other)
+
+    def __rmul__(self, other):
+        return self._scaled_by(other)
+
+    def _scaled_by(self, other):
+        """sf.Modes times something that is not Modes: a scalar, or an array whose axes are the LEADING axes of the modes (the
+        mode axis is appended to it: `abd.t * modes` scales every time step, bms_charges.py:166)"""
+        o = np.asarray(other)
+        if o.ndim >= 1:
+            o = o[..., np.newaxis]
+        return self._with(self.view(np.ndarray) * o, self.s)
+
+    __array_priority__ = 100.0
+
     def evaluate(self, R):
         """Values at the rotors R (array of quaternions, any shape): shape self.shape[:-1] + R.shape."""
         a = self.view(np.ndarray)
@@ -459,6 +518,7 @@ def make_sf_module():
     m.eth_GHP = lambda modes, spin_weight=0, ell_min=0: wigner.eth_GHP(modes, spin_weight, ell_min)
     m.ethbar_GHP = lambda modes, spin_weight=0, ell_min=0: wigner.ethbar_GHP(modes, spin_weight, ell_min)
     m.SWSH_grid = SWSH_grid
+    m.ladder_operator_coefficient = lambda ell, m_: math.sqrt(ell * (ell + 1) - m_ * (m_ + 1))  # <l, m+1| L+ |l, m>
     m._Wigner_D_matrices = _Wigner_D_matrices
     m._linear_matrix_offset = wigner.linear_matrix_offset
     m.WignerD = WignerD
@@ -472,7 +532,7 @@ def make_spinsfast_module():
     m = _PermissiveModule("spinsfast")
     m.__path__ = []
     m.map2salm = lambda f, s, lmax: spinsfast_ref.map2salm(np.asarray(f).view(np.ndarray), s, lmax)
-    m.salm2map = lambda a, s, lmax, n_theta, n_phi: spinsfast_ref.salm2map(np.asarray(a).view(np.ndarray), s, lmax, n_theta, n_phi)
+    m.salm2map = lambda salm, s, lmax, Ntheta, Nphi: spinsfast_ref.salm2map(np.asarray(salm).view(np.ndarray), s, lmax, Ntheta, Nphi)
     m.N_lm = lambda lmax: (lmax + 1) ** 2
     return m
 

@@ -327,3 +327,77 @@ def test_g11_gpu_vs_reference_mode_operators(ctx, device):
         other = make(name, dt, lmin, lmax, "other")
         got = np.array([w.inner_product(other), w.inner_product(other, t1=2.0, t2=7.0)])
         assert np.abs(got - g[f"{name}_inner"]).max() < 1e-12 * np.abs(g[f"{name}_inner"]).max()
+
+
+# ---- g12: the Bondi charges computed by the reference's own scri/asymptotic_bondi_data/bms_charges.py:14-192
+def test_g12_oracle_vs_reference_charges():
+    from oracle import bms_charges_ref as cref
+
+    g = load("g12_ref_bms_charges.npz")
+    u, raw, L = g["u"], g["raw"], int(g["ell_max"])
+    psi1, psi2, sigma = raw[1], raw[2], raw[5]
+    tol = 2e-13
+    assert np.abs(cref.mass_aspect(u, psi2, sigma, L) - g["mass_aspect"]).max() < tol * np.abs(g["mass_aspect"]).max()
+    assert np.abs(cref.mass_aspect(u, psi2, sigma, 2) - g["mass_aspect_ell2"]).max() < tol * np.abs(g["mass_aspect"]).max()
+    P = cref.four_momentum(u, psi2, sigma)
+    assert np.abs(P - g["bondi_four_momentum"]).max() < tol * np.abs(P).max()
+    assert np.abs(np.sqrt(P[:, 0] ** 2 - (P[:, 1:] ** 2).sum(axis=1)) - g["bondi_rest_mass"]).max() < tol * np.abs(P).max()
+    assert np.abs(cref.angular_momentum(psi1, sigma) - g["bondi_angular_momentum"]).max() < tol
+    assert np.abs(cref.com_charge(psi1, sigma) - g["bondi_CoM_charge"]).max() < tol
+    assert np.abs(cref.boost_charge(u, psi1, psi2, sigma) - g["bondi_boost_charge"]).max() < 20 * tol * np.abs(g["bondi_boost_charge"]).max()
+    assert np.abs(cref.dimensionless_spin(u, psi1, psi2, sigma) - g["bondi_dimensionless_spin"]).max() < 1e-12
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("device", [False, True])
+def test_g12_gpu_vs_reference_charges(ctx, device):
+    import scri_amd
+
+    g = load("g12_ref_bms_charges.npz")
+    u, raw, L = g["u"], g["raw"], int(g["ell_max"])
+    a = scri_amd.AsymptoticBondiData(u, L, ctx=ctx)
+    a._raw_data[:] = raw
+    if device:
+        a = a.to_device()
+    tol = 5e-12
+    assert np.abs(np.asarray(a.mass_aspect().ndarray) - g["mass_aspect"]).max() < tol
+    assert np.abs(np.asarray(a.mass_aspect(2).ndarray) - g["mass_aspect_ell2"]).max() < tol
+    assert np.abs(a.bondi_four_momentum() - g["bondi_four_momentum"]).max() < tol
+    assert np.abs(a.bondi_rest_mass() - g["bondi_rest_mass"]).max() < tol
+    assert np.abs(a.bondi_angular_momentum() - g["bondi_angular_momentum"]).max() < tol
+    assert np.abs(a.bondi_CoM_charge() - g["bondi_CoM_charge"]).max() < tol
+    assert np.abs(a.bondi_boost_charge() - g["bondi_boost_charge"]).max() < 20 * tol
+    assert np.abs(a.bondi_dimensionless_spin() - g["bondi_dimensionless_spin"]).max() < 1e-9
+
+
+# ---- g13: LdtVector / LLMatrix / angular_velocity / LLDominantEigenvector by the reference's own scri/mode_calculations.py
+def test_g13_oracle_vs_reference_mode_calculations():
+    from oracle import mode_calculations_ref as mc
+
+    g = load("g13_ref_mode_calculations.npz")
+    for tag in ("a", "b"):
+        t, data = g[f"{tag}_t"], g[f"{tag}_data"]
+        lmin, lmax = (int(x) for x in g[f"{tag}_ells"])
+        dd = mc.data_dot(t, data)
+        ldt, ll = mc.LdtVector(data, dd, lmin, lmax), mc.LLMatrix(data, lmin, lmax)
+        assert np.abs(ldt - g[f"{tag}_LdtVector"]).max() < 1e-13 * np.abs(ldt).max()
+        assert np.abs(ll - g[f"{tag}_LLMatrix"]).max() < 1e-14 * np.abs(ll).max()
+        om = mc.angular_velocity(t, data, lmin, lmax)
+        assert np.abs(om - g[f"{tag}_angular_velocity"]).max() < 1e-11 * max(1.0, np.abs(om).max())
+
+
+@pytest.mark.gpu
+def test_g13_gpu_vs_reference_mode_calculations(ctx):
+    import scri_amd
+
+    g = load("g13_ref_mode_calculations.npz")
+    for tag, dt in (("a", scri_amd.h), ("b", scri_amd.psi2)):
+        t, data = g[f"{tag}_t"], g[f"{tag}_data"]
+        lmin, lmax = (int(x) for x in g[f"{tag}_ells"])
+        w = scri_amd.WaveformModes(t=t, data=data.copy(), ell_min=lmin, ell_max=lmax, dataType=dt, frameType=scri_amd.Inertial,
+                                   r_is_scaled_out=True, m_is_scaled_out=True, ctx=ctx)
+        assert np.abs(w.LdtVector() - g[f"{tag}_LdtVector"]).max() < 1e-11 * np.abs(g[f"{tag}_LdtVector"]).max()
+        assert np.abs(w.LLMatrix() - g[f"{tag}_LLMatrix"]).max() < 1e-13 * np.abs(g[f"{tag}_LLMatrix"]).max()
+        assert np.abs(w.angular_velocity() - g[f"{tag}_angular_velocity"]).max() < 1e-9 * max(1.0, np.abs(g[f"{tag}_angular_velocity"]).max())
+        got, expect = w.LLDominantEigenvector(), g[f"{tag}_LLDominantEigenvector"]
+        assert np.abs(got - expect).max() < 1e-9
