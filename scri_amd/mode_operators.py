@@ -338,3 +338,44 @@ class ModeOperators:
             "{} = {}.SI_units(current_unit_mass_in_solar_masses={}, distance_from_source_in_megaparsecs={})".format(
                 W, self, current_unit_mass_in_solar_masses, distance_from_source_in_megaparsecs))
         return W
+
+    # ------------------------------------------------------------------ pickling, printing (waveform_base.py:735-796)
+    def __getstate__(self):
+        """State for copy / pickle: the weights as a host array (a device-resident object is read back), no engine context (the
+        unpickled object takes the process-wide one on first use)"""
+        import copy
+
+        state = copy.deepcopy({k: v for k, v in self.__dict__.items() if k not in ("_ctx", "_dev", "_host")})  # (deep, as in the reference)
+        state["_host"] = self._dev.cpu().numpy() if self._dev is not None else np.array(self._host, copy=True)  # (the source stays where it is)
+        return state
+
+    def __setstate__(self, state):
+        from .waveform_modes import _next_num
+
+        old_num = state.get("num")
+        self.__dict__.update(state)
+        self._ctx, self._dev = None, None
+        _next_num[0] += 1
+        self.num = _next_num[0]  # every object keeps a number of its own
+        self.history = list(self.history)
+        self._append_history(f"copied, deepcopied, or unpickled as {self}")
+        self._append_history("{} = {}".format(self, f"{self}".replace(str(self.num), str(old_num))))
+
+    def __repr__(self):
+        from textwrap import dedent
+
+        opts = np.get_printoptions()
+        np.set_printoptions(threshold=6, linewidth=150, precision=6)
+        try:
+            rep = """
+             {0}(
+                 t={1},
+                 frame={2},
+                 data={3},
+                 frameType={4}, dataType={5},
+                 r_is_scaled_out={6}, m_is_scaled_out={7})  # num = {8}""".format(
+                type(self).__name__, str(self.t).replace("\n", "\n" + " " * 19), str(self.frame).replace("\n", "\n" + " " * 23),
+                str(self.data).replace("\n", "\n" + " " * 22), self.frameType, self.dataType, self.r_is_scaled_out, self.m_is_scaled_out, self.num)
+        finally:
+            np.set_printoptions(**opts)
+        return dedent(rep)

@@ -174,3 +174,23 @@ def test_descriptors_and_weights():
     assert w.is_valid
     c = w.deepcopy()
     assert c.num != w.num and np.array_equal(c.data, w.data) and c.data is not w.data and c.history[-1].endswith(".deepcopy()")
+
+
+def test_pickling_and_repr():
+    """tests/test_waveform.py:45-53 of the reference (an empty object) and the same for a waveform with data and a frame"""
+    import copy
+    import pickle
+
+    import scri_amd
+
+    W1 = scri_amd.WaveformModes()
+    W2 = pickle.loads(pickle.dumps(W1))
+    assert W1._allclose(W2, rtol=0, atol=0) and W2.num != W1.num
+    W = linear_waveform(n_times=50)
+    for clone in (pickle.loads(pickle.dumps(W)), copy.deepcopy(W), copy.copy(W)):
+        assert clone.num != W.num and W._allclose(clone, rtol=0, atol=0)
+        assert np.array_equal(clone.data, W.data) and np.array_equal(clone.frame, W.frame) and clone.data is not W.data
+        assert (clone.ell_min, clone.ell_max, clone.dataType, clone.frameType) == (W.ell_min, W.ell_max, W.dataType, W.frameType)
+        assert clone.history[: len(W.history)] == W.history and "unpickled as" in clone.history[len(W.history)]
+    text = repr(W)
+    assert text.strip().startswith("WaveformModes(") and f"# num = {W.num}" in text and "frameType=4, dataType=7" in text
