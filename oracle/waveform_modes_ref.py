@@ -218,3 +218,16 @@ def intersection(t1, t2, min_step=None, min_time=None, max_time=None):
         if t[I] > maxt:
             break
     return t[:I]
+
+
+def compare_data(w_b, w_a):
+    """The data half of WaveformBase.compare (scri/waveform_base.py:577-687): A - B on intersection(B.t, A.t), each mode through its
+    own real and imaginary CubicSpline (:675-683); returns (times, data)."""
+    times = intersection(w_b.t, w_a.t)
+    out = np.zeros((times.shape[0], w_a.data.shape[1]), dtype=complex)
+    for a_mode in range(w_a.data.shape[1]):
+        b_mode = a_mode  # same (l, m) order on both sides in the oracle's container
+        re_a, im_a = CubicSpline(w_a.t, w_a.data[:, a_mode].real), CubicSpline(w_a.t, w_a.data[:, a_mode].imag)
+        re_b, im_b = CubicSpline(w_b.t, w_b.data[:, b_mode].real), CubicSpline(w_b.t, w_b.data[:, b_mode].imag)
+        out[:, a_mode] = (re_a(times) - re_b(times)) + 1j * (im_a(times) - im_b(times))
+    return times, out

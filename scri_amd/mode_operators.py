@@ -379,3 +379,49 @@ class ModeOperators:
         finally:
             np.set_printoptions(**opts)
         return dedent(rep)
+
+    # ------------------------------------------------------------------ difference of two waveforms (waveform_base.py:577-687)
+    def compare(self, w_a, min_time_step=0.005, min_time=-3.0e300):
+        """A waveform holding A - B on the common time axis of the two (B = this object): the mode data of both are interpolated
+        there (not-a-knot cubic splines, on the GPU) and subtracted mode by mode, and `frame` is the rotation taking this frame
+        into A's, with the sign that keeps its mean rotor nearer to +1 than to -1."""
+        import warnings
+
+        from . import quaternions
+        from .waveform_modes import WaveformModes
+
+        if self.frameType != w_a.frameType:
+            warnings.warn("\nWarning:\n    This Waveform is in the " + self.frame_type_string + " frame,"
+                          "\n    The Waveform in the argument is in the " + w_a.frame_type_string + " frame."
+                          "\n    Comparing them probably does not make sense.\n")
+        if self.n_modes != w_a.n_modes:
+            raise Exception("Trying to compare waveforms with mismatched LM data.\nA.n_modes=" + str(w_a.n_modes) + "\tB.n_modes()=" + str(self.n_modes))
+        times = time_intersection(self.t, w_a.t)
+        # A's modes may come in another order: column of (l, m) in this object for every column of A
+        order = np.array([self.index(ell, m) for ell, m in w_a.LM], dtype=int)
+        data = engine.cubic_spline(w_a.t, w_a.data, times, ctx=self._ctx) - engine.cubic_spline(self.t, self.data[:, order], times, ctx=self._ctx)
+        fa, fb = np.asarray(w_a.frame, dtype=float).reshape(-1, 4), np.asarray(self.frame, dtype=float).reshape(-1, 4)
+        at = lambda f, t: quaternions.squad(f, t, times) if f.shape[0] > 1 else f  # noqa: E731
+        if fa.shape[0] >= 1 and fb.shape[0] >= 1:
+            frame = quaternions.multiply(at(fa, w_a.t), quaternions.conjugate(at(fb, self.t)) / np.sum(at(fb, self.t) ** 2, axis=-1, keepdims=True))
+        elif fb.shape[0] >= 1:
+            B = at(fb, self.t)
+            frame = quaternions.conjugate(B) / np.sum(B**2, axis=-1, keepdims=True)
+        elif fa.shape[0] >= 1:
+            frame = at(fa, w_a.t)
+        else:
+            frame = np.zeros((0, 4))
+        frame = np.atleast_2d(frame)
+        if frame.shape[0] == times.shape[0] and frame.shape[0] > 1:
+            # mean rotor in the chordal metric: the normalised time integral of the rotor series
+            mean = engine.spline_derivative(times, frame.astype(complex), times[-1:], order=-1, ctx=self._ctx).real[0]
+            if mean[0] < 0:  # nearer to -1 than to +1: |R + 1| < |R - 1|
+                frame = -frame
+        elif frame.shape[0] == 1 and frame[0, 0] < 0:
+            frame = -frame
+        W = WaveformModes(t=times, data=data, history=[], frame=frame, frameType=self.frameType, dataType=self.dataType,
+                          r_is_scaled_out=self.r_is_scaled_out, m_is_scaled_out=self.m_is_scaled_out, ell_min=w_a.ell_min, ell_max=w_a.ell_max,
+                          ctx=self._ctx)
+        W.history += ["B.compare(A)\n", "### A.history.str():\n" + "".join(w_a.history), "### B.history.str():\n" + "".join(self.history),
+                      "### End of old histories from `compare`"]
+        return W

@@ -168,3 +168,45 @@ def test_norm_on_the_gpu_adds_in_the_reference_order(ctx, n, ell_min, ell_max):
     wide = torch.full((n, nm + 5), float("nan"), dtype=torch.complex128, device="cuda")
     wide[:, :nm] = torch.from_numpy(data).cuda()
     assert np.array_equal(engine.row_norm(None, ctx=ctx, device_tensor=wide[:, :nm]), expect)
+
+
+def test_compare_two_waveforms(ctx):
+    """WaveformBase.compare (scri/waveform_base.py:577-687): A - B on the common time axis; the frame takes B's into A's"""
+    import scri_amd
+    from oracle import quat
+    from scri_amd import quaternions
+
+    oa = random_waveform(dataType=h, ell_max=5, n=70, seed=1)
+    ob = random_waveform(dataType=h, ell_max=5, n=55, seed=2)
+    ob = WM(t=np.linspace(0.5, 9.0, 55), data=ob.data, ell_min=2, ell_max=5, dataType=h, frame=ob.frame)
+    # smooth data (a random series is no test of an interpolant): low-order polynomials in t with random coefficients
+    ca, cb = oa.data[:4], ob.data[:4]
+    oa = WM(t=oa.t, data=sum(ca[k][None, :] * (oa.t[:, None] / 10.0) ** k for k in range(4)), ell_min=2, ell_max=5, dataType=h, frame=oa.frame)
+    ob = WM(t=ob.t, data=sum(cb[k][None, :] * (ob.t[:, None] / 10.0) ** k for k in range(4)), ell_min=2, ell_max=5, dataType=h, frame=ob.frame)
+    times, expect = ref.compare_data(ob, oa)
+    A, B = gpu(oa, ctx), gpu(ob, ctx)
+    C = B.compare(A)
+    assert np.array_equal(C.t, times) and (C.ell_min, C.ell_max, C.dataType) == (2, 5, B.dataType)
+    assert np.abs(C.data - expect).max() < 1e-12 * np.abs(expect).max()
+    assert "B.compare(A)\n" in C.history and C.history[-1] == "### End of old histories from `compare`"
+    # frames: a smooth rotor series on either side; C.frame * B(t) = A(t) (up to the overall sign the method fixes)
+    ta, tb = oa.t, ob.t
+    fa = np.stack([np.cos(0.1 * ta), np.sin(0.1 * ta) * 0.6, np.sin(0.1 * ta) * 0.8, 0 * ta], axis=1)
+    fb = np.stack([np.cos(0.07 * tb + 0.2), 0 * tb, np.sin(0.07 * tb + 0.2), 0 * tb], axis=1)
+    A.frame, B.frame = fa, fb
+    C = B.compare(A)
+    Ai, Bi = quaternions.squad(fa, ta, times), quaternions.squad(fb, tb, times)
+    assert C.frame.shape == (times.size, 4)
+    back = quaternions.multiply(C.frame, Bi)
+    assert min(np.abs(back - Ai).max(), np.abs(back + Ai).max()) < 1e-12
+    assert np.mean(C.frame[:, 0]) > 0
+    A.frame, B.frame = fa[:1], fb[:1]
+    C = B.compare(A)
+    q = quat.qmul(fa[0], quat.qinverse(fb[0]))
+    assert C.frame.shape == (1, 4) and np.abs(C.frame[0] - (q if q[0] >= 0 else -q)).max() < 1e-14
+    with pytest.raises(Exception, match="mismatched LM data"):
+        B.compare(gpu(random_waveform(dataType=h, ell_max=4, n=70), ctx))
+    with pytest.warns(UserWarning, match="Comparing them probably does not make sense"):
+        other = gpu(oa, ctx)
+        other.frameType = scri_amd.Corotating
+        B.compare(other)
