@@ -37,6 +37,58 @@ def D_inverse(h, ell_max):
     return np.asarray(h) * _ell_factors(ell_max, lambda l: 0.0 if l < 2 else 4.0 / ((l + 2) * (l + 1) * l * (l - 1)))
 
 
+# the reference's names for the two operators (map_to_superrest_frame.py:76,95; used by bms_charges.py:111)
+𝔇 = D_operator
+𝔇inverse = D_inverse
+
+
+def MT_to_WM(h_mts, sxs_version=False, dataType=None):
+    """A ModesTimeSeries as a WaveformModes (map_to_superrest_frame.py:18-52): the modes from l = |s| on, Inertial frame, r and M
+    scaled out, data type `dataType` (default h).  The sxs flavour needs the `sxs` package, which this image lacks."""
+    from . import WaveformModes, Inertial, h
+
+    if sxs_version:
+        raise NotImplementedError("sxs.WaveformModes objects need the sxs package")
+    s = abs(h_mts.s)
+    return WaveformModes(t=np.asarray(h_mts.t), data=np.array(h_mts)[:, LM_index(s, -s, 0):], ell_min=s, ell_max=h_mts.ell_max, frameType=Inertial,
+                         dataType=h if dataType is None else dataType, r_is_scaled_out=True, m_is_scaled_out=True, ctx=getattr(h_mts, "_ctx", None))
+
+
+def WM_to_MT(h_wm):
+    """A WaveformModes as a ModesTimeSeries with the same l range (map_to_superrest_frame.py:55-73), products truncated at max"""
+    from .modes_time_series import ModesTimeSeries
+
+    return ModesTimeSeries(np.array(h_wm.data), h_wm.t, spin_weight=h_wm.spin_weight, ell_min=h_wm.ell_min, ell_max=h_wm.ell_max,
+                           multiplication_truncator=max)
+
+
+def time_translation(abd, t_0=0):
+    """A copy of `abd` on the time axis t - t_0 (map_to_superrest_frame.py:666-684: the fields carry their own time axis, so
+    shifting `abd.t` of a plain copy would leave theirs behind)"""
+    out = abd.copy()
+    out.t = out.t - t_0
+    return out
+
+
+def rotation(abd, phi=0):
+    """`abd` with the physical system turned by -phi about z (map_to_superrest_frame.py:687-717): every field goes through
+    WaveformModes.rotate_physical_system -- for a rotation the detour of the reference through h = 2 sigma-bar and the
+    Newman-Penrose factors drops out (conjugation of the field commutes with turning it), so the six fields are rotated as they
+    are, by one constant-rotor kernel launch each; much cheaper than abd.transform()."""
+    from . import WaveformModes, Inertial, psi2
+    from .rotations import rotate_physical_system
+
+    q = np.array([math.cos(-phi / 2.0), 0.0, 0.0, math.sin(-phi / 2.0)])  # quaternion.from_rotation_vector(-phi z)
+    out = abd.copy()
+    for name in ("psi0", "psi1", "psi2", "psi3", "psi4", "sigma"):
+        field = getattr(abd, name)
+        w = WaveformModes(t=abd.t, data=np.array(field.ndarray), ell_min=0, ell_max=abd.ell_max, frameType=Inertial, dataType=psi2,
+                          r_is_scaled_out=True, m_is_scaled_out=True, ctx=getattr(abd, "_ctx", None))
+        rotate_physical_system(w, q)
+        setattr(out, name, w.data)
+    return out
+
+
 def _to_grid(modes, ell_max, ctx=None):
     n = 2 * ell_max + 1
     return engine.salm2map(modes, 0, ell_max, n, n, ctx=ctx)
