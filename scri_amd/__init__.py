@@ -36,6 +36,7 @@ from . import engine  # noqa: E402,F401
 from .waveform_modes import WaveformModes  # noqa: E402,F401
 from .waveform_grid import WaveformGrid  # noqa: E402,F401
 from .rotations import rotate_decomposition_basis, rotate_physical_system, to_inertial_frame, to_corotating_frame, to_coprecessing_frame  # noqa: E402,F401
+from .rotations import get_alignment_of_decomposition_frame_to_modes, align_decomposition_frame_to_modes  # noqa: E402,F401
 from .asymptotic_bondi_data import AsymptoticBondiData  # noqa: E402,F401
 from . import bms_transformations  # noqa: E402,F401
 from . import mode_calculations  # noqa: E402,F401
@@ -50,6 +51,8 @@ WaveformModes.rotate_physical_system = rotate_physical_system
 WaveformModes.to_inertial_frame = to_inertial_frame
 WaveformModes.to_corotating_frame = to_corotating_frame
 WaveformModes.to_coprecessing_frame = to_coprecessing_frame
+WaveformModes.get_alignment_of_decomposition_frame_to_modes = get_alignment_of_decomposition_frame_to_modes
+WaveformModes.align_decomposition_frame_to_modes = align_decomposition_frame_to_modes
 
 
 def patch_scri(scri=None, ctx=None):

@@ -26,6 +26,11 @@ def LdtVector(W):
 
 def LLMatrix(W):
     r"""<LL>^{ab} = Re \sum \bar f^{l,m'} <l,m'|L_a L_b|l,m> f^{l,m}; [n_times, 3, 3]"""
+    n = W.n_times
+    if 0 < n < 4:
+        # the kernel also forms <Ldt>, whose spline needs four samples; <LL> needs none: pad the series with copies of its last row
+        data = np.concatenate([W.data, np.repeat(W.data[-1:], 4 - n, axis=0)], axis=0)
+        return engine.angular_velocity(np.arange(4.0), data, W.ell_min, W.ell_max, ctx=getattr(W, "_ctx", None), parts=True)[1][:n]
     return _parts(W)[1]
 
 

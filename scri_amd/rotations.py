@@ -126,3 +126,70 @@ def to_corotating_frame(W, R0=(1.0, 0.0, 0.0, 0.0), tolerance=1e-12, z_alignment
     W.frameType = Corotating
     out = (W,) + ((omega,) if return_omega else ()) + ((log_frame,) if truncate_log_frame else ())
     return out if len(out) > 1 else W
+
+
+def _qvec(v):
+    return np.array([0.0, v[0], v[1], v[2]])
+
+
+def _qinv(q):
+    return quaternions.conjugate(q) / np.sum(np.asarray(q, dtype=float) ** 2)
+
+
+def get_alignment_of_decomposition_frame_to_modes(w, t_fid, nHat_t_fid=(0.0, 1.0, 0.0, 0.0), ell_max=None):
+    """The constant rotor R_eps that fixes the attitude of a corotating (coprecessing, coorbital) frame at the fiducial time
+    (scri/rotations.py:114-225): the frame's z axis onto the dominant eigenvector of <LL> (on the side of the angular velocity),
+    the phase of the (2, +-2) modes to zero, x nearer to `nHat_t_fid` than to its opposite.  Found, not applied."""
+    from . import Coprecessing, Coorbital, Corotating
+    from .mode_calculations import angular_velocity, LLDominantEigenvector
+
+    if ell_max is None:
+        ell_max = w.ell_max
+    if w.frameType not in [Coprecessing, Coorbital, Corotating]:
+        raise ValueError(
+            "get_alignment_of_decomposition_frame_to_modes only takes Waveforms in the coprecessing, coorbital, or corotating frames.  "
+            "This Waveform is in the '{0}' frame.".format(w.frame_type_string))
+    if w.frame.shape[0] != w.n_times:
+        raise ValueError(
+            "get_alignment_of_decomposition_frame_to_modes requires full information about the Waveform's frame."
+            "This Waveform has {0} time steps, but only {1} rotors in its frame.".format(w.n_times, w.frame.shape[0]))
+    if t_fid < w.t[0] or t_fid > w.t[-1]:
+        raise ValueError("The requested alignment time t_fid={0} is outside the range of times in this waveform ({1}, {2}).".format(t_fid, w.t[0], w.t[-1]))
+    nHat = np.asarray(quaternions.as_float_array(nHat_t_fid), dtype=float).reshape(4)
+    # direction of the angular velocity near t_fid: an 11-sample window of the l = 2 modes, back in the inertial frame
+    i_fid = int(np.nonzero(w.t <= t_fid)[0][-1])
+    if i_fid < w.t.size - 1:
+        i_fid += 1
+    i1 = max(i_fid - 5, 0)
+    i2 = w.t.size if i1 + 11 > w.t.size else i1 + 11
+    region = w[i1:i2, 2].copy().to_inertial_frame()
+    omega = _qvec(angular_velocity(region)[i_fid - i1])
+    omega /= np.linalg.norm(omega)
+    # ... as seen from this waveform's frame
+    R = w.frame[i_fid] if w.frame.shape[0] > 1 else w.frame[0]
+    omega = quaternions.multiply(quaternions.multiply(_qinv(R), omega), R)
+    instant = w[i1:i2].copy().interpolate(np.array([t_fid]))
+    R_f0 = instant.frame[0]
+    V_f = _qvec(LLDominantEigenvector(instant[:, : ell_max + 1])[0])
+    V_f /= np.linalg.norm(V_f)
+    if np.dot(omega[1:], V_f[1:]) < 0:
+        V_f = -V_f
+    z = np.array([0.0, 0.0, 0.0, 1.0])
+    R_V_f = quaternions.sqrt(quaternions.multiply(-V_f, z))  # takes z onto V_f
+    instant.rotate_decomposition_basis(R_V_f)
+    d22, d2m2 = instant.data[0, instant.index(2, 2)], instant.data[0, instant.index(2, -2)]
+    phase = np.arctan2(d22.imag, d22.real) - np.arctan2(d2m2.imag, d2m2.real)
+    R_eps = quaternions.multiply(R_V_f, quaternions.exp(np.array([0.0, 0.0, 0.0, -phase / 8.0])))
+    total = quaternions.multiply(R_f0, R_eps)
+    x_axis = quaternions.multiply(quaternions.multiply(total, np.array([0.0, 1.0, 0.0, 0.0])), _qinv(total))
+    if np.dot(nHat[1:], x_axis[1:]) < 0:
+        R_eps = quaternions.multiply(R_eps, quaternions.exp(np.array([0.0, 0.0, 0.0, np.pi / 2.0])))
+    return R_eps
+
+
+def align_decomposition_frame_to_modes(w, t_fid, nHat_t_fid=(0.0, 1.0, 0.0, 0.0), ell_max=None):
+    """Fix the attitude of the corotating frame (scri/rotations.py:228-265): a corotating frame is defined up to a constant rotor
+    on the right; this one puts z along the dominant eigenvector of <LL> at t_fid and the (2, 2) phase to zero."""
+    R_eps = get_alignment_of_decomposition_frame_to_modes(w, t_fid, nHat_t_fid, ell_max)
+    w._append_history("{0}.align_decomposition_frame_to_modes({1}, {2}, {3})  # R_eps={4}".format(w, t_fid, nHat_t_fid, ell_max, R_eps))
+    return w.rotate_decomposition_basis(R_eps)

@@ -187,3 +187,46 @@ def test_frame_velocity_and_truncated_log_frame(ctx):
     total = w.angular_velocity(include_frame_velocity=True)
     assert np.allclose(total[50:-50], [0.0, 0.0, omega], atol=1e-7)
     assert np.allclose(total_before, [0.0, 0.0, omega], atol=1e-9, rtol=3e-7)
+
+
+def test_align_decomposition_frame_to_modes(ctx):
+    """scri/rotations.py:114-265 (no test in the reference): after the alignment the decomposition frame at t_fid has its z axis
+    along the dominant eigenvector of <LL> on the side of the angular velocity, the (2, 2) and (2, -2) phases cancel, and x is
+    nearer to the given direction than to its opposite; the rotor is a constant right factor of the frame."""
+    import scri_amd
+    from scri_amd import quaternions
+
+    n = 400
+    t = np.linspace(0.0, 40.0, n)
+    LM = np.array([[l, m] for l in range(2, 5) for m in range(-l, l + 1)])
+    rng = np.random.default_rng(8)
+    amp = (rng.normal(size=LM.shape[0]) + 1j * rng.normal(size=LM.shape[0])) * 0.02
+    amp[(LM[:, 0] == 2) & (LM[:, 1] == 2)] = 1.0 + 0.3j
+    amp[(LM[:, 0] == 2) & (LM[:, 1] == -2)] = 1.0 - 0.3j
+    data = amp[None, :] * np.exp(-1j * LM[None, :, 1] * (0.4 * t + 0.002 * t**2)[:, None])
+    w = scri_amd.WaveformModes(t=t, data=data, ell_min=2, ell_max=4, dataType=scri_amd.h, frameType=scri_amd.Inertial, r_is_scaled_out=True,
+                               m_is_scaled_out=True, ctx=ctx)
+    tilt = np.array([np.cos(0.35), np.sin(0.35) * 0.6, np.sin(0.35) * 0.8, 0.0])
+    w.rotate_decomposition_basis(tilt)  # the orbital axis is no longer z
+    w.frame = np.zeros((0, 4))  # ... and that is the inertial frame we start from
+    w.to_corotating_frame()
+    before_frame = w.frame.copy()
+    t_fid = 17.3
+    with pytest.raises(ValueError, match="outside the range"):
+        w.get_alignment_of_decomposition_frame_to_modes(100.0)
+    R_eps = w.get_alignment_of_decomposition_frame_to_modes(t_fid)
+    assert abs(np.linalg.norm(R_eps) - 1.0) < 1e-13
+    w.align_decomposition_frame_to_modes(t_fid)
+    assert np.abs(w.frame - quaternions.multiply(before_frame, R_eps)).max() < 1e-13
+    inst = w.copy().interpolate(np.array([t_fid]))
+    V = inst.LLDominantEigenvector()[0]
+    assert abs(abs(V[2]) - 1.0) < 1e-9 and np.hypot(V[0], V[1]) < 1e-4  # z of the aligned frame
+    d22, d2m2 = inst.data[0, inst.index(2, 2)], inst.data[0, inst.index(2, -2)]
+    dphi = np.angle(d22) - np.angle(d2m2)
+    assert abs((dphi + np.pi) % (2 * np.pi) - np.pi) < 1e-7  # the two phases cancel (a quarter turn about z moves both by pi)
+    Rf = inst.frame[0]
+    x_axis = quaternions.multiply(quaternions.multiply(Rf, np.array([0.0, 1.0, 0.0, 0.0])), quaternions.conjugate(Rf))
+    assert x_axis[1] > 0  # nearer to +x than to -x
+    inertial = scri_amd.WaveformModes(t=t, data=data, ell_min=2, ell_max=4, dataType=scri_amd.h, frameType=scri_amd.Inertial, ctx=ctx)
+    with pytest.raises(ValueError, match="only takes Waveforms in the"):
+        inertial.get_alignment_of_decomposition_frame_to_modes(t_fid)
