@@ -74,15 +74,15 @@ class ModeOperators:
         ell, m = self._columns()
         return (ell * (ell + 1) - self.ell_min**2 - m).astype(np.int32)
 
-    def _mode_map(self, idx_a, coef_a, conj_a=False, idx_b=None, coef_b=None, conj_b=False):
-        """out[t, j] = coef_a[j] op(data[t, idx_a[j]]) + coef_b[j] op(data[t, idx_b[j]]) as a host array (a device-resident
-        object is read where it lives)"""
+    def _mode_map(self, idx_a, coef_a, conj_a=False, idx_b=None, coef_b=None, conj_b=False, stay=False):
+        """out[t, j] = coef_a[j] op(data[t, idx_a[j]]) + coef_b[j] op(data[t, idx_b[j]]): a host array -- or, for a device-resident
+        object with stay=True, the device tensor (the object is read where it lives either way)"""
         if self.is_device_resident:
             from .device_series import DeviceModesTimeSeries
 
             d = DeviceModesTimeSeries(self._dev, self.t, self.spin_weight if abs(self.spin_weight) < 100 else 0, self.ell_min, self.ell_max, ctx=self._ctx)
             out = d._map(len(idx_a), idx_a, coef_a, conj_a, other=d if idx_b is not None else None, idx_b=idx_b, coef_b=coef_b, conj_b=conj_b)
-            return out.cpu().numpy()
+            return out if stay else out.cpu().numpy()
         b = self.data if idx_b is not None else None
         return engine.mode_map(self.data, idx_a, coef_a, conj_a, b, idx_b, coef_b, conj_b, ctx=self._ctx)
 
@@ -147,13 +147,16 @@ class ModeOperators:
         idx, sign = self._parity_tables(direction)
         n = idx.size
         if part == "conjugate":
-            data = self._mode_map(idx, sign.astype(complex), conj_a=True)
+            data = self._mode_map(idx, sign.astype(complex), conj_a=True, stay=True)
         else:
             half = 0.5 if part == "symmetric_part" else -0.5
-            data = self._mode_map(np.arange(n, dtype=np.int32), np.full(n, 0.5 + 0j), False, idx, (half * sign).astype(complex), True)
+            data = self._mode_map(np.arange(n, dtype=np.int32), np.full(n, 0.5 + 0j), False, idx, (half * sign).astype(complex), True, stay=True)
         W = self.copy_without_data()
         W.t = self.t.copy()
-        W.data = data
+        if isinstance(data, np.ndarray):
+            W.data = data
+        else:  # the result of a device-resident object stays in HBM
+            W._host, W._dev = None, data
         W.frame = self.frame * np.asarray(_FRAME[part][direction], dtype=float)[None, :]
         W._append_history(f"{W} = {self}.{direction}parity_{part}")
         return W
@@ -195,7 +198,11 @@ class ModeOperators:
         coef_a = np.where(m == 0, 1.0, r).astype(complex)
         idx_b = np.where(m > 0, partner, np.where(m < 0, own, -1)).astype(np.int32)  # the m < 0 member, conjugated
         coef_b = np.where(m > 0, r, np.where(m < 0, -r, 0.0)).astype(complex)
-        self.data = self._mode_map(idx_a, coef_a, False, idx_b, coef_b, True)
+        out = self._mode_map(idx_a, coef_a, False, idx_b, coef_b, True, stay=True)
+        if isinstance(out, np.ndarray):
+            self.data = out
+        else:
+            self._host, self._dev = None, out
         self._append_history(f"{self}.convert_to_conjugate_pairs()")
 
     def convert_from_conjugate_pairs(self):

@@ -30,6 +30,7 @@ def test_parity_operators_equal_the_oracle_bit_for_bit(ctx, dataType, device):
         for part, fn in (("conjugate", ref.parity_conjugate), ("symmetric_part", ref.parity_symmetric_part),
                          ("antisymmetric_part", ref.parity_antisymmetric_part)):
             got = getattr(w, f"{d}parity_{part}")
+            assert got.is_device_resident == device  # a device-resident object's results stay in HBM
             expect = fn(o, d.rstrip("_"))
             assert np.array_equal(got.data, expect.data), (d, part)
             assert np.array_equal(got.frame, expect.frame) and np.array_equal(got.t, o.t)
@@ -101,9 +102,12 @@ def test_eth_and_ladder_factors(ctx, dataType, device):
 
 def test_conjugate_pairs_truncate_and_inner_product(ctx):
     o = random_waveform(dataType=h, ell_max=6, n=60)
+    expect = ref.convert_to_conjugate_pairs(o)
+    wd = gpu(o, ctx, device=True)
+    wd.convert_to_conjugate_pairs()
+    assert wd.is_device_resident and np.abs(wd.data - expect.data).max() < 4e-16 * np.abs(o.data).max()
     w = gpu(o, ctx)
     w.convert_to_conjugate_pairs()
-    expect = ref.convert_to_conjugate_pairs(o)
     assert np.abs(w.data - expect.data).max() < 4e-16 * np.abs(o.data).max()
     assert np.allclose(w.norm(), ref.norm(o), rtol=1e-14, atol=0)
     w.convert_from_conjugate_pairs()
