@@ -508,6 +508,19 @@ def theta_phi(n_theta, n_phi):
                      for th in np.linspace(0.0, np.pi, num=n_theta, endpoint=True)])
 
 
+_CG_CACHE = {}
+
+
+def _clebsch_gordan(j1, m1, j2, m2, j3, m3):
+    """sf.clebsch_gordan(j_1, m_1, j_2, m_2, j_3, m_3) = <j1 m1 j2 m2 | j3 m3> (Condon-Shortley), here from sympy's exact value"""
+    key = (j1, m1, j2, m2, j3, m3)
+    if key not in _CG_CACHE:
+        from sympy.physics.quantum.cg import CG
+
+        _CG_CACHE[key] = float(CG(j1, m1, j2, m2, j3, m3).doit()) if abs(m1) <= j1 and abs(m2) <= j2 and abs(m3) <= j3 else 0.0
+    return _CG_CACHE[key]
+
+
 def make_sf_module():
     m = _PermissiveModule("spherical_functions")
     m.__path__ = []
@@ -519,6 +532,7 @@ def make_sf_module():
     m.ethbar_GHP = lambda modes, spin_weight=0, ell_min=0: wigner.ethbar_GHP(modes, spin_weight, ell_min)
     m.SWSH_grid = SWSH_grid
     m.ladder_operator_coefficient = lambda ell, m_: math.sqrt(ell * (ell + 1) - m_ * (m_ + 1))  # <l, m+1| L+ |l, m>
+    m.clebsch_gordan = _clebsch_gordan
     m._Wigner_D_matrices = _Wigner_D_matrices
     m._linear_matrix_offset = wigner.linear_matrix_offset
     m.WignerD = WignerD
@@ -551,6 +565,7 @@ def install():
         return lambda f: f
 
     numba.njit = numba.jit = njit
+    numba.complex128, numba.float64, numba.int64 = np.complex128, np.float64, np.int64  # (dtype arguments of np.zeros in scri/flux.py)
     sys.modules["numba"] = numba
     q = make_quaternion_module()
     sys.modules["quaternion"] = q
