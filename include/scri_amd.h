@@ -277,7 +277,8 @@ int bms_row_norm(bms_ctx* ctx, const void* data, int64_t ld, int64_t n_rows, int
 /* ModesTimeSeries.grid_multiply (scri/modes_time_series.py:142-202): modes a (spin_a, l = 0..ell_max_a,
  * c16[n_times][(ell_max_a+1)^2]) and b likewise are evaluated on the (2 working_ell_max + 1)^2 equiangular grid
  * (spinsfast.salm2map), multiplied there, and the product is analysed (map2salm, spin spin_a + spin_b) into
- * out c16[n_times][(output_ell_max+1)^2]. */
+ * out c16[n_times][(output_ell_max+1)^2].  Spin weights of the factors and of the product up to +-4 (the boost flux of
+ * scri/flux.py multiplies ethbar h, s = -3, with its conjugate). */
 int bms_grid_multiply(bms_ctx* ctx, const void* a, int spin_a, int ell_max_a, const void* b, int spin_b, int ell_max_b, int mem,
                       int64_t n_times, int working_ell_max, int output_ell_max, void* out);
 

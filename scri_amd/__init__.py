@@ -44,6 +44,8 @@ from .modes_time_series import ModesTimeSeries  # noqa: E402,F401
 from . import file_io  # noqa: E402,F401
 from .file_io import create_abd_from_h5, create_abd_from_waveforms  # noqa: E402,F401
 from .bms_transformations import LorentzTransformation, BMSTransformation  # noqa: E402,F401
+from . import flux  # noqa: E402,F401
+from .flux import energy_flux, momentum_flux, angular_momentum_flux, boost_flux, poincare_fluxes  # noqa: E402,F401
 
 # Same grafting the reference performs at import (scri/__init__.py:140-142)
 WaveformModes.rotate_decomposition_basis = rotate_decomposition_basis
@@ -52,6 +54,11 @@ WaveformModes.to_inertial_frame = to_inertial_frame
 WaveformModes.to_corotating_frame = to_corotating_frame
 WaveformModes.to_coprecessing_frame = to_coprecessing_frame
 WaveformModes.get_alignment_of_decomposition_frame_to_modes = get_alignment_of_decomposition_frame_to_modes
+WaveformModes.energy_flux = energy_flux
+WaveformModes.momentum_flux = momentum_flux
+WaveformModes.angular_momentum_flux = angular_momentum_flux
+WaveformModes.boost_flux = boost_flux
+WaveformModes.poincare_fluxes = poincare_fluxes
 WaveformModes.align_decomposition_frame_to_modes = align_decomposition_frame_to_modes
 
 

@@ -2587,8 +2587,9 @@ extern "C" int bms_grid_multiply(bms_ctx* c, const void* a, int spin_a, int ell_
   HIP_TRY(c, hipSetDevice(c->device));
   if (ell_max_a < 0 || ell_max_b < 0 || working_ell_max < 1 || output_ell_max < 0 || output_ell_max > working_ell_max)
     return fail(c, BMS_ERR_INVALID, "bad l ranges (need 0 <= output_ell_max <= working_ell_max)");
-  if (std::abs(spin_a) > 2 || std::abs(spin_b) > 2 || std::abs(spin_a + spin_b) > 4)
-    return fail(c, BMS_ERR_UNSUPPORTED, "spin weights beyond +-2 are not supported");
+  // (factors up to |s| = 4, as bms_salm2map / bms_map2salm take them: the boost flux multiplies ethbar h, s = -3)
+  if (std::abs(spin_a) > 4 || std::abs(spin_b) > 4 || std::abs(spin_a + spin_b) > 4)
+    return fail(c, BMS_ERR_UNSUPPORTED, "spin weights beyond +-4 are not supported");
   if (n_times <= 0) return BMS_OK;
   // A grid that resolves the product (band limit B = l_a + l_b <= working_ell_max) gives the modes l <= output_ell_max exactly
   // (up to rounding) as soon as 2 W + 1 > B + output_ell_max and 2 W - 1 >= B -- phi sampling and the extended theta transform of

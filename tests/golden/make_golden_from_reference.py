@@ -28,6 +28,10 @@ quaternion, spherical_functions, spinsfast) and writes
                             LLMatrix, angular_velocity, LLDominantEigenvector -- the reference's loops; the ladder coefficient
                             sqrt(l(l+1) - m(m+1)) and scipy's spline (data_dot) are third party.
 
+  g14_ref_fluxes.npz        scri/flux.py:182-798 on a chirp with all modes l = 2..5 (N = 64): energy, momentum, angular-momentum and boost
+                            flux, poincare_fluxes, and single expectation values <a|p_z|b>, <a|p_+|b>, <a|p_-|b> (s = -1, -2, -3) --
+                            the reference's matrix elements and loops; Clebsch-Gordan coefficients from sympy (third party).
+
 Only the .npz files travel; tests/test_golden.py checks the oracle (CPU) and the HIP path (GPU) against them.
 """
 import os
@@ -203,10 +207,39 @@ def g13():
     np.savez_compressed(os.path.join(HERE, "g13_ref_mode_calculations.npz"), source="/root/reference/scri (unmodified) on stand-ins", **out)
 
 
+def g14():
+    import functools
+
+    import scri.flux as flux
+
+    n, lmin, lmax = 64, 2, 5
+    t = np.linspace(3.0, 35.0, n) + 0.05 * np.sin(np.arange(n))
+    data = synthetic.chirp_modes(t, lmin, lmax, 141) * (1 + 0.01 * t[:, None])
+    h = _wm(t, data, lmin, lmax, scri.h)
+    out = dict(t=t, data=data, ells=np.array([lmin, lmax]))
+    out["energy_flux"] = flux.energy_flux(h)
+    out["momentum_flux"] = flux.momentum_flux(h)
+    out["angular_momentum_flux"] = flux.angular_momentum_flux(h)
+    out["boost_flux"] = flux.boost_flux(h)
+    e, p, j, b = flux.poincare_fluxes(h)
+    out.update(poincare_e=e, poincare_p=p, poincare_j=j, poincare_b=b)
+    hdot = h.copy()
+    hdot.dataType = scri.hdot
+    hdot.data = h.data_dot
+    out["hdot"] = hdot.data
+    # single expectation values: a = hdot-like, b = h-like objects of spin s (the data are just numbers here)
+    for s in (-1, -2, -3):
+        for name, gen in (("p_z", flux.p_z), ("p_plus", flux.p_plus), ("p_minus", flux.p_minus)):
+            out[f"{name}_s{-s}"] = flux.matrix_expectation_value(hdot, functools.partial(gen, s=s), h)[1]
+    for name, gen in (("j_z", flux.j_z), ("j_plus", flux.j_plus), ("j_minus", flux.j_minus)):
+        out[name] = flux.matrix_expectation_value(hdot, gen, h)[1]
+    np.savez_compressed(os.path.join(HERE, "g14_ref_fluxes.npz"), source="/root/reference/scri (unmodified) on stand-ins", **out)
+
+
 if __name__ == "__main__":
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
-        only = [f for f in (g10, g8, g9, g11, g12, g13) if "--" + f.__name__ in sys.argv]
-        for f in only or (g10, g8, g9, g11, g12, g13):
+        only = [f for f in (g10, g8, g9, g11, g12, g13, g14) if "--" + f.__name__ in sys.argv]
+        for f in only or (g10, g8, g9, g11, g12, g13, g14):
             f()
             print("wrote", f.__name__)

@@ -401,3 +401,49 @@ def test_g13_gpu_vs_reference_mode_calculations(ctx):
         assert np.abs(w.angular_velocity() - g[f"{tag}_angular_velocity"]).max() < 1e-9 * max(1.0, np.abs(g[f"{tag}_angular_velocity"]).max())
         got, expect = w.LLDominantEigenvector(), g[f"{tag}_LLDominantEigenvector"]
         assert np.abs(got - expect).max() < 1e-9
+
+
+# ---- g14: the fluxes of scri/flux.py:182-798 computed by the reference's own matrix elements and loops
+def test_g14_oracle_vs_reference_fluxes():
+    from oracle import flux_ref
+
+    g = load("g14_ref_fluxes.npz")
+    t, data = g["t"], g["data"]
+    lmin, lmax = (int(x) for x in g["ells"])
+    hdot = flux_ref.data_dot(t, data)
+    assert np.abs(hdot - g["hdot"]).max() < 1e-13 * np.abs(g["hdot"]).max()
+    rel = lambda a, b: np.abs(a - b).max() / np.abs(b).max()  # noqa: E731
+    assert rel(flux_ref.energy_flux(hdot), g["energy_flux"]) < 1e-13
+    assert rel(flux_ref.silly_momentum_flux(hdot, lmin, lmax), g["momentum_flux"]) < 1e-12
+    assert rel(flux_ref.silly_angular_momentum_flux(data, hdot, lmin, lmax), g["angular_momentum_flux"]) < 1e-12
+    assert rel(flux_ref.boost_flux(t, data, hdot, lmin, lmax), g["boost_flux"]) < 1e-12
+
+
+@pytest.mark.gpu
+def test_g14_gpu_vs_reference_fluxes(ctx):
+    import scri_amd
+    from scri_amd import flux
+
+    g = load("g14_ref_fluxes.npz")
+    lmin, lmax = (int(x) for x in g["ells"])
+    h = scri_amd.WaveformModes(t=g["t"], data=g["data"].copy(), ell_min=lmin, ell_max=lmax, dataType=scri_amd.h, frameType=scri_amd.Inertial,
+                               r_is_scaled_out=True, m_is_scaled_out=True, ctx=ctx)
+    rel = lambda a, b: np.abs(a - b).max() / np.abs(b).max()  # noqa: E731
+    for s in (1, 2, 3):  # single expectation values, spin -1, -2, -3
+        a, b = flux._Field(g["hdot"], -s, lmin, lmax, ctx), flux._Field(g["data"], -s, lmin, lmax, ctx)
+        for name, got in zip(("p_plus", "p_minus", "p_z"), flux._chi(a, b)):
+            assert rel(got, g[f"{name}_s{s}"]) < 1e-13, (s, name)
+    assert rel(h.energy_flux(), g["energy_flux"]) < 1e-13
+    assert rel(h.momentum_flux(), g["momentum_flux"]) < 1e-13
+    assert rel(h.angular_momentum_flux(), g["angular_momentum_flux"]) < 1e-13
+    assert rel(h.boost_flux(), g["boost_flux"]) < 1e-12
+    e, p, j, b = scri_amd.poincare_fluxes(h)
+    assert rel(e, g["poincare_e"]) < 1e-13 and rel(p, g["poincare_p"]) < 1e-13 and rel(j, g["poincare_j"]) < 1e-13 and rel(b, g["poincare_b"]) < 1e-12
+    hdot = h.copy()
+    hdot.dataType, hdot.data = scri_amd.hdot, g["hdot"].copy()
+    assert rel(scri_amd.momentum_flux(hdot), g["momentum_flux"]) < 1e-13 and rel(scri_amd.energy_flux(hdot), g["energy_flux"]) < 1e-13
+    assert rel(scri_amd.boost_flux(h, hdot), g["boost_flux"]) < 1e-12
+    with pytest.raises(ValueError, match="expected to have data of type `h`"):
+        scri_amd.angular_momentum_flux(hdot)
+    with pytest.raises(ValueError, match="can only be calculated from a `WaveformModes` object"):
+        scri_amd.energy_flux(g["data"])

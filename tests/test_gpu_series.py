@@ -138,3 +138,24 @@ def test_waveform_interpolation_reference_cases(ctx):
         assert np.array_equal(out.t, t_out) and out.data.shape == (t_out.size, w.n_data_sets)
         expect = np.array([(m - 1j * m) * (t_out if kind == "linear" else np.ones_like(t_out)) for m in lm[:, 1]]).T
         assert np.allclose(out.data, expect, rtol=4e-15, atol=0)
+
+
+@pytest.mark.parametrize("sa,sb,la,lb", [(3, -3, 5, 5), (-3, 3, 6, 4), (3, -2, 5, 5), (-3, 1, 4, 6), (-4, 4, 5, 5), (3, -3, 12, 12)])
+def test_grid_multiply_takes_factors_of_spin_three_and_four(ctx, sa, sb, la, lb):
+    """the boost flux multiplies ethbar h (s = -3) with its conjugate (scri/flux.py:640-700): factors up to |s| = 4, as salm2map /
+    map2salm take them; against the oracle's grid product"""
+    from oracle import modes_time_series_ref as mref
+    from scri_amd import engine
+
+    rng = np.random.default_rng(la + lb + sa)
+    n = 7
+    a = rng.normal(size=(n, (la + 1) ** 2)) + 1j * rng.normal(size=(n, (la + 1) ** 2))
+    b = rng.normal(size=(n, (lb + 1) ** 2)) + 1j * rng.normal(size=(n, (lb + 1) ** 2))
+    a[:, : sa * sa] = 0
+    b[:, : sb * sb] = 0
+    for out_l in (max(1, abs(sa + sb)), min(la, lb)):
+        got = engine.grid_multiply(a, sa, la, b, sb, lb, la + lb, out_l, ctx=ctx)
+        expect = mref.grid_multiply(a, sa, la, b, sb, lb, working_ell_max=la + lb, output_ell_max=out_l)
+        assert np.abs(got - expect).max() < 1e-13 * np.abs(expect).max()
+    with pytest.raises(NotImplementedError, match="beyond"):
+        engine.grid_multiply(a, 5, la, b, sb, lb, la + lb, 2, ctx=ctx)
