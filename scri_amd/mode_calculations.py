@@ -104,3 +104,55 @@ def corotating_frame(W, R0=(1.0, 0.0, 0.0, 0.0), tolerance=1e-12, z_alignment_re
         frame = quaternions.multiply(frame, correction)
     frame = frame / np.linalg.norm(frame, axis=1)[:, np.newaxis]
     return (frame, omega) if return_omega else frame
+
+
+# ---- two-waveform versions (scri/mode_calculations.py:55-260): <f| L_a |g> and <f| L_a L_b |g>
+def _ladder_applied(W, which):
+    """L_+ g, L_- g or L_z g along the mode axis (one bms_mode_map launch): (L_+ g)_{l,m} = sqrt((l - m + 1)(l + m)) g_{l,m-1}, ..."""
+    LM = np.asarray(W.LM)
+    ell, m = LM[:, 0], LM[:, 1]
+    own = np.arange(ell.size, dtype=np.int32)
+    if which == "z":
+        src, coef = own, m.astype(float)
+    elif which == "+":
+        src = np.where(m - 1 >= -ell, own - 1, -1).astype(np.int32)
+        coef = np.sqrt(np.maximum((ell - (m - 1)) * (ell + (m - 1) + 1.0), 0.0))
+    else:
+        src = np.where(m + 1 <= ell, own + 1, -1).astype(np.int32)
+        coef = np.sqrt(np.maximum((ell + (m + 1)) * (ell - (m + 1) + 1.0), 0.0))
+    out = W.copy()
+    out.data = engine.mode_map(W.data, src, coef.astype(complex), ctx=getattr(W, "_ctx", None))
+    return out
+
+
+def _braket(W1, W2):
+    return np.einsum("ij, ij -> i", np.conjugate(W1.data), W2.data)
+
+
+def LVector(W1, W2):
+    r"""<L>^a = \sum \bar f^{l,m'} <l,m'|L_a|l,m> g^{l,m} for two waveforms with the same modes; complex [n_times, 3], mode frame"""
+    Lp, Lm, Lz = (_braket(W1, _ladder_applied(W2, w)) for w in "+-z")
+    return np.stack([0.5 * (Lp + Lm), -0.5j * (Lp - Lm), Lz], axis=1)
+
+
+def LLComparisonMatrix(W1, W2):
+    r"""<LL>^{ab} = \sum \bar f^{l,m'} <l,m'|L_a L_b|l,m> g^{l,m}; complex [n_times, 3, 3].
+
+    As in the reference (scri/mode_calculations.py:187), the <L_y L_z> term is added to the (y, y) element and the (y, z) element
+    stays zero -- a slip of an index there, kept so that the numbers are the reference's."""
+    T = {}
+    for b in "+-z":
+        right = _ladder_applied(W2, b)
+        for a in "+-z":
+            T[a + b] = _braket(W1, _ladder_applied(right, a))
+    LL = np.empty((W1.n_times, 3, 3), dtype=complex)
+    LL[:, 0, 0] = (T["++"] + T["+-"] + T["-+"] + T["--"]) / 4
+    LL[:, 0, 1] = -1j * (T["++"] - T["+-"] + T["-+"] - T["--"]) / 4
+    LL[:, 0, 2] = (T["+z"] + T["-z"]) / 2
+    LL[:, 1, 0] = -1j * (T["++"] + T["+-"] - T["-+"] - T["--"]) / 4
+    LL[:, 1, 1] = -(T["++"] - T["+-"] - T["-+"] + T["--"]) / 4 - 1j * (T["+z"] - T["-z"]) / 2
+    LL[:, 1, 2] = 0.0
+    LL[:, 2, 0] = (T["z+"] + T["z-"]) / 2
+    LL[:, 2, 1] = -1j * (T["z+"] - T["z-"]) / 2
+    LL[:, 2, 2] = T["zz"]
+    return LL

@@ -204,6 +204,12 @@ def g13():
         out[f"{tag}_LLMatrix"] = np.asarray(w.LLMatrix())
         out[f"{tag}_angular_velocity"] = np.asarray(w.angular_velocity())
         out[f"{tag}_LLDominantEigenvector"] = np.asarray(w.LLDominantEigenvector())
+        import scri.mode_calculations as mc
+
+        other = _wm(t, synthetic.chirp_modes(t, lmin, lmax, seed + 50) * (1 - 0.02 * t[:, None]), lmin, lmax, dt)
+        out[f"{tag}_other"] = other.data
+        out[f"{tag}_LVector"] = np.asarray(mc.LVector(w, other))
+        out[f"{tag}_LLComparisonMatrix"] = np.asarray(mc.LLComparisonMatrix(w, other))
     np.savez_compressed(os.path.join(HERE, "g13_ref_mode_calculations.npz"), source="/root/reference/scri (unmodified) on stand-ins", **out)
 
 

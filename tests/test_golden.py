@@ -401,6 +401,14 @@ def test_g13_gpu_vs_reference_mode_calculations(ctx):
         assert np.abs(w.angular_velocity() - g[f"{tag}_angular_velocity"]).max() < 1e-9 * max(1.0, np.abs(g[f"{tag}_angular_velocity"]).max())
         got, expect = w.LLDominantEigenvector(), g[f"{tag}_LLDominantEigenvector"]
         assert np.abs(got - expect).max() < 1e-9
+        # the two-waveform forms (scri/mode_calculations.py:55-260), index slip of the reference's (y, y) / (y, z) elements included
+        from scri_amd import mode_calculations as mcalc
+
+        other = scri_amd.WaveformModes(t=t, data=g[f"{tag}_other"].copy(), ell_min=lmin, ell_max=lmax, dataType=dt, frameType=scri_amd.Inertial, ctx=ctx)
+        lv, llc = g[f"{tag}_LVector"], g[f"{tag}_LLComparisonMatrix"]
+        assert np.abs(mcalc.LVector(w, other) - lv).max() < 1e-13 * np.abs(lv).max()
+        assert np.abs(mcalc.LLComparisonMatrix(w, other) - llc).max() < 1e-13 * np.abs(llc).max()
+        assert np.all(llc[:, 1, 2] == 0)
 
 
 # ---- g14: the fluxes of scri/flux.py:182-798 computed by the reference's own matrix elements and loops
