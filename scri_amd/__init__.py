@@ -46,6 +46,9 @@ from .file_io import create_abd_from_h5, create_abd_from_waveforms  # noqa: E402
 from .bms_transformations import LorentzTransformation, BMSTransformation  # noqa: E402,F401
 from . import flux  # noqa: E402,F401
 from .flux import energy_flux, momentum_flux, angular_momentum_flux, boost_flux, poincare_fluxes  # noqa: E402,F401
+from .mode_calculations import (  # noqa: E402,F401
+    LdtVector, LVector, LLComparisonMatrix, LLMatrix, LLDominantEigenvector, angular_velocity, corotating_frame, inner_product,
+)
 
 # Same grafting the reference performs at import (scri/__init__.py:140-142)
 WaveformModes.rotate_decomposition_basis = rotate_decomposition_basis
@@ -54,6 +57,8 @@ WaveformModes.to_inertial_frame = to_inertial_frame
 WaveformModes.to_corotating_frame = to_corotating_frame
 WaveformModes.to_coprecessing_frame = to_coprecessing_frame
 WaveformModes.get_alignment_of_decomposition_frame_to_modes = get_alignment_of_decomposition_frame_to_modes
+WaveformModes.LVector = mode_calculations.LVector
+WaveformModes.LLComparisonMatrix = mode_calculations.LLComparisonMatrix
 WaveformModes.energy_flux = energy_flux
 WaveformModes.momentum_flux = momentum_flux
 WaveformModes.angular_momentum_flux = angular_momentum_flux

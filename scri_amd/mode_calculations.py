@@ -156,3 +156,22 @@ def LLComparisonMatrix(W1, W2):
     LL[:, 2, 1] = -1j * (T["z+"] - T["z-"]) / 2
     LL[:, 2, 2] = T["zz"]
     return LL
+
+
+def inner_product(t, abar, b, axis=None, apply_conjugate=False, ctx=None):
+    """Time-domain complex inner product <a, b> of two arrays of samples (scri/mode_calculations.py:493-533): the definite integral
+    over `t` of abar * b (of conj(abar) * b with apply_conjugate), through the not-a-knot cubic spline of the integrand -- the GPU
+    spline antiderivative (bms_spline_derivative, order -1).  The time axis is `axis` (default: the first axis whose length is
+    len(t), as quaternion.calculus.spline_definite_integral infers it)."""
+    t = np.asarray(t, dtype=float)
+    integrand = (np.conjugate(abar) if apply_conjugate else np.asarray(abar)) * np.asarray(b)
+    if axis is None:
+        matches = [i for i, n in enumerate(integrand.shape) if n == t.shape[0]]
+        if not matches:
+            raise ValueError(f"no axis of the integrand (shape {integrand.shape}) has the length of t ({t.shape[0]})")
+        axis = matches[0]
+    moved = np.moveaxis(np.asarray(integrand, dtype=complex), axis, 0)
+    flat = np.ascontiguousarray(moved.reshape(moved.shape[0], -1))
+    total = engine.spline_derivative(t, flat, t[-1:], order=-1, ctx=ctx)[0]
+    out = total.reshape(moved.shape[1:])
+    return out if np.iscomplexobj(integrand) else out.real

@@ -230,3 +230,21 @@ def test_align_decomposition_frame_to_modes(ctx):
     inertial = scri_amd.WaveformModes(t=t, data=data, ell_min=2, ell_max=4, dataType=scri_amd.h, frameType=scri_amd.Inertial, ctx=ctx)
     with pytest.raises(ValueError, match="only takes Waveforms in the"):
         inertial.get_alignment_of_decomposition_frame_to_modes(t_fid)
+
+
+def test_time_domain_inner_product(ctx):
+    """scri/mode_calculations.py:493-533 against scipy's spline integral, along either axis, with and without the conjugation"""
+    from scipy.interpolate import CubicSpline
+    import scri_amd
+
+    rng = np.random.default_rng(3)
+    t = np.sort(rng.uniform(0.0, 20.0, 80))
+    t[1:] = np.maximum(t[1:], t[:-1] + 0.01)
+    a = np.sin(0.3 * t)[:, None] * (rng.normal(size=5) + 1j * rng.normal(size=5))[None, :]
+    b = np.cos(0.2 * t + 0.1)[:, None] * (rng.normal(size=5) + 1j * rng.normal(size=5))[None, :]
+    expect = CubicSpline(t, np.conj(a) * b).integrate(t[0], t[-1])
+    assert np.abs(scri_amd.inner_product(t, a, b, apply_conjugate=True, ctx=ctx) - expect).max() < 1e-12 * np.abs(expect).max()
+    assert np.abs(scri_amd.inner_product(t, np.conj(a), b, ctx=ctx) - expect).max() < 1e-12 * np.abs(expect).max()
+    assert np.abs(scri_amd.inner_product(t, np.conj(a).T.copy(), b.T.copy(), axis=1, ctx=ctx) - expect).max() < 1e-12 * np.abs(expect).max()
+    real = scri_amd.inner_product(t, a.real[:, 0], b.real[:, 0], ctx=ctx)
+    assert np.isrealobj(real) and abs(real - CubicSpline(t, a.real[:, 0] * b.real[:, 0]).integrate(t[0], t[-1])) < 1e-12 * max(1.0, abs(real))
