@@ -46,6 +46,7 @@ from .file_io import create_abd_from_h5, create_abd_from_waveforms  # noqa: E402
 from .bms_transformations import LorentzTransformation, BMSTransformation  # noqa: E402,F401
 from . import flux  # noqa: E402,F401
 from . import utilities  # noqa: E402,F401
+from . import sample_waveforms  # noqa: E402,F401
 from .flux import energy_flux, momentum_flux, angular_momentum_flux, boost_flux, poincare_fluxes  # noqa: E402,F401
 from .mode_calculations import (  # noqa: E402,F401
     LdtVector, LVector, LLComparisonMatrix, LLMatrix, LLDominantEigenvector, angular_velocity, corotating_frame, inner_product,
