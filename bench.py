@@ -27,7 +27,13 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 FP64_MATRIX_PEAK_TFLOPS = 78.6  # MI355X fp64 matrix (= vector) peak, AMD public spec
+# the synthesis product: with the spline evaluation in its epilogue on the WaveformModes route (kernels_gemm_eval.hip; round 4), the
+# plain product for AsymptoticBondiData (time-dependent mixing between synthesis and spline) and with SCRI_AMD_NO_GEMM_EVAL
 DOMINANT_KERNEL = "bms::zgemm3m_mfma_kernel"
+
+
+def dominant_kernel(abd):
+    return "bms::zgemm3m_mfma_kernel" if abd or os.environ.get("SCRI_AMD_NO_GEMM_EVAL") else "bms::zgemm3m_eval_kernel"
 # HBM traffic of the dominant kernel: measured BY THIS RUN where rocprofv3 is on the PATH -- before the parent process touches
 # the GPU it runs two short child passes of this same script under `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` (separate
 # passes, as MI355X_MICROARCH.md prescribes; traffic = 2 x FETCH_SIZE + WRITE_SIZE KiB on gfx950) and reads their counter CSVs.
@@ -120,12 +126,8 @@ def launch_ranks(n, argv):
     """`python bench.py --gpus N` outside a launcher: start N ranks as a CHILD process group (torch.distributed.run) before this
     process has touched the GPU, wait, hand back the exit code.  With fewer GPUs than ranks the run is a gloo dry run (ranks share
     devices, halos through the host: plumbing only, the line says so)."""
-    import socket
     import subprocess
 
-    with socket.socket() as sock:
-        sock.bind(("127.0.0.1", 0))
-        port = sock.getsockname()[1]
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     if "SCRI_AMD_BENCH_BACKEND" not in env:
@@ -136,8 +138,10 @@ def launch_ranks(n, argv):
                 env["SCRI_AMD_BENCH_BACKEND"] = "gloo"
         except Exception:  # noqa: BLE001
             pass
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    # (--standalone: the launcher binds a free port itself and hands it to the ranks as MASTER_PORT -- a port found here by
+    # bind(0) + close could be taken by another process before the launcher listens on it)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--standalone", "--local-addr", "127.0.0.1", "--nnodes=1", f"--nproc-per-node={n}",
+           os.path.abspath(__file__)] + list(argv)
     return subprocess.call(cmd, env=env)
 
 
@@ -358,9 +362,9 @@ def plumbing_only(args, rank, world, backend_note=None):
     return 0 if int(ok) else 1
 
 
-def abd_boost_free_line(ctx, n_rows=10_000):
-    """Secondary measurement: AsymptoticBondiData (psi0..psi4 + sigma, l <= 24, 99 x 99 working grid: one GPU's cfg5 rows, here
-    `n_rows` of them) under cfg5's supertranslation + frame rotation WITHOUT its boost -- elimination on the modes, two-kernel
+def abd_boost_free_line(ctx, n_rows=25_000):
+    """Secondary measurement: AsymptoticBondiData (psi0..psi4 + sigma, l <= 24, 99 x 99 working grid: `n_rows` = 25 000 is one GPU's
+    share of cfg5, the shape of profiles/r03_c_separable_probe_abd.txt) under cfg5's supertranslation + frame rotation WITHOUT its boost -- elimination on the modes, two-kernel
     separable synthesis (theta stage per field, phi stage of the six fields fused with their mixing) -- and the same through the six
     dense products.  HIP-event time of the synthesis kernels against the HBM roofline with their algorithmic bytes: modes read,
     F written and read, grids written."""
@@ -381,7 +385,7 @@ def abd_boost_free_line(ctx, n_rows=10_000):
         for route in ("separable", "dense"):
             if route == "dense":
                 os.environ["SCRI_AMD_NO_SEPARABLE_SYNTHESIS"] = "1"
-            reps = 3 if route == "separable" else 1
+            reps = 3
             engine.transform_abd(u, d_in.data_ptr(), L, tr, ctx=ctx, device=True, out_ptr=d_out.data_ptr())
             ctx.synchronize()
             ctx.get_timing(reset=True)
@@ -438,6 +442,8 @@ def main():
     if args.workload is None:
         args.workload = "cfg3" if args.gpus == 1 else "cfg4"
     pmc_child = os.environ.get("SCRI_AMD_BENCH_PMC_CHILD") == "1"
+    global DOMINANT_KERNEL
+    DOMINANT_KERNEL = dominant_kernel(args.workload == "cfg5")
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         # no launcher around us: be the launcher (child processes; nothing in this process has touched the GPU)
@@ -785,11 +791,18 @@ def main():
             },
             "roofline": {
                 "bound": "mfma",
-                "kernel": "zgemm3m_mfma_kernel (synthesis: modes -> grid)",
-                "achieved": achieved,
+                "kernel": (f"{DOMINANT_KERNEL.split('::')[1]} (synthesis: modes -> grid" +
+                           ("; the spline is solved on the modes and evaluated in this kernel's epilogue, spline_straddle_eval_kernel for the "
+                            "3 of 64 windows that straddle two row tiles is inside the timed launch)" if "eval" in DOMINANT_KERNEL else ")")),
+                # `achieved` / `frac`: flops the matrix pipe EXECUTES (3 real products per complex one, one column per pole ring) over
+                # the kernel's time; `achieved_nominal` / `frac_nominal`: SURVEY 8(d)'s algorithmic 8 n_modes n_pix per row, which
+                # counts work the kernel does not do and can exceed what the chip sustains
+                "achieved": executed,
                 "peak": FP64_MATRIX_PEAK_TFLOPS,
                 "unit": "TFLOP/s",
-                "frac": (achieved / FP64_MATRIX_PEAK_TFLOPS) if achieved else None,
+                "frac": (executed / FP64_MATRIX_PEAK_TFLOPS) if executed else None,
+                "achieved_nominal": achieved,
+                "frac_nominal": (achieved / FP64_MATRIX_PEAK_TFLOPS) if achieved else None,
                 "traffic": traffic,
                 "traffic_source": traffic_note,
                 "traffic_unit": "HBM-side bytes per launch of the kernel (L2 misses: Infinity-Cache hits included); the A operand passes "
@@ -838,9 +851,16 @@ def main():
                 gbs = bytes_per_row * rows_b / (ms / calls * 1e-3) / 1e9  # per launch
                 return {"algorithmic_bytes_per_step": bytes_per_row, "achieved_GBps": gbs, "frac_of_8TBps": gbs / 8000.0}
 
-            total_bytes = 16 * (n_modes + n_cols_b) + 32 * n_cols_b + 16 * (n_cols_b + n_modes_out)
+            eval_route = "eval" in DOMINANT_KERNEL
+            if eval_route:
+                # both sweeps of the spline solve on the n_modes + 1 mode columns, the product reads the solved modes and writes
+                # the SAMPLES (its epilogue evaluates the spline), the analysis reads them: the grid crosses HBM once each way
+                total_bytes = 2 * 32 * (n_modes + 1) + 16 * (n_modes + 1 + n_cols_b) + 16 * (n_cols_b + n_modes_out)
+            else:
+                total_bytes = 16 * (n_modes + n_cols_b) + 32 * n_cols_b + 16 * (n_cols_b + n_modes_out)
             line["hbm_stages"] = {
-                "spline_back_substitution": stage("spline_backward", 32 * n_cols_b),
+                ("spline_back_substitution_on_modes" if eval_route else "spline_back_substitution"):
+                    stage("spline_backward", 32 * (n_modes + 1) if eval_route else 32 * n_cols_b),
                 "analysis": stage("analysis_fused", 16 * (n_cols_b + n_modes_out)),
                 "spline_elimination_on_modes": stage("spline_forward", 32 * (n_modes + 1)),
                 "whole_transform_materialised_grid": {

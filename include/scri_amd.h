@@ -61,7 +61,8 @@ int bms_ctx_set_stream(bms_ctx* ctx, void* hip_stream);
 /* run on the device's default (null) stream -- handle 0, which bms_ctx_set_stream takes as "own stream" -- so that work a
  * caller queued there (torch's default stream: allocations, copies, memsets) is ordered before the engine's kernels */
 int bms_ctx_use_default_stream(bms_ctx* ctx);
-/* cap on the grid work space in bytes (time axis is processed in chunks that fit); 0 = default (96 GB of the 288 GB) */
+/* cap on the grid work space in bytes (time axis is processed in chunks that fit); 0 = default: min(96 GB, a third of the device
+ * memory that is free at the time).  With the default a call that runs out of device memory halves the cap and tries again. */
 int bms_ctx_set_workspace_limit(bms_ctx* ctx, uint64_t bytes);
 /* block until all work queued by this context has finished */
 int bms_ctx_synchronize(bms_ctx* ctx);

@@ -233,6 +233,28 @@ def to_modes(t, grid, s, ell_max, ell_min=None):
 def transform(w_modes, **kwargs):
     """scri/waveform_grid.py:615-630 / scri/waveform_modes.py:705-719."""
     ell_max = kwargs.pop("ell_max", w_modes.ell_max)
+    if np.ndim(w_modes.data) > 2:
+        # Extra trailing data dimensions: `final_dim` = their product; the spline loop of from_modes (:574-588) and the map2salm
+        # loop of to_modes (:299-308) walk `final_indices` one at a time, i.e. every trailing index is a series of its own under
+        # the same transformation.  (Literally, :475-484 contracts with np.tensordot, which leaves the extra axes BEFORE the grid
+        # axes, so that :581 indexes the wrong axis and raises IndexError -- the reference cannot run this case; what is restated
+        # here is what its two loops spell out.)
+        trailing = w_modes.data.shape[2:]
+        flat = w_modes.data.reshape(w_modes.data.shape[:2] + (-1,))
+        aux_keys = [k for k in kwargs if k.startswith("psi") and k.endswith("_modes")]
+        outs = []
+        for f in range(flat.shape[2]):
+            kw_f = dict(kwargs, ell_max=ell_max)
+            for k in aux_keys:
+                a = kwargs[k]
+                kw_f[k] = WM(t=a.t, data=np.ascontiguousarray(a.data.reshape(a.data.shape[:2] + (-1,))[:, :, f]), ell_min=a.ell_min, ell_max=a.ell_max,
+                             dataType=a.dataType, frameType=a.frameType, r_is_scaled_out=a.r_is_scaled_out, m_is_scaled_out=a.m_is_scaled_out)
+            w_f = WM(t=w_modes.t, data=np.ascontiguousarray(flat[:, :, f]), ell_min=w_modes.ell_min, ell_max=w_modes.ell_max, dataType=w_modes.dataType,
+                     frameType=w_modes.frameType, r_is_scaled_out=w_modes.r_is_scaled_out, m_is_scaled_out=w_modes.m_is_scaled_out)
+            outs.append(transform(w_f, **kw_f))
+        data = np.stack([o.data for o in outs], axis=2).reshape(outs[0].data.shape + trailing)
+        return WM(t=outs[0].t, data=data, ell_min=outs[0].ell_min, ell_max=outs[0].ell_max, dataType=w_modes.dataType, frameType=w_modes.frameType,
+                  r_is_scaled_out=w_modes.r_is_scaled_out, m_is_scaled_out=w_modes.m_is_scaled_out)
     uprm, grid, n_theta, n_phi = from_modes(w_modes, **kwargs)
     s = w_modes.spin_weight
     data = to_modes(uprm, grid, s, ell_max)

@@ -266,7 +266,7 @@ class _PinnedBlock:
 # reference) with the same address and size: a temporary whose freed block malloc hands out again at the same address is a new
 # object and starts from zero, so one-off arrays (copies made by the shim, the fresh copy an adapter builds per call) are never
 # page-locked, and a range that moved (ndarray.resize) is released before anything else happens.
-_reg_lock = threading.Lock()
+_reg_lock = threading.RLock()  # re-entrant: a finalizer (_release) can fire on this thread while the lock is held (cyclic GC during an allocation)
 _seen_inputs = collections.OrderedDict()  # id(owner) -> [weakref to owner, address, nbytes, sightings] (small LRU)
 _registered = {}  # id(owner) -> (address, nbytes, weakref.finalize handle)
 REGISTER_MIN_BYTES = 32 << 20

@@ -70,7 +70,11 @@ struct bms_ctx {
   hipStream_t stream = nullptr;
   hipStream_t aux = nullptr;  // set-up kernels whose results the host waits for run here, beside the main stream's work
   std::string err;
-  uint64_t ws_limit = 96ull << 30;  // a third of the 288 GB: one GPU's cfg5 rows (25 000 steps, six 99 x 99 grids, 76 GB) are ONE chunk
+  // cap on the grids of one chunk of the time axis: min(96 GB, a third of the memory that was free when the context was created)
+  // unless the caller sets one (one GPU's cfg5 rows -- 25 000 steps, six 99 x 99 grids, 76 GB -- are ONE chunk on an otherwise empty
+  // MI355X); a call that still runs out of memory halves it and tries again (with_smaller_chunks)
+  uint64_t ws_limit = 96ull << 30;
+  bool ws_limit_set = false;  // by the caller: then it is kept as given
   std::map<std::string, DevBuf> bufs;  // grow-only named work space
   int delta_lmax = -1;                 // Delta tables cached up to this l
   int delta_mfma_lmax = -1;            // ... in the MFMA B-image packing
@@ -256,6 +260,28 @@ static int dev_buf_t(bms_ctx* c, const char* name, size_t count, T** out) {
 
 extern "C" int bms_version(void) { return 1; }
 
+// Default cap of the chunked grids: other tenants of the GPU (torch tensors of the caller, further ranks of a dry run, a smaller
+// device) shrink it; tables, F arrays and the grow-only named buffers come on top, hence a third and not all of what is free.
+static uint64_t default_ws_limit() {
+  size_t free_b = 0, total_b = 0;
+  uint64_t lim = 96ull << 30;
+  if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b > 0) lim = std::min<uint64_t>(lim, (uint64_t)free_b / 3);
+  (void)hipGetLastError();
+  return std::max<uint64_t>(lim, 256ull << 20);
+}
+
+// Runs `call` again with half the work space cap while it fails for lack of device memory (the buffer that failed was released
+// before the attempt, so a smaller chunk finds room); a cap the caller set is not touched.
+template <class F>
+static int with_smaller_chunks(bms_ctx* c, F call) {
+  int rc = call();
+  for (int attempt = 0; rc == BMS_ERR_NOMEM && !c->ws_limit_set && attempt < 5 && c->ws_limit > (512ull << 20); ++attempt) {
+    c->ws_limit /= 2;
+    rc = call();
+  }
+  return rc;
+}
+
 extern "C" int bms_ctx_create(int device, bms_ctx** out) {
   if (!out) return fail(nullptr, BMS_ERR_INVALID, "bms_ctx_create: ctx pointer is NULL");
   *out = nullptr;
@@ -285,6 +311,7 @@ extern "C" int bms_ctx_create(int device, bms_ctx** out) {
   }
   c->stream = c->own_stream;
   if (hipStreamCreateWithFlags(&c->aux, hipStreamNonBlocking) != hipSuccess) c->aux = nullptr;
+  c->ws_limit = default_ws_limit();
   *out = c;
   return BMS_OK;
 }
@@ -339,10 +366,22 @@ extern "C" int bms_host_unregister(void* p) {
   return BMS_OK;
 }
 
+// The page-locked rotor ring is reused once the stream has passed its slots: before the context moves to another stream the
+// old one is drained, so that no slot still waits for its copy on a stream nobody will synchronise any more.
+static int switch_stream(bms_ctx* c, hipStream_t s) {
+  if (s == c->stream) return BMS_OK;
+  if (c->rot_ring_next) {
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    c->rot_ring_next = 0;
+  }
+  c->stream = s;
+  return BMS_OK;
+}
+
 extern "C" int bms_ctx_set_stream(bms_ctx* c, void* s) {
   if (!c) return BMS_ERR_INVALID;
-  c->stream = s ? (hipStream_t)s : c->own_stream;
-  return BMS_OK;
+  return switch_stream(c, s ? (hipStream_t)s : c->own_stream);
 }
 
 // The device's default (null) stream has the handle 0, which bms_ctx_set_stream reads as "back to the context's own
@@ -350,13 +389,13 @@ extern "C" int bms_ctx_set_stream(bms_ctx* c, void* s) {
 // here, so that the engine's kernels are ordered behind them instead of racing them on a non-blocking stream.
 extern "C" int bms_ctx_use_default_stream(bms_ctx* c) {
   if (!c) return BMS_ERR_INVALID;
-  c->stream = nullptr;
-  return BMS_OK;
+  return switch_stream(c, nullptr);
 }
 
 extern "C" int bms_ctx_set_workspace_limit(bms_ctx* c, uint64_t bytes) {
   if (!c) return BMS_ERR_INVALID;
-  c->ws_limit = bytes ? bytes : (96ull << 30);
+  c->ws_limit_set = bytes != 0;
+  c->ws_limit = bytes ? bytes : default_ws_limit();
   return BMS_OK;
 }
 
@@ -1179,6 +1218,7 @@ struct DevPixel {
 struct PieceTables {  // tables shared by the pieces of one pipelined call: per direction, and per knot of the WHOLE series
   PixelTables T;
   DevPixel DP;
+  int col_plan = 0;  // the column order T / DP were built in
   bool times_valid = false;
   double* d_x = nullptr;
   BsplineTable* d_bstab = nullptr;
@@ -1202,6 +1242,19 @@ static BsplineSpread skew_spread(const PixelTables& T, int cA, int cB, const dou
     sp.skew_offset_range = std::max(sp.skew_offset_range, b1 - b0);
   }
   return sp;
+}
+
+// Bound on how many rows a sample can lie from the knots of its spline window within knots [g0, g1): |skew| / (mean step) with a margin
+// (the evaluation verifies the bracket it searches and falls back to the whole range: kernels_gemm_eval.hip).  0: no bound known.
+static int eval_search_halfwidth(const PixelTables& T, int cA, int cB, const double* x_host, int64_t g0, int64_t g1) {
+  if ((int)T.skew_a.size() < cB || (int)T.skew_b.size() < cB || g1 - g0 < 2) return 0;
+  double am = 0.0, bm = 0.0;
+  for (int p = cA; p < cB; ++p) am = std::max(am, std::fabs(T.skew_a[p])), bm = std::max(bm, std::fabs(T.skew_b[p]));
+  const double xm = std::max(std::fabs(x_host[g0] - T.tt), std::fabs(x_host[g1 - 1] - T.tt));
+  const double dx = (x_host[g1 - 1] - x_host[g0]) / (double)(g1 - 1 - g0);
+  const double rows = 1.25 * (am * xm + bm) / dx + 3.0;
+  if (!(rows < 1e6)) return 0;
+  return (int)std::ceil(rows);
 }
 
 // Is the rotor grid of this transformation of the form F R(Theta_j, phi'_k), rings of the rotated equiangular grid at
@@ -1541,7 +1594,7 @@ extern "C" int bms_transform_modes_shard(bms_ctx* c, const bms_wm_input* in, con
                                          int64_t* first_index_out) {
   if (!c) return BMS_ERR_INVALID;
   if (!data_out) return fail(c, BMS_ERR_INVALID, "NULL argument");
-  return transform_modes_impl(c, in, tr, sh, t_out, data_out, n_times_out, first_index_out, nullptr);
+  return with_smaller_chunks(c, [&] { return transform_modes_impl(c, in, tr, sh, t_out, data_out, n_times_out, first_index_out, nullptr); });
 }
 
 // Host arrays in, host arrays out, as a three-stage pipeline over time shards of the OUTPUT range: the upload of shard k + 1
@@ -1703,7 +1756,7 @@ extern "C" int bms_modes_to_grid(bms_ctx* c, const bms_wm_input* in, const bms_t
                                  int64_t* n_times_out) {
   if (!c) return BMS_ERR_INVALID;
   if (!grid_out) return fail(c, BMS_ERR_INVALID, "NULL argument");
-  return transform_modes_impl(c, in, tr, nullptr, t_out, nullptr, n_times_out, nullptr, grid_out);
+  return with_smaller_chunks(c, [&] { return transform_modes_impl(c, in, tr, nullptr, t_out, nullptr, n_times_out, nullptr, grid_out); });
 }
 
 static int transform_modes_impl(bms_ctx* c, const bms_wm_input* in, const bms_transformation* tr, const bms_shard* sh, double* t_out,
@@ -1845,6 +1898,14 @@ static int transform_modes_impl(bms_ctx* c, const bms_wm_input* in, const bms_tr
     }
   }
   const bool sep = no_boost ? (syn.nt != 0 || syn.large) : axis_boost;
+  // Dense route: the back substitution commutes with the synthesis product as well, so it runs on the modes too and the product's
+  // epilogue evaluates the spline (kernels_gemm_eval.hip): the grid of coefficients never reaches HBM.
+  const bool gemm_eval = bs && !sep && rows_avail >= 8 && !getenv("SCRI_AMD_NO_GEMM_EVAL");
+  double* d_Ac = nullptr;
+  if (gemm_eval) {
+    if ((rc = dev_buf_t(c, "Afull", (size_t)rows_avail * ld_af, &d_Ac))) return rc;
+    TIMED(c, BMS_TAG_SPLINE_BACKWARD, launch_bspline_backward_modes(S, d_Af, ld_af, n_modes + 1, d_Ac, ld_af, row0, rows_avail, d_bstab, SPLINE_TILE, SPLINE_HALO));
+  }
   if (sep) {
     const double* q = tr->frame_rotation;
     if (!(q[0] == 1.0 && q[1] == 0.0 && q[2] == 0.0 && q[3] == 0.0)) {
@@ -1873,16 +1934,22 @@ static int transform_modes_impl(bms_ctx* c, const bms_wm_input* in, const bms_tr
   }
   PixelTables T;
   DevPixel DP;
+  const int col_plan = (grid_out || sep || sep_fields) ? 0 : column_plan(tr, n_out);
   if (shared && c->piece_tables_valid) {
+    // (the pieces of a pipelined call share the per-direction tables of the first one, built in ITS column order: a piece that
+    // chose the other synthesis route -- it would have to hold fewer than two rows -- must not read them in a different order)
+    if (shared->col_plan != col_plan)
+      return fail(c, BMS_ERR_UNSUPPORTED, "a piece of the pipelined call chose another synthesis route than the first one (column plan %d vs %d)",
+                  col_plan, shared->col_plan);
     T = shared->T;
     DP = shared->DP;
   } else {
-    if ((rc = device_pixel_tables(c, tr, T, psi ? 1 : 0, s, in->conformal_weight, coef0.empty() ? nullptr : &coef0, nullptr, cv, DP,
-                                  (grid_out || sep || sep_fields) ? 0 : column_plan(tr, n_out), c->aux)))
+    if ((rc = device_pixel_tables(c, tr, T, psi ? 1 : 0, s, in->conformal_weight, coef0.empty() ? nullptr : &coef0, nullptr, cv, DP, col_plan, c->aux)))
       return rc;
     if (shared) {
       shared->T = T;
       shared->DP = DP;
+      shared->col_plan = col_plan;
       c->piece_tables_valid = true;
     }
   }
@@ -2032,15 +2099,27 @@ static int transform_modes_impl(bms_ctx* c, const bms_wm_input* in, const bms_tr
                   "shard holds rows [%lld, %lld) but outputs [%lld, %lld) need rows [%lld, %lld): halo too small "
                   "(use bms_shard_plan)",
                   (long long)row0, (long long)(row0 + rows_avail), (long long)c0, (long long)c1, (long long)g0, (long long)g1);
-    double *d_Y, *d_R = nullptr, *d_G, *d_Yaux = nullptr;
-    if ((rc = dev_buf_t(c, "Y", (size_t)rows_in * ldg, &d_Y))) return rc;
+    double *d_Y = nullptr, *d_R = nullptr, *d_G, *d_Yaux = nullptr;
+    if (!gemm_eval)
+      if ((rc = dev_buf_t(c, "Y", (size_t)rows_in * ldg, &d_Y))) return rc;
     if (!bs)
       if ((rc = dev_buf_t(c, "R", (size_t)rows_in * ldg, &d_R))) return rc;  // eliminated rows (either form)
     if (grid_out && in->mem == BMS_DEVICE)
       d_G = (double*)grid_out + (size_t)(c0 - i_lo) * P2;  // straight into the caller's grid
     else if ((rc = dev_buf_t(c, "G", (size_t)rows_out * ldG, &d_G)))
       return rc;
-    if (bs) {
+    if (gemm_eval) {
+      SplineEval ev;
+      ev.table = d_bstab, ev.x = d_x, ev.skew_a = d_skewa, ev.skew_b = d_skewb, ev.tt = T.tt, ev.g0 = g0, ev.n_knots = n;
+      ev.i_lo = c0, ev.i_hi = c1, ev.out = d_G, ev.ldo = ldG;
+      ev.search_halfwidth = eval_search_halfwidth(T, cA, cB, in->t, g0, g1);
+      ev.side = nullptr, ev.side_ld = ldg;
+      static const int eval_step = getenv("SCRI_AMD_GEMM_EVAL_STEP") ? atoi(getenv("SCRI_AMD_GEMM_EVAL_STEP")) : 64;
+      if (eval_step != 61)
+        if ((rc = dev_buf_t(c, "Cside", (size_t)zgemm3m_eval_side_rows(rows_in) * ldg, &ev.side))) return rc;
+      TIMED(c, BMS_TAG_GEMM_SYNTHESIS, launch_zgemm3m_eval(S, d_Ac + (g0 - row0) * ld_af, ld_af, F[0].d_B + 2 * cA, ldb, rows_in, n_pix, n_modes_in + 1,
+                                                           d_scale, ev));
+    } else if (bs) {
       if (sep) {  // (k = 1 without a boost: no column scale)
         if ((rc = run_synthesis(c, syn, d_Af + (g0 - row0) * ld_af, ld_af, rows_in, coef0.empty() ? nullptr : DP.col_off, d_Y, ldg,
                                 axis_boost ? DP.col_scale : nullptr)))
@@ -2776,7 +2855,7 @@ extern "C" int bms_transform_abd_shard(bms_ctx* c, const double* u, const void* 
                                        const bms_transformation* tr, const bms_shard* sh, double* u_out, void* raw_out,
                                        int64_t* n_times_out, int64_t* first_index_out) {
   if (!c) return BMS_ERR_INVALID;
-  return transform_abd_impl(c, u, raw, mem, n_times, ell_max, tr, sh, u_out, raw_out, n_times_out, first_index_out);
+  return with_smaller_chunks(c, [&] { return transform_abd_impl(c, u, raw, mem, n_times, ell_max, tr, sh, u_out, raw_out, n_times_out, first_index_out); });
 }
 
 static int transform_abd_impl(bms_ctx* c, const double* u, const void* raw, int mem, int64_t n_times, int ell_max,

@@ -147,6 +147,29 @@ hipError_t launch_dgemm(hipStream_t stream, const double* A, long long lda, cons
 hipError_t launch_zgemm3m(hipStream_t stream, const double* A, long long lda, const double* B, long long ldb, double* C,
                           long long ldc, long long M, int N, int K, const double* col_off, const double* col_scale);
 
+// ---- the same product with the spline evaluation in its epilogue (kernels_gemm_eval.hip): A holds B-spline coefficients of the
+// modes (both sweeps of the collocation solve done on the modes), the product is the coefficient grid, and each 64-knot tile
+// evaluates the output samples whose four coefficients it holds -- only the samples are written.
+struct BsplineTable;
+struct SplineEval {
+  const BsplineTable* table;  // per knot (global index), as for launch_bspline_backward_eval
+  const double* x;            // knots = output abscissae before the skew (global index)
+  const double* skew_a;       // per column of the launch (may be null)
+  const double* skew_b;
+  double tt;
+  long long g0;       // knot of row 0 of A
+  long long n_knots;  // of the whole series
+  long long i_lo, i_hi;  // output rows (indices into x); out row 0 = i_lo
+  double* out;
+  long long ldo;
+  int search_halfwidth;  // bound on |row of a sample - knot of its window| (0: none known)
+  double* side;          // 6 rows of ldc doubles per 64-row tile (zgemm3m_eval_side_rows(M) rows), or null: overlapping tiles
+  long long side_ld;
+};
+long long zgemm3m_eval_side_rows(long long M);
+hipError_t launch_zgemm3m_eval(hipStream_t stream, const double* A, long long lda, const double* B, long long ldb, long long M, int N,
+                               int K, const double* col_scale, const SplineEval& e);
+
 // ---- shared-matrix not-a-knot cubic spline along time (waveform_grid.py:574-588)
 struct SplineTable {  // per knot j
   double P, Q, A, C;  // r'_j = P (y_j - y_{j-1}) + Q (y_{j+1} - y_j) - A r'_{j-1};  s_j = r'_j - C s_{j+1}
@@ -186,6 +209,9 @@ hipError_t launch_bspline_table(hipStream_t stream, const double* x, long long n
 hipError_t launch_bspline_forward_modes(hipStream_t stream, const double* A, long long lda, int n_modes, double* Aout,
                                         long long ldo, long long g0, long long n_rows, long long n_knots,
                                         const BsplineForward* table, int tile, int halo, int with_ones);
+// the back substitution on the eliminated modes: Aout = B-spline coefficients of the n_cols columns (out of place)
+hipError_t launch_bspline_backward_modes(hipStream_t stream, const double* A, long long lda, int n_cols, double* Aout, long long ldo,
+                                         long long g0, long long n_rows, const BsplineTable* table, int tile, int halo);
 // AsymptoticBondiData: Horner mixing of the six synthesised fields (as launch_abd_mix) fused with their elimination
 struct AbdGrids;
 hipError_t launch_abd_mix_forward(hipStream_t stream, const AbdGrids& Y, const AbdGrids& R, long long ld, int n_cols, long long g0,

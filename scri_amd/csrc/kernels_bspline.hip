@@ -226,6 +226,68 @@ hipError_t launch_bspline_forward_modes(hipStream_t stream, const double* A, lon
   return hipGetLastError();
 }
 
+// ------------------------------------------------------------------------------------------------ backward, on the modes
+// The back substitution c_k = c'_k - G_k c_{k+1} - D_k c_{k+2} is, like the elimination, a linear map along time whose
+// coefficients all columns share, so it commutes with the synthesis as well: run on the n_modes + 1 columns of the
+// eliminated modes it leaves B-spline COEFFICIENTS of the modes, the synthesis product of those is the coefficient grid
+// itself, and what remains to do on the grid is a 4-tap evaluation without any recurrence (kernels_gemm_eval.hip).
+// Thread (column p, tile): knots of the tile marching down, started `halo` knots above it (out of place: the tile above
+// still reads the eliminated rows this one would overwrite).
+__global__ __launch_bounds__(64) void bspline_backward_modes_kernel(const double* __restrict__ A, long long lda, int n_cols,
+                                                                    double* __restrict__ O, long long ldo, long long g0,
+                                                                    long long n_rows, const BsplineTable* __restrict__ table,
+                                                                    int tile, int halo) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n_cols) return;
+  const long long jA = g0 + (long long)blockIdx.y * tile;
+  long long jB = jA + tile;
+  const long long jend = g0 + n_rows;
+  if (jB > jend) jB = jend;
+  long long jE = jB + halo;
+  if (jE > jend) jE = jend;
+  const double* ap = A + 2LL * p - g0 * lda;
+  double* op = O + 2LL * p - g0 * ldo;
+  int opaque_zero;
+  asm volatile("v_mov_b32 %0, 0" : "=v"(opaque_zero));
+  const BsplineTable* tv = table + opaque_zero;  // (row factors as vector loads, requested with the data: see the elimination)
+  auto ld2 = [&](long long j) { return *reinterpret_cast<const double2*>(ap + j * lda); };
+  auto ldt = [&](long long j) { return *reinterpret_cast<const double2*>(&tv[j].G); };  // (G_j, D_j)
+  // w0 = c_{k+1}, w1 = c_{k+2}; the march starts from the eliminated value of the top row (exact at the true end, where
+  // G = D = 0, and forgotten like 0.268^halo elsewhere)
+  double2 w0 = {0.0, 0.0}, w1 = {0.0, 0.0};
+  auto step = [&](long long j, double2 r, double2 gd) {
+    double2 c;
+    c.x = r.x - gd.x * w0.x - gd.y * w1.x;
+    c.y = r.y - gd.x * w0.y - gd.y * w1.y;
+    if (j < jB) *reinterpret_cast<double2*>(op + j * ldo) = c;
+    w1 = w0;
+    w0 = c;
+  };
+  long long j = jE - 1;
+  for (; j - 3 >= jA; j -= 4) {
+    double2 r[4], gd[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      r[g] = ld2(j - g);
+      gd[g] = ldt(j - g);
+    }
+#pragma unroll
+    for (int g = 0; g < 4; ++g) step(j - g, r[g], gd[g]);
+  }
+  for (; j >= jA; --j) step(j, ld2(j), ldt(j));
+}
+
+hipError_t launch_bspline_backward_modes(hipStream_t stream, const double* A, long long lda, int n_cols, double* Aout, long long ldo,
+                                         long long g0, long long n_rows, const BsplineTable* table, int tile, int halo) {
+  if (n_rows <= 0 || n_cols <= 0) return hipSuccess;
+  static const int tile_env = getenv("SCRI_AMD_BSPLINE_TILE_FWD") ? atoi(getenv("SCRI_AMD_BSPLINE_TILE_FWD")) : 0;
+  tile = tile_env > 0 ? tile_env : tile;
+  const long long n_tiles = (n_rows + tile - 1) / tile;
+  dim3 grid((n_cols + 63) / 64, (unsigned)n_tiles);
+  hipLaunchKernelGGL(bspline_backward_modes_kernel, grid, dim3(64), 0, stream, A, lda, n_cols, Aout, ldo, g0, n_rows, table, tile, halo);
+  return hipGetLastError();
+}
+
 // ------------------------------------------------------------------------------------------------ ABD: mixing + forward
 // The Horner mixing of the six AsymptoticBondiData fields (kernels_swsh.hip, abd_mix_kernel; transformations.py:340-385)
 // has time-dependent coefficients, so the elimination cannot move onto the modes -- but the two grid passes can be one:

@@ -185,8 +185,6 @@ def _prepare(w_modes, kwargs):
                 "of dataType '{}'. Proceeding with the transformation as if it "
                 "were dataType 'Psi4'.".format(w_modes.data_type_string)
             )
-    if len(w_modes._data_shape() if hasattr(w_modes, "_data_shape") else np.shape(w_modes.data)) != 2:
-        raise NotImplementedError("extra trailing data dimensions are not supported by the GPU engine")
     return supertranslation, frame_rotation, boost_velocity, n_theta, n_phi, type_term, aux
 
 
@@ -217,7 +215,27 @@ def transform(w_modes, **kwargs):
 
     tr = engine.make_transformation(supertranslation, frame_rotation, boost_velocity, n_theta, n_phi, ell_max_out)
     dev_out = None
-    if getattr(w_modes, "is_device_resident", False) and not aux:
+    trailing = tuple(w_modes._data_shape()[2:])
+    if trailing:
+        # Extra trailing data dimensions (scri/waveform_grid.py:299-308, 574-594: `final_dim`): every trailing index is an
+        # independent series under the same transformation -- to_modes and the spline loop of from_modes walk them one by one --
+        # so each goes through the engine on its own and the results are stacked back.  (The reference's own from_modes cannot be
+        # run on such data: its tensordot puts the extra axes BEFORE the grid axes and the per-pixel loop then indexes the wrong
+        # axis -- IndexError at :581.  What is built here is what those loops say.)
+        if aux and any(np.shape(a[0])[2:] != trailing for a in aux):
+            raise ValueError("auxiliary waveforms must carry the same trailing data dimensions")
+        flat = np.reshape(w_modes.data, w_modes.data.shape[:2] + (-1,))
+        aux_flat = [np.reshape(a[0], np.shape(a[0])[:2] + (-1,)) for a in aux]
+        pieces = []
+        for f in range(flat.shape[2]):
+            aux_f = [(np.ascontiguousarray(af[:, :, f]),) + tuple(a[1:]) for af, a in zip(aux_flat, aux)]
+            t_new, d = engine.transform_modes(
+                w_modes.t, np.ascontiguousarray(flat[:, :, f]), w_modes.ell_min, w_modes.ell_max, s, w_modes.conformal_weight, type_term, tr,
+                aux=aux_f, ctx=w_modes._ctx,
+            )
+            pieces.append(np.array(d))
+        data_new = np.stack(pieces, axis=2).reshape(pieces[0].shape + trailing)
+    elif getattr(w_modes, "is_device_resident", False) and not aux:
         # weights in HBM (WaveformModes.to_device): the transformation reads and writes them there
         from . import device_series
         from .mode_algebra import LM_total_size
@@ -265,7 +283,8 @@ def _with_device_data(dev, cls, kw):
 class WaveformGrid:
     """A waveform on a (theta, phi) grid at each time (the part of scri.WaveformGrid the transformation path shows:
     scri/waveform_grid.py:193-630): `from_modes` puts a WaveformModes object on the -- optionally BMS-transformed -- grid,
-    `to_modes` analyses it back, `transform` does both.  data: complex [n_times, n_theta * n_phi], theta-major."""
+    `to_modes` analyses it back, `transform` does both.  data: complex [n_times, n_theta * n_phi, ...], theta-major; extra
+    trailing dimensions are independent series (scri/waveform_grid.py:299-308, 574-594)."""
 
     def __init__(self, t, data, n_theta, n_phi, frameType, dataType, r_is_scaled_out, m_is_scaled_out, history=(), ctx=None,
                  constructor_statement=None):
@@ -276,7 +295,7 @@ class WaveformGrid:
         self.r_is_scaled_out, self.m_is_scaled_out = bool(r_is_scaled_out), bool(m_is_scaled_out)
         self.history = list(history) + [constructor_statement or "WaveformGrid(...)"]
         self._ctx = ctx
-        if self.data.ndim != 2 or self.data.shape != (self.t.size, self.n_theta * self.n_phi):
+        if self.data.ndim < 2 or self.data.shape[:2] != (self.t.size, self.n_theta * self.n_phi):
             raise ValueError(f"data.shape={self.data.shape} does not agree with n_times={self.t.size}, n_theta*n_phi={self.n_theta * self.n_phi}")
 
     @property
@@ -300,10 +319,26 @@ class WaveformGrid:
         original_kwargs = kwargs.copy()
         supertranslation, frame_rotation, boost_velocity, n_theta, n_phi, type_term, aux = _prepare(w_modes, kwargs)
         tr = engine.make_transformation(supertranslation, frame_rotation, boost_velocity, n_theta, n_phi, w_modes.ell_max)
-        t_new, grid = engine.transform_modes(
-            w_modes.t, w_modes.data, w_modes.ell_min, w_modes.ell_max, w_modes.spin_weight, w_modes.conformal_weight, type_term, tr,
-            aux=aux, ctx=w_modes._ctx, grid=True,
-        )
+        trailing = tuple(np.shape(w_modes.data)[2:])
+        if trailing:  # every trailing index is a series of its own (see `transform`)
+            if aux and any(np.shape(a[0])[2:] != trailing for a in aux):
+                raise ValueError("auxiliary waveforms must carry the same trailing data dimensions")
+            flat = np.reshape(w_modes.data, w_modes.data.shape[:2] + (-1,))
+            aux_flat = [np.reshape(a[0], np.shape(a[0])[:2] + (-1,)) for a in aux]
+            grids = []
+            for f in range(flat.shape[2]):
+                aux_f = [(np.ascontiguousarray(af[:, :, f]),) + tuple(a[1:]) for af, a in zip(aux_flat, aux)]
+                t_new, g = engine.transform_modes(
+                    w_modes.t, np.ascontiguousarray(flat[:, :, f]), w_modes.ell_min, w_modes.ell_max, w_modes.spin_weight,
+                    w_modes.conformal_weight, type_term, tr, aux=aux_f, ctx=w_modes._ctx, grid=True,
+                )
+                grids.append(np.array(g))
+            grid = np.stack(grids, axis=2).reshape(grids[0].shape + trailing)
+        else:
+            t_new, grid = engine.transform_modes(
+                w_modes.t, w_modes.data, w_modes.ell_min, w_modes.ell_max, w_modes.spin_weight, w_modes.conformal_weight, type_term, tr,
+                aux=aux, ctx=w_modes._ctx, grid=True,
+            )
         if kwargs:
             warnings.warn("\nUnused kwargs passed to this function:\n{}".format(pprint.pformat(kwargs, width=1)))
         return cls(
@@ -327,8 +362,17 @@ class WaveformGrid:
             raise ValueError(f"Input `ell_max` should be a nonnegative integer; got `{ell_max}`.")
         if not isinstance(ell_min, numbers.Integral) or ell_min < 0 or ell_min > ell_max:
             raise ValueError(f"Input `ell_min` should be an integer between 0 and {ell_max}; got `{ell_min}`.")
-        grid = self.data.reshape(self.n_times, self.n_theta, self.n_phi)
-        modes = engine.map2salm(grid, s, int(ell_max), ell_min=int(ell_min), ctx=self._ctx)
+        trailing = self.data.shape[2:]
+        if trailing:
+            # final_dim (scri/waveform_grid.py:299-308): the maps of all trailing indices of all times are one batch of map2salm
+            final_dim = int(np.prod(trailing))
+            grid = np.moveaxis(self.data.reshape(self.n_times, self.n_theta, self.n_phi, final_dim), 3, 1)
+            modes = engine.map2salm(np.ascontiguousarray(grid).reshape(self.n_times * final_dim, self.n_theta, self.n_phi), s, int(ell_max),
+                                    ell_min=int(ell_min), ctx=self._ctx)
+            modes = np.moveaxis(modes.reshape(self.n_times, final_dim, -1), 1, 2).reshape((self.n_times, -1) + tuple(trailing))
+        else:
+            grid = self.data.reshape(self.n_times, self.n_theta, self.n_phi)
+            modes = engine.map2salm(grid, s, int(ell_max), ell_min=int(ell_min), ctx=self._ctx)
         return WaveformModes(
             t=self.t, data=modes, history=self.history, ell_min=int(ell_min), ell_max=int(ell_max), frameType=self.frameType,
             dataType=self.dataType, r_is_scaled_out=self.r_is_scaled_out, m_is_scaled_out=self.m_is_scaled_out,

@@ -115,6 +115,43 @@ def test_cfg3_chunks_and_shards_equal_whole(cfg3):
     assert np.abs(np.concatenate(parts) - out.data).max() < 1e-14 * np.abs(out.data).max()
 
 
+def test_cfg3_stress_variant_beta_1e_2_windows_shards_and_partition(ctx):
+    """SURVEY 8(d)'s stress variant of cfg3 at full size: the same series under a boost of |v| = 1e-2 (26.7 x cfg3's).  A direction's
+    time axis is skewed by up to beta |u| / dt = 1000 rows at the end of the series (scri/waveform_grid.py:564-568, 578), which is
+    what the chunk plan, the shard halos and the search windows of the evaluating product have to cover: three windows of the
+    one-GPU result against the oracle on input slices (the oracle trims beta (t_a + t_b) / dt rows from a slice, so the late
+    slices are longer), the 8 time shards of sharding.plan against the whole, and the partition verdict (halo ~ 1000 rows of a
+    12 500-row shard: still "rows")."""
+    from scri_amd import engine, sharding, synthetic
+
+    t, data, spec = synthetic.workload("cfg3")
+    kw = dict(spec["kwargs"])
+    kw["boost_velocity"] = list(26.7 * np.asarray(kw["boost_velocity"]))
+    beta = float(np.linalg.norm(kw["boost_velocity"]))
+    assert 0.0099 < beta < 0.0101
+    out = _gpu_wm(t, data, 16, h, ctx).transform(**kw)
+    assert N - 2300 < out.n_times < N - 900 and np.all(np.diff(out.t) > 0)  # the window loses ~ beta t_end / dt rows at either end
+    worst = _window_check(out.t, out.data, t, data, kw, 16, [(0, 400), (50_000, 1800), (N - 3200, 3200)])
+    assert worst < 1e-12
+    tr = engine.make_transformation(kw["supertranslation"], kw["frame_rotation"], kw["boost_velocity"], 37, 37, 16)
+    have, need, window = sharding.plan(t, tr, 8)
+    assert window[1] - window[0] == out.n_times
+    halos = [max(h0 - n0, n1 - h1) for (h0, h1), (n0, n1) in zip(have, need)]
+    assert 900 < max(halos) < 1200, halos  # skew of the last shard + the spline margin
+    assert sharding.choose_partition(have, need) == "rows"
+    scale = np.abs(out.data).max()
+    row = 0
+    for r in range(8):
+        ext = data[need[r][0] : need[r][1]]
+        tp, dp, first = engine.transform_modes(t, ext, 2, 16, -2, -1, engine.BMS_TERM_H, tr, ctx=ctx,
+                                               shard=(need[r][0], ext.shape[0], have[r][0], have[r][1]))
+        assert first == window[0] + row
+        assert np.array_equal(tp, out.t[row : row + tp.shape[0]])
+        assert np.abs(dp - out.data[row : row + dp.shape[0]]).max() < 1e-14 * scale
+        row += dp.shape[0]
+    assert row == out.n_times
+
+
 def _window_check(out_t, out_data, t_in, data_in, kw, ell_max, windows, margin=60, tol=1e-12):
     """Windows of a full-size output against the oracle run on slices of the input: `windows` = [(i0, rows)]; the oracle's
     own first / last `margin` outputs see a truncated spline and are left out."""
