@@ -343,14 +343,16 @@ def plumbing_only(args, rank, world, backend_note=None):
     kw = spec["kwargs"]
     ell_max = spec["ell_max"]
     lst = int(round(np.sqrt(len(kw["supertranslation"])))) - 1
-    n_theta = 2 * (ell_max + lst) + 1
+    abd = args.workload == "cfg5"
+    n_theta = 2 * (2 * ell_max + 1) + 1 if abd else 2 * (ell_max + lst) + 1
     n_global = int(args.n_times or 8000)
     tr = engine.make_transformation(kw["supertranslation"], kw.get("frame_rotation", [1, 0, 0, 0]), kw.get("boost_velocity", [0, 0, 0]),
                                     n_theta, n_theta, ell_max)
     have, need, window = sharding.plan(np.arange(n_global) * spec["dt"], tr, world)
-    _, mine, _ = synthetic.workload(args.workload, n_times=n_global, rows=have[rank])
-    ext = sharding.exchange_halos(torch.from_numpy(mine), have[rank], need[rank], have, need)
-    _, expect, _ = synthetic.workload(args.workload, n_times=n_global, rows=need[rank])
+    gen = synthetic.abd_workload if abd else synthetic.workload
+    _, mine, _ = gen(args.workload, n_times=n_global, rows=have[rank])
+    ext = sharding.exchange_halos(torch.from_numpy(mine), have[rank], need[rank], have, need, dim=1 if abd else 0)  # (six fields: rows = axis 1)
+    _, expect, _ = gen(args.workload, n_times=n_global, rows=need[rank])
     ok = torch.tensor([1 if np.array_equal(ext.numpy(), expect) else 0])
     dist.all_reduce(ok, op=dist.ReduceOp.MIN)
     if rank == 0:
@@ -419,7 +421,8 @@ def main():
     ap.add_argument("--workload", default=None, choices=["cfg2", "cfg3", "cfg4", "cfg5"],
                     help="default: cfg3 on one GPU, cfg4 (1e6 steps in all, strong scaling) on several")
     ap.add_argument("--n-times", type=int, default=None,
-                    help="time steps PER GPU (default: 1e5; cfg5: 2e5 / 8); cfg4: time steps IN ALL (default 1e6)")
+                    help="time steps PER GPU (default: 1e5; cfg5 on one GPU: 2e5 / 8); cfg4, and cfg5 on several GPUs: time steps IN ALL "
+                    "(defaults 1e6 / 2e5)")
     ap.add_argument("--overlap-halo", action="store_true",
                     help="N > 1, time shards: transform the outputs that need own rows only while the halos travel, then the "
                     "two edges (three engine calls per step instead of one)")
@@ -536,7 +539,9 @@ def main():
     spec = dict(synthetic.CONFIGS[args.workload])
     spec["name"] = args.workload
     abd = args.workload == "cfg5"
-    strong = args.workload == "cfg4"  # total work fixed, sharded `world` ways
+    # total work fixed, sharded `world` ways: cfg4 (1e6 steps), and cfg5 on several GPUs (BASELINE.json configs[4]: 2e5 steps, 8 GPUs;
+    # scri/asymptotic_bondi_data/transformations.py:391-412 is what the shards reproduce) -- on one GPU cfg5 stays one rank's share
+    strong = args.workload == "cfg4" or (abd and world > 1)
     if strong:
         n_global = int(args.n_times or spec["n_times"])
         per_gpu = -(-n_global // world)
@@ -591,22 +596,28 @@ def main():
     ctx.enable_timing(True)
     halo_rows = (have[rank][0] - need[rank][0], need[rank][1] - have[rank][1]) if world > 1 else (0, 0)
 
-    # ---- cfg4: the whole series on ONE GPU (rank 0's), in the same run: the reference of the strong-scaling line
+    # ---- cfg4 / cfg5 on several GPUs: the whole series on ONE GPU (rank 0's), in the same run: the reference of the strong-scaling line
     n1 = None
     whole_out = None
     if strong and world > 1 and not args.no_n1_reference:
         if rank == 0:
-            _, whole_host, _ = synthetic.workload(args.workload, n_times=n_global)
+            if abd:
+                _, whole_host, _ = synthetic.abd_workload(args.workload, n_times=n_global)
+            else:
+                _, whole_host, _ = synthetic.workload(args.workload, n_times=n_global)
             whole = torch.from_numpy(whole_host).to(dev)
             del whole_host
-            whole_out = torch.empty((n_global, n_modes), dtype=torch.complex128, device=dev)
+            whole_out = torch.empty(((6, n_global, n_modes) if abd else (n_global, n_modes)), dtype=torch.complex128, device=dev)
             reps = 3
             for i in range(reps + 1):
                 if i == 1:
                     ctx.synchronize()
                     t1 = time.perf_counter()
-                n1_rows = engine.transform_modes(t_global, whole.data_ptr(), 2, ell_max, -2, -1, engine.BMS_TERM_H, tr, ctx=ctx, device=True,
-                                                 ld=n_modes, out_ptr=whole_out.data_ptr())[1]
+                if abd:
+                    n1_rows = engine.transform_abd(t_global, whole.data_ptr(), ell_max, tr, ctx=ctx, device=True, out_ptr=whole_out.data_ptr())[1]
+                else:
+                    n1_rows = engine.transform_modes(t_global, whole.data_ptr(), 2, ell_max, -2, -1, engine.BMS_TERM_H, tr, ctx=ctx, device=True,
+                                                     ld=n_modes, out_ptr=whole_out.data_ptr())[1]
             ctx.synchronize()
             n1 = {"ms_per_step": 1e3 * (time.perf_counter() - t1) / reps, "steps": reps, "where": "rank 0's GPU, before the sharded loop"}
             del whole
@@ -708,7 +719,7 @@ def main():
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
     elapsed = float(el.item())
 
-    # ---- cfg4, N > 1: the shards' outputs of the LAST timed step, reassembled on rank 0, against rank 0's own single-GPU
+    # ---- cfg4 / cfg5, N > 1: the shards' outputs of the LAST timed step, reassembled on rank 0, against rank 0's own single-GPU
     # transform of the whole series from the same run (the check of the RCCL path that only hardware can give; the same
     # comparison on one device is tests/test_gpu_full_size.py::test_cfg4_eight_shards_equal_whole, bar 1e-14 x scale)
     parity = None
@@ -723,13 +734,13 @@ def main():
             if counts[r] == 0:
                 continue
             if r == rank:
-                piece = out[: counts[r]].to(comm_dev)
+                piece = (out[:, : counts[r]] if abd else out[: counts[r]]).contiguous().to(comm_dev)
             else:
-                piece = torch.empty((counts[r], n_modes), dtype=torch.complex128, device=comm_dev)
+                piece = torch.empty(((6, counts[r], n_modes) if abd else (counts[r], n_modes)), dtype=torch.complex128, device=comm_dev)
             piece_real = torch.view_as_real(piece)
             dist.broadcast(piece_real, src=r)
             if rank == 0:
-                ref = whole_out[offset : offset + counts[r]]
+                ref = whole_out[:, offset : offset + counts[r]] if abd else whole_out[offset : offset + counts[r]]
                 got = piece.to(dev)
                 worst = max(worst, float((got - ref).abs().max()))
                 scale = max(scale, float(ref.abs().max()))

@@ -32,6 +32,9 @@ quaternion, spherical_functions, spinsfast) and writes
                             flux, poincare_fluxes, and single expectation values <a|p_z|b>, <a|p_+|b>, <a|p_-|b> (s = -1, -2, -3) --
                             the reference's matrix elements and loops; Clebsch-Gordan coefficients from sympy (third party).
 
+  g15_ref_trailing_dims.npz  extra trailing data dimensions (scri/waveform_grid.py:299-308, 574-594): WaveformGrid.to_modes of two series
+                            side by side, and the exception the reference's own transform raises on such data.
+
 Only the .npz files travel; tests/test_golden.py checks the oracle (CPU) and the HIP path (GPU) against them.
 """
 import os
@@ -242,10 +245,44 @@ def g14():
     np.savez_compressed(os.path.join(HERE, "g14_ref_fluxes.npz"), source="/root/reference/scri (unmodified) on stand-ins", **out)
 
 
+def g15():
+    """Extra trailing data dimensions (scri/waveform_grid.py:299-308, 574-594).  What the reference's own source
+    does with data[N, n_modes, 2]: to_modes walks `final_dim` (recorded: the grid of the g8 `h` transformation, two series side by
+    side, analysed back); from_modes / transform cannot run -- np.tensordot at :475-484 leaves the extra axis BEFORE the grid axes,
+    the loop at :581 indexes axis 1 with the ring number and raises IndexError (recorded as the exception's type and text)."""
+    n, L = 240, 6
+    t = np.linspace(-12.0, 36.0, n)
+    kw = dict(supertranslation=_real_supertranslation(3, 81, 0.05), frame_rotation=np.array([0.4, 1.0, -2.0, 0.3]) / np.linalg.norm([0.4, 1.0, -2.0, 0.3]),
+              boost_velocity=np.array([0.012, -0.02, 0.015]))
+    a = synthetic.chirp_modes(t, 2, L, 82) * (1 + 0.01 * t[:, None])
+    b = synthetic.chirp_modes(t, 2, L, 87)
+    data = np.stack([a, b], axis=2)  # [N, n_modes, 2]
+    out = dict(t=t, ell_max=L, seeds=np.array([82, 87]), **kw)  # (the input is regenerated from the seeds by the tests)
+    try:
+        _wm(t, data, 2, L, scri.h).transform(**kw)
+        out["transform_exception"] = "none"
+    except Exception as e:  # noqa: BLE001
+        out["transform_exception"] = f"{type(e).__name__}: {e}"
+    # the two series one by one (what the loops say), then both grids side by side through the reference's to_modes
+    grids, outs = [], []
+    for d in (a, b):
+        g = scri.WaveformGrid.from_modes(_wm(t, d, 2, L, scri.h), **kw)
+        grids.append(g.data)
+        outs.append(g.to_modes(L).data)
+    g2 = scri.WaveformGrid(t=g.t, data=np.stack(grids, axis=2), n_theta=g.n_theta, n_phi=g.n_phi, frameType=scri.Inertial, dataType=scri.h,
+                           r_is_scaled_out=True, m_is_scaled_out=True)
+    m2 = g2.to_modes(L)
+    assert m2.data.shape == outs[0].shape + (2,)
+    keep = slice(None, None, 10)  # (to_modes works time by time: every tenth row keeps the fixture small)
+    out.update(t_out=g.t, rows_kept=np.arange(g.t.size)[keep], n_theta=g.n_theta, n_phi=g.n_phi, grid_two=g2.data[keep], modes_two=m2.data[keep],
+               rows_kept_single=np.arange(g.t.size)[::4], modes_a=outs[0][::4], modes_b=outs[1][::4])
+    np.savez_compressed(os.path.join(HERE, "g15_ref_trailing_dims.npz"), source="/root/reference/scri (unmodified) on stand-ins", **out)
+
+
 if __name__ == "__main__":
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
-        only = [f for f in (g10, g8, g9, g11, g12, g13, g14) if "--" + f.__name__ in sys.argv]
-        for f in only or (g10, g8, g9, g11, g12, g13, g14):
+        only = [f for f in (g10, g8, g9, g11, g12, g13, g14, g15) if "--" + f.__name__ in sys.argv]
+        for f in only or (g10, g8, g9, g11, g12, g13, g14, g15):
             f()
             print("wrote", f.__name__)

@@ -32,6 +32,16 @@ def test_bench_starts_its_own_ranks_and_exchanges_halos():
     assert a1 > 3000 and b0 < 3000  # both ranks fetched rows of the other
 
 
+def test_cfg5_six_field_halo_exchange_between_two_ranks():
+    """cfg5 on several GPUs is a strong-scaling run too (BASELINE.json configs[4]): the six fields' rows travel along axis 1 of the
+    [6, rows, modes] storage.  Plumbing only here; the line with its in-run parity figure is the `-m gpu` test below."""
+    rc, line, err = _run(["--gpus", "2", "--plumbing-only", "--workload", "cfg5", "--n-times", "1200"])
+    assert rc == 0, err
+    assert line["plumbing_only"] and line["workload"] == "cfg5" and line["halo_rows_exact"] and line["n_times_total"] == 1200
+    (a0, a1), (b0, b1) = line["need"]
+    assert a1 > 600 and b0 < 600
+
+
 def test_failed_rccl_bring_up_is_agreed_on_by_all_ranks_and_falls_back_to_gloo():
     """RCCL asked for where it cannot come up (no GPUs here): every rank publishes its outcome in the ranks' own key-value store,
     reads everybody's, and all of them switch to gloo together -- no rank is left waiting in a collective."""
@@ -72,3 +82,18 @@ def test_two_rank_cfg4_line_carries_its_own_parity_check():
     assert par["rows_compared"] == par["rows_of_n1_result"] > 59000
     assert par["within_bar"], par
     assert line["strong_scaling"]["sharded_vs_n1_max_abs_diff"] <= 1e-14 * par["scale_max_abs"]
+
+
+@pytest.mark.gpu
+def test_two_rank_cfg5_strong_scaling_line_carries_its_own_parity_check():
+    """`--workload cfg5 --gpus N`: total fixed (here 4000 steps instead of 2e5), rank 0 transforms the whole six-field series
+    first, the two shards' outputs are gathered and compared with it (scri/asymptotic_bondi_data/transformations.py:391-412 is what
+    the shards reproduce); two ranks share the box's one GPU (gloo dry run)."""
+    rc, line, err = _run(["--gpus", "2", "--steps", "2", "--warmup", "1", "--workload", "cfg5", "--n-times", "4000"], timeout=900)
+    assert rc == 0, err
+    assert line["n_gpus"] == 2 and line["scaling"] == "strong" and line["config"]["ranks"]["world_size"] == 2
+    ss = line["strong_scaling"]
+    assert ss["n_times_total"] == 4000 and ss["n1_same_run"]["ms_per_step"] > 0
+    par = ss["parity"]
+    assert par["rows_compared"] == par["rows_of_n1_result"] > 3900
+    assert par["within_bar"], par

@@ -107,6 +107,40 @@ def test_g8_oracle_vs_reference_wm_transform():
     assert o.ell_max == 5 and np.array_equal(o.t, g["h_st_t_out"]) and np.abs(o.data - g["h_st_out"]).max() < 2e-14
 
 
+def _g15_input(g):
+    from scri_amd import synthetic
+
+    t = g["t"]
+    a = synthetic.chirp_modes(t, 2, 6, int(g["seeds"][0])) * (1 + 0.01 * t[:, None])
+    b = synthetic.chirp_modes(t, 2, 6, int(g["seeds"][1]))
+    return t, np.stack([a, b], axis=2)
+
+
+def test_g15_oracle_trailing_dimensions_vs_reference():
+    """Extra trailing data dimensions (scri/waveform_grid.py:299-308, 574-594).  The reference's own transform raises on such data
+    (recorded in the fixture: its tensordot leaves the extra axis before the grid axes); what its `final_dim` loops spell out --
+    every trailing index a series of its own -- is what the oracle restates: data[N, n_modes, 2] transforms to the stack of the two
+    separate transforms, each equal to what the reference computes for the series alone, and to_modes of two grids side by side
+    equals the reference's."""
+    from oracle import spinsfast_ref
+
+    g = load("g15_ref_trailing_dims.npz")
+    assert str(g["transform_exception"]).startswith("IndexError")
+    t, data = _g15_input(g)
+    o = grid_ref.transform(WM(t=t, data=data, ell_min=2, ell_max=6, dataType=h), **_g8_kw(g))
+    assert o.data.shape[2:] == (2,) and np.array_equal(o.t, g["t_out"])
+    for f, name in enumerate(("modes_a", "modes_b")):
+        single = grid_ref.transform(WM(t=t, data=np.ascontiguousarray(data[:, :, f]), ell_min=2, ell_max=6, dataType=h), **_g8_kw(g))
+        assert np.array_equal(o.data[:, :, f], single.data)
+        assert np.abs(o.data[g["rows_kept_single"], :, f] - g[name]).max() < 2e-14 * max(1.0, np.abs(g[name]).max())
+    # the reference's to_modes on [N', n_pix, 2]
+    n_theta, n_phi = int(g["n_theta"]), int(g["n_phi"])
+    grid = g["grid_two"]
+    for f in range(2):
+        m = grid_ref.to_modes(g["t_out"][g["rows_kept"]], grid[:, :, f].reshape(-1, n_theta, n_phi), -2, 6)
+        assert np.abs(m - g["modes_two"][:, :, f]).max() < 2e-14 * max(1.0, np.abs(g["modes_two"]).max())
+
+
 def test_g9_oracle_vs_reference_abd_transform():
     """oracle/abd_ref.py against scri/asymptotic_bondi_data/transformations.py:199-431 run from the reference checkout."""
     g = load("g9_ref_abd_transform.npz")
@@ -208,6 +242,39 @@ def test_g8_gpu_vs_reference_wm_transform(ctx):
     assert o.t.shape == g["psi2_t_out"].shape and np.abs(o.data - g["psi2_out"]).max() < 1e-13 * max(1.0, np.abs(g["psi2_out"]).max())
     o = _gpu_wm(t, g["h_in"], 2, 6, scri_amd.h, ctx).transform(supertranslation=g["supertranslation"], n_theta=23, n_phi=25, ell_max=5)
     assert o.ell_max == 5 and o.t.shape == g["h_st_t_out"].shape and np.abs(o.data - g["h_st_out"]).max() < 1e-13
+
+
+@pytest.mark.gpu
+def test_g15_gpu_trailing_dimensions(ctx):
+    """data[N, n_modes, F] through WaveformModes.transform / WaveformGrid.from_modes / to_modes: the stack of the F separate
+    transforms BIT FOR BIT, each equal to what the reference computes for that series alone; to_modes of two grids side by side
+    against the reference's own to_modes."""
+    import scri_amd
+
+    g = load("g15_ref_trailing_dims.npz")
+    t, data = _g15_input(g)
+    kw = _g8_kw(g)
+    o = _gpu_wm(t, data, 2, 6, scri_amd.h, ctx).transform(**kw)
+    assert o.data.shape == (g["t_out"].shape[0], 45, 2) and np.abs(o.t - g["t_out"]).max() < 1e-13
+    gr = scri_amd.WaveformGrid.from_modes(_gpu_wm(t, data, 2, 6, scri_amd.h, ctx), **kw)
+    assert gr.data.shape == (o.n_times, int(g["n_theta"]) * int(g["n_phi"]), 2)
+    back = gr.to_modes(6)
+    for f, name in enumerate(("modes_a", "modes_b")):
+        w1 = _gpu_wm(t, np.ascontiguousarray(data[:, :, f]), 2, 6, scri_amd.h, ctx)
+        single = w1.transform(**kw)
+        assert np.array_equal(o.data[:, :, f], single.data)
+        assert np.array_equal(gr.data[:, :, f], scri_amd.WaveformGrid.from_modes(w1, **kw).data)
+        assert np.abs(o.data[g["rows_kept_single"], :, f] - g[name]).max() < 1e-13 * max(1.0, np.abs(g[name]).max())
+        assert np.abs(back.data[:, :, f] - single.data).max() < 1e-13 * max(1.0, np.abs(single.data).max())
+    two = scri_amd.WaveformGrid(g["t_out"][g["rows_kept"]], g["grid_two"], int(g["n_theta"]), int(g["n_phi"]), scri_amd.Inertial, scri_amd.h, True, True,
+                                ctx=ctx).to_modes(6)
+    assert two.data.shape == g["modes_two"].shape and np.abs(two.data - g["modes_two"]).max() < 1e-13 * max(1.0, np.abs(g["modes_two"]).max())
+    # a (2, 3) block of trailing dimensions keeps its shape
+    d6 = np.stack([data[:, :, 0] * (1 + 0.1 * k) for k in range(6)], axis=2).reshape(data.shape[:2] + (2, 3))
+    o6 = _gpu_wm(t, d6, 2, 6, scri_amd.psi4, ctx).transform(**kw)
+    assert o6.data.shape == (o.n_times, 45, 2, 3)
+    ref = _gpu_wm(t, np.ascontiguousarray(d6[:, :, 1, 2]), 2, 6, scri_amd.psi4, ctx).transform(**kw)
+    assert np.array_equal(o6.data[:, :, 1, 2], ref.data)
 
 
 @pytest.mark.gpu
