@@ -2113,6 +2113,7 @@ static int transform_modes_impl(bms_ctx* c, const bms_wm_input* in, const bms_tr
       ev.table = d_bstab, ev.x = d_x, ev.skew_a = d_skewa, ev.skew_b = d_skewb, ev.tt = T.tt, ev.g0 = g0, ev.n_knots = n;
       ev.i_lo = c0, ev.i_hi = c1, ev.out = d_G, ev.ldo = ldG;
       ev.search_halfwidth = eval_search_halfwidth(T, cA, cB, in->t, g0, g1);
+      ev.inv_dx = (g1 - g0 >= 2 && in->t[g1 - 1] > in->t[g0]) ? (double)(g1 - 1 - g0) / (in->t[g1 - 1] - in->t[g0]) : 0.0;
       ev.side = nullptr, ev.side_ld = ldg;
       static const int eval_step = getenv("SCRI_AMD_GEMM_EVAL_STEP") ? atoi(getenv("SCRI_AMD_GEMM_EVAL_STEP")) : 64;
       if (eval_step != 61)

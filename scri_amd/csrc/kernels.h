@@ -163,6 +163,7 @@ struct SplineEval {
   double* out;
   long long ldo;
   int search_halfwidth;  // bound on |row of a sample - knot of its window| (0: none known)
+  double inv_dx;         // 1 / (mean step of the knots of this launch), or 0: a first guess for the row of an abscissa
   double* side;          // 6 rows of ldc doubles per 64-row tile (zgemm3m_eval_side_rows(M) rows), or null: overlapping tiles
   long long side_ld;
 };

@@ -46,6 +46,7 @@ struct EvalArgs {
   double* out;
   long long ldo;
   int search_halfwidth;  // samples of a window lie within this many rows of its knots (host bound; 0: search everything)
+  double inv_dx;         // 1 / (mean step of the launch's knots): turns an abscissa into a first guess of its row (0: no guess)
   double* side;          // ROW_STEP = 64: [n_row_tiles][6][side_ld] first / last three rows of every tile, or null
   long long side_ld;
   int dbg;               // timing experiments (results wrong): 1 no evaluation, 2 no sample stores, 4 no straddle kernel, 8 no search
@@ -102,23 +103,24 @@ struct EvalMarch {
 // than carried and shifted in registers: the evaluating waves share their SIMDs' issue slots with the matrix instructions of the
 // other workgroups, so every vector instruction saved here is matrix time gained.  Returns false if the source could not supply
 // a sample's abscissa (the LDS window left behind: the caller goes on from global memory); the state is then at that sample.
-template <class SRC, class WIN>
+// INTERIOR: the caller's windows touch neither end of the series (no shared end windows, no open last interval).
+template <bool INTERIOR, class SRC, class WIN>
 __device__ __forceinline__ bool eval_march(EvalMarch& m, const SRC& src, WIN win, int dbg) {
   if (!src.has(m.i)) return false;
   double xi = src.samp(m.i);
   double sk = m.sa * (xi - m.tt) + m.sb;
   double ue = xi + sk;
   const double inf = __builtin_huge_val();
-  double xhi = m.jl >= m.jl_open ? inf : src.knot(m.jl + 1);
+  double xhi = (!INTERIOR && m.jl >= m.jl_open) ? inf : src.knot(m.jl + 1);
   while (true) {
     if (!(ue < xhi)) {  // the sample lies beyond this interval
       if (++m.jl >= m.jl_end) return true;
-      xhi = m.jl >= m.jl_open ? inf : src.knot(m.jl + 1);
+      xhi = (!INTERIOR && m.jl >= m.jl_open) ? inf : src.knot(m.jl + 1);
     }
     if (ue < xhi) {
       const auto tb = src.tab(m.jl);
       int fl = m.jl - 1;
-      fl = fl < m.f_lo ? m.f_lo : (fl > m.f_hi ? m.f_hi : fl);
+      if (!INTERIOR) fl = fl < m.f_lo ? m.f_lo : (fl > m.f_hi ? m.f_hi : fl);
       const double2 q0 = win(fl, 0), q1 = win(fl, 1), q2 = win(fl, 2), q3 = win(fl, 3);
       // t = u_eval - x_j, formed as (x_i - x_j) + skew to keep the small difference exact (as the marching kernels do)
       const double t = (xi - src.knot(m.jl)) + sk;
@@ -169,8 +171,25 @@ struct EvalFromLds {
   __device__ __forceinline__ bool has(int i) const { return (unsigned)(i - i_a) < (unsigned)E_XS; }
   __device__ __forceinline__ double samp(int i) const { return xs_lds[i - i_a]; }
   // first i with u_eval(i) >= y, or -1 if the window cannot tell
-  __device__ __forceinline__ int first(double y, double sa, double sb, double tt, int n_i) const {
+  __device__ __forceinline__ int first(double y, double sa, double sb, double tt, int n_i, double inv_dx) const {
     int lo = 0, hi = E_XS;
+    if (inv_dx > 0.0) {
+      // On a (nearly) uniform axis the row follows from the abscissa: u_eval(i) >= y <=> x_i >= (y - sb + sa tt) / (1 + sa).  The
+      // guess is CHECKED against its two neighbours' exact u_eval and only narrows the search: right or one off on the benchmark
+      // axes, where it replaces nine dependent LDS round trips (and ~90 vector instructions) by two.
+      const double z = (y - (sb - sa * tt)) / (1.0 + sa);
+      const double gf = (z - xs_lds[0]) * inv_dx;
+      int g = gf < 0.0 ? 0 : (gf > (double)(E_XS - 1) ? E_XS - 1 : (int)gf);
+      const double xa = xs_lds[g], xb = xs_lds[g + 1 < E_XS ? g + 1 : E_XS - 1];
+      const bool below = xa + (sa * (xa - tt) + sb) < y;  // row g lies below y: the answer is above g
+      const bool next_below = xb + (sa * (xb - tt) + sb) < y;
+      if (below && !next_below && g + 1 < E_XS)
+        lo = hi = g + 1;
+      else if (!below && g > 0) {
+        const double xc = xs_lds[g - 1];
+        if (xc + (sa * (xc - tt) + sb) < y) lo = hi = g;
+      }
+    }
 #pragma unroll
     for (int st = 0; st < 9; ++st) {  // E_XS = 2^8: 257 possible answers
       const int mid = lo < hi ? (lo + hi) >> 1 : (lo < E_XS ? lo : E_XS - 1);  // (converged: any valid entry, the comparison changes nothing)
@@ -192,7 +211,8 @@ struct EvalFromLds {
 // lds: the staged copies, if from_lds (by value: a struct whose address is taken lives in scratch memory, and a scratch load in
 // the loop waits, through vmcnt, for the previous turn's sample to reach memory).
 template <class WIN>
-__device__ __forceinline__ void eval_windows(const EvalArgs& ev, const bool from_lds, const EvalFromLds lds, int col, long long kT, int fa, int fb, WIN win) {
+__device__ __forceinline__ void eval_windows(const EvalArgs& ev, const bool from_lds, const EvalFromLds lds, int col, double sa, double sb, long long kT,
+                                             int fa, int fb, WIN win) {
   const long long n = ev.n;
   {
     const long long cap = n - 3 - kT;  // window starts are 0 .. n - 4
@@ -205,7 +225,7 @@ __device__ __forceinline__ void eval_windows(const EvalArgs& ev, const bool from
   m.jl_open = n - 2 - kT > FAR ? FAR : (int)(n - 2 - kT);                                      // the last interval claims everything above
   m.jl = fa == m.f_lo ? m.f_lo : fa + 1;                                                       // window 0 serves intervals 0 and 1
   m.jl_end = fb - 1 == m.f_hi ? m.jl_open + 1 : fb + 1;                                        // window n - 4 serves n - 3 and n - 2
-  m.sa = ev.skew_a ? ev.skew_a[col] : 0.0, m.sb = ev.skew_b ? ev.skew_b[col] : 0.0;
+  m.sa = sa, m.sb = sb;
   m.n_i = (int)(ev.i_hi - ev.i_lo);
   m.tt = ev.tt;
   m.ldo = ev.ldo;
@@ -214,13 +234,18 @@ __device__ __forceinline__ void eval_windows(const EvalArgs& ev, const bool from
   if (kT + m.jl == 0)
     i = 0;
   else if (from_lds)
-    i = lds.first(lds.knot(m.jl), m.sa, m.sb, m.tt, m.n_i);
+    i = lds.first(lds.knot(m.jl), m.sa, m.sb, m.tt, m.n_i, ev.inv_dx);
   if (i < 0) i = eval_lower_bound(bp, m.n_i, m.sa, m.sb, m.tt, ev.x[kT + m.jl], kT + m.jl - ev.i_lo, ev.search_halfwidth);
   if (i >= m.n_i) return;
   m.i = i;
   m.op = ev.out + 2LL * col + (long long)i * ev.ldo;
-  if (from_lds && eval_march(m, lds, win, ev.dbg)) return;
-  eval_march(m, EvalFromGlobal{ev, bp, kT}, win, ev.dbg);
+  const bool interior = fa > m.f_lo && fb - 1 < m.f_hi && fb + 1 < m.jl_open;
+  if (from_lds && interior) {
+    if (eval_march<true>(m, lds, win, ev.dbg)) return;
+  } else if (from_lds) {
+    if (eval_march<false>(m, lds, win, ev.dbg)) return;
+  }
+  eval_march<false>(m, EvalFromGlobal{ev, bp, kT}, win, ev.dbg);
 }
 
 template <int ROW_STEP>
@@ -232,6 +257,7 @@ __global__ __launch_bounds__(256, 3) void zgemm3m_eval_kernel(const double* __re
   __shared__ __attribute__((aligned(16))) double t_lds[64 * 16];
   __shared__ __attribute__((aligned(16))) double xk_lds[64];
   __shared__ __attribute__((aligned(16))) double xs_lds[E_XS];
+  __shared__ __attribute__((aligned(16))) double2 sk_lds[E_BN];  // (skew_a, skew_b) of the tile's columns
   double2* As = lds;
   double2* Bs = lds + 2 * E_ASZ;
 
@@ -265,6 +291,12 @@ __global__ __launch_bounds__(256, 3) void zgemm3m_eval_kernel(const double* __re
   if (i_a_ll > n_i - 1) i_a_ll = n_i - 1;
   if (i_a_ll < 0) i_a_ll = 0;
   const int i_a = (int)i_a_ll;
+  if (tid < E_BN) {
+    // (read in the epilogue from LDS: as global loads there, their s_waitcnt vmcnt(0) also waited for every sample the first half
+    // of the tile had just stored to reach memory)
+    const int col = n0 + tid < N ? n0 + tid : N - 1;
+    sk_lds[tid] = double2{ev.skew_a ? ev.skew_a[col] : 0.0, ev.skew_b ? ev.skew_b[col] : 0.0};
+  }
   if (from_lds) {
     {
       long long row = tid >> 2;
@@ -357,6 +389,7 @@ __global__ __launch_bounds__(256, 3) void zgemm3m_eval_kernel(const double* __re
 
   unsigned long long tr_t1 = 0;
   if (ev.trace) tr_t1 = __builtin_readcyclecounter();
+  if (ev.dbg & 256) __builtin_amdgcn_s_setprio(3);
   // ---- epilogue: recombine and scale, then the tile is parked in the operand LDS half by half (columns 0..31 by the waves wn = 0,
   // then 32..63) and every thread evaluates 8 windows of one column of the parked half
   double2 cv[2][2][4];
@@ -400,7 +433,8 @@ __global__ __launch_bounds__(256, 3) void zgemm3m_eval_kernel(const double* __re
       if (fb > f_rows) fb = f_rows;
       const auto win = [&](int fl, int qq) { return Cs[(fl + qq) * E_PC + ec]; };
       const EvalFromLds src{(lds_cdp)t_lds, (lds_cdp)xk_lds, (lds_cdp)xs_lds, i_a};
-      eval_windows(ev, from_lds, src, col, kT, fa, fb, win);
+      const double2 sk = sk_lds[h * 32 + ec];
+      eval_windows(ev, from_lds, src, col, sk.x, sk.y, kT, fa, fb, win);
     }
     if (h == 0) __syncthreads();
   }
@@ -464,7 +498,7 @@ __global__ __launch_bounds__(256) void spline_straddle_eval_kernel(int N, int n_
   }
   const auto win = [&](int fl, int qq) { return w_lds[fl + qq][tid]; };
   const EvalFromLds src{(lds_cdp)t_lds, (lds_cdp)xk_lds, (lds_cdp)xs_lds, i_a};
-  eval_windows(ev, from_lds, src, col, kT, 0, fb, win);
+  eval_windows(ev, from_lds, src, col, ev.skew_a ? ev.skew_a[col] : 0.0, ev.skew_b ? ev.skew_b[col] : 0.0, kT, 0, fb, win);
 }
 
 hipError_t launch_zgemm3m_eval(hipStream_t stream, const double* A, long long lda, const double* B, long long ldb, long long M, int N,
@@ -474,6 +508,7 @@ hipError_t launch_zgemm3m_eval(hipStream_t stream, const double* A, long long ld
   EvalArgs ev;
   ev.table = e.table, ev.x = e.x, ev.skew_a = e.skew_a, ev.skew_b = e.skew_b, ev.tt = e.tt, ev.g0 = e.g0, ev.n = e.n_knots;
   ev.i_lo = e.i_lo, ev.i_hi = e.i_hi, ev.out = e.out, ev.ldo = e.ldo, ev.search_halfwidth = e.search_halfwidth;
+  ev.inv_dx = e.inv_dx;
   ev.side = e.side, ev.side_ld = e.side_ld;
   static const int dbg_env = getenv("SCRI_AMD_GEMM_EVAL_DBG") ? atoi(getenv("SCRI_AMD_GEMM_EVAL_DBG")) : 0;
   ev.dbg = dbg_env;
