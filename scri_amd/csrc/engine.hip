@@ -1873,12 +1873,7 @@ static int transform_modes_impl(bms_ctx* c, const bms_wm_input* in, const bms_tr
   if (rc) return rc;
   const long long ld_af = round_up(2LL * (n_modes + 1), 16);  // rows on 128-byte lines
   double* d_Af = nullptr;
-  if (bs && rows_avail > 0) {
-    if ((rc = dev_buf_t(c, "Afwd", (size_t)rows_avail * ld_af, &d_Af))) return rc;
-    TIMED(c, BMS_TAG_SPLINE_FORWARD, launch_bspline_forward_modes(S, F[0].d_data, F[0].ld * 2, n_modes, d_Af, ld_af, row0, rows_avail, n, d_bsfwd,
-                                                                  SPLINE_TILE, SPLINE_HALO, 1));
-  }
-  trace.mark("input staging, time upload, spline factors, elimination on the modes (enqueue)");
+  trace.mark("input staging, time upload, spline factors (enqueue)");
   // Without a boost the grid is the equiangular grid seen through the constant frame rotation: rotate the (eliminated) modes
   // once and synthesise ring by ring (kernels_synthesis.hip) instead of multiplying with the dense sYlm matrix.  The grid
   // keeps its natural column order for that.
@@ -1903,9 +1898,22 @@ static int transform_modes_impl(bms_ctx* c, const bms_wm_input* in, const bms_tr
   const bool gemm_eval = bs && !sep && rows_avail >= 8 && !getenv("SCRI_AMD_NO_GEMM_EVAL");
   double* d_Ac = nullptr;
   if (gemm_eval) {
+    // both sweeps of the spline solve on the modes: in one pass over memory (a thread keeps its column's tile in registers), or --
+    // SCRI_AMD_TWO_SWEEPS, the form the kernel was checked against -- as elimination and back substitution one after the other
     if ((rc = dev_buf_t(c, "Afull", (size_t)rows_avail * ld_af, &d_Ac))) return rc;
-    TIMED(c, BMS_TAG_SPLINE_BACKWARD, launch_bspline_backward_modes(S, d_Af, ld_af, n_modes + 1, d_Ac, ld_af, row0, rows_avail, d_bstab, SPLINE_TILE, SPLINE_HALO));
+    if (getenv("SCRI_AMD_TWO_SWEEPS")) {
+      if ((rc = dev_buf_t(c, "Afwd", (size_t)rows_avail * ld_af, &d_Af))) return rc;
+      TIMED(c, BMS_TAG_SPLINE_FORWARD, launch_bspline_forward_modes(S, F[0].d_data, F[0].ld * 2, n_modes, d_Af, ld_af, row0, rows_avail, n, d_bsfwd,
+                                                                    SPLINE_TILE, SPLINE_HALO, 1));
+      TIMED(c, BMS_TAG_SPLINE_BACKWARD, launch_bspline_backward_modes(S, d_Af, ld_af, n_modes + 1, d_Ac, ld_af, row0, rows_avail, d_bstab, SPLINE_TILE, SPLINE_HALO));
+    } else
+      TIMED(c, BMS_TAG_SPLINE_FORWARD, launch_bspline_solve_modes(S, F[0].d_data, F[0].ld * 2, n_modes, d_Ac, ld_af, row0, rows_avail, d_bsfwd, d_bstab, 1));
+  } else if (bs && rows_avail > 0) {
+    if ((rc = dev_buf_t(c, "Afwd", (size_t)rows_avail * ld_af, &d_Af))) return rc;
+    TIMED(c, BMS_TAG_SPLINE_FORWARD, launch_bspline_forward_modes(S, F[0].d_data, F[0].ld * 2, n_modes, d_Af, ld_af, row0, rows_avail, n, d_bsfwd,
+                                                                  SPLINE_TILE, SPLINE_HALO, 1));
   }
+  trace.mark("elimination / solve on the modes (enqueue)");
   if (sep) {
     const double* q = tr->frame_rotation;
     if (!(q[0] == 1.0 && q[1] == 0.0 && q[2] == 0.0 && q[3] == 0.0)) {

@@ -213,6 +213,10 @@ hipError_t launch_bspline_forward_modes(hipStream_t stream, const double* A, lon
 // the back substitution on the eliminated modes: Aout = B-spline coefficients of the n_cols columns (out of place)
 hipError_t launch_bspline_backward_modes(hipStream_t stream, const double* A, long long lda, int n_cols, double* Aout, long long ldo,
                                          long long g0, long long n_rows, const BsplineTable* table, int tile, int halo);
+// both sweeps in one pass over memory (a thread keeps its column's tile + run-in rows in registers): Aout[r][0 .. n_modes] =
+// B-spline coefficients of [A | 1]
+hipError_t launch_bspline_solve_modes(hipStream_t stream, const double* A, long long lda, int n_modes, double* Aout, long long ldo,
+                                      long long g0, long long n_rows, const BsplineForward* fwd, const BsplineTable* table, int with_ones);
 // AsymptoticBondiData: Horner mixing of the six synthesised fields (as launch_abd_mix) fused with their elimination
 struct AbdGrids;
 hipError_t launch_abd_mix_forward(hipStream_t stream, const AbdGrids& Y, const AbdGrids& R, long long ld, int n_cols, long long g0,

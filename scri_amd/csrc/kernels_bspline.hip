@@ -288,6 +288,94 @@ hipError_t launch_bspline_backward_modes(hipStream_t stream, const double* A, lo
   return hipGetLastError();
 }
 
+// ------------------------------------------------------------------------------------------------ both sweeps, on the modes
+// Elimination and back substitution of a tile in ONE pass over memory: a thread keeps its column's TT + 2 HH rows in REGISTERS
+// (the tile and HH knots of run-in either side: the elimination starts HH knots below the tile, runs to HH knots above it, and
+// the back substitution comes back down from there; both recurrences forget their starts like 0.268^HH), so the modes are read
+// once and their coefficients written once -- 2 x 16 (n_modes + 1) bytes per knot instead of the 4 x of the two separate sweeps
+// (the run-in rows are re-read by the neighbouring tiles: L2 traffic, not HBM).  Rows outside [g0, g0 + n_rows) are virtual:
+// zero data behind identity factors.  The per-knot factors are wave-uniform and travel through LDS (one coalesced load by the
+// wave, broadcast reads in the sweeps); every register index is a compile-time constant.
+template <int TT, int HH>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void bspline_solve_modes_kernel(
+    const double* __restrict__ A, long long lda, int n_modes, double* __restrict__ O, long long ldo, long long g0, long long n_rows,
+    const BsplineForward* __restrict__ fwd, const BsplineTable* __restrict__ table, int with_ones) {
+  constexpr int NR = TT + 2 * HH;
+  __shared__ __attribute__((aligned(16))) double fw[NR][4];  // P, A, E of row r (identity for virtual rows)
+  __shared__ __attribute__((aligned(16))) double bw[NR][2];  // G, D
+  const int lane = threadIdx.x;
+  // Blocks b, b + 8, .. share an XCD (round-robin dispatch) and with it an L2: every XCD gets a CONTIGUOUS range of time tiles, walked
+  // in time order, so that the run-in rows a tile shares with its neighbours are L2 hits there instead of a second read from HBM by
+  // another XCD.
+  const int n_real = 2 * (n_modes + with_ones), ncb = (n_real + 63) / 64;
+  const long long n_tiles = (n_rows + TT - 1) / TT, per_xcd = (n_tiles + 7) / 8;
+  const long long q = blockIdx.x >> 3;
+  const long long tile = (long long)(blockIdx.x & 7) * per_xcd + q / ncb;
+  if (q / ncb >= per_xcd || tile >= n_tiles) return;
+  // a thread = one REAL column (the factors are real: Re and Im of a mode are two independent recurrences), so that the
+  // NR rows of a column are NR x 2 of the 256 registers a thread has at two waves per SIMD
+  const int p = (int)(q % ncb) * 64 + lane;
+  const long long jA = g0 + tile * TT, jend = g0 + n_rows;
+  const long long j0 = jA - HH;  // row of register 0
+  for (int r = lane; r < NR; r += 64) {
+    const long long j = j0 + r;
+    const bool ok = j >= g0 && j < jend;
+    double2 pa = {1.0, 0.0}, ex = {0.0, 0.0}, gd = {0.0, 0.0};
+    if (ok) {
+      pa = *reinterpret_cast<const double2*>(&fwd[j].P);
+      ex = *reinterpret_cast<const double2*>(&fwd[j].E);
+      gd = *reinterpret_cast<const double2*>(&table[j].G);
+    }
+    *reinterpret_cast<double2*>(&fw[r][0]) = pa;
+    fw[r][2] = ex.x;
+    *reinterpret_cast<double2*>(&bw[r][0]) = gd;
+  }
+  const bool live = p < n_real;
+  const bool ones = with_ones && p >= 2 * n_modes;  // the constant series 1 + 0 i
+  const double one_value = (p & 1) ? 0.0 : 1.0;
+  const double* ap = A + (live && !ones ? p : 0);
+  double v[NR];
+#pragma unroll
+  for (int r = 0; r < NR; ++r) {
+    const long long j = j0 + r;
+    const bool ok = j >= g0 && j < jend;  // (wave-uniform)
+    v[r] = ok ? (ones ? one_value : ap[(j - g0) * lda]) : 0.0;
+  }
+  __syncthreads();
+  // elimination: c'_j = P_j y_j - A_j c'_{j-1} - E_j c'_{j-2}
+#pragma unroll
+  for (int r = 0; r < NR; ++r) {
+    const double2 pa = *reinterpret_cast<const double2*>(&fw[r][0]);
+    const double e = fw[r][2];
+    const double c1 = r >= 1 ? v[r - 1] : 0.0, c2 = r >= 2 ? v[r - 2] : 0.0;
+    v[r] = pa.x * v[r] - pa.y * c1 - e * c2;
+  }
+  // back substitution: c_k = c'_k - G_k c_{k+1} - D_k c_{k+2}
+#pragma unroll
+  for (int r = NR - 1; r >= HH; --r) {
+    const double2 gd = *reinterpret_cast<const double2*>(&bw[r][0]);
+    const double w0 = r + 1 < NR ? v[r + 1] : 0.0, w1 = r + 2 < NR ? v[r + 2] : 0.0;
+    v[r] = v[r] - gd.x * w0 - gd.y * w1;
+  }
+  if (!live) return;
+  double* op = O + p;
+#pragma unroll
+  for (int r = HH; r < HH + TT; ++r) {
+    const long long j = j0 + r;
+    if (j < jend) op[(j - g0) * ldo] = v[r];
+  }
+}
+
+hipError_t launch_bspline_solve_modes(hipStream_t stream, const double* A, long long lda, int n_modes, double* Aout, long long ldo,
+                                      long long g0, long long n_rows, const BsplineForward* fwd, const BsplineTable* table, int with_ones) {
+  if (n_rows <= 0 || n_modes <= 0) return hipSuccess;
+  constexpr int TT = 48, HH = 32;
+  const long long ncb = (2 * (n_modes + with_ones) + 63) / 64, n_tiles = (n_rows + TT - 1) / TT, per_xcd = (n_tiles + 7) / 8;
+  dim3 grid((unsigned)(8 * per_xcd * ncb));
+  hipLaunchKernelGGL((bspline_solve_modes_kernel<TT, HH>), grid, dim3(64), 0, stream, A, lda, n_modes, Aout, ldo, g0, n_rows, fwd, table, with_ones);
+  return hipGetLastError();
+}
+
 // ------------------------------------------------------------------------------------------------ ABD: mixing + forward
 // The Horner mixing of the six AsymptoticBondiData fields (kernels_swsh.hip, abd_mix_kernel; transformations.py:340-385)
 // has time-dependent coefficients, so the elimination cannot move onto the modes -- but the two grid passes can be one:

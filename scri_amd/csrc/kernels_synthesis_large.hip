@@ -32,13 +32,16 @@ typedef double v4d_t __attribute__((ext_vector_type(4)));
 
 // ---- theta stage: F[t][mi][j] = sum_l Tsyn[(l, m)][j] A[t][(l, m)]
 template <int KL, int NTJ>
-__global__ __launch_bounds__(256) void theta_synthesis_mfma_kernel(const double* __restrict__ A, long long lda, long long n_rows,
+__global__ __launch_bounds__(256, NTJ <= 4 ? 3 : 2) void theta_synthesis_mfma_kernel(const double* __restrict__ A, long long lda, long long n_rows,
                                                                    int n_theta, int L, int ell_min, int jp, int rows_per_block,
                                                                    const double* __restrict__ Tsyn, double* __restrict__ F) {
   constexpr int PQ = 4 * KL + 2;  // 2 x odd: conflict-free fragment reads
   __shared__ double As[4][16 * PQ];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, fi = lane & 15, fk = lane >> 4;
   const int mi = blockIdx.x, m = mi - L, nm = 2 * L + 1;
+  // the rings of an m may be shared out over gridDim.z workgroups (tiles of 16 rings from tile0 on): half the table fragments per
+  // lane, so that three waves instead of two fit a SIMD -- the gathers of the modes are then done once per part
+  const int tile0 = blockIdx.z * NTJ;
   const int am = m < 0 ? -m : m;
   const int l0 = am > ell_min ? am : ell_min;  // first l of this m
   const int nl = L - l0 + 1;                   // its number of l values (k extent of the product)
@@ -51,7 +54,7 @@ __global__ __launch_bounds__(256) void theta_synthesis_mfma_kernel(const double*
     const long long o = (long long)l * (l + 1) - (long long)ell_min * ell_min + m;
 #pragma unroll
     for (int n = 0; n < NTJ; ++n) {
-      const int j = 16 * n + fi;
+      const int j = 16 * (n + tile0) + fi;
       bq[s][n] = (l <= L && j < n_theta) ? Tsyn[o * n_theta + j] : 0.0;
     }
   }
@@ -104,7 +107,7 @@ __global__ __launch_bounds__(256) void theta_synthesis_mfma_kernel(const double*
     // results r = 2h (re), 2h+1 (im) of time step t0 + fk + 4 h, ring j = 16 n + fi (the padding rings j >= n_theta get zeros)
 #pragma unroll
     for (int n = 0; n < NTJ; ++n) {
-      const int j = 16 * n + fi;
+      const int j = 16 * (n + tile0) + fi;
       if (j < jp) {
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
@@ -428,9 +431,16 @@ hipError_t launch_synthesis_large(hipStream_t stream, const double* A, long long
   const int n_modes = (L + 1) * (L + 1) - ell_min * ell_min;
   static const int rows_per_block = getenv("SCRI_AMD_TS_ROWS") ? atoi(getenv("SCRI_AMD_TS_ROWS")) : 256;
   const dim3 grid1(nm, (unsigned)((n_rows + rows_per_block - 1) / rows_per_block));
-  const int kl = (L + 1 - ell_min + 3) / 4, ntj = (n_theta + 15) / 16;
+  const int kl = (L + 1 - ell_min + 3) / 4, ntj_all = (n_theta + 15) / 16;
+  // SCRI_AMD_TS_SPLIT=1 and more than four ring tiles (n_theta > 64): two workgroups per m, each with half of them
+  // (measured, round 4: 99 x 99 / l <= 24, 25 000 steps, six fields: 14.65 ms split against 13.09 ms whole -- three waves per SIMD at
+  // 153 registers do not make up for gathering every mode twice; off unless asked for)
+  static const int ts_split = getenv("SCRI_AMD_TS_SPLIT") ? atoi(getenv("SCRI_AMD_TS_SPLIT")) : 0;
+  const int parts = ts_split && ntj_all > 4 ? 2 : 1;
+  const int ntj = (ntj_all + parts - 1) / parts;
+  const dim3 grid1z(grid1.x, grid1.y, parts);
 #define TS_GO(KL, NTJ)                                                                                                      \
-  hipLaunchKernelGGL((theta_synthesis_mfma_kernel<KL, NTJ>), grid1, dim3(256), 0, stream, A, lda, n_rows, n_theta, L, ell_min, jp, \
+  hipLaunchKernelGGL((theta_synthesis_mfma_kernel<KL, NTJ>), grid1z, dim3(256), 0, stream, A, lda, n_rows, n_theta, L, ell_min, jp, \
                      rows_per_block, Tsyn, F)
 #define TS_KL(NTJ)  \
   if (kl <= 5)      \
@@ -441,6 +451,8 @@ hipError_t launch_synthesis_large(hipStream_t stream, const double* A, long long
     TS_GO(9, NTJ);
   if (ntj <= 3) {
     TS_KL(3)
+  } else if (ntj == 4) {
+    TS_KL(4)
   } else if (ntj <= 5) {
     TS_KL(5)
   } else {
@@ -484,9 +496,16 @@ hipError_t launch_theta_synthesis(hipStream_t stream, const double* A, long long
   const int L = ell_max, nm = 2 * L + 1, jp = large_analysis_jp(n_theta);
   static const int rows_per_block = getenv("SCRI_AMD_TS_ROWS") ? atoi(getenv("SCRI_AMD_TS_ROWS")) : 256;
   const dim3 grid1(nm, (unsigned)((n_rows + rows_per_block - 1) / rows_per_block));
-  const int kl = (L + 1 - ell_min + 3) / 4, ntj = (n_theta + 15) / 16;
+  const int kl = (L + 1 - ell_min + 3) / 4, ntj_all = (n_theta + 15) / 16;
+  // SCRI_AMD_TS_SPLIT=1 and more than four ring tiles (n_theta > 64): two workgroups per m, each with half of them
+  // (measured, round 4: 99 x 99 / l <= 24, 25 000 steps, six fields: 14.65 ms split against 13.09 ms whole -- three waves per SIMD at
+  // 153 registers do not make up for gathering every mode twice; off unless asked for)
+  static const int ts_split = getenv("SCRI_AMD_TS_SPLIT") ? atoi(getenv("SCRI_AMD_TS_SPLIT")) : 0;
+  const int parts = ts_split && ntj_all > 4 ? 2 : 1;
+  const int ntj = (ntj_all + parts - 1) / parts;
+  const dim3 grid1z(grid1.x, grid1.y, parts);
 #define TS_GO(KL, NTJ)                                                                                                      \
-  hipLaunchKernelGGL((theta_synthesis_mfma_kernel<KL, NTJ>), grid1, dim3(256), 0, stream, A, lda, n_rows, n_theta, L, ell_min, jp, \
+  hipLaunchKernelGGL((theta_synthesis_mfma_kernel<KL, NTJ>), grid1z, dim3(256), 0, stream, A, lda, n_rows, n_theta, L, ell_min, jp, \
                      rows_per_block, Tsyn, F)
 #define TS_KL(NTJ)  \
   if (kl <= 5)      \
@@ -497,6 +516,8 @@ hipError_t launch_theta_synthesis(hipStream_t stream, const double* A, long long
     TS_GO(9, NTJ);
   if (ntj <= 3) {
     TS_KL(3)
+  } else if (ntj == 4) {
+    TS_KL(4)
   } else if (ntj <= 5) {
     TS_KL(5)
   } else {
