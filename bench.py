@@ -863,17 +863,19 @@ def main():
                 return {"algorithmic_bytes_per_step": bytes_per_row, "achieved_GBps": gbs, "frac_of_8TBps": gbs / 8000.0}
 
             eval_route = "eval" in DOMINANT_KERNEL
+            two_sweeps = bool(os.environ.get("SCRI_AMD_TWO_SWEEPS"))
             if eval_route:
-                # both sweeps of the spline solve on the n_modes + 1 mode columns, the product reads the solved modes and writes
-                # the SAMPLES (its epilogue evaluates the spline), the analysis reads them: the grid crosses HBM once each way
-                total_bytes = 2 * 32 * (n_modes + 1) + 16 * (n_modes + 1 + n_cols_b) + 16 * (n_cols_b + n_modes_out)
+                # both sweeps of the spline solve on the n_modes + 1 mode columns in ONE pass over memory (read once, written once:
+                # bspline_solve_modes_kernel; two passes with SCRI_AMD_TWO_SWEEPS), the product reads the solved modes and writes the
+                # SAMPLES (its epilogue evaluates the spline), the analysis reads them: the grid crosses HBM once each way
+                total_bytes = (2 if two_sweeps else 1) * 32 * (n_modes + 1) + 16 * (n_modes + 1 + n_cols_b) + 16 * (n_cols_b + n_modes_out)
             else:
                 total_bytes = 16 * (n_modes + n_cols_b) + 32 * n_cols_b + 16 * (n_cols_b + n_modes_out)
             line["hbm_stages"] = {
-                ("spline_back_substitution_on_modes" if eval_route else "spline_back_substitution"):
-                    stage("spline_backward", 32 * (n_modes + 1) if eval_route else 32 * n_cols_b),
                 "analysis": stage("analysis_fused", 16 * (n_cols_b + n_modes_out)),
-                "spline_elimination_on_modes": stage("spline_forward", 32 * (n_modes + 1)),
+                ("spline_solve_on_modes" if eval_route and not two_sweeps else "spline_elimination_on_modes"): stage("spline_forward", 32 * (n_modes + 1)),
+                **({"spline_back_substitution": stage("spline_backward", 32 * n_cols_b)} if not eval_route else
+                   ({"spline_back_substitution_on_modes": stage("spline_backward", 32 * (n_modes + 1))} if two_sweeps else {})),
                 "whole_transform_materialised_grid": {
                     "algorithmic_bytes_per_step": total_bytes,
                     "achieved_GBps": total_bytes * (n_global / world) / (ms_per_step * 1e-3) / 1e9,

@@ -15,6 +15,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <map>
 #include <string>
 #include <vector>
@@ -1431,7 +1432,8 @@ static int column_plan(const bms_transformation* tr, int n_out) {
 // On return T.n_pix is the number of COLUMNS (everything downstream is per column); T.n_theta * T.n_phi stays the grid.
 static int device_pixel_tables(bms_ctx* c, const bms_transformation* tr, PixelTables& T, int mode, int spin, int cw,
                                const std::vector<cplx>* coef0, const std::vector<cplx>* coef1, const cplx cv[4], DevPixel& D,
-                               int plan, hipStream_t PS = nullptr) {
+                               int plan, hipStream_t PS = nullptr,
+                               const std::function<int(hipStream_t, const DevPixel&, int)>& behind_tables = nullptr) {
   if (!PS) PS = c->stream;
   init_pixel_tables(tr, T);
   const int n_pix = T.n_pix, lst = tr->ell_max_supertranslation, nst = (lst + 1) * (lst + 1);
@@ -1485,6 +1487,9 @@ static int device_pixel_tables(bms_ctx* c, const bms_transformation* tr, PixelTa
   // k, alpha, skew_a, skew_b are contiguous (n_pix apart): one copy back
   std::vector<double> back((size_t)4 * n_pix);
   HIP_TRY(c, hipMemcpyAsync(back.data(), D.k, sizeof(double) * 4 * n_pix, hipMemcpyDeviceToHost, PS));
+  // what needs the device tables only (the synthesis matrix: the rotors) is queued behind them on the same stream, so that it
+  // runs while the host waits and the main stream still works on the modes
+  if (behind_tables && (rc = behind_tables(PS, D, n_cols))) return rc;
   HIP_TRY(c, hipStreamSynchronize(PS));
   T.n_pix = n_cols;
   T.k.assign(back.data(), back.data() + n_cols);
@@ -1943,6 +1948,7 @@ static int transform_modes_impl(bms_ctx* c, const bms_wm_input* in, const bms_tr
   PixelTables T;
   DevPixel DP;
   const int col_plan = (grid_out || sep || sep_fields) ? 0 : column_plan(tr, n_out);
+  bool B_built = false;
   if (shared && c->piece_tables_valid) {
     // (the pieces of a pipelined call share the per-direction tables of the first one, built in ITS column order: a piece that
     // chose the other synthesis route -- it would have to hold fewer than two rows -- must not read them in a different order)
@@ -1952,7 +1958,26 @@ static int transform_modes_impl(bms_ctx* c, const bms_wm_input* in, const bms_tr
     T = shared->T;
     DP = shared->DP;
   } else {
-    if ((rc = device_pixel_tables(c, tr, T, psi ? 1 : 0, s, in->conformal_weight, coef0.empty() ? nullptr : &coef0, nullptr, cv, DP, col_plan, c->aux)))
+    // dense route of a single field: its synthesis matrix (and the row that carries the offsets) is built on the auxiliary stream
+    // right behind the per-direction tables, beside the spline solve on the main stream
+    std::function<int(hipStream_t, const DevPixel&, int)> build_B;
+    if (bs && !sep && !sep_fields && !psi && c->aux) {
+      build_B = [&](hipStream_t PS, const DevPixel& D, int n_cols_) -> int {
+        FieldPlan& f = F[0];
+        f.K = 2 * LM_total_size(f.ell_min, f.ell_max);
+        f.ldb = round_up(2LL * n_cols_, 128);
+        const long long rows = round_up(f.K, 16);
+        int rc2;
+        if ((rc2 = dev_buf_t(c, "Bsyn0", (size_t)rows * f.ldb, &f.d_B))) return rc2;
+        HIP_TRY(c, hipMemsetAsync(f.d_B, 0, sizeof(double) * rows * f.ldb, PS));
+        TIMED(c, BMS_TAG_SETUP, launch_swsh_matrix_complex(PS, D.rotors, n_cols_, f.spin, f.ell_min, f.ell_max, f.d_B, f.ldb));
+        TIMED(c, BMS_TAG_SETUP, launch_negated_row(PS, D.col_off, f.d_B + (size_t)(f.K / 2) * f.ldb, 2 * n_cols_));
+        B_built = true;
+        return BMS_OK;
+      };
+    }
+    if ((rc = device_pixel_tables(c, tr, T, psi ? 1 : 0, s, in->conformal_weight, coef0.empty() ? nullptr : &coef0, nullptr, cv, DP, col_plan, c->aux,
+                                  build_B)))
       return rc;
     if (shared) {
       shared->T = T;
@@ -2045,12 +2070,13 @@ static int transform_modes_impl(bms_ctx* c, const bms_wm_input* in, const bms_tr
       }
       continue;
     }
+    if (fi == 0 && B_built) continue;  // (built behind the per-direction tables on the auxiliary stream)
     if ((rc = dev_buf_t(c, nm, (size_t)rows * ldb, &f.d_B))) return rc;
     HIP_TRY(c, hipMemsetAsync(f.d_B, 0, sizeof(double) * rows * ldb, S));
     TIMED(c, BMS_TAG_SETUP, launch_swsh_matrix_complex(S, d_rot, n_cols, f.spin, f.ell_min, f.ell_max, f.d_B, ldb));
   }
   const int n_modes_in = F[0].K / 2;
-  if (bs && !sep)  // row n_modes of B multiplies the eliminated constant series: it carries the per-column offset
+  if (bs && !sep && !B_built)  // row n_modes of B multiplies the eliminated constant series: it carries the per-column offset
     TIMED(c, BMS_TAG_SETUP, launch_negated_row(S, DP.col_off, F[0].d_B + (size_t)n_modes_in * ldb, 2 * n_cols));
   trace.mark("uploads + synthesis matrices");
   AnalysisPlan ana;
@@ -2123,7 +2149,7 @@ static int transform_modes_impl(bms_ctx* c, const bms_wm_input* in, const bms_tr
       ev.search_halfwidth = eval_search_halfwidth(T, cA, cB, in->t, g0, g1);
       ev.inv_dx = (g1 - g0 >= 2 && in->t[g1 - 1] > in->t[g0]) ? (double)(g1 - 1 - g0) / (in->t[g1 - 1] - in->t[g0]) : 0.0;
       ev.side = nullptr, ev.side_ld = ldg;
-      static const int eval_step = getenv("SCRI_AMD_GEMM_EVAL_STEP") ? atoi(getenv("SCRI_AMD_GEMM_EVAL_STEP")) : 64;
+      const int eval_step = getenv("SCRI_AMD_GEMM_EVAL_STEP") ? atoi(getenv("SCRI_AMD_GEMM_EVAL_STEP")) : 64;  // (read per call, like the other route switches)
       if (eval_step != 61)
         if ((rc = dev_buf_t(c, "Cside", (size_t)zgemm3m_eval_side_rows(rows_in) * ldg, &ev.side))) return rc;
       TIMED(c, BMS_TAG_GEMM_SYNTHESIS, launch_zgemm3m_eval(S, d_Ac + (g0 - row0) * ld_af, ld_af, F[0].d_B + 2 * cA, ldb, rows_in, n_pix, n_modes_in + 1,

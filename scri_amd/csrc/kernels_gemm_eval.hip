@@ -389,7 +389,6 @@ __global__ __launch_bounds__(256, 3) void zgemm3m_eval_kernel(const double* __re
 
   unsigned long long tr_t1 = 0;
   if (ev.trace) tr_t1 = __builtin_readcyclecounter();
-  if (ev.dbg & 256) __builtin_amdgcn_s_setprio(3);
   // ---- epilogue: recombine and scale, then the tile is parked in the operand LDS half by half (columns 0..31 by the waves wn = 0,
   // then 32..63) and every thread evaluates 8 windows of one column of the parked half
   double2 cv[2][2][4];
@@ -512,7 +511,7 @@ hipError_t launch_zgemm3m_eval(hipStream_t stream, const double* A, long long ld
   ev.side = e.side, ev.side_ld = e.side_ld;
   static const int dbg_env = getenv("SCRI_AMD_GEMM_EVAL_DBG") ? atoi(getenv("SCRI_AMD_GEMM_EVAL_DBG")) : 0;
   ev.dbg = dbg_env;
-  static const int step_env = getenv("SCRI_AMD_GEMM_EVAL_STEP") ? atoi(getenv("SCRI_AMD_GEMM_EVAL_STEP")) : 0;
+  const int step_env = getenv("SCRI_AMD_GEMM_EVAL_STEP") ? atoi(getenv("SCRI_AMD_GEMM_EVAL_STEP")) : 0;
   const int step = (step_env == 61 || step_env == 64) ? step_env : (e.side ? 64 : 61);
   if (step == 64 && !e.side) return hipErrorInvalidValue;
   if (step == 61) ev.side = nullptr;

@@ -41,6 +41,10 @@ def _zrot(a):
 
 WM_CASES = {
     "boosted (dense product, B-spline on the modes)": dict(boost=[1e-3, 2e-3, -3e-3], rot=[0.9, 0.1, -0.3, 0.2], env={}),
+    "boosted, overlapping row tiles of the evaluating product": dict(boost=[1e-3, 2e-3, -3e-3], rot=[0.9, 0.1, -0.3, 0.2], env={"SCRI_AMD_GEMM_EVAL_STEP": "61"}),
+    "boosted, two sweeps on the modes": dict(boost=[1e-3, 2e-3, -3e-3], rot=[0.9, 0.1, -0.3, 0.2], env={"SCRI_AMD_TWO_SWEEPS": "1"}),
+    "boosted, back substitution on the grid": dict(boost=[1e-3, 2e-3, -3e-3], rot=[0.9, 0.1, -0.3, 0.2], env={"SCRI_AMD_NO_GEMM_EVAL": "1"}),
+    "strongly boosted (samples far from their knots: global-memory march)": dict(boost=[0.1, -0.2, 0.15], rot=[0.9, 0.1, -0.3, 0.2], env={}),
     "boost-free (one-kernel separable synthesis)": dict(boost=[0, 0, 0], rot=[0.9, 0.1, -0.3, 0.2], env={}),
     "boost-free, two-kernel form": dict(boost=[0, 0, 0], rot=[1.0, 0, 0, 0], env={"SCRI_AMD_NO_SPLIT_SYNTHESIS": "1"}),
     "axis boost (one-kernel form with the scale)": dict(boost=[0, 0, 0.2], rot=_zrot(0.4), env={"SCRI_AMD_AXIS_BOOST_MIN_WORK": "0"}),
@@ -57,7 +61,7 @@ def test_transform_modes_between_guards(ctx, monkeypatch, case, ell_max, n):
 
     spec = WM_CASES[case]
     for k in ("SCRI_AMD_NO_SEPARABLE_SYNTHESIS", "SCRI_AMD_NO_SPLIT_SYNTHESIS", "SCRI_AMD_AXIS_BOOST_MIN_WORK", "SCRI_AMD_NO_BSPLINE",
-              "SCRI_AMD_NO_SPLIT_ANALYSIS", "SCRI_AMD_NO_AXIS_BOOST_SEPARABLE"):
+              "SCRI_AMD_NO_SPLIT_ANALYSIS", "SCRI_AMD_NO_AXIS_BOOST_SEPARABLE", "SCRI_AMD_GEMM_EVAL_STEP", "SCRI_AMD_TWO_SWEEPS", "SCRI_AMD_NO_GEMM_EVAL"):
         monkeypatch.delenv(k, raising=False)
     for k, v in spec["env"].items():
         monkeypatch.setenv(k, v)
@@ -237,6 +241,51 @@ def test_psi_type_with_device_companions_and_a_shard_between_guards(ctx, monkeyp
         assert np.abs(t_ref[i_first : i_first + n_new] - t_out).max() < 1e-12
         assert np.abs(got - d_ref[i_first : i_first + n_new]).max() < 1e-13 * max(1.0, np.abs(d_ref).max())
         _check_guards(dst, (o1 - o0) * n3)
+
+
+@pytest.mark.parametrize("env", [{}, {"SCRI_AMD_GEMM_EVAL_STEP": "61"}, {"SCRI_AMD_TWO_SWEEPS": "1"}])
+@pytest.mark.parametrize("boost_scale", [1.0, 40.0])
+def test_h_type_time_shard_through_the_evaluating_product_between_guards(ctx, monkeypatch, env, boost_scale):
+    """The dense route of the h type (spline solved on the modes in one pass, evaluated in the product's epilogue, straddle kernel)
+    on a time shard from the middle of a series whose buffer holds ONLY the planned rows -- the solve kernel's run-in rows, the
+    product's row tiles, the staged knot / abscissa windows and the side rows all end at the shard's edges -- and on the whole
+    series; a strong boost (samples tens of rows from their knots) as well."""
+    from scri_amd import engine, synthetic
+
+    for k in ("SCRI_AMD_GEMM_EVAL_STEP", "SCRI_AMD_TWO_SWEEPS", "SCRI_AMD_NO_GEMM_EVAL", "SCRI_AMD_NO_BSPLINE"):
+        monkeypatch.delenv(k, raising=False)
+    n, ell_max = 2100, 9
+    t = np.linspace(0.0, 210.0, n) + 0.01 * np.sin(np.linspace(0.0, 60.0, n))  # (not quite uniform: the row guess has to be checked)
+    data = synthetic.chirp_modes(t, 2, ell_max, 21)
+    nm = data.shape[1]
+    st = synthetic.real_supertranslation(0.1 * (np.arange(9) - 2.0 + 0.5j * np.arange(9)))
+    n_theta = 2 * (ell_max + 2) + 1
+    tr = engine.make_transformation(st, [0.8, 0.2, -0.5, 0.1], list(boost_scale * np.array([2e-3, -1e-3, 3e-3])), n_theta, n_theta, ell_max)
+    monkeypatch.setenv("SCRI_AMD_NO_GEMM_EVAL", "1")
+    t_ref, d_ref = engine.transform_modes(t, data, 2, ell_max, -2, -1, engine.BMS_TERM_H, tr, ctx=ctx)  # back substitution on the grid
+    monkeypatch.delenv("SCRI_AMD_NO_GEMM_EVAL")
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    scale = max(1.0, np.abs(d_ref).max())
+    src, sp = _guarded_input(data)
+    dst, dp = _guarded_output(n * nm)
+    t_out, n_new = engine.transform_modes(t, sp, 2, ell_max, -2, -1, engine.BMS_TERM_H, tr, ctx=ctx, device=True, ld=nm, out_ptr=dp)
+    ctx.synchronize()
+    got = dst[GUARD : GUARD + n_new * nm].cpu().numpy().reshape(n_new, nm)
+    assert n_new == d_ref.shape[0] and np.array_equal(t_out, t_ref) and np.isfinite(got).all()
+    assert np.abs(got - d_ref).max() < 1e-13 * scale
+    _check_guards(dst, n * nm)
+    for o0, o1 in ((700, 1300), (0, 150), (n - 400, n)):  # (the strong boost trims ~ 270 rows from the end of the output)
+        (r0, r1), (w0, w1) = engine.shard_plan(t, tr, o0, o1)
+        src, sp = _guarded_input(data[r0:r1])
+        dst, dp = _guarded_output((o1 - o0) * nm)
+        t_out, n_new, first = engine.transform_modes(t, sp, 2, ell_max, -2, -1, engine.BMS_TERM_H, tr, ctx=ctx, device=True, ld=nm, out_ptr=dp,
+                                                     shard=(r0, r1 - r0, o0, o1))
+        ctx.synchronize()
+        got = dst[GUARD : GUARD + n_new * nm].cpu().numpy().reshape(n_new, nm)
+        assert n_new == min(o1, w1) - max(o0, w0) > 50 and first == max(o0, w0) and np.isfinite(got).all()
+        assert np.abs(got - d_ref[first - w0 : first - w0 + n_new]).max() < 1e-13 * scale
+        _check_guards(dst, (o1 - o0) * nm)
 
 
 def test_abd_shard_and_column_parts_between_guards(ctx, monkeypatch):
