@@ -88,6 +88,11 @@ struct bms_ctx {
   // constant rotors of internal rotations travel through a page-locked ring (a truly asynchronous copy: no stream
   // synchronisation to protect a stack copy); the ring is drained once per lap
   double* rot_ring_host = nullptr;
+  // per-direction scalars on their way back to the host (device_pixel_tables): page-locked, so that the copy is asynchronous and what is
+  // queued behind it starts without the host; two events order the host and the main stream behind the auxiliary one
+  double* pix_back_host = nullptr;
+  size_t pix_back_cap = 0;
+  hipEvent_t ev_tables = nullptr, ev_aux_done = nullptr;
   double* rot_ring_dev = nullptr;
   int rot_ring_next = 0;
   std::map<std::pair<int, int>, RotResPlan> rot_res_plans;  // LDS-resident table images built so far, by (ell_min, ell_max)
@@ -329,6 +334,9 @@ extern "C" void bms_ctx_destroy(bms_ctx* c) {
   }
   for (auto e : c->event_pool) (void)hipEventDestroy(e);
   if (c->rot_ring_host) (void)hipHostFree(c->rot_ring_host);
+  if (c->pix_back_host) (void)hipHostFree(c->pix_back_host);
+  if (c->ev_tables) (void)hipEventDestroy(c->ev_tables);
+  if (c->ev_aux_done) (void)hipEventDestroy(c->ev_aux_done);
   if (c->rot_ring_dev) (void)hipFree(c->rot_ring_dev);
   if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
   if (c->aux) (void)hipStreamDestroy(c->aux);
@@ -1161,11 +1169,17 @@ static void time_window(int64_t n, const bms_shard* sh, int64_t& lo, int64_t& hi
 // spline tile for the whole-series building blocks (slope form): one tile = exact recurrences on an irregular axis
 static int spline_tile_for(const double* x, int64_t n);
 
-static int validate_common(bms_ctx* c, int64_t n, const double* t, const bms_transformation* tr, int64_t lo = 0, int64_t hi = -1,
-                           bool* regular = nullptr, int64_t n_min = 4) {
+// (the two halves of validate_common, for the caller that has the GPU start on the call before the host walks the time axis)
+static int validate_transformation(bms_ctx* c, int64_t n, const double* t, const bms_transformation* tr, int64_t n_min) {
   if (n < n_min) return fail(c, BMS_ERR_INVALID, "need at least %lld time steps, got %lld", (long long)n_min, (long long)n);
-  if (hi < 0) hi = n;
   if (!(t[n - 1] > t[0])) return fail(c, BMS_ERR_INVALID, "time array must be strictly increasing (first/last)");
+  if (tr->n_theta < 2 || tr->n_phi < 1) return fail(c, BMS_ERR_INVALID, "bad grid size %d x %d", tr->n_theta, tr->n_phi);
+  if (tr->ell_max_supertranslation < 1 || !tr->supertranslation) return fail(c, BMS_ERR_INVALID, "supertranslation must hold at least l <= 1");
+  const double* v = tr->boost_velocity;
+  if (!(v[0] * v[0] + v[1] * v[1] + v[2] * v[2] < 1.0)) return fail(c, BMS_ERR_INVALID, "boost speed must be < 1");
+  return BMS_OK;
+}
+static int walk_time_axis(bms_ctx* c, const double* t, int64_t lo, int64_t hi, bool* regular) {
   double bmin[3] = {INFINITY, INFINITY, INFINITY}, bmax[3] = {0.0, 0.0, 0.0};  // step range of the last three 16-step blocks
   bool reg = true;
   // (block by block, the block's minimum and maximum by a branch-free inner loop the compiler vectorises -- this walk is host
@@ -1191,11 +1205,16 @@ static int validate_common(bms_ctx* c, int64_t n, const double* t, const bms_tra
     bmax[0] = bmax[1], bmax[1] = bmax[2];
   }
   if (regular) *regular = reg || getenv("SCRI_AMD_ASSUME_REGULAR_MESH") != nullptr;  // (the switch exists to show what the guard prevents)
-  if (tr->n_theta < 2 || tr->n_phi < 1) return fail(c, BMS_ERR_INVALID, "bad grid size %d x %d", tr->n_theta, tr->n_phi);
-  if (tr->ell_max_supertranslation < 1 || !tr->supertranslation) return fail(c, BMS_ERR_INVALID, "supertranslation must hold at least l <= 1");
-  const double* v = tr->boost_velocity;
-  if (!(v[0] * v[0] + v[1] * v[1] + v[2] * v[2] < 1.0)) return fail(c, BMS_ERR_INVALID, "boost speed must be < 1");
   return BMS_OK;
+}
+static int validate_common(bms_ctx* c, int64_t n, const double* t, const bms_transformation* tr, int64_t lo = 0, int64_t hi = -1,
+                           bool* regular = nullptr, int64_t n_min = 4) {
+  // (order of the checks as it always was: size, first/last, the walk, then the transformation)
+  if (n < n_min) return fail(c, BMS_ERR_INVALID, "need at least %lld time steps, got %lld", (long long)n_min, (long long)n);
+  if (!(t[n - 1] > t[0])) return fail(c, BMS_ERR_INVALID, "time array must be strictly increasing (first/last)");
+  int rc = walk_time_axis(c, t, lo, hi < 0 ? n : hi, regular);
+  if (rc) return rc;
+  return validate_transformation(c, n, t, tr, n_min);
 }
 
 
@@ -1441,7 +1460,8 @@ static int column_plan(const bms_transformation* tr, int n_out) {
 static int device_pixel_tables(bms_ctx* c, const bms_transformation* tr, PixelTables& T, int mode, int spin, int cw,
                                const std::vector<cplx>* coef0, const std::vector<cplx>* coef1, const cplx cv[4], DevPixel& D,
                                int plan, hipStream_t PS = nullptr,
-                               const std::function<int(hipStream_t, const DevPixel&, int)>& behind_tables = nullptr) {
+                               const std::function<int(hipStream_t, const DevPixel&, int)>& behind_tables = nullptr,
+                               const std::function<void()>& while_waiting = nullptr) {
   if (!PS) PS = c->stream;
   init_pixel_tables(tr, T);
   const int n_pix = T.n_pix, lst = tr->ell_max_supertranslation, nst = (lst + 1) * (lst + 1);
@@ -1492,18 +1512,37 @@ static int device_pixel_tables(bms_ctx* c, const bms_transformation* tr, PixelTa
     D.col_of_pixel = d_perm + n_pix;
   }
   TIMED(c, BMS_TAG_SETUP, launch_pixel_tables(PS, P, O, n_cols, d_perm));
-  // k, alpha, skew_a, skew_b are contiguous (n_pix apart): one copy back
-  std::vector<double> back((size_t)4 * n_pix);
-  HIP_TRY(c, hipMemcpyAsync(back.data(), D.k, sizeof(double) * 4 * n_pix, hipMemcpyDeviceToHost, PS));
-  // what needs the device tables only (the synthesis matrix: the rotors) is queued behind them on the same stream, so that it
-  // runs while the host waits and the main stream still works on the modes
-  if (behind_tables && (rc = behind_tables(PS, D, n_cols))) return rc;
-  HIP_TRY(c, hipStreamSynchronize(PS));
+  // k, alpha, skew_a, skew_b are contiguous (n_pix apart): one copy back, into page-locked memory
+  if (c->pix_back_cap < (size_t)4 * n_pix) {
+    if (c->pix_back_host) (void)hipHostFree(c->pix_back_host);
+    c->pix_back_host = nullptr, c->pix_back_cap = 0;
+    HIP_TRY(c, hipHostMalloc((void**)&c->pix_back_host, sizeof(double) * 4 * n_pix, hipHostMallocDefault));
+    c->pix_back_cap = (size_t)4 * n_pix;
+  }
+  const double* back = c->pix_back_host;
+  HIP_TRY(c, hipMemcpyAsync(c->pix_back_host, D.k, sizeof(double) * 4 * n_pix, hipMemcpyDeviceToHost, PS));
+  if (behind_tables && PS != c->stream) {
+    // what needs the device tables only (the synthesis matrix: the rotors) is queued behind them on the same stream: it runs while the
+    // main stream still works on the modes; the host waits for the copy alone, the main stream for all of it
+    if (!c->ev_tables) HIP_TRY(c, hipEventCreateWithFlags(&c->ev_tables, hipEventDisableTiming));
+    if (!c->ev_aux_done) HIP_TRY(c, hipEventCreateWithFlags(&c->ev_aux_done, hipEventDisableTiming));
+    HIP_TRY(c, hipEventRecord(c->ev_tables, PS));
+    rc = behind_tables(PS, D, n_cols);
+    HIP_TRY(c, hipEventRecord(c->ev_aux_done, PS));
+    HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev_aux_done, 0));
+    if (while_waiting) while_waiting();  // host work of the caller that needs nothing from here
+    HIP_TRY(c, hipEventSynchronize(c->ev_tables));
+    if (rc) return rc;
+  } else {
+    if (behind_tables && (rc = behind_tables(PS, D, n_cols))) return rc;
+    if (while_waiting) while_waiting();
+    HIP_TRY(c, hipStreamSynchronize(PS));
+  }
   T.n_pix = n_cols;
-  T.k.assign(back.data(), back.data() + n_cols);
-  T.alpha.assign(back.data() + n_pix, back.data() + n_pix + n_cols);
-  T.skew_a.assign(back.data() + 2 * (size_t)n_pix, back.data() + 2 * (size_t)n_pix + n_cols);
-  T.skew_b.assign(back.data() + 3 * (size_t)n_pix, back.data() + 3 * (size_t)n_pix + n_cols);
+  T.k.assign(back, back + n_cols);
+  T.alpha.assign(back + n_pix, back + n_pix + n_cols);
+  T.skew_a.assign(back + 2 * (size_t)n_pix, back + 2 * (size_t)n_pix + n_cols);
+  T.skew_b.assign(back + 3 * (size_t)n_pix, back + 3 * (size_t)n_pix + n_cols);
   return BMS_OK;
 }
 
@@ -1600,7 +1639,7 @@ extern "C" int bms_output_window(bms_ctx* c, const double* t, int64_t n, const b
 }
 
 static int transform_modes_impl(bms_ctx* c, const bms_wm_input* in, const bms_transformation* tr, const bms_shard* sh, double* t_out,
-                                void* data_out, int64_t* n_times_out, int64_t* first_index_out, void* grid_out);
+                                void* data_out, int64_t* n_times_out, int64_t* first_index_out, void* grid_out, bool walk_first = false);
 
 extern "C" int bms_transform_modes_shard(bms_ctx* c, const bms_wm_input* in, const bms_transformation* tr,
                                          const bms_shard* sh, double* t_out, void* data_out, int64_t* n_times_out,
@@ -1773,7 +1812,7 @@ extern "C" int bms_modes_to_grid(bms_ctx* c, const bms_wm_input* in, const bms_t
 }
 
 static int transform_modes_impl(bms_ctx* c, const bms_wm_input* in, const bms_transformation* tr, const bms_shard* sh, double* t_out,
-                                void* data_out, int64_t* n_times_out, int64_t* first_index_out, void* grid_out) {
+                                void* data_out, int64_t* n_times_out, int64_t* first_index_out, void* grid_out, bool walk_first) {
   if (!in || !tr || !t_out || !n_times_out) return fail(c, BMS_ERR_INVALID, "NULL argument");
   HIP_TRY(c, hipSetDevice(c->device));
   const int64_t n = in->n_times;
@@ -1802,9 +1841,18 @@ static int transform_modes_impl(bms_ctx* c, const bms_wm_input* in, const bms_tr
     const int64_t r0 = sh ? sh->data_row0 : 0, r1 = r0 + (sh ? sh->data_rows : n);
     if ((rc = upload_times_bspline(c, in->t, n, t_lo, t_hi, r0, r1, &d_x, &d_bstab, &d_bsfwd))) return rc;
   }
-  rc = validate_common(c, n, in->t, tr, t_lo, t_hi, &regular_mesh);
+  // The walk itself is put off as well, to the moment the host would otherwise sit waiting for the per-direction tables: until then
+  // the axis is taken to be what it nearly always is (increasing, not graded).  A walk that finds otherwise drains what was queued
+  // and either fails the call as it always did or starts it again, walk first.
+  const bool walk_later = times_ahead && c->aux && !walk_first && !getenv("SCRI_AMD_WALK_FIRST");
+  int walk_rc = BMS_OK;
+  bool walked = false, walk_regular = true;
+  if (walk_later) {
+    rc = validate_transformation(c, n, in->t, tr, 4);
+  } else
+    rc = validate_common(c, n, in->t, tr, t_lo, t_hi, &regular_mesh);
   if (rc) return rc;
-  trace0.mark("time upload + spline factors (enqueue), validate_common (walk over the time axis)");
+  trace0.mark("time upload + spline factors (enqueue), checks");
   const int s = in->spin_weight;
   if (in->ell_min < 0 || in->ell_max < in->ell_min) return fail(c, BMS_ERR_INVALID, "bad ell range");
   const int n_modes = LM_total_size(in->ell_min, in->ell_max);
@@ -1926,7 +1974,10 @@ static int transform_modes_impl(bms_ctx* c, const bms_wm_input* in, const bms_tr
   double* d_Ac = nullptr;
   if (gemm_eval) {
     // both sweeps of the spline solve on the modes: in one pass over memory (a thread keeps its column's tile in registers), or --
-    // SCRI_AMD_TWO_SWEEPS, the form the kernel was checked against -- as elimination and back substitution one after the other
+    // SCRI_AMD_TWO_SWEEPS, the form the kernel was checked against -- as elimination and back substitution one after the other.
+    // (Queued BEFORE the per-direction tables of the auxiliary stream: behind them -- so that their few small workgroups find free
+    // SIMDs, which this kernel's 2 x 245 registers per lane do not leave -- the host's wait shrinks from 300 to 250 us, but the solve
+    // starts that much later and the product waits for it: 5.56 against 5.41 ms per transform.)
     if ((rc = dev_buf_t(c, "Afull", (size_t)rows_avail * ld_af, &d_Ac))) return rc;
     if (getenv("SCRI_AMD_TWO_SWEEPS")) {
       if ((rc = dev_buf_t(c, "Afwd", (size_t)rows_avail * ld_af, &d_Af))) return rc;
@@ -1998,9 +2049,24 @@ static int transform_modes_impl(bms_ctx* c, const bms_wm_input* in, const bms_tr
         return BMS_OK;
       };
     }
-    if ((rc = device_pixel_tables(c, tr, T, psi ? 1 : 0, s, in->conformal_weight, coef0.empty() ? nullptr : &coef0, nullptr, cv, DP, col_plan, c->aux,
-                                  build_B)))
-      return rc;
+    std::function<void()> walk;
+    if (walk_later)
+      walk = [&] {
+        walk_rc = walk_time_axis(c, in->t, t_lo, t_hi, &walk_regular);
+        walked = true;
+      };
+    rc = device_pixel_tables(c, tr, T, psi ? 1 : 0, s, in->conformal_weight, coef0.empty() ? nullptr : &coef0, nullptr, cv, DP, col_plan, c->aux, build_B,
+                             walk);
+    if (walk_later) {
+      if (!walked) walk();  // (device_pixel_tables left before its wait)
+      if (walk_rc) return walk_rc;
+      if (!walk_regular) {  // graded axis: everything above was planned for a regular one
+        HIP_TRY(c, hipStreamSynchronize(c->aux));
+        HIP_TRY(c, hipStreamSynchronize(S));
+        return transform_modes_impl(c, in, tr, sh, t_out, data_out, n_times_out, first_index_out, grid_out, true);
+      }
+    }
+    if (rc) return rc;
     if (shared) {
       shared->T = T;
       shared->DP = DP;

@@ -473,3 +473,39 @@ def test_separable_synthesis_reads_nothing_past_the_modes(ctx, monkeypatch, n):
     ref = run()
     assert got.shape == ref.shape and not np.array_equal(got, ref)
     assert np.abs(got - ref).max() < 1e-13 * max(1.0, np.abs(ref).max())
+
+
+@pytest.mark.parametrize("defect", ["swap", "repeat", "nan"])
+def test_defect_in_the_middle_of_the_time_axis_is_reported_by_the_late_walk(ctx, defect, monkeypatch):
+    """The host walks the time axis while it waits for the per-direction tables (engine.hip, `walk_later`): by then the time axis is in
+    HBM and the spline solve has been queued on it.  A defect found by that walk fails the call exactly as the walk-first order does,
+    and the context is usable afterwards."""
+    from scri_amd import engine
+
+    rng = np.random.default_rng(5)
+    n, ell_max = 4000, 4
+    t = np.linspace(-50.0, 150.0, n)
+    nm = (ell_max + 1) ** 2 - 4
+    data = rng.normal(size=(n, nm)) + 1j * rng.normal(size=(n, nm))
+    st = np.zeros(9, dtype=complex)
+    st[0] = 0.1
+    tr = engine.make_transformation(st, [1, 0, 0, 0], np.array([0.01, 0.02, -0.01]), 13, 13, ell_max)
+    good = engine.transform_modes(t, data, 2, ell_max, -2, -1, engine.BMS_TERM_H, tr, ctx=ctx)
+    bad = t.copy()
+    if defect == "swap":
+        bad[2500], bad[2501] = bad[2501], bad[2500]
+    elif defect == "repeat":
+        bad[2501] = bad[2500]
+    else:
+        bad[2501] = np.nan
+    messages = []
+    for first in (False, True):
+        if first:
+            monkeypatch.setenv("SCRI_AMD_WALK_FIRST", "1")
+        with pytest.raises(ValueError, match=r"strictly increasing \(index 250[12]\)") as err:
+            engine.transform_modes(bad, data, 2, ell_max, -2, -1, engine.BMS_TERM_H, tr, ctx=ctx)
+        messages.append(str(err.value))
+    assert messages[0] == messages[1]
+    monkeypatch.delenv("SCRI_AMD_WALK_FIRST")
+    again = engine.transform_modes(t, data, 2, ell_max, -2, -1, engine.BMS_TERM_H, tr, ctx=ctx)
+    assert np.array_equal(again[0], good[0]) and np.array_equal(again[1], good[1])
