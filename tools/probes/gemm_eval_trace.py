@@ -35,3 +35,8 @@ print("one CU, first 12 blocks (start, K end, exit; relative, kcycles):")
 for r in o[:12]:
     print("  wave slot %2d simd %d: %8.1f %8.1f %8.1f   tile %d,%d" % (wave[m][r], simd[m][r], (t0[m][r] - base) / 1e3, (t1[m][r] - base) / 1e3, (t2[m][r] - base) / 1e3,
                                                              a[m][r, 1] & 0xFFFFFFFF, a[m][r, 1] >> 32))
+# K loop duration by column panel: is the half-empty last panel (its waves wn = 1 skip their products) any quicker?
+bn = (a[:, 1] >> 32).astype(np.int64)
+for p in sorted(set([0, 1, int(bn.max()) - 1, int(bn.max())])):
+    sel = bn == p
+    print("panel %2d: K loop median %8.0f, epilogue median %8.0f (%d tiles)" % (p, np.median((t1 - t0)[sel]), np.median((t2 - t1)[sel]), sel.sum()))
