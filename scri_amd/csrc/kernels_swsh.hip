@@ -120,7 +120,7 @@ hipError_t launch_pixel_tables(hipStream_t stream, const PixelSpec& P, const Pix
 // adjacent columns marching over the knots together, would write every output row in 16-byte pieces.  Storing the
 // columns sorted by the skew rate keeps the lanes of a wave within a few rows of each other at any time.  Nothing else
 // cares about the order (the synthesis matrix and every per-pixel table are simply built in it); the analysis reads
-// grid pixel g from column inv[g].  One workgroup, (key, index) pairs ranked in LDS; n <= 2048.
+// grid pixel g from column inv[g].  One workgroup, bitonic sort of (key, index) pairs in LDS; n <= 2048.
 constexpr int SORT_N = 2048;
 // The rings theta = 0 and theta = pi are one direction each: their n_phi pixels differ only by a rotation of the rotor
 // about its own z axis, i.e. by the spin phase e^{-+ i s phi_k} of the value.  Only pixel k = 0 of a pole ring becomes a
@@ -152,24 +152,22 @@ __global__ __launch_bounds__(1024) void pixel_sort_kernel(PixelSpec P, int n, in
     k[i] = key;
     id[i] = i;
   }
-  // Rank by counting: position of item i = number of items before it in the order (key, index).  Every thread reads the same
-  // LDS word at the same time (a broadcast), n <= 2048 turns of two compares: a tenth of the 66 barrier-separated stages of a
-  // bitonic network on this size, and the same permutation (the order is total).
-  __syncthreads();
-  (void)sort_n;
-  int rank[SORT_N / 1024] = {0, 0};
-  double mine[SORT_N / 1024];
-#pragma unroll
-  for (int r = 0; r < SORT_N / 1024; ++r) mine[r] = tid + 1024 * r < n ? k[tid + 1024 * r] : INFINITY;
-  for (int j = 0; j < n; ++j) {
-    const double kj = k[j];
-#pragma unroll
-    for (int r = 0; r < SORT_N / 1024; ++r) rank[r] += (kj < mine[r] || (kj == mine[r] && j < tid + 1024 * r)) ? 1 : 0;
+  for (int size = 2; size <= sort_n; size <<= 1) {
+    for (int stride = size >> 1; stride > 0; stride >>= 1) {
+      __syncthreads();
+      for (int t = tid; t < sort_n / 2; t += blockDim.x) {
+        const int a = 2 * t - (t & (stride - 1)), b = a + stride;
+        const bool up = (a & size) == 0;
+        const double ka = k[a], kb = k[b];
+        const int ia = id[a], ib = id[b];
+        const bool a_gt_b = ka > kb || (ka == kb && ia > ib);
+        if (a_gt_b == up) {
+          k[a] = kb, k[b] = ka;
+          id[a] = ib, id[b] = ia;
+        }
+      }
+    }
   }
-  __syncthreads();
-#pragma unroll
-  for (int r = 0; r < SORT_N / 1024; ++r)
-    if (tid + 1024 * r < n) id[rank[r]] = tid + 1024 * r;
   __syncthreads();
   const int n_cols = n - 2 * (n_phi - 1);
   for (int i = tid; i < n_cols; i += blockDim.x) {
