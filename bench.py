@@ -769,6 +769,14 @@ def main():
         if traffic is None and not pmc_child:
             traffic, fallback_note = committed_pmc_traffic(args.workload, world, per_gpu)
             traffic_note = fallback_note if traffic_note == "not measured" else f"{traffic_note}; {fallback_note}"
+        # what the workload's transformation is made of, and with it the route and the kernel that dominates: with a boost the dense
+        # product (MFMA-bound); without one (cfg2: a rotor series first, then supertranslation only) the separable synthesis, HBM-bound
+        v_kw = np.asarray(kw.get("boost_velocity", np.zeros(3)), dtype=float)
+        has_boost = bool(np.any(v_kw != 0.0))
+        workload_terms = " + ".join(
+            [f"supertranslation(l<={int(round(np.sqrt(len(kw['supertranslation'])))) - 1})"] * ("supertranslation" in kw)
+            + ["frame_rotation"] * ("frame_rotation" in kw)
+            + [f"boost |v|={float(np.linalg.norm(v_kw)):.3g}"] * has_boost) or "identity"
         line = {
             "metric": {
                 "cfg3": "timesteps/sec for full BMS transform, l_max=16, 1e5 steps; fp64",
@@ -792,7 +800,9 @@ def main():
                     f"{args.workload}: AsymptoticBondiData psi0..psi4 + sigma, ell 0..{ell_max} (6 x {n_modes} modes), " if abd
                     else f"{args.workload}: WaveformModes h, ell 2..{ell_max} ({n_modes} modes), "
                 )
-                + f"{per_gpu} time steps per GPU ({n_global} total), supertranslation(l<=2) + frame_rotation + boost |v|={3.7417e-4 * args.boost_scale:.3g}, "
+                + f"{per_gpu} time steps per GPU ({n_global} total), " + workload_terms
+                + (" (cfg2's second step; its first, the rotor series, is the `rotation` line of the default run at this l range: tools/bench_rotation.py 8)"
+                   if args.workload == "cfg2" else "") + ", "
                 f"{n_theta}x{n_theta} grid, {n_out} output steps on rank 0",
                 "ranks": dict({"world_size": dist.get_world_size() if world > 1 else 1, "backend": dist.get_backend() if world > 1 else None},
                               **({"note": backend_note} if backend_note else {})),
@@ -828,6 +838,14 @@ def main():
             },
             "kernels": kernels,
         }
+        if not has_boost and not abd and g_ms > 0:
+            # no dense product on this route: the dominant kernel is the separable synthesis (reads the solved / eliminated modes, writes the grid)
+            bytes_per_row = 16 * (n_modes + 1 + n_pix)
+            ms_launch = g_ms / max(g_calls, 1)
+            gbs = bytes_per_row * rows_in / (ms_launch * 1e-3) / 1e9
+            line["roofline"] = {"bound": "hbm", "kernel": "synthesis_split_kernel (separable synthesis: no boost in this workload)", "achieved": gbs, "peak": 8000.0,
+                                "unit": "GB/s", "frac": gbs / 8000.0, "traffic": None, "traffic_source": "no PMC pass for this workload",
+                                "bytes_per_step": bytes_per_row, "ms_per_launch": ms_launch, "csrc_hash": csrc_hash()}
         if world > 1 and not columns:
             all_halo = [(have[r][0] - need[r][0], need[r][1] - have[r][1]) for r in range(world)]
             row_bytes = 16 * n_modes * n_fields
