@@ -838,8 +838,10 @@ def main():
             },
             "kernels": kernels,
         }
-        if not has_boost and not abd and g_ms > 0:
-            # no dense product on this route: the dominant kernel is the separable synthesis (reads the solved / eliminated modes, writes the grid)
+        if not has_boost and not abd and g_ms > 0 and timing.get("spline_backward", (0.0, 0))[1] > 0:
+            # no dense product on this route (a boost-free shape too large for the engine's small-shape rule, which keeps l <= 8 on the evaluating
+            # product: then there is no back substitution on the grid and the MFMA roofline above is the right one): the dominant kernel is the
+            # separable synthesis (reads the eliminated modes, writes the grid)
             bytes_per_row = 16 * (n_modes + 1 + n_pix)
             ms_launch = g_ms / max(g_calls, 1)
             gbs = bytes_per_row * rows_in / (ms_launch * 1e-3) / 1e9

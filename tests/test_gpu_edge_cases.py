@@ -85,9 +85,10 @@ def test_large_grid_analysis_variants(ctx, monkeypatch, n_theta, n_phi, spin, el
 
 
 @pytest.mark.parametrize("n_theta,n_phi", [(20, 24), (31, 38), (19, 18), (39, 39), (17, 34)])
-def test_separable_synthesis_on_user_grids(ctx, n_theta, n_phi):
+def test_separable_synthesis_on_user_grids(ctx, n_theta, n_phi, monkeypatch):
     """Boost-free transformations on caller-chosen grids, even n_phi included (a Nyquist column that is its own mirror image,
     side columns k = 17..19 of the 4x4x4 product) against the oracle."""
+    monkeypatch.setenv("SCRI_AMD_NO_SMALL_DENSE", "1")  # (shapes this small take the evaluating product by default: the separable kernels are meant)
     t = np.linspace(-5, 25, 180)
     _check(_wm(t, 6, 13), ctx, n_theta=n_theta, n_phi=n_phi, supertranslation=np.array([0.3, 0.1 - 0.2j, 0.15, -0.1 - 0.2j]),
            frame_rotation=np.array([0.8, -0.3, 0.4, 0.2]))
@@ -151,6 +152,7 @@ def test_boost_free_transformations_take_the_separable_synthesis(ctx, monkeypatc
         return w.transform(**kw)
 
     monkeypatch.delenv("SCRI_AMD_NO_SEPARABLE_SYNTHESIS", raising=False)  # (the suite may be run with the switch set)
+    monkeypatch.setenv("SCRI_AMD_NO_SMALL_DENSE", "1")  # (up to l <= 8 the default is the evaluating product: next test)
     ctx.enable_timing(True)
     ctx.get_timing(reset=True)
     got = run()
@@ -441,6 +443,7 @@ def test_separable_synthesis_reads_nothing_past_the_modes(ctx, monkeypatch, n):
     """Boost-free psi-type / slope-form transformations hand the one-kernel synthesis rows WITHOUT the constant column the h / sigma
     route appends: the kernel must not touch the element behind a row's modes (behind the last row: memory past the caller's
     buffer).  A device-resident series whose buffer is followed by NaNs shows it."""
+    monkeypatch.setenv("SCRI_AMD_NO_SMALL_DENSE", "1")
     import torch
     from scri_amd import engine, synthetic
 
@@ -509,3 +512,39 @@ def test_defect_in_the_middle_of_the_time_axis_is_reported_by_the_late_walk(ctx,
     monkeypatch.delenv("SCRI_AMD_WALK_FIRST")
     again = engine.transform_modes(t, data, 2, ell_max, -2, -1, engine.BMS_TERM_H, tr, ctx=ctx)
     assert np.array_equal(again[0], good[0]) and np.array_equal(again[1], good[1])
+
+
+
+@pytest.mark.parametrize("ell_max,n,expect_dense", [(4, 300, True), (8, 900, True), (8, 9, True), (10, 400, False)])
+def test_small_boost_free_shapes_take_the_evaluating_product(ctx, monkeypatch, ell_max, n, expect_dense):
+    """Since the dense product evaluates the spline itself it beats separable synthesis + back substitution on the grid for small shapes
+    (engine.hip, `small_dense`: n_modes x grid <= 40 000, i.e. up to l <= 8 on the default grid, and at least 8 rows): the route is chosen by
+    that rule, and both routes agree to rounding."""
+    import scri_amd
+    from scri_amd import synthetic
+    from oracle import containers
+
+    t = np.linspace(-20.0, 30.0, n)
+    data = synthetic.chirp_modes(t, 2, ell_max, 3 + ell_max)
+    st = synthetic.real_supertranslation(0.2 * (np.arange(9) - 4.0 + 1j * np.arange(9)[::-1]))
+    kw = dict(supertranslation=st, frame_rotation=np.array([0.3, -0.5, 0.7, 0.41]) / np.linalg.norm([0.3, -0.5, 0.7, 0.41]))
+
+    def run():
+        w = scri_amd.WaveformModes(t=t, data=data, ell_min=2, ell_max=ell_max, dataType=containers.h, frameType=scri_amd.Inertial,
+                                   r_is_scaled_out=True, m_is_scaled_out=True, ctx=ctx)
+        ctx.enable_timing(True)
+        ctx.get_timing(reset=True)
+        out = w.transform(**kw)
+        tags = {k for k, v in ctx.get_timing(reset=True).items() if v[1]}
+        ctx.enable_timing(False)
+        return out, tags
+
+    for k in ("SCRI_AMD_NO_SEPARABLE_SYNTHESIS", "SCRI_AMD_NO_SMALL_DENSE", "SCRI_AMD_NO_GEMM_EVAL"):
+        monkeypatch.delenv(k, raising=False)
+    got, tags = run()
+    assert ("rotate" not in tags) == expect_dense  # (the separable route turns the modes into the rotated frame first)
+    monkeypatch.setenv("SCRI_AMD_NO_SMALL_DENSE", "1")
+    ref, tags_ref = run()
+    assert "rotate" in tags_ref
+    assert np.array_equal(got.t, ref.t)
+    assert np.abs(got.data - ref.data).max() < 1e-13 * max(1.0, np.abs(ref.data).max())
