@@ -49,7 +49,7 @@ struct EvalArgs {
   double inv_dx;         // 1 / (mean step of the launch's knots): turns an abscissa into a first guess of its row (0: no guess)
   double* side;          // ROW_STEP = 64: [n_row_tiles][6][side_ld] first / last three rows of every tile, or null
   long long side_ld;
-  int dbg;               // timing experiments (results wrong): 1 no evaluation, 2 no sample stores, 4 no straddle kernel, 8 no search
+  int dbg;               // timing experiments (results wrong): 1 no evaluation, 2 no sample stores, 4 no straddle kernel, 8 no search; 32 (results right): launch-wide sample window
   unsigned long long* trace;  // (debug) 5 words per block: hw id | xcc id << 32, tile, clock at start / K loop end / exit
 };
 
@@ -207,6 +207,44 @@ struct EvalFromLds {
   }
 };
 
+// The window of output rows the samples of a tile can have, from the time skews of the tile's OWN columns at its first and last knot
+// (smin, smax): a sample of global row I sits near knot I + skew / dx, so the knots [kT, kT + rows) are met by the rows
+// [kT - smax / dx, kT + rows - smin / dx].  Columns are stored sorted by skew rate, so the spread within a tile stays a few dozen rows
+// where the skew itself is hundreds (late times of a long series, strong boosts): a window centred per tile keeps those tiles on the
+// LDS path, which a bound for the whole launch (ev.search_halfwidth) sends to global memory as soon as the largest skew anywhere exceeds
+// 92 rows -- 1e6 steps: 46.9 -> 44.4 ms per transform.  The margin (3 rows + 3 % of the skew) absorbs a local step that differs from the mean one;
+// beyond it the search reports the miss and the thread goes to global memory, as before.
+__device__ __forceinline__ bool eval_tile_window(const EvalArgs& ev, long long kT, int rows, int n_i, double smin, double smax, int* i_a) {
+  if (!(ev.inv_dx > 0.0) || (ev.dbg & 32)) {  // no mean step known (or the A/B switch): the launch-wide bound
+    const bool ok = ev.search_halfwidth > 0 && 2 * ev.search_halfwidth + 72 <= E_XS;
+    long long ia = kT - ev.i_lo - ev.search_halfwidth - 2;
+    ia = ia > n_i - 1 ? n_i - 1 : ia;
+    *i_a = (int)(ia < 0 ? 0 : ia);
+    return ok;
+  }
+  const double r_hi = smax * ev.inv_dx, r_lo = smin * ev.inv_dx;
+  const double amax = fabs(r_hi) > fabs(r_lo) ? fabs(r_hi) : fabs(r_lo);
+  if (!(amax < 1e8)) {
+    *i_a = 0;
+    return false;
+  }
+  const long long margin = 3 + (long long)(0.03 * amax);
+  long long ia = kT - ev.i_lo - (long long)ceil(r_hi) - margin - 1;
+  const long long ib = kT + rows - ev.i_lo - (long long)floor(r_lo) + margin + 1;
+  const bool ok = ib - ia <= E_XS;
+  ia = ia > n_i - 1 ? n_i - 1 : ia;
+  *i_a = (int)(ia < 0 ? 0 : ia);
+  return ok;
+}
+__device__ __forceinline__ void wave_min_max(double& mn, double& mx) {
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) {
+    const double a = __shfl_xor(mn, d, 64), b = __shfl_xor(mx, d, 64);
+    mn = a < mn ? a : mn;
+    mx = b > mx ? b : mx;
+  }
+}
+
 // The windows [fa, fb) (relative to kT, the knot of the caller's row 0) of one column; win(fl, q) returns C[kT + fl + q][p];
 // lds: the staged copies, if from_lds (by value: a struct whose address is taken lives in scratch memory, and a scratch load in
 // the loop waits, through vmcnt, for the previous turn's sample to reach memory).
@@ -258,6 +296,7 @@ __global__ __launch_bounds__(256, 3) void zgemm3m_eval_kernel(const double* __re
   __shared__ __attribute__((aligned(16))) double xk_lds[64];
   __shared__ __attribute__((aligned(16))) double xs_lds[E_XS];
   __shared__ __attribute__((aligned(16))) double2 sk_lds[E_BN];  // (skew_a, skew_b) of the tile's columns
+  __shared__ double win_lds[2];                                  // smallest / largest skew of the tile (eval_tile_window)
   double2* As = lds;
   double2* Bs = lds + 2 * E_ASZ;
 
@@ -286,36 +325,17 @@ __global__ __launch_bounds__(256, 3) void zgemm3m_eval_kernel(const double* __re
   const long long rows_valid = (M - m0) < E_BM ? (M - m0) : E_BM;
   const long long kT = ev.g0 + m0;  // knot of the tile's row 0
   const int n_i = (int)(ev.i_hi - ev.i_lo);
-  const bool from_lds = ev.search_halfwidth > 0 && 2 * ev.search_halfwidth + 72 <= E_XS;
-  long long i_a_ll = kT - ev.i_lo - ev.search_halfwidth - 2;
-  if (i_a_ll > n_i - 1) i_a_ll = n_i - 1;
-  if (i_a_ll < 0) i_a_ll = 0;
-  const int i_a = (int)i_a_ll;
   if (tid < E_BN) {
     // (read in the epilogue from LDS: as global loads there, their s_waitcnt vmcnt(0) also waited for every sample the first half
     // of the tile had just stored to reach memory)
     const int col = n0 + tid < N ? n0 + tid : N - 1;
-    sk_lds[tid] = double2{ev.skew_a ? ev.skew_a[col] : 0.0, ev.skew_b ? ev.skew_b[col] : 0.0};
-  }
-  if (from_lds) {
-    {
-      long long row = tid >> 2;
-      if (row > rows_valid - 1) row = rows_valid - 1;
-      const double* src = ev.table[kT + row].m + 4 * (tid & 3);
-      const double2 v0 = *reinterpret_cast<const double2*>(src), v1 = *reinterpret_cast<const double2*>(src + 2);
-      double2* dst = reinterpret_cast<double2*>(t_lds + 16 * (tid >> 2) + 4 * (tid & 3));
-      dst[0] = v0, dst[1] = v1;
-    }
-    if (tid < 64) {
-      long long row = tid;
-      if (row > rows_valid - 1) row = rows_valid - 1;
-      xk_lds[tid] = ev.x[kT + row];
-    }
-    {
-      int i = i_a + tid;
-      if (i > n_i - 1) i = n_i - 1;
-      xs_lds[tid] = ev.x[ev.i_lo + i];
-    }
+    const double sa = ev.skew_a ? ev.skew_a[col] : 0.0, sb = ev.skew_b ? ev.skew_b[col] : 0.0;
+    sk_lds[tid] = double2{sa, sb};
+    // smallest and largest time skew of the tile's columns over its knots (affine in the knot: the ends decide)
+    const double s0 = sa * (ev.x[kT] - ev.tt) + sb, s1 = sa * (ev.x[kT + rows_valid - 1] - ev.tt) + sb;
+    double mn = s0 < s1 ? s0 : s1, mx = s0 < s1 ? s1 : s0;
+    wave_min_max(mn, mx);
+    if (tid == 0) win_lds[0] = mn, win_lds[1] = mx;
   }
 
   v4d p1[2][2], p2[2][2], p3[2][2];
@@ -356,6 +376,30 @@ __global__ __launch_bounds__(256, 3) void zgemm3m_eval_kernel(const double* __re
   E_LOAD_GLOBAL(0);
   E_STORE_LDS(0);
   __syncthreads();
+  // (behind the first barrier: the tile's skew range is known to every thread; the copies requested here are in LDS long before the
+  // K loop, whose every turn ends in a barrier, is through)
+  int i_a;
+  const bool from_lds = eval_tile_window(ev, kT, (int)rows_valid, n_i, win_lds[0], win_lds[1], &i_a);
+  if (from_lds) {
+    {
+      long long row = tid >> 2;
+      if (row > rows_valid - 1) row = rows_valid - 1;
+      const double* src = ev.table[kT + row].m + 4 * (tid & 3);
+      const double2 v0 = *reinterpret_cast<const double2*>(src), v1 = *reinterpret_cast<const double2*>(src + 2);
+      double2* dst = reinterpret_cast<double2*>(t_lds + 16 * (tid >> 2) + 4 * (tid & 3));
+      dst[0] = v0, dst[1] = v1;
+    }
+    if (tid < 64) {
+      long long row = tid;
+      if (row > rows_valid - 1) row = rows_valid - 1;
+      xk_lds[tid] = ev.x[kT + row];
+    }
+    {
+      int i = i_a + tid;
+      if (i > n_i - 1) i = n_i - 1;
+      xs_lds[tid] = ev.x[ev.i_lo + i];
+    }
+  }
 
   const bool wave_has_columns = n0 + wn * 32 < N;
   for (int kt = 0; kt < nk; ++kt) {
@@ -460,13 +504,27 @@ __global__ __launch_bounds__(256) void spline_straddle_eval_kernel(int N, int n_
   if (bnd + 1 >= n_row_tiles) return;
   const long long kT = ev.g0 + 64LL * bnd + 61;  // knot of side row 0 of this boundary
   const int n_i = (int)(ev.i_hi - ev.i_lo);
-  const bool from_lds = ev.search_halfwidth > 0 && 2 * ev.search_halfwidth + 72 <= E_XS;
-  long long i_a_ll = kT - ev.i_lo - ev.search_halfwidth - 2;
-  if (i_a_ll > n_i - 1) i_a_ll = n_i - 1;
-  if (i_a_ll < 0) i_a_ll = 0;
-  const int i_a = (int)i_a_ll;
+  const long long k_last = ev.g0 + M - 1;
+  __shared__ double red_lds[8];
+  const int colc = col < N ? col : N - 1;
+  const double sa_t = ev.skew_a ? ev.skew_a[colc] : 0.0, sb_t = ev.skew_b ? ev.skew_b[colc] : 0.0;
+  {
+    // skew range of the block's 256 columns over the six knots of the boundary
+    const double s0 = sa_t * (ev.x[kT] - ev.tt) + sb_t, s1 = sa_t * (ev.x[kT + 5 > k_last ? k_last : kT + 5] - ev.tt) + sb_t;
+    double mn = s0 < s1 ? s0 : s1, mx = s0 < s1 ? s1 : s0;
+    wave_min_max(mn, mx);
+    if ((tid & 63) == 0) red_lds[2 * (tid >> 6)] = mn, red_lds[2 * (tid >> 6) + 1] = mx;
+  }
+  __syncthreads();
+  double smin = red_lds[0], smax = red_lds[1];
+#pragma unroll
+  for (int w = 1; w < 4; ++w) {
+    smin = red_lds[2 * w] < smin ? red_lds[2 * w] : smin;
+    smax = red_lds[2 * w + 1] > smax ? red_lds[2 * w + 1] : smax;
+  }
+  int i_a;
+  const bool from_lds = eval_tile_window(ev, kT, 6, n_i, smin, smax, &i_a);
   if (from_lds) {
-    const long long k_last = ev.g0 + M - 1;
     if (tid < 64) {  // 8 rows x 8 pairs of table words
       long long jj = kT + (tid >> 3);
       if (jj > k_last) jj = k_last;
@@ -497,7 +555,7 @@ __global__ __launch_bounds__(256) void spline_straddle_eval_kernel(int N, int n_
   }
   const auto win = [&](int fl, int qq) { return w_lds[fl + qq][tid]; };
   const EvalFromLds src{(lds_cdp)t_lds, (lds_cdp)xk_lds, (lds_cdp)xs_lds, i_a};
-  eval_windows(ev, from_lds, src, col, ev.skew_a ? ev.skew_a[col] : 0.0, ev.skew_b ? ev.skew_b[col] : 0.0, kT, 0, fb, win);
+  eval_windows(ev, from_lds, src, col, sa_t, sb_t, kT, 0, fb, win);
 }
 
 hipError_t launch_zgemm3m_eval(hipStream_t stream, const double* A, long long lda, const double* B, long long ldb, long long M, int N,
