@@ -214,8 +214,11 @@ struct EvalFromLds {
 // LDS path, which a bound for the whole launch (ev.search_halfwidth) sends to global memory as soon as the largest skew anywhere exceeds
 // 92 rows -- 1e6 steps: 46.9 -> 44.4 ms per transform.  The margin (3 rows + 3 % of the skew) absorbs a local step that differs from the mean one;
 // beyond it the search reports the miss and the thread goes to global memory, as before.
+__device__ __forceinline__ bool eval_launch_wide_window(const EvalArgs& ev) {
+  return !(ev.inv_dx > 0.0) || (ev.dbg & 32) || (ev.search_halfwidth > 0 && 2 * ev.search_halfwidth + 72 <= E_XS);
+}
 __device__ __forceinline__ bool eval_tile_window(const EvalArgs& ev, long long kT, int rows, int n_i, double smin, double smax, int* i_a) {
-  if (!(ev.inv_dx > 0.0) || (ev.dbg & 32)) {  // no mean step known (or the A/B switch): the launch-wide bound
+  if (eval_launch_wide_window(ev)) {  // the bound for the whole launch fits the window (or nothing better is known): no reduction needed
     const bool ok = ev.search_halfwidth > 0 && 2 * ev.search_halfwidth + 72 <= E_XS;
     long long ia = kT - ev.i_lo - ev.search_halfwidth - 2;
     ia = ia > n_i - 1 ? n_i - 1 : ia;
@@ -331,11 +334,13 @@ __global__ __launch_bounds__(256, 3) void zgemm3m_eval_kernel(const double* __re
     const int col = n0 + tid < N ? n0 + tid : N - 1;
     const double sa = ev.skew_a ? ev.skew_a[col] : 0.0, sb = ev.skew_b ? ev.skew_b[col] : 0.0;
     sk_lds[tid] = double2{sa, sb};
-    // smallest and largest time skew of the tile's columns over its knots (affine in the knot: the ends decide)
-    const double s0 = sa * (ev.x[kT] - ev.tt) + sb, s1 = sa * (ev.x[kT + rows_valid - 1] - ev.tt) + sb;
-    double mn = s0 < s1 ? s0 : s1, mx = s0 < s1 ? s1 : s0;
-    wave_min_max(mn, mx);
-    if (tid == 0) win_lds[0] = mn, win_lds[1] = mx;
+    if (!eval_launch_wide_window(ev)) {
+      // smallest and largest time skew of the tile's columns over its knots (affine in the knot: the ends decide)
+      const double s0 = sa * (ev.x[kT] - ev.tt) + sb, s1 = sa * (ev.x[kT + rows_valid - 1] - ev.tt) + sb;
+      double mn = s0 < s1 ? s0 : s1, mx = s0 < s1 ? s1 : s0;
+      wave_min_max(mn, mx);
+      if (tid == 0) win_lds[0] = mn, win_lds[1] = mx;
+    }
   }
 
   v4d p1[2][2], p2[2][2], p3[2][2];
@@ -379,7 +384,8 @@ __global__ __launch_bounds__(256, 3) void zgemm3m_eval_kernel(const double* __re
   // (behind the first barrier: the tile's skew range is known to every thread; the copies requested here are in LDS long before the
   // K loop, whose every turn ends in a barrier, is through)
   int i_a;
-  const bool from_lds = eval_tile_window(ev, kT, (int)rows_valid, n_i, win_lds[0], win_lds[1], &i_a);
+  const bool wide = eval_launch_wide_window(ev);
+  const bool from_lds = eval_tile_window(ev, kT, (int)rows_valid, n_i, wide ? 0.0 : win_lds[0], wide ? 0.0 : win_lds[1], &i_a);
   if (from_lds) {
     {
       long long row = tid >> 2;
