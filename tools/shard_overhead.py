@@ -11,13 +11,14 @@ spec = synthetic.CONFIGS["cfg3"]
 kw, L = spec["kwargs"], spec["ell_max"]
 nth = 2 * (L + 2) + 1
 tr = engine.make_transformation(kw["supertranslation"], kw["frame_rotation"], kw["boost_velocity"], nth, nth, L)
-n_global = 100_000 * world
+n_global = int(sys.argv[3]) if len(sys.argv) > 3 else 100_000 * world  # (1000000: a rank's shard of cfg4)
 t = np.arange(n_global) * spec["dt"]
 have, need, window = sharding.plan(t, tr, world)
 _, rows, _ = synthetic.workload("cfg3", n_times=n_global, rows=need[rank])
 d = torch.from_numpy(rows).cuda()
 nm = rows.shape[1]
 out = torch.empty((have[rank][1] - have[rank][0], nm), dtype=torch.complex128, device="cuda")
+per_rank = n_global // world
 ctx = _lib.Context(0)
 ctx.enable_timing(True)
 def step():
@@ -30,4 +31,4 @@ for _ in range(10): r = step()
 torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 10
 tm = ctx.get_timing(reset=True)
 print({k: round(v[0] / 10, 3) for k, v in tm.items() if v[1]})
-print(f"world {world} rank {rank}: rows held {rows.shape[0]} (halo {rows.shape[0] - 100000}), outputs {r[1]}, {dt * 1e3:.3f} ms per step")
+print(f"world {world} rank {rank}: rows held {rows.shape[0]} (halo {rows.shape[0] - per_rank}), outputs {r[1]}, {dt * 1e3:.3f} ms per step")
