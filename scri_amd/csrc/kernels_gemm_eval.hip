@@ -497,52 +497,49 @@ __global__ __launch_bounds__(256, 3) void zgemm3m_eval_kernel(const double* __re
 }
 
 // The windows that straddle two 64-knot tiles (ROW_STEP = 64): f = 64 b + 61 .. 64 b + 63 for boundary b, from the six side rows
-// [tile b: rows 61..63][tile b + 1: rows 0..2].  Block = (256 columns, boundary); tables of the few intervals involved and the
-// window of output abscissae are staged in LDS as in the product's epilogue.
-__global__ __launch_bounds__(256) void spline_straddle_eval_kernel(int N, int n_row_tiles, EvalArgs ev, long long M) {
-  __shared__ __attribute__((aligned(16))) double2 w_lds[6][256];
+// [tile b: rows 61..63][tile b + 1: rows 0..2].  Block = one wave: (the 64 columns of a column panel of the product, boundary) -- the
+// same columns as a tile of the product, so that their skews lie as close together and the window of output abscissae is placed the
+// same way; tables of the few intervals involved and that window are staged in LDS as in the product's epilogue.
+__global__ __launch_bounds__(64) void spline_straddle_eval_kernel(int N, int n_row_tiles, EvalArgs ev, long long M) {
+  __shared__ __attribute__((aligned(16))) double2 w_lds[6][64];
   __shared__ __attribute__((aligned(16))) double t_lds[8 * 16];
   __shared__ __attribute__((aligned(16))) double xk_lds[8];
   __shared__ __attribute__((aligned(16))) double xs_lds[E_XS];
   const int tid = threadIdx.x;
-  const int col = blockIdx.x * blockDim.x + tid;
+  const int col = blockIdx.x * 64 + tid;
   const int bnd = blockIdx.y;
   if (bnd + 1 >= n_row_tiles) return;
   const long long kT = ev.g0 + 64LL * bnd + 61;  // knot of side row 0 of this boundary
   const int n_i = (int)(ev.i_hi - ev.i_lo);
   const long long k_last = ev.g0 + M - 1;
-  __shared__ double red_lds[8];
   const int colc = col < N ? col : N - 1;
   const double sa_t = ev.skew_a ? ev.skew_a[colc] : 0.0, sb_t = ev.skew_b ? ev.skew_b[colc] : 0.0;
-  {
-    // skew range of the block's 256 columns over the six knots of the boundary
+  double smin = 0.0, smax = 0.0;
+  if (!eval_launch_wide_window(ev)) {
+    // skew range of the block's 64 columns over the six knots of the boundary
     const double s0 = sa_t * (ev.x[kT] - ev.tt) + sb_t, s1 = sa_t * (ev.x[kT + 5 > k_last ? k_last : kT + 5] - ev.tt) + sb_t;
-    double mn = s0 < s1 ? s0 : s1, mx = s0 < s1 ? s1 : s0;
-    wave_min_max(mn, mx);
-    if ((tid & 63) == 0) red_lds[2 * (tid >> 6)] = mn, red_lds[2 * (tid >> 6) + 1] = mx;
-  }
-  __syncthreads();
-  double smin = red_lds[0], smax = red_lds[1];
-#pragma unroll
-  for (int w = 1; w < 4; ++w) {
-    smin = red_lds[2 * w] < smin ? red_lds[2 * w] : smin;
-    smax = red_lds[2 * w + 1] > smax ? red_lds[2 * w + 1] : smax;
+    smin = s0 < s1 ? s0 : s1, smax = s0 < s1 ? s1 : s0;
+    wave_min_max(smin, smax);
   }
   int i_a;
   const bool from_lds = eval_tile_window(ev, kT, 6, n_i, smin, smax, &i_a);
   if (from_lds) {
-    if (tid < 64) {  // 8 rows x 8 pairs of table words
+    {  // 8 rows x 8 pairs of table words
       long long jj = kT + (tid >> 3);
       if (jj > k_last) jj = k_last;
       reinterpret_cast<double2*>(t_lds)[tid] = *reinterpret_cast<const double2*>(ev.table[jj].m + 2 * (tid & 7));
-    } else if (tid < 72) {
-      long long jj = kT + (tid - 64);
-      if (jj > k_last) jj = k_last;
-      xk_lds[tid - 64] = ev.x[jj];
     }
-    int i = i_a + tid;
-    if (i > n_i - 1) i = n_i - 1;
-    xs_lds[tid] = ev.x[ev.i_lo + i];
+    if (tid < 8) {
+      long long jj = kT + tid;
+      if (jj > k_last) jj = k_last;
+      xk_lds[tid] = ev.x[jj];
+    }
+#pragma unroll
+    for (int r = 0; r < E_XS / 64; ++r) {
+      int i = i_a + tid + 64 * r;
+      if (i > n_i - 1) i = n_i - 1;
+      xs_lds[tid + 64 * r] = ev.x[ev.i_lo + i];
+    }
     __syncthreads();
   }
   if (col >= N) return;
@@ -599,7 +596,7 @@ hipError_t launch_zgemm3m_eval(hipStream_t stream, const double* A, long long ld
     hipLaunchKernelGGL(zgemm3m_eval_kernel<64>, dim3((unsigned)grid), dim3(256), 0, stream, A, lda, B, ldb, M, N, K, nbm, nbn, st_rows_log2,
                        col_scale, ev);
     if (nbm > 1 && !(ev.dbg & 4))
-      hipLaunchKernelGGL(spline_straddle_eval_kernel, dim3((N + 255) / 256, (unsigned)(nbm - 1)), dim3(256), 0, stream, N, nbm, ev, M);
+      hipLaunchKernelGGL(spline_straddle_eval_kernel, dim3((N + 63) / 64, (unsigned)(nbm - 1)), dim3(64), 0, stream, N, nbm, ev, M);
   }
   if (ev.trace) {  // (debug: blocks the host)
     std::vector<unsigned long long> h(5 * (size_t)grid);
