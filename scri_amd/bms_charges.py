@@ -14,32 +14,46 @@ def mass_aspect(self, truncate_ell=max):
     truncate_ell: an int truncates every term to that ell_max (terms that are not needed are not computed); a callable is
     used as the truncator of the product (default `max`: the larger ell_max of the two factors); a false value keeps
     the full product."""
+    # one formula, three ways of choosing the band limit of its two terms
     if callable(truncate_ell):
-        return -(self.psi2 + self.sigma.multiply(self.sigma.bar.dot, truncator=truncate_ell)).real
+        product_ell, psi2 = truncate_ell, self.psi2
     elif truncate_ell:
-        return -(
-            self.psi2.truncate_ell(truncate_ell) + self.sigma.multiply(self.sigma.bar.dot, truncator=lambda tup: truncate_ell)
-        ).real
+        product_ell, psi2 = (lambda ells: truncate_ell), self.psi2.truncate_ell(truncate_ell)
     else:
-        return -(self.psi2 + self.sigma * self.sigma.bar.dot).real
+        product_ell, psi2 = sum, self.psi2  # l_a + l_b: nothing of the product is dropped
+    news_term = self.sigma.multiply(self.sigma.bar.dot, truncator=product_ell)
+    return -((psi2 + news_term).real)
+
+
+# Rows: (t, x, y, z); columns: (Re a_00, Re a_1-1, Im a_1-1, Re a_10, Re a_11, Im a_11).  The real part of an l <= 1 function against
+# (1, sin th cos ph, sin th sin ph, cos th) over the sphere, divided by 4 pi: Y_00 = 1/sqrt(4 pi), Y_10 = sqrt(3/4pi) cos th,
+# Y_1+-1 = -+ sqrt(3/8pi) sin th e^{+-i ph}.
+_ASPECT_TO_VECTOR = np.array(
+    [
+        [1.0, 0.0, 0.0, 0.0, 0.0, 0.0],
+        [0.0, 1.0 / sqrt(6), 0.0, 0.0, -1.0 / sqrt(6), 0.0],
+        [0.0, 0.0, 1.0 / sqrt(6), 0.0, 0.0, 1.0 / sqrt(6)],
+        [0.0, 0.0, 0.0, 1.0 / sqrt(3), 0.0, 0.0],
+    ]
+) / sqrt(4 * np.pi)
 
 
 def charge_vector_from_aspect(charge):
     """l <= 1 modes of a charge aspect as a four-vector: v = (1/4pi) int Re{a} (1, sin th cos ph, sin th sin ph, cos th)
-    (bms_charges.py:50-69)."""
-    charge = np.asarray(charge)
-    four_vector = np.empty(charge.shape[:-1] + (4,), dtype=float)
-    four_vector[..., 0] = charge[..., 0].real
-    four_vector[..., 1] = (charge[..., 1] - charge[..., 3]).real / sqrt(6)
-    four_vector[..., 2] = (charge[..., 1] + charge[..., 3]).imag / sqrt(6)
-    four_vector[..., 3] = charge[..., 2].real / sqrt(3)
-    return four_vector / np.sqrt(4 * np.pi)
+    (bms_charges.py:50-69), as ONE real 4 x 6 matrix applied to (Re a_00, Re a_1-1, Im a_1-1, Re a_10, Re a_11, Im a_11)."""
+    a = np.asarray(charge)[..., :4]
+    parts = np.stack([a[..., 0].real, a[..., 1].real, a[..., 1].imag, a[..., 2].real, a[..., 3].real, a[..., 3].imag], axis=-1)
+    return parts @ _ASPECT_TO_VECTOR.T
+
+
+def _minkowski_norm_squared(P):
+    """E^2 - |p|^2 of four-vectors along the last axis"""
+    return P[..., 0] ** 2 - np.einsum("...i,...i->...", P[..., 1:], P[..., 1:])
 
 
 def bondi_rest_mass(self):
     """Rest mass of the Bondi four-momentum (bms_charges.py:72-76)"""
-    four_momentum = self.bondi_four_momentum()
-    return np.sqrt(four_momentum[:, 0] ** 2 - np.sum(four_momentum[:, 1:] ** 2, axis=1))
+    return np.sqrt(_minkowski_norm_squared(self.bondi_four_momentum()))
 
 
 def bondi_four_momentum(self):
@@ -86,19 +100,15 @@ def bondi_CoM_charge(self):
 
 
 def bondi_dimensionless_spin(self):
-    """Dimensionless Bondi spin vector (bms_charges.py:139-160)"""
-    N = self.bondi_boost_charge()
-    J = self.bondi_angular_momentum()
-    P = self.bondi_four_momentum()
-    M_sqr = (P[:, 0] ** 2 - np.sum(P[:, 1:] ** 2, axis=1))[:, np.newaxis]
-    v = P[:, 1:] / (P[:, 0])[:, np.newaxis]
-    v_norm = np.linalg.norm(v, axis=1)
-    vhat = v.copy()
-    t_idx = v_norm != 0  # normalise only where the velocity does not vanish
-    vhat[t_idx] = v[t_idx] / v_norm[t_idx, np.newaxis]
-    gamma = (1 / np.sqrt(1 - v_norm**2))[:, np.newaxis]
-    J_dot_vhat = np.einsum("ij,ij->i", J, vhat)[:, np.newaxis]
-    return (gamma * (J + np.cross(v, N)) - (gamma - 1) * J_dot_vhat * vhat) / M_sqr
+    """Dimensionless Bondi spin vector chi = [gamma (J + v x N) - (gamma - 1) (J . v^) v^] / M^2 with v = p / E
+    (bms_charges.py:139-160), as one expression on (P, J, N)."""
+    P, J, N = self.bondi_four_momentum(), self.bondi_angular_momentum(), self.bondi_boost_charge()
+    velocity = P[:, 1:] / P[:, :1]
+    speed = np.sqrt(np.einsum("ti,ti->t", velocity, velocity))[:, np.newaxis]
+    direction = np.divide(velocity, speed, out=velocity.copy(), where=speed != 0)  # (a vanishing velocity has no direction: kept)
+    lorentz = 1.0 / np.sqrt(1.0 - speed**2)
+    along = np.einsum("ti,ti->t", J, direction)[:, np.newaxis] * direction
+    return (lorentz * (J + np.cross(velocity, N)) - (lorentz - 1.0) * along) / _minkowski_norm_squared(P)[:, np.newaxis]
 
 
 def CWWY_angular_momentum(self):

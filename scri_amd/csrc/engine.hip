@@ -76,6 +76,7 @@ struct bms_ctx {
   // MI355X); a call that still runs out of memory halves it and tries again (with_smaller_chunks)
   uint64_t ws_limit = 96ull << 30;
   bool ws_limit_set = false;  // by the caller: then it is kept as given
+  bool alloc_failed = false;  // a device allocation of the running call failed (as opposed to a cap that is too small by plan)
   std::map<std::string, DevBuf> bufs;  // grow-only named work space
   int delta_lmax = -1;                 // Delta tables cached up to this l
   int delta_mfma_lmax = -1;            // ... in the MFMA B-image packing
@@ -118,9 +119,14 @@ struct bms_ctx {
   long long tag_calls[BMS_TAG_COUNT] = {0};
 };
 
+static inline void note_alloc_failure(bms_ctx* c) {
+  if (c) c->alloc_failed = true;
+}
+
 struct ScopedTimer {  // brackets one kernel launch with two events when timing is enabled
   bms_ctx* c;
   int tag;
+  hipStream_t stream;  // the stream the bracketed kernel is launched on (events recorded elsewhere would bracket unrelated work)
   hipEvent_t a = nullptr, b = nullptr;
   static hipEvent_t get(bms_ctx* c) {
     if (!c->event_pool.empty()) {
@@ -132,16 +138,16 @@ struct ScopedTimer {  // brackets one kernel launch with two events when timing 
     (void)hipEventCreate(&e);
     return e;
   }
-  ScopedTimer(bms_ctx* c_, int tag_) : c(c_), tag(tag_) {
+  ScopedTimer(bms_ctx* c_, int tag_, hipStream_t stream_ = nullptr) : c(c_), tag(tag_), stream(stream_ ? stream_ : c_->stream) {
     if (c->timing) {
       a = get(c);
       b = get(c);
-      (void)hipEventRecord(a, c->stream);
+      (void)hipEventRecord(a, stream);
     }
   }
   ~ScopedTimer() {
     if (c->timing) {
-      (void)hipEventRecord(b, c->stream);
+      (void)hipEventRecord(b, stream);
       c->timed.push_back({tag, a, b});
       // a context that never asks for its timings must not collect events for ever: pairs that have completed are folded
       // into the totals once a few thousand are pending (no synchronisation: unfinished pairs stay)
@@ -169,6 +175,12 @@ struct ScopedTimer {  // brackets one kernel launch with two events when timing 
     ScopedTimer st__(ctx, tag);   \
     HIP_TRY(ctx, expr);           \
   } while (0)
+// the same for a kernel launched on another stream than the context's main one
+#define TIMED_ON(ctx, strm, tag, expr)  \
+  do {                                  \
+    ScopedTimer st__(ctx, tag, strm);   \
+    HIP_TRY(ctx, expr);                 \
+  } while (0)
 
 static thread_local std::string g_create_error;
 
@@ -176,7 +188,7 @@ static thread_local std::string g_create_error;
 struct HostTrace {
   bool on;
   std::chrono::steady_clock::time_point t0;
-  HostTrace() : on(getenv("SCRI_AMD_TRACE") != nullptr), t0(std::chrono::steady_clock::now()) {}
+  HostTrace() : on(route_env("SCRI_AMD_TRACE") != nullptr), t0(std::chrono::steady_clock::now()) {}
   void mark(const char* what) {
     if (!on) return;
     auto t1 = std::chrono::steady_clock::now();
@@ -198,12 +210,15 @@ static int fail(bms_ctx* c, int code, const char* fmt, ...) {
   return code;
 }
 
+static inline void note_alloc_failure(bms_ctx* c);
 #define HIP_TRY(ctx, expr)                                                                                   \
   do {                                                                                                       \
     hipError_t e__ = (expr);                                                                                 \
-    if (e__ != hipSuccess)                                                                                   \
+    if (e__ != hipSuccess) {                                                                                 \
+      if (e__ == hipErrorOutOfMemory) note_alloc_failure(ctx);                                               \
       return fail(ctx, e__ == hipErrorOutOfMemory ? BMS_ERR_NOMEM : BMS_ERR_HIP, "%s failed: %s (%s:%d)", #expr, \
                   hipGetErrorString(e__), __FILE__, __LINE__);                                               \
+    }                                                                                                        \
   } while (0)
 
 // The stream the results of a pipelined call leave on.  The runtime executes device-to-host copies as shader copies
@@ -213,7 +228,7 @@ static int fail(bms_ctx* c, int code, const char* fmt, ...) {
 // beyond the run-to-run spread (a first sweep that read 13.6 ms on 8 CUs against 14.8 was that spread), so the default stays
 // unconfined.
 static hipError_t create_download_stream(bms_ctx* c) {
-  const char* e = getenv("SCRI_AMD_DOWN_CUS");
+  const char* e = BMS_PROBE_ENV("SCRI_AMD_DOWN_CUS");
   const int want = e ? atoi(e) : 0;
   if (want > 0) {
     hipDeviceProp_t prop;
@@ -248,6 +263,7 @@ static int dev_buf(bms_ctx* c, const char* name, size_t bytes, void** out) {
     if (e != hipSuccess) {
       (void)hipGetLastError();
       b.p = nullptr;
+      c->alloc_failed = true;
       return fail(c, BMS_ERR_NOMEM, "hipMalloc of %zu bytes for work space '%s' failed: %s", want, name,
                   hipGetErrorString(e));
     }
@@ -276,15 +292,25 @@ static uint64_t default_ws_limit() {
   return std::max<uint64_t>(lim, 256ull << 20);
 }
 
-// Runs `call` again with half the work space cap while it fails for lack of device memory (the buffer that failed was released
-// before the attempt, so a smaller chunk finds room); a cap the caller set is not touched.
+// Runs `call` again with half the work space cap while it fails because a device ALLOCATION failed (the buffer that failed was
+// released before the attempt, so a smaller chunk finds room).  Not retried: a cap the caller set, and the planning error "the cap
+// holds fewer than N rows" -- halving only makes that one worse.  The halved cap lasts for this call only: one transient shortage (a
+// temporary tensor of the caller) must not leave every later call of the context with chunks up to 32x smaller.  If every attempt
+// fails the FIRST message is the one reported.
 template <class F>
 static int with_smaller_chunks(bms_ctx* c, F call) {
+  c->alloc_failed = false;
   int rc = call();
-  for (int attempt = 0; rc == BMS_ERR_NOMEM && !c->ws_limit_set && attempt < 5 && c->ws_limit > (512ull << 20); ++attempt) {
+  if (rc != BMS_ERR_NOMEM || !c->alloc_failed || c->ws_limit_set) return rc;
+  const uint64_t cap = c->ws_limit;
+  const std::string first = c->err;
+  for (int attempt = 0; rc == BMS_ERR_NOMEM && c->alloc_failed && attempt < 5 && c->ws_limit > (512ull << 20); ++attempt) {
     c->ws_limit /= 2;
+    c->alloc_failed = false;
     rc = call();
   }
+  c->ws_limit = cap;
+  if (rc == BMS_ERR_NOMEM) c->err = first;
   return rc;
 }
 
@@ -404,6 +430,7 @@ extern "C" int bms_ctx_use_default_stream(bms_ctx* c) {
 extern "C" int bms_ctx_set_workspace_limit(bms_ctx* c, uint64_t bytes) {
   if (!c) return BMS_ERR_INVALID;
   c->ws_limit_set = bytes != 0;
+  if (!bytes) HIP_TRY(c, hipSetDevice(c->device));  // (the default is sized from THIS context's device)
   c->ws_limit = bytes ? bytes : default_ws_limit();
   return BMS_OK;
 }
@@ -664,7 +691,7 @@ static int rotate_impl(bms_ctx* c, void* data, int mem, int64_t n_times, int64_t
   std::vector<Segment> segs;
   int rc = BMS_OK;
   {
-    const bool allow_res = !getenv("SCRI_AMD_ROTATE_VALU") && !getenv("SCRI_AMD_ROTATE_STAGED") && ld * 256 <= 0x7ffe0000LL;
+    const bool allow_res = !route_env("SCRI_AMD_ROTATE_VALU") && !route_env("SCRI_AMD_ROTATE_STAGED") && ld * 256 <= 0x7ffe0000LL;
     int l = ell_min;
     while (l <= ell_max) {
       Segment sg{};
@@ -686,7 +713,7 @@ static int rotate_impl(bms_ctx* c, void* data, int mem, int64_t n_times, int64_t
       if (!placed) {
         sg.lo = l;
         sg.hi = ell_max;
-        sg.kind = (rotate_mfma_supported(ell_max) && !getenv("SCRI_AMD_ROTATE_VALU")) ? 1 : 2;
+        sg.kind = (rotate_mfma_supported(ell_max) && !route_env("SCRI_AMD_ROTATE_VALU")) ? 1 : 2;
         if (sg.kind == 2 && rotate_waves_per_block(ell_max) < 1)
           return fail(c, BMS_ERR_UNSUPPORTED, "ell_max=%d too large for the rotation kernels", ell_max);
       }
@@ -970,10 +997,10 @@ static int upload(bms_ctx* c, const char* name, const void* host, size_t bytes, 
 static int build_analysis(bms_ctx* c, const char* tag, int n_theta, int n_phi, int spin, int ell_min_out, int ell_max_out,
                           AnalysisPlan& A) {
   hipStream_t S = c->stream;
-  const std::array<int, 6> key = {n_theta, n_phi, spin, ell_min_out, ell_max_out, (getenv("SCRI_AMD_NO_FUSED_ANALYSIS") ? 1 : 0) + (getenv("SCRI_AMD_NO_LARGE_ANALYSIS") ? 2 : 0)};
+  const std::array<int, 6> key = {n_theta, n_phi, spin, ell_min_out, ell_max_out, (route_env("SCRI_AMD_NO_FUSED_ANALYSIS") ? 1 : 0) + (route_env("SCRI_AMD_NO_LARGE_ANALYSIS") ? 2 : 0)};
   {
     auto it = c->plans.find(tag);
-    if (it != c->plans.end() && it->second.first == key && !getenv("SCRI_AMD_NO_PLAN_CACHE")) {
+    if (it != c->plans.end() && it->second.first == key && !route_env("SCRI_AMD_NO_PLAN_CACHE")) {
       A = it->second.second;
       return BMS_OK;
     }
@@ -991,9 +1018,9 @@ static int build_analysis(bms_ctx* c, const char* tag, int n_theta, int n_phi, i
   int rc;
   void* vp;
   char nm_[64];
-  A.fused = A.separable && fused_analysis_supported(n_theta, n_phi, A.L, A.n_out) && !getenv("SCRI_AMD_NO_FUSED_ANALYSIS");
-  A.large = A.separable && !A.fused && large_analysis_supported(n_theta, n_phi, A.L) && !getenv("SCRI_AMD_NO_LARGE_ANALYSIS") &&
-            !getenv("SCRI_AMD_NO_FUSED_ANALYSIS");
+  A.fused = A.separable && fused_analysis_supported(n_theta, n_phi, A.L, A.n_out) && !route_env("SCRI_AMD_NO_FUSED_ANALYSIS");
+  A.large = A.separable && !A.fused && large_analysis_supported(n_theta, n_phi, A.L) && !route_env("SCRI_AMD_NO_LARGE_ANALYSIS") &&
+            !route_env("SCRI_AMD_NO_FUSED_ANALYSIS");
   A.ell_min_out = ell_min_out;
   A.spin = spin;
   if (A.separable) {
@@ -1204,7 +1231,7 @@ static int walk_time_axis(bms_ctx* c, const double* t, int64_t lo, int64_t hi, b
     bmin[0] = bmin[1], bmin[1] = bmin[2];
     bmax[0] = bmax[1], bmax[1] = bmax[2];
   }
-  if (regular) *regular = reg || getenv("SCRI_AMD_ASSUME_REGULAR_MESH") != nullptr;  // (the switch exists to show what the guard prevents)
+  if (regular) *regular = reg || BMS_PROBE_ENV("SCRI_AMD_ASSUME_REGULAR_MESH") != nullptr;  // (the switch exists to show what the guard prevents)
   return BMS_OK;
 }
 static int validate_common(bms_ctx* c, int64_t n, const double* t, const bms_transformation* tr, int64_t lo = 0, int64_t hi = -1,
@@ -1227,7 +1254,7 @@ static int spline_tile_for(const double* x, int64_t n) {
     bmax[2] = std::max(bmax[2], h);
     if (++in_block == 16 || i == n - 1) {
       const double mn = std::min(bmin[0], std::min(bmin[1], bmin[2])), mx = std::max(bmax[0], std::max(bmax[1], bmax[2]));
-      if (mx > 1e3 * mn && !getenv("SCRI_AMD_ASSUME_REGULAR_MESH")) return (int)std::min<int64_t>(n + 1, 0x7fffffff);
+      if (mx > 1e3 * mn && !BMS_PROBE_ENV("SCRI_AMD_ASSUME_REGULAR_MESH")) return (int)std::min<int64_t>(n + 1, 0x7fffffff);
       bmin[0] = bmin[1], bmin[1] = bmin[2], bmin[2] = INFINITY;
       bmax[0] = bmax[1], bmax[1] = bmax[2], bmax[2] = 0.0;
       in_block = 0;
@@ -1294,7 +1321,7 @@ static int eval_search_halfwidth(const PixelTables& T, int cA, int cB, const dou
 // costs n_modes x n_pix multiply-adds per step and overtakes it only from about l_max = 13 on the default grids (measured:
 // tools/axis_boost_probe.py; l <= 8 on 17 x 17: 0.45 ms dense, 0.81 ms separable per 10^5 steps; l <= 16 on 33 x 33: 4.2 and 2.3).
 static bool axis_boost_pays(int n_modes, int n_theta, int n_phi) {
-  const char* e = getenv("SCRI_AMD_AXIS_BOOST_MIN_WORK");  // (read per call, like the other route switches)
+  const char* e = route_env("SCRI_AMD_AXIS_BOOST_MIN_WORK");  // (read per call, like the other route switches)
   const long long min_work = e ? atoll(e) : 160000;
   return (long long)n_modes * n_theta * n_phi >= min_work;
 }
@@ -1308,7 +1335,7 @@ static bool separable_rotor_grid(const bms_transformation* tr, std::vector<doubl
     for (int j = 0; j < n_theta; ++j) thetas[j] = M_PI * j / (n_theta - 1);
     return true;
   }
-  if (getenv("SCRI_AMD_NO_AXIS_BOOST_SEPARABLE")) return false;
+  if (route_env("SCRI_AMD_NO_AXIS_BOOST_SEPARABLE")) return false;
   double zf[3];
   rotate_z(F, zf);
   const double cx = bs.vhat[1] * zf[2] - bs.vhat[2] * zf[1], cy = bs.vhat[2] * zf[0] - bs.vhat[0] * zf[2], cz = bs.vhat[0] * zf[1] - bs.vhat[1] * zf[0];
@@ -1340,7 +1367,7 @@ static bool separable_rotor_grid(const bms_transformation* tr, std::vector<doubl
 static bool separable_rotor_grid(bms_ctx* c, const bms_transformation* tr, std::vector<double>& thetas) {
   const double key[9] = {tr->frame_rotation[0], tr->frame_rotation[1], tr->frame_rotation[2], tr->frame_rotation[3], tr->boost_velocity[0],
                          tr->boost_velocity[1], tr->boost_velocity[2], (double)tr->n_theta, (double)tr->n_phi};
-  const bool switched_off = getenv("SCRI_AMD_NO_AXIS_BOOST_SEPARABLE") != nullptr;  // (the switch is read per call)
+  const bool switched_off = route_env("SCRI_AMD_NO_AXIS_BOOST_SEPARABLE") != nullptr;  // (the switch is read per call)
   if (!switched_off && c->ring_verdict >= 0 && std::memcmp(key, c->ring_key, sizeof key) == 0) {
     if (c->ring_verdict) thetas = c->ring_thetas;
     return c->ring_verdict != 0;
@@ -1433,7 +1460,7 @@ static int run_synthesis(bms_ctx* c, const SynthesisPlan& P, const double* A, lo
                          long long ldy, const double* scale) {
   hipStream_t S = c->stream;
   if (rows <= 0) return BMS_OK;
-  if (P.nt && rows >= 2 && !getenv("SCRI_AMD_NO_SPLIT_SYNTHESIS")) {
+  if (P.nt && rows >= 2 && !route_env("SCRI_AMD_NO_SPLIT_SYNTHESIS")) {
     TIMED(c, BMS_TAG_GEMM_SYNTHESIS, launch_synthesis_split(S, A, lda, rows, P.g, P.nt, P.d_T, P.d_meta, off, Y, ldy, P.lds, c->n_cu, scale));
   } else if (P.large) {
     double* d_F;
@@ -1449,7 +1476,7 @@ static int run_synthesis(bms_ctx* c, const SynthesisPlan& P, const double* A, lo
 // order (the fused kernel) the two pole rings are stored once each (1) and, with a boost, whose time skew grows with |u|,
 // the columns are also sorted by the skew rate (2).
 static int column_plan(const bms_transformation* tr, int n_out) {
-  if (getenv("SCRI_AMD_NO_COLUMN_SORT") || getenv("SCRI_AMD_NO_FUSED_ANALYSIS")) return 0;
+  if (route_env("SCRI_AMD_NO_COLUMN_SORT") || route_env("SCRI_AMD_NO_FUSED_ANALYSIS")) return 0;
   if (tr->n_theta < 3 || tr->n_theta * tr->n_phi > pixel_sort_max() || tr->n_theta > MAX_THETA_SEPARABLE ||
       !fused_analysis_supported(tr->n_theta, tr->n_phi, tr->ell_max_out, n_out))
     return 0;
@@ -1508,10 +1535,10 @@ static int device_pixel_tables(bms_ctx* c, const bms_transformation* tr, PixelTa
   int* d_perm = nullptr;
   if (plan) {
     if ((rc = dev_buf_t(c, "pix_perm", (size_t)2 * n_pix, &d_perm))) return rc;
-    TIMED(c, BMS_TAG_SETUP, launch_pixel_sort(PS, P, tr->n_theta, tr->n_phi, plan == 2, d_perm, d_perm + n_pix));
+    TIMED_ON(c, PS, BMS_TAG_SETUP, launch_pixel_sort(PS, P, tr->n_theta, tr->n_phi, plan == 2, d_perm, d_perm + n_pix));
     D.col_of_pixel = d_perm + n_pix;
   }
-  TIMED(c, BMS_TAG_SETUP, launch_pixel_tables(PS, P, O, n_cols, d_perm));
+  TIMED_ON(c, PS, BMS_TAG_SETUP, launch_pixel_tables(PS, P, O, n_cols, d_perm));
   // k, alpha, skew_a, skew_b are contiguous (n_pix apart): one copy back, into page-locked memory
   if (c->pix_back_cap < (size_t)4 * n_pix) {
     if (c->pix_back_host) (void)hipHostFree(c->pix_back_host);
@@ -1725,7 +1752,7 @@ extern "C" int bms_transform_modes_pipelined(bms_ctx* c, const bms_wm_input* in,
   // each other through events and the host runs ahead, so that the kernels of consecutive pieces follow each other without the
   // host's round trip in between -- measured, three alternating runs: 14.9 / 15.1 / 16.2 ms with the host wait, 14.9 / 15.1 / 13.7
   // with events: no difference, the transfers and not the kernels' gaps set the time.
-  const bool host_wait = getenv("SCRI_AMD_PIPE_EVENTS") == nullptr;
+  const bool host_wait = BMS_PROBE_ENV("SCRI_AMD_PIPE_EVENTS") == nullptr;
   auto upload_piece = [&](int k) -> hipError_t {
     // the buffer was read by the kernels of piece k - 2 (host_wait: the host has waited for them before it gets here)
     const int64_t rows = r1[k] - r0[k];
@@ -1835,7 +1862,7 @@ static int transform_modes_impl(bms_ctx* c, const bms_wm_input* in, const bms_tr
   BsplineTable* d_bstab = nullptr;
   BsplineForward* d_bsfwd = nullptr;
   int rc;
-  const bool times_ahead = n >= 8 && in->t && !c->async_pieces && !getenv("SCRI_AMD_NO_BSPLINE") &&
+  const bool times_ahead = n >= 8 && in->t && !c->async_pieces && !route_env("SCRI_AMD_NO_BSPLINE") &&
                            (!sh || (sh->data_row0 >= 0 && sh->data_rows >= 0 && sh->data_row0 + sh->data_rows <= n));
   if (times_ahead) {
     const int64_t r0 = sh ? sh->data_row0 : 0, r1 = r0 + (sh ? sh->data_rows : n);
@@ -1844,7 +1871,7 @@ static int transform_modes_impl(bms_ctx* c, const bms_wm_input* in, const bms_tr
   // The walk itself is put off as well, to the moment the host would otherwise sit waiting for the per-direction tables: until then
   // the axis is taken to be what it nearly always is (increasing, not graded).  A walk that finds otherwise drains what was queued
   // and either fails the call as it always did or starts it again, walk first.
-  const bool walk_later = times_ahead && c->aux && !walk_first && !getenv("SCRI_AMD_WALK_FIRST");
+  const bool walk_later = times_ahead && c->aux && !walk_first && !route_env("SCRI_AMD_WALK_FIRST");
   int walk_rc = BMS_OK;
   bool walked = false, walk_regular = true;
   if (walk_later) {
@@ -1915,7 +1942,7 @@ static int transform_modes_impl(bms_ctx* c, const bms_wm_input* in, const bms_tr
   // Without psi mixing the map modes -> grid values is linear along the columns with time-independent coefficients, so
   // the spline's forward elimination is done on the modes (B-spline form, kernels_bspline.hip) and the grid is passed over
   // once, by the back substitution + evaluation.
-  const bool bsg = n >= 8 && regular_mesh && !getenv("SCRI_AMD_NO_BSPLINE");  // B-spline form (else: the slope form, kernels_spline.hip)
+  const bool bsg = n >= 8 && regular_mesh && !route_env("SCRI_AMD_NO_BSPLINE");  // B-spline form (else: the slope form, kernels_spline.hip)
   const bool bs = bsg && !psi;                                                 // ... with the elimination commuted onto the modes
   // (a "shard" that holds every row of every column is the whole series: only its output range is restricted)
   if (!regular_mesh && sh != nullptr && !(sh->data_row0 == 0 && sh->data_rows == n && sh->col_parts <= 1))
@@ -1962,8 +1989,8 @@ static int transform_modes_impl(bms_ctx* c, const bms_wm_input* in, const bms_tr
   // synthesis PLUS back substitution on the grid, and up to l <= 8 (77 modes x 21 x 21) it wins -- 1e5 steps, supertranslation + frame
   // rotation: l <= 4 0.62 -> 0.54 ms, l <= 6 0.89 -> 0.70, l <= 8 1.20 -> 1.12; from l <= 10 (1.65 vs 1.81) the separable route is ahead
   // (tools/probes/dense_vs_separable_small.py).
-  const bool small_dense = no_boost && rows_avail >= 8 && (long long)n_modes * tr->n_theta * tr->n_phi <= 40000 && !getenv("SCRI_AMD_NO_SMALL_DENSE");
-  if (bs && !small_dense && rows_avail >= 2 && !(sh && sh->col_parts > 1) && tr->n_theta >= 3 && !getenv("SCRI_AMD_NO_SEPARABLE_SYNTHESIS")) {
+  const bool small_dense = no_boost && rows_avail >= 8 && (long long)n_modes * tr->n_theta * tr->n_phi <= 40000 && !route_env("SCRI_AMD_NO_SMALL_DENSE");
+  if (bs && !small_dense && rows_avail >= 2 && !(sh && sh->col_parts > 1) && tr->n_theta >= 3 && !route_env("SCRI_AMD_NO_SEPARABLE_SYNTHESIS")) {
     if (no_boost) {
       if ((rc = build_synthesis(c, tr->n_theta, tr->n_phi, s, in->ell_min, in->ell_max, syn))) return rc;
     } else if (axis_boost_pays(n_modes, tr->n_theta, tr->n_phi) && large_synthesis_supported(tr->n_theta, tr->n_phi, in->ell_min, in->ell_max) &&
@@ -1975,7 +2002,7 @@ static int transform_modes_impl(bms_ctx* c, const bms_wm_input* in, const bms_tr
   const bool sep = no_boost ? (syn.nt != 0 || syn.large) : axis_boost;
   // Dense route: the back substitution commutes with the synthesis product as well, so it runs on the modes too and the product's
   // epilogue evaluates the spline (kernels_gemm_eval.hip): the grid of coefficients never reaches HBM.
-  const bool gemm_eval = bs && !sep && rows_avail >= 8 && !getenv("SCRI_AMD_NO_GEMM_EVAL");
+  const bool gemm_eval = bs && !sep && rows_avail >= 8 && !route_env("SCRI_AMD_NO_GEMM_EVAL");
   double* d_Ac = nullptr;
   if (gemm_eval) {
     // both sweeps of the spline solve on the modes: in one pass over memory (a thread keeps its column's tile in registers), or --
@@ -1984,7 +2011,7 @@ static int transform_modes_impl(bms_ctx* c, const bms_wm_input* in, const bms_tr
     // SIMDs, which this kernel's 2 x 245 registers per lane do not leave -- the host's wait shrinks from 300 to 250 us, but the solve
     // starts that much later and the product waits for it: 5.56 against 5.41 ms per transform.)
     if ((rc = dev_buf_t(c, "Afull", (size_t)rows_avail * ld_af, &d_Ac))) return rc;
-    if (getenv("SCRI_AMD_TWO_SWEEPS")) {
+    if (route_env("SCRI_AMD_TWO_SWEEPS")) {
       if ((rc = dev_buf_t(c, "Afwd", (size_t)rows_avail * ld_af, &d_Af))) return rc;
       TIMED(c, BMS_TAG_SPLINE_FORWARD, launch_bspline_forward_modes(S, F[0].d_data, F[0].ld * 2, n_modes, d_Af, ld_af, row0, rows_avail, n, d_bsfwd,
                                                                     SPLINE_TILE, SPLINE_HALO, 1));
@@ -2010,7 +2037,7 @@ static int transform_modes_impl(bms_ctx* c, const bms_wm_input* in, const bms_tr
   // as they do behind the dense product.
   SynthesisPlan syn_f[5];
   bool sep_fields = false;
-  if (!bs && rows_avail >= 1 && !(sh && sh->col_parts > 1) && tr->n_theta >= 3 && !getenv("SCRI_AMD_NO_SEPARABLE_SYNTHESIS") &&
+  if (!bs && rows_avail >= 1 && !(sh && sh->col_parts > 1) && tr->n_theta >= 3 && !route_env("SCRI_AMD_NO_SEPARABLE_SYNTHESIS") &&
       (no_boost || (axis_boost_pays(n_modes, tr->n_theta, tr->n_phi) && separable_rotor_grid(c, tr, ring_theta)))) {
     sep_fields = true;
     for (int fi = 0; fi < 1 + (psi ? in->n_aux : 0) && sep_fields; ++fi) {
@@ -2048,8 +2075,8 @@ static int transform_modes_impl(bms_ctx* c, const bms_wm_input* in, const bms_tr
         int rc2;
         if ((rc2 = dev_buf_t(c, "Bsyn0", (size_t)rows * f.ldb, &f.d_B))) return rc2;
         HIP_TRY(c, hipMemsetAsync(f.d_B, 0, sizeof(double) * rows * f.ldb, PS));
-        TIMED(c, BMS_TAG_SETUP, launch_swsh_matrix_complex(PS, D.rotors, n_cols_, f.spin, f.ell_min, f.ell_max, f.d_B, f.ldb));
-        TIMED(c, BMS_TAG_SETUP, launch_negated_row(PS, D.col_off, f.d_B + (size_t)(f.K / 2) * f.ldb, 2 * n_cols_));
+        TIMED_ON(c, PS, BMS_TAG_SETUP, launch_swsh_matrix_complex(PS, D.rotors, n_cols_, f.spin, f.ell_min, f.ell_max, f.d_B, f.ldb));
+        TIMED_ON(c, PS, BMS_TAG_SETUP, launch_negated_row(PS, D.col_off, f.d_B + (size_t)(f.K / 2) * f.ldb, 2 * n_cols_));
         B_built = true;
         return BMS_OK;
       };
@@ -2242,7 +2269,7 @@ static int transform_modes_impl(bms_ctx* c, const bms_wm_input* in, const bms_tr
       ev.search_halfwidth = eval_search_halfwidth(T, cA, cB, in->t, g0, g1);
       ev.inv_dx = (g1 - g0 >= 2 && in->t[g1 - 1] > in->t[g0]) ? (double)(g1 - 1 - g0) / (in->t[g1 - 1] - in->t[g0]) : 0.0;
       ev.side = nullptr, ev.side_ld = ldg;
-      const int eval_step = getenv("SCRI_AMD_GEMM_EVAL_STEP") ? atoi(getenv("SCRI_AMD_GEMM_EVAL_STEP")) : 64;  // (read per call, like the other route switches)
+      const int eval_step = route_env("SCRI_AMD_GEMM_EVAL_STEP") ? atoi(route_env("SCRI_AMD_GEMM_EVAL_STEP")) : 64;  // (read per call, like the other route switches)
       if (eval_step != 61)
         if ((rc = dev_buf_t(c, "Cside", (size_t)zgemm3m_eval_side_rows(rows_in) * ldg, &ev.side))) return rc;
       TIMED(c, BMS_TAG_GEMM_SYNTHESIS, launch_zgemm3m_eval(S, d_Ac + (g0 - row0) * ld_af, ld_af, F[0].d_B + 2 * cA, ldb, rows_in, n_pix, n_modes_in + 1,
@@ -2667,7 +2694,7 @@ extern "C" int bms_salm2map(bms_ctx* c, const void* modes, int mem, int64_t n_ma
   const long long P2 = 2LL * n_pix, ldb = round_up(P2, 128);
   // the equiangular grid itself: separable (kernels_synthesis_large.hip) wherever that kernel takes the shape
   SynthesisPlan syn;
-  if (n_theta >= 3 && ell_max >= 1 && !getenv("SCRI_AMD_NO_SEPARABLE_SYNTHESIS"))
+  if (n_theta >= 3 && ell_max >= 1 && !route_env("SCRI_AMD_NO_SEPARABLE_SYNTHESIS"))
     if ((rc = build_synthesis(c, n_theta, n_phi, spin, 0, ell_max, syn))) return rc;
   double* d_B = nullptr;
   if (!syn.large) {
@@ -2803,7 +2830,7 @@ extern "C" int bms_grid_multiply(bms_ctx* c, const void* a, int spin_a, int ell_
   // map2salm -- so the smallest such W serves: the reference's default (W = B, output l_a) needs 2.3 times fewer pixels, and for
   // l_a + l_b <= 25 it is a grid the separable synthesis and the fused analysis take (n_theta <= 40).  A caller's smaller W
   // (aliasing, as in the reference) is kept as given.
-  if (working_ell_max >= ell_max_a + ell_max_b && !getenv("SCRI_AMD_GRID_MULTIPLY_FULL_GRID")) {
+  if (working_ell_max >= ell_max_a + ell_max_b && !route_env("SCRI_AMD_GRID_MULTIPLY_FULL_GRID")) {
     const int B = ell_max_a + ell_max_b;
     working_ell_max = std::max({(B + output_ell_max + 1) / 2, (B + 2) / 2, output_ell_max, 1});
   }
@@ -2822,7 +2849,7 @@ extern "C" int bms_grid_multiply(bms_ctx* c, const void* a, int spin_a, int ell_
     }
   // the equiangular grid itself: both syntheses are separable where the kernel takes the shape (kernels_synthesis.hip)
   SynthesisPlan syn_a, syn_b;
-  bool sep = n_times >= 2 && ell_max_a >= 1 && ell_max_b >= 1 && !getenv("SCRI_AMD_NO_SEPARABLE_SYNTHESIS");
+  bool sep = n_times >= 2 && ell_max_a >= 1 && ell_max_b >= 1 && !route_env("SCRI_AMD_NO_SEPARABLE_SYNTHESIS");
   if (sep) {
     if ((rc = build_synthesis(c, n_theta, n_phi, spin_a, 0, ell_max_a, syn_a))) return rc;
     if ((rc = build_synthesis(c, n_theta, n_phi, spin_b, 0, ell_max_b, syn_b))) return rc;
@@ -3035,7 +3062,7 @@ static int transform_abd_impl(bms_ctx* c, const double* u, const void* raw, int 
   SynthesisPlan syn5[5];
   const bool no_boost = v[0] == 0 && v[1] == 0 && v[2] == 0;
   std::vector<double> ring_theta;
-  bool sep = !(sh && sh->col_parts > 1) && tr->n_theta >= 3 && !getenv("SCRI_AMD_NO_SEPARABLE_SYNTHESIS") &&
+  bool sep = !(sh && sh->col_parts > 1) && tr->n_theta >= 3 && !route_env("SCRI_AMD_NO_SEPARABLE_SYNTHESIS") &&
              (no_boost || (axis_boost_pays((ell_max + 1) * (ell_max + 1), tr->n_theta, tr->n_phi) &&
                            large_synthesis_supported(tr->n_theta, tr->n_phi, 0, ell_max) && separable_rotor_grid(c, tr, ring_theta)));
   for (int si = 0; si < 5 && sep; ++si) {
@@ -3085,7 +3112,7 @@ static int transform_abd_impl(bms_ctx* c, const double* u, const void* raw, int 
   double* d_x;
   // the Horner mixing has time-dependent coefficients, so the elimination stays on the grid; the B-spline form still saves
   // the back substitution its second input stream (kernels_bspline.hip)
-  const bool bsg = n >= 8 && regular_mesh && !getenv("SCRI_AMD_NO_BSPLINE");
+  const bool bsg = n >= 8 && regular_mesh && !route_env("SCRI_AMD_NO_BSPLINE");
   SplineTable* d_tab = nullptr;
   BsplineTable* d_bstab = nullptr;
   BsplineForward* d_bsfwd = nullptr;

@@ -4,7 +4,12 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "env.h"
+
 namespace bms {
+
+// y extent of a launch grid (HIP: 65 535); launchers whose y counts time tiles cut longer launches into slices or refuse them
+constexpr long long GRID_Y_MAX = 65535;
 
 constexpr int ROT_MB = 4;  // mu-block of the packed Delta tables (see kernels_rotate.hip)
 

@@ -657,7 +657,7 @@ __global__ __launch_bounds__(640, 1) void analysis_split_kernel(
 }
 
 int split_analysis_supported(int n_theta, int n_phi, int L, int n_out, bool dedup_poles, SplitGeom& g, size_t& lds_bytes, int& nt) {
-  if (getenv("SCRI_AMD_NO_SPLIT_ANALYSIS")) return 0;
+  if (route_env("SCRI_AMD_NO_SPLIT_ANALYSIS")) return 0;
   if (n_theta < 3 || n_theta > 40 || n_phi < 2 || L < 1 || L > 16) return 0;
   // (n_rows >= 2 and 16 ldg < 2^31 are checked by the caller)
   g.n_theta = n_theta;
@@ -705,7 +705,7 @@ hipError_t launch_analysis_fused(hipStream_t stream, const double* G, long long 
       // natural order 0.51 -> 0.58 ms (64-byte pieces: nothing to gain) and the small rows of cfg2 0.22 -> 0.27 ms.  So:
       // gathered grids whose rows are long, while three pairs of rows of each of the XCD's 32 CUs fit its 4 MiB L2.
       const long long pair_bytes = 16 * ldg;
-      sg.ahead = getenv("SCRI_AMD_SPLIT_PREFETCH") ? atoi(getenv("SCRI_AMD_SPLIT_PREFETCH"))
+      sg.ahead = BMS_PROBE_ENV("SCRI_AMD_SPLIT_PREFETCH") ? atoi(BMS_PROBE_ENV("SCRI_AMD_SPLIT_PREFETCH"))
                                                    : (col_of_pixel && pair_bytes >= (32 << 10) && 96 * pair_bytes <= (4LL << 20) ? 1 : 0);
       static const long long cus = [] {
         int dev = 0, n = 256;
@@ -746,7 +746,7 @@ hipError_t launch_analysis_fused(hipStream_t stream, const double* G, long long 
   // persistent workgroups, two per CU (what registers and LDS allow): measured 0.76 ms at 2 x CUs vs 1.00 ms at 3 x
   // (tail) and 1.16 ms at 1 x on cfg3
   static const long long max_blocks = [] {
-    if (getenv("SCRI_AMD_FUSED_BLOCKS")) return atoll(getenv("SCRI_AMD_FUSED_BLOCKS"));
+    if (BMS_PROBE_ENV("SCRI_AMD_FUSED_BLOCKS")) return atoll(BMS_PROBE_ENV("SCRI_AMD_FUSED_BLOCKS"));
     int dev = 0, cus = 256;
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
       cus = 256;
@@ -1028,7 +1028,7 @@ hipError_t launch_analysis_large(hipStream_t stream, const double* G, long long 
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
   const int kq = (n_theta + 3) / 4;
-  static const int rows_per_block = getenv("SCRI_AMD_TQ_ROWS") ? atoi(getenv("SCRI_AMD_TQ_ROWS")) : 256;
+  static const int rows_per_block = BMS_PROBE_ENV("SCRI_AMD_TQ_ROWS") ? atoi(BMS_PROBE_ENV("SCRI_AMD_TQ_ROWS")) : 256;
   const dim3 grid2(nm, (unsigned)((n_rows + rows_per_block - 1) / rows_per_block));
   // columns of one m: l = max(|m|, ell_min_out) .. L, at most L + 1 - ell_min_out
   const int ntq = (L + 1 - ell_min_out + 15) / 16;

@@ -217,9 +217,10 @@ hipError_t launch_bspline_forward_modes(hipStream_t stream, const double* A, lon
                                         const BsplineForward* table, int tile, int halo, int with_ones) {
   (void)n_knots;
   if (n_rows <= 0 || n_modes <= 0) return hipSuccess;
-  static const int tile_env = getenv("SCRI_AMD_BSPLINE_TILE_FWD") ? atoi(getenv("SCRI_AMD_BSPLINE_TILE_FWD")) : 0;
+  static const int tile_env = BMS_PROBE_ENV("SCRI_AMD_BSPLINE_TILE_FWD") ? atoi(BMS_PROBE_ENV("SCRI_AMD_BSPLINE_TILE_FWD")) : 0;
   tile = tile_env > 0 ? tile_env : tile;
   const long long n_tiles = (n_rows + tile - 1) / tile;
+  if (n_tiles > GRID_Y_MAX) return hipErrorInvalidValue;  // (21 M knots at the 320-knot tile: the engine's chunks stay far below)
   dim3 grid((n_modes + with_ones + 63) / 64, (unsigned)n_tiles);
   hipLaunchKernelGGL(bspline_forward_modes_kernel, grid, dim3(64), 0, stream, A, lda, n_modes, Aout, ldo, g0, n_rows, table,
                      tile, halo, with_ones);
@@ -280,9 +281,10 @@ __global__ __launch_bounds__(64) void bspline_backward_modes_kernel(const double
 hipError_t launch_bspline_backward_modes(hipStream_t stream, const double* A, long long lda, int n_cols, double* Aout, long long ldo,
                                          long long g0, long long n_rows, const BsplineTable* table, int tile, int halo) {
   if (n_rows <= 0 || n_cols <= 0) return hipSuccess;
-  static const int tile_env = getenv("SCRI_AMD_BSPLINE_TILE_FWD") ? atoi(getenv("SCRI_AMD_BSPLINE_TILE_FWD")) : 0;
+  static const int tile_env = BMS_PROBE_ENV("SCRI_AMD_BSPLINE_TILE_FWD") ? atoi(BMS_PROBE_ENV("SCRI_AMD_BSPLINE_TILE_FWD")) : 0;
   tile = tile_env > 0 ? tile_env : tile;
   const long long n_tiles = (n_rows + tile - 1) / tile;
+  if (n_tiles > GRID_Y_MAX) return hipErrorInvalidValue;
   dim3 grid((n_cols + 63) / 64, (unsigned)n_tiles);
   hipLaunchKernelGGL(bspline_backward_modes_kernel, grid, dim3(64), 0, stream, A, lda, n_cols, Aout, ldo, g0, n_rows, table, tile, halo);
   return hipGetLastError();
@@ -469,6 +471,7 @@ hipError_t launch_abd_mix_forward(hipStream_t stream, const AbdGrids& Y, const A
                                   const double* inv_k, const double* inv_k3) {
   if (n_rows <= 0 || n_cols <= 0) return hipSuccess;
   const long long n_tiles = (n_rows + tile - 1) / tile;
+  if (n_tiles > GRID_Y_MAX) return hipErrorInvalidValue;
   dim3 grid((n_cols + 63) / 64, (unsigned)n_tiles);
   hipLaunchKernelGGL(abd_mix_forward_kernel, grid, dim3(64), 0, stream, Y, R, ld, n_cols, g0, n_rows, table, tile, halo, alpha,
                      ethk_over_k, eth_alpha, etheth_alpha, inv_k, inv_k3);
@@ -756,7 +759,7 @@ hipError_t launch_bspline_backward_eval(hipStream_t stream, const double* C, lon
                                         long long n_rows, long long n_knots, const double* x, const BsplineTable* table,
                                         int tile, int halo, const double* base, const double* skew_a, const double* skew_b,
                                         double tt, long long i_lo, long long i_hi, double* out, long long ldo, const BsplineSpread* spread) {
-  static const int tile_env = getenv("SCRI_AMD_SPLINE_TILE_BWD") ? atoi(getenv("SCRI_AMD_SPLINE_TILE_BWD")) : 0;
+  static const int tile_env = BMS_PROBE_ENV("SCRI_AMD_SPLINE_TILE_BWD") ? atoi(BMS_PROBE_ENV("SCRI_AMD_SPLINE_TILE_BWD")) : 0;
   if (n_rows <= 0 || n_cols <= 0 || i_hi <= i_lo) return hipSuccess;
   if (tile_env > 0) {
     tile = tile_env;
@@ -778,7 +781,7 @@ hipError_t launch_bspline_backward_eval(hipStream_t stream, const double* C, lon
     }
   }
   const long long n_tiles = (n_rows + tile - 1) / tile;
-  static const int xp = getenv("SCRI_AMD_BS_XP") ? atoi(getenv("SCRI_AMD_BS_XP")) : 0;
+  static const int xp = BMS_PROBE_ENV("SCRI_AMD_BS_XP") ? atoi(BMS_PROBE_ENV("SCRI_AMD_BS_XP")) : 0;
   // Tile by tile: may the march read the output abscissae from the window staged with the table words?  Only while the lanes
   // of a wave stay within a few samples of each other, i.e. while (range of the skew rate within 64 columns) x |x - tt| + (range
   // of the skew offset) is a few time steps; elsewhere (and when the caller gives no bound) the lanes gather them.
@@ -796,7 +799,7 @@ hipError_t launch_bspline_backward_eval(hipStream_t stream, const double* C, lon
   for (long long y0 = 0; y0 < n_tiles;) {
     const bool w = fits(y0);
     long long y1 = y0 + 1;
-    while (y1 < n_tiles && fits(y1) == w) ++y1;
+    while (y1 < n_tiles && y1 - y0 < GRID_Y_MAX && fits(y1) == w) ++y1;
     dim3 grid((n_cols + 63) / 64, (unsigned)(y1 - y0));
     if (xp == 1) {  // (ring rows, knots per group, deferred stores, register sets, non-temporal rows, abscissa window)
       BS_GO(8, 3, 0, 2, false, false);

@@ -329,12 +329,12 @@ hipError_t launch_zgemm3m(hipStream_t stream, const double* A, long long lda, co
   // XCD shares one 64-column slice of B, which then lives in L2/L1 while A streams: 4.07 against 4.18 ms at cfg3, 1563 row
   // tiles), 32 x 2 otherwise (cfg5's chunks are ~130 row tiles: 64-row super-tiles would leave every third one nearly
   // empty; 94.6 against 96.6 ms).  SCRI_AMD_ZGEMM_ST_ROWS_LOG2 overrides.
-  static const int st_env = getenv("SCRI_AMD_ZGEMM_ST_ROWS_LOG2") ? atoi(getenv("SCRI_AMD_ZGEMM_ST_ROWS_LOG2")) : -1;
+  static const int st_env = BMS_PROBE_ENV("SCRI_AMD_ZGEMM_ST_ROWS_LOG2") ? atoi(BMS_PROBE_ENV("SCRI_AMD_ZGEMM_ST_ROWS_LOG2")) : -1;
   const int st_rows_log2 = (st_env >= 0 && st_env <= 6) ? st_env : (nbm >= 512 ? 6 : 5);
   const int sr = 1 << st_rows_log2, sc = 64 >> st_rows_log2;
   const long long n_super = (long long)((nbm + sr - 1) / sr) * ((nbn + sc - 1) / sc);
   const long long grid = ((n_super + 7) / 8) * 8 * 64;
-  static const bool four = getenv("SCRI_AMD_ZGEMM_4M") && atoi(getenv("SCRI_AMD_ZGEMM_4M")) != 0;
+  static const bool four = BMS_PROBE_ENV("SCRI_AMD_ZGEMM_4M") && atoi(BMS_PROBE_ENV("SCRI_AMD_ZGEMM_4M")) != 0;
   if (four)
     hipLaunchKernelGGL(zgemm3m_mfma_kernel<true>, dim3((unsigned)grid), dim3(256), 0, stream, A, lda, B, ldb, C, ldc, M, N,
                        K, nbm, nbn, st_rows_log2, col_off, col_scale);
@@ -349,7 +349,7 @@ hipError_t launch_dgemm(hipStream_t stream, const double* A, long long lda, cons
   if (M <= 0 || N <= 0) return hipSuccess;
   const int nbm = (int)((M + G_BM - 1) / G_BM);
   const int nbn = (N + G_BN - 1) / G_BN;
-  static const int st_rows_log2 = getenv("SCRI_AMD_GEMM_ST_ROWS_LOG2") ? atoi(getenv("SCRI_AMD_GEMM_ST_ROWS_LOG2")) : 5;
+  static const int st_rows_log2 = BMS_PROBE_ENV("SCRI_AMD_GEMM_ST_ROWS_LOG2") ? atoi(BMS_PROBE_ENV("SCRI_AMD_GEMM_ST_ROWS_LOG2")) : 5;
   const int sr = 1 << st_rows_log2, sc = 64 >> st_rows_log2;
   const long long n_super = (long long)((nbm + sr - 1) / sr) * ((nbn + sc - 1) / sc);
   const long long grid = ((n_super + 7) / 8) * 8 * 64;

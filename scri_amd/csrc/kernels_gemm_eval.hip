@@ -53,6 +53,15 @@ struct EvalArgs {
   unsigned long long* trace;  // (debug) 5 words per block: hw id | xcc id << 32, tile, clock at start / K loop end / exit
 };
 
+// (the knock-out bits and the timeline exist in probe builds only: env.h)
+#if BMS_PROBES
+#define EV_DBG(ev) ((ev).dbg)
+#define EV_TRACE(ev) ((ev).trace)
+#else
+#define EV_DBG(ev) 0
+#define EV_TRACE(ev) (static_cast<unsigned long long*>(nullptr))
+#endif
+
 // first i in [0, n_i) with u_eval(i) >= y (n_i if none); guess = index where it would lie without any skew
 __device__ __forceinline__ int eval_lower_bound(const double* __restrict__ bp, int n_i, double sa, double sb, double tt, double y,
                                                 long long guess, int halfwidth) {
@@ -215,7 +224,7 @@ struct EvalFromLds {
 // 92 rows -- 1e6 steps: 46.9 -> 44.4 ms per transform.  The margin (3 rows + 3 % of the skew) absorbs a local step that differs from the mean one;
 // beyond it the search reports the miss and the thread goes to global memory, as before.
 __device__ __forceinline__ bool eval_launch_wide_window(const EvalArgs& ev) {
-  return !(ev.inv_dx > 0.0) || (ev.dbg & 32) || (ev.search_halfwidth > 0 && 2 * ev.search_halfwidth + 72 <= E_XS);
+  return !(ev.inv_dx > 0.0) || (EV_DBG(ev) & 32) || (ev.search_halfwidth > 0 && 2 * ev.search_halfwidth + 72 <= E_XS);
 }
 __device__ __forceinline__ bool eval_tile_window(const EvalArgs& ev, long long kT, int rows, int n_i, double smin, double smax, int* i_a) {
   if (eval_launch_wide_window(ev)) {  // the bound for the whole launch fits the window (or nothing better is known): no reduction needed
@@ -282,11 +291,11 @@ __device__ __forceinline__ void eval_windows(const EvalArgs& ev, const bool from
   m.op = ev.out + 2LL * col + (long long)i * ev.ldo;
   const bool interior = fa > m.f_lo && fb - 1 < m.f_hi && fb + 1 < m.jl_open;
   if (from_lds && interior) {
-    if (eval_march<true>(m, lds, win, ev.dbg)) return;
+    if (eval_march<true>(m, lds, win, EV_DBG(ev))) return;
   } else if (from_lds) {
-    if (eval_march<false>(m, lds, win, ev.dbg)) return;
+    if (eval_march<false>(m, lds, win, EV_DBG(ev))) return;
   }
-  eval_march<false>(m, EvalFromGlobal{ev, bp, kT}, win, ev.dbg);
+  eval_march<false>(m, EvalFromGlobal{ev, bp, kT}, win, EV_DBG(ev));
 }
 
 template <int ROW_STEP>
@@ -317,7 +326,7 @@ __global__ __launch_bounds__(256, 3) void zgemm3m_eval_kernel(const double* __re
   const long long m0 = (long long)bm * ROW_STEP;
   const int n0 = bn * E_BN;
   unsigned long long tr_t0 = 0;
-  if (ev.trace) tr_t0 = __builtin_readcyclecounter();  // (debug timeline: tools/probes/gemm_eval_trace.py)
+  if (EV_TRACE(ev)) tr_t0 = __builtin_readcyclecounter();  // (debug timeline: tools/probes/gemm_eval_trace.py)
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;  // (wave-uniform: the epilogue branches on it around barriers)
   const int wm = wave >> 1, wn = wave & 1;
@@ -438,7 +447,7 @@ __global__ __launch_bounds__(256, 3) void zgemm3m_eval_kernel(const double* __re
 #undef E_STORE_LDS
 
   unsigned long long tr_t1 = 0;
-  if (ev.trace) tr_t1 = __builtin_readcyclecounter();
+  if (EV_TRACE(ev)) tr_t1 = __builtin_readcyclecounter();
   // ---- epilogue: recombine and scale, then the tile is parked in the operand LDS half by half (columns 0..31 by the waves wn = 0,
   // then 32..63) and every thread evaluates 8 windows of one column of the parked half
   double2 cv[2][2][4];
@@ -470,7 +479,7 @@ __global__ __launch_bounds__(256, 3) void zgemm3m_eval_kernel(const double* __re
     }
     __syncthreads();
     const int col = n0 + h * 32 + ec;
-    if (col < N && !(ev.dbg & 1)) {
+    if (col < N && !(EV_DBG(ev) & 1)) {
       if (ROW_STEP == 64 && ev.side != nullptr && eg < 6) {
         // rows 0..2 and 61..63 of the tile, for the windows that straddle the tile boundary (side row eg of tile bm)
         const int row = eg < 3 ? eg : 58 + eg;
@@ -487,7 +496,7 @@ __global__ __launch_bounds__(256, 3) void zgemm3m_eval_kernel(const double* __re
     }
     if (h == 0) __syncthreads();
   }
-  if (ev.trace && tid == 0) {
+  if (EV_TRACE(ev) && tid == 0) {
     const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4), xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20);
     unsigned long long* tp = ev.trace + 5LL * b;
     tp[0] = (unsigned long long)hw | ((unsigned long long)xcc << 32);
@@ -500,14 +509,14 @@ __global__ __launch_bounds__(256, 3) void zgemm3m_eval_kernel(const double* __re
 // [tile b: rows 61..63][tile b + 1: rows 0..2].  Block = one wave: (the 64 columns of a column panel of the product, boundary) -- the
 // same columns as a tile of the product, so that their skews lie as close together and the window of output abscissae is placed the
 // same way; tables of the few intervals involved and that window are staged in LDS as in the product's epilogue.
-__global__ __launch_bounds__(64) void spline_straddle_eval_kernel(int N, int n_row_tiles, EvalArgs ev, long long M) {
+__global__ __launch_bounds__(64) void spline_straddle_eval_kernel(int N, int n_row_tiles, int n_col_panels, EvalArgs ev, long long M) {
   __shared__ __attribute__((aligned(16))) double2 w_lds[6][64];
   __shared__ __attribute__((aligned(16))) double t_lds[8 * 16];
   __shared__ __attribute__((aligned(16))) double xk_lds[8];
   __shared__ __attribute__((aligned(16))) double xs_lds[E_XS];
   const int tid = threadIdx.x;
-  const int col = blockIdx.x * 64 + tid;
-  const int bnd = blockIdx.y;
+  const int bnd = blockIdx.x / n_col_panels;  // (one-dimensional grid: boundary-major, the panels of a boundary next to each other)
+  const int col = (blockIdx.x - bnd * n_col_panels) * 64 + tid;
   if (bnd + 1 >= n_row_tiles) return;
   const long long kT = ev.g0 + 64LL * bnd + 61;  // knot of side row 0 of this boundary
   const int n_i = (int)(ev.i_hi - ev.i_lo);
@@ -570,34 +579,44 @@ hipError_t launch_zgemm3m_eval(hipStream_t stream, const double* A, long long ld
   ev.i_lo = e.i_lo, ev.i_hi = e.i_hi, ev.out = e.out, ev.ldo = e.ldo, ev.search_halfwidth = e.search_halfwidth;
   ev.inv_dx = e.inv_dx;
   ev.side = e.side, ev.side_ld = e.side_ld;
-  static const int dbg_env = getenv("SCRI_AMD_GEMM_EVAL_DBG") ? atoi(getenv("SCRI_AMD_GEMM_EVAL_DBG")) : 0;
+  ev.dbg = 0;
+#if BMS_PROBES
+  static const int dbg_env = BMS_PROBE_ENV("SCRI_AMD_GEMM_EVAL_DBG") ? atoi(BMS_PROBE_ENV("SCRI_AMD_GEMM_EVAL_DBG")) : 0;
   ev.dbg = dbg_env;
-  const int step_env = getenv("SCRI_AMD_GEMM_EVAL_STEP") ? atoi(getenv("SCRI_AMD_GEMM_EVAL_STEP")) : 0;
+#endif
+  const int step_env = route_env("SCRI_AMD_GEMM_EVAL_STEP") ? atoi(route_env("SCRI_AMD_GEMM_EVAL_STEP")) : 0;
   const int step = (step_env == 61 || step_env == 64) ? step_env : (e.side ? 64 : 61);
   if (step == 64 && !e.side) return hipErrorInvalidValue;
   if (step == 61) ev.side = nullptr;
   const int nbm = step == 61 ? (int)((M - 3 + 60) / 61) : (int)((M + 63) / 64);
   const int nbn = (N + E_BN - 1) / E_BN;
-  static const int st_env = getenv("SCRI_AMD_ZGEMM_ST_ROWS_LOG2") ? atoi(getenv("SCRI_AMD_ZGEMM_ST_ROWS_LOG2")) : -1;
+  static const int st_env = BMS_PROBE_ENV("SCRI_AMD_ZGEMM_ST_ROWS_LOG2") ? atoi(BMS_PROBE_ENV("SCRI_AMD_ZGEMM_ST_ROWS_LOG2")) : -1;
   const int st_rows_log2 = (st_env >= 0 && st_env <= 6) ? st_env : (nbm >= 512 ? 6 : 5);
   const int sr = 1 << st_rows_log2, sc = 64 >> st_rows_log2;
   const long long n_super = (long long)((nbm + sr - 1) / sr) * ((nbn + sc - 1) / sc);
   const long long grid = ((n_super + 7) / 8) * 8 * 64;
   ev.trace = nullptr;
-  const char* trace_path = getenv("SCRI_AMD_GEMM_EVAL_TRACE");
+#if BMS_PROBES
+  const char* trace_path = BMS_PROBE_ENV("SCRI_AMD_GEMM_EVAL_TRACE");
   if (trace_path) {
     if (hipMalloc(&ev.trace, 40 * (size_t)grid) != hipSuccess) ev.trace = nullptr;
     if (ev.trace) (void)hipMemsetAsync(ev.trace, 0, 40 * (size_t)grid, stream);
   }
+#endif
   if (step == 61)
     hipLaunchKernelGGL(zgemm3m_eval_kernel<61>, dim3((unsigned)grid), dim3(256), 0, stream, A, lda, B, ldb, M, N, K, nbm, nbn, st_rows_log2,
                        col_scale, ev);
   else {
     hipLaunchKernelGGL(zgemm3m_eval_kernel<64>, dim3((unsigned)grid), dim3(256), 0, stream, A, lda, B, ldb, M, N, K, nbm, nbn, st_rows_log2,
                        col_scale, ev);
-    if (nbm > 1 && !(ev.dbg & 4))
-      hipLaunchKernelGGL(spline_straddle_eval_kernel, dim3((N + 63) / 64, (unsigned)(nbm - 1)), dim3(64), 0, stream, N, nbm, ev, M);
+    // one block per (tile boundary, column panel), panels fastest, in a one-dimensional grid (a grid's y extent stops at 65 535:
+    // a chunk of more than 4.19 M rows has more boundaries than that)
+    const long long n_straddle = (long long)(nbm - 1) * nbn;
+    if (n_straddle > 0x7fffffffLL) return hipErrorInvalidValue;
+    if (nbm > 1 && !(EV_DBG(ev) & 4))
+      hipLaunchKernelGGL(spline_straddle_eval_kernel, dim3((unsigned)n_straddle), dim3(64), 0, stream, N, nbm, nbn, ev, M);
   }
+#if BMS_PROBES
   if (ev.trace) {  // (debug: blocks the host)
     std::vector<unsigned long long> h(5 * (size_t)grid);
     (void)hipStreamSynchronize(stream);
@@ -608,6 +627,7 @@ hipError_t launch_zgemm3m_eval(hipStream_t stream, const double* A, long long ld
       fclose(f);
     }
   }
+#endif
   return hipGetLastError();
 }
 

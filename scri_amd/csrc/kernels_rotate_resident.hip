@@ -534,7 +534,7 @@ bool rotate_resident_plan(int ell_min, int ell_max, RotResPlan* P, size_t* lds_b
   P->kpad_max = kmax;
   // 8 waves (two per SIMD, 256 registers each); 12 (168 registers: spills in the per-l instances) on request for l_max <= 11
   P->waves = 8;
-  if (const char* e = getenv("SCRI_AMD_ROTATE_WAVES")) P->waves = atoi(e) == 12 && ell_max <= 11 ? 12 : 8;
+  if (const char* e = BMS_PROBE_ENV("SCRI_AMD_ROTATE_WAVES")) P->waves = atoi(e) == 12 && ell_max <= 11 ? 12 : 8;
   const size_t bytes = sizeof(double) * ((size_t)tab + (size_t)P->waves * (kmax + 1) * 32);  // + the dump row of a wave
   if (bytes > 160u * 1024u) return false;
   *lds_bytes = bytes;
@@ -551,7 +551,7 @@ bool rotate_resident_plan(int ell_min, int ell_max, RotResPlan* P, size_t* lds_b
   // last round of the deal cut into per-l pieces (kernel): l <= 16: 0.265 / 0.259 / 0.264 / 0.265 ms per 1e5 steps for 1 / 2 / 3 / 4
   // groups, l <= 8: 0.0665 / 0.0709 / 0.0761 / 0.0804 (every unit pays one rotor set-up)
   int G = nl >= 10 ? 2 : 1;
-  if (const char* e = getenv("SCRI_AMD_ROTATE_GROUPS")) G = atoi(e) < 1 ? 1 : (atoi(e) > 4 ? 4 : atoi(e));
+  if (const char* e = BMS_PROBE_ENV("SCRI_AMD_ROTATE_GROUPS")) G = atoi(e) < 1 ? 1 : (atoi(e) > 4 ? 4 : atoi(e));
   P->n_groups = 0;
   int l = ell_min, used = 0;
   for (int gidx = 0; gidx < G && l <= ell_max; ++gidx) {

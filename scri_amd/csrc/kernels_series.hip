@@ -123,6 +123,7 @@ hipError_t launch_spline_prefix(hipStream_t stream, const double* Y, const doubl
   if (n <= 0 || n_cols <= 0) return hipSuccess;
   const int tile = 512;
   const long long n_tiles = (n + tile - 1) / tile;
+  if (n_tiles > GRID_Y_MAX) return hipErrorInvalidValue;
   dim3 grid((n_cols + 63) / 64, (unsigned)n_tiles), one((n_cols + 63) / 64, 1);
   for (int second = 0; second < order; ++second)
     for (int phase = 1; phase <= 3; ++phase) {
@@ -206,6 +207,7 @@ hipError_t launch_spline_prefix_levels(hipStream_t stream, const double* Y, cons
   if (n <= 0 || n_cols <= 0) return hipSuccess;
   const int tile = 512;
   const long long n_tiles = (n + tile - 1) / tile;
+  if (n_tiles > GRID_Y_MAX) return hipErrorInvalidValue;
   dim3 grid((n_cols + 63) / 64, (unsigned)n_tiles), one((n_cols + 63) / 64, 1);
   for (int r = 1; r <= levels; ++r)
     for (int phase = 1; phase <= 3; ++phase)

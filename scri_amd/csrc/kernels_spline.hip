@@ -170,11 +170,12 @@ __global__ __launch_bounds__(64) void spline_forward_kernel(const double* __rest
 hipError_t launch_spline_forward(hipStream_t stream, const double* Y, double* R, long long ld, int n_cols,
                                  long long g0, long long n_rows, long long n_knots, const double* x,
                                  const SplineTable* table, int tile, int halo) {
-  static const int tile_env = getenv("SCRI_AMD_SPLINE_TILE_FWD") ? atoi(getenv("SCRI_AMD_SPLINE_TILE_FWD")) : 0;
+  static const int tile_env = BMS_PROBE_ENV("SCRI_AMD_SPLINE_TILE_FWD") ? atoi(BMS_PROBE_ENV("SCRI_AMD_SPLINE_TILE_FWD")) : 0;
   if (tile_env > 0) tile = tile_env;
   (void)x;
   if (n_rows <= 0 || n_cols <= 0) return hipSuccess;
   const long long n_tiles = (n_rows + tile - 1) / tile;
+  if (n_tiles > GRID_Y_MAX) return hipErrorInvalidValue;
   dim3 grid((n_cols + 63) / 64, (unsigned)n_tiles);
   hipLaunchKernelGGL(spline_forward_kernel, grid, dim3(64), 0, stream, Y, R, ld, n_cols, g0, n_rows, n_knots, table,
                      tile, halo);
@@ -362,10 +363,11 @@ hipError_t launch_spline_backward_eval(hipStream_t stream, const double* Y, cons
                                        const SplineTable* table, int tile, int halo, const double* base,
                                        const double* skew_a, const double* skew_b, double tt, long long i_lo,
                                        long long i_hi, double* out, long long ldo) {
-  static const int tile_env = getenv("SCRI_AMD_SPLINE_TILE_BWD") ? atoi(getenv("SCRI_AMD_SPLINE_TILE_BWD")) : 0;
+  static const int tile_env = BMS_PROBE_ENV("SCRI_AMD_SPLINE_TILE_BWD") ? atoi(BMS_PROBE_ENV("SCRI_AMD_SPLINE_TILE_BWD")) : 0;
   if (tile_env > 0) tile = tile_env;
   if (n_rows <= 0 || n_cols <= 0 || i_hi <= i_lo) return hipSuccess;
   const long long n_tiles = (n_rows + tile - 1) / tile;
+  if (n_tiles > GRID_Y_MAX) return hipErrorInvalidValue;
   dim3 grid((n_cols + 63) / 64, (unsigned)n_tiles);
   hipLaunchKernelGGL(spline_backward_eval_kernel, grid, dim3(64), 0, stream, Y, R, ld, n_cols, g0, n_rows, n_knots, x,
                      table, tile, halo, base, skew_a, skew_b, tt, i_lo, i_hi, out, ldo);

@@ -415,7 +415,7 @@ __global__ __launch_bounds__(64) void phi_synthesis_mix6_kernel(Mix6Args a, long
 }
 
 int large_synthesis_supported(int n_theta, int n_phi, int ell_min, int ell_max) {
-  if (getenv("SCRI_AMD_NO_SEPARABLE_SYNTHESIS") || getenv("SCRI_AMD_NO_LARGE_SYNTHESIS")) return 0;
+  if (route_env("SCRI_AMD_NO_SEPARABLE_SYNTHESIS") || route_env("SCRI_AMD_NO_LARGE_SYNTHESIS")) return 0;
   const int nk = n_phi / 2 + 1;
   return n_theta >= 2 && n_theta <= 104 && n_phi >= 1 && nk <= 64 && ell_max >= 1 && ell_max <= 33 && ell_min >= 0 && ell_min <= ell_max;
 }
@@ -429,13 +429,13 @@ hipError_t launch_synthesis_large(hipStream_t stream, const double* A, long long
   if (n_rows <= 0) return hipSuccess;
   const int L = ell_max, nm = 2 * L + 1, jp = large_analysis_jp(n_theta);
   const int n_modes = (L + 1) * (L + 1) - ell_min * ell_min;
-  static const int rows_per_block = getenv("SCRI_AMD_TS_ROWS") ? atoi(getenv("SCRI_AMD_TS_ROWS")) : 256;
+  static const int rows_per_block = BMS_PROBE_ENV("SCRI_AMD_TS_ROWS") ? atoi(BMS_PROBE_ENV("SCRI_AMD_TS_ROWS")) : 256;
   const dim3 grid1(nm, (unsigned)((n_rows + rows_per_block - 1) / rows_per_block));
   const int kl = (L + 1 - ell_min + 3) / 4, ntj_all = (n_theta + 15) / 16;
   // SCRI_AMD_TS_SPLIT=1 and more than four ring tiles (n_theta > 64): two workgroups per m, each with half of them
   // (measured, round 4: 99 x 99 / l <= 24, 25 000 steps, six fields: 14.65 ms split against 13.09 ms whole -- three waves per SIMD at
   // 153 registers do not make up for gathering every mode twice; off unless asked for)
-  static const int ts_split = getenv("SCRI_AMD_TS_SPLIT") ? atoi(getenv("SCRI_AMD_TS_SPLIT")) : 0;
+  static const int ts_split = BMS_PROBE_ENV("SCRI_AMD_TS_SPLIT") ? atoi(BMS_PROBE_ENV("SCRI_AMD_TS_SPLIT")) : 0;
   const int parts = ts_split && ntj_all > 4 ? 2 : 1;
   const int ntj = (ntj_all + parts - 1) / parts;
   const dim3 grid1z(grid1.x, grid1.y, parts);
@@ -494,13 +494,13 @@ hipError_t launch_theta_synthesis(hipStream_t stream, const double* A, long long
                                   int ell_max, const double* Tsyn, double* F) {
   if (n_rows <= 0) return hipSuccess;
   const int L = ell_max, nm = 2 * L + 1, jp = large_analysis_jp(n_theta);
-  static const int rows_per_block = getenv("SCRI_AMD_TS_ROWS") ? atoi(getenv("SCRI_AMD_TS_ROWS")) : 256;
+  static const int rows_per_block = BMS_PROBE_ENV("SCRI_AMD_TS_ROWS") ? atoi(BMS_PROBE_ENV("SCRI_AMD_TS_ROWS")) : 256;
   const dim3 grid1(nm, (unsigned)((n_rows + rows_per_block - 1) / rows_per_block));
   const int kl = (L + 1 - ell_min + 3) / 4, ntj_all = (n_theta + 15) / 16;
   // SCRI_AMD_TS_SPLIT=1 and more than four ring tiles (n_theta > 64): two workgroups per m, each with half of them
   // (measured, round 4: 99 x 99 / l <= 24, 25 000 steps, six fields: 14.65 ms split against 13.09 ms whole -- three waves per SIMD at
   // 153 registers do not make up for gathering every mode twice; off unless asked for)
-  static const int ts_split = getenv("SCRI_AMD_TS_SPLIT") ? atoi(getenv("SCRI_AMD_TS_SPLIT")) : 0;
+  static const int ts_split = BMS_PROBE_ENV("SCRI_AMD_TS_SPLIT") ? atoi(BMS_PROBE_ENV("SCRI_AMD_TS_SPLIT")) : 0;
   const int parts = ts_split && ntj_all > 4 ? 2 : 1;
   const int ntj = (ntj_all + parts - 1) / parts;
   const dim3 grid1z(grid1.x, grid1.y, parts);
@@ -529,7 +529,7 @@ hipError_t launch_theta_synthesis(hipStream_t stream, const double* A, long long
 }
 
 int abd_mix6_supported(int n_theta, int n_phi, int ell_max) {
-  if (getenv("SCRI_AMD_NO_FUSED_ABD_MIX")) return 0;
+  if (route_env("SCRI_AMD_NO_FUSED_ABD_MIX")) return 0;
   // (the F tiles of a pass borrow the LDS area of its results: 2 L + 1 <= n_phi; three workgroups or more per CU)
   return large_synthesis_supported(n_theta, n_phi, 0, ell_max) && 2 * ell_max + 1 <= n_phi && (size_t)6 * 4 * n_phi * 16 <= 53 * 1024;
 }

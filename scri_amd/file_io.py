@@ -43,21 +43,25 @@ def monotonize(y):
     return np.asarray(y)[monotonic_indices(y)]
 
 
+def _mass_power(data_type):
+    """The power of the Christodoulou mass that a field of this type carries (psi_n: n - 4, strain: -1, its time derivative: 0)"""
+    if data_type in (psi0, psi1, psi2, psi3, psi4):
+        return data_type - 4
+    if data_type == h:
+        return -1
+    if data_type == hdot:
+        return 0
+    raise ValueError("DataType not determined.")
+
+
 def make_variable_dimensionless(WM, ch_mass=1.0):
-    """Scale out the Christodoulou mass, in place (scri/SpEC/file_io/__init__.py:421-450)."""
+    """Scale out the Christodoulou mass, in place (scri/SpEC/file_io/__init__.py:421-450): times in units of the mass, the field
+    by the mass to the power its type carries."""
     if WM.m_is_scaled_out:
         print("Data is already dimensionless!")
         return
-    if WM.dataType in [psi4, psi3, psi2, psi1, psi0]:
-        unit_scale_factor = (ch_mass) ** (WM.dataType - 4)
-    elif WM.dataType == h:
-        unit_scale_factor = 1 / ch_mass
-    elif WM.dataType == hdot:
-        unit_scale_factor = 1.0
-    else:
-        raise ValueError("DataType not determined.")
-    WM.t = WM.t / ch_mass
-    WM.data = WM.data * unit_scale_factor
+    power = _mass_power(WM.dataType)  # (raises before anything is touched)
+    WM.t, WM.data = WM.t / ch_mass, WM.data * float(ch_mass) ** power
     WM.m_is_scaled_out = True
 
 

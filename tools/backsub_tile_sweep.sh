@@ -1,4 +1,6 @@
 #!/bin/bash
+# Needs the probe build of the library (its switch does not exist in the default one; scri_amd/csrc/env.h):
+#   make -C scri_amd/csrc PROBES=1 && export SCRI_AMD_LIB_PATH=$PWD/scri_amd/libscri_amd_probes.so
 # back substitution of the cfg3 bench: tile length vs kernel time (HIP events), SCRI_AMD_SPLINE_TILE_BWD
 for t in 0 172 200 257 290 320 400 513; do
   for i in 1 2; do

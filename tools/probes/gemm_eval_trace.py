@@ -1,3 +1,5 @@
+# Needs the probe build of the library (its switch does not exist in the default one; scri_amd/csrc/env.h):
+#   make -C scri_amd/csrc PROBES=1 && export SCRI_AMD_LIB_PATH=$PWD/scri_amd/libscri_amd_probes.so
 """Timeline of the evaluating product's workgroups (debug trace: SCRI_AMD_GEMM_EVAL_TRACE=<file>): do the epilogues of the
 workgroups that share a CU coincide?"""
 import sys, numpy as np

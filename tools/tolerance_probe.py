@@ -1,3 +1,5 @@
+# Needs the probe build of the library (its switch does not exist in the default one; scri_amd/csrc/env.h):
+#   make -C scri_amd/csrc PROBES=1 && export SCRI_AMD_LIB_PATH=$PWD/scri_amd/libscri_amd_probes.so
 """Observed maxima of the reference's analytic translation sweeps (tests/test_waveform_grid.py:41-158) on the GPU, without
 assertions: run once per setting of SCRI_AMD_ZGEMM_4M (0 = three real products per complex one, 1 = four) to see which
 digits the synthesis costs.  Prints one JSON line.   python tools/tolerance_probe.py [label]"""

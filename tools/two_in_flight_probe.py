@@ -1,3 +1,5 @@
+# Needs the probe build of the library (its switch does not exist in the default one; scri_amd/csrc/env.h):
+#   make -C scri_amd/csrc PROBES=1 && export SCRI_AMD_LIB_PATH=$PWD/scri_amd/libscri_amd_probes.so
 """MEASUREMENT: throughput of the cfg3 transform with 1, 2 and 3 transforms in flight (one context + one host thread each, every
 context on its own stream; ctypes releases the GIL): does the HBM-bound tail of transform k (back substitution, analysis) hide
 under the MFMA-bound synthesis of transform k + 1?  SCRI_AMD_ZGEMM_ST_ROWS_LOG2 selects the GEMM's super-tile shape (6: 64 x 1,
