@@ -152,7 +152,7 @@ def cpu_baseline(spec, n_sample):
     from oracle.containers import WM, h
     from scri_amd import synthetic
 
-    t, data, _ = synthetic.workload(spec["name"], n_times=n_sample)
+    t, data, _ = synthetic.workload(spec["name"], n_times=n_sample, axis=spec.get("axis", "uniform"))
     w = WM(t=t, data=data, ell_min=2, ell_max=spec["ell_max"], dataType=h)
     t0 = time.perf_counter()
     out = grid_ref.transform(w, **spec["kwargs"])
@@ -348,7 +348,7 @@ def plumbing_only(args, rank, world, backend_note=None):
     n_global = int(args.n_times or 8000)
     tr = engine.make_transformation(kw["supertranslation"], kw.get("frame_rotation", [1, 0, 0, 0]), kw.get("boost_velocity", [0, 0, 0]),
                                     n_theta, n_theta, ell_max)
-    have, need, window = sharding.plan(np.arange(n_global) * spec["dt"], tr, world)
+    have, need, window = sharding.plan(synthetic.time_axis(n_global, spec["dt"], args.time_axis), tr, world)
     gen = synthetic.abd_workload if abd else synthetic.workload
     _, mine, _ = gen(args.workload, n_times=n_global, rows=have[rank])
     ext = sharding.exchange_halos(torch.from_numpy(mine), have[rank], need[rank], have, need, dim=1 if abd else 0)  # (six fields: rows = axis 1)
@@ -433,6 +433,9 @@ def main():
                     help="N > 1: time shards + halo exchange (rows) or grid-column parts + reduce-scatter (columns, for strong "
                     "boosts); auto = sharding.choose_partition (rows for the BASELINE.json workloads)")
     ap.add_argument("--boost-scale", type=float, default=1.0, help="multiplies the workload's boost velocity (stress variants)")
+    ap.add_argument("--time-axis", default="uniform", choices=["uniform", "jitter", "sxs"],
+                    help="time samples of the synthetic series (scri_amd/synthetic.py::time_axis): BASELINE.json's uniform dt, every sample "
+                    "jittered by +-30 %% of dt, or steps shrinking 20x over the series as an inspiral -> merger run's do (same span, same signals)")
     ap.add_argument("--no-live-pmc", action="store_true",
                     help="N = 1: do not run the two rocprofv3 --pmc child passes that measure roofline.traffic (the committed summary "
                     "is reported instead if it was taken on this build's kernel sources, otherwise null)")
@@ -464,7 +467,7 @@ def main():
         traffic_note = "not measured: this run is itself under a profiler"
     if world == 1 and not pmc_child and not args.no_live_pmc and args.workload == "cfg3" and not under_profiler:
         child = ["--gpus", "1", "--steps", "3", "--warmup", "1", "--cpu-sample", "0", "--no-live-pmc", "--workload", args.workload,
-                 "--boost-scale", str(args.boost_scale)] + (["--n-times", str(args.n_times)] if args.n_times else [])
+                 "--boost-scale", str(args.boost_scale), "--time-axis", args.time_axis] + (["--n-times", str(args.n_times)] if args.n_times else [])
         traffic, traffic_note = live_pmc_traffic(child)
 
     import datetime
@@ -538,6 +541,7 @@ def main():
 
     spec = dict(synthetic.CONFIGS[args.workload])
     spec["name"] = args.workload
+    spec["axis"] = args.time_axis  # (the one-core CPU baseline runs on the same axis; the all-cores one keeps the uniform axis)
     abd = args.workload == "cfg5"
     # total work fixed, sharded `world` ways: cfg4 (1e6 steps), and cfg5 on several GPUs (BASELINE.json configs[4]: 2e5 steps, 8 GPUs;
     # scri/asymptotic_bondi_data/transformations.py:391-412 is what the shards reproduce) -- on one GPU cfg5 stays one rank's share
@@ -567,16 +571,16 @@ def main():
     n_fields = 6 if abd else 1
 
     # this rank's rows of the global series, resident in HBM before the timed region
-    have, need, window = sharding.plan(np.arange(n_global) * spec["dt"], tr, world)
+    have, need, window = sharding.plan(synthetic.time_axis(n_global, spec["dt"], args.time_axis), tr, world)
     own = have[rank][1] - have[rank][0]
     columns = world > 1 and (args.partition == "columns" or (args.partition == "auto" and sharding.choose_partition(have, need) == "columns"))
     if columns and abd:
         raise SystemExit("--partition columns is wired into the bench for the WaveformModes workloads only")
     if abd:
-        t_global, local_host, _ = synthetic.abd_workload(args.workload, n_times=n_global, rows=have[rank])
+        t_global, local_host, _ = synthetic.abd_workload(args.workload, n_times=n_global, rows=have[rank], axis=args.time_axis)
         out = torch.empty((6, own, n_modes), dtype=torch.complex128, device=dev)
     else:
-        t_global, local_host, _ = synthetic.workload(args.workload, n_times=n_global, rows=have[rank])
+        t_global, local_host, _ = synthetic.workload(args.workload, n_times=n_global, rows=have[rank], axis=args.time_axis)
         out = torch.empty((own, n_modes), dtype=torch.complex128, device=dev)
     local = torch.from_numpy(local_host).to(dev)
     del local_host
@@ -602,9 +606,9 @@ def main():
     if strong and world > 1 and not args.no_n1_reference:
         if rank == 0:
             if abd:
-                _, whole_host, _ = synthetic.abd_workload(args.workload, n_times=n_global)
+                _, whole_host, _ = synthetic.abd_workload(args.workload, n_times=n_global, axis=args.time_axis)
             else:
-                _, whole_host, _ = synthetic.workload(args.workload, n_times=n_global)
+                _, whole_host, _ = synthetic.workload(args.workload, n_times=n_global, axis=args.time_axis)
             whole = torch.from_numpy(whole_host).to(dev)
             del whole_host
             whole_out = torch.empty(((6, n_global, n_modes) if abd else (n_global, n_modes)), dtype=torch.complex128, device=dev)
@@ -713,6 +717,7 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     timing = ctx.get_timing(reset=True)
+    eval_stats = ctx.eval_stats(reset=True)  # (the warm-up steps count too: the same launches)
 
     el = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
     if world > 1:
@@ -800,7 +805,8 @@ def main():
                     f"{args.workload}: AsymptoticBondiData psi0..psi4 + sigma, ell 0..{ell_max} (6 x {n_modes} modes), " if abd
                     else f"{args.workload}: WaveformModes h, ell 2..{ell_max} ({n_modes} modes), "
                 )
-                + f"{per_gpu} time steps per GPU ({n_global} total), " + workload_terms
+                + f"{per_gpu} time steps per GPU ({n_global} total"
+                + ("" if args.time_axis == "uniform" else f"; NON-UNIFORM time axis '{args.time_axis}': synthetic.time_axis") + "), " + workload_terms
                 + (" (cfg2's second step; its first, the rotor series, is the `rotation` line of the default run at this l range: tools/bench_rotation.py 8)"
                    if args.workload == "cfg2" else "") + ", "
                 f"{n_theta}x{n_theta} grid, {n_out} output steps on rank 0",
@@ -838,6 +844,11 @@ def main():
             },
             "kernels": kernels,
         }
+        if eval_stats[0] > 0:
+            # the evaluating product stages a window of output times per tile in LDS; tiles whose samples leave it search global memory
+            line["eval_window"] = {"time_axis": args.time_axis, "tiles": eval_stats[0], "tiles_off_the_lds_path": eval_stats[1],
+                                   "marches_continued_from_global_memory": eval_stats[2],
+                                   "share_off_the_lds_path": eval_stats[1] / eval_stats[0]}
         if not has_boost and not abd and g_ms > 0 and timing.get("spline_backward", (0.0, 0))[1] > 0:
             # no dense product on this route (a boost-free shape too large for the engine's small-shape rule, which keeps l <= 8 on the evaluating
             # product: then there is no back substitution on the grid and the MFMA roofline above is the right one): the dominant kernel is the

@@ -74,6 +74,8 @@ SIGNATURES = {
     "bms_ctx_set_stream": (c_int, [c_vp, c_vp]),
     "bms_ctx_use_default_stream": (c_int, [c_vp]),
     "bms_ctx_set_workspace_limit": (c_int, [c_vp, ctypes.c_uint64]),
+    "bms_ctx_reserve": (c_int, [c_vp, ctypes.c_uint64]),
+    "bms_ctx_get_eval_stats": (c_int, [c_vp, ctypes.POINTER(c_i64), c_int]),
     "bms_ctx_synchronize": (c_int, [c_vp]),
     "bms_ctx_enable_timing": (c_int, [c_vp, c_int]),
     "bms_ctx_get_timing": (c_int, [c_vp, c_dp, ctypes.POINTER(c_i64), c_int]),
@@ -391,6 +393,17 @@ class Context:
 
     def synchronize(self):
         self.check(load().bms_ctx_synchronize(self._h), "bms_ctx_synchronize")
+
+    def eval_stats(self, reset=True):
+        """(tiles launched, tiles off the LDS path, marches continued from global memory) of the evaluating product since the last reset"""
+        out = (c_i64 * 3)()
+        self.check(load().bms_ctx_get_eval_stats(self._h, out, 1 if reset else 0), "bms_ctx_get_eval_stats")
+        return tuple(int(v) for v in out)
+
+    def reserve(self, nbytes=0):
+        """Warm-up: have the driver map `nbytes` of device memory (0: the work-space cap) now, so that the first full-size call of the
+        process costs what the second does (bms_ctx_reserve)."""
+        self.check(load().bms_ctx_reserve(self._h, int(nbytes)), "bms_ctx_reserve")
 
     def enable_timing(self, on=True):
         self.check(load().bms_ctx_enable_timing(self._h, 1 if on else 0), "bms_ctx_enable_timing")

@@ -76,6 +76,9 @@ struct bms_ctx {
   // MI355X); a call that still runs out of memory halves it and tries again (with_smaller_chunks)
   uint64_t ws_limit = 96ull << 30;
   bool ws_limit_set = false;  // by the caller: then it is kept as given
+  // evaluating product (kernels_gemm_eval.hip): how often its samples left the window of abscissae a tile stages in LDS
+  unsigned long long* d_eval_stats = nullptr;  // device: [0] tiles / boundary blocks off the LDS path, [1] marches continued from global memory
+  uint64_t eval_tiles = 0;                     // tiles + boundary blocks launched since the last reset
   bool alloc_failed = false;  // a device allocation of the running call failed (as opposed to a cap that is too small by plan)
   std::map<std::string, DevBuf> bufs;  // grow-only named work space
   int delta_lmax = -1;                 // Delta tables cached up to this l
@@ -354,6 +357,7 @@ extern "C" void bms_ctx_destroy(bms_ctx* c) {
   (void)hipStreamSynchronize(c->stream);
   for (auto& kv : c->bufs)
     if (kv.second.p) (void)hipFree(kv.second.p);
+  if (c->d_eval_stats) (void)hipFree(c->d_eval_stats);
   for (auto& t : c->timed) {
     (void)hipEventDestroy(t.a);
     (void)hipEventDestroy(t.b);
@@ -432,6 +436,53 @@ extern "C" int bms_ctx_set_workspace_limit(bms_ctx* c, uint64_t bytes) {
   c->ws_limit_set = bytes != 0;
   if (!bytes) HIP_TRY(c, hipSetDevice(c->device));  // (the default is sized from THIS context's device)
   c->ws_limit = bytes ? bytes : default_ws_limit();
+  return BMS_OK;
+}
+
+// The first device allocations of a process are slow on this platform (the driver maps fresh memory at 40 - 80 ms per GB; memory a
+// process has held before comes back in under a millisecond: tools/probes/alloc_rate_probe.py), so the first full-size call of a
+// process pays seconds for its work space.  bms_ctx_reserve takes that cost up front: `bytes` of device memory (0: the work space cap
+// of the context) are allocated in blocks that are held together, written once and released again.
+extern "C" int bms_ctx_reserve(bms_ctx* c, uint64_t bytes) {
+  if (!c) return BMS_ERR_INVALID;
+  HIP_TRY(c, hipSetDevice(c->device));
+  if (!bytes) bytes = c->ws_limit;
+  const uint64_t block = 16ull << 30;
+  std::vector<void*> held;
+  uint64_t got = 0;
+  hipError_t e = hipSuccess;
+  while (got < bytes) {
+    const uint64_t want = std::min<uint64_t>(block, bytes - got);
+    void* p = nullptr;
+    if ((e = hipMalloc(&p, want)) != hipSuccess) break;
+    held.push_back(p);
+    if ((e = hipMemsetAsync(p, 0, want, c->stream)) != hipSuccess) break;
+    got += want;
+  }
+  (void)hipStreamSynchronize(c->stream);
+  for (void* p : held) (void)hipFree(p);
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    return fail(c, e == hipErrorOutOfMemory ? BMS_ERR_NOMEM : BMS_ERR_HIP, "bms_ctx_reserve: %llu of %llu bytes reserved, then: %s",
+                (unsigned long long)got, (unsigned long long)bytes, hipGetErrorString(e));
+  }
+  return BMS_OK;
+}
+
+// Diagnostics of the evaluating product: out[0] = tiles and tile-boundary blocks launched since the last reset, out[1] = those whose
+// samples did not fit the window of output abscissae staged in LDS (they search and read the axis in global memory: same results,
+// slower), out[2] = per-column marches that started in the window and had to go on from global memory.
+extern "C" int bms_ctx_get_eval_stats(bms_ctx* c, int64_t* out /*[3]*/, int reset) {
+  if (!c || !out) return BMS_ERR_INVALID;
+  HIP_TRY(c, hipSetDevice(c->device));
+  unsigned long long h[2] = {0, 0};
+  if (c->d_eval_stats) {
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, hipMemcpy(h, c->d_eval_stats, 16, hipMemcpyDeviceToHost));
+    if (reset) HIP_TRY(c, hipMemset(c->d_eval_stats, 0, 16));
+  }
+  out[0] = (int64_t)c->eval_tiles, out[1] = (int64_t)h[0], out[2] = (int64_t)h[1];
+  if (reset) c->eval_tiles = 0;
   return BMS_OK;
 }
 
@@ -1306,7 +1357,11 @@ static int eval_search_halfwidth(const PixelTables& T, int cA, int cB, const dou
   double am = 0.0, bm = 0.0;
   for (int p = cA; p < cB; ++p) am = std::max(am, std::fabs(T.skew_a[p])), bm = std::max(bm, std::fabs(T.skew_b[p]));
   const double xm = std::max(std::fabs(x_host[g0] - T.tt), std::fabs(x_host[g1 - 1] - T.tt));
-  const double dx = (x_host[g1 - 1] - x_host[g0]) / (double)(g1 - 1 - g0);
+  // the SHORTEST local step counts (mean over 64 knots, tile by tile): on a graded axis the launch's mean step understates the rows a
+  // skew spans where the steps are short, and a bound that is too small sends every tile there through the global-memory search
+  double dx = (x_host[g1 - 1] - x_host[g0]) / (double)(g1 - 1 - g0);
+  for (int64_t k = g0; k + 64 < g1; k += 64) dx = std::min(dx, (x_host[k + 64] - x_host[k]) / 64.0);
+  if (!(dx > 0.0)) return 0;
   const double rows = 1.25 * (am * xm + bm) / dx + 3.0;
   if (!(rows < 1e6)) return 0;
   return (int)std::ceil(rows);
@@ -2269,6 +2324,15 @@ static int transform_modes_impl(bms_ctx* c, const bms_wm_input* in, const bms_tr
       ev.search_halfwidth = eval_search_halfwidth(T, cA, cB, in->t, g0, g1);
       ev.inv_dx = (g1 - g0 >= 2 && in->t[g1 - 1] > in->t[g0]) ? (double)(g1 - 1 - g0) / (in->t[g1 - 1] - in->t[g0]) : 0.0;
       ev.side = nullptr, ev.side_ld = ldg;
+      if (!c->d_eval_stats) {
+        HIP_TRY(c, hipMalloc(&c->d_eval_stats, 16));
+        HIP_TRY(c, hipMemsetAsync(c->d_eval_stats, 0, 16, S));
+      }
+      ev.stats = c->d_eval_stats;
+      {
+        const uint64_t nbm = (uint64_t)((rows_in + 63) / 64), nbn = (uint64_t)((n_pix + 63) / 64);
+        c->eval_tiles += nbm * nbn + (nbm > 0 ? nbm - 1 : 0) * nbn;
+      }
       const int eval_step = route_env("SCRI_AMD_GEMM_EVAL_STEP") ? atoi(route_env("SCRI_AMD_GEMM_EVAL_STEP")) : 64;  // (read per call, like the other route switches)
       if (eval_step != 61)
         if ((rc = dev_buf_t(c, "Cside", (size_t)zgemm3m_eval_side_rows(rows_in) * ldg, &ev.side))) return rc;

@@ -6,10 +6,34 @@
 
 #include "env.h"
 
+#include <map>
+#include <mutex>
+#include <utility>
+
 namespace bms {
 
 // y extent of a launch grid (HIP: 65 535); launchers whose y counts time tiles cut longer launches into slices or refuse them
 constexpr long long GRID_Y_MAX = 65535;
+
+// Dynamic LDS beyond 64 KB needs hipFuncAttributeMaxDynamicSharedMemorySize on the kernel.  It is set ONCE per (kernel, device), to
+// everything the CU has beyond the kernel's static LDS: a per-launch value is a race between host threads that launch the same kernel
+// with different sizes (thread A sets 124 KB, thread B sets 60 KB, A's launch is refused) -- contexts are meant to be driven from
+// several threads (include/scri_amd.h).
+inline hipError_t allow_dynamic_lds(const void* fn) {
+  static std::mutex mu;
+  static std::map<std::pair<const void*, int>, hipError_t> done;
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  std::lock_guard<std::mutex> guard(mu);
+  const auto key = std::make_pair(fn, dev);
+  const auto it = done.find(key);
+  if (it != done.end()) return it->second;
+  hipFuncAttributes attr;
+  hipError_t e = hipFuncGetAttributes(&attr, fn);
+  if (e == hipSuccess) e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - (int)attr.sharedSizeBytes);
+  done[key] = e;
+  return e;
+}
 
 constexpr int ROT_MB = 4;  // mu-block of the packed Delta tables (see kernels_rotate.hip)
 
@@ -168,7 +192,8 @@ struct SplineEval {
   double* out;
   long long ldo;
   int search_halfwidth;  // bound on |row of a sample - knot of its window| (0: none known)
-  double inv_dx;         // 1 / (mean step of the knots of this launch), or 0: a first guess for the row of an abscissa
+  double inv_dx;         // 1 / (mean step of the knots of this launch), or 0: row guesses allowed at all (the kernel uses each tile's own step)
+  unsigned long long* stats;  // device, or null: [0] += tiles whose samples left the staged window, [1] += marches continued from global memory
   double* side;          // 6 rows of ldc doubles per 64-row tile (zgemm3m_eval_side_rows(M) rows), or null: overlapping tiles
   long long side_ld;
 };

@@ -104,8 +104,7 @@ hipError_t launch_theta_quadrature(hipStream_t stream, const double* F, long lon
     int threads = ((n_out + 63) / 64) * 64;                                                                              \
     if (threads > MAXT) threads = MAXT;                                                                                  \
     const int bx = (n_out + threads - 1) / threads;                                                                      \
-    hipError_t e = hipFuncSetAttribute((const void*)theta_quadrature_kernel<NT, MAXT>,                                   \
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                            \
+    hipError_t e = allow_dynamic_lds((const void*)theta_quadrature_kernel<NT, MAXT>);                            \
     if (e != hipSuccess) return e;                                                                                       \
     hipLaunchKernelGGL((theta_quadrature_kernel<NT, MAXT>), dim3(bx, (unsigned)by), dim3(threads), lds, stream, F, n_rows,  \
                        n_theta, nm, n_out, m_index, T, out, ldo);                                                        \
@@ -680,7 +679,7 @@ template <typename K>
 static hipError_t launch_fused_t(K kernel, hipStream_t stream, dim3 grid, dim3 block, size_t lds, const double* G, long long ldg,
                                  long long n_rows, const FusedGeom& g, const int* m_index, const double* T, const double* D,
                                  double* out, long long ldo, const int* col_of_pixel) {
-  hipError_t e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipError_t e = allow_dynamic_lds((const void*)kernel);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(kernel, grid, block, lds, stream, G, ldg, n_rows, g, m_index, T, D, out, ldo, col_of_pixel);
   return hipGetLastError();
@@ -720,8 +719,7 @@ hipError_t launch_analysis_fused(hipStream_t stream, const double* G, long long 
       const int ks = (sg.nk + 3) / 4;
 #define SPLIT_GO(NT, KS)                                                                                                   \
   {                                                                                                                        \
-    hipError_t e = hipFuncSetAttribute((const void*)analysis_split_kernel<NT, KS>, hipFuncAttributeMaxDynamicSharedMemorySize, \
-                                       (int)slds);                                                                         \
+    hipError_t e = allow_dynamic_lds((const void*)analysis_split_kernel<NT, KS>);                                                                         \
     if (e != hipSuccess) return e;                                                                                         \
     hipLaunchKernelGGL((analysis_split_kernel<NT, KS>), sgrid, sblock, slds, stream, G, ldg, n_rows, sg, m_index, T, out, ldo, \
                        col_of_pixel);                                                                                      \

@@ -49,6 +49,7 @@ struct EvalArgs {
   double inv_dx;         // 1 / (mean step of the launch's knots): turns an abscissa into a first guess of its row (0: no guess)
   double* side;          // ROW_STEP = 64: [n_row_tiles][6][side_ld] first / last three rows of every tile, or null
   long long side_ld;
+  unsigned long long* stats;  // [0] += tiles (and boundary blocks) whose samples left the staged window, [1] += marches that went on from global memory (may be null)
   int dbg;               // timing experiments (results wrong): 1 no evaluation, 2 no sample stores, 4 no straddle kernel, 8 no search; 32 (results right): launch-wide sample window
   unsigned long long* trace;  // (debug) 5 words per block: hw id | xcc id << 32, tile, clock at start / K loop end / exit
 };
@@ -175,12 +176,13 @@ struct EvalFromLds {
   lds_cdp xk_lds;  // [64]
   lds_cdp xs_lds;  // [E_XS]
   int i_a;
+  double inv_dx;   // 1 / (mean step of the staged abscissae): the window's OWN step, not the launch's (0: no guess)
   __device__ __forceinline__ double knot(int jl) const { return xk_lds[jl]; }
   __device__ __forceinline__ lds_cdp tab(int jl) const { return t_lds + 16 * jl; }
   __device__ __forceinline__ bool has(int i) const { return (unsigned)(i - i_a) < (unsigned)E_XS; }
   __device__ __forceinline__ double samp(int i) const { return xs_lds[i - i_a]; }
   // first i with u_eval(i) >= y, or -1 if the window cannot tell
-  __device__ __forceinline__ int first(double y, double sa, double sb, double tt, int n_i, double inv_dx) const {
+  __device__ __forceinline__ int first(double y, double sa, double sb, double tt, int n_i) const {
     int lo = 0, hi = E_XS;
     if (inv_dx > 0.0) {
       // On a (nearly) uniform axis the row follows from the abscissa: u_eval(i) >= y <=> x_i >= (y - sb + sa tt) / (1 + sa).  The
@@ -226,7 +228,9 @@ struct EvalFromLds {
 __device__ __forceinline__ bool eval_launch_wide_window(const EvalArgs& ev) {
   return !(ev.inv_dx > 0.0) || (EV_DBG(ev) & 32) || (ev.search_halfwidth > 0 && 2 * ev.search_halfwidth + 72 <= E_XS);
 }
-__device__ __forceinline__ bool eval_tile_window(const EvalArgs& ev, long long kT, int rows, int n_i, double smin, double smax, int* i_a) {
+// inv_dx: 1 / (mean step of the TILE's knots).  The launch-wide mean misplaces the window on a graded axis: where the steps are 6x
+// shorter than the mean (the late part of an inspiral -> merger series) a skew of 40 mean steps is 240 rows.
+__device__ __forceinline__ bool eval_tile_window(const EvalArgs& ev, long long kT, int rows, int n_i, double smin, double smax, double inv_dx, int* i_a) {
   if (eval_launch_wide_window(ev)) {  // the bound for the whole launch fits the window (or nothing better is known): no reduction needed
     const bool ok = ev.search_halfwidth > 0 && 2 * ev.search_halfwidth + 72 <= E_XS;
     long long ia = kT - ev.i_lo - ev.search_halfwidth - 2;
@@ -234,7 +238,7 @@ __device__ __forceinline__ bool eval_tile_window(const EvalArgs& ev, long long k
     *i_a = (int)(ia < 0 ? 0 : ia);
     return ok;
   }
-  const double r_hi = smax * ev.inv_dx, r_lo = smin * ev.inv_dx;
+  const double r_hi = smax * inv_dx, r_lo = smin * inv_dx;
   const double amax = fabs(r_hi) > fabs(r_lo) ? fabs(r_hi) : fabs(r_lo);
   if (!(amax < 1e8)) {
     *i_a = 0;
@@ -284,8 +288,11 @@ __device__ __forceinline__ void eval_windows(const EvalArgs& ev, const bool from
   if (kT + m.jl == 0)
     i = 0;
   else if (from_lds)
-    i = lds.first(lds.knot(m.jl), m.sa, m.sb, m.tt, m.n_i, ev.inv_dx);
-  if (i < 0) i = eval_lower_bound(bp, m.n_i, m.sa, m.sb, m.tt, ev.x[kT + m.jl], kT + m.jl - ev.i_lo, ev.search_halfwidth);
+    i = lds.first(lds.knot(m.jl), m.sa, m.sb, m.tt, m.n_i);
+  if (i < 0) {
+    if (from_lds && ev.stats) atomicAdd(ev.stats + 1, 1ull);
+    i = eval_lower_bound(bp, m.n_i, m.sa, m.sb, m.tt, ev.x[kT + m.jl], kT + m.jl - ev.i_lo, ev.search_halfwidth);
+  }
   if (i >= m.n_i) return;
   m.i = i;
   m.op = ev.out + 2LL * col + (long long)i * ev.ldo;
@@ -295,6 +302,7 @@ __device__ __forceinline__ void eval_windows(const EvalArgs& ev, const bool from
   } else if (from_lds) {
     if (eval_march<false>(m, lds, win, EV_DBG(ev))) return;
   }
+  if (from_lds && ev.stats) atomicAdd(ev.stats + 1, 1ull);
   eval_march<false>(m, EvalFromGlobal{ev, bp, kT}, win, EV_DBG(ev));
 }
 
@@ -308,7 +316,7 @@ __global__ __launch_bounds__(256, 3) void zgemm3m_eval_kernel(const double* __re
   __shared__ __attribute__((aligned(16))) double xk_lds[64];
   __shared__ __attribute__((aligned(16))) double xs_lds[E_XS];
   __shared__ __attribute__((aligned(16))) double2 sk_lds[E_BN];  // (skew_a, skew_b) of the tile's columns
-  __shared__ double win_lds[2];                                  // smallest / largest skew of the tile (eval_tile_window)
+  __shared__ double win_lds[4];  // smallest / largest skew of the tile (eval_tile_window); 1 / mean step of its knots; of its staged abscissae
   double2* As = lds;
   double2* Bs = lds + 2 * E_ASZ;
 
@@ -349,6 +357,10 @@ __global__ __launch_bounds__(256, 3) void zgemm3m_eval_kernel(const double* __re
       double mn = s0 < s1 ? s0 : s1, mx = s0 < s1 ? s1 : s0;
       wave_min_max(mn, mx);
       if (tid == 0) win_lds[0] = mn, win_lds[1] = mx;
+    }
+    if (tid == 0) {  // the tile's own mean step (a graded axis: the launch's mean can be several times off)
+      const double span = ev.x[kT + rows_valid - 1] - ev.x[kT];
+      win_lds[2] = (rows_valid > 1 && span > 0.0) ? (double)(rows_valid - 1) / span : ev.inv_dx;
     }
   }
 
@@ -394,8 +406,14 @@ __global__ __launch_bounds__(256, 3) void zgemm3m_eval_kernel(const double* __re
   // K loop, whose every turn ends in a barrier, is through)
   int i_a;
   const bool wide = eval_launch_wide_window(ev);
-  const bool from_lds = eval_tile_window(ev, kT, (int)rows_valid, n_i, wide ? 0.0 : win_lds[0], wide ? 0.0 : win_lds[1], &i_a);
+  const bool from_lds = eval_tile_window(ev, kT, (int)rows_valid, n_i, wide ? 0.0 : win_lds[0], wide ? 0.0 : win_lds[1], win_lds[2], &i_a);
+  if (!from_lds && tid == 0 && ev.stats) atomicAdd(ev.stats, 1ull);
   if (from_lds) {
+    if (tid == 0) {  // mean step of the window of abscissae staged below: the first guess of a sample's row (EvalFromLds::first)
+      const int i_b = i_a + E_XS - 1 < n_i - 1 ? i_a + E_XS - 1 : n_i - 1;
+      const double span = ev.x[ev.i_lo + i_b] - ev.x[ev.i_lo + i_a];
+      win_lds[3] = (ev.inv_dx > 0.0 && i_b > i_a && span > 0.0) ? (double)(i_b - i_a) / span : 0.0;
+    }
     {
       long long row = tid >> 2;
       if (row > rows_valid - 1) row = rows_valid - 1;
@@ -490,7 +508,7 @@ __global__ __launch_bounds__(256, 3) void zgemm3m_eval_kernel(const double* __re
       if (fb > f_own) fb = f_own;
       if (fb > f_rows) fb = f_rows;
       const auto win = [&](int fl, int qq) { return Cs[(fl + qq) * E_PC + ec]; };
-      const EvalFromLds src{(lds_cdp)t_lds, (lds_cdp)xk_lds, (lds_cdp)xs_lds, i_a};
+      const EvalFromLds src{(lds_cdp)t_lds, (lds_cdp)xk_lds, (lds_cdp)xs_lds, i_a, from_lds ? win_lds[3] : 0.0};
       const double2 sk = sk_lds[h * 32 + ec];
       eval_windows(ev, from_lds, src, col, sk.x, sk.y, kT, fa, fb, win);
     }
@@ -530,9 +548,23 @@ __global__ __launch_bounds__(64) void spline_straddle_eval_kernel(int N, int n_r
     smin = s0 < s1 ? s0 : s1, smax = s0 < s1 ? s1 : s0;
     wave_min_max(smin, smax);
   }
+  // the local mean step, over the 64 knots around the boundary (six knots alone are too few on a jittered axis)
+  double inv_dx_loc = ev.inv_dx;
+  {
+    const long long ka = kT - 29 < ev.g0 ? ev.g0 : kT - 29, kb = kT + 34 > k_last ? k_last : kT + 34;
+    const double span = ev.x[kb] - ev.x[ka];
+    if (kb > ka && span > 0.0) inv_dx_loc = (double)(kb - ka) / span;
+  }
   int i_a;
-  const bool from_lds = eval_tile_window(ev, kT, 6, n_i, smin, smax, &i_a);
+  const bool from_lds = eval_tile_window(ev, kT, 6, n_i, smin, smax, inv_dx_loc, &i_a);
+  if (!from_lds && tid == 0 && ev.stats) atomicAdd(ev.stats, 1ull);
+  double inv_dx_win = 0.0;
   if (from_lds) {
+    {
+      const int i_b = i_a + E_XS - 1 < n_i - 1 ? i_a + E_XS - 1 : n_i - 1;
+      const double span = ev.x[ev.i_lo + i_b] - ev.x[ev.i_lo + i_a];
+      if (ev.inv_dx > 0.0 && i_b > i_a && span > 0.0) inv_dx_win = (double)(i_b - i_a) / span;
+    }
     {  // 8 rows x 8 pairs of table words
       long long jj = kT + (tid >> 3);
       if (jj > k_last) jj = k_last;
@@ -566,7 +598,7 @@ __global__ __launch_bounds__(64) void spline_straddle_eval_kernel(int N, int n_r
     w_lds[3 + e][tid] = *reinterpret_cast<const double2*>(s1 + e * ev.side_ld);
   }
   const auto win = [&](int fl, int qq) { return w_lds[fl + qq][tid]; };
-  const EvalFromLds src{(lds_cdp)t_lds, (lds_cdp)xk_lds, (lds_cdp)xs_lds, i_a};
+  const EvalFromLds src{(lds_cdp)t_lds, (lds_cdp)xk_lds, (lds_cdp)xs_lds, i_a, inv_dx_win};
   eval_windows(ev, from_lds, src, col, sa_t, sb_t, kT, 0, fb, win);
 }
 
@@ -579,6 +611,7 @@ hipError_t launch_zgemm3m_eval(hipStream_t stream, const double* A, long long ld
   ev.i_lo = e.i_lo, ev.i_hi = e.i_hi, ev.out = e.out, ev.ldo = e.ldo, ev.search_halfwidth = e.search_halfwidth;
   ev.inv_dx = e.inv_dx;
   ev.side = e.side, ev.side_ld = e.side_ld;
+  ev.stats = e.stats;
   ev.dbg = 0;
 #if BMS_PROBES
   static const int dbg_env = BMS_PROBE_ENV("SCRI_AMD_GEMM_EVAL_DBG") ? atoi(BMS_PROBE_ENV("SCRI_AMD_GEMM_EVAL_DBG")) : 0;

@@ -207,7 +207,7 @@ hipError_t launch_rotate_modes(hipStream_t stream, double* data, long long n_tim
   if (waves < 1) return hipErrorInvalidValue;
   const int pitch = (2 * ell_max + 1) | 1;
   const size_t lds = (size_t)waves * 2 * 64 * pitch * sizeof(double);
-  hipError_t e = hipFuncSetAttribute((const void*)rotate_modes_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipError_t e = allow_dynamic_lds((const void*)rotate_modes_kernel);
   if (e != hipSuccess) return e;
   const long long tpb = (long long)waves * ROT_TPW;
   const long long blocks = (n_times + tpb - 1) / tpb;

@@ -302,8 +302,7 @@ hipError_t launch_rotate_modes_mfma(hipStream_t stream, double* data, long long 
   const int ntl = (2 * ell_max + 1 + 15) / 16;
 #define RM_LAUNCH(NTMAX)                                                                                                 \
   {                                                                                                                      \
-    hipError_t e = hipFuncSetAttribute((const void*)rotate_modes_mfma_kernel<NTMAX>,                                     \
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                            \
+    hipError_t e = allow_dynamic_lds((const void*)rotate_modes_mfma_kernel<NTMAX>);                            \
     if (e != hipSuccess) return e;                                                                                       \
     hipLaunchKernelGGL(rotate_modes_mfma_kernel<NTMAX>, dim3((unsigned)blocks), dim3(256), lds, stream, data, n_times, ld, \
                        ell_min, ell_max, RaRb, rotor_stride, btab, boff, geo);                                           \

@@ -607,8 +607,7 @@ hipError_t launch_rotate_modes_resident(hipStream_t stream, double* data, long l
   const int nu = ka / 2;
 #define RR_LAUNCH(NU, W)                                                                                                       \
   {                                                                                                                          \
-    e = hipFuncSetAttribute((const void*)rotate_modes_resident_kernel<NU, W>, hipFuncAttributeMaxDynamicSharedMemorySize,     \
-                            (int)lds_bytes);                                                                                 \
+    e = allow_dynamic_lds((const void*)rotate_modes_resident_kernel<NU, W>);                                                                                 \
     if (e != hipSuccess) return e;                                                                                           \
     hipLaunchKernelGGL((rotate_modes_resident_kernel<NU, W>), dim3((unsigned)blocks), dim3(64 * W), lds_bytes, stream, data, \
                        n_times, ld, RaRb, rotor_stride, tab_global, P);                                                      \

@@ -465,7 +465,7 @@ hipError_t launch_angular_velocity(hipStream_t stream, const double* F, const do
   const int waves = 4;
   const size_t lds = (size_t)waves * 2 * n_modes * sizeof(double2);
   if (lds > 64 * 1024) {
-    hipError_t e = hipFuncSetAttribute((const void*)angular_velocity_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipError_t e = allow_dynamic_lds((const void*)angular_velocity_kernel);
     if (e != hipSuccess) return e;
   }
   hipLaunchKernelGGL(angular_velocity_kernel, dim3((unsigned)((n_times + waves - 1) / waves)), dim3(64 * waves), lds, stream, F,

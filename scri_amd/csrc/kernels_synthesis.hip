@@ -363,8 +363,7 @@ hipError_t launch_synthesis_split(hipStream_t stream, const double* A, long long
   const dim3 grid((unsigned)(n_pairs < max_blocks ? n_pairs : max_blocks)), block(64 * (g.nth + g.nph));
 #define SYN_GO_S(NT, LEN, SC)                                                                                                       \
   {                                                                                                                                  \
-    hipError_t e = hipFuncSetAttribute((const void*)synthesis_split_kernel<NT, LEN, SC>, hipFuncAttributeMaxDynamicSharedMemorySize, \
-                                       (int)lds_bytes);                                                                              \
+    hipError_t e = allow_dynamic_lds((const void*)synthesis_split_kernel<NT, LEN, SC>);                                                                              \
     if (e != hipSuccess) return e;                                                                                                   \
     hipLaunchKernelGGL((synthesis_split_kernel<NT, LEN, SC>), grid, block, lds_bytes, stream, A, lda, n_rows, g, Tsyn, meta, off, scale, \
                        Y, ldy);                                                                                                      \

@@ -550,7 +550,7 @@ hipError_t launch_phi_synthesis_mix6(hipStream_t stream, const double* const F6[
   const unsigned grid = (unsigned)(items < 256 * 4 ? items : 256 * 4);
 #define M6_GO(KM, NTC)                                                                                                    \
   {                                                                                                                       \
-    hipError_t e_ = hipFuncSetAttribute((const void*)phi_synthesis_mix6_kernel<KM, NTC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+    hipError_t e_ = allow_dynamic_lds((const void*)phi_synthesis_mix6_kernel<KM, NTC>); \
     if (e_ != hipSuccess) return e_;                                                                                      \
     hipLaunchKernelGGL((phi_synthesis_mix6_kernel<KM, NTC>), dim3(grid), dim3(64), lds, stream, a, n_rows, n_theta, n_phi, L, jp);  \
   }

@@ -87,15 +87,34 @@ CONFIGS = {
 
 ABD_SPINS = (2, 1, 0, -1, -2, 2)
 
+TIME_AXES = ("uniform", "jitter", "sxs")
 
-def abd_workload(name="cfg5", n_times=None, rows=None, ell_max=None):
+
+def time_axis(n, dt, kind="uniform"):
+    """The time samples of a workload.  BASELINE.json's configurations are uniformly stepped (`uniform`: i dt); real scri inputs (SXS
+    / CCE output) are not, so two more axes of the same span n dt carry the same smooth signals (the data are functions of t):
+    `jitter` -- every sample moved by up to +-30 % of dt (seeded; steps between 0.4 and 1.6 dt);
+    `sxs`    -- steps shrinking geometrically by 20x over the series, as an inspiral -> merger run's do."""
+    i = np.arange(n, dtype=float)
+    if kind == "uniform":
+        return i * dt
+    if kind == "jitter":
+        return (i + 0.3 * np.random.default_rng(1234).uniform(-1.0, 1.0, size=n)) * dt
+    if kind == "sxs":
+        steps = 20.0 ** (-i / max(n - 1, 1))
+        t = np.concatenate([[0.0], np.cumsum(steps[:-1])])
+        return t * (n * dt / (t[-1] + steps[-1]))
+    raise ValueError(f"time axis {kind!r}: one of {TIME_AXES}")
+
+
+def abd_workload(name="cfg5", n_times=None, rows=None, ell_max=None, axis="uniform"):
     """(u_global, raw[6, rows, (ell_max+1)^2], spec): every field as `chirp_modes` (its own seed), zeros below |s|."""
     spec = dict(CONFIGS[name])
     n = int(n_times or spec["n_times"])
     spec["n_times"] = n
     if ell_max is not None:
         spec["ell_max"] = int(ell_max)
-    u = np.arange(n) * spec["dt"]
+    u = time_axis(n, spec["dt"], axis)
     r0, r1 = rows if rows is not None else (0, n)
     nm = (spec["ell_max"] + 1) ** 2
     raw = np.zeros((6, r1 - r0, nm), dtype=complex)
@@ -105,12 +124,12 @@ def abd_workload(name="cfg5", n_times=None, rows=None, ell_max=None):
     return u, raw, spec
 
 
-def workload(name, n_times=None, rows=None):
-    """(t_global, data[rows], spec): `rows=(r0, r1)` generates only those rows of the global series."""
+def workload(name, n_times=None, rows=None, axis="uniform"):
+    """(t_global, data[rows], spec): `rows=(r0, r1)` generates only those rows of the global series; `axis`: time_axis()."""
     spec = dict(CONFIGS[name])
     n = int(n_times or spec["n_times"])
     spec["n_times"] = n
-    t = np.arange(n) * spec["dt"]
+    t = time_axis(n, spec["dt"], axis)
     r0, r1 = rows if rows is not None else (0, n)
     data = chirp_modes(t[r0:r1], 2, spec["ell_max"], spec["seed"])
     return t, data, spec

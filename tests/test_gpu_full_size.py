@@ -169,6 +169,44 @@ def _window_check(out_t, out_data, t_in, data_in, kw, ell_max, windows, margin=6
     return worst
 
 
+@pytest.mark.parametrize("axis", ["jitter", "sxs"])
+def test_cfg3_on_non_uniform_time_axes(ctx, axis):
+    """cfg3 at full size on the two non-uniform axes of synthetic.time_axis (every BASELINE workload has dt = 0.1; SXS / CCE output is
+    adaptively stepped): `jitter` (+-30 % of dt per sample) and `sxs` (steps shrinking 20x over the series).  The spline is the
+    not-a-knot interpolant on the REAL knots (scri/waveform_grid.py:574-588), so the oracle on input slices applies unchanged: three
+    windows each (the late `sxs` window is long: a skew of 3.7 time units is 240 rows of 0.016 there), the 8 time shards of
+    sharding.plan against the whole series, and the share of the evaluating product's tiles that stayed on their LDS window."""
+    from scri_amd import engine, sharding, synthetic
+
+    t, data, spec = synthetic.workload("cfg3", axis=axis)
+    kw = spec["kwargs"]
+    d = np.diff(t)
+    assert d.min() > 0 and (d.max() / d.min() > 3.5 if axis == "jitter" else d[0] / d[-1] > 19)
+    ctx.eval_stats(reset=True)
+    out = _gpu_wm(t, data, 16, h, ctx).transform(**kw)
+    tiles, off_lds, continued = ctx.eval_stats(reset=True)
+    assert N - 700 < out.n_times <= N and np.all(np.diff(out.t) > 0)
+    windows = [(0, 400), (50_000, 600), (N - 400, 400)] if axis == "jitter" else [(0, 400), (50_000, 700), (N - 2000, 2000)]
+    worst = _window_check(out.t, out.data, t, data, kw, 16, windows)
+    assert worst < 1e-12
+    # the product's tiles place their window of output rows from their OWN knots' step: (nearly) all of them stay in LDS
+    assert tiles > 30_000 and off_lds <= 0.02 * tiles, (tiles, off_lds, continued)
+    # eight time shards (each from its own rows + halo, what eight ranks compute) == the whole series
+    tr = engine.make_transformation(kw["supertranslation"], kw["frame_rotation"], kw["boost_velocity"], 37, 37, 16)
+    have, need, window = sharding.plan(t, tr, 8)
+    parts = []
+    for r in range(8):
+        ext = data[need[r][0] : need[r][1]]
+        parts.append(engine.transform_modes(t, ext, 2, 16, -2, -1, engine.BMS_TERM_H, tr, ctx=ctx,
+                                            shard=(need[r][0], ext.shape[0], have[r][0], have[r][1]))[1])
+    whole = np.concatenate(parts)
+    assert whole.shape == out.data.shape and np.abs(whole - out.data).max() < 1e-14 * np.abs(out.data).max()
+    # and without the boost (separable synthesis): one late window against the oracle
+    kw0 = {k: v for k, v in kw.items() if k != "boost_velocity"}
+    out0 = _gpu_wm(t, data, 16, h, ctx).transform(**kw0)
+    assert _window_check(out0.t, out0.data, t, data, kw0, 16, [(N - 700, 700)]) < 1e-12
+
+
 def test_cfg2_full_size_rotation_then_supertranslation(ctx):
     """BASELINE.json configs[1] at full size (l <= 8, 1e5 steps): the series rotation (seed 4), then the supertranslation.
     Size-independent properties of the rotation (unitarity per l block, R then R^-1), and WINDOWS of both full-size

@@ -1,6 +1,6 @@
 """Wall time of the workflow the reference documents as taking "an hour or two" (docs/tutorial_abd.rst:387-388): an
 AsymptoticBondiData object (Kerr, moved by a supertranslation + rotation + boost) mapped to its super rest frame.
-Usage: python tools/superrest_timing.py [n_times] [ell_max] [padding_time]"""
+Usage: python tools/superrest_timing.py [n_times] [ell_max] [padding_time] [--reserve]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -8,10 +8,16 @@ import torch  # (the device-resident window allocates through torch: its import,
 import scri_amd
 from tests.test_oracle_charges import kerr_schild_abd
 
+reserve = "--reserve" in sys.argv  # warm-up: Context.reserve() (bms_ctx_reserve) before anything else
+sys.argv = [a for a in sys.argv if a != "--reserve"]
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 20000
 ell_max = int(sys.argv[2]) if len(sys.argv) > 2 else 8
 pad = float(sys.argv[3]) if len(sys.argv) > 3 else 250.0
 ctx = scri_amd.Context(0)
+if reserve:
+    t0 = time.perf_counter()
+    ctx.reserve()
+    print(f"Context.reserve(): {time.perf_counter() - t0:.2f} s (once per process; the driver maps the work space here instead of inside the first call)")
 u = np.linspace(-1000, 1000, num=n)
 a = scri_amd.AsymptoticBondiData(u, ell_max, ctx=ctx)
 a._raw_data[:] = kerr_schild_abd(2.0, 0.456, ell_max, u)
