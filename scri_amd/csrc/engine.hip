@@ -262,7 +262,11 @@ static int dev_buf(bms_ctx* c, const char* name, size_t bytes, void** out) {
       b.cap = 0;
     }
     size_t want = bytes + bytes / 16 + 4096;
+    const auto t_a = std::chrono::steady_clock::now();
     hipError_t e = hipMalloc(&b.p, want);
+    if (route_env("SCRI_AMD_TRACE"))
+      fprintf(stderr, "[scri_amd] work space '%s' grows to %.3f GB: hipMalloc %.1f ms\n", name, want / 1073741824.0,
+              std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_a).count());
     if (e != hipSuccess) {
       (void)hipGetLastError();
       b.p = nullptr;
@@ -447,14 +451,24 @@ extern "C" int bms_ctx_reserve(bms_ctx* c, uint64_t bytes) {
   if (!c) return BMS_ERR_INVALID;
   HIP_TRY(c, hipSetDevice(c->device));
   if (!bytes) bytes = c->ws_limit;
-  const uint64_t block = 16ull << 30;
+  // the largest blocks first (a later allocation larger than anything the process has held before is slow again, whatever the
+  // total: tools/probes/alloc_rate_probe.py), halving the block when the device refuses it
+  uint64_t block = bytes;
   std::vector<void*> held;
   uint64_t got = 0;
   hipError_t e = hipSuccess;
   while (got < bytes) {
     const uint64_t want = std::min<uint64_t>(block, bytes - got);
     void* p = nullptr;
-    if ((e = hipMalloc(&p, want)) != hipSuccess) break;
+    if ((e = hipMalloc(&p, want)) != hipSuccess) {
+      (void)hipGetLastError();
+      if (e == hipErrorOutOfMemory && block > (1ull << 30)) {
+        block /= 2;
+        e = hipSuccess;
+        continue;
+      }
+      break;
+    }
     held.push_back(p);
     if ((e = hipMemsetAsync(p, 0, want, c->stream)) != hipSuccess) break;
     got += want;
@@ -2058,8 +2072,42 @@ static int transform_modes_impl(bms_ctx* c, const bms_wm_input* in, const bms_tr
   // Dense route: the back substitution commutes with the synthesis product as well, so it runs on the modes too and the product's
   // epilogue evaluates the spline (kernels_gemm_eval.hip): the grid of coefficients never reaches HBM.
   const bool gemm_eval = bs && !sep && rows_avail >= 8 && !route_env("SCRI_AMD_NO_GEMM_EVAL");
+  // Separable route without a boost, grids the one-kernel synthesis takes: the same step -- the whole solve on the modes, and the
+  // synthesis kernel evaluates the spline from the last four coefficient rows it has produced (kernels_synthesis_eval.hip).  NOT the
+  // default (SCRI_AMD_SYNTHESIS_EVAL selects it): built for VERDICT r4 item 1, correct on every axis, and slower than the two kernels
+  // it replaces -- 3.5 against 0.65 + 0.96 ms at l <= 16, 1e5 steps (profiles/r05_b_synthesis_eval_*).  A pixel's
+  // samples trail its knots by skew_b / dt rows; the kernel stages a window of the time axis per segment, so the SPREAD of the skews
+  // over the pixels has to stay within a few hundred rows: bounded here, before the per-direction tables exist, by the supertranslation's
+  // coefficients (|Y_lm| <= sqrt((2 l + 1) / 4 pi); the l = 0 part is the time translation and shifts every pixel alike).
+  bool syn_eval = false;
+  {
+    size_t se_lds = 0;
+    int se_nph = 0, se_rr = 0, se_xw = 0;
+    if (sep && no_boost && bs && syn.nt != 0 && rows_avail >= 8 && in->t && route_env("SCRI_AMD_SYNTHESIS_EVAL") &&
+        synthesis_eval_supported(syn.g, syn.nt, &se_lds, &se_nph, &se_rr, &se_xw)) {
+      double bound = 0.0;
+      for (int l = 1; l <= lst; ++l)
+        for (int m = -l; m <= l; ++m) {
+          const cplx a = st[LM_index(l, m, 0)];
+          bound += std::sqrt(a.re * a.re + a.im * a.im) * std::sqrt((2 * l + 1) / (4 * M_PI));
+        }
+      const int64_t r0 = row0, r1 = row0 + rows_avail;
+      double dx = (in->t[r1 - 1] - in->t[r0]) / (double)(r1 - 1 - r0);
+      for (int64_t k = r0; k + 64 < r1; k += 64) dx = std::min(dx, (in->t[k + 64] - in->t[k]) / 64.0);
+      syn_eval = dx > 0.0 && 2.0 * bound / dx <= (se_xw >= 1024 ? 384.0 : 160.0);  // (segment + spread + slack within the staged window)
+      // the inhomogeneous term of h / sigma is subtracted on the modes (its per-direction values are the synthesis of coef0): it must lie
+      // in the band of the data
+      for (int l = 0; l <= lst && !coef0.empty(); ++l)
+        for (int m = -l; m <= l; ++m) {
+          const cplx a = coef0[LM_index(l, m, 0)];
+          if ((a.re != 0 || a.im != 0) && (l < in->ell_min || l > in->ell_max)) syn_eval = false;
+        }
+    }
+  }
+  std::vector<int> term_col;  // (function scope: the upload below is asynchronous; the call ends with a synchronisation)
+  std::vector<double> term_val;
   double* d_Ac = nullptr;
-  if (gemm_eval) {
+  if (gemm_eval || syn_eval) {
     // both sweeps of the spline solve on the modes: in one pass over memory (a thread keeps its column's tile in registers), or --
     // SCRI_AMD_TWO_SWEEPS, the form the kernel was checked against -- as elimination and back substitution one after the other.
     // (Queued BEFORE the per-direction tables of the auxiliary stream: behind them -- so that their few small workgroups find free
@@ -2073,6 +2121,23 @@ static int transform_modes_impl(bms_ctx* c, const bms_wm_input* in, const bms_tr
       TIMED(c, BMS_TAG_SPLINE_BACKWARD, launch_bspline_backward_modes(S, d_Af, ld_af, n_modes + 1, d_Ac, ld_af, row0, rows_avail, d_bstab, SPLINE_TILE, SPLINE_HALO));
     } else
       TIMED(c, BMS_TAG_SPLINE_FORWARD, launch_bspline_solve_modes(S, F[0].d_data, F[0].ld * 2, n_modes, d_Ac, ld_af, row0, rows_avail, d_bsfwd, d_bstab, 1));
+    if (syn_eval && !coef0.empty()) {
+      // C - off . 1 on the modes: column (l, m) of the solved modes loses coef0_lm times the solved constant column
+      for (int l = in->ell_min; l <= std::min(lst, in->ell_max); ++l)
+        for (int m = -l; m <= l; ++m) {
+          const cplx a = coef0[LM_index(l, m, 0)];
+          if (a.re == 0 && a.im == 0) continue;
+          term_col.push_back(LM_index(l, m, in->ell_min));
+          term_val.push_back(a.re);
+          term_val.push_back(a.im);
+        }
+      if (!term_col.empty()) {
+        void *vc, *vv;
+        if ((rc = upload(c, "term_col", term_col.data(), sizeof(int) * term_col.size(), &vc))) return rc;
+        if ((rc = upload(c, "term_val", term_val.data(), sizeof(double) * term_val.size(), &vv))) return rc;
+        TIMED(c, BMS_TAG_POINTWISE, launch_sub_const_modes(S, d_Ac, ld_af, rows_avail, (int)term_col.size(), (const int*)vc, (const double*)vv, n_modes));
+      }
+    }
   } else if (bs && rows_avail > 0) {
     if ((rc = dev_buf_t(c, "Afwd", (size_t)rows_avail * ld_af, &d_Af))) return rc;
     TIMED(c, BMS_TAG_SPLINE_FORWARD, launch_bspline_forward_modes(S, F[0].d_data, F[0].ld * 2, n_modes, d_Af, ld_af, row0, rows_avail, n, d_bsfwd,
@@ -2084,7 +2149,7 @@ static int transform_modes_impl(bms_ctx* c, const bms_wm_input* in, const bms_tr
     if (!(q[0] == 1.0 && q[1] == 0.0 && q[2] == 0.0 && q[3] == 0.0)) {
       // sYlm(F G) = sum_m' D_{m m'}(F) sYlm'(G): the modes as seen from the rotated frame (the constant column stays)
       const double sp[4] = {q[0], q[3], q[2], q[1]};  // (w + i z, y + i x)
-      if ((rc = rotate_impl(c, d_Af, BMS_DEVICE, rows_avail, ld_af / 2, in->ell_min, in->ell_max, sp, false, false))) return rc;
+      if ((rc = rotate_impl(c, syn_eval ? d_Ac : d_Af, BMS_DEVICE, rows_avail, ld_af / 2, in->ell_min, in->ell_max, sp, false, false))) return rc;
     }
   }
   // The psi-mixing types (whose elimination stays on the grid) and the slope-form fallback of the others: without a boost every
@@ -2309,7 +2374,7 @@ static int transform_modes_impl(bms_ctx* c, const bms_wm_input* in, const bms_tr
                   "(use bms_shard_plan)",
                   (long long)row0, (long long)(row0 + rows_avail), (long long)c0, (long long)c1, (long long)g0, (long long)g1);
     double *d_Y = nullptr, *d_R = nullptr, *d_G, *d_Yaux = nullptr;
-    if (!gemm_eval)
+    if (!gemm_eval && !syn_eval)
       if ((rc = dev_buf_t(c, "Y", (size_t)rows_in * ldg, &d_Y))) return rc;
     if (!bs)
       if ((rc = dev_buf_t(c, "R", (size_t)rows_in * ldg, &d_R))) return rc;  // eliminated rows (either form)
@@ -2338,6 +2403,17 @@ static int transform_modes_impl(bms_ctx* c, const bms_wm_input* in, const bms_tr
         if ((rc = dev_buf_t(c, "Cside", (size_t)zgemm3m_eval_side_rows(rows_in) * ldg, &ev.side))) return rc;
       TIMED(c, BMS_TAG_GEMM_SYNTHESIS, launch_zgemm3m_eval(S, d_Ac + (g0 - row0) * ld_af, ld_af, F[0].d_B + 2 * cA, ldb, rows_in, n_pix, n_modes_in + 1,
                                                            d_scale, ev));
+    } else if (syn_eval) {
+      SplineEval ev;
+      ev.table = d_bstab, ev.x = d_x, ev.skew_a = nullptr, ev.skew_b = d_skewb, ev.tt = T.tt, ev.g0 = g0, ev.n_knots = n;
+      ev.i_lo = c0, ev.i_hi = c1, ev.out = d_G, ev.ldo = ldG;
+      ev.search_halfwidth = 0, ev.inv_dx = 0.0, ev.side = nullptr, ev.side_ld = 0, ev.stats = nullptr;
+      double s_min = 0.0, s_max = 0.0;
+      if ((int)T.skew_b.size() < cB) return fail(c, BMS_ERR_HIP, "internal: per-direction skews missing on the host");
+      s_min = s_max = T.skew_b[cA];
+      for (int p = cA; p < cB; ++p) s_min = std::min(s_min, T.skew_b[p]), s_max = std::max(s_max, T.skew_b[p]);
+      TIMED(c, BMS_TAG_GEMM_SYNTHESIS, launch_synthesis_eval(S, d_Ac + (g0 - row0) * ld_af, ld_af, rows_in, syn.g, syn.nt, syn.d_T, syn.d_meta, ev, s_min,
+                                                             s_max, c->n_cu));
     } else if (bs) {
       if (sep) {  // (k = 1 without a boost: no column scale)
         if ((rc = run_synthesis(c, syn, d_Af + (g0 - row0) * ld_af, ld_af, rows_in, coef0.empty() ? nullptr : DP.col_off, d_Y, ldg,

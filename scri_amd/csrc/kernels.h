@@ -147,6 +147,18 @@ hipError_t launch_synthesis_split(hipStream_t stream, const double* A, long long
                                   const double* Tsyn, const int* meta, const double* off, double* Y, long long ldy, size_t lds_bytes,
                                   int n_cu, const double* scale = nullptr);
 
+// the one-kernel form with the spline evaluation in it (kernels_synthesis_eval.hip): A = B-spline coefficients of the (rotated) modes
+// over the knots e.g0 .. e.g0 + n_rows - 1 (n_modes per row), the output e.out = SAMPLES at the output rows [e.i_lo, e.i_hi) in grid
+// order; e.skew_b per grid pixel (e.skew_a unused: no boost), s_min / s_max = its range.
+// g, nt, Tsyn, meta: synthesis_split_plan's.
+struct SplineEval;
+int synthesis_eval_supported(const SynGeom& g, int nt, size_t* lds_bytes, int* nph, int* ring_rows, int* staged_abscissae);
+hipError_t launch_synthesis_eval(hipStream_t stream, const double* A, long long lda, long long n_rows, const SynGeom& g, int nt,
+                                 const double* Tsyn, const int* meta, const SplineEval& e, double s_min, double s_max, int n_cu);
+// Y[k][col[j]] -= c[j] Y[k][one_col] (complex; c: n complex numbers, col: n column indices, all device memory): the h / sigma term
+// subtracted on the modes
+hipError_t launch_sub_const_modes(hipStream_t stream, double* Y, long long ld, long long n_rows, int n, const int* col, const double* c, int one_col);
+
 // two-kernel form for the grids the one-kernel form does not take (kernels_synthesis_large.hip): n_theta <= 104, n_phi <= 127,
 // l_max <= 33, any l_min; F = n_rows x (2 l_max + 1) x large_analysis_jp(n_theta) complex of work space.  With `off` the row has
 // one more complex number at column n_modes (the eliminated constant series), which multiplies -off[pixel]; `scale` (2 doubles per

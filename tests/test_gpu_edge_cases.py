@@ -548,3 +548,105 @@ def test_small_boost_free_shapes_take_the_evaluating_product(ctx, monkeypatch, e
     assert "rotate" in tags_ref
     assert np.array_equal(got.t, ref.t)
     assert np.abs(got.data - ref.data).max() < 1e-13 * max(1.0, np.abs(ref.data).max())
+
+
+def _fused_case(ell_max, n, mesh, st_scale, seed):
+    from scri_amd import synthetic
+
+    rng = np.random.default_rng(seed)
+    if mesh == "uniform":
+        t = np.linspace(-40.0, 55.0, n)
+    elif mesh == "jitter":
+        t = (np.arange(n) + 0.3 * rng.uniform(-1, 1, size=n)) * (95.0 / n) - 40.0
+    elif mesh == "graded":  # steps shrinking 20x over the series
+        steps = 20.0 ** (-np.arange(n) / (n - 1.0))
+        t = np.cumsum(steps)
+        t = t * (95.0 / t[-1]) - 40.0
+    else:  # "rough": steps drawn between 0.2 and 1.8 of the mean
+        t = np.cumsum(rng.uniform(0.2, 1.8, size=n)) * (95.0 / n) - 40.0
+    data = synthetic.chirp_modes(t, 2, ell_max, 40 + ell_max)
+    lst = 3
+    st = synthetic.real_supertranslation(st_scale * (rng.normal(size=(lst + 1) ** 2) + 1j * rng.normal(size=(lst + 1) ** 2)))
+    rot = np.array([0.3, -0.5, 0.7, 0.41])
+    return t, data, dict(supertranslation=st, frame_rotation=rot / np.linalg.norm(rot))
+
+
+@pytest.mark.parametrize("mesh", ["uniform", "jitter", "graded", "rough"])
+@pytest.mark.parametrize("ell_max,n,st_scale", [(16, 700, 0.02), (16, 1900, 0.3), (12, 333, 0.3), (10, 5000, 0.2), (9, 64, 0.05), (16, 9, 0.01),
+                                                 (14, 1100, 6.0)])
+def test_synthesis_with_the_evaluation_in_it_equals_the_two_pass_route_and_the_oracle(ctx, monkeypatch, mesh, ell_max, n, st_scale):
+    """`synthesis_eval_kernel` (boost-free WaveformModes: the spline solved on the modes, evaluated by the synthesis kernel from the
+    last four coefficient rows of each pixel) against the route it replaces -- elimination on the modes, `synthesis_split_kernel`,
+    `bspline_backward_eval_kernel` -- and against the oracle: uniform, jittered, graded and rough time axes; supertranslations from
+    a fraction of a step to tens of steps (the pixels' samples then trail their knots by very different numbers of rows; the last
+    case exceeds the bound of the route and must fall back by itself); series from 9 samples up."""
+    import scri_amd
+
+    t, data, kw = _fused_case(ell_max, n, mesh, st_scale, 7 * ell_max + n)
+    monkeypatch.setenv("SCRI_AMD_NO_SMALL_DENSE", "1")
+    monkeypatch.delenv("SCRI_AMD_NO_SEPARABLE_SYNTHESIS", raising=False)
+
+    def run():
+        w = scri_amd.WaveformModes(t=t, data=data, ell_min=2, ell_max=ell_max, dataType=scri_amd.h, frameType=scri_amd.Inertial,
+                                   r_is_scaled_out=True, m_is_scaled_out=True, ctx=ctx)
+        ctx.enable_timing(True)
+        ctx.get_timing(reset=True)
+        out = w.transform(**kw)
+        tags = {k for k, v in ctx.get_timing(reset=True).items() if v[1]}
+        ctx.enable_timing(False)
+        return out, tags
+
+    monkeypatch.setenv("SCRI_AMD_SYNTHESIS_EVAL", "1")
+    got, tags = run()
+    dt_min = np.diff(t).min()
+    if st_scale <= 0.3 and mesh in ("uniform", "jitter"):  # (elsewhere the bound on the spread of the skews may send the call to the old route)
+        assert "spline_backward" not in tags, tags  # no pass over a grid of coefficients on this route
+    monkeypatch.delenv("SCRI_AMD_SYNTHESIS_EVAL", raising=False)
+    ref, tags_ref = run()
+    assert "spline_backward" in tags_ref
+    assert got.n_times == ref.n_times and np.array_equal(got.t, ref.t)
+    scale = max(1.0, np.abs(ref.data).max())
+    assert np.abs(got.data - ref.data).max() < 3e-13 * scale, (np.abs(got.data - ref.data).max(), dt_min)
+    if n <= 2000:
+        e = grid_ref.transform(WM(t=t, data=data, ell_min=2, ell_max=ell_max, dataType=h), **kw)
+        assert e.t.shape == got.t.shape and np.abs(got.t - e.t).max() < 1e-12
+        assert np.abs(got.data - e.data).max() < 1e-12 * max(1.0, np.abs(e.data).max())
+
+
+def test_synthesis_with_the_evaluation_in_it_chunks_shards_and_grid_output(ctx, monkeypatch):
+    """The same kernel under what the engine does around it: the time axis walked in chunks of a small work space (each chunk a
+    launch with its own run-in rows), time shards with halos (what the ranks of a sharded run compute), a series long enough for
+    several segments per workgroup, and the grid output of WaveformGrid.from_modes."""
+    import scri_amd
+    from scri_amd import engine, sharding
+
+    ell_max, n = 16, 9000
+    t, data, kw = _fused_case(ell_max, n, "jitter", 0.8, 99)
+    monkeypatch.setenv("SCRI_AMD_NO_SMALL_DENSE", "1")
+    monkeypatch.setenv("SCRI_AMD_SYNTHESIS_EVAL", "1")
+    n_theta = 2 * (ell_max + 3) + 1
+    tr = engine.make_transformation(kw["supertranslation"], kw["frame_rotation"], [0.0, 0.0, 0.0], n_theta, n_theta, ell_max)
+    t1, d1 = engine.transform_modes(t, data, 2, ell_max, -2, -1, engine.BMS_TERM_H, tr, ctx=ctx)
+    d1 = np.array(d1)
+    monkeypatch.delenv("SCRI_AMD_SYNTHESIS_EVAL", raising=False)
+    t0, d0 = engine.transform_modes(t, data, 2, ell_max, -2, -1, engine.BMS_TERM_H, tr, ctx=ctx)
+    monkeypatch.setenv("SCRI_AMD_SYNTHESIS_EVAL", "1")
+    scale = np.abs(d0).max()
+    assert np.array_equal(t0, t1) and np.abs(d1 - d0).max() < 3e-13 * scale
+    small = scri_amd.Context(0, workspace_limit=48 << 20)  # ~ 8 chunks
+    t2, d2 = engine.transform_modes(t, data, 2, ell_max, -2, -1, engine.BMS_TERM_H, tr, ctx=small)
+    assert np.array_equal(t2, t1) and np.abs(d2 - d1).max() < 1e-14 * scale
+    have, need, window = sharding.plan(t, tr, 4)
+    parts = []
+    for r in range(4):
+        ext = data[need[r][0] : need[r][1]]
+        parts.append(np.array(engine.transform_modes(t, ext, 2, ell_max, -2, -1, engine.BMS_TERM_H, tr, ctx=small,
+                                                     shard=(need[r][0], ext.shape[0], have[r][0], have[r][1]))[1]))
+    small.close()
+    assert np.abs(np.concatenate(parts) - d1).max() < 1e-14 * scale
+    # from_modes on its own: the grid of samples in grid order, new route against old
+    tg, g1 = engine.transform_modes(t[:1200], data[:1200], 2, ell_max, -2, -1, engine.BMS_TERM_H, tr, ctx=ctx, grid=True)
+    g1 = np.array(g1)
+    monkeypatch.delenv("SCRI_AMD_SYNTHESIS_EVAL", raising=False)
+    tg0, g0 = engine.transform_modes(t[:1200], data[:1200], 2, ell_max, -2, -1, engine.BMS_TERM_H, tr, ctx=ctx, grid=True)
+    assert np.array_equal(tg, tg0) and g1.shape == g0.shape and np.abs(g1 - g0).max() < 3e-13 * max(1.0, np.abs(g0).max())

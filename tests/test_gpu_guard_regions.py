@@ -45,7 +45,8 @@ WM_CASES = {
     "boosted, two sweeps on the modes": dict(boost=[1e-3, 2e-3, -3e-3], rot=[0.9, 0.1, -0.3, 0.2], env={"SCRI_AMD_TWO_SWEEPS": "1"}),
     "boosted, back substitution on the grid": dict(boost=[1e-3, 2e-3, -3e-3], rot=[0.9, 0.1, -0.3, 0.2], env={"SCRI_AMD_NO_GEMM_EVAL": "1"}),
     "strongly boosted (samples far from their knots: global-memory march)": dict(boost=[0.1, -0.2, 0.15], rot=[0.9, 0.1, -0.3, 0.2], env={}),
-    "boost-free (one-kernel separable synthesis)": dict(boost=[0, 0, 0], rot=[0.9, 0.1, -0.3, 0.2], env={"SCRI_AMD_NO_SMALL_DENSE": "1"}),
+    "boost-free (one-kernel separable synthesis with the spline evaluation in it)": dict(boost=[0, 0, 0], rot=[0.9, 0.1, -0.3, 0.2], env={"SCRI_AMD_NO_SMALL_DENSE": "1", "SCRI_AMD_SYNTHESIS_EVAL": "1"}),
+    "boost-free (one-kernel separable synthesis, back substitution on the grid)": dict(boost=[0, 0, 0], rot=[0.9, 0.1, -0.3, 0.2], env={"SCRI_AMD_NO_SMALL_DENSE": "1"}),
     "boost-free, two-kernel form": dict(boost=[0, 0, 0], rot=[1.0, 0, 0, 0], env={"SCRI_AMD_NO_SPLIT_SYNTHESIS": "1", "SCRI_AMD_NO_SMALL_DENSE": "1"}),
     "boost-free, small shapes on the evaluating product": dict(boost=[0, 0, 0], rot=[0.9, 0.1, -0.3, 0.2], env={}),
     "axis boost (one-kernel form with the scale)": dict(boost=[0, 0, 0.2], rot=_zrot(0.4), env={"SCRI_AMD_AXIS_BOOST_MIN_WORK": "0"}),
@@ -63,7 +64,7 @@ def test_transform_modes_between_guards(ctx, monkeypatch, case, ell_max, n):
     spec = WM_CASES[case]
     for k in ("SCRI_AMD_NO_SEPARABLE_SYNTHESIS", "SCRI_AMD_NO_SPLIT_SYNTHESIS", "SCRI_AMD_AXIS_BOOST_MIN_WORK", "SCRI_AMD_NO_BSPLINE",
               "SCRI_AMD_NO_SPLIT_ANALYSIS", "SCRI_AMD_NO_AXIS_BOOST_SEPARABLE", "SCRI_AMD_GEMM_EVAL_STEP", "SCRI_AMD_TWO_SWEEPS", "SCRI_AMD_NO_GEMM_EVAL",
-              "SCRI_AMD_NO_SMALL_DENSE"):
+              "SCRI_AMD_NO_SMALL_DENSE", "SCRI_AMD_SYNTHESIS_EVAL"):
         monkeypatch.delenv(k, raising=False)
     for k, v in spec["env"].items():
         monkeypatch.setenv(k, v)
