@@ -64,9 +64,10 @@ int bms_ctx_use_default_stream(bms_ctx* ctx);
 /* cap on the grid work space in bytes (time axis is processed in chunks that fit); 0 = default: min(96 GB, a third of the device
  * memory that is free at the time).  With the default a call that runs out of device memory halves the cap and tries again. */
 int bms_ctx_set_workspace_limit(bms_ctx* ctx, uint64_t bytes);
-/* Warm-up for short-lived callers: allocates, writes once and releases `bytes` of device memory (0: the work-space cap), so that the
- * first full-size call of the process finds memory the driver has already mapped (fresh memory costs 40 - 80 ms per GB on this
- * platform: the first device-resident map_to_superrest_frame of a process took 2.45 s, the second 0.92 s).  No reference counterpart. */
+/* For short-lived callers: ONE device allocation of `bytes` (0: the work-space cap plus an eighth) from which the context carves
+ * its work-space buffers afterwards, so that the first full-size call of the process allocates nothing (device allocations cost
+ * 70 - 120 ms per GB on this platform: the first device-resident map_to_superrest_frame of a process took 2.45 - 3.3 s, the second
+ * 0.92 s).  May be called again to add room.  No reference counterpart. */
 int bms_ctx_reserve(bms_ctx* ctx, uint64_t bytes);
 /* Diagnostics of the evaluating product (the dense route's synthesis + spline evaluation): out[0] = tiles launched since the last
  * reset, out[1] = tiles whose samples left the window of output times staged in LDS (non-uniform time axes, strong boosts: same

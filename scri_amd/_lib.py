@@ -401,8 +401,8 @@ class Context:
         return tuple(int(v) for v in out)
 
     def reserve(self, nbytes=0):
-        """Warm-up: have the driver map `nbytes` of device memory (0: the work-space cap) now, so that the first full-size call of the
-        process costs what the second does (bms_ctx_reserve)."""
+        """One device allocation of `nbytes` (0: the work-space cap plus an eighth) that the context's work-space buffers are carved from
+        afterwards: the first full-size call of the process then allocates nothing (bms_ctx_reserve)."""
         self.check(load().bms_ctx_reserve(self._h, int(nbytes)), "bms_ctx_reserve")
 
     def enable_timing(self, on=True):

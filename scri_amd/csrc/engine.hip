@@ -32,6 +32,39 @@ using namespace bms;
 struct DevBuf {
   void* p = nullptr;
   size_t cap = 0;
+  int slab = -1;  // >= 0: carved from that reserved slab (bms_ctx_reserve) at offset `slab_off`, not an allocation of its own
+  size_t slab_off = 0;
+};
+struct Slab {  // one device allocation that the named work-space buffers are carved from (first fit, free regions coalesced)
+  char* base = nullptr;
+  size_t cap = 0;
+  std::map<size_t, size_t> free;  // offset -> length
+  bool take(size_t want, size_t* off) {
+    for (auto it = free.begin(); it != free.end(); ++it)
+      if (it->second >= want) {
+        *off = it->first;
+        const size_t rest = it->second - want;
+        free.erase(it);
+        if (rest) free[*off + want] = rest;
+        return true;
+      }
+    return false;
+  }
+  void give(size_t off, size_t len) {
+    auto nx = free.lower_bound(off);
+    if (nx != free.end() && off + len == nx->first) {
+      len += nx->second;
+      nx = free.erase(nx);
+    }
+    if (nx != free.begin()) {
+      auto pv = std::prev(nx);
+      if (pv->first + pv->second == off) {
+        pv->second += len;
+        return;
+      }
+    }
+    free[off] = len;
+  }
 };
 
 // ---------------------------------------------------------------------------------------------- analysis plan
@@ -81,6 +114,7 @@ struct bms_ctx {
   uint64_t eval_tiles = 0;                     // tiles + boundary blocks launched since the last reset
   bool alloc_failed = false;  // a device allocation of the running call failed (as opposed to a cap that is too small by plan)
   std::map<std::string, DevBuf> bufs;  // grow-only named work space
+  std::vector<Slab> slabs;             // reserved by bms_ctx_reserve; the newest one with room serves the named buffers
   int delta_lmax = -1;                 // Delta tables cached up to this l
   int delta_mfma_lmax = -1;            // ... in the MFMA B-image packing
   hipStream_t pipe_up = nullptr, pipe_down = nullptr;  // bms_transform_modes_pipelined: uploads and downloads beside the kernels
@@ -252,16 +286,34 @@ static hipError_t create_download_stream(bms_ctx* c) {
 static int dev_buf(bms_ctx* c, const char* name, size_t bytes, void** out) {
   DevBuf& b = c->bufs[name];
   if (b.cap < bytes) {
+    size_t want = bytes + bytes / 16 + 4096;
+    want = (want + 255) & ~(size_t)255;
     if (b.p) {
+      // the old block goes back (to its slab or to the runtime): nothing queued may still use it
       HIP_TRY(c, hipStreamSynchronize(c->stream));
+      if (c->aux) HIP_TRY(c, hipStreamSynchronize(c->aux));
       // (a pipelined call's uploads and downloads run on their own streams and may still use the old block)
       if (c->pipe_up) HIP_TRY(c, hipStreamSynchronize(c->pipe_up));
       if (c->pipe_down) HIP_TRY(c, hipStreamSynchronize(c->pipe_down));
-      HIP_TRY(c, hipFree(b.p));
+      if (b.slab >= 0)
+        c->slabs[b.slab].give(b.slab_off, b.cap);
+      else
+        HIP_TRY(c, hipFree(b.p));
       b.p = nullptr;
       b.cap = 0;
+      b.slab = -1;
     }
-    size_t want = bytes + bytes / 16 + 4096;
+    // from a reserved slab if one has room (bms_ctx_reserve): no allocation
+    for (int i = (int)c->slabs.size() - 1; i >= 0; --i) {
+      size_t off;
+      if (c->slabs[i].take(want, &off)) {
+        b.p = c->slabs[i].base + off;
+        b.cap = want;
+        b.slab = i, b.slab_off = off;
+        *out = b.p;
+        return BMS_OK;
+      }
+    }
     const auto t_a = std::chrono::steady_clock::now();
     hipError_t e = hipMalloc(&b.p, want);
     if (route_env("SCRI_AMD_TRACE"))
@@ -360,7 +412,8 @@ extern "C" void bms_ctx_destroy(bms_ctx* c) {
   (void)hipSetDevice(c->device);
   (void)hipStreamSynchronize(c->stream);
   for (auto& kv : c->bufs)
-    if (kv.second.p) (void)hipFree(kv.second.p);
+    if (kv.second.p && kv.second.slab < 0) (void)hipFree(kv.second.p);
+  for (auto& sl : c->slabs) (void)hipFree(sl.base);
   if (c->d_eval_stats) (void)hipFree(c->d_eval_stats);
   for (auto& t : c->timed) {
     (void)hipEventDestroy(t.a);
@@ -443,43 +496,28 @@ extern "C" int bms_ctx_set_workspace_limit(bms_ctx* c, uint64_t bytes) {
   return BMS_OK;
 }
 
-// The first device allocations of a process are slow on this platform (the driver maps fresh memory at 40 - 80 ms per GB; memory a
-// process has held before comes back in under a millisecond: tools/probes/alloc_rate_probe.py), so the first full-size call of a
-// process pays seconds for its work space.  bms_ctx_reserve takes that cost up front: `bytes` of device memory (0: the work space cap
-// of the context) are allocated in blocks that are held together, written once and released again.
+// Device allocations are slow on this platform -- 70 to 120 ms per GB for the tens of GB a full-size call needs (measured inside the first
+// device-resident map_to_superrest_frame of a process: 'R' grows to 22.8 GB: 2 657 ms, to 32.1 GB: 2 342 ms), and memory a process has
+// merely held before does not come back faster (a throw-away allocation of the whole cap up front changed nothing:
+// profiles/r05_a_superrest_reserve_*).  bms_ctx_reserve therefore takes ONE allocation of `bytes` (0: the work-space cap plus an eighth)
+// that the context's named work-space buffers are carved from afterwards: the first full-size call of the process then allocates
+// nothing.  A buffer that outgrows its region gives it back to the slab and takes a larger one (first fit, neighbours coalesced: the
+// last buffer grows in place); without room it falls back to an allocation of its own.  Further calls add slabs.
 extern "C" int bms_ctx_reserve(bms_ctx* c, uint64_t bytes) {
   if (!c) return BMS_ERR_INVALID;
   HIP_TRY(c, hipSetDevice(c->device));
-  if (!bytes) bytes = c->ws_limit;
-  // the largest blocks first (a later allocation larger than anything the process has held before is slow again, whatever the
-  // total: tools/probes/alloc_rate_probe.py), halving the block when the device refuses it
-  uint64_t block = bytes;
-  std::vector<void*> held;
-  uint64_t got = 0;
-  hipError_t e = hipSuccess;
-  while (got < bytes) {
-    const uint64_t want = std::min<uint64_t>(block, bytes - got);
-    void* p = nullptr;
-    if ((e = hipMalloc(&p, want)) != hipSuccess) {
-      (void)hipGetLastError();
-      if (e == hipErrorOutOfMemory && block > (1ull << 30)) {
-        block /= 2;
-        e = hipSuccess;
-        continue;
-      }
-      break;
-    }
-    held.push_back(p);
-    if ((e = hipMemsetAsync(p, 0, want, c->stream)) != hipSuccess) break;
-    got += want;
-  }
-  (void)hipStreamSynchronize(c->stream);
-  for (void* p : held) (void)hipFree(p);
+  if (!bytes) bytes = c->ws_limit + c->ws_limit / 8;
+  Slab sl;
+  void* p = nullptr;
+  hipError_t e = hipMalloc(&p, bytes);
   if (e != hipSuccess) {
     (void)hipGetLastError();
-    return fail(c, e == hipErrorOutOfMemory ? BMS_ERR_NOMEM : BMS_ERR_HIP, "bms_ctx_reserve: %llu of %llu bytes reserved, then: %s",
-                (unsigned long long)got, (unsigned long long)bytes, hipGetErrorString(e));
+    return fail(c, e == hipErrorOutOfMemory ? BMS_ERR_NOMEM : BMS_ERR_HIP, "bms_ctx_reserve: hipMalloc of %llu bytes failed: %s",
+                (unsigned long long)bytes, hipGetErrorString(e));
   }
+  sl.base = (char*)p, sl.cap = bytes;
+  sl.free[0] = bytes;
+  c->slabs.push_back(sl);
   return BMS_OK;
 }
 

@@ -650,3 +650,30 @@ def test_synthesis_with_the_evaluation_in_it_chunks_shards_and_grid_output(ctx, 
     monkeypatch.delenv("SCRI_AMD_SYNTHESIS_EVAL", raising=False)
     tg0, g0 = engine.transform_modes(t[:1200], data[:1200], 2, ell_max, -2, -1, engine.BMS_TERM_H, tr, ctx=ctx, grid=True)
     assert np.array_equal(tg, tg0) and g1.shape == g0.shape and np.abs(g1 - g0).max() < 3e-13 * max(1.0, np.abs(g0).max())
+
+
+def test_reserved_slab_serves_the_work_space(ctx):
+    """Context.reserve (bms_ctx_reserve): one allocation up front from which the named work-space buffers are carved -- same results
+    as a context that allocates on demand; a slab that is too small leaves the larger buffers to allocations of their own; a second
+    reserve adds room."""
+    import scri_amd
+
+    w = _wm(np.linspace(-30.0, 45.0, 2500), 10, 5)
+    kw = dict(supertranslation=np.array([0.0, 0.02, 0.01 + 0.01j, -0.02, 0.005, 0, 0.01, 0, 0.005]),
+              frame_rotation=np.array([0.9, 0.1, -0.3, 0.2]) / np.linalg.norm([0.9, 0.1, -0.3, 0.2]), boost_velocity=np.array([1e-3, -2e-3, 1.5e-3]))
+    kw["supertranslation"] = kw["supertranslation"].astype(complex)
+    from scri_amd import synthetic
+
+    kw["supertranslation"] = synthetic.real_supertranslation(kw["supertranslation"])
+    ref = _gpu(w, ctx).transform(**kw)
+    for nbytes in (1 << 30, 4 << 20):  # roomy; too small for the grids (they fall back to their own allocations)
+        c2 = scri_amd.Context(0)
+        c2.reserve(nbytes)
+        got = _gpu(w, c2).transform(**kw)
+        assert np.array_equal(got.t, ref.t) and np.array_equal(got.data, ref.data)
+        c2.reserve(256 << 20)  # a second slab: later growth is served from it
+        w2 = _wm(np.linspace(-30.0, 45.0, 5200), 10, 5)
+        got2 = _gpu(w2, c2).transform(**kw)
+        ref2 = _gpu(w2, ctx).transform(**kw)
+        assert np.array_equal(got2.data, ref2.data)
+        c2.close()

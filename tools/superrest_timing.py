@@ -17,7 +17,7 @@ ctx = scri_amd.Context(0)
 if reserve:
     t0 = time.perf_counter()
     ctx.reserve()
-    print(f"Context.reserve(): {time.perf_counter() - t0:.2f} s (once per process; the driver maps the work space here instead of inside the first call)")
+    print(f"Context.reserve(): {time.perf_counter() - t0:.2f} s (once per process: one allocation that the work-space buffers are carved from)")
 u = np.linspace(-1000, 1000, num=n)
 a = scri_amd.AsymptoticBondiData(u, ell_max, ctx=ctx)
 a._raw_data[:] = kerr_schild_abd(2.0, 0.456, ell_max, u)
