@@ -3382,6 +3382,19 @@ static int transform_abd_impl(bms_ctx* c, const double* u, const void* raw, int 
     return BMS_OK;
   }
 
+  // sigma' = (sigma - eth eth alpha) / k mixes with nothing and its offset and scale do not depend on time: it takes the evaluating
+  // product of the WaveformModes route (its spline solved on the modes, evaluated in the product's epilogue, kernels_gemm_eval.hip) and
+  // stays out of the mixing + elimination pass and of the back substitution -- two of the four passes over its grid
+  const bool sigma_eval = !sep && bsg && !short_series && rows_avail >= 8 && !route_env("SCRI_AMD_NO_ABD_SIGMA_EVAL");
+  double* d_As = nullptr;
+  if (sigma_eval) {
+    if ((rc = dev_buf_t(c, "abd_As", (size_t)rows_avail * ld_af, &d_As))) return rc;
+    TIMED(c, BMS_TAG_SPLINE_FORWARD, launch_bspline_solve_modes(S, d_raw + (size_t)5 * rows_avail * nm * 2, 2LL * nm, nm, d_As, ld_af, row0, rows_avail,
+                                                                d_bsfwd, d_bstab, 1));
+    // row nm of the spin-2 harmonics (psi0 shares them and stops at row nm - 1) multiplies the solved constant series: -eth eth alpha
+    TIMED(c, BMS_TAG_SETUP, launch_negated_row(S, DP.ethetha, d_B[4] + (size_t)nm * ldb, 2 * n_cols));
+  }
+
   // ---- chunk loop: 6 fields x (Y, R, G)
   const BsplineSpread spread = skew_spread(T, cA, cB, u);
   const int margin = SPLINE_HALO + 2;
@@ -3428,6 +3441,7 @@ static int transform_abd_impl(bms_ctx* c, const double* u, const void* raw, int 
     }
     for (int f = 0; f < 6 && !fused_mix; ++f) {
       grids.y[f] = d_Y + (size_t)f * rows_in * ldg;
+      if (f == 5 && sigma_eval) continue;  // (straight to its samples, below)
       if (sep) {
         if ((rc = run_synthesis(c, syn5[spins[f] + 2], d_raw + ((size_t)f * rows_avail + (g0 - row0)) * nm * 2, 2LL * nm, rows_in, nullptr, grids.y[f], ldg)))
           return rc;
@@ -3447,7 +3461,7 @@ static int transform_abd_impl(bms_ctx* c, const double* u, const void* raw, int 
       AbdGrids elim;
       for (int f = 0; f < 6; ++f) elim.y[f] = d_R + (size_t)f * rows_in * ldg;
       TIMED(c, BMS_TAG_SPLINE_FORWARD, launch_abd_mix_forward(S, grids, elim, ldg, n_pix, g0, rows_in, d_bsfwd, SPLINE_TILE, SPLINE_HALO, d_alpha, d_ethk,
-                                                              d_etha, d_ethetha, d_ik, d_ik3));
+                                                              d_etha, d_ethetha, d_ik, d_ik3, sigma_eval ? 5 : 6));
     } else {
       TIMED(c, BMS_TAG_POINTWISE,
             launch_abd_mix(S, grids, ldg, n_pix, rows_in, d_x + g0, d_alpha, d_ethk, d_etha, d_ethetha, d_ik, d_ik3));
@@ -3457,6 +3471,17 @@ static int transform_abd_impl(bms_ctx* c, const double* u, const void* raw, int 
       double* Gf = d_G + (size_t)f * rows_out * ldG;
       if (short_series) {
         TIMED(c, BMS_TAG_SPLINE_BACKWARD, launch_short_series_eval(S, grids.y[f], ldg, n_pix, (int)n, d_x, d_x, d_skewa, d_skewb, T.tt, c0, c1_, Gf, ldG));
+      } else if (f == 5 && sigma_eval) {
+        SplineEval ev;
+        ev.table = d_bstab, ev.x = d_x, ev.skew_a = d_skewa, ev.skew_b = d_skewb, ev.tt = T.tt, ev.g0 = g0, ev.n_knots = n;
+        ev.i_lo = c0, ev.i_hi = c1_, ev.out = Gf, ev.ldo = ldG;
+        ev.search_halfwidth = eval_search_halfwidth(T, cA, cB, u, g0, g1);
+        ev.inv_dx = (g1 - g0 >= 2 && u[g1 - 1] > u[g0]) ? (double)(g1 - 1 - g0) / (u[g1 - 1] - u[g0]) : 0.0;
+        ev.side = nullptr, ev.side_ld = ldg, ev.stats = nullptr;
+        if ((rc = dev_buf_t(c, "Cside", (size_t)zgemm3m_eval_side_rows(rows_in) * ldg, &ev.side))) return rc;
+        const int skip = 4 < nm ? 4 : 0;  // (spin 2: no modes below l = 2)
+        TIMED(c, BMS_TAG_GEMM_SYNTHESIS, launch_zgemm3m_eval(S, d_As + (g0 - row0) * ld_af + 2 * skip, ld_af, d_B[4] + 2 * cA + (size_t)skip * ldb, ldb, rows_in,
+                                                             n_pix, nm - skip + 1, DP.col_scale + 2 * cA, ev));
       } else if (bsg) {
         TIMED(c, BMS_TAG_SPLINE_BACKWARD, launch_bspline_backward_eval(S, Rf, ldg, n_pix, g0, rows_in, n, d_x, d_bstab, SPLINE_TILE, SPLINE_HALO,
                                                                        d_x, d_skewa, d_skewb, T.tt, c0, c1_, Gf, ldG, &spread));

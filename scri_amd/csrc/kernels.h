@@ -264,7 +264,7 @@ struct AbdGrids;
 hipError_t launch_abd_mix_forward(hipStream_t stream, const AbdGrids& Y, const AbdGrids& R, long long ld, int n_cols, long long g0,
                                   long long n_rows, const BsplineForward* table, int tile, int halo, const double* alpha,
                                   const double* ethk_over_k, const double* eth_alpha, const double* etheth_alpha,
-                                  const double* inv_k, const double* inv_k3);
+                                  const double* inv_k, const double* inv_k3, int n_fields = 6 /* 5: without sigma */);
 // B[row][0 .. 2 n_cols) = -off[0 .. 2 n_cols): the synthesis-matrix row that multiplies the constant column
 hipError_t launch_negated_row(hipStream_t stream, const double* off, double* row, int n);
 // back substitution + evaluation (arguments as launch_spline_backward_eval, C = eliminated grid coefficients)

@@ -382,6 +382,8 @@ hipError_t launch_bspline_solve_modes(hipStream_t stream, const double* A, long 
 // The Horner mixing of the six AsymptoticBondiData fields (kernels_swsh.hip, abd_mix_kernel; transformations.py:340-385)
 // has time-dependent coefficients, so the elimination cannot move onto the modes -- but the two grid passes can be one:
 // read the six synthesised fields once, mix in registers, run the six recurrences, write the six eliminated fields.
+// NF = 6: psi0 .. psi4 and sigma; NF = 5: sigma stays out (it mixes with nothing and takes the evaluating product: engine.hip)
+template <int NF>
 __global__ __launch_bounds__(64) void abd_mix_forward_kernel(AbdGrids Yg, AbdGrids Rg, long long ld, int n_cols, long long g0,
                                                              long long n_rows, const BsplineForward* __restrict__ table, int tile,
                                                              int halo, const double* __restrict__ alpha,
@@ -404,12 +406,12 @@ __global__ __launch_bounds__(64) void abd_mix_forward_kernel(AbdGrids Yg, AbdGri
   asm volatile("v_mov_b32 %0, 0" : "=v"(opaque_zero));
   const BsplineForward* tv = table + opaque_zero;  // row factors as vector loads, requested with the data
   const long long col = 2LL * p - g0 * ld;
-  double2 c1[6], c2[6];
+  double2 c1[NF], c2[NF];
 #pragma unroll
-  for (int f = 0; f < 6; ++f) c1[f] = c2[f] = double2{0.0, 0.0};
+  for (int f = 0; f < NF; ++f) c1[f] = c2[f] = double2{0.0, 0.0};
   auto load = [&](long long j, double2* y, double2& pa, double2& ex) {
 #pragma unroll
-    for (int f = 0; f < 6; ++f) y[f] = *reinterpret_cast<const double2*>(Yg.y[f] + col + j * ld);
+    for (int f = 0; f < NF; ++f) y[f] = *reinterpret_cast<const double2*>(Yg.y[f] + col + j * ld);
     pa = *reinterpret_cast<const double2*>(&tv[j].P);
     ex = *reinterpret_cast<const double2*>(&tv[j].E);  // (E, x_j)
   };
@@ -417,8 +419,9 @@ __global__ __launch_bounds__(64) void abd_mix_forward_kernel(AbdGrids Yg, AbdGri
     const double dt = ex.y - al;
     const cplx X = {A.re * dt - B.re, A.im * dt - B.im};
     cplx f[6];
+    f[5] = {0.0, 0.0};
 #pragma unroll
-    for (int i = 0; i < 6; ++i) f[i] = {y[i].x, y[i].y};
+    for (int i = 0; i < NF; ++i) f[i] = {y[i].x, y[i].y};
     auto axpy = [](cplx t, cplx X, double c, cplx f) {  // t*X + c*f
       cplx r = cmul(t, X);
       return cplx{r.re + c * f.re, r.im + c * f.im};
@@ -441,7 +444,7 @@ __global__ __launch_bounds__(64) void abd_mix_forward_kernel(AbdGrids Yg, AbdGri
                            {t3.re * ik3, t3.im * ik3}, {f[4].re * ik3, f[4].im * ik3},
                            {(f[5].re - EE.re) * ik, (f[5].im - EE.im) * ik}};
 #pragma unroll
-    for (int i = 0; i < 6; ++i) {
+    for (int i = 0; i < NF; ++i) {
       double2 c0;
       c0.x = pa.x * mixed[i].re - pa.y * c1[i].x - ex.x * c2[i].x;
       c0.y = pa.x * mixed[i].im - pa.y * c1[i].y - ex.x * c2[i].y;
@@ -452,14 +455,14 @@ __global__ __launch_bounds__(64) void abd_mix_forward_kernel(AbdGrids Yg, AbdGri
   };
   long long j = jS;
   for (; j + 2 <= jB; j += 2) {
-    double2 y0[6], y1[6], pa0, pa1, ex0, ex1;
+    double2 y0[NF], y1[NF], pa0, pa1, ex0, ex1;
     load(j, y0, pa0, ex0);
     load(j + 1, y1, pa1, ex1);
     step(j, y0, pa0, ex0);
     step(j + 1, y1, pa1, ex1);
   }
   for (; j < jB; ++j) {
-    double2 y0[6], pa0, ex0;
+    double2 y0[NF], pa0, ex0;
     load(j, y0, pa0, ex0);
     step(j, y0, pa0, ex0);
   }
@@ -468,13 +471,17 @@ __global__ __launch_bounds__(64) void abd_mix_forward_kernel(AbdGrids Yg, AbdGri
 hipError_t launch_abd_mix_forward(hipStream_t stream, const AbdGrids& Y, const AbdGrids& R, long long ld, int n_cols, long long g0,
                                   long long n_rows, const BsplineForward* table, int tile, int halo, const double* alpha,
                                   const double* ethk_over_k, const double* eth_alpha, const double* etheth_alpha,
-                                  const double* inv_k, const double* inv_k3) {
+                                  const double* inv_k, const double* inv_k3, int n_fields) {
   if (n_rows <= 0 || n_cols <= 0) return hipSuccess;
   const long long n_tiles = (n_rows + tile - 1) / tile;
   if (n_tiles > GRID_Y_MAX) return hipErrorInvalidValue;
   dim3 grid((n_cols + 63) / 64, (unsigned)n_tiles);
-  hipLaunchKernelGGL(abd_mix_forward_kernel, grid, dim3(64), 0, stream, Y, R, ld, n_cols, g0, n_rows, table, tile, halo, alpha,
-                     ethk_over_k, eth_alpha, etheth_alpha, inv_k, inv_k3);
+  if (n_fields == 5)
+    hipLaunchKernelGGL(abd_mix_forward_kernel<5>, grid, dim3(64), 0, stream, Y, R, ld, n_cols, g0, n_rows, table, tile, halo, alpha,
+                       ethk_over_k, eth_alpha, etheth_alpha, inv_k, inv_k3);
+  else
+    hipLaunchKernelGGL(abd_mix_forward_kernel<6>, grid, dim3(64), 0, stream, Y, R, ld, n_cols, g0, n_rows, table, tile, halo, alpha,
+                       ethk_over_k, eth_alpha, etheth_alpha, inv_k, inv_k3);
   return hipGetLastError();
 }
 

@@ -163,6 +163,8 @@ BMS_HD void pixel_tables_one(const PixelSpec& P, const PixelOut& O, int p, int p
     const double one_over_k = P.gamma * (1 - vr);
     O.ik[p] = one_over_k;
     O.ik3[p] = one_over_k * one_over_k * one_over_k;
+    // sigma' = (sigma - eth eth alpha) / k as a per-column scale of the evaluating product (kernels_gemm_eval.hip)
+    if (O.col_scale) O.col_scale[2 * p] = one_over_k, O.col_scale[2 * p + 1] = one_over_k;
   }
 }
 

@@ -44,7 +44,7 @@ ROUTE_SWITCHES = {
     "SCRI_AMD_NO_BSPLINE", "SCRI_AMD_NO_COLUMN_SORT", "SCRI_AMD_NO_FUSED_ABD_MIX", "SCRI_AMD_NO_FUSED_ANALYSIS", "SCRI_AMD_NO_GEMM_EVAL",
     "SCRI_AMD_NO_LARGE_ANALYSIS", "SCRI_AMD_NO_LARGE_SYNTHESIS", "SCRI_AMD_NO_PLAN_CACHE", "SCRI_AMD_NO_SEPARABLE_SYNTHESIS",
     "SCRI_AMD_NO_SMALL_DENSE", "SCRI_AMD_NO_SPLIT_ANALYSIS", "SCRI_AMD_NO_SPLIT_SYNTHESIS", "SCRI_AMD_ROTATE_STAGED", "SCRI_AMD_ROTATE_VALU",
-    "SCRI_AMD_TRACE", "SCRI_AMD_TWO_SWEEPS", "SCRI_AMD_WALK_FIRST", "SCRI_AMD_SYNTHESIS_EVAL",
+    "SCRI_AMD_TRACE", "SCRI_AMD_TWO_SWEEPS", "SCRI_AMD_WALK_FIRST", "SCRI_AMD_SYNTHESIS_EVAL", "SCRI_AMD_NO_ABD_SIGMA_EVAL",
 }
 
 
