@@ -306,20 +306,36 @@ def boost_free_line(local, t_global, kw, n_theta, ell_max, ctx):
         return engine.transform_modes(t_global, local.data_ptr(), 2, ell_max, -2, -1, engine.BMS_TERM_H, tr, ctx=ctx, device=True,
                                       ld=nm, out_ptr=out.data_ptr())[1]
 
-    for _ in range(3):
-        go()
-    ctx.synchronize()
-    ctx.get_timing(reset=True)
     reps = 10
-    t0 = time.perf_counter()
-    for _ in range(reps):
-        n_new = go()
-    ctx.synchronize()
-    wall = (time.perf_counter() - t0) / reps
-    tm = ctx.get_timing(reset=True)
+
+    def measure():
+        for _ in range(3):
+            go()
+        ctx.synchronize()
+        ctx.get_timing(reset=True)
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            n = go()
+        ctx.synchronize()
+        return (time.perf_counter() - t0) / reps, ctx.get_timing(reset=True), n
+
+    wall, tm, n_new = measure()
+    # the same through synthesis_eval_kernel (round 5: the spline evaluated inside the separable synthesis, no pass over a grid of
+    # coefficients; opt-in because it is not faster -- DESIGN.md 4.0 (xxiii)): reported beside the default so that the choice can be checked
+    fused = None
+    if not os.environ.get("SCRI_AMD_SYNTHESIS_EVAL"):
+        os.environ["SCRI_AMD_SYNTHESIS_EVAL"] = "1"
+        try:
+            wall_f, tm_f, _ = measure()
+            fused = {"ms_per_step": wall_f * 1e3, "kernels": {k: v[0] / reps for k, v in tm_f.items() if v[1]},
+                     "route": "SCRI_AMD_SYNTHESIS_EVAL=1: bspline_solve_modes_kernel + synthesis_eval_kernel (gemm_synthesis) instead of elimination + "
+                              "synthesis_split_kernel + bspline_backward_eval_kernel"}
+        finally:
+            del os.environ["SCRI_AMD_SYNTHESIS_EVAL"]
     ms = tm["gemm_synthesis"][0] / max(tm["gemm_synthesis"][1], 1)
     bytes_per_step = 16 * (nm + 1 + n_theta * n_theta)
     return {
+        "fused_route": fused,
         "metric": "timesteps/s, transformation without a boost (supertranslation + frame rotation), separable synthesis",
         "value": n / wall,
         "ms_per_step": wall * 1e3,

@@ -64,7 +64,7 @@ int bms_ctx_use_default_stream(bms_ctx* ctx);
 /* cap on the grid work space in bytes (time axis is processed in chunks that fit); 0 = default: min(96 GB, a third of the device
  * memory that is free at the time).  With the default a call that runs out of device memory halves the cap and tries again. */
 int bms_ctx_set_workspace_limit(bms_ctx* ctx, uint64_t bytes);
-/* For short-lived callers: ONE device allocation of `bytes` (0: the work-space cap plus an eighth) from which the context carves
+/* For short-lived callers: ONE device allocation of `bytes` (0: one and a half times the work-space cap) from which the context carves
  * its work-space buffers afterwards, so that the first full-size call of the process allocates nothing (device allocations cost
  * 70 - 120 ms per GB on this platform: the first device-resident map_to_superrest_frame of a process took 2.45 - 3.3 s, the second
  * 0.92 s).  May be called again to add room.  No reference counterpart. */

@@ -401,7 +401,7 @@ class Context:
         return tuple(int(v) for v in out)
 
     def reserve(self, nbytes=0):
-        """One device allocation of `nbytes` (0: the work-space cap plus an eighth) that the context's work-space buffers are carved from
+        """One device allocation of `nbytes` (0: one and a half times the work-space cap) that the context's work-space buffers are carved from
         afterwards: the first full-size call of the process then allocates nothing (bms_ctx_reserve)."""
         self.check(load().bms_ctx_reserve(self._h, int(nbytes)), "bms_ctx_reserve")
 

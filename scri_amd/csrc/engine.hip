@@ -311,6 +311,8 @@ static int dev_buf(bms_ctx* c, const char* name, size_t bytes, void** out) {
         b.cap = want;
         b.slab = i, b.slab_off = off;
         *out = b.p;
+        if (route_env("SCRI_AMD_TRACE"))
+          fprintf(stderr, "[scri_amd] work space '%s' grows to %.3f GB: from slab %d at %.3f GB\n", name, want / 1073741824.0, i, off / 1073741824.0);
         return BMS_OK;
       }
     }
@@ -499,14 +501,22 @@ extern "C" int bms_ctx_set_workspace_limit(bms_ctx* c, uint64_t bytes) {
 // Device allocations are slow on this platform -- 70 to 120 ms per GB for the tens of GB a full-size call needs (measured inside the first
 // device-resident map_to_superrest_frame of a process: 'R' grows to 22.8 GB: 2 657 ms, to 32.1 GB: 2 342 ms), and memory a process has
 // merely held before does not come back faster (a throw-away allocation of the whole cap up front changed nothing:
-// profiles/r05_a_superrest_reserve_*).  bms_ctx_reserve therefore takes ONE allocation of `bytes` (0: the work-space cap plus an eighth)
+// profiles/r05_a_superrest_reserve_*).  bms_ctx_reserve therefore takes ONE allocation of `bytes` (0: one and a half times the work-space cap)
 // that the context's named work-space buffers are carved from afterwards: the first full-size call of the process then allocates
 // nothing.  A buffer that outgrows its region gives it back to the slab and takes a larger one (first fit, neighbours coalesced: the
 // last buffer grows in place); without room it falls back to an allocation of its own.  Further calls add slabs.
 extern "C" int bms_ctx_reserve(bms_ctx* c, uint64_t bytes) {
   if (!c) return BMS_ERR_INVALID;
   HIP_TRY(c, hipSetDevice(c->device));
-  if (!bytes) bytes = c->ws_limit + c->ws_limit / 8;
+  if (!bytes) {
+    // the chunk grids may take the whole cap; tables, staging copies and the F arrays of the separable routes come on top, and a buffer
+    // that grows needs its new region while its neighbours still hold theirs (the device-resident map_to_superrest_frame at 1e5 steps,
+    // l <= 12: 115 GB in all for a 96 GB cap): half as much again, within four fifths of what is free now
+    bytes = c->ws_limit + c->ws_limit / 2;
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b > 0) bytes = std::min<uint64_t>(bytes, (uint64_t)free_b / 5 * 4);
+    (void)hipGetLastError();
+  }
   Slab sl;
   void* p = nullptr;
   hipError_t e = hipMalloc(&p, bytes);

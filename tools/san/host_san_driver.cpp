@@ -189,6 +189,52 @@ void frame_integration() {
   }
 }
 
+
+// The slab the named work-space buffers are carved from (bms_ctx_reserve): random grow / release sequences against a brute-force
+// picture of the address range -- regions never overlap, freed neighbours coalesce, what is free plus what is held is the slab.
+void slab_allocator() {
+  std::mt19937_64 rng(11);
+  for (int round = 0; round < 40; ++round) {
+    Slab sl;
+    sl.cap = 1 << 20;
+    sl.free[0] = sl.cap;
+    struct Held {
+      size_t off, len;
+    };
+    std::vector<Held> held;
+    for (int step = 0; step < 400; ++step) {
+      const bool take = held.empty() || (rng() % 3) != 0;
+      if (take) {
+        const size_t want = ((size_t)(rng() % 60000) + 1 + 255) & ~(size_t)255;
+        size_t off = 0;
+        if (sl.take(want, &off)) {
+          REQUIRE(off + want <= sl.cap && off % 256 == 0);
+          for (const Held& h : held) REQUIRE(off + want <= h.off || h.off + h.len <= off);
+          held.push_back({off, want});
+        } else {
+          for (const auto& f : sl.free) REQUIRE(f.second < want);  // refused only if no hole is large enough
+        }
+      } else {
+        const size_t i = rng() % held.size();
+        sl.give(held[i].off, held[i].len);
+        held.erase(held.begin() + i);
+      }
+      size_t free_total = 0, prev_end = (size_t)-1;
+      for (const auto& f : sl.free) {
+        REQUIRE(f.second > 0);
+        REQUIRE(prev_end == (size_t)-1 || prev_end < f.first);  // sorted, and coalesced: no two holes touch
+        prev_end = f.first + f.second;
+        free_total += f.second;
+      }
+      size_t held_total = 0;
+      for (const Held& h : held) held_total += h.len;
+      REQUIRE(free_total + held_total == sl.cap);
+    }
+    for (const Held& h : held) sl.give(h.off, h.len);
+    REQUIRE(sl.free.size() == 1 && sl.free.begin()->first == 0 && sl.free.begin()->second == sl.cap);
+  }
+}
+
 }  // namespace
 
 int main() {
@@ -205,6 +251,7 @@ int main() {
   for (const Shape& s : shapes) run_shape(s);
   short_series_and_odd_grids();
   frame_integration();
+  slab_allocator();
   std::printf("host sanitizer run: %d checks, clean\n", g_checks);
   return 0;
 }
