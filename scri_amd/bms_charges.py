@@ -56,47 +56,53 @@ def bondi_rest_mass(self):
     return np.sqrt(_minkowski_norm_squared(self.bondi_four_momentum()))
 
 
+_DIPOLE = 1  # the charges below are the l <= 1 part of their aspects
+
+
+def _four_vector(aspect):
+    return charge_vector_from_aspect(aspect.ndarray)
+
+
+def _three_vector(aspect):
+    return _four_vector(aspect)[:, 1:]
+
+
+def _dipole_product(a, b):
+    """a b truncated to l <= 1 (a grid product on a grid that is exact for l_a + l_b; only the l <= 1 modes are kept)"""
+    return a.multiply(b, truncator=lambda ells: _DIPOLE)
+
+
 def bondi_four_momentum(self):
     """l < 2 part of the mass aspect as a four-vector (bms_charges.py:79-88)"""
-    ell_max = 1
-    charge_aspect = self.mass_aspect(ell_max).ndarray
-    return charge_vector_from_aspect(charge_aspect)
+    return _four_vector(self.mass_aspect(_DIPOLE))
 
 
 def _psi1_sigma_term(self, ell_max):
     """psi1 + sigma eth sigma-bar, truncated (the common part of the angular-momentum, boost and CoM aspects)"""
-    return self.psi1.truncate_ell(ell_max) + self.sigma.multiply(self.sigma.bar.eth_GHP, truncator=lambda tup: ell_max)
+    return self.psi1.truncate_ell(ell_max) + self.sigma.multiply(self.sigma.bar.eth_GHP, truncator=lambda ells: ell_max)
 
 
 def bondi_angular_momentum(self):
     """Total Bondi angular momentum vector from i (psi1 + sigma eth sigma-bar)  (bms_charges.py:91-106)"""
-    ell_max = 1
-    charge_aspect = (1j * _psi1_sigma_term(self, ell_max)).ndarray
-    return charge_vector_from_aspect(charge_aspect)[:, 1:]
+    return _three_vector(1j * _psi1_sigma_term(self, _DIPOLE))
+
+
+def _com_aspect(self):
+    """- [psi1 + sigma eth sigma-bar + (1/2) eth(sigma sigma-bar)], l <= 1: the aspect of G = N + t P"""
+    shear_norm = _dipole_product(self.sigma, self.sigma.bar)
+    return -(_psi1_sigma_term(self, _DIPOLE) + 0.5 * shear_norm.eth_GHP)
 
 
 def bondi_boost_charge(self):
-    """- [psi1 + sigma eth sigma-bar + (1/2) eth(sigma sigma-bar) - t eth Re{psi2 + sigma d_t sigma-bar}]
+    """N = G - t P as an aspect: - [psi1 + sigma eth sigma-bar + (1/2) eth(sigma sigma-bar) - t eth Re{psi2 + sigma d_t sigma-bar}]
     (bms_charges.py:163-182)"""
-    ell_max = 1
-    mass_term = (
-        self.psi2.truncate_ell(ell_max) + self.sigma.multiply(self.sigma.bar.dot, truncator=lambda tup: ell_max)
-    ).real.eth_GHP
-    charge_aspect = -(
-        _psi1_sigma_term(self, ell_max)
-        + 0.5 * self.sigma.multiply(self.sigma.bar, truncator=lambda tup: ell_max).eth_GHP
-        - self.t[:, np.newaxis] * mass_term
-    ).ndarray
-    return charge_vector_from_aspect(charge_aspect)[:, 1:]
+    energy_density = (self.psi2.truncate_ell(_DIPOLE) + _dipole_product(self.sigma, self.sigma.bar.dot)).real
+    return _three_vector(_com_aspect(self) + self.t[:, np.newaxis] * energy_density.eth_GHP)
 
 
 def bondi_CoM_charge(self):
     """G = N + t P = - [psi1 + sigma eth sigma-bar + (1/2) eth(sigma sigma-bar)]  (bms_charges.py:185-200)"""
-    ell_max = 1
-    charge_aspect = -(
-        _psi1_sigma_term(self, ell_max) + 0.5 * self.sigma.multiply(self.sigma.bar, truncator=lambda tup: ell_max).eth_GHP
-    ).ndarray
-    return charge_vector_from_aspect(charge_aspect)[:, 1:]
+    return _three_vector(_com_aspect(self))
 
 
 def bondi_dimensionless_spin(self):
@@ -117,16 +123,13 @@ def CWWY_angular_momentum(self):
     from .map_to_superrest_frame import D_inverse
     from .modes_time_series import ModesTimeSeries
 
-    ell_max = 1
     potential = self.sigma.ethbar_GHP.ethbar_GHP + self.sigma.bar.eth_GHP.eth_GHP
     if hasattr(potential, "scale_by_ell"):  # device-resident series: the diagonal D^-1 as one more mode map
         potential = potential.scale_by_ell(lambda l: 0.0 if l < 2 else 4.0 / ((l + 2) * (l + 1) * l * (l - 1)))
     else:
         potential = ModesTimeSeries(D_inverse(potential.ndarray, self.ell_max), self.t, spin_weight=0, ell_min=0, ell_max=self.ell_max)
-    charge_aspect = (
-        1j * (_psi1_sigma_term(self, ell_max) + potential.multiply(self.mass_aspect().eth_GHP, truncator=lambda tup: ell_max))
-    ).ndarray
-    return charge_vector_from_aspect(charge_aspect)[:, 1:]
+    correction = _dipole_product(potential, self.mass_aspect().eth_GHP)
+    return _three_vector(1j * (_psi1_sigma_term(self, _DIPOLE) + correction))
 
 
 def supermomentum(self, supermomentum_def, **kwargs):
