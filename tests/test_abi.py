@@ -117,3 +117,22 @@ def test_one_hip_runtime_whichever_is_loaded_first():
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stderr
     assert out.stdout.strip().splitlines()[-1] == "1"
+
+
+def test_probe_build_carries_the_probe_switches_and_the_same_abi():
+    """`make PROBES=1` -> libscri_amd_probes.so: the variant the scripts under tools/probes load through SCRI_AMD_LIB_PATH.  It must keep
+    building, export what the header declares, and -- unlike the default library -- contain the knock-out / trace switches."""
+    import shutil
+    import subprocess
+
+    if not (os.path.exists("/opt/rocm/bin/hipcc") or shutil.which("hipcc")):
+        pytest.skip("no hipcc")
+    csrc = os.path.join(ROOT, "scri_amd", "csrc")
+    subprocess.check_call(["make", "-C", csrc, "PROBES=1", "-j8"], stdout=subprocess.DEVNULL)
+    path = os.path.join(ROOT, "scri_amd", "libscri_amd_probes.so")
+    blob = open(path, "rb").read()
+    for name in (b"SCRI_AMD_GEMM_EVAL_DBG", b"SCRI_AMD_GEMM_EVAL_TRACE", b"SCRI_AMD_SE_KNOCK", b"SCRI_AMD_ASSUME_REGULAR_MESH"):
+        assert name in blob, name
+    lib = ctypes.CDLL(path)
+    for name in _declared_functions():
+        assert hasattr(lib, name), name
