@@ -677,3 +677,23 @@ def test_reserved_slab_serves_the_work_space(ctx):
         ref2 = _gpu(w2, ctx).transform(**kw)
         assert np.array_equal(got2.data, ref2.data)
         c2.close()
+
+
+def test_eval_window_statistics(ctx):
+    """bms_ctx_get_eval_stats: tiles of the evaluating product launched since the last reset, how many of them had samples outside
+    the window of output times they stage in LDS, how many per-column marches went on from global memory.  A mild boost keeps every
+    tile on its window; a boost of 0.3 c (a direction's samples trail its knots by hundreds of rows within one tile's columns)
+    does not -- and both give the oracle's numbers."""
+    t = np.linspace(-30.0, 40.0, 1500)
+    w = _wm(t, 8, 3)
+    st = np.zeros(9, dtype=complex)
+    st[0], st[2] = 0.3, 0.05
+    ctx.eval_stats(reset=True)
+    assert ctx.eval_stats(reset=False) == (0, 0, 0)
+    _check(w, ctx, supertranslation=st, boost_velocity=np.array([1e-3, -2e-3, 1.5e-3]))
+    tiles, off, cont = ctx.eval_stats(reset=True)
+    assert tiles > 0 and off == 0 and cont == 0
+    _check(w, ctx, tol=4e-12, supertranslation=st, boost_velocity=np.array([0.2, -0.15, 0.18]))
+    tiles2, off2, cont2 = ctx.eval_stats(reset=True)
+    assert tiles2 > 0 and off2 + cont2 > 0
+    assert ctx.eval_stats(reset=False) == (0, 0, 0)
