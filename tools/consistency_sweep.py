@@ -7,7 +7,8 @@ properties the full-size tests check on the BASELINE.json shapes only (tests/tes
 
 tests/test_gpu_fuzz.py covers the parameter space against the oracle on SMALL series (n <= 260, l <= 7); this sweep is where
 chunk seams, tile windows of the evaluating product and halos meet random skews.  Usage:
-    python tools/consistency_sweep.py [last_seed [first_seed]]        (prints failures; exit code = their number)"""
+    python tools/consistency_sweep.py [last_seed [first_seed]]        (prints failures; exit code = their number)
+SWEEP_ABD=1: the same for AsymptoticBondiData (six fields with their mixing; 2e3 .. 1.2e4 steps, l <= 8)."""
 import os
 import sys
 
@@ -150,14 +151,113 @@ def one(seed, ctx):
     return bad, what
 
 
+def one_abd(seed, ctx):
+    """AsymptoticBondiData (all six fields, Horner mixing): whole = chunks = shards, and windows against the oracle"""
+    from oracle import abd_ref
+    from oracle.containers import ABD
+    from scri_amd.asymptotic_bondi_data import _process_transformation_kwargs as abd_kwargs
+
+    rng = np.random.default_rng(99_000 + seed)
+    L = int(rng.integers(2, 9))
+    n = int(rng.integers(2_000, 12_000))
+    axis = ["uniform", "jitter", "sxs"][int(rng.integers(3))]
+    u, raw, _ = synthetic.abd_workload("cfg5", n_times=n, ell_max=L, axis=axis)
+    kw = {}
+    if rng.random() < 0.85:
+        kw["supertranslation"] = real_supertranslation(int(rng.integers(1, 4)), int(rng.integers(1 << 30)), 10.0 ** rng.uniform(-2.0, 0.0))
+    if rng.random() < 0.7:
+        q = rng.normal(size=4)
+        kw["frame_rotation"] = q / np.linalg.norm(q)
+    beta = 0.0
+    if rng.random() < 0.8:
+        v = rng.normal(size=3)
+        beta = min(10.0 ** rng.uniform(-4, np.log10(0.3)), 1_200 * 0.1 / max(abs(u[0]), abs(u[-1])))
+        kw["boost_velocity"] = v / np.linalg.norm(v) * beta
+    what = f"ABD seed {seed}: n={n} l<={L} {axis} beta={beta:.2e} keys={sorted(kw)}"
+    rot, boost, st, wl, out_l = abd_kwargs(L, **dict(kw))
+    tr = engine.make_transformation(st, rot, boost, 2 * wl + 1, 2 * wl + 1, out_l)
+    u_w, raw_w = engine.transform_abd(u, raw, L, tr, ctx=ctx)
+    bad = []
+    if u_w.shape[0] < 50:
+        return bad, what + " (window too small, skipped)"
+    scale = max(1.0, np.abs(raw_w).max())
+
+    # --- chunks
+    n_pix = (2 * wl + 1) ** 2
+    per_row = 16.0 * 2 * 64 * ((n_pix + 63) // 64) * 8.0
+    chunks = int(rng.integers(3, 9))
+    small = scri_amd.Context(0, workspace_limit=int(max(per_row * (n / chunks + 300), 32 << 20)))
+    try:
+        u_c, raw_c = engine.transform_abd(u, raw, L, tr, ctx=small)
+        DONE["chunked runs"] += 1
+        if not np.array_equal(u_c, u_w):
+            bad.append("chunks: time axis differs")
+        elif not np.abs(raw_c - raw_w).max() < 1e-13 * scale:
+            bad.append(f"chunks ({chunks} wanted): {np.abs(raw_c - raw_w).max() / scale:.2e}")
+    except scri_amd.BMSError as e:
+        DONE["work-space limit reported too small"] += 1
+        if "work space limit" not in str(e):
+            bad.append(f"chunks: {e}")
+    finally:
+        del small
+
+    # --- shards
+    ranks = int(rng.integers(2, 7))
+    have, need, window = sharding.plan(u, tr, ranks)
+    if window[1] - window[0] != u_w.shape[0]:
+        bad.append(f"shards: window {window} against {u_w.shape[0]} outputs")
+    else:
+        row = 0
+        DONE["sharded runs"] += 1
+        for r in range(ranks):
+            DONE["shards"] += 1
+            ext = np.ascontiguousarray(raw[:, need[r][0]:need[r][1]])
+            up, rp, first = engine.transform_abd(u, ext, L, tr, ctx=ctx, shard=(need[r][0], ext.shape[1], have[r][0], have[r][1]))
+            if (up.shape[0] and first != window[0] + row) or not np.array_equal(up, u_w[row:row + up.shape[0]]):
+                bad.append(f"shard {r} of {ranks}: rows misplaced")
+                break
+            err = np.abs(rp - raw_w[:, row:row + up.shape[0]]).max() if up.shape[0] else 0.0
+            if not err < 1e-13 * scale:
+                bad.append(f"shard {r} of {ranks}: {err / scale:.2e}")
+            row += up.shape[0]
+        if not bad and row != u_w.shape[0]:
+            bad.append(f"shards: {row} rows against {u_w.shape[0]}")
+
+    # --- one oracle window (the bar of tests/test_gpu_full_size.py::_abd_window_check: 1e-12 of the scale + the rounding of the
+    # reference's own abscissae k (u - alpha), which a time derivative carries into the result)
+    skew_rows = int(np.ceil(beta * max(abs(u[0]), abs(u[-1])) / np.diff(u).min())) if beta else 0
+    half = 160 + int(1.3 * skew_rows) + 70
+    if 2 * half + 50 < n and (2 * half) * n_pix < 2.5e6:
+        i0 = int(rng.integers(0, n - 2 * half))
+        e = abd_ref.transform(ABD(u[i0:i0 + 2 * half], raw[:, i0:i0 + 2 * half], L), **kw)
+        if e.n_times >= 140:
+            keep = e.u[60:-60]
+            keep = keep[(keep >= u_w[0]) & (keep <= u_w[-1])]
+            if keep.size:
+                gi = np.minimum(np.searchsorted(u_w, keep - 1e-9), u_w.shape[0] - 1)
+                if not np.abs(u_w[gi] - keep).max() < 1e-9 * max(1.0, abs(keep).max()):
+                    bad.append(f"oracle window at {i0}: time samples differ")
+                else:
+                    DONE["oracle windows"] += 1
+                    sel = np.isin(e.u, keep)
+                    osc = max(1.0, np.abs(e.raw).max())
+                    for f in range(6):
+                        noise = 8 * np.finfo(float).eps * np.abs(e.u).max() * np.abs(np.gradient(e.raw[f], e.u, axis=0)).max()
+                        err = np.abs(raw_w[f][gi] - e.raw[f][sel]).max()
+                        if not err < 1e-12 * osc + noise:
+                            bad.append(f"oracle window at {i0}, field {f}: {err:.2e} (bar {1e-12 * osc + noise:.2e})")
+    return bad, what
+
+
 def main():
     last = int(sys.argv[1]) if len(sys.argv) > 1 else 40
     first = int(sys.argv[2]) if len(sys.argv) > 2 else 0
     ctx = scri_amd.Context(0)
     failures = 0
+    fn = one_abd if os.environ.get("SWEEP_ABD") else one
     for seed in range(first, last):
         try:
-            bad, what = one(seed, ctx)
+            bad, what = fn(seed, ctx)
         except Exception as e:  # noqa: BLE001  (a sweep: report and go on)
             bad, what = [f"{type(e).__name__}: {str(e)[:300]}"], f"seed {seed}"
         if bad:
