@@ -2,6 +2,7 @@
 properties the full-size tests check on the BASELINE.json shapes only (tests/test_gpu_full_size.py):
 
   * a small work space (3 .. 12 chunks of the time axis) gives the result of one chunk,
+  * weights resident in HBM (to_device) give the host path's result (bit for bit below the size at which host arrays travel in pieces),
   * the shards of sharding.plan (2 .. 8 ranks), each run from its own rows + halo, reassemble to the whole,
   * random windows of the output match the oracle run on slices of the input (the slice is widened by the boost's time skew).
 
@@ -24,7 +25,7 @@ from scri_amd.waveform_grid import process_transformation_kwargs
 from tests.test_gpu_transform_modes import real_supertranslation
 
 quat.ROBUST_POLES = True
-DONE = {"chunked runs": 0, "work-space limit reported too small": 0, "sharded runs": 0, "shards": 0, "column partitions": 0, "oracle windows": 0}
+DONE = {"chunked runs": 0, "device-resident runs": 0, "... of them bit for bit the host run": 0, "work-space limit reported too small": 0, "sharded runs": 0, "shards": 0, "column partitions": 0, "oracle windows": 0}
 
 
 def _gpu(t, data, ell_max, dataType, ctx):
@@ -81,6 +82,20 @@ def one(seed, ctx):
             bad.append(f"chunks: {e}")
     finally:
         del small
+
+    # --- weights resident in HBM (to_device): the same kernels on the caller's device memory
+    dev = _gpu(t, data.copy(), ell_max, dataType, ctx).to_device().transform(**kw)
+    DONE["device-resident runs"] += 1
+    if not dev.is_device_resident:
+        bad.append("device-resident input gave a host result")
+    elif dev.n_times != whole.n_times or not np.array_equal(dev.t, whole.t):
+        bad.append("device-resident run: time axis differs from the host run's")
+    else:
+        # (host arrays of 64 MB and more travel in pieces, each with its own tiles of the spline solve: equal to rounding, not bit for bit)
+        err = np.abs(dev.data - whole.data).max()
+        DONE["... of them bit for bit the host run"] += int(err == 0.0)
+        if not err < 1e-13 * scale:
+            bad.append(f"device-resident run: {err / scale:.2e} from the host run")
 
     # --- shards (single-field type h only: the engine call below is the one sharding.py makes)
     if dataType == h:
