@@ -434,29 +434,38 @@ __global__ __launch_bounds__(256, 3) void zgemm3m_eval_kernel(const double* __re
     }
   }
 
-  const bool wave_has_columns = n0 + wn * 32 < N;
+  // A panel whose columns all lie in its first half (the last one: 17 of 64 columns at cfg3, 9 at cfg5) would leave the waves of the
+  // second half without products and the other two with a full load; there the four waves take 16 rows x 32 columns each instead
+  // (half the products per SIMD, all four SIMDs busy).
+  const bool narrow = n0 + 32 >= N;
+  const int rbase = narrow ? wave * 16 : wm * 32, cbase = narrow ? 0 : wn * 32;
+  const bool wave_has_columns = n0 + cbase < N;
   for (int kt = 0; kt < nk; ++kt) {
     const int buf = kt & 1;
     if (kt + 1 < nk) E_LOAD_GLOBAL(kt + 1);
-    const double2* as = As + buf * E_ASZ + (wm * 32 + fi) * E_PA + fk;
-    const double2* bs = Bs + buf * E_BSZ + fk * E_PB + wn * 32 + fi;
+    const double2* as = As + buf * E_ASZ + (rbase + fi) * E_PA + fk;
+    const double2* bs = Bs + buf * E_BSZ + fk * E_PB + cbase + fi;
 #pragma unroll
     for (int kk = 0; wave_has_columns && kk < E_KC / 4; ++kk) {
-      const double2 a0 = as[kk * 4], a1 = as[16 * E_PA + kk * 4];
+      const double2 a0 = as[kk * 4];
       const double2 b0 = bs[kk * 4 * E_PB], b1 = bs[kk * 4 * E_PB + 16];
+      const double sa0 = a0.x + a0.y, sb0 = b0.x + b0.y, sb1 = b1.x + b1.y;
       p1[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0.x, b0.x, p1[0][0], 0, 0, 0);
       p1[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0.x, b1.x, p1[0][1], 0, 0, 0);
-      p1[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1.x, b0.x, p1[1][0], 0, 0, 0);
-      p1[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1.x, b1.x, p1[1][1], 0, 0, 0);
       p2[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0.y, b0.y, p2[0][0], 0, 0, 0);
       p2[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0.y, b1.y, p2[0][1], 0, 0, 0);
-      p2[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1.y, b0.y, p2[1][0], 0, 0, 0);
-      p2[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1.y, b1.y, p2[1][1], 0, 0, 0);
-      const double sa0 = a0.x + a0.y, sa1 = a1.x + a1.y, sb0 = b0.x + b0.y, sb1 = b1.x + b1.y;
       p3[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(sa0, sb0, p3[0][0], 0, 0, 0);
       p3[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(sa0, sb1, p3[0][1], 0, 0, 0);
-      p3[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(sa1, sb0, p3[1][0], 0, 0, 0);
-      p3[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(sa1, sb1, p3[1][1], 0, 0, 0);
+      if (!narrow) {
+        const double2 a1 = as[16 * E_PA + kk * 4];
+        const double sa1 = a1.x + a1.y;
+        p1[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1.x, b0.x, p1[1][0], 0, 0, 0);
+        p1[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1.x, b1.x, p1[1][1], 0, 0, 0);
+        p2[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1.y, b0.y, p2[1][0], 0, 0, 0);
+        p2[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1.y, b1.y, p2[1][1], 0, 0, 0);
+        p3[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(sa1, sb0, p3[1][0], 0, 0, 0);
+        p3[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(sa1, sb1, p3[1][1], 0, 0, 0);
+      }
     }
     if (kt + 1 < nk) E_STORE_LDS(buf ^ 1);
     __syncthreads();
@@ -471,7 +480,7 @@ __global__ __launch_bounds__(256, 3) void zgemm3m_eval_kernel(const double* __re
   double2 cv[2][2][4];
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
-    const int col = n0 + wn * 32 + j * 16 + fi;
+    const int col = n0 + cbase + j * 16 + fi;
     const bool okc = col < N;
     const double sc_r = (okc && col_scale) ? col_scale[2 * col] : 1.0, sc_i = (okc && col_scale) ? col_scale[2 * col + 1] : 1.0;
 #pragma unroll
@@ -487,13 +496,14 @@ __global__ __launch_bounds__(256, 3) void zgemm3m_eval_kernel(const double* __re
   const int ec = tid & 31, eg = tid >> 5;
 #pragma unroll
   for (int h = 0; h < 2; ++h) {
-    if (wn == h) {
+    if (narrow ? h == 0 : wn == h) {  // (a narrow panel: every wave parks its 16 rows of the first half)
 #pragma unroll
       for (int j = 0; j < 2; ++j)
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
-          for (int rr = 0; rr < 4; ++rr) Cs[(wm * 32 + i * 16 + fk + 4 * rr) * E_PC + j * 16 + fi] = cv[i][j][rr];
+          for (int rr = 0; rr < 4; ++rr)
+            if (i == 0 || !narrow) Cs[(rbase + i * 16 + fk + 4 * rr) * E_PC + j * 16 + fi] = cv[i][j][rr];
     }
     __syncthreads();
     const int col = n0 + h * 32 + ec;
