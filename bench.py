@@ -429,6 +429,78 @@ def abd_boost_free_line(ctx, n_rows=25_000):
     return out
 
 
+def inprocess_line(args):
+    """`--inprocess N`: ONE process, N devices, numpy in / numpy out -- the callers the reference has (scri/waveform_modes.py:705-719,
+    scri/asymptotic_bondi_data/transformations.py:391-412 take host arrays in one process).  engine.transform_modes / transform_abd
+    with `devices=[...]` deal the time shards of the pipelined call over one context and one host thread per device; every device
+    gets its rows + halo at upload time, so there is no process group and no GPU-to-GPU traffic.  The rate is PCIe-INCLUSIVE (host
+    arrays in, host arrays out: not comparable with the device-resident `value` of the default line).  With fewer devices than N
+    the contexts share devices (plumbing + parity only; the line says so)."""
+    import torch
+
+    from scri_amd import engine, synthetic
+
+    n = args.inprocess
+    n_dev = max(torch.cuda.device_count(), 1)
+    devices = [i % n_dev for i in range(n)]
+    workload = args.workload or ("cfg3" if n == 1 else "cfg4")
+    abd = workload == "cfg5"
+    spec = dict(synthetic.CONFIGS[workload])
+    kw, ell_max = spec["kwargs"], spec["ell_max"]
+    lst = int(round(np.sqrt(len(kw["supertranslation"])))) - 1
+    n_global = int(args.n_times or (100_000 if workload in ("cfg2", "cfg3") else spec["n_times"]))
+    n_theta = 2 * int(args.working_ell_max or 2 * ell_max + 1) + 1 if abd else 2 * (ell_max + lst) + 1
+    tr = engine.make_transformation(kw["supertranslation"], kw.get("frame_rotation", [1, 0, 0, 0]), kw.get("boost_velocity", [0, 0, 0]),
+                                    n_theta, n_theta, ell_max)
+    gen = synthetic.abd_workload if abd else synthetic.workload
+    t, data, _ = gen(workload, n_times=n_global, axis=args.time_axis)
+    pieces = engine.pieces_for(devices)
+
+    def go(devs, pcs):
+        if abd:
+            return engine.transform_abd(t, data, ell_max, tr, devices=devs, pieces=pcs)
+        return engine.transform_modes(t, data, 2, ell_max, -2, -1, engine.BMS_TERM_H, tr, devices=devs, pieces=pcs)
+
+    for _ in range(max(args.warmup, 2)):  # (the second sighting page-locks the input in place: _lib.register_if_reused)
+        t_out, out = go(devices, pieces)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        t_out, out = go(devices, pieces)
+    elapsed = time.perf_counter() - t0
+    out = np.array(out)
+    # parity inside the run: the same number of time shards on ONE context (bit for bit), and the default one-context call (rounding)
+    t_one, out_one = go(None, pieces)
+    same_bits = bool(np.array_equal(t_one, t_out) and np.array_equal(out_one, out))
+    t1 = time.perf_counter()
+    reps1 = max(1, min(3, args.steps))
+    for _ in range(reps1):
+        t_def, out_def = go(None, None)
+    one_ctx_ms = 1e3 * (time.perf_counter() - t1) / reps1
+    scale = float(np.abs(out_def).max())
+    diff = float(np.abs(np.asarray(out_def) - out).max())
+    shared = n_dev < n
+    line = {
+        "metric": "timesteps/sec for full BMS transform, host arrays in and out (PCIe-inclusive), one process over several devices; fp64",
+        "value": n_global * args.steps / elapsed, "unit": "timesteps/s", "n_gpus": n, "steps": args.steps, "warmup": max(args.warmup, 2),
+        "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "strong" if n > 1 else None, "vs_baseline": None,
+        "dtype": "f64", "data": "synthetic",
+        "config": {
+            "workload": f"{workload}: {'AsymptoticBondiData psi0..psi4 + sigma' if abd else 'WaveformModes h'}, ell_max {ell_max}, {n_global} time steps in "
+                        f"host memory, {n_theta}x{n_theta} grid, {t_out.size} output steps",
+            "sharding": f"in-process: {pieces} time shards of the pipelined call dealt over {n} contexts on devices {devices}, one host thread each, rows + "
+                        "halo shipped at upload time (no process group, no GPU-to-GPU traffic); engine.transform_" + ("abd" if abd else "modes") + "(devices=...)",
+            "devices_shared": shared,
+            "note": ("the contexts share devices: plumbing and parity only, NO timing claim is possible on this box" if shared else
+                     "one context per device"),
+        },
+        "parity": {"bit_identical_to_one_context_with_the_same_shards": same_bits, "max_abs_diff_vs_default_one_context_call": diff,
+                   "scale_max_abs": scale, "bar": 1e-14 * scale, "within_bar": bool(same_bits and diff <= 1e-14 * scale)},
+        "one_context_same_run": {"ms_per_step": one_ctx_ms, "pieces": engine.PIPELINE_PIECES},
+    }
+    print("\n" + json.dumps(line), flush=True)
+    return 0 if line["parity"]["within_bar"] else 1
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -460,7 +532,12 @@ def main():
                     "tensors, checked against the synthetic series; prints a line with \"plumbing_only\": true and no measurement")
     ap.add_argument("--no-parity", action="store_true", help="cfg4, N > 1: skip the comparison of the reassembled shard outputs with "
                     "rank 0's single-GPU result of the same run")
+    ap.add_argument("--inprocess", type=int, default=0, metavar="N",
+                    help="ONE process, N devices, host arrays in and out: engine.transform_modes(devices=[0..N-1]) (no process group; with fewer "
+                    "devices than N the contexts share them: parity only).  Prints its own line; PCIe-inclusive, not the headline `value`")
     args = ap.parse_args()
+    if args.inprocess:
+        return inprocess_line(args)
     if args.workload is None:
         args.workload = "cfg3" if args.gpus == 1 else "cfg4"
     pmc_child = os.environ.get("SCRI_AMD_BENCH_PMC_CHILD") == "1"
@@ -586,12 +663,15 @@ def main():
     n_pix = n_theta * n_theta
     n_fields = 6 if abd else 1
 
-    # this rank's rows of the global series, resident in HBM before the timed region
-    have, need, window = sharding.plan(synthetic.time_axis(n_global, spec["dt"], args.time_axis), tr, world)
-    own = have[rank][1] - have[rank][0]
-    columns = world > 1 and (args.partition == "columns" or (args.partition == "auto" and sharding.choose_partition(have, need) == "columns"))
-    if columns and abd:
-        raise SystemExit("--partition columns is wired into the bench for the WaveformModes workloads only")
+    # this rank's rows of the global series, resident in HBM before the timed region.  Plan, halo exchange, shard call and row
+    # placement are the library's (scri_amd/sharding.py::ShardedTransform -- what WaveformModes.transform(group=...) runs too)
+    ctx = _lib.Context(dev_index, stream=run_stream.cuda_stream)
+    ctx.enable_timing(True)
+    st = sharding.ShardedTransform("abd" if abd else "modes", synthetic.time_axis(n_global, spec["dt"], args.time_axis), tr, 2, ell_max, -2, -1,
+                                   engine.BMS_TERM_H, partition=args.partition, overlap=args.overlap_halo, ctx=ctx)
+    have, need, window = st.have, st.need, st.window
+    own = st.own
+    columns = st.partition == "columns" and world > 1
     if abd:
         t_global, local_host, _ = synthetic.abd_workload(args.workload, n_times=n_global, rows=have[rank], axis=args.time_axis)
         out = torch.empty((6, own, n_modes), dtype=torch.complex128, device=dev)
@@ -600,20 +680,12 @@ def main():
         out = torch.empty((own, n_modes), dtype=torch.complex128, device=dev)
     local = torch.from_numpy(local_host).to(dev)
     del local_host
-    # N > 1, WaveformModes: the rows a rank needs (own rows + halos) live in one buffer; the own rows are placed there once
-    # and every step only moves the halo rows
-    ext_buf = None
-    if columns:
-        # every rank's contribution covers all output rows; equal blocks for the reduce-scatter
-        n_new_all = window[1] - window[0]
-        part_buf = torch.zeros((sharding.padded_rows(n_new_all, world)[0], n_modes), dtype=torch.complex128, device=dev)
-    if world > 1 and not abd and not columns:
-        ext_buf = torch.empty((need[rank][1] - need[rank][0], n_modes), dtype=torch.complex128, device=dev)
-        lo = have[rank][0] - need[rank][0]
-        ext_buf[lo : lo + own] = local
-        local = ext_buf[lo : lo + own]
-    ctx = _lib.Context(dev_index, stream=run_stream.cuda_stream)
-    ctx.enable_timing(True)
+    # N > 1, WaveformModes, time shards: the series lives inside the exchange buffer (own rows placed once, every step only moves the halos)
+    view = st.own_rows_view(like=local)
+    if view is not None:
+        view.copy_(local)
+        local = view
+    n_new_all = window[1] - window[0]
     halo_rows = (have[rank][0] - need[rank][0], need[rank][1] - have[rank][1]) if world > 1 else (0, 0)
 
     # ---- cfg4 / cfg5 on several GPUs: the whole series on ONE GPU (rank 0's), in the same run: the reference of the strong-scaling line
@@ -652,69 +724,11 @@ def main():
     # kernels that read them without a host-side synchronisation of the device
     stream_ordered = world > 1 and backend == "nccl"
 
-    # --overlap-halo: outputs [a, b) of this rank need its own rows only (bms_shard_plan says so); they are transformed
-    # while the halos travel, the edges [i0, a) and [b, i1) afterwards
-    interior = None
-    if args.overlap_halo and world > 1 and not abd and not columns:
-        i0, i1 = have[rank]
-        a, b = i0 + 2 * halo_rows[0] + 8, i1 - 2 * halo_rows[1] - 8
-        if rank == 0:
-            a = i0
-        if rank == world - 1:
-            b = i1
-        while b - a > 64:
-            (n0, n1_), _ = engine.shard_plan(t_global, tr, a, b)
-            if n0 >= i0 and n1_ <= i1:
-                break
-            a, b = (a + 16 if n0 < i0 else a), (b - 16 if n1_ > i1 else b)
-        if b - a > 64:
-            interior = (a, b)
-
-    def transform_rows(src_ptr, src_row0, src_rows, o0, o1):
-        """outputs with global index in [o0, o1) from the rows [src_row0, src_row0 + src_rows) at src_ptr -> their place in `out`"""
-        if o1 <= o0:
-            return 0
-        first_out = max(o0, window[0]) - max(have[rank][0], window[0])
-        return engine.transform_modes(
-            t_global, src_ptr, 2, ell_max, -2, -1, engine.BMS_TERM_H, tr, ctx=ctx, device=True, ld=n_modes,
-            out_ptr=out.data_ptr() + 16 * n_modes * max(first_out, 0), shard=(src_row0, src_rows, o0, o1),
-        )[1]
+    interior = st.interior  # --overlap-halo: outputs [a, b) of this rank need its own rows only and are transformed while the halos travel
 
     def step():
-        if columns:
-            # plan B: gather the whole input series, transform this rank's grid columns over all times, reduce-scatter the sum
-            full = sharding.replicate_rows(local, have)
-            engine.transform_modes(
-                t_global, full.data_ptr(), 2, ell_max, -2, -1, engine.BMS_TERM_H, tr, ctx=ctx, device=True, ld=n_modes,
-                out_ptr=part_buf.data_ptr(), shard=(0, n_global, 0, n_global, rank, world),
-            )
-            rows, _ = sharding.reduce_scatter_rows(part_buf, n_new_all)
-            return rows.shape[0]
-        if world > 1 and interior is not None:
-            i0, i1 = have[rank]
-            pending = sharding.exchange_halos(local, have[rank], need[rank], have, need, out=ext_buf, wait=False)
-            n_new = transform_rows(local.data_ptr(), i0, own, interior[0], interior[1])  # own rows only: runs under the exchange
-            ext = pending()
-            if not stream_ordered:
-                torch.cuda.synchronize()
-            n_new += transform_rows(ext.data_ptr(), need[rank][0], ext.shape[0], i0, interior[0])
-            n_new += transform_rows(ext.data_ptr(), need[rank][0], ext.shape[0], interior[1], i1)
-            return n_new
-        if world > 1:
-            ext = sharding.exchange_halos(local, have[rank], need[rank], have, need, dim=1 if abd else 0, out=ext_buf)
-            if not stream_ordered:
-                torch.cuda.synchronize()
-        else:
-            ext = local
-        row0 = need[rank][0] if world > 1 else 0
-        if abd:
-            shard = (row0, ext.shape[1], have[rank][0], have[rank][1])
-            return engine.transform_abd(t_global, ext.data_ptr(), ell_max, tr, ctx=ctx, shard=shard, device=True, out_ptr=out.data_ptr())[1]
-        t_out, n_new, first = engine.transform_modes(
-            t_global, ext.data_ptr(), 2, ell_max, -2, -1, engine.BMS_TERM_H, tr, ctx=ctx, device=True, ld=n_modes,
-            out_ptr=out.data_ptr(), shard=(row0, ext.shape[0], have[rank][0], have[rank][1]),
-        )
-        return n_new
+        t_out, rows, first = st(local, out=out)
+        return rows.shape[1 if abd else 0]
 
     def fence():
         torch.cuda.synchronize()
@@ -828,9 +842,7 @@ def main():
                 f"{n_theta}x{n_theta} grid, {n_out} output steps on rank 0",
                 "ranks": dict({"world_size": dist.get_world_size() if world > 1 else 1, "backend": dist.get_backend() if world > 1 else None},
                               **({"note": backend_note} if backend_note else {})),
-                "sharding": "none" if world == 1 else (
-                    f"grid columns x{world}: all-gather of input modes, reduce-scatter of output modes (RCCL)" if columns
-                    else f"time axis x{world}, RCCL point-to-point halo exchange of input modes"),
+                "sharding": st.describe(),
             },
             "roofline": {
                 "bound": "mfma",

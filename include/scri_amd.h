@@ -185,6 +185,19 @@ int bms_transform_modes_pipelined(bms_ctx* ctx, const bms_wm_input* in, const bm
  * before it travels down.  u_out must hold n_times doubles.  Results equal bms_transform_abd's to rounding. */
 int bms_transform_abd_pipelined(bms_ctx* ctx, const double* u, const void* raw, int64_t n_times, int ell_max,
                                 const bms_transformation* tr, int pieces, double* u_out, void* raw_out, int64_t* n_times_out);
+
+/* One process, several GPUs, host arrays in and out (the callers the reference has: scri/waveform_modes.py:705-719 and
+ * scri/asymptotic_bondi_data/transformations.py:391-412 take numpy arrays in one process).  The output window is cut into `pieces`
+ * exactly as the two calls above cut it; these transform pieces [piece0, piece1) only and put them at their place in t_out / data_out,
+ * which are the arrays of the WHOLE window (page-locked memory from bms_host_alloc / bms_host_register is visible to every device);
+ * *n_times_out is the whole window's row count.  The caller deals the pieces over one context per device and calls from one host
+ * thread per context (the library is re-entrant per context): every device receives its own rows + halo at upload time, so nothing
+ * travels GPU to GPU, and the result equals the one-context call with the same `pieces` bit for bit. */
+int bms_transform_modes_pipelined_part(bms_ctx* ctx, const bms_wm_input* in, const bms_transformation* tr, int pieces, int piece0,
+                                       int piece1, double* t_out, void* data_out, int64_t* n_times_out);
+int bms_transform_abd_pipelined_part(bms_ctx* ctx, const double* u, const void* raw, int64_t n_times, int ell_max,
+                                     const bms_transformation* tr, int pieces, int piece0, int piece1, double* u_out, void* raw_out,
+                                     int64_t* n_times_out);
 /* WaveformGrid.from_modes on its own (scri/waveform_grid.py:331-613): the first half of bms_transform_modes -- the field on the
  * boost-distorted grid at the new time slices, grid_out c16[n_times][n_theta * n_phi] (only the first *n_times_out rows are
  * written; grid order, theta-major), in the memory space in->mem.  bms_map2salm of it is WaveformGrid.to_modes (:274-329). */

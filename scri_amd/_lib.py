@@ -105,6 +105,14 @@ SIGNATURES = {
         c_int,
         [c_vp, c_dp, c_vp, c_i64, c_int, ctypes.POINTER(bms_transformation), c_int, c_dp, c_vp, ctypes.POINTER(c_i64)],
     ),
+    "bms_transform_modes_pipelined_part": (
+        c_int,
+        [c_vp, ctypes.POINTER(bms_wm_input), ctypes.POINTER(bms_transformation), c_int, c_int, c_int, c_dp, c_vp, ctypes.POINTER(c_i64)],
+    ),
+    "bms_transform_abd_pipelined_part": (
+        c_int,
+        [c_vp, c_dp, c_vp, c_i64, c_int, ctypes.POINTER(bms_transformation), c_int, c_int, c_int, c_dp, c_vp, ctypes.POINTER(c_i64)],
+    ),
     "bms_rotate_const": (c_int, [c_vp, c_vp, c_int, c_i64, c_i64, c_int, c_int, c_dp]),
     "bms_rotate_series": (c_int, [c_vp, c_vp, c_int, c_i64, c_i64, c_int, c_int, c_vp]),
     "bms_rotate_const_D": (c_int, [c_vp, c_vp, c_int, c_i64, c_i64, c_int, c_int, c_vp]),
@@ -372,6 +380,7 @@ class Context:
             _raise(rc, None, "bms_ctx_create")
         self._h = h
         self.device = int(device)
+        self.stream_handle = None  # the hipStream_t the caller handed over (0: the device's default stream); None: the context's own
         if stream is not None:
             self.set_stream(stream)
         if workspace_limit:
@@ -384,6 +393,7 @@ class Context:
     def set_stream(self, stream):
         """stream: a hipStream_t handle; None = the context's own stream; 0 = the device's default (null) stream, which is what
         torch.cuda.current_stream().cuda_stream reports unless the caller switched streams"""
+        self.stream_handle = None if stream is None else int(stream)
         if stream is None:
             self.check(load().bms_ctx_set_stream(self._h, c_vp(0)), "bms_ctx_set_stream")
         elif int(stream) == 0:

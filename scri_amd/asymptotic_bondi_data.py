@@ -183,11 +183,24 @@ class AsymptoticBondiData:
 
         Keyword arguments: time_translation, space_translation, spacetime_translation,
         supertranslation, frame_rotation, boost_velocity, output_ell_max, working_ell_max."""
+        # scri_amd extension (not in the reference): `group` = a torch.distributed process group over whose ranks the time axis is
+        # split; this object then holds THIS rank's contiguous block of rows, and so does the result (scri_amd/sharding.py)
+        group = kwargs.pop("group", None)
+        devices = kwargs.pop("devices", None)  # the GPUs of this process a long host-memory series is dealt over (engine.transform_abd)
         frame_rotation, boost_velocity, supertranslation, working_ell_max, output_ell_max = _process_transformation_kwargs(
             self.ell_max, **kwargs
         )
         n_theta = 2 * working_ell_max + 1
         tr = engine.make_transformation(supertranslation, frame_rotation, boost_velocity, n_theta, n_theta, output_ell_max)
+        if group is not None:
+            from . import sharding
+
+            u_global, have = sharding.gather_time_axis(self._time, group)
+            u_new, raw_new, _ = sharding.transform_abd_sharded(self._raw_dev if self._device else self._raw_data, u_global, self.ell_max, tr,
+                                                              group=group, have=have, ctx=self._ctx)
+            if self._device:
+                return type(self)(np.array(u_new), output_ell_max, ctx=self._ctx, _raw=raw_new.contiguous(), device=True)
+            return type(self)(u_new, output_ell_max, ctx=self._ctx, _raw=np.ascontiguousarray(raw_new))
         if self._device:
             # HBM to HBM: the output window is known before anything moves, so the result is allocated at its exact size
             from . import device_series
@@ -199,7 +212,7 @@ class AsymptoticBondiData:
             if n_new != out.shape[1]:
                 out = out[:, :n_new].contiguous()
             return type(self)(np.array(u_new), output_ell_max, ctx=self._ctx, _raw=out, device=True)
-        u_new, raw_new = engine.transform_abd(self._time, self._raw_data, self.ell_max, tr, ctx=self._ctx)
+        u_new, raw_new = engine.transform_abd(self._time, self._raw_data, self.ell_max, tr, ctx=self._ctx, devices=devices)
         # `type(self)(timeprime, output_ell_max)` in the reference (transformations.py:417): the result starts from the
         # constructor's defaults (multiplication_truncator = sum, frameType = Inertial), whatever the input carried
         return type(self)(u_new, output_ell_max, ctx=self._ctx, _raw=raw_new)

@@ -438,7 +438,7 @@ extern "C" const char* bms_last_error(const bms_ctx* c) { return c ? c->err.c_st
 
 extern "C" void* bms_host_alloc(uint64_t bytes) {
   void* p = nullptr;
-  if (bytes == 0 || hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) return nullptr;
+  if (bytes == 0 || hipHostMalloc(&p, bytes, hipHostMallocPortable) != hipSuccess) return nullptr;
   return p;
 }
 extern "C" void bms_host_free(void* p) {
@@ -449,7 +449,7 @@ extern "C" void bms_host_free(void* p) {
 // on the second sighting of an array and undoes it when the array is freed).
 extern "C" int bms_host_register(void* p, uint64_t bytes) {
   if (!p || !bytes) return BMS_ERR_INVALID;
-  if (hipHostRegister(p, bytes, hipHostRegisterDefault) != hipSuccess) {
+  if (hipHostRegister(p, bytes, hipHostRegisterPortable) != hipSuccess) {
     (void)hipGetLastError();
     return BMS_ERR_HIP;
   }
@@ -1802,6 +1802,16 @@ extern "C" int bms_transform_modes_shard(bms_ctx* c, const bms_wm_input* in, con
 // Results are those of the sharded path (equal to the one-call path to rounding).  No psi companions (aux) here.
 extern "C" int bms_transform_modes_pipelined(bms_ctx* c, const bms_wm_input* in, const bms_transformation* tr, int pieces,
                                              double* t_out, void* data_out, int64_t* n_times_out) {
+  return bms_transform_modes_pipelined_part(c, in, tr, pieces, 0, pieces < 1 ? 1 : pieces, t_out, data_out, n_times_out);
+}
+
+// The same for pieces [piece0, piece1) of the `pieces` the output window is cut into: t_out / data_out are the arrays of the WHOLE
+// window (every piece lands at its own place), *n_times_out is the whole window's row count.  One process that owns several GPUs
+// deals the pieces of one transformation over one context per device, one host thread each (scri_amd/engine.py, `devices=`): every
+// context ships its own rows + halo at upload time, so there is no GPU-to-GPU traffic at all, and the results are
+// those of the one-context call with the same `pieces`, bit for bit (a piece's arithmetic depends on its cut only).
+extern "C" int bms_transform_modes_pipelined_part(bms_ctx* c, const bms_wm_input* in, const bms_transformation* tr, int pieces, int piece0,
+                                                  int piece1, double* t_out, void* data_out, int64_t* n_times_out) {
   if (!c) return BMS_ERR_INVALID;
   if (!in || !tr || !t_out || !data_out || !n_times_out) return fail(c, BMS_ERR_INVALID, "NULL argument");
   if (in->mem != BMS_HOST || in->n_aux != 0) return fail(c, BMS_ERR_INVALID, "the pipelined path takes host data without auxiliary fields");
@@ -1825,6 +1835,9 @@ extern "C" int bms_transform_modes_pipelined(bms_ctx* c, const bms_wm_input* in,
   if (n_new <= 0) return BMS_OK;
   if (pieces < 1) pieces = 1;
   if (pieces > n_new / 8) pieces = (int)std::max<int64_t>(1, n_new / 8);
+  // (a clamped count keeps the pieces that exist: a caller that dealt a larger count over its contexts still covers every one once)
+  const int p0 = std::min(std::max(piece0, 0), pieces), p1 = std::min(std::max(piece1, p0), pieces);
+  if (p1 <= p0) return BMS_OK;
   const int n_modes = LM_total_size(in->ell_min, in->ell_max);
   const int s_abs = std::abs(in->spin_weight);
   const int n_out = LM_total_size(s_abs, tr->ell_max_out);
@@ -1832,7 +1845,7 @@ extern "C" int bms_transform_modes_pipelined(bms_ctx* c, const bms_wm_input* in,
   std::vector<int64_t> cut(pieces + 1), r0(pieces), r1(pieces);
   int64_t max_rows = 0, max_out = 0;
   for (int k = 0; k <= pieces; ++k) cut[k] = i_lo + (n_new * k) / pieces;
-  for (int k = 0; k < pieces; ++k) {
+  for (int k = p0; k < p1; ++k) {
     int64_t ja, jb;
     needed_knots(T, in->t, n, cut[k], cut[k + 1], ja, jb);
     const int margin = SPLINE_HALO + 2;  // as bms_shard_plan
@@ -1851,13 +1864,13 @@ extern "C" int bms_transform_modes_pipelined(bms_ctx* c, const bms_wm_input* in,
     HIP_TRY(c, create_download_stream(c));
   }
   std::vector<hipEvent_t> ev_up(pieces), ev_c(pieces), ev_dn(pieces);
-  for (int k = 0; k < pieces; ++k) {
+  for (int k = p0; k < p1; ++k) {
     ev_up[k] = ScopedTimer::get(c);
     ev_c[k] = ScopedTimer::get(c);
     ev_dn[k] = ScopedTimer::get(c);
   }
   auto give_back = [&]() {
-    for (int k = 0; k < pieces; ++k) {
+    for (int k = p0; k < p1; ++k) {
       c->event_pool.push_back(ev_up[k]);
       c->event_pool.push_back(ev_c[k]);
       c->event_pool.push_back(ev_dn[k]);
@@ -1873,13 +1886,13 @@ extern "C" int bms_transform_modes_pipelined(bms_ctx* c, const bms_wm_input* in,
   auto upload_piece = [&](int k) -> hipError_t {
     // the buffer was read by the kernels of piece k - 2 (host_wait: the host has waited for them before it gets here)
     const int64_t rows = r1[k] - r0[k];
-    if (!host_wait && k >= 2) {
+    if (!host_wait && k >= p0 + 2) {
       const hipError_t ew = hipStreamWaitEvent(c->pipe_up, ev_c[k - 2], 0);
       if (ew != hipSuccess) return ew;
     }
     hipError_t e = in->ld == n_modes
-                       ? hipMemcpyAsync(d_in[k & 1], host_in + (size_t)r0[k] * in->ld * 16, (size_t)rows * n_modes * 16, hipMemcpyHostToDevice, c->pipe_up)
-                       : hipMemcpy2DAsync(d_in[k & 1], (size_t)n_modes * 16, host_in + (size_t)r0[k] * in->ld * 16, (size_t)in->ld * 16,
+                       ? hipMemcpyAsync(d_in[(k - p0) & 1], host_in + (size_t)r0[k] * in->ld * 16, (size_t)rows * n_modes * 16, hipMemcpyHostToDevice, c->pipe_up)
+                       : hipMemcpy2DAsync(d_in[(k - p0) & 1], (size_t)n_modes * 16, host_in + (size_t)r0[k] * in->ld * 16, (size_t)in->ld * 16,
                                           (size_t)n_modes * 16, (size_t)rows, hipMemcpyHostToDevice, c->pipe_up);
     if (e != hipSuccess) return e;
     return hipEventRecord(ev_up[k], c->pipe_up);
@@ -1896,30 +1909,30 @@ extern "C" int bms_transform_modes_pipelined(bms_ctx* c, const bms_wm_input* in,
   c->piece_tables = &shared_tables;
   c->piece_tables_valid = false;
   c->async_pieces = true;
-  hipError_t he = upload_piece(0);
+  hipError_t he = upload_piece(p0);
   if (he != hipSuccess) {
     give_back();
     return fail(c, BMS_ERR_HIP, "pipelined upload: %s", hipGetErrorString(he));
   }
-  for (int k = 0; k < pieces && rc == BMS_OK; ++k) {
+  for (int k = p0; k < p1 && rc == BMS_OK; ++k) {
     // piece k + 1 travels while piece k is transformed; its buffer was read by the kernels of piece k - 1.  (Piece 0 reads
     // its per-direction tables back with a blocking copy, which waits for every upload under way: piece 1 is sent after it.)
     auto send_next = [&]() -> hipError_t {
-      if (k + 1 >= pieces) return hipSuccess;
+      if (k + 1 >= p1) return hipSuccess;
       return upload_piece(k + 1);
     };
-    if (k > 0 && (he = send_next()) != hipSuccess) break;
+    if (k > p0 && (he = send_next()) != hipSuccess) break;
     if ((he = hipStreamWaitEvent(c->stream, ev_up[k], 0)) != hipSuccess) break;
-    if (k >= 2 && (he = hipStreamWaitEvent(c->stream, ev_dn[k - 2], 0)) != hipSuccess) break;  // its output buffer has left
+    if (k >= p0 + 2 && (he = hipStreamWaitEvent(c->stream, ev_dn[k - 2], 0)) != hipSuccess) break;  // its output buffer has left
     bms_wm_input piece = *in;
-    piece.data = d_in[k & 1];
+    piece.data = d_in[(k - p0) & 1];
     piece.ld = n_modes;
     piece.mem = BMS_DEVICE;
     const bms_shard sh = {r0[k], r1[k] - r0[k], cut[k], cut[k + 1], 0, 0};
     int64_t got = 0, first = 0;
-    rc = transform_modes_impl(c, &piece, tr, &sh, t_out + (cut[k] - i_lo), d_out[k & 1], &got, &first, nullptr);
+    rc = transform_modes_impl(c, &piece, tr, &sh, t_out + (cut[k] - i_lo), d_out[(k - p0) & 1], &got, &first, nullptr);
     if (rc) break;
-    if (k == 0 && (he = send_next()) != hipSuccess) break;
+    if (k == p0 && (he = send_next()) != hipSuccess) break;
     if (got != cut[k + 1] - cut[k] || first != cut[k]) {
       rc = fail(c, BMS_ERR_HIP, "pipelined shard [%lld, %lld) produced %lld rows from %lld", (long long)cut[k], (long long)cut[k + 1],
                 (long long)got, (long long)first);
@@ -1932,7 +1945,7 @@ extern "C" int bms_transform_modes_pipelined(bms_ctx* c, const bms_wm_input* in,
     // page-locked array from the analysis kernel (on a side stream, with a small grid) was tried: the stores leave at 42 GB/s
     // instead of 57 and every memory-bound kernel running beside them crawls -- 19.8 ms against 15.7 ms per cfg3 transform.
     if ((he = host_wait ? hipEventSynchronize(ev_c[k]) : hipStreamWaitEvent(c->pipe_down, ev_c[k], 0)) != hipSuccess) break;
-    if ((he = hipMemcpyAsync(host_out + (size_t)(cut[k] - i_lo) * n_out * 16, d_out[k & 1], (size_t)got * n_out * 16,
+    if ((he = hipMemcpyAsync(host_out + (size_t)(cut[k] - i_lo) * n_out * 16, d_out[(k - p0) & 1], (size_t)got * n_out * 16,
                              hipMemcpyDeviceToHost, c->pipe_down)) != hipSuccess)
       break;
     if ((he = hipEventRecord(ev_dn[k], c->pipe_down)) != hipSuccess) break;
@@ -3524,6 +3537,12 @@ static int transform_abd_impl(bms_ctx* c, const double* u, const void* raw, int 
 // down at the same time.  raw: host c16[6][n][(ell_max+1)^2]; raw_out: host c16[6][i_hi - i_lo][n_out] (best page-locked).
 extern "C" int bms_transform_abd_pipelined(bms_ctx* c, const double* u, const void* raw, int64_t n, int ell_max,
                                            const bms_transformation* tr, int pieces, double* u_out, void* raw_out, int64_t* n_times_out) {
+  return bms_transform_abd_pipelined_part(c, u, raw, n, ell_max, tr, pieces, 0, pieces < 1 ? 1 : pieces, u_out, raw_out, n_times_out);
+}
+
+// Pieces [piece0, piece1) of the same plan (see bms_transform_modes_pipelined_part): u_out / raw_out are the arrays of the whole window.
+extern "C" int bms_transform_abd_pipelined_part(bms_ctx* c, const double* u, const void* raw, int64_t n, int ell_max, const bms_transformation* tr,
+                                                int pieces, int piece0, int piece1, double* u_out, void* raw_out, int64_t* n_times_out) {
   if (!c) return BMS_ERR_INVALID;
   if (!u || !raw || !tr || !u_out || !raw_out || !n_times_out) return fail(c, BMS_ERR_INVALID, "NULL argument");
   HIP_TRY(c, hipSetDevice(c->device));
@@ -3545,11 +3564,13 @@ extern "C" int bms_transform_abd_pipelined(bms_ctx* c, const double* u, const vo
   if (n_new <= 0) return BMS_OK;
   if (pieces < 1) pieces = 1;
   if (pieces > n_new / 8) pieces = (int)std::max<int64_t>(1, n_new / 8);
+  const int p0 = std::min(std::max(piece0, 0), pieces), p1 = std::min(std::max(piece1, p0), pieces);
+  if (p1 <= p0) return BMS_OK;
   const int64_t nm = (int64_t)(ell_max + 1) * (ell_max + 1), n_out = (int64_t)(tr->ell_max_out + 1) * (tr->ell_max_out + 1);
   std::vector<int64_t> cut(pieces + 1), r0(pieces), r1(pieces);
   int64_t max_rows = 0, max_out = 0;
   for (int k = 0; k <= pieces; ++k) cut[k] = i_lo + (n_new * k) / pieces;
-  for (int k = 0; k < pieces; ++k) {
+  for (int k = p0; k < p1; ++k) {
     int64_t ja, jb;
     needed_knots(T, u, n, cut[k], cut[k + 1], ja, jb);
     const int margin = SPLINE_HALO + 2;  // as bms_shard_plan
@@ -3568,16 +3589,16 @@ extern "C" int bms_transform_abd_pipelined(bms_ctx* c, const double* u, const vo
     HIP_TRY(c, create_download_stream(c));
   }
   std::vector<hipEvent_t> ev_up(pieces), ev_c(pieces), ev_dn(pieces);
-  for (int k = 0; k < pieces; ++k) ev_up[k] = ScopedTimer::get(c), ev_c[k] = ScopedTimer::get(c), ev_dn[k] = ScopedTimer::get(c);
+  for (int k = p0; k < p1; ++k) ev_up[k] = ScopedTimer::get(c), ev_c[k] = ScopedTimer::get(c), ev_dn[k] = ScopedTimer::get(c);
   auto give_back = [&]() {
-    for (int k = 0; k < pieces; ++k) c->event_pool.push_back(ev_up[k]), c->event_pool.push_back(ev_c[k]), c->event_pool.push_back(ev_dn[k]);
+    for (int k = p0; k < p1; ++k) c->event_pool.push_back(ev_up[k]), c->event_pool.push_back(ev_c[k]), c->event_pool.push_back(ev_dn[k]);
   };
   const char* host_in = (const char*)raw;
   char* host_out = (char*)raw_out;
   auto upload_piece = [&](int k) -> hipError_t {  // the six fields' rows [r0, r1) -> c16[6][rows][nm]
     const int64_t rows = r1[k] - r0[k];
     for (int f = 0; f < 6; ++f) {
-      const hipError_t e = hipMemcpyAsync(d_in[k & 1] + (size_t)f * rows * nm * 2, host_in + ((size_t)f * n + r0[k]) * nm * 16, (size_t)rows * nm * 16,
+      const hipError_t e = hipMemcpyAsync(d_in[(k - p0) & 1] + (size_t)f * rows * nm * 2, host_in + ((size_t)f * n + r0[k]) * nm * 16, (size_t)rows * nm * 16,
                                           hipMemcpyHostToDevice, c->pipe_up);
       if (e != hipSuccess) return e;
     }
@@ -3595,20 +3616,20 @@ extern "C" int bms_transform_abd_pipelined(bms_ctx* c, const double* u, const vo
   c->piece_tables = &shared_tables;
   c->piece_tables_valid = false;
   c->async_pieces = true;
-  hipError_t he = upload_piece(0);
+  hipError_t he = upload_piece(p0);
   if (he != hipSuccess) {
     give_back();
     return fail(c, BMS_ERR_HIP, "pipelined upload: %s", hipGetErrorString(he));
   }
-  for (int k = 0; k < pieces && rc == BMS_OK; ++k) {
-    if (k > 0 && k + 1 < pieces && (he = upload_piece(k + 1)) != hipSuccess) break;
+  for (int k = p0; k < p1 && rc == BMS_OK; ++k) {
+    if (k > p0 && k + 1 < p1 && (he = upload_piece(k + 1)) != hipSuccess) break;
     if ((he = hipStreamWaitEvent(c->stream, ev_up[k], 0)) != hipSuccess) break;
-    if (k >= 2 && (he = hipStreamWaitEvent(c->stream, ev_dn[k - 2], 0)) != hipSuccess) break;  // its output buffer has left
+    if (k >= p0 + 2 && (he = hipStreamWaitEvent(c->stream, ev_dn[k - 2], 0)) != hipSuccess) break;  // its output buffer has left
     const bms_shard sh = {r0[k], r1[k] - r0[k], cut[k], cut[k + 1], 0, 0};
     int64_t got = 0, first = 0;
-    rc = transform_abd_impl(c, u, d_in[k & 1], BMS_DEVICE, n, ell_max, tr, &sh, u_out + (cut[k] - i_lo), d_out[k & 1], &got, &first);
+    rc = transform_abd_impl(c, u, d_in[(k - p0) & 1], BMS_DEVICE, n, ell_max, tr, &sh, u_out + (cut[k] - i_lo), d_out[(k - p0) & 1], &got, &first);
     if (rc) break;
-    if (k == 0 && pieces > 1 && (he = upload_piece(1)) != hipSuccess) break;  // (after piece 0's blocking table read-back)
+    if (k == p0 && p0 + 1 < p1 && (he = upload_piece(p0 + 1)) != hipSuccess) break;  // (after piece 0's blocking table read-back)
     if (got != cut[k + 1] - cut[k] || first != cut[k]) {
       rc = fail(c, BMS_ERR_HIP, "pipelined shard [%lld, %lld) produced %lld rows from %lld", (long long)cut[k], (long long)cut[k + 1],
                 (long long)got, (long long)first);
@@ -3617,7 +3638,7 @@ extern "C" int bms_transform_abd_pipelined(bms_ctx* c, const double* u, const vo
     if ((he = hipEventRecord(ev_c[k], c->stream)) != hipSuccess) break;
     if ((he = hipEventSynchronize(ev_c[k])) != hipSuccess) break;
     for (int f = 0; f < 6 && he == hipSuccess; ++f)
-      he = hipMemcpyAsync(host_out + ((size_t)f * n_new + (cut[k] - i_lo)) * n_out * 16, d_out[k & 1] + (size_t)f * got * n_out * 2,
+      he = hipMemcpyAsync(host_out + ((size_t)f * n_new + (cut[k] - i_lo)) * n_out * 16, d_out[(k - p0) & 1] + (size_t)f * got * n_out * 2,
                           (size_t)got * n_out * 16, hipMemcpyDeviceToHost, c->pipe_down);
     if (he != hipSuccess) break;
     if ((he = hipEventRecord(ev_dn[k], c->pipe_down)) != hipSuccess) break;

@@ -6,6 +6,8 @@ The scri-compatible classes in ``scri_amd.waveform_modes`` etc. are built on top
 """
 import ctypes
 import os
+import threading
+
 import numpy as np
 
 from . import _lib
@@ -134,7 +136,110 @@ PIPELINE_MIN_BYTES = 64 << 20
 PIPELINE_PIECES = int(os.environ.get("SCRI_AMD_PIPELINE_PIECES", "10"))  # cfg3, round 2: 15.5 ms at 4 pieces, 15.0 at 6, 13.9 at 8, 13.6 at 10 (26.9 as one call)
 
 
-def _transform_modes_pipelined(t, data, inp, transformation, n_out, ctx):
+_device_contexts = {}  # (device, slot) -> Context of the one-process multi-device calls (slot: the k-th context on that device)
+_device_contexts_lock = threading.Lock()
+
+
+def default_devices():
+    """SCRI_AMD_DEVICES = "0,1,2,3" (or "all"): the devices host-memory transformations of long series are dealt over when the caller
+    names none -- existing callers of w.transform(**kw) / abd.transform(**kw) then use every GPU of the node unchanged.  Unset: one."""
+    env = os.environ.get("SCRI_AMD_DEVICES", "").strip()
+    if not env:
+        return None
+    if env == "all":
+        import torch  # (device_count() does not initialise the GPU)
+
+        return list(range(max(torch.cuda.device_count(), 1)))
+    return [int(x) for x in env.split(",") if x.strip() != ""]
+
+
+def contexts_for(devices, first=None):
+    """One context per entry of `devices` (a device named k times gets k contexts: on a one-GPU box `[0, 0, 0, 0]` runs the
+    four-way code path).  Kept for the life of the process -- their work space is what makes the second call fast.  `first`: a
+    context the caller already has; it serves the first entry that names its device."""
+    out, counts = [], {}
+    with _device_contexts_lock:
+        for d in devices:
+            d = int(d)
+            slot = counts.get(d, 0)
+            counts[d] = slot + 1
+            if first is not None and first.device == d and slot == 0:
+                out.append(first)
+                continue
+            ctx = _device_contexts.get((d, slot))
+            if ctx is None or not ctx.handle:
+                ctx = _device_contexts[(d, slot)] = _lib.Context(d)
+            out.append(ctx)
+    return out
+
+
+def pieces_for(devices):
+    """How many time shards a multi-device call cuts the output window into: at least three per context (upload, kernels and
+    download of neighbouring shards overlap inside each context as in the one-context pipeline)"""
+    n = len(devices)
+    return n * max(3, -(-PIPELINE_PIECES // n))
+
+
+def _run_dealt(ctxs, pieces, call):
+    """call(ctx, piece0, piece1) on one host thread per context (ctypes releases the GIL inside the library; a context is used
+    by one thread at a time: the threading contract of include/scri_amd.h).  Returns the exceptions, per context."""
+    n = len(ctxs)
+    errors = [None] * n
+
+    def run(k):
+        try:
+            p0, p1 = (pieces * k) // n, (pieces * (k + 1)) // n
+            if p1 > p0:
+                call(ctxs[k], p0, p1)
+        except BaseException as e:  # noqa: BLE001 -- re-raised by the caller's thread
+            errors[k] = e
+
+    threads = [threading.Thread(target=run, args=(k,)) for k in range(1, n)]
+    for th in threads:
+        th.start()
+    run(0)
+    for th in threads:
+        th.join()
+    return errors
+
+
+def _raise_dealt(errors):
+    """None if every context finished; "unsupported" if the series is one the engine does not shard; raises anything else"""
+    if any(isinstance(e, NotImplementedError) for e in errors):
+        return "unsupported"
+    for e in errors:
+        if e is not None:
+            raise e
+    return None
+
+
+def _transform_modes_multi(t, data, inp, transformation, n_out, ctxs, pieces):
+    """bms_transform_modes_pipelined_part on one context per device: the `pieces` time shards of the output window dealt in
+    contiguous runs over the contexts, slice + halo shipped at upload time (no GPU-to-GPU traffic).  None: not sharded."""
+    if not np.all(np.diff(t) > 0):
+        return None
+    i_lo, i_hi = output_window(t, transformation, ctx=ctxs[0])
+    n_new = i_hi - i_lo
+    if n_new < 8 * pieces:
+        return None
+    out = _lib.pinned_empty((n_new, n_out), np.complex128)
+    t_out = np.empty(n_new, dtype=float)
+    lib = _lib.load()
+
+    def call(ctx, p0, p1):
+        got = c_i64(0)
+        rc = lib.bms_transform_modes_pipelined_part(ctx.handle, ctypes.byref(inp), ctypes.byref(transformation), pieces, p0, p1,
+                                                    dptr(t_out), vptr(out), ctypes.byref(got))
+        ctx.check(rc, "bms_transform_modes_pipelined_part")
+        if got.value != n_new:
+            raise RuntimeError(f"pieces [{p0}, {p1}): the window has {got.value} rows on device {ctx.device}, {n_new} here")
+
+    if _raise_dealt(_run_dealt(ctxs, pieces, call)) == "unsupported":
+        return None
+    return t_out, out
+
+
+def _transform_modes_pipelined(t, data, inp, transformation, n_out, ctx, pieces=None):
     """Host-memory callers of a long series wait for PCIe, not for the kernels (cfg3: 456 MB each way against 6 ms of
     kernels), and one call does upload -> kernels -> download one after the other.  bms_transform_modes_pipelined cuts the
     output range into PIPELINE_PIECES time shards (bms_shard_plan names the input rows each one needs, exactly as for the
@@ -142,17 +247,18 @@ def _transform_modes_pipelined(t, data, inp, transformation, n_out, ctx):
     are those of the sharded path (equal to the one-call path to rounding; tests/test_gpu_sharding.py).  Returns None when
     the series cannot be sharded (graded time steps).  SCRI_AMD_PIPELINE_THREADS=1: round 1's version of the same idea
     (two contexts fed by two host threads)."""
-    if not os.environ.get("SCRI_AMD_PIPELINE_THREADS"):
+    if pieces is not None or not os.environ.get("SCRI_AMD_PIPELINE_THREADS"):
+        pieces = int(pieces or PIPELINE_PIECES)
         if not np.all(np.diff(t) > 0):
             return None  # the one-call path raises the ValueError the reference's callers expect
         i_lo, i_hi = output_window(t, transformation, ctx=ctx)
         n_new = i_hi - i_lo
-        if n_new < 8 * PIPELINE_PIECES:
+        if n_new < 8 * pieces:
             return None
         out = _lib.pinned_empty((n_new, n_out), np.complex128)
         t_out = np.empty(n_new, dtype=float)
         got = c_i64(0)
-        rc = _lib.load().bms_transform_modes_pipelined(ctx.handle, ctypes.byref(inp), ctypes.byref(transformation), PIPELINE_PIECES,
+        rc = _lib.load().bms_transform_modes_pipelined(ctx.handle, ctypes.byref(inp), ctypes.byref(transformation), pieces,
                                                        dptr(t_out), vptr(out), ctypes.byref(got))
         try:
             ctx.check(rc, "bms_transform_modes_pipelined")
@@ -230,6 +336,8 @@ def transform_modes(
     out_ptr=None,
     shard=None,
     grid=False,
+    devices=None,
+    pieces=None,
 ):
     """bms_transform_modes.  Host mode: data complex128 [N, n_modes] -> (t_out[N'], data_out[N', n_out]).
     grid=True (host mode, no shard): bms_modes_to_grid instead -- the field on the distorted grid at the new time slices,
@@ -241,8 +349,16 @@ def transform_modes(
     rows [data_row0, data_row0 + data_rows); outputs are those with global input index in [out_i0, out_i1);
     the returned tuple then has the first global index appended.  Two more entries (col_part, col_parts) select a
     part of the grid columns (include/scri_amd.h, bms_shard): the output is then that part's contribution, to be
-    summed over the parts."""
-    ctx = _ctx(ctx)
+    summed over the parts.
+    devices (host mode, no shard, no aux): the GPUs of this process the time shards of the pipelined call are dealt over, one
+    context and one host thread per entry, e.g. [0, 1, ..., 7] (default: SCRI_AMD_DEVICES, else the one context `ctx`); every
+    device receives its own rows + halo at upload time.  pieces: the number of time shards (default PIPELINE_PIECES on one
+    context, pieces_for(devices) on several); the result depends on `pieces` only (to rounding), not on how they are dealt."""
+    if devices is None and not device and shard is None and not grid and not aux:
+        devices = default_devices()
+    if devices is not None and (device or shard is not None or grid or aux):
+        raise ValueError("`devices` deals a whole host-memory series over several GPUs: no shard, no device pointers, no psi companions")
+    ctx = _ctx(ctx) if not devices else contexts_for(devices[:1], first=ctx)[0]
     t = np.ascontiguousarray(t, dtype=float)
     n = t.shape[0]
     inp = bms_wm_input()
@@ -307,8 +423,13 @@ def transform_modes(
         return t_out[: n_new.value], out[: n_new.value]
     if not device:
         _lib.register_if_reused(data)  # an input array seen for the second time is page-locked in place: uploads at PCIe rate
-    if shard is None and not aux and data.nbytes >= PIPELINE_MIN_BYTES and not os.environ.get("SCRI_AMD_NO_PIPELINE"):
-        res = _transform_modes_pipelined(t, data, inp, transformation, n_out, ctx)
+    if devices:
+        ctxs = contexts_for(devices, first=ctx)
+        res = _transform_modes_multi(t, data, inp, transformation, n_out, ctxs, int(pieces or pieces_for(devices)))
+        if res is not None:
+            return res
+    elif shard is None and not aux and (pieces is not None or data.nbytes >= PIPELINE_MIN_BYTES) and not os.environ.get("SCRI_AMD_NO_PIPELINE"):
+        res = _transform_modes_pipelined(t, data, inp, transformation, n_out, ctx, pieces=pieces)
         if res is not None:
             return res
     out = _lib.pinned_empty((max(n_alloc, 1), n_out), np.complex128)
@@ -344,14 +465,20 @@ def shard_plan(t, transformation, out_i0, out_i1, ctx=None):
     return (need[0], need[1]), (win[0], win[1])
 
 
-def transform_abd(u, raw, ell_max, transformation, ctx=None, shard=None, device=False, out_ptr=None):
+def transform_abd(u, raw, ell_max, transformation, ctx=None, shard=None, device=False, out_ptr=None, devices=None, pieces=None):
     """bms_transform_abd[_shard]: raw complex128 [6, N, (ell_max+1)^2] -> (u_out[N'], raw_out[6, N', n_out]).
 
     shard = (data_row0, data_rows, out_i0, out_i1): `u` stays the GLOBAL time axis, `raw` holds rows
     [data_row0, data_row0 + data_rows) of every field, and the result carries a third element, the global input
     index of output row 0.  device=True: `raw` and `out_ptr` are device pointers (c16[6][data_rows][n_modes] and
-    c16[6][out_i1 - out_i0][n_out]); returns (u_out, n_new[, first])."""
-    ctx = _ctx(ctx)
+    c16[6][out_i1 - out_i0][n_out]); returns (u_out, n_new[, first]).
+    devices / pieces (host arrays, no shard): as transform_modes -- the time shards of the pipelined call dealt over one context
+    per device of this process."""
+    if devices is None and not device and shard is None:
+        devices = default_devices()
+    if devices is not None and (device or shard is not None):
+        raise ValueError("`devices` deals a whole host-memory series over several GPUs: no shard, no device pointers")
+    ctx = _ctx(ctx) if not devices else contexts_for(devices[:1], first=ctx)[0]
     u = np.ascontiguousarray(u, dtype=float)
     n = u.shape[0]
     n_rows = n if shard is None else int(shard[1])
@@ -385,10 +512,26 @@ def transform_abd(u, raw, ell_max, transformation, ctx=None, shard=None, device=
         fs_out = i_hi - i_lo
         u_out = np.empty(max(fs_out, 1), dtype=float)
     out = _lib.pinned_empty((6, max(fs_out, 1), n_out), np.complex128)
-    if (shard is None and raw.nbytes >= PIPELINE_MIN_BYTES and fs_out >= 8 * PIPELINE_PIECES and not os.environ.get("SCRI_AMD_NO_PIPELINE")):
+    n_pieces = int(pieces or (pieces_for(devices) if devices else PIPELINE_PIECES))
+    if devices and fs_out >= 8 * n_pieces and np.all(np.diff(u) > 0):
+        # one process, several GPUs: the time shards dealt over one context per device, rows + halo shipped at upload time
+        lib = _lib.load()
+
+        def call(cx, p0, p1):
+            got = c_i64(0)
+            rc_ = lib.bms_transform_abd_pipelined_part(cx.handle, dptr(u), vptr(raw), n, int(ell_max), ctypes.byref(transformation), n_pieces,
+                                                       p0, p1, dptr(u_out), vptr(out), ctypes.byref(got))
+            cx.check(rc_, "bms_transform_abd_pipelined_part")
+            if got.value != out.shape[1]:
+                raise RuntimeError(f"pieces [{p0}, {p1}): the window has {got.value} rows on device {cx.device}, {out.shape[1]} here")
+
+        if _raise_dealt(_run_dealt(contexts_for(devices, first=ctx), n_pieces, call)) is None:
+            return u_out, out
+    elif (shard is None and (pieces is not None or raw.nbytes >= PIPELINE_MIN_BYTES) and fs_out >= 8 * n_pieces
+          and not os.environ.get("SCRI_AMD_NO_PIPELINE")):
         # a long series in host memory: uploads, kernels and downloads of consecutive time shards side by side
         rc = _lib.load().bms_transform_abd_pipelined(
-            ctx.handle, dptr(u), vptr(raw), n, int(ell_max), ctypes.byref(transformation), PIPELINE_PIECES, dptr(u_out), vptr(out),
+            ctx.handle, dptr(u), vptr(raw), n, int(ell_max), ctypes.byref(transformation), n_pieces, dptr(u_out), vptr(out),
             ctypes.byref(n_new),
         )
         try:

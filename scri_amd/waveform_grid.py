@@ -200,6 +200,13 @@ def transform(w_modes, **kwargs):
             "Expected WaveformModes object in argument 1; " "got `{}` instead.".format(type(w_modes).__name__)
         )
     ell_max_out = kwargs.pop("ell_max", w_modes.ell_max)
+    # scri_amd extension (not in the reference): `group` = a torch.distributed process group over whose ranks the time axis of the
+    # series is split -- `w_modes` then holds THIS rank's contiguous block of rows, and so does the result (scri_amd/sharding.py)
+    group = kwargs.pop("group", None)
+    partition = kwargs.pop("partition", "auto")
+    overlap_halo = kwargs.pop("overlap_halo", False)
+    # ... and `devices` = the GPUs of THIS process a long host-memory series is dealt over (engine.transform_modes; default SCRI_AMD_DEVICES)
+    devices = kwargs.pop("devices", None)
     original_kwargs = kwargs.copy()
     supertranslation, frame_rotation, boost_velocity, n_theta, n_phi, type_term, aux = _prepare(w_modes, kwargs)
     s = w_modes.spin_weight
@@ -216,7 +223,22 @@ def transform(w_modes, **kwargs):
     tr = engine.make_transformation(supertranslation, frame_rotation, boost_velocity, n_theta, n_phi, ell_max_out)
     dev_out = None
     trailing = tuple(w_modes._data_shape()[2:])
-    if trailing:
+    if group is not None:
+        from . import sharding
+
+        if trailing or aux:
+            raise NotImplementedError("a series sharded over a process group carries neither trailing data dimensions nor psi companions")
+        t_global, have = sharding.gather_time_axis(w_modes.t, group)
+        resident = getattr(w_modes, "is_device_resident", False)
+        t_new, rows, _ = sharding.transform_modes_sharded(
+            w_modes._dev if resident else w_modes.data, t_global, w_modes.ell_min, w_modes.ell_max, s, w_modes.conformal_weight, type_term, tr,
+            group=group, have=have, partition=partition, overlap=overlap_halo, ctx=w_modes._ctx,
+        )
+        if resident:
+            dev_out, data_new = rows, np.empty((0, 0))
+        else:
+            data_new = rows
+    elif trailing:
         # Extra trailing data dimensions (scri/waveform_grid.py:299-308, 574-594: `final_dim`): every trailing index is an
         # independent series under the same transformation -- to_modes and the spline loop of from_modes walk them one by one --
         # so each goes through the engine on its own and the results are stacked back.  (The reference's own from_modes cannot be
@@ -250,7 +272,7 @@ def transform(w_modes, **kwargs):
     else:
         t_new, data_new = engine.transform_modes(
             w_modes.t, w_modes.data, w_modes.ell_min, w_modes.ell_max, s, w_modes.conformal_weight, type_term, tr,
-            aux=aux, ctx=w_modes._ctx,
+            aux=aux, ctx=w_modes._ctx, devices=None if aux else devices,
         )
     if kwargs:
         warnings.warn("\nUnused kwargs passed to this function:\n{}".format(pprint.pformat(kwargs, width=1)))

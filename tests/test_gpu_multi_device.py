@@ -1,0 +1,102 @@
+"""One process, several devices, numpy in / numpy out (engine.transform_modes / transform_abd with `devices=[...]`): the time
+shards of the pipelined call dealt over one context and one host thread per entry.  On a one-GPU box the entries all name
+device 0 -- four contexts, four threads, the same code path -- and the result must equal the single-context pipelined call with
+the same number of time shards BIT FOR BIT (a shard's arithmetic depends on its cut only), and the default call to rounding.
+Callers: scri/waveform_modes.py:705-719, scri/asymptotic_bondi_data/transformations.py:391-412, map_to_superrest_frame.py:1029."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("axis", ["uniform", "sxs"])
+def test_cfg3_four_contexts_bit_identical_to_one(ctx, axis):
+    from scri_amd import engine, synthetic
+
+    t, data, spec = synthetic.workload("cfg3", axis=axis)  # full size: 1e5 x 285
+    kw = spec["kwargs"]
+    tr = engine.make_transformation(kw["supertranslation"], kw["frame_rotation"], kw["boost_velocity"], 37, 37, 16)
+    args = (t, data, 2, 16, -2, -1, engine.BMS_TERM_H, tr)
+    devices = [0, 0, 0, 0]
+    pieces = engine.pieces_for(devices)
+    assert pieces == 12
+    t_one, d_one = engine.transform_modes(*args, ctx=ctx, pieces=pieces)
+    t_four, d_four = engine.transform_modes(*args, ctx=ctx, devices=devices)
+    assert np.array_equal(t_four, t_one) and np.array_equal(d_four, d_one)
+    # however the shards are dealt: three contexts, five contexts, the same twelve shards
+    for devs in ([0, 0, 0], [0] * 5):
+        t_k, d_k = engine.transform_modes(*args, ctx=ctx, devices=devs, pieces=pieces)
+        assert np.array_equal(t_k, t_one) and np.array_equal(d_k, d_one)
+    # against the default call (ten shards) and the one-call device path: rounding
+    t_def, d_def = engine.transform_modes(*args, ctx=ctx)
+    assert np.array_equal(t_def, t_one)
+    assert np.abs(d_def - d_one).max() < 1e-14 * np.abs(d_def).max()
+
+
+def test_cfg5_slice_four_contexts_bit_identical_to_one(ctx):
+    from scri_amd import engine, synthetic
+
+    u, raw, spec = synthetic.abd_workload("cfg5", n_times=3000)  # l <= 24, six fields, 99 x 99 working grid
+    kw, L = spec["kwargs"], spec["ell_max"]
+    n_theta = 2 * (2 * L + 1) + 1
+    tr = engine.make_transformation(kw["supertranslation"], kw["frame_rotation"], kw["boost_velocity"], n_theta, n_theta, L)
+    devices = [0, 0, 0, 0]
+    pieces = engine.pieces_for(devices)
+    u_one, r_one = engine.transform_abd(u, raw, L, tr, ctx=ctx, pieces=pieces)
+    u_four, r_four = engine.transform_abd(u, raw, L, tr, ctx=ctx, devices=devices)
+    assert np.array_equal(u_four, u_one) and np.array_equal(r_four, r_one)
+    u_def, r_def = engine.transform_abd(u, raw, L, tr, ctx=ctx)
+    assert np.array_equal(u_def, u_one)
+    assert np.abs(np.asarray(r_def) - r_one).max() < 1e-14 * max(1.0, np.abs(r_def).max())
+
+
+def test_devices_keyword_of_the_scri_level_calls(ctx, monkeypatch):
+    """w.transform(devices=...) / abd.transform(devices=...) and the SCRI_AMD_DEVICES default: the caller's two-line change"""
+    import scri_amd
+    from scri_amd import engine, synthetic
+
+    t, data, spec = synthetic.workload("cfg3", n_times=8000)
+    kw = dict(spec["kwargs"])
+    data = np.ascontiguousarray(data[:, : 9 * 9 - 4])
+    w = scri_amd.WaveformModes(t=t, data=data, ell_min=2, ell_max=8, dataType=scri_amd.h, frameType=scri_amd.Inertial,
+                               r_is_scaled_out=True, m_is_scaled_out=True, ctx=ctx)
+    ref = w.transform(**kw)
+    got = w.transform(devices=[0, 0], **kw)
+    assert np.array_equal(got.t, ref.t) and np.abs(got.data - ref.data).max() < 1e-14 * np.abs(ref.data).max()
+    monkeypatch.setenv("SCRI_AMD_DEVICES", "0,0,0")
+    assert engine.default_devices() == [0, 0, 0]
+    env = w.transform(**kw)  # an unchanged caller
+    assert np.array_equal(env.t, ref.t) and np.abs(env.data - ref.data).max() < 1e-14 * np.abs(ref.data).max()
+    monkeypatch.delenv("SCRI_AMD_DEVICES")
+
+    from test_gpu_sharding import _abd_case
+
+    u, raw, _, L = _abd_case(n=2000, ell_max=4)
+    abd = scri_amd.AsymptoticBondiData(u, L, ctx=ctx)
+    abd._raw_data[:] = raw
+    st = np.zeros(9, dtype=complex)
+    st[0], st[2], st[6] = 0.3, 0.05, 0.02
+    kw_abd = dict(supertranslation=st, frame_rotation=[0.9, 0.1, -0.3, 0.2], boost_velocity=[2e-3, -1e-3, 3e-3])
+    ref = abd.transform(**kw_abd)
+    got = abd.transform(devices=[0, 0, 0], **kw_abd)
+    assert np.array_equal(got.t, ref.t)
+    assert np.abs(got._raw_data - ref._raw_data).max() < 1e-14 * max(1.0, np.abs(ref._raw_data).max())
+
+
+def test_errors_of_one_context_reach_the_caller(ctx):
+    """a series that is not increasing goes to the one-call path, whose check raises what the reference's callers expect; a bad
+    device index raises from the context's creation; `devices` with a shard is refused"""
+    from scri_amd import _lib, engine, synthetic
+
+    t, data, spec = synthetic.workload("cfg3", n_times=4000)
+    kw = spec["kwargs"]
+    data = np.ascontiguousarray(data[:, : 9 * 9 - 4])
+    tr = engine.make_transformation(kw["supertranslation"], kw["frame_rotation"], kw["boost_velocity"], 21, 21, 8)
+    bad = t.copy()
+    bad[2000] = bad[1999]
+    with pytest.raises(ValueError):
+        engine.transform_modes(bad, data, 2, 8, -2, -1, engine.BMS_TERM_H, tr, ctx=ctx, devices=[0, 0])
+    with pytest.raises((ValueError, _lib.BMSError)):
+        engine.transform_modes(t, data, 2, 8, -2, -1, engine.BMS_TERM_H, tr, ctx=ctx, devices=[0, 99])
+    with pytest.raises(ValueError, match="devices"):
+        engine.transform_modes(t, data, 2, 8, -2, -1, engine.BMS_TERM_H, tr, ctx=ctx, devices=[0, 0], shard=(0, 4000, 0, 4000))

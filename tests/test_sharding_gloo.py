@@ -263,3 +263,178 @@ def test_choose_partition():
     assert sharding.choose_partition(have, [(0, 140), (90, 200)]) == "columns"
     assert sharding.choose_partition(have, [(0, 0), (100, 100)]) == "rows"  # nothing to produce
     assert sharding.padded_rows(10, 4) == (12, 3)
+
+
+# ------------------------------------------------------------------------------------------------- the library functions
+# scri_amd.sharding.ShardedTransform / transform_modes_sharded / transform_abd_sharded and the `group=` keyword of
+# WaveformModes.transform / AsymptoticBondiData.transform: the plan -> halo -> shard call -> row placement that bench.py and a
+# multi-GPU caller run.  No GPU here, so the per-shard arithmetic is the oracle (`compute=`; for the class methods the engine's
+# two entry points are replaced by oracle-backed stand-ins inside the worker processes): what is tested is everything AROUND
+# the shard call.
+def _oracle_compute_modes(kw, ell_max):
+    def compute(t_global, ext, shard):
+        from oracle import waveform_grid_ref as grid_ref
+        from oracle.containers import WM, h
+
+        if len(shard) == 6 and shard[5] > 1:  # a part of the grid columns over all times
+            w = WM(t=t_global, data=ext, ell_min=2, ell_max=ell_max, dataType=h)
+            uprm, grid, n_th, n_ph = grid_ref.from_modes(w, **kw)
+            mask = (np.arange(n_th * n_ph) % shard[5] == shard[4]).reshape(n_th, n_ph)
+            return uprm, grid_ref.to_modes(uprm, grid * mask[None], -2, ell_max), None
+        idx, t_out, data = _oracle_shard(t_global, ext, shard[0], shard[2], shard[3], kw, ell_max)
+        return t_out, data, (idx[0] if idx.size else shard[2])
+
+    return compute
+
+
+def _oracle_compute_abd(kw, ell_max):
+    def compute(u_global, ext, shard):
+        from oracle import abd_ref
+        from oracle.containers import ABD
+
+        row0, n_rows, o0, o1 = shard[:4]
+        sub = abd_ref.transform(ABD(u_global[row0 : row0 + n_rows], ext, ell_max), **kw)
+        tt = kw["supertranslation"][0].real / np.sqrt(4 * np.pi)
+        gamma = 1 / np.sqrt(1 - np.dot(kw["boost_velocity"], kw["boost_velocity"]))
+        uprm = (u_global - tt) / gamma
+        idx = np.searchsorted(uprm, sub.u - 1e-9)
+        keep = (idx >= o0) & (idx < o1)
+        return sub.u[keep], sub.raw[:, keep], (idx[keep][0] if keep.any() else o0)
+
+    return compute
+
+
+def _library_worker(rank, world, port, n_times, ell_max, tmpdir):
+    import torch
+    import torch.distributed as dist
+
+    import scri_amd
+    from scri_amd import engine, synthetic, sharding
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        t, _, spec = synthetic.workload("cfg3", n_times=n_times)
+        kw = dict(spec["kwargs"])
+        kw["boost_velocity"] = np.array([1.0, 2.0, 3.0]) * 1e-3
+        n_theta = 2 * (ell_max + 2) + 1
+        nm = (ell_max + 1) ** 2 - 4
+        tr = engine.make_transformation(kw["supertranslation"], kw["frame_rotation"], kw["boost_velocity"], n_theta, n_theta, ell_max)
+        compute = _oracle_compute_modes(kw, ell_max)
+        results = {}
+        # (i) near-equal blocks, one call; (ii) the same with the interior transformed under the exchange; (iii) UNEVEN blocks
+        uneven = [(0, 250), (250, n_times)]
+        for tag, have, overlap in (("even", None, False), ("overlap", None, True), ("uneven", uneven, False)):
+            st = sharding.ShardedTransform("modes", t, tr, 2, ell_max, -2, -1, engine.BMS_TERM_H, have=have, overlap=overlap, compute=compute)
+            assert st.partition == "rows" and (st.interior is not None) == overlap
+            _, mine, _ = synthetic.workload("cfg3", n_times=n_times, rows=st.have[rank])
+            mine = np.ascontiguousarray(mine[:, :nm])
+            t_out, rows, first = st(mine)
+            assert isinstance(rows, np.ndarray) and rows.shape == (t_out.size, nm) and t_out.size == st.n_out_rows
+            # a caller that keeps its rows in the exchange buffer: the same result, and a second call reuses the buffer
+            view = st.own_rows_view(like=torch.from_numpy(mine))
+            view.copy_(torch.from_numpy(mine))
+            t2, rows2, first2 = st(view)
+            assert first2 == first and np.array_equal(t2, t_out) and torch.equal(rows2, torch.from_numpy(rows))
+            results[tag] = (t_out, rows, first)
+        # (iv) the one-shot function; (v) the column partition through the same call
+        _, mine, _ = synthetic.workload("cfg3", n_times=n_times, rows=sharding.shard_bounds(n_times, world, rank))
+        mine = np.ascontiguousarray(mine[:, :nm])
+        t_f, rows_f, first_f = sharding.transform_modes_sharded(mine, t, 2, ell_max, -2, -1, engine.BMS_TERM_H, tr, compute=compute)
+        assert first_f == results["even"][2] and np.array_equal(rows_f, results["even"][1])
+        t_c, rows_c, first_c = sharding.transform_modes_sharded(mine, t, 2, ell_max, -2, -1, engine.BMS_TERM_H, tr, partition="columns", compute=compute)
+        results["columns"] = (t_c, rows_c, first_c)
+
+        # (vi) WaveformModes.transform(group=...) on a rank-local series: the engine's entry point replaced by the oracle
+        def fake_transform_modes(t_, data, ell_min, ell_max_, s, cw, term, tr_, aux=(), ctx=None, device=False, ld=None, out_ptr=None, shard=None, grid=False):
+            assert not device and shard is not None and (ell_min, ell_max_, s, cw, term) == (2, ell_max, -2, -1, engine.BMS_TERM_H)
+            return compute(np.asarray(t_), np.asarray(data), tuple(shard))
+
+        engine.transform_modes = fake_transform_modes
+        i0, i1 = sharding.shard_bounds(n_times, world, rank)
+        w = scri_amd.WaveformModes(t=t[i0:i1], data=mine, ell_min=2, ell_max=ell_max, dataType=scri_amd.h, frameType=scri_amd.Inertial,
+                                   r_is_scaled_out=True, m_is_scaled_out=True)
+        got = w.transform(group=dist.group.WORLD, **kw)
+        assert got.ell_min == 2 and got.ell_max == ell_max and np.array_equal(got.t, results["even"][0]) and np.array_equal(got.data, results["even"][1])
+        np.savez(os.path.join(tmpdir, f"lib{rank}.npz"), **{f"{k}_{i}": v for k, r in results.items() for i, v in enumerate(r)})
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(900)
+def test_two_rank_library_functions_equal_global(tmp_path):
+    import torch.multiprocessing as mp
+
+    from oracle import waveform_grid_ref as grid_ref
+    from oracle.containers import WM, h
+    from scri_amd import synthetic
+
+    n_times, ell_max, world = 600, 4, 2
+    mp.spawn(_library_worker, args=(world, _free_port(), n_times, ell_max, str(tmp_path)), nprocs=world, join=True)
+    parts = [np.load(tmp_path / f"lib{r}.npz") for r in range(world)]
+    t, data, spec = synthetic.workload("cfg3", n_times=n_times)
+    kw = dict(spec["kwargs"])
+    kw["boost_velocity"] = np.array([1.0, 2.0, 3.0]) * 1e-3
+    nm = (ell_max + 1) ** 2 - 4
+    ref = grid_ref.transform(WM(t=t, data=data[:, :nm], ell_min=2, ell_max=ell_max, dataType=h), **kw)
+    scale = max(1.0, np.abs(ref.data).max())
+    for tag in ("even", "overlap", "uneven", "columns"):
+        t_sh = np.concatenate([p[f"{tag}_0"] for p in parts])
+        d_sh = np.concatenate([p[f"{tag}_1"] for p in parts])
+        firsts = [int(p[f"{tag}_2"]) for p in parts]
+        assert t_sh.shape == ref.t.shape and np.abs(t_sh - ref.t).max() < 1e-13, tag
+        assert firsts[1] == firsts[0] + parts[0][f"{tag}_0"].size, tag  # consecutive blocks of output rows, in rank order
+        assert np.abs(d_sh - ref.data).max() < 1e-13 * scale, tag
+
+
+def _library_abd_worker(rank, world, port, n_times, ell_max, tmpdir):
+    import torch.distributed as dist
+
+    import scri_amd
+    from scri_amd import engine, sharding
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        u, raw, kw = _abd_inputs(n_times, ell_max)
+        n_theta = 2 * (2 * ell_max + 1) + 1
+        tr = engine.make_transformation(kw["supertranslation"], [1, 0, 0, 0], kw["boost_velocity"], n_theta, n_theta, ell_max)
+        compute = _oracle_compute_abd(kw, ell_max)
+        i0, i1 = sharding.shard_bounds(n_times, world, rank)
+        mine = np.ascontiguousarray(raw[:, i0:i1])
+        u_out, raw_out, first = sharding.transform_abd_sharded(mine, u, ell_max, tr, compute=compute)
+        assert raw_out.shape == (6, u_out.size, (ell_max + 1) ** 2)
+
+        # AsymptoticBondiData.transform(group=...) on the rank-local object
+        def fake_transform_abd(u_, raw_, ell_max_, tr_, ctx=None, shard=None, device=False, out_ptr=None):
+            assert not device and shard is not None and ell_max_ == ell_max
+            return compute(np.asarray(u_), np.asarray(raw_), tuple(shard))
+
+        engine.transform_abd = fake_transform_abd
+        abd = scri_amd.AsymptoticBondiData(u[i0:i1], ell_max)
+        abd._raw_data[:] = mine
+        got = abd.transform(group=dist.group.WORLD, **kw)
+        assert got.n_times == u_out.size and np.array_equal(got.t, u_out) and np.array_equal(got._raw_data, raw_out)
+        np.savez(os.path.join(tmpdir, f"libabd{rank}.npz"), u=u_out, raw=raw_out, first=first)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(900)
+def test_two_rank_library_abd_equals_global(tmp_path):
+    import torch.multiprocessing as mp
+
+    from oracle import abd_ref
+    from oracle.containers import ABD
+
+    n_times, ell_max, world = 400, 2, 2
+    mp.spawn(_library_abd_worker, args=(world, _free_port(), n_times, ell_max, str(tmp_path)), nprocs=world, join=True)
+    parts = [np.load(tmp_path / f"libabd{r}.npz") for r in range(world)]
+    u, raw, kw = _abd_inputs(n_times, ell_max)
+    ref = abd_ref.transform(ABD(u, raw, ell_max), **kw)
+    assert int(parts[1]["first"]) == int(parts[0]["first"]) + parts[0]["u"].size
+    assert np.abs(np.concatenate([p["u"] for p in parts]) - ref.u).max() < 1e-13
+    got = np.concatenate([p["raw"] for p in parts], axis=1)
+    assert got.shape == ref.raw.shape and np.abs(got - ref.raw).max() < 1e-12 * max(1.0, np.abs(ref.raw).max())
