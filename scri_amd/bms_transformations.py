@@ -36,6 +36,10 @@ class Rotor(np.ndarray):
 # ------------------------------------------------------------------------------------------------ SL(2,C)
 
 
+_PAULI = np.array([[[0, 1], [1, 0]], [[0, -1j], [1j, 0]], [[1, 0], [0, -1]]], dtype=complex)
+_SIGMA_Y_FLIP = np.array([1.0, -1.0, 1.0])
+
+
 def fourvec_to_spin_matrix(fourvec):
     """Inner product of a four vector with the Pauli matrices (Penrose & Rindler vol. 1, eq. 1.2.39);
     scri/bms_transformations.py:10-24."""
@@ -67,10 +71,13 @@ def Lorentz_to_spin_matrix(lorentz):
 
 def pure_spin_matrix_to_Lorentz(A, is_rotation=None, tol=1e-14):
     """A unitary (rotation) or Hermitian (boost) spin matrix -> rotor / velocity; scri/bms_transformations.py:59-111."""
-    logA = scipy.linalg.logm(A)
-    nvec = np.array([(logA[1, 0] + logA[0, 1]) / 2, (logA[1, 0] - logA[0, 1]) / 2, (logA[0, 0] - logA[1, 1]) / 2])
-    nvec_re = np.array([nvec[0].imag, nvec[1].real, nvec[2].imag])
-    nvec_im = np.array([-nvec[0].real, nvec[1].imag, -nvec[2].real])
+    # log A = sum_k c_k sigma_k with c_k = tr(log A sigma_k) / 2.  The spin matrices of fourvec_to_spin_matrix are
+    # exp(i psi/2 (n_x sigma_x - n_y sigma_y + n_z sigma_z)) for a rotation and the same with psi -> i artanh(beta) for a boost, so the
+    # rotation generator sits in the imaginary parts of c and the boost generator in minus the real parts, each with the sign of
+    # the sigma_y component flipped.
+    c = np.einsum("ij,kji->k", scipy.linalg.logm(A), _PAULI) / 2
+    nvec_re = _SIGMA_Y_FLIP * c.imag
+    nvec_im = -_SIGMA_Y_FLIP * c.real
     if is_rotation is None:
         if np.linalg.norm(nvec_im) < tol:
             is_rotation = True

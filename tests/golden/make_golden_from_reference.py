@@ -35,6 +35,17 @@ quaternion, spherical_functions, spinsfast) and writes
   g15_ref_trailing_dims.npz  extra trailing data dimensions (scri/waveform_grid.py:299-308, 574-594): WaveformGrid.to_modes of two series
                             side by side, and the exception the reference's own transform raises on such data.
 
+  g16_ref_bms_algebra.npz   scri/bms_transformations.py:183-592 at its default ell_max = 12, |v| = 0.17, a generic real supertranslation
+                            (l <= 4): BMSTransformation.reorder for all 36 (input order, output order) pairs, .inverse for the six
+                            orders, two compositions; LorentzTransformation reorder (both ways), inverse, product.  The case table,
+                            the SL(2,C) bookkeeping and transform_supertranslation's statements are the reference's; the grid /
+                            quadrature arithmetic underneath it is the stand-ins'.
+
+  g17_ref_bit_transforms.npz  scri/utilities.py:194-406 and scri/SpEC/file_io/__init__.py:50-70 under the identity `njit`: xor_timeseries(_reverse),
+                            multishuffle forward and back (8/16/32/64 bit, six width tuples each), fletcher32 (odd and even
+                            lengths beyond one 360-word block), index_is_monotonic.  Integer / bit work: every byte is the
+                            reference's own (no arithmetic stand-in is involved).
+
 Only the .npz files travel; tests/test_golden.py checks the oracle (CPU) and the HIP path (GPU) against them.
 """
 import os
@@ -279,10 +290,135 @@ def g15():
     np.savez_compressed(os.path.join(HERE, "g15_ref_trailing_dims.npz"), source="/root/reference/scri (unmodified) on stand-ins", **out)
 
 
+ORDERS = [
+    ["supertranslation", "frame_rotation", "boost_velocity"],
+    ["supertranslation", "boost_velocity", "frame_rotation"],
+    ["frame_rotation", "supertranslation", "boost_velocity"],
+    ["frame_rotation", "boost_velocity", "supertranslation"],
+    ["boost_velocity", "supertranslation", "frame_rotation"],
+    ["boost_velocity", "frame_rotation", "supertranslation"],
+]
+
+
+def g16():
+    import scri.bms_transformations as bt
+
+    L = 12  # the reference's default; its reorder builds intermediate objects at the default and raises on any other (:419 -> :281)
+    S = np.zeros((L + 1) ** 2, dtype=complex)
+    S[:25] = _real_supertranslation(4, 161, 0.1)
+    q = np.array([0.7, -0.3, 0.5, 0.4])
+    q /= np.linalg.norm(q)
+    v = np.array([0.09, -0.11, 0.095])  # |v| = 0.171: second-order boost terms (3e-2) are far above the comparison bar
+    S2 = np.zeros((L + 1) ** 2, dtype=complex)
+    S2[:16] = _real_supertranslation(3, 162, 0.07)
+    q2 = np.array([-0.2, 0.6, 0.1, 0.75])
+    q2 /= np.linalg.norm(q2)
+    v2 = np.array([-0.05, 0.12, 0.03])
+
+    def parts(b):
+        return np.array(b.supertranslation), np.array(b.frame_rotation.components, dtype=float), np.array(b.boost_velocity, dtype=float)
+
+    out = dict(ell_max=L, S=S, q=q, v=v, S2=S2, q2=q2, v2=v2, orders=np.array(["|".join(o) for o in ORDERS]))
+    rS, rq, rv = np.zeros((6, 6, S.size), dtype=complex), np.zeros((6, 6, 4)), np.zeros((6, 6, 3))
+    for i, o_in in enumerate(ORDERS):
+        B = bt.BMSTransformation(supertranslation=S, frame_rotation=q, boost_velocity=v, order=list(o_in))
+        for j, o_out in enumerate(ORDERS):
+            R = B.reorder(list(o_out))
+            assert R.order == o_out
+            rS[i, j], rq[i, j], rv[i, j] = parts(R)
+    out.update(reorder_S=rS, reorder_q=rq, reorder_v=rv)
+    iS, iq, iv, io = np.zeros((6, S.size), dtype=complex), np.zeros((6, 4)), np.zeros((6, 3)), []
+    for i, o_in in enumerate(ORDERS):
+        Bi = bt.BMSTransformation(supertranslation=S, frame_rotation=q, boost_velocity=v, order=list(o_in)).inverse()
+        iS[i], iq[i], iv[i] = parts(Bi)
+        io.append("|".join(Bi.order))
+    out.update(inverse_S=iS, inverse_q=iq, inverse_v=iv, inverse_orders=np.array(io))
+    # an explicit output order of the inverse
+    Bx = bt.BMSTransformation(supertranslation=S, frame_rotation=q, boost_velocity=v, order=list(ORDERS[2])).inverse(output_order=list(ORDERS[4]))
+    out["inverse_explicit_S"], out["inverse_explicit_q"], out["inverse_explicit_v"] = parts(Bx)
+    # two compositions (other * self): normal order x normal order, and two mixed orders
+    for tag, (o1, o2) in (("a", (ORDERS[0], ORDERS[0])), ("b", (ORDERS[3], ORDERS[4]))):
+        B1 = bt.BMSTransformation(supertranslation=S, frame_rotation=q, boost_velocity=v, order=list(o1))
+        B2 = bt.BMSTransformation(supertranslation=S2, frame_rotation=q2, boost_velocity=v2, order=list(o2))
+        C = B1 * B2
+        out[f"compose_{tag}_S"], out[f"compose_{tag}_q"], out[f"compose_{tag}_v"] = parts(C)
+        out[f"compose_{tag}_orders"] = np.array(["|".join(o1), "|".join(o2), "|".join(C.order)])
+    # LorentzTransformation: reorder both ways, inverse (default and explicit order), product
+    fb, bf = ["frame_rotation", "boost_velocity"], ["boost_velocity", "frame_rotation"]
+    for tag, o_in, o_out in (("fb_bf", fb, bf), ("bf_fb", bf, fb)):
+        Lr = bt.LorentzTransformation(frame_rotation=q, boost_velocity=v, order=list(o_in)).reorder(list(o_out))
+        out[f"lorentz_reorder_{tag}_q"], out[f"lorentz_reorder_{tag}_v"] = np.array(Lr.frame_rotation.components), np.array(Lr.boost_velocity)
+        Li = bt.LorentzTransformation(frame_rotation=q, boost_velocity=v, order=list(o_in)).inverse()
+        assert Li.order == o_in[::-1]
+        out[f"lorentz_inverse_{tag[:2]}_q"], out[f"lorentz_inverse_{tag[:2]}_v"] = np.array(Li.frame_rotation.components), np.array(Li.boost_velocity)
+    Li = bt.LorentzTransformation(frame_rotation=q, boost_velocity=v, order=list(fb)).inverse(output_order=list(fb))
+    out["lorentz_inverse_fb_to_fb_q"], out["lorentz_inverse_fb_to_fb_v"] = np.array(Li.frame_rotation.components), np.array(Li.boost_velocity)
+    Lp = bt.LorentzTransformation(frame_rotation=q, boost_velocity=v, order=list(bf)) * bt.LorentzTransformation(frame_rotation=q2, boost_velocity=v2)
+    out["lorentz_product_q"], out["lorentz_product_v"] = np.array(Lp.frame_rotation.components), np.array(Lp.boost_velocity)
+    # transform_supertranslation on its own (bms_transformations.py:151-180)
+    out["transformed_S"] = bt.transform_supertranslation(S, bt.LorentzTransformation(frame_rotation=q, boost_velocity=v))
+    # the quirk: away from the default ell_max most reorders raise (the intermediate objects are built with ell_max = 12 and the
+    # padding of the shorter supertranslation goes negative, :419 -> :281): recorded per (input order, output order) pair at ell_max = 8
+    raises = np.zeros((6, 6), dtype=bool)
+    for i, o_in in enumerate(ORDERS):
+        for j, o_out in enumerate(ORDERS):
+            try:
+                bt.BMSTransformation(supertranslation=S[:81], frame_rotation=q, boost_velocity=v, ell_max=8, order=list(o_in)).reorder(list(o_out))
+            except ValueError:
+                raises[i, j] = True
+    out["reorder_at_ell_max_8_raises"] = raises
+    np.savez_compressed(os.path.join(HERE, "g16_ref_bms_algebra.npz"), source="scri/bms_transformations.py:183-592 (the reference's file, stand-ins underneath)", **out)
+
+
+def g17():
+    import scri.utilities as ut
+    from scri.SpEC.file_io import index_is_monotonic
+
+    rng = np.random.default_rng(171)
+    out = {}
+    # xor_timeseries / _reverse: complex [N, k] (the storage format's use), real [N, k], one row, one column
+    for tag, arr in (("c", rng.normal(size=(40, 5)) + 1j * rng.normal(size=(40, 5))), ("f", rng.normal(size=(33, 3))),
+                     ("row", rng.normal(size=(1, 6)) + 1j * rng.normal(size=(1, 6))), ("col", rng.normal(size=(17, 1)))):
+        x = ut.xor_timeseries(arr.copy())
+        back = ut.xor_timeseries_reverse(x.copy())
+        assert np.array_equal(back.view(np.uint64), arr.view(np.uint64))
+        out[f"xor_{tag}_in"], out[f"xor_{tag}_out"] = arr.view(np.uint64).copy(), x.view(np.uint64).copy()
+    # multishuffle: four word sizes, six width tuples each (uniform bits / bytes / whole word, straddling, decreasing, increasing)
+    tuples = {
+        8: [(1,) * 8, (8,), (4, 4), (3, 5), (2, 2, 4), (1, 7)],
+        16: [(1,) * 16, (8, 8), (16,), (5, 3, 7, 1), (8, 4, 2, 2), (1, 1, 2, 4, 8)],
+        32: [(1,) * 32, (8,) * 4, (32,), (11, 9, 12), (8, 8, 4, 4, 2, 2, 1, 1, 1, 1), (1, 3, 4, 8, 16)],
+        64: [(1,) * 64, (8,) * 8, (64,), (13, 17, 3, 31), (8, 8, 4, 4, 4, 4, 2, 2, 2, 2, 1, 1, 1, 1, 4, 16), (16, 16, 32)],
+    }
+    for bits, ws in tuples.items():
+        dt = np.dtype(f"u{bits // 8}")
+        # an odd element count: pieces straddle words everywhere.  (8-bit words: 31 elements -- the reference's unshuffle keeps its bit
+        # cursor in the word's own dtype, which numba widens but plain numpy scalars do not: past 255 bits it would wrap HERE only)
+        data = rng.integers(0, 2**bits, size=31 if bits == 8 else 61, dtype=dt)
+        out[f"shuffle_{bits}_in"] = data
+        for k, w in enumerate(ws):
+            sh = ut.multishuffle(tuple(w))(data.copy())
+            un = ut.multishuffle(tuple(w), forward=False)(sh.copy())
+            assert sh.dtype == dt and np.array_equal(un, data), (bits, w)
+            out[f"shuffle_{bits}_{k}_widths"], out[f"shuffle_{bits}_{k}_out"], out[f"shuffle_{bits}_{k}_back"] = np.array(w), sh, un
+    # fletcher32: lengths below, at and beyond the 360-word block, odd and even; one float array
+    for n in (1, 2, 359, 360, 361, 721, 1001, 1440):
+        d = rng.integers(0, 2**16, size=n, dtype=np.uint16)
+        out[f"fletcher_{n}_in"], out[f"fletcher_{n}_out"] = d, np.uint32(ut.fletcher32(d))
+    f = rng.normal(size=(37, 5))
+    out["fletcher_f8_in"], out["fletcher_f8_out"] = f, np.uint32(ut.fletcher32(f))
+    # index_is_monotonic: increasing with repeats and dips, decreasing, constant ends
+    for tag, y in (("up", np.array([0.0, 1, 2, 2, 3, 2.5, 2.9, 3.0, 3.1, 10, 9, 11])), ("down", np.array([5.0, 4, 4.5, 3, 3, 2, 2.5, 1, 0])),
+                   ("flat", np.array([1.0, 2, 0.5, 1.0])), ("noise", np.cumsum(rng.normal(0.3, 1.0, size=200)))):
+        out[f"mono_{tag}_in"], out[f"mono_{tag}_out"] = y, np.array(index_is_monotonic(y))
+    np.savez_compressed(os.path.join(HERE, "g17_ref_bit_transforms.npz"), source="scri/utilities.py:194-406, scri/SpEC/file_io/__init__.py:50-70 (the reference's files, identity njit)", **out)
+
+
 if __name__ == "__main__":
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
-        only = [f for f in (g10, g8, g9, g11, g12, g13, g14, g15) if "--" + f.__name__ in sys.argv]
-        for f in only or (g10, g8, g9, g11, g12, g13, g14, g15):
+        every = (g10, g8, g9, g11, g12, g13, g14, g15, g16, g17)
+        only = [f for f in every if "--" + f.__name__ in sys.argv]
+        for f in only or every:
             f()
             print("wrote", f.__name__)

@@ -1,0 +1,174 @@
+"""g16 / g17: fixtures computed by the reference's OWN files (tests/golden/make_golden_from_reference.py):
+scri/bms_transformations.py:183-592 (BMSTransformation / LorentzTransformation reorder, inverse, product) and
+scri/utilities.py:194-406 + scri/SpEC/file_io/__init__.py:50-70 (xor, multishuffle, fletcher32, index_is_monotonic: bytes).
+
+CPU: the oracle's restatements against the reference's bytes, and the repo's host-side group algebra (whose one grid
+operation, transform_supertranslation, is routed to the oracle HERE because there is no GPU) against the reference's values.
+GPU: scri_amd.bms_transformations as shipped (transform_supertranslation on the engine) <= 1e-13, kernels_bits.hip bit for bit."""
+import os
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+G16 = os.path.join(HERE, "golden", "g16_ref_bms_algebra.npz")
+G17 = os.path.join(HERE, "golden", "g17_ref_bit_transforms.npz")
+BAR = 1e-13
+
+
+def _orders(g):
+    return [o.split("|") for o in g["orders"]]
+
+
+def _check_bms(b, S, q, v, what):
+    assert np.abs(b.supertranslation - S).max() < BAR, what
+    assert np.abs(np.asarray(b.frame_rotation.components) - q).max() < BAR, what
+    assert np.abs(b.boost_velocity - v).max() < BAR, what
+
+
+def _run_g16(bt, ctx=None):
+    g = np.load(G16)
+    orders = _orders(g)
+    L = int(g["ell_max"])
+    S, q, v, S2, q2, v2 = (g[k] for k in ("S", "q", "v", "S2", "q2", "v2"))
+    kw = dict(ell_max=L) if ctx is None else dict(ell_max=L, ctx=ctx)
+    # reorder: all 36 (input order, output order) pairs
+    for i, o_in in enumerate(orders):
+        B = bt.BMSTransformation(supertranslation=S, frame_rotation=q, boost_velocity=v, order=list(o_in), **kw)
+        for j, o_out in enumerate(orders):
+            R = B.reorder(list(o_out))
+            assert R.order == o_out
+            _check_bms(R, g["reorder_S"][i, j], g["reorder_q"][i, j], g["reorder_v"][i, j], (o_in, o_out))
+    # inverse: six orders (default output order = the reversed one) and one explicit order
+    for i, o_in in enumerate(orders):
+        Bi = bt.BMSTransformation(supertranslation=S, frame_rotation=q, boost_velocity=v, order=list(o_in), **kw).inverse()
+        assert "|".join(Bi.order) == str(g["inverse_orders"][i])
+        _check_bms(Bi, g["inverse_S"][i], g["inverse_q"][i], g["inverse_v"][i], ("inverse", o_in))
+    Bx = bt.BMSTransformation(supertranslation=S, frame_rotation=q, boost_velocity=v, order=list(orders[2]), **kw).inverse(output_order=list(orders[4]))
+    _check_bms(Bx, g["inverse_explicit_S"], g["inverse_explicit_q"], g["inverse_explicit_v"], "inverse, explicit order")
+    # compositions
+    for tag in ("a", "b"):
+        o1, o2, oc = (x.split("|") for x in g[f"compose_{tag}_orders"])
+        B1 = bt.BMSTransformation(supertranslation=S, frame_rotation=q, boost_velocity=v, order=o1, **kw)
+        B2 = bt.BMSTransformation(supertranslation=S2, frame_rotation=q2, boost_velocity=v2, order=o2, **kw)
+        C = B1 * B2
+        assert C.order == oc
+        _check_bms(C, g[f"compose_{tag}_S"], g[f"compose_{tag}_q"], g[f"compose_{tag}_v"], ("compose", tag))
+    # transform_supertranslation on its own
+    got = bt.transform_supertranslation(S, bt.LorentzTransformation(frame_rotation=q, boost_velocity=v, ell_max=L), **({} if ctx is None else {"ctx": ctx}))
+    assert np.abs(got - g["transformed_S"]).max() < BAR
+
+
+def test_g16_lorentz_algebra_vs_reference():
+    """pure host arithmetic (SL(2,C) bookkeeping): no grid, no GPU"""
+    from scri_amd import bms_transformations as bt
+
+    g = np.load(G16)
+    q, v, q2, v2 = g["q"], g["v"], g["q2"], g["v2"]
+    fb, bf = ["frame_rotation", "boost_velocity"], ["boost_velocity", "frame_rotation"]
+    for tag, o_in, o_out in (("fb_bf", fb, bf), ("bf_fb", bf, fb)):
+        Lr = bt.LorentzTransformation(frame_rotation=q, boost_velocity=v, order=list(o_in)).reorder(list(o_out))
+        assert Lr.order == o_out
+        assert np.abs(Lr.frame_rotation.components - g[f"lorentz_reorder_{tag}_q"]).max() < BAR
+        assert np.abs(Lr.boost_velocity - g[f"lorentz_reorder_{tag}_v"]).max() < BAR
+        Li = bt.LorentzTransformation(frame_rotation=q, boost_velocity=v, order=list(o_in)).inverse()
+        assert Li.order == o_in[::-1]
+        assert np.abs(Li.frame_rotation.components - g[f"lorentz_inverse_{tag[:2]}_q"]).max() < BAR
+        assert np.abs(Li.boost_velocity - g[f"lorentz_inverse_{tag[:2]}_v"]).max() < BAR
+    Li = bt.LorentzTransformation(frame_rotation=q, boost_velocity=v, order=list(fb)).inverse(output_order=list(fb))
+    assert np.abs(Li.frame_rotation.components - g["lorentz_inverse_fb_to_fb_q"]).max() < BAR
+    assert np.abs(Li.boost_velocity - g["lorentz_inverse_fb_to_fb_v"]).max() < BAR
+    Lp = bt.LorentzTransformation(frame_rotation=q, boost_velocity=v, order=list(bf)) * bt.LorentzTransformation(frame_rotation=q2, boost_velocity=v2)
+    assert np.abs(Lp.frame_rotation.components - g["lorentz_product_q"]).max() < BAR
+    assert np.abs(Lp.boost_velocity - g["lorentz_product_v"]).max() < BAR
+    # the second-order boost terms are visible at this speed: the fixture is not a small-velocity case
+    assert np.linalg.norm(v) > 0.15
+    # the quirk recorded with the fixture: away from its default ell_max = 12 the reference's own reorder raises for most order pairs
+    # (its intermediate objects are built at 12); this implementation carries ell_max along and has no such case (GPU test below)
+    assert g["reorder_at_ell_max_8_raises"].sum() >= 24
+
+
+def test_g16_bms_algebra_host_logic_vs_reference(monkeypatch):
+    """the repo's two-step reorder / inverse / product against the reference's 190-line case table, all 36 order pairs; the grid
+    step (transform_supertranslation) is the oracle's here -- the GPU test below runs the same with the engine"""
+    from oracle import abd_ref
+    from scri_amd import bms_transformations as bt
+
+    def oracle_ts(S, lorentz, ell_max=None, ctx=None):
+        linv = lorentz.inverse(output_order=["frame_rotation", "boost_velocity"])
+        return abd_ref.transform_supertranslation(np.asarray(S, dtype=complex), linv.frame_rotation.components, linv.boost_velocity,
+                                                  lorentz.ell_max if ell_max is None else ell_max)
+
+    monkeypatch.setattr(bt, "transform_supertranslation", oracle_ts)
+    _run_g16(bt)
+
+
+@pytest.mark.gpu
+def test_g16_gpu_bms_algebra_vs_reference(ctx):
+    from scri_amd import bms_transformations as bt
+
+    _run_g16(bt, ctx=ctx)
+    # where the reference raises (ell_max = 8): every pair works here and round-trips
+    g = np.load(G16)
+    orders = _orders(g)
+    B = bt.BMSTransformation(supertranslation=g["S"][:81], frame_rotation=g["q"], boost_velocity=g["v"], ell_max=8, order=list(orders[3]), ctx=ctx)
+    for o in orders:
+        assert B.reorder(list(o)).reorder(list(orders[3])).is_close_to(B), o
+
+
+# ------------------------------------------------------------------------------------------------- g17: bytes
+def _g17_cases():
+    g = np.load(G17)
+    xor = [(k[4:-3], g[k], g[k[:-3] + "_out"]) for k in g.files if k.startswith("xor_") and k.endswith("_in")]
+    shuffles = []
+    for bits in (8, 16, 32, 64):
+        for k in range(6):
+            shuffles.append((bits, tuple(int(x) for x in g[f"shuffle_{bits}_{k}_widths"]), g[f"shuffle_{bits}_in"], g[f"shuffle_{bits}_{k}_out"],
+                             g[f"shuffle_{bits}_{k}_back"]))
+    fletcher = [(k[9:-3], g[k], int(g[k[:-3] + "_out"])) for k in g.files if k.startswith("fletcher_") and k.endswith("_in")]
+    mono = [(k[5:-3], g[k], g[k[:-3] + "_out"]) for k in g.files if k.startswith("mono_") and k.endswith("_in")]
+    assert len(xor) == 4 and len(shuffles) == 24 and len(fletcher) == 9 and len(mono) == 4
+    return xor, shuffles, fletcher, mono
+
+
+def test_g17_oracle_bit_transforms_vs_reference():
+    from oracle import file_io_ref, utilities_ref as ur
+
+    xor, shuffles, fletcher, mono = _g17_cases()
+    for tag, a, out in xor:
+        c = a.copy().view(np.float64)
+        assert np.array_equal(ur.xor_timeseries(c).view(np.uint64), out), tag
+        assert np.array_equal(ur.xor_timeseries_reverse(out.copy().view(np.float64)).view(np.uint64), a), tag
+    for bits, widths, data, out, back in shuffles:
+        assert np.array_equal(back, data)
+        assert np.array_equal(ur.multishuffle(data, widths), out), (bits, widths)
+        assert np.array_equal(ur.multishuffle(out, widths, forward=False), data), (bits, widths)
+    for tag, d, expect in fletcher:
+        assert int(ur.fletcher32(d)) == expect, tag
+    for tag, y, expect in mono:
+        assert np.array_equal(file_io_ref.index_is_monotonic(y), expect), tag
+
+
+def test_g17_host_index_is_monotonic_vs_reference():
+    from scri_amd import file_io
+
+    for tag, y, expect in _g17_cases()[3]:
+        assert np.array_equal(file_io.index_is_monotonic(y), expect), tag
+
+
+@pytest.mark.gpu
+def test_g17_gpu_bit_transforms_vs_reference(ctx):
+    """kernels_bits.hip against the reference's own bytes"""
+    from scri_amd import utilities
+
+    xor, shuffles, fletcher, _ = _g17_cases()
+    for tag, a, out in xor:
+        got = utilities.xor_timeseries(a.copy().view(np.float64), ctx=ctx)
+        assert np.array_equal(got.view(np.uint64), out), tag
+        assert np.array_equal(utilities.xor_timeseries_reverse(out.copy().view(np.float64), ctx=ctx).view(np.uint64), a), tag
+    for bits, widths, data, out, back in shuffles:
+        sh = utilities.multishuffle(widths, ctx=ctx)(data.copy())
+        assert sh.dtype == out.dtype and np.array_equal(sh, out), (bits, widths)
+        assert np.array_equal(utilities.multishuffle(widths, forward=False, ctx=ctx)(out.copy()), data), (bits, widths)
+    for tag, d, expect in fletcher:
+        assert int(utilities.fletcher32(d, ctx=ctx)) == expect, tag
