@@ -33,7 +33,8 @@ DOMINANT_KERNEL = "bms::zgemm3m_mfma_kernel"
 
 
 def dominant_kernel(abd):
-    return "bms::zgemm3m_mfma_kernel" if abd or os.environ.get("SCRI_AMD_NO_GEMM_EVAL") else "bms::zgemm3m_eval_kernel"
+    # (before a context exists: its default for the option is what the environment says at bms_ctx_create; the bench never changes it)
+    return "bms::zgemm3m_mfma_kernel" if abd or os.environ.get("SCRI_AMD_NO_GEMM_EVAL", "0") not in ("0", "") else "bms::zgemm3m_eval_kernel"
 # HBM traffic of the dominant kernel: measured BY THIS RUN where rocprofv3 is on the PATH -- before the parent process touches
 # the GPU it runs two short child passes of this same script under `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` (separate
 # passes, as MI355X_MICROARCH.md prescribes; traffic = 2 x FETCH_SIZE + WRITE_SIZE KiB on gfx950) and reads their counter CSVs.
@@ -146,25 +147,33 @@ def launch_ranks(n, argv):
 
 
 def cpu_baseline(spec, n_sample):
-    """Reference-structured CPU path (numpy zgemm + per-pixel scipy spline loop + dense map2salm): the oracle,
-    timed on a bounded sample (first n_sample time steps of the same workload), 1 thread of Python/FITPACK."""
-    from oracle import waveform_grid_ref as grid_ref
-    from oracle.containers import WM, h
-    from scri_amd import synthetic
+    """Reference-structured CPU path (numpy zgemm + per-pixel scipy spline loop + dense map2salm): the oracle, timed on a bounded
+    sample (first n_sample time steps of the same workload) on ONE core -- the same worker, pinned to one core with one BLAS thread,
+    that the all-cores leg runs P of (one definition for both legs)."""
+    import multiprocessing as mp
 
-    t, data, _ = synthetic.workload(spec["name"], n_times=n_sample, axis=spec.get("axis", "uniform"))
-    w = WM(t=t, data=data, ell_min=2, ell_max=spec["ell_max"], dataType=h)
-    t0 = time.perf_counter()
-    out = grid_ref.transform(w, **spec["kwargs"])
-    dt = time.perf_counter() - t0
+    cpus = _one_socket_cpus()
+    saved = {k: os.environ.get(k) for k in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS")}
+    for k in saved:
+        os.environ[k] = "1"
+    try:
+        with mp.get_context("spawn").Pool(1) as pool:
+            pool.map(_cpu_worker, [(spec["name"], 200, spec.get("axis", "uniform"), None)])  # imports paid before the clock starts
+            dt, n_out = pool.map(_cpu_worker, [(spec["name"], n_sample, spec.get("axis", "uniform"), cpus[0])])[0]
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
     return {
         "value": n_sample / dt,
         "unit": "timesteps/s",
         "cores": 1,
         "kind": "port",
         "sample": f"first {n_sample} of the 1e5 time steps of the same workload, oracle/waveform_grid_ref.transform "
-        f"(numpy tensordot + per-pixel scipy InterpolatedUnivariateSpline loop + dense map2salm), {dt:.1f} s, "
-        f"{out.t.size} output steps",
+        f"(numpy tensordot + per-pixel scipy InterpolatedUnivariateSpline loop + dense map2salm) in one process pinned to one core, {dt:.1f} s, "
+        f"{n_out} output steps",
     }
 
 
@@ -188,37 +197,86 @@ def _host_cores():
     return max(1, min(n, 64))
 
 
+def _one_socket_cpus():
+    """Logical CPUs of this process's affinity mask that are the FIRST hardware thread of a physical core of ONE socket (the socket
+    of the first allowed CPU): the "single-socket" denominator of the north star.  Falls back to the usable-core count."""
+    try:
+        allowed = sorted(os.sched_getaffinity(0))
+    except AttributeError:
+        allowed = list(range(os.cpu_count() or 1))
+    topo = {}
+    try:
+        cpu = None
+        for line in open("/proc/cpuinfo"):
+            k, _, v = line.partition(":")
+            k, v = k.strip(), v.strip()
+            if k == "processor":
+                cpu = int(v)
+                topo[cpu] = [0, cpu]
+            elif k == "physical id" and cpu is not None:
+                topo[cpu][0] = int(v)
+            elif k == "core id" and cpu is not None:
+                topo[cpu][1] = int(v)
+    except (OSError, ValueError):
+        topo = {}
+    usable = [c for c in allowed if c in topo] or allowed
+    socket = topo.get(usable[0], [0, 0])[0]
+    seen, cpus = set(), []
+    for c in usable:
+        s_, core = topo.get(c, [socket, c])
+        if s_ == socket and core not in seen:
+            seen.add(core)
+            cpus.append(c)
+    return cpus[: _host_cores()]
+
+
 def _cpu_worker(job):
-    """One process of the all-cores CPU baseline: the oracle on its own slice of the sample (spawned, never touches the GPU)."""
-    name, i0, i1, n_total = job
+    """One process of the all-cores CPU baseline: the oracle on the SAME sample the one-core leg transforms (spawned, pinned to one
+    core of the socket, never touches the GPU)."""
+    name, n_sample, axis, cpu = job
+    if cpu is not None:
+        try:
+            os.sched_setaffinity(0, {cpu})
+        except (AttributeError, OSError):
+            pass
     from oracle import waveform_grid_ref as grid_ref
     from oracle.containers import WM, h
     from scri_amd import synthetic
 
     spec = dict(synthetic.CONFIGS[name])
-    t, data, _ = synthetic.workload(name, n_times=n_total, rows=(i0, i1))
-    w = WM(t=t[i0:i1], data=data, ell_min=2, ell_max=spec["ell_max"], dataType=h)
+    t, data, _ = synthetic.workload(name, n_times=n_sample, axis=axis)
+    w = WM(t=t, data=data, ell_min=2, ell_max=spec["ell_max"], dataType=h)
     t0 = time.perf_counter()
-    grid_ref.transform(w, **spec["kwargs"])
-    return time.perf_counter() - t0
+    out = grid_ref.transform(w, **spec["kwargs"])
+    return time.perf_counter() - t0, int(out.t.size)
 
 
 def cpu_baseline_all_cores(spec, n_sample):
-    """The same oracle on every host core at once: the sample is cut into one contiguous slice per process (each slice is a
-    complete transform of its own rows), BLAS threads pinned to 1 per process.  The generous "one socket" denominator."""
+    """The same oracle on every physical core of one socket at once, ONE definition with the one-core leg: each of the P processes
+    transforms the same `n_sample`-step sample (first n_sample steps of the workload, same time axis), BLAS threads pinned to 1 per
+    process; throughput = P x n_sample / wall.  P is also bounded by host memory (the reference-shaped transform of 30 000 steps of
+    cfg3 holds about 3 GB of grids and spline temporaries per process)."""
     import multiprocessing as mp
 
-    procs = _host_cores()
-    per = max(200, n_sample // procs)
-    jobs = [(spec["name"], p * per, (p + 1) * per, procs * per) for p in range(procs)]
+    cpus = _one_socket_cpus()
+    per_proc = 3.5e9 * n_sample / 30000.0
+    try:
+        import psutil
+
+        fit = int(psutil.virtual_memory().available * 0.7 // max(per_proc, 1.0))
+    except Exception:  # noqa: BLE001
+        fit = len(cpus)
+    procs = max(1, min(len(cpus), fit))
+    cpus = cpus[:procs]
+    axis = spec.get("axis", "uniform")
     saved = {k: os.environ.get(k) for k in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS")}
     for k in saved:
         os.environ[k] = "1"
     try:
         with mp.get_context("spawn").Pool(procs) as pool:
-            pool.map(_cpu_worker, [(spec["name"], 0, 200, 200)] * procs)  # imports paid before the clock starts
+            pool.map(_cpu_worker, [(spec["name"], 200, axis, None)] * procs)  # imports paid before the clock starts
             t0 = time.perf_counter()
-            pool.map(_cpu_worker, jobs)
+            each = [e[0] for e in pool.map(_cpu_worker, [(spec["name"], n_sample, axis, c) for c in cpus], chunksize=1)]
             dt = time.perf_counter() - t0
     finally:
         for k, v in saved.items():
@@ -227,11 +285,13 @@ def cpu_baseline_all_cores(spec, n_sample):
             else:
                 os.environ[k] = v
     return {
-        "value": procs * per / dt,
+        "value": procs * n_sample / dt,
         "unit": "timesteps/s",
         "cores": procs,
         "kind": "port",
-        "sample": f"{procs} processes x {per} time steps each of the same workload, oracle/waveform_grid_ref.transform, {dt:.1f} s wall",
+        "sample": f"{procs} processes (one per physical core of one socket, pinned), EACH the first {n_sample} of the 1e5 time steps of the same "
+        f"workload -- the one-core leg's sample -- oracle/waveform_grid_ref.transform, {dt:.1f} s wall (slowest process {max(each):.1f} s, "
+        f"fastest {min(each):.1f} s)",
     }
 
 
@@ -320,28 +380,25 @@ def boost_free_line(local, t_global, kw, n_theta, ell_max, ctx):
         return (time.perf_counter() - t0) / reps, ctx.get_timing(reset=True), n
 
     wall, tm, n_new = measure()
-    # the same through synthesis_eval_kernel (round 5: the spline evaluated inside the separable synthesis, no pass over a grid of
-    # coefficients; opt-in because it is not faster -- DESIGN.md 4.0 (xxiii)): reported beside the default so that the choice can be checked
-    fused = None
-    if not os.environ.get("SCRI_AMD_SYNTHESIS_EVAL"):
-        os.environ["SCRI_AMD_SYNTHESIS_EVAL"] = "1"
-        try:
-            wall_f, tm_f, _ = measure()
-            fused = {"ms_per_step": wall_f * 1e3, "kernels": {k: v[0] / reps for k, v in tm_f.items() if v[1]},
-                     "route": "SCRI_AMD_SYNTHESIS_EVAL=1: bspline_solve_modes_kernel + synthesis_eval_kernel (gemm_synthesis) instead of elimination + "
-                              "synthesis_split_kernel + bspline_backward_eval_kernel"}
-        finally:
-            del os.environ["SCRI_AMD_SYNTHESIS_EVAL"]
+    # Default route since round 6 (shape rule of the engine: l_max >= 15): bspline_solve_modes_kernel + synthesis_eval_kernel -- the spline
+    # evaluated inside the separable synthesis, no pass over a grid of coefficients, no `spline_backward` kernel.  The route it replaced
+    # (elimination + synthesis_split_kernel + bspline_backward_eval_kernel) is measured beside it through the context's option, so that the
+    # choice can be checked on every run.
+    with ctx.options(NO_SYNTHESIS_EVAL=1):
+        wall_2, tm_2, _ = measure()
+    two_pass = {"ms_per_step": wall_2 * 1e3, "kernels": {k: v[0] / reps for k, v in tm_2.items() if v[1]},
+                "route": "context option NO_SYNTHESIS_EVAL=1: elimination + synthesis_split_kernel + bspline_backward_eval_kernel"}
+    fused_default = tm.get("spline_backward", (0.0, 0))[1] == 0
     ms = tm["gemm_synthesis"][0] / max(tm["gemm_synthesis"][1], 1)
     bytes_per_step = 16 * (nm + 1 + n_theta * n_theta)
     return {
-        "fused_route": fused,
+        "two_pass_route": two_pass,
         "metric": "timesteps/s, transformation without a boost (supertranslation + frame rotation), separable synthesis",
         "value": n / wall,
         "ms_per_step": wall * 1e3,
         "n_out": int(n_new),
         "kernels": {k: v[0] / reps for k, v in tm.items() if v[1]},
-        "synthesis_roofline": {"bound": "hbm", "kernel": "synthesis_split_kernel", "achieved": n * bytes_per_step / (ms * 1e-3) / 1e9,
+        "synthesis_roofline": {"bound": "hbm", "kernel": "synthesis_eval_kernel (modes in, SAMPLES out)" if fused_default else "synthesis_split_kernel", "achieved": n * bytes_per_step / (ms * 1e-3) / 1e9,
                                "peak": 8000.0, "unit": "GB/s", "frac": n * bytes_per_step / (ms * 1e-3) / 8e12,
                                "bytes_per_step": bytes_per_step, "ms_per_launch": ms},
     }
@@ -398,11 +455,10 @@ def abd_boost_free_line(ctx, n_rows=25_000):
     d_in = torch.from_numpy(raw).to(torch.device("cuda", ctx.device))
     d_out = torch.empty_like(d_in)
     out = {"metric": "timesteps/s, AsymptoticBondiData transformation without a boost (cfg5 fields and grid)", "n_times": n_rows}
-    saved = os.environ.pop("SCRI_AMD_NO_SEPARABLE_SYNTHESIS", None)
+    saved = ctx.option("NO_SEPARABLE_SYNTHESIS")
     try:
         for route in ("separable", "dense"):
-            if route == "dense":
-                os.environ["SCRI_AMD_NO_SEPARABLE_SYNTHESIS"] = "1"
+            ctx.option("NO_SEPARABLE_SYNTHESIS", 1 if route == "dense" else 0)
             reps = 3
             engine.transform_abd(u, d_in.data_ptr(), L, tr, ctx=ctx, device=True, out_ptr=d_out.data_ptr())
             ctx.synchronize()
@@ -415,9 +471,7 @@ def abd_boost_free_line(ctx, n_rows=25_000):
             tm = {k: v[0] / reps for k, v in ctx.get_timing(reset=True).items() if v[1]}
             out[route] = {"ms_per_step": wall * 1e3, "value": n_rows / wall, "kernels": tm}
     finally:
-        os.environ.pop("SCRI_AMD_NO_SEPARABLE_SYNTHESIS", None)
-        if saved is not None:
-            os.environ["SCRI_AMD_NO_SEPARABLE_SYNTHESIS"] = saved
+        ctx.option("NO_SEPARABLE_SYNTHESIS", saved)
     nm, jp = (L + 1) ** 2, (n_theta + 7) // 8 * 8
     bytes_per_step = 6 * 16 * (nm + 1 + 2 * (2 * L + 1) * jp + n_theta * n_theta)
     ms = out["separable"]["kernels"].get("gemm_synthesis")
@@ -634,7 +688,7 @@ def main():
 
     spec = dict(synthetic.CONFIGS[args.workload])
     spec["name"] = args.workload
-    spec["axis"] = args.time_axis  # (the one-core CPU baseline runs on the same axis; the all-cores one keeps the uniform axis)
+    spec["axis"] = args.time_axis  # (both CPU baselines run on the same axis)
     abd = args.workload == "cfg5"
     # total work fixed, sharded `world` ways: cfg4 (1e6 steps), and cfg5 on several GPUs (BASELINE.json configs[4]: 2e5 steps, 8 GPUs;
     # scri/asymptotic_bondi_data/transformations.py:391-412 is what the shards reproduce) -- on one GPU cfg5 stays one rank's share
@@ -923,7 +977,7 @@ def main():
                 return {"algorithmic_bytes_per_step": bytes_per_row, "achieved_GBps": gbs, "frac_of_8TBps": gbs / 8000.0}
 
             eval_route = "eval" in DOMINANT_KERNEL
-            two_sweeps = bool(os.environ.get("SCRI_AMD_TWO_SWEEPS"))
+            two_sweeps = bool(ctx.option("TWO_SWEEPS"))
             if eval_route:
                 # both sweeps of the spline solve on the n_modes + 1 mode columns in ONE pass over memory (read once, written once:
                 # bspline_solve_modes_kernel; two passes with SCRI_AMD_TWO_SWEEPS), the product reads the solved modes and writes the

@@ -61,6 +61,14 @@ int bms_ctx_set_stream(bms_ctx* ctx, void* hip_stream);
 /* run on the device's default (null) stream -- handle 0, which bms_ctx_set_stream takes as "own stream" -- so that work a
  * caller queued there (torch's default stream: allocations, copies, memsets) is ordered before the engine's kernels */
 int bms_ctx_use_default_stream(bms_ctx* ctx);
+/* Route options of ONE context: choices between routes that give the same results to rounding (dense product vs separable
+ * synthesis, evaluating product vs product + back substitution, fused vs two-pass boost-free route, ...; the list is
+ * scri_amd/csrc/env.h, names with or without the SCRI_AMD_ prefix, e.g. "NO_GEMM_EVAL").  Flags take 0 / 1; AXIS_BOOST_MIN_WORK a
+ * count of multiply-adds (< 0: built-in threshold, 0: always) and GEMM_EVAL_STEP 0 / 61 / 64.  A context takes its DEFAULTS from the
+ * SCRI_AMD_<NAME> environment variables once, inside bms_ctx_create; no call reads the environment afterwards, so two contexts of
+ * one process may run different routes concurrently ("re-entrant per ctx").  BMS_ERR_INVALID for an unknown name. */
+int bms_ctx_set_option(bms_ctx* ctx, const char* name, int64_t value);
+int bms_ctx_get_option(bms_ctx* ctx, const char* name, int64_t* value);
 /* cap on the grid work space in bytes (time axis is processed in chunks that fit); 0 = default: min(96 GB, a third of the device
  * memory that is free at the time).  With the default a call that runs out of device memory halves the cap and tries again. */
 int bms_ctx_set_workspace_limit(bms_ctx* ctx, uint64_t bytes);

@@ -73,6 +73,8 @@ SIGNATURES = {
     "bms_last_error": (ctypes.c_char_p, [c_vp]),
     "bms_ctx_set_stream": (c_int, [c_vp, c_vp]),
     "bms_ctx_use_default_stream": (c_int, [c_vp]),
+    "bms_ctx_set_option": (c_int, [c_vp, ctypes.c_char_p, c_i64]),
+    "bms_ctx_get_option": (c_int, [c_vp, ctypes.c_char_p, ctypes.POINTER(c_i64)]),
     "bms_ctx_set_workspace_limit": (c_int, [c_vp, ctypes.c_uint64]),
     "bms_ctx_reserve": (c_int, [c_vp, ctypes.c_uint64]),
     "bms_ctx_get_eval_stats": (c_int, [c_vp, ctypes.POINTER(c_i64), c_int]),
@@ -368,6 +370,13 @@ def _raise(code, ctx, what):
     raise BMSError(text)
 
 
+_live_contexts = __import__("weakref").WeakSet()  # every Context of the process that has not been closed
+
+
+def live_contexts():
+    return [c for c in list(_live_contexts) if getattr(c, "_h", None)]
+
+
 class Context:
     """Owns one bms_ctx (one GPU, one stream).  `stream`: optional hipStream_t handle (int), e.g.
     torch.cuda.current_stream().cuda_stream, so that work is ordered with the caller's."""
@@ -379,6 +388,7 @@ class Context:
         if rc != 0:
             _raise(rc, None, "bms_ctx_create")
         self._h = h
+        _live_contexts.add(self)
         self.device = int(device)
         self.stream_handle = None  # the hipStream_t the caller handed over (0: the device's default stream); None: the context's own
         if stream is not None:
@@ -403,6 +413,32 @@ class Context:
 
     def synchronize(self):
         self.check(load().bms_ctx_synchronize(self._h), "bms_ctx_synchronize")
+
+    def option(self, name, value=None):
+        """Route option of THIS context (scri_amd/csrc/env.h lists them; "NO_GEMM_EVAL" or "SCRI_AMD_NO_GEMM_EVAL").  With a value:
+        set it (flags 0 / 1) and return the previous value; without: read it.  Contexts take their defaults from the environment
+        when they are created and never look at it again."""
+        key = name.encode()
+        old = c_i64(0)
+        self.check(load().bms_ctx_get_option(self._h, key, ctypes.byref(old)), "bms_ctx_get_option")
+        if value is not None:
+            self.check(load().bms_ctx_set_option(self._h, key, int(value)), "bms_ctx_set_option")
+        return int(old.value)
+
+    def options(self, **kw):
+        """with ctx.options(NO_GEMM_EVAL=1): ...   -- route options for the duration of a block"""
+        import contextlib
+
+        @contextlib.contextmanager
+        def scope():
+            saved = {k: self.option(k, v) for k, v in kw.items()}
+            try:
+                yield self
+            finally:
+                for k, v in saved.items():
+                    self.option(k, v)
+
+        return scope()
 
     def eval_stats(self, reset=True):
         """(tiles launched, tiles off the LDS path, marches continued from global memory) of the evaluating product since the last reset"""

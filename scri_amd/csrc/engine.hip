@@ -104,11 +104,14 @@ struct bms_ctx {
   hipStream_t stream = nullptr;
   hipStream_t aux = nullptr;  // set-up kernels whose results the host waits for run here, beside the main stream's work
   std::string err;
+  RouteOptions opt;  // route switches of THIS context: defaults from the environment at bms_ctx_create, then bms_ctx_set_option (env.h)
   // cap on the grids of one chunk of the time axis: min(96 GB, a third of the memory that was free when the context was created)
   // unless the caller sets one (one GPU's cfg5 rows -- 25 000 steps, six 99 x 99 grids, 76 GB -- are ONE chunk on an otherwise empty
   // MI355X); a call that still runs out of memory halves it and tries again (with_smaller_chunks)
   uint64_t ws_limit = 96ull << 30;
   bool ws_limit_set = false;  // by the caller: then it is kept as given
+  uint64_t sticky_limit = 0;  // the reduced cap a call of this context last succeeded with after allocation failures (with_smaller_chunks) ...
+  int sticky_left = 0;        // ... and for how many more calls it is tried first
   // evaluating product (kernels_gemm_eval.hip): how often its samples left the window of abscissae a tile stages in LDS
   unsigned long long* d_eval_stats = nullptr;  // device: [0] tiles / boundary blocks off the LDS path, [1] marches continued from global memory
   uint64_t eval_tiles = 0;                     // tiles + boundary blocks launched since the last reset
@@ -225,7 +228,7 @@ static thread_local std::string g_create_error;
 struct HostTrace {
   bool on;
   std::chrono::steady_clock::time_point t0;
-  HostTrace() : on(route_env("SCRI_AMD_TRACE") != nullptr), t0(std::chrono::steady_clock::now()) {}
+  explicit HostTrace(const bms_ctx* c) : on(c && c->opt.on(OPT_TRACE)), t0(std::chrono::steady_clock::now()) {}
   void mark(const char* what) {
     if (!on) return;
     auto t1 = std::chrono::steady_clock::now();
@@ -311,14 +314,14 @@ static int dev_buf(bms_ctx* c, const char* name, size_t bytes, void** out) {
         b.cap = want;
         b.slab = i, b.slab_off = off;
         *out = b.p;
-        if (route_env("SCRI_AMD_TRACE"))
+        if (c->opt.on(OPT_TRACE))
           fprintf(stderr, "[scri_amd] work space '%s' grows to %.3f GB: from slab %d at %.3f GB\n", name, want / 1073741824.0, i, off / 1073741824.0);
         return BMS_OK;
       }
     }
     const auto t_a = std::chrono::steady_clock::now();
     hipError_t e = hipMalloc(&b.p, want);
-    if (route_env("SCRI_AMD_TRACE"))
+    if (c->opt.on(OPT_TRACE))
       fprintf(stderr, "[scri_amd] work space '%s' grows to %.3f GB: hipMalloc %.1f ms\n", name, want / 1073741824.0,
               std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_a).count());
     if (e != hipSuccess) {
@@ -355,22 +358,41 @@ static uint64_t default_ws_limit() {
 
 // Runs `call` again with half the work space cap while it fails because a device ALLOCATION failed (the buffer that failed was
 // released before the attempt, so a smaller chunk finds room).  Not retried: a cap the caller set, and the planning error "the cap
-// holds fewer than N rows" -- halving only makes that one worse.  The halved cap lasts for this call only: one transient shortage (a
-// temporary tensor of the caller) must not leave every later call of the context with chunks up to 32x smaller.  If every attempt
-// fails the FIRST message is the one reported.
+// holds fewer than N rows" -- halving only makes that one worse.  The cap itself is restored after the call; the reduced value that
+// worked is only REMEMBERED for a bounded number of calls (below), so one transient shortage (a temporary tensor of the caller) does
+// not leave every later call of the context with chunks up to 32x smaller.  If every attempt fails the FIRST message is reported.
 template <class F>
 static int with_smaller_chunks(bms_ctx* c, F call) {
   c->alloc_failed = false;
+  const uint64_t tiles0 = c->eval_tiles;
+  // A context that had to halve its cap keeps the reduced one for the next calls (sticky_left): under STEADY memory pressure (a
+  // co-resident tensor of the caller) every call would otherwise free its grown buffers, fail the same multi-GB allocation and
+  // re-allocate smaller ones -- seconds per call at 70-120 ms per GB.  The full cap is tried again after 16 calls, or as soon as
+  // the device reports room for it.
+  const uint64_t full = c->ws_limit;
+  if (c->sticky_left > 0 && c->sticky_limit && !c->ws_limit_set) {
+    size_t free_b = 0, total_b = 0;
+    const bool room = hipMemGetInfo(&free_b, &total_b) == hipSuccess && (uint64_t)free_b > full + full / 2;
+    (void)hipGetLastError();
+    if (room || --c->sticky_left == 0)
+      c->sticky_limit = 0;
+    else
+      c->ws_limit = std::min(full, c->sticky_limit);
+  }
   int rc = call();
-  if (rc != BMS_ERR_NOMEM || !c->alloc_failed || c->ws_limit_set) return rc;
-  const uint64_t cap = c->ws_limit;
+  if (rc != BMS_ERR_NOMEM || !c->alloc_failed || c->ws_limit_set) {
+    c->ws_limit = full;
+    return rc;
+  }
   const std::string first = c->err;
   for (int attempt = 0; rc == BMS_ERR_NOMEM && c->alloc_failed && attempt < 5 && c->ws_limit > (512ull << 20); ++attempt) {
     c->ws_limit /= 2;
     c->alloc_failed = false;
+    c->eval_tiles = tiles0;  // (diagnostic counter: the failed attempt's launches, if any, are not counted twice)
     rc = call();
   }
-  c->ws_limit = cap;
+  if (rc == BMS_OK) c->sticky_limit = c->ws_limit, c->sticky_left = 16;
+  c->ws_limit = full;
   if (rc == BMS_ERR_NOMEM) c->err = first;
   return rc;
 }
@@ -405,7 +427,36 @@ extern "C" int bms_ctx_create(int device, bms_ctx** out) {
   c->stream = c->own_stream;
   if (hipStreamCreateWithFlags(&c->aux, hipStreamNonBlocking) != hipSuccess) c->aux = nullptr;
   c->ws_limit = default_ws_limit();
+  c->opt.read_environment();  // the ONLY place the route switches meet the environment: they are this context's defaults from here on
   *out = c;
+  return BMS_OK;
+}
+
+// Route options of one context (env.h lists them; names with or without the SCRI_AMD_ prefix).  Setting one drops the context's cached
+// plans (their shape may depend on the route); like every entry point it must not run while another thread uses the same context.
+extern "C" int bms_ctx_set_option(bms_ctx* c, const char* name, int64_t value) {
+  if (!c) return BMS_ERR_INVALID;
+  const int i = route_option_index(name);
+  if (i < 0) return fail(c, BMS_ERR_INVALID, "bms_ctx_set_option: no route option named '%s'", name ? name : "(null)");
+  if (i == OPT_GEMM_EVAL_STEP && value != 0 && value != 61 && value != 64)
+    return fail(c, BMS_ERR_INVALID, "GEMM_EVAL_STEP is 0 (automatic), 61 or 64; got %lld", (long long)value);
+  if (i == OPT_AXIS_BOOST_MIN_WORK)
+    c->opt.v[i] = value < 0 ? -1 : value;  // (a count of multiply-adds; 0: the axis-boost route whenever it applies; < 0: the built-in threshold)
+  else if (i == OPT_GEMM_EVAL_STEP)
+    c->opt.v[i] = value;
+  else
+    c->opt.v[i] = value != 0;
+  c->plans.clear();
+  c->syn_plans.clear();
+  c->syn_plans_axis.clear();
+  c->ring_verdict = -1;
+  return BMS_OK;
+}
+extern "C" int bms_ctx_get_option(bms_ctx* c, const char* name, int64_t* value) {
+  if (!c || !value) return BMS_ERR_INVALID;
+  const int i = route_option_index(name);
+  if (i < 0) return fail(c, BMS_ERR_INVALID, "bms_ctx_get_option: no route option named '%s'", name ? name : "(null)");
+  *value = c->opt.v[i];
   return BMS_OK;
 }
 
@@ -540,8 +591,12 @@ extern "C" int bms_ctx_get_eval_stats(bms_ctx* c, int64_t* out /*[3]*/, int rese
   unsigned long long h[2] = {0, 0};
   if (c->d_eval_stats) {
     HIP_TRY(c, hipStreamSynchronize(c->stream));
-    HIP_TRY(c, hipMemcpy(h, c->d_eval_stats, 16, hipMemcpyDeviceToHost));
-    if (reset) HIP_TRY(c, hipMemset(c->d_eval_stats, 0, 16));
+    HIP_TRY(c, hipMemcpyAsync(h, c->d_eval_stats, 16, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (reset) {
+      HIP_TRY(c, hipMemsetAsync(c->d_eval_stats, 0, 16, c->stream));  // (on the stream the kernels count on: a following launch is ordered behind it)
+      HIP_TRY(c, hipStreamSynchronize(c->stream));
+    }
   }
   out[0] = (int64_t)c->eval_tiles, out[1] = (int64_t)h[0], out[2] = (int64_t)h[1];
   if (reset) c->eval_tiles = 0;
@@ -804,7 +859,7 @@ static int rotate_impl(bms_ctx* c, void* data, int mem, int64_t n_times, int64_t
   std::vector<Segment> segs;
   int rc = BMS_OK;
   {
-    const bool allow_res = !route_env("SCRI_AMD_ROTATE_VALU") && !route_env("SCRI_AMD_ROTATE_STAGED") && ld * 256 <= 0x7ffe0000LL;
+    const bool allow_res = !c->opt.on(OPT_ROTATE_VALU) && !c->opt.on(OPT_ROTATE_STAGED) && ld * 256 <= 0x7ffe0000LL;
     int l = ell_min;
     while (l <= ell_max) {
       Segment sg{};
@@ -826,7 +881,7 @@ static int rotate_impl(bms_ctx* c, void* data, int mem, int64_t n_times, int64_t
       if (!placed) {
         sg.lo = l;
         sg.hi = ell_max;
-        sg.kind = (rotate_mfma_supported(ell_max) && !route_env("SCRI_AMD_ROTATE_VALU")) ? 1 : 2;
+        sg.kind = (rotate_mfma_supported(ell_max) && !c->opt.on(OPT_ROTATE_VALU)) ? 1 : 2;
         if (sg.kind == 2 && rotate_waves_per_block(ell_max) < 1)
           return fail(c, BMS_ERR_UNSUPPORTED, "ell_max=%d too large for the rotation kernels", ell_max);
       }
@@ -1110,10 +1165,10 @@ static int upload(bms_ctx* c, const char* name, const void* host, size_t bytes, 
 static int build_analysis(bms_ctx* c, const char* tag, int n_theta, int n_phi, int spin, int ell_min_out, int ell_max_out,
                           AnalysisPlan& A) {
   hipStream_t S = c->stream;
-  const std::array<int, 6> key = {n_theta, n_phi, spin, ell_min_out, ell_max_out, (route_env("SCRI_AMD_NO_FUSED_ANALYSIS") ? 1 : 0) + (route_env("SCRI_AMD_NO_LARGE_ANALYSIS") ? 2 : 0)};
+  const std::array<int, 6> key = {n_theta, n_phi, spin, ell_min_out, ell_max_out, (c->opt.on(OPT_NO_FUSED_ANALYSIS) ? 1 : 0) + (c->opt.on(OPT_NO_LARGE_ANALYSIS) ? 2 : 0)};
   {
     auto it = c->plans.find(tag);
-    if (it != c->plans.end() && it->second.first == key && !route_env("SCRI_AMD_NO_PLAN_CACHE")) {
+    if (it != c->plans.end() && it->second.first == key && !c->opt.on(OPT_NO_PLAN_CACHE)) {
       A = it->second.second;
       return BMS_OK;
     }
@@ -1131,9 +1186,9 @@ static int build_analysis(bms_ctx* c, const char* tag, int n_theta, int n_phi, i
   int rc;
   void* vp;
   char nm_[64];
-  A.fused = A.separable && fused_analysis_supported(n_theta, n_phi, A.L, A.n_out) && !route_env("SCRI_AMD_NO_FUSED_ANALYSIS");
-  A.large = A.separable && !A.fused && large_analysis_supported(n_theta, n_phi, A.L) && !route_env("SCRI_AMD_NO_LARGE_ANALYSIS") &&
-            !route_env("SCRI_AMD_NO_FUSED_ANALYSIS");
+  A.fused = A.separable && fused_analysis_supported(n_theta, n_phi, A.L, A.n_out) && !c->opt.on(OPT_NO_FUSED_ANALYSIS);
+  A.large = A.separable && !A.fused && large_analysis_supported(n_theta, n_phi, A.L) && !c->opt.on(OPT_NO_LARGE_ANALYSIS) &&
+            !c->opt.on(OPT_NO_FUSED_ANALYSIS);
   A.ell_min_out = ell_min_out;
   A.spin = spin;
   if (A.separable) {
@@ -1216,7 +1271,7 @@ static int run_analysis(bms_ctx* c, const AnalysisPlan& A, const double* d_G, lo
   const long long P2 = 2LL * A.n_pix, ld = ld_cols ? ld_cols : P2;  // row stride of d_G
   if (A.fused) {
     TIMED(c, BMS_TAG_ANALYSIS_FUSED, launch_analysis_fused(S, d_G, ld, rows, A.n_theta, A.n_phi, A.L, A.n_out,
-                                                           A.d_mindex, A.d_T, A.d_dcs, d_out, ldo, col_of_pixel, A.spin));
+                                                           A.d_mindex, A.d_T, A.d_dcs, d_out, ldo, col_of_pixel, A.spin, !c->opt.on(OPT_NO_SPLIT_ANALYSIS)));
   } else if (A.large) {
     if (col_of_pixel) return fail(c, BMS_ERR_UNSUPPORTED, "internal: sorted columns need the fused analysis");
     double* d_F;
@@ -1437,12 +1492,15 @@ static int eval_search_halfwidth(const PixelTables& T, int cA, int cB, const dou
 // The two-kernel synthesis moves (2 l_max + 1) x n_theta numbers per time step through HBM twice; the dense product it replaces
 // costs n_modes x n_pix multiply-adds per step and overtakes it only from about l_max = 13 on the default grids (measured:
 // tools/axis_boost_probe.py; l <= 8 on 17 x 17: 0.45 ms dense, 0.81 ms separable per 10^5 steps; l <= 16 on 33 x 33: 4.2 and 2.3).
-static bool axis_boost_pays(int n_modes, int n_theta, int n_phi) {
-  const char* e = route_env("SCRI_AMD_AXIS_BOOST_MIN_WORK");  // (read per call, like the other route switches)
-  const long long min_work = e ? atoll(e) : 160000;
+static bool large_synthesis_route(const bms_ctx* c, int n_theta, int n_phi, int ell_min, int ell_max) {
+  return !c->opt.on(OPT_NO_SEPARABLE_SYNTHESIS) && !c->opt.on(OPT_NO_LARGE_SYNTHESIS) && large_synthesis_supported(n_theta, n_phi, ell_min, ell_max) != 0;
+}
+static bool axis_boost_pays(const bms_ctx* c, int n_modes, int n_theta, int n_phi) {
+  const long long o = c->opt.v[OPT_AXIS_BOOST_MIN_WORK];  // (< 0: the built-in threshold; 0: always)
+  const long long min_work = o < 0 ? 160000 : o;
   return (long long)n_modes * n_theta * n_phi >= min_work;
 }
-static bool separable_rotor_grid(const bms_transformation* tr, std::vector<double>& thetas) {
+static bool separable_rotor_grid(const bms_transformation* tr, std::vector<double>& thetas, bool axis_boost_off = false) {
   const int n_theta = tr->n_theta, n_phi = tr->n_phi;
   const double* fr = tr->frame_rotation;
   const Quat F = {fr[0], fr[1], fr[2], fr[3]};
@@ -1452,7 +1510,7 @@ static bool separable_rotor_grid(const bms_transformation* tr, std::vector<doubl
     for (int j = 0; j < n_theta; ++j) thetas[j] = M_PI * j / (n_theta - 1);
     return true;
   }
-  if (route_env("SCRI_AMD_NO_AXIS_BOOST_SEPARABLE")) return false;
+  if (axis_boost_off) return false;
   double zf[3];
   rotate_z(F, zf);
   const double cx = bs.vhat[1] * zf[2] - bs.vhat[2] * zf[1], cy = bs.vhat[2] * zf[0] - bs.vhat[0] * zf[2], cz = bs.vhat[0] * zf[1] - bs.vhat[1] * zf[0];
@@ -1484,12 +1542,12 @@ static bool separable_rotor_grid(const bms_transformation* tr, std::vector<doubl
 static bool separable_rotor_grid(bms_ctx* c, const bms_transformation* tr, std::vector<double>& thetas) {
   const double key[9] = {tr->frame_rotation[0], tr->frame_rotation[1], tr->frame_rotation[2], tr->frame_rotation[3], tr->boost_velocity[0],
                          tr->boost_velocity[1], tr->boost_velocity[2], (double)tr->n_theta, (double)tr->n_phi};
-  const bool switched_off = route_env("SCRI_AMD_NO_AXIS_BOOST_SEPARABLE") != nullptr;  // (the switch is read per call)
+  const bool switched_off = c->opt.on(OPT_NO_AXIS_BOOST_SEPARABLE);
   if (!switched_off && c->ring_verdict >= 0 && std::memcmp(key, c->ring_key, sizeof key) == 0) {
     if (c->ring_verdict) thetas = c->ring_thetas;
     return c->ring_verdict != 0;
   }
-  const bool yes = separable_rotor_grid(tr, thetas);
+  const bool yes = separable_rotor_grid(tr, thetas, switched_off);
   if (!switched_off) {
     std::memcpy(c->ring_key, key, sizeof key);
     c->ring_verdict = yes ? 1 : 0;
@@ -1527,10 +1585,10 @@ static int build_synthesis(bms_ctx* c, int n_theta, int n_phi, int spin, int ell
   }
   std::vector<int> meta;
   int len = 0;
-  if (!synthesis_split_plan(n_theta, n_phi, ell_min, ell_max, P.g, meta, P.lds, P.nt, len)) P.nt = 0;
+  if (c->opt.on(OPT_NO_SEPARABLE_SYNTHESIS) || !synthesis_split_plan(n_theta, n_phi, ell_min, ell_max, P.g, meta, P.lds, P.nt, len)) P.nt = 0;
   // (behind an axis boost the one-kernel form also keeps the per-pixel scale in LDS)
   if (thetas && P.nt && P.lds + synthesis_split_scale_bytes(n_theta, n_phi) > 160 * 1024) P.nt = 0;
-  P.large = large_synthesis_supported(n_theta, n_phi, ell_min, ell_max) != 0;
+  P.large = !c->opt.on(OPT_NO_SEPARABLE_SYNTHESIS) && !c->opt.on(OPT_NO_LARGE_SYNTHESIS) && large_synthesis_supported(n_theta, n_phi, ell_min, ell_max) != 0;
   P.n_theta = n_theta, P.n_phi = n_phi, P.ell_min = ell_min, P.ell_max = ell_max;
   if (!P.nt && !P.large) return BMS_OK;
   hipStream_t S = c->stream;
@@ -1577,7 +1635,7 @@ static int run_synthesis(bms_ctx* c, const SynthesisPlan& P, const double* A, lo
                          long long ldy, const double* scale) {
   hipStream_t S = c->stream;
   if (rows <= 0) return BMS_OK;
-  if (P.nt && rows >= 2 && !route_env("SCRI_AMD_NO_SPLIT_SYNTHESIS")) {
+  if (P.nt && rows >= 2 && !c->opt.on(OPT_NO_SPLIT_SYNTHESIS)) {
     TIMED(c, BMS_TAG_GEMM_SYNTHESIS, launch_synthesis_split(S, A, lda, rows, P.g, P.nt, P.d_T, P.d_meta, off, Y, ldy, P.lds, c->n_cu, scale));
   } else if (P.large) {
     double* d_F;
@@ -1592,8 +1650,8 @@ static int run_synthesis(bms_ctx* c, const SynthesisPlan& P, const double* A, lo
 // Column plan of the grids: 0 = one column per grid pixel, in grid order.  When the analysis can read the columns in any
 // order (the fused kernel) the two pole rings are stored once each (1) and, with a boost, whose time skew grows with |u|,
 // the columns are also sorted by the skew rate (2).
-static int column_plan(const bms_transformation* tr, int n_out) {
-  if (route_env("SCRI_AMD_NO_COLUMN_SORT") || route_env("SCRI_AMD_NO_FUSED_ANALYSIS")) return 0;
+static int column_plan(const bms_ctx* c, const bms_transformation* tr, int n_out) {
+  if (c->opt.on(OPT_NO_COLUMN_SORT) || c->opt.on(OPT_NO_FUSED_ANALYSIS)) return 0;
   if (tr->n_theta < 3 || tr->n_theta * tr->n_phi > pixel_sort_max() || tr->n_theta > MAX_THETA_SEPARABLE ||
       !fused_analysis_supported(tr->n_theta, tr->n_phi, tr->ell_max_out, n_out))
     return 0;
@@ -1725,6 +1783,17 @@ static int part_analysis_matrix(bms_ctx* c, const AnalysisPlan& A, const char* n
 }
 
 // The shared pipeline: `nf` synthesised fields -> pointwise stage -> spline -> analysis, chunked over time.
+// tiles + tile-boundary blocks one launch of the evaluating product works through (the denominator of bms_ctx_get_eval_stats): 64-row
+// tiles with a boundary block between neighbours, or overlapping tiles that advance 61 rows
+static uint64_t eval_tile_count(long long rows, int n_cols, int step) {
+  const uint64_t nbn = (uint64_t)((n_cols + 63) / 64);
+  if (step == 61) return (uint64_t)std::max<long long>(0, (rows - 3 + 60) / 61) * nbn;
+  const uint64_t nbm = (uint64_t)((rows + 63) / 64);
+  return nbm * nbn + (nbm > 0 ? nbm - 1 : 0) * nbn;
+}
+
+constexpr int SYN_EVAL_MIN_ELL = 15;  // the evaluating separable synthesis (kernels_synthesis_eval.hip) by default from this l_max on
+
 struct PointwiseWM {
   // WM flavour: y = (f0 + sum_i coeff_i f_i X^power_i - off) * scale, see bms_transform_modes
   const double* d_off = nullptr;
@@ -1976,7 +2045,7 @@ static int transform_modes_impl(bms_ctx* c, const bms_wm_input* in, const bms_tr
   int64_t t_lo, t_hi;
   time_window(n, sh, t_lo, t_hi);
   bool regular_mesh = true;
-  HostTrace trace0;
+  HostTrace trace0(c);
   struct DrainOnExit {  // whatever path leaves this call, nothing enqueued here still reads the caller's buffers
     hipStream_t s;
     bool skip;  // pieces of the pipelined path: its own buffers, drained by the pipeline
@@ -1992,7 +2061,7 @@ static int transform_modes_impl(bms_ctx* c, const bms_wm_input* in, const bms_tr
   BsplineTable* d_bstab = nullptr;
   BsplineForward* d_bsfwd = nullptr;
   int rc;
-  const bool times_ahead = n >= 8 && in->t && !c->async_pieces && !route_env("SCRI_AMD_NO_BSPLINE") &&
+  const bool times_ahead = n >= 8 && in->t && !c->async_pieces && !c->opt.on(OPT_NO_BSPLINE) &&
                            (!sh || (sh->data_row0 >= 0 && sh->data_rows >= 0 && sh->data_row0 + sh->data_rows <= n));
   if (times_ahead) {
     const int64_t r0 = sh ? sh->data_row0 : 0, r1 = r0 + (sh ? sh->data_rows : n);
@@ -2001,7 +2070,7 @@ static int transform_modes_impl(bms_ctx* c, const bms_wm_input* in, const bms_tr
   // The walk itself is put off as well, to the moment the host would otherwise sit waiting for the per-direction tables: until then
   // the axis is taken to be what it nearly always is (increasing, not graded).  A walk that finds otherwise drains what was queued
   // and either fails the call as it always did or starts it again, walk first.
-  const bool walk_later = times_ahead && c->aux && !walk_first && !route_env("SCRI_AMD_WALK_FIRST");
+  const bool walk_later = times_ahead && c->aux && !walk_first && !c->opt.on(OPT_WALK_FIRST);
   int walk_rc = BMS_OK;
   bool walked = false, walk_regular = true;
   if (walk_later) {
@@ -2022,7 +2091,7 @@ static int transform_modes_impl(bms_ctx* c, const bms_wm_input* in, const bms_tr
   const cplx* st = (const cplx*)tr->supertranslation;
 
   // ---------------------------------------------------------------- per-pixel tables (GPU) and output window (host)
-  HostTrace trace;
+  HostTrace trace(c);
   hipStream_t S = c->stream;
   const bool nontrivial = [&] {
     const double* v = tr->boost_velocity;
@@ -2072,7 +2141,7 @@ static int transform_modes_impl(bms_ctx* c, const bms_wm_input* in, const bms_tr
   // Without psi mixing the map modes -> grid values is linear along the columns with time-independent coefficients, so
   // the spline's forward elimination is done on the modes (B-spline form, kernels_bspline.hip) and the grid is passed over
   // once, by the back substitution + evaluation.
-  const bool bsg = n >= 8 && regular_mesh && !route_env("SCRI_AMD_NO_BSPLINE");  // B-spline form (else: the slope form, kernels_spline.hip)
+  const bool bsg = n >= 8 && regular_mesh && !c->opt.on(OPT_NO_BSPLINE);  // B-spline form (else: the slope form, kernels_spline.hip)
   const bool bs = bsg && !psi;                                                 // ... with the elimination commuted onto the modes
   // (a "shard" that holds every row of every column is the whole series: only its output range is restricted)
   if (!regular_mesh && sh != nullptr && !(sh->data_row0 == 0 && sh->data_rows == n && sh->col_parts <= 1))
@@ -2119,11 +2188,11 @@ static int transform_modes_impl(bms_ctx* c, const bms_wm_input* in, const bms_tr
   // synthesis PLUS back substitution on the grid, and up to l <= 8 (77 modes x 21 x 21) it wins -- 1e5 steps, supertranslation + frame
   // rotation: l <= 4 0.62 -> 0.54 ms, l <= 6 0.89 -> 0.70, l <= 8 1.20 -> 1.12; from l <= 10 (1.65 vs 1.81) the separable route is ahead
   // (tools/probes/dense_vs_separable_small.py).
-  const bool small_dense = no_boost && rows_avail >= 8 && (long long)n_modes * tr->n_theta * tr->n_phi <= 40000 && !route_env("SCRI_AMD_NO_SMALL_DENSE");
-  if (bs && !small_dense && rows_avail >= 2 && !(sh && sh->col_parts > 1) && tr->n_theta >= 3 && !route_env("SCRI_AMD_NO_SEPARABLE_SYNTHESIS")) {
+  const bool small_dense = no_boost && rows_avail >= 8 && (long long)n_modes * tr->n_theta * tr->n_phi <= 40000 && !c->opt.on(OPT_NO_SMALL_DENSE);
+  if (bs && !small_dense && rows_avail >= 2 && !(sh && sh->col_parts > 1) && tr->n_theta >= 3 && !c->opt.on(OPT_NO_SEPARABLE_SYNTHESIS)) {
     if (no_boost) {
       if ((rc = build_synthesis(c, tr->n_theta, tr->n_phi, s, in->ell_min, in->ell_max, syn))) return rc;
-    } else if (axis_boost_pays(n_modes, tr->n_theta, tr->n_phi) && large_synthesis_supported(tr->n_theta, tr->n_phi, in->ell_min, in->ell_max) &&
+    } else if (axis_boost_pays(c, n_modes, tr->n_theta, tr->n_phi) && large_synthesis_route(c, tr->n_theta, tr->n_phi, in->ell_min, in->ell_max) &&
                separable_rotor_grid(c, tr, ring_theta)) {
       if ((rc = build_synthesis(c, tr->n_theta, tr->n_phi, s, in->ell_min, in->ell_max, syn, &ring_theta))) return rc;
       axis_boost = syn.large || syn.nt != 0;
@@ -2132,7 +2201,7 @@ static int transform_modes_impl(bms_ctx* c, const bms_wm_input* in, const bms_tr
   const bool sep = no_boost ? (syn.nt != 0 || syn.large) : axis_boost;
   // Dense route: the back substitution commutes with the synthesis product as well, so it runs on the modes too and the product's
   // epilogue evaluates the spline (kernels_gemm_eval.hip): the grid of coefficients never reaches HBM.
-  const bool gemm_eval = bs && !sep && rows_avail >= 8 && !route_env("SCRI_AMD_NO_GEMM_EVAL");
+  const bool gemm_eval = bs && !sep && rows_avail >= 8 && !c->opt.on(OPT_NO_GEMM_EVAL);
   // Separable route without a boost, grids the one-kernel synthesis takes: the same step -- the whole solve on the modes, and the
   // synthesis kernel evaluates the spline from the last four coefficient rows it has produced (kernels_synthesis_eval.hip).  NOT the
   // default (SCRI_AMD_SYNTHESIS_EVAL selects it): built for VERDICT r4 item 1, correct on every axis, and slower than the two kernels
@@ -2144,7 +2213,10 @@ static int transform_modes_impl(bms_ctx* c, const bms_wm_input* in, const bms_tr
   {
     size_t se_lds = 0;
     int se_nph = 0, se_rr = 0, se_xw = 0;
-    if (sep && no_boost && bs && syn.nt != 0 && rows_avail >= 8 && in->t && route_env("SCRI_AMD_SYNTHESIS_EVAL") &&
+    // Shape rule (round 6): from l_max = SYN_EVAL_MIN_ELL on the fused kernel is ahead of the two it replaces on every time axis
+    // (profiles/r06_*_boost_free_routes_by_ell.txt), below it is behind; options SYNTHESIS_EVAL / NO_SYNTHESIS_EVAL force either.
+    const bool want_syn_eval = c->opt.on(OPT_SYNTHESIS_EVAL) || (!c->opt.on(OPT_NO_SYNTHESIS_EVAL) && in->ell_max >= SYN_EVAL_MIN_ELL);
+    if (sep && no_boost && bs && syn.nt != 0 && rows_avail >= 8 && in->t && want_syn_eval &&
         synthesis_eval_supported(syn.g, syn.nt, &se_lds, &se_nph, &se_rr, &se_xw)) {
       double bound = 0.0;
       for (int l = 1; l <= lst; ++l)
@@ -2175,7 +2247,7 @@ static int transform_modes_impl(bms_ctx* c, const bms_wm_input* in, const bms_tr
     // SIMDs, which this kernel's 2 x 245 registers per lane do not leave -- the host's wait shrinks from 300 to 250 us, but the solve
     // starts that much later and the product waits for it: 5.56 against 5.41 ms per transform.)
     if ((rc = dev_buf_t(c, "Afull", (size_t)rows_avail * ld_af, &d_Ac))) return rc;
-    if (route_env("SCRI_AMD_TWO_SWEEPS")) {
+    if (c->opt.on(OPT_TWO_SWEEPS)) {
       if ((rc = dev_buf_t(c, "Afwd", (size_t)rows_avail * ld_af, &d_Af))) return rc;
       TIMED(c, BMS_TAG_SPLINE_FORWARD, launch_bspline_forward_modes(S, F[0].d_data, F[0].ld * 2, n_modes, d_Af, ld_af, row0, rows_avail, n, d_bsfwd,
                                                                     SPLINE_TILE, SPLINE_HALO, 1));
@@ -2218,8 +2290,8 @@ static int transform_modes_impl(bms_ctx* c, const bms_wm_input* in, const bms_tr
   // as they do behind the dense product.
   SynthesisPlan syn_f[5];
   bool sep_fields = false;
-  if (!bs && rows_avail >= 1 && !(sh && sh->col_parts > 1) && tr->n_theta >= 3 && !route_env("SCRI_AMD_NO_SEPARABLE_SYNTHESIS") &&
-      (no_boost || (axis_boost_pays(n_modes, tr->n_theta, tr->n_phi) && separable_rotor_grid(c, tr, ring_theta)))) {
+  if (!bs && rows_avail >= 1 && !(sh && sh->col_parts > 1) && tr->n_theta >= 3 && !c->opt.on(OPT_NO_SEPARABLE_SYNTHESIS) &&
+      (no_boost || (axis_boost_pays(c, n_modes, tr->n_theta, tr->n_phi) && separable_rotor_grid(c, tr, ring_theta)))) {
     sep_fields = true;
     for (int fi = 0; fi < 1 + (psi ? in->n_aux : 0) && sep_fields; ++fi) {
       const int f_spin = fi ? in->aux_spin[fi - 1] : s, f_lo = fi ? in->aux_ell_min[fi - 1] : in->ell_min, f_hi = fi ? in->aux_ell_max[fi - 1] : in->ell_max;
@@ -2233,7 +2305,7 @@ static int transform_modes_impl(bms_ctx* c, const bms_wm_input* in, const bms_tr
   }
   PixelTables T;
   DevPixel DP;
-  const int col_plan = (grid_out || sep || sep_fields) ? 0 : column_plan(tr, n_out);
+  const int col_plan = (grid_out || sep || sep_fields) ? 0 : column_plan(c, tr, n_out);
   bool B_built = false;
   if (shared && c->piece_tables_valid) {
     // (the pieces of a pipelined call share the per-direction tables of the first one, built in ITS column order: a piece that
@@ -2455,11 +2527,9 @@ static int transform_modes_impl(bms_ctx* c, const bms_wm_input* in, const bms_tr
         HIP_TRY(c, hipMemsetAsync(c->d_eval_stats, 0, 16, S));
       }
       ev.stats = c->d_eval_stats;
-      {
-        const uint64_t nbm = (uint64_t)((rows_in + 63) / 64), nbn = (uint64_t)((n_pix + 63) / 64);
-        c->eval_tiles += nbm * nbn + (nbm > 0 ? nbm - 1 : 0) * nbn;
-      }
-      const int eval_step = route_env("SCRI_AMD_GEMM_EVAL_STEP") ? atoi(route_env("SCRI_AMD_GEMM_EVAL_STEP")) : 64;  // (read per call, like the other route switches)
+      const int eval_step = c->opt.v[OPT_GEMM_EVAL_STEP] ? (int)c->opt.v[OPT_GEMM_EVAL_STEP] : 64;
+      ev.step = eval_step;
+      c->eval_tiles += eval_tile_count(rows_in, n_pix, eval_step);
       if (eval_step != 61)
         if ((rc = dev_buf_t(c, "Cside", (size_t)zgemm3m_eval_side_rows(rows_in) * ldg, &ev.side))) return rc;
       TIMED(c, BMS_TAG_GEMM_SYNTHESIS, launch_zgemm3m_eval(S, d_Ac + (g0 - row0) * ld_af, ld_af, F[0].d_B + 2 * cA, ldb, rows_in, n_pix, n_modes_in + 1,
@@ -2895,7 +2965,7 @@ extern "C" int bms_salm2map(bms_ctx* c, const void* modes, int mem, int64_t n_ma
   const long long P2 = 2LL * n_pix, ldb = round_up(P2, 128);
   // the equiangular grid itself: separable (kernels_synthesis_large.hip) wherever that kernel takes the shape
   SynthesisPlan syn;
-  if (n_theta >= 3 && ell_max >= 1 && !route_env("SCRI_AMD_NO_SEPARABLE_SYNTHESIS"))
+  if (n_theta >= 3 && ell_max >= 1 && !c->opt.on(OPT_NO_SEPARABLE_SYNTHESIS))
     if ((rc = build_synthesis(c, n_theta, n_phi, spin, 0, ell_max, syn))) return rc;
   double* d_B = nullptr;
   if (!syn.large) {
@@ -3031,7 +3101,7 @@ extern "C" int bms_grid_multiply(bms_ctx* c, const void* a, int spin_a, int ell_
   // map2salm -- so the smallest such W serves: the reference's default (W = B, output l_a) needs 2.3 times fewer pixels, and for
   // l_a + l_b <= 25 it is a grid the separable synthesis and the fused analysis take (n_theta <= 40).  A caller's smaller W
   // (aliasing, as in the reference) is kept as given.
-  if (working_ell_max >= ell_max_a + ell_max_b && !route_env("SCRI_AMD_GRID_MULTIPLY_FULL_GRID")) {
+  if (working_ell_max >= ell_max_a + ell_max_b && !c->opt.on(OPT_GRID_MULTIPLY_FULL_GRID)) {
     const int B = ell_max_a + ell_max_b;
     working_ell_max = std::max({(B + output_ell_max + 1) / 2, (B + 2) / 2, output_ell_max, 1});
   }
@@ -3050,7 +3120,7 @@ extern "C" int bms_grid_multiply(bms_ctx* c, const void* a, int spin_a, int ell_
     }
   // the equiangular grid itself: both syntheses are separable where the kernel takes the shape (kernels_synthesis.hip)
   SynthesisPlan syn_a, syn_b;
-  bool sep = n_times >= 2 && ell_max_a >= 1 && ell_max_b >= 1 && !route_env("SCRI_AMD_NO_SEPARABLE_SYNTHESIS");
+  bool sep = n_times >= 2 && ell_max_a >= 1 && ell_max_b >= 1 && !c->opt.on(OPT_NO_SEPARABLE_SYNTHESIS);
   if (sep) {
     if ((rc = build_synthesis(c, n_theta, n_phi, spin_a, 0, ell_max_a, syn_a))) return rc;
     if ((rc = build_synthesis(c, n_theta, n_phi, spin_b, 0, ell_max_b, syn_b))) return rc;
@@ -3263,9 +3333,9 @@ static int transform_abd_impl(bms_ctx* c, const double* u, const void* raw, int 
   SynthesisPlan syn5[5];
   const bool no_boost = v[0] == 0 && v[1] == 0 && v[2] == 0;
   std::vector<double> ring_theta;
-  bool sep = !(sh && sh->col_parts > 1) && tr->n_theta >= 3 && !route_env("SCRI_AMD_NO_SEPARABLE_SYNTHESIS") &&
-             (no_boost || (axis_boost_pays((ell_max + 1) * (ell_max + 1), tr->n_theta, tr->n_phi) &&
-                           large_synthesis_supported(tr->n_theta, tr->n_phi, 0, ell_max) && separable_rotor_grid(c, tr, ring_theta)));
+  bool sep = !(sh && sh->col_parts > 1) && tr->n_theta >= 3 && !c->opt.on(OPT_NO_SEPARABLE_SYNTHESIS) &&
+             (no_boost || (axis_boost_pays(c, (ell_max + 1) * (ell_max + 1), tr->n_theta, tr->n_phi) &&
+                           large_synthesis_route(c, tr->n_theta, tr->n_phi, 0, ell_max) && separable_rotor_grid(c, tr, ring_theta)));
   for (int si = 0; si < 5 && sep; ++si) {
     if ((rc = build_synthesis(c, tr->n_theta, tr->n_phi, si - 2, 0, ell_max, syn5[si], no_boost ? nullptr : &ring_theta))) return rc;
     sep = syn5[si].large;
@@ -3278,7 +3348,7 @@ static int transform_abd_impl(bms_ctx* c, const double* u, const void* raw, int 
     T = shared->T;
     DP = shared->DP;
   } else {
-    if ((rc = device_pixel_tables(c, tr, T, 2, 0, 0, &c1, &c2, cv, DP, sep ? 0 : column_plan(tr, n_out)))) return rc;
+    if ((rc = device_pixel_tables(c, tr, T, 2, 0, 0, &c1, &c2, cv, DP, sep ? 0 : column_plan(c, tr, n_out)))) return rc;
     if (shared) {
       shared->T = T;
       shared->DP = DP;
@@ -3313,7 +3383,7 @@ static int transform_abd_impl(bms_ctx* c, const double* u, const void* raw, int 
   double* d_x;
   // the Horner mixing has time-dependent coefficients, so the elimination stays on the grid; the B-spline form still saves
   // the back substitution its second input stream (kernels_bspline.hip)
-  const bool bsg = n >= 8 && regular_mesh && !route_env("SCRI_AMD_NO_BSPLINE");
+  const bool bsg = n >= 8 && regular_mesh && !c->opt.on(OPT_NO_BSPLINE);
   SplineTable* d_tab = nullptr;
   BsplineTable* d_bstab = nullptr;
   BsplineForward* d_bsfwd = nullptr;
@@ -3365,7 +3435,8 @@ static int transform_abd_impl(bms_ctx* c, const double* u, const void* raw, int 
   // Without a boost the Horner mixing has time-independent coefficients (k = 1, eth k = 0: X = -eth alpha), so it commutes with the
   // spline's forward elimination: that runs on the MODES (6 x (l_max+1)^2 columns + the constant series, instead of six grids), the
   // fields are synthesised as eliminated coefficients and mixed on their way out of the phi stage (phi_synthesis_mix6_kernel)
-  const bool fused_mix = sep && no_boost && bsg && !short_series && abd_mix6_supported(tr->n_theta, tr->n_phi, ell_max);
+  const bool fused_mix = sep && no_boost && bsg && !short_series && !c->opt.on(OPT_NO_FUSED_ABD_MIX) && large_synthesis_route(c, tr->n_theta, tr->n_phi, 0, ell_max) &&
+                         abd_mix6_supported(tr->n_theta, tr->n_phi, ell_max);
   const long long ld_af = round_up(2LL * (nm + 1), 16);
   double* d_Af = nullptr;
   if (fused_mix) {
@@ -3408,7 +3479,7 @@ static int transform_abd_impl(bms_ctx* c, const double* u, const void* raw, int 
   // sigma' = (sigma - eth eth alpha) / k mixes with nothing and its offset and scale do not depend on time: it takes the evaluating
   // product of the WaveformModes route (its spline solved on the modes, evaluated in the product's epilogue, kernels_gemm_eval.hip) and
   // stays out of the mixing + elimination pass and of the back substitution -- two of the four passes over its grid
-  const bool sigma_eval = !sep && bsg && !short_series && rows_avail >= 8 && !route_env("SCRI_AMD_NO_ABD_SIGMA_EVAL");
+  const bool sigma_eval = !sep && bsg && !short_series && rows_avail >= 8 && !c->opt.on(OPT_NO_ABD_SIGMA_EVAL);
   double* d_As = nullptr;
   if (sigma_eval) {
     if ((rc = dev_buf_t(c, "abd_As", (size_t)rows_avail * ld_af, &d_As))) return rc;
@@ -3500,8 +3571,16 @@ static int transform_abd_impl(bms_ctx* c, const double* u, const void* raw, int 
         ev.i_lo = c0, ev.i_hi = c1_, ev.out = Gf, ev.ldo = ldG;
         ev.search_halfwidth = eval_search_halfwidth(T, cA, cB, u, g0, g1);
         ev.inv_dx = (g1 - g0 >= 2 && u[g1 - 1] > u[g0]) ? (double)(g1 - 1 - g0) / (u[g1 - 1] - u[g0]) : 0.0;
-        ev.side = nullptr, ev.side_ld = ldg, ev.stats = nullptr;
-        if ((rc = dev_buf_t(c, "Cside", (size_t)zgemm3m_eval_side_rows(rows_in) * ldg, &ev.side))) return rc;
+        ev.side = nullptr, ev.side_ld = ldg;
+        if (!c->d_eval_stats) {
+          HIP_TRY(c, hipMalloc(&c->d_eval_stats, 16));
+          HIP_TRY(c, hipMemsetAsync(c->d_eval_stats, 0, 16, S));
+        }
+        ev.stats = c->d_eval_stats;
+        ev.step = c->opt.v[OPT_GEMM_EVAL_STEP] == 61 ? 61 : 64;
+        c->eval_tiles += eval_tile_count(rows_in, n_pix, ev.step);
+        if (ev.step != 61)
+          if ((rc = dev_buf_t(c, "Cside", (size_t)zgemm3m_eval_side_rows(rows_in) * ldg, &ev.side))) return rc;
         const int skip = 4 < nm ? 4 : 0;  // (spin 2: no modes below l = 2)
         TIMED(c, BMS_TAG_GEMM_SYNTHESIS, launch_zgemm3m_eval(S, d_As + (g0 - row0) * ld_af + 2 * skip, ld_af, d_B[4] + 2 * cA + (size_t)skip * ldb, ldb, rows_in,
                                                              n_pix, nm - skip + 1, DP.col_scale + 2 * cA, ev));

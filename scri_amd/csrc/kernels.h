@@ -124,7 +124,7 @@ hipError_t launch_dft_cs_matrix(hipStream_t stream, int n_phi, int L, double* D)
 // rings are read from their ring's column times the spin phase e^{-+ i spin phi_k}
 hipError_t launch_analysis_fused(hipStream_t stream, const double* G, long long ldg, long long n_rows, int n_theta, int n_phi,
                                  int L, int n_out, const int* m_index, const double* T, const double* D, double* out,
-                                 long long ldo, const int* col_of_pixel, int spin);
+                                 long long ldo, const int* col_of_pixel, int spin, bool allow_split = true);
 
 // series of 2 or 3 samples (ABD flavour): line / parabola through the samples, rows 0..n-1 of Y
 hipError_t launch_short_series_eval(hipStream_t stream, const double* Y, long long ld, int n_cols, int n, const double* x,
@@ -208,6 +208,7 @@ struct SplineEval {
   unsigned long long* stats;  // device, or null: [0] += tiles whose samples left the staged window, [1] += marches continued from global memory
   double* side;          // 6 rows of ldc doubles per 64-row tile (zgemm3m_eval_side_rows(M) rows), or null: overlapping tiles
   long long side_ld;
+  int step = 0;          // rows a tile advances: 0 = automatic (64 with `side`, 61 without), 61 or 64 (the context's GEMM_EVAL_STEP option)
 };
 long long zgemm3m_eval_side_rows(long long M);
 hipError_t launch_zgemm3m_eval(hipStream_t stream, const double* A, long long lda, const double* B, long long ldb, long long M, int N,

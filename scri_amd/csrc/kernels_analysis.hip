@@ -656,7 +656,6 @@ __global__ __launch_bounds__(640, 1) void analysis_split_kernel(
 }
 
 int split_analysis_supported(int n_theta, int n_phi, int L, int n_out, bool dedup_poles, SplitGeom& g, size_t& lds_bytes, int& nt) {
-  if (route_env("SCRI_AMD_NO_SPLIT_ANALYSIS")) return 0;
   if (n_theta < 3 || n_theta > 40 || n_phi < 2 || L < 1 || L > 16) return 0;
   // (n_rows >= 2 and 16 ldg < 2^31 are checked by the caller)
   g.n_theta = n_theta;
@@ -687,7 +686,7 @@ static hipError_t launch_fused_t(K kernel, hipStream_t stream, dim3 grid, dim3 b
 
 hipError_t launch_analysis_fused(hipStream_t stream, const double* G, long long ldg, long long n_rows, int n_theta, int n_phi,
                                  int L, int n_out, const int* m_index, const double* T, const double* D, double* out,
-                                 long long ldo, const int* col_of_pixel, int spin) {
+                                 long long ldo, const int* col_of_pixel, int spin, bool allow_split) {
   if (n_rows <= 0) return hipSuccess;
   FusedGeom g;
   size_t lds;
@@ -697,7 +696,7 @@ hipError_t launch_analysis_fused(hipStream_t stream, const double* G, long long 
     SplitGeom sg;
     size_t slds;
     int nt;
-    if (n_rows >= 2 && ldg < (1LL << 26) && split_analysis_supported(n_theta, n_phi, L, n_out, col_of_pixel != nullptr, sg, slds, nt)) {
+    if (allow_split && n_rows >= 2 && ldg < (1LL << 26) && split_analysis_supported(n_theta, n_phi, L, n_out, col_of_pixel != nullptr, sg, slds, nt)) {
       sg.spin = spin;
       // Prefetch: measured at cfg3 it takes the gathered grid of the transformation from 0.67 to 0.52 ms per 1e5 rows (its
       // 16-byte pieces land on 64 different lines per request and are expensive as L2 misses), costs the same shape in

@@ -627,8 +627,7 @@ hipError_t launch_zgemm3m_eval(hipStream_t stream, const double* A, long long ld
   static const int dbg_env = BMS_PROBE_ENV("SCRI_AMD_GEMM_EVAL_DBG") ? atoi(BMS_PROBE_ENV("SCRI_AMD_GEMM_EVAL_DBG")) : 0;
   ev.dbg = dbg_env;
 #endif
-  const int step_env = route_env("SCRI_AMD_GEMM_EVAL_STEP") ? atoi(route_env("SCRI_AMD_GEMM_EVAL_STEP")) : 0;
-  const int step = (step_env == 61 || step_env == 64) ? step_env : (e.side ? 64 : 61);
+  const int step = (e.step == 61 || e.step == 64) ? e.step : (e.side ? 64 : 61);  // (e.step: the context's GEMM_EVAL_STEP option, 0 = automatic)
   if (step == 64 && !e.side) return hipErrorInvalidValue;
   if (step == 61) ev.side = nullptr;
   const int nbm = step == 61 ? (int)((M - 3 + 60) / 61) : (int)((M + 63) / 64);

@@ -304,7 +304,6 @@ size_t synthesis_split_scale_bytes(int n_theta, int n_phi) { return sizeof(doubl
 // meta[list][e] = mode index | m slot << 10 | flush << 16 | valid << 17.
 int synthesis_split_plan(int n_theta, int n_phi, int ell_min, int ell_max, SynGeom& g, std::vector<int>& meta, size_t& lds_bytes,
                          int& nt, int& len) {
-  if (route_env("SCRI_AMD_NO_SEPARABLE_SYNTHESIS")) return 0;
   if (n_theta < 3 || n_theta > 40 || n_phi < 2 || n_phi / 2 + 1 > 17 + SYN_XCOLS || ell_max < 1 || ell_max > 16 || ell_min < 0 || ell_min > ell_max) return 0;
   const int n_modes = (ell_max + 1) * (ell_max + 1) - ell_min * ell_min;
   if (n_modes > 1023) return 0;

@@ -415,7 +415,6 @@ __global__ __launch_bounds__(64) void phi_synthesis_mix6_kernel(Mix6Args a, long
 }
 
 int large_synthesis_supported(int n_theta, int n_phi, int ell_min, int ell_max) {
-  if (route_env("SCRI_AMD_NO_SEPARABLE_SYNTHESIS") || route_env("SCRI_AMD_NO_LARGE_SYNTHESIS")) return 0;
   const int nk = n_phi / 2 + 1;
   return n_theta >= 2 && n_theta <= 104 && n_phi >= 1 && nk <= 64 && ell_max >= 1 && ell_max <= 33 && ell_min >= 0 && ell_min <= ell_max;
 }
@@ -529,7 +528,6 @@ hipError_t launch_theta_synthesis(hipStream_t stream, const double* A, long long
 }
 
 int abd_mix6_supported(int n_theta, int n_phi, int ell_max) {
-  if (route_env("SCRI_AMD_NO_FUSED_ABD_MIX")) return 0;
   // (the F tiles of a pass borrow the LDS area of its results: 2 L + 1 <= n_phi; three workgroups or more per CU)
   return large_synthesis_supported(n_theta, n_phi, 0, ell_max) && 2 * ell_max + 1 <= n_phi && (size_t)6 * 4 * n_phi * 16 <= 53 * 1024;
 }

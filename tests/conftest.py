@@ -46,3 +46,32 @@ def _oracle_pole_convention(request):
     quat.ROBUST_POLES = request.node.get_closest_marker("gpu") is not None
     yield
     quat.ROBUST_POLES = old
+
+
+@pytest.fixture
+def route(monkeypatch):
+    """route(name, value="1"): a route option (scri_amd/csrc/env.h) for the duration of one test -- set on every live context of
+    the process through bms_ctx_set_option (contexts read the environment only when they are created) AND exported, so that a
+    context the test creates afterwards starts with it.  Names that are not route options (SCRI_AMD_NO_PIPELINE and the other
+    Python-level switches) are plain environment variables."""
+    from scri_amd import _lib
+
+    changed = []
+
+    def set_(name, value="1"):
+        """value None: back to the built-in default (the variable removed, the option cleared)"""
+        if value is None:
+            monkeypatch.delenv(name, raising=False)
+            value = -1 if name.endswith("AXIS_BOOST_MIN_WORK") else 0  # (its 0 means "always": the unset state is -1)
+        else:
+            monkeypatch.setenv(name, str(value))
+        for c in _lib.live_contexts():
+            try:
+                changed.append((c, name, c.option(name, int(value))))
+            except ValueError:
+                return  # not a route option of the library: the environment variable is all there is
+
+    yield set_
+    for c, name, old in reversed(changed):
+        if getattr(c, "_h", None):
+            c.option(name, old)

@@ -59,16 +59,16 @@ FRAMES = [
 
 @pytest.mark.parametrize("case", range(len(FRAMES)))
 @pytest.mark.parametrize("ell_max,n,working,forced", [(4, 120, None, True), (10, 64, None, False), (6, 40, 15, True), (20, 24, None, False)])
-def test_abd_axis_boost_separable_equals_dense_and_oracle(ctx, monkeypatch, case, ell_max, n, working, forced):
+def test_abd_axis_boost_separable_equals_dense_and_oracle(ctx, monkeypatch, case, ell_max, n, working, forced, route):
     import scri_amd
 
     rotor, v, certain = FRAMES[case]
     if ell_max > 10 and case not in (0, 3):
         pytest.skip("large l_max: two frames are enough")
     if forced:
-        monkeypatch.setenv("SCRI_AMD_AXIS_BOOST_MIN_WORK", "0")
+        route("SCRI_AMD_AXIS_BOOST_MIN_WORK", "0")
     else:
-        monkeypatch.delenv("SCRI_AMD_AXIS_BOOST_MIN_WORK", raising=False)
+        route("SCRI_AMD_AXIS_BOOST_MIN_WORK", None)
     o = smooth_abd(n, ell_max, 300 + ell_max + n)
     kw = dict(supertranslation=real_st(min(ell_max, 3), 7, 0.05), boost_velocity=np.asarray(v, dtype=float))
     if rotor is not None:
@@ -81,13 +81,13 @@ def test_abd_axis_boost_separable_equals_dense_and_oracle(ctx, monkeypatch, case
         g._raw_data[:] = o.raw
         return g.transform(**kw)
 
-    monkeypatch.delenv("SCRI_AMD_NO_SEPARABLE_SYNTHESIS", raising=False)
-    monkeypatch.delenv("SCRI_AMD_NO_AXIS_BOOST_SEPARABLE", raising=False)
+    route("SCRI_AMD_NO_SEPARABLE_SYNTHESIS", None)
+    route("SCRI_AMD_NO_AXIS_BOOST_SEPARABLE", None)
     ctx.enable_timing(True)
     ctx.get_timing(reset=True)
     got = run()
     n_sep = _rotations(ctx)
-    monkeypatch.setenv("SCRI_AMD_NO_AXIS_BOOST_SEPARABLE", "1")
+    route("SCRI_AMD_NO_AXIS_BOOST_SEPARABLE", "1")
     ref = run()
     n_dense = _rotations(ctx)
     ctx.enable_timing(False)
@@ -104,7 +104,7 @@ def test_abd_axis_boost_separable_equals_dense_and_oracle(ctx, monkeypatch, case
 @pytest.mark.parametrize("case", range(len(FRAMES)))
 @pytest.mark.parametrize("data_type,ell_max,forced", [("h", 8, True), ("sigma", 5, True), ("psi4", 12, True), ("psi3", 6, True), ("h", 16, False),
                                                        ("psi3", 14, False), ("h", 20, False)])
-def test_waveform_modes_axis_boost_separable_equals_dense_and_oracle(ctx, monkeypatch, case, data_type, ell_max, forced):
+def test_waveform_modes_axis_boost_separable_equals_dense_and_oracle(ctx, monkeypatch, case, data_type, ell_max, forced, route):
     import scri_amd
     from scri_amd import synthetic
 
@@ -112,9 +112,9 @@ def test_waveform_modes_axis_boost_separable_equals_dense_and_oracle(ctx, monkey
     if ell_max > 12 and case not in (1, 2):
         pytest.skip("large l_max: two frames are enough")
     if forced:
-        monkeypatch.setenv("SCRI_AMD_AXIS_BOOST_MIN_WORK", "0")
+        route("SCRI_AMD_AXIS_BOOST_MIN_WORK", "0")
     else:
-        monkeypatch.delenv("SCRI_AMD_AXIS_BOOST_MIN_WORK", raising=False)
+        route("SCRI_AMD_AXIS_BOOST_MIN_WORK", None)
     n = 150
     t = np.linspace(-30.0, 40.0, n)
     spins = {"psi3": -1, "psi4": -2, "h": -2, "sigma": 2}
@@ -136,13 +136,13 @@ def test_waveform_modes_axis_boost_separable_equals_dense_and_oracle(ctx, monkey
         extra = {k: wrap(k[:4], v_, abs(spins[k[:4]])) for k, v_ in aux.items()}
         return w.transform(**kw, **extra)
 
-    monkeypatch.delenv("SCRI_AMD_NO_SEPARABLE_SYNTHESIS", raising=False)
-    monkeypatch.delenv("SCRI_AMD_NO_AXIS_BOOST_SEPARABLE", raising=False)
+    route("SCRI_AMD_NO_SEPARABLE_SYNTHESIS", None)
+    route("SCRI_AMD_NO_AXIS_BOOST_SEPARABLE", None)
     ctx.enable_timing(True)
     ctx.get_timing(reset=True)
     got = run()
     n_sep = _rotations(ctx)
-    monkeypatch.setenv("SCRI_AMD_NO_AXIS_BOOST_SEPARABLE", "1")
+    route("SCRI_AMD_NO_AXIS_BOOST_SEPARABLE", "1")
     ref = run()
     n_dense = _rotations(ctx)
     ctx.enable_timing(False)
@@ -159,14 +159,14 @@ def test_waveform_modes_axis_boost_separable_equals_dense_and_oracle(ctx, monkey
         assert np.abs(got.data - expect.data).max() < 1e-12 * scale
 
 
-def test_oblique_boost_keeps_the_dense_route(ctx, monkeypatch):
+def test_oblique_boost_keeps_the_dense_route(ctx, monkeypatch, route):
     """A boost a hair off the axis is not separable: the engine's check has to send it to the dense product."""
     import scri_amd
 
     o = smooth_abd(40, 4, 5)
-    monkeypatch.setenv("SCRI_AMD_AXIS_BOOST_MIN_WORK", "0")
-    monkeypatch.delenv("SCRI_AMD_NO_SEPARABLE_SYNTHESIS", raising=False)
-    monkeypatch.delenv("SCRI_AMD_NO_AXIS_BOOST_SEPARABLE", raising=False)
+    route("SCRI_AMD_AXIS_BOOST_MIN_WORK", "0")
+    route("SCRI_AMD_NO_SEPARABLE_SYNTHESIS", None)
+    route("SCRI_AMD_NO_AXIS_BOOST_SEPARABLE", None)
     g = scri_amd.AsymptoticBondiData(o.u, o.ell_max, ctx=ctx)
     g._raw_data[:] = o.raw
     kw = dict(boost_velocity=[1e-9, 0.0, 0.3], frame_rotation=_zrot(0.4))
@@ -179,14 +179,14 @@ def test_oblique_boost_keeps_the_dense_route(ctx, monkeypatch):
     assert np.abs(got._raw_data - expect.raw).max() < 1e-12 * max(1.0, np.abs(expect.raw).max())
 
 
-def test_small_shapes_keep_the_dense_product(ctx, monkeypatch):
+def test_small_shapes_keep_the_dense_product(ctx, monkeypatch, route):
     """Below the break-even (l <= 8 on 17 x 17) an axis boost stays on the dense product, which is faster there."""
     import scri_amd
     from scri_amd import synthetic
 
-    monkeypatch.delenv("SCRI_AMD_AXIS_BOOST_MIN_WORK", raising=False)
-    monkeypatch.delenv("SCRI_AMD_NO_SEPARABLE_SYNTHESIS", raising=False)
-    monkeypatch.delenv("SCRI_AMD_NO_AXIS_BOOST_SEPARABLE", raising=False)
+    route("SCRI_AMD_AXIS_BOOST_MIN_WORK", None)
+    route("SCRI_AMD_NO_SEPARABLE_SYNTHESIS", None)
+    route("SCRI_AMD_NO_AXIS_BOOST_SEPARABLE", None)
     t = np.linspace(-30.0, 40.0, 100)
     w = scri_amd.WaveformModes(t=t, data=synthetic.chirp_modes(t, 2, 8, 4), ell_min=2, ell_max=8, dataType=scri_amd.h, frameType=scri_amd.Inertial,
                                r_is_scaled_out=True, m_is_scaled_out=True, ctx=ctx)
@@ -197,15 +197,15 @@ def test_small_shapes_keep_the_dense_product(ctx, monkeypatch):
     ctx.enable_timing(False)
 
 
-def test_axis_boost_time_shards_and_pipelined_pieces(ctx, monkeypatch):
+def test_axis_boost_time_shards_and_pipelined_pieces(ctx, monkeypatch, route):
     """The route under the time shards of the multi-GPU split and under the pipelined pieces of a host caller (every piece builds the
     ring tables of the same transformation): both reassemble to the one-call result."""
     import scri_amd
     from scri_amd import engine, sharding, synthetic
 
-    monkeypatch.delenv("SCRI_AMD_AXIS_BOOST_MIN_WORK", raising=False)
-    monkeypatch.delenv("SCRI_AMD_NO_SEPARABLE_SYNTHESIS", raising=False)
-    monkeypatch.delenv("SCRI_AMD_NO_AXIS_BOOST_SEPARABLE", raising=False)
+    route("SCRI_AMD_AXIS_BOOST_MIN_WORK", None)
+    route("SCRI_AMD_NO_SEPARABLE_SYNTHESIS", None)
+    route("SCRI_AMD_NO_AXIS_BOOST_SEPARABLE", None)
     n, ell_max = 5000, 14
     t = np.linspace(0.0, 500.0, n)
     data = synthetic.chirp_modes(t, 2, ell_max, 9)
@@ -264,37 +264,37 @@ def _axis_kwargs(rng, ell_max):
 
 
 @pytest.mark.parametrize("seed", range(24))
-def test_random_axis_boost_waveform_transform_against_the_oracle(ctx, monkeypatch, seed):
+def test_random_axis_boost_waveform_transform_against_the_oracle(ctx, monkeypatch, seed, route):
     """The seeded sweep of tests/test_gpu_fuzz.py (data types with their mixing terms, l ranges, grids, jittered time axes) with
     every boost along the grid's axis, all shapes pushed onto the separable route."""
     import tests.test_gpu_fuzz as fuzz
 
-    monkeypatch.setenv("SCRI_AMD_AXIS_BOOST_MIN_WORK", "0")
-    monkeypatch.delenv("SCRI_AMD_NO_SEPARABLE_SYNTHESIS", raising=False)
-    monkeypatch.delenv("SCRI_AMD_NO_AXIS_BOOST_SEPARABLE", raising=False)
+    route("SCRI_AMD_AXIS_BOOST_MIN_WORK", "0")
+    route("SCRI_AMD_NO_SEPARABLE_SYNTHESIS", None)
+    route("SCRI_AMD_NO_AXIS_BOOST_SEPARABLE", None)
     monkeypatch.setattr(fuzz, "_random_kwargs", _axis_kwargs)
     fuzz.test_random_waveform_transform(ctx, seed)
 
 
 @pytest.mark.parametrize("seed", range(8))
-def test_random_axis_boost_abd_transform_against_the_oracle(ctx, monkeypatch, seed):
+def test_random_axis_boost_abd_transform_against_the_oracle(ctx, monkeypatch, seed, route):
     import tests.test_gpu_fuzz as fuzz
 
-    monkeypatch.setenv("SCRI_AMD_AXIS_BOOST_MIN_WORK", "0")
-    monkeypatch.delenv("SCRI_AMD_NO_SEPARABLE_SYNTHESIS", raising=False)
-    monkeypatch.delenv("SCRI_AMD_NO_AXIS_BOOST_SEPARABLE", raising=False)
+    route("SCRI_AMD_AXIS_BOOST_MIN_WORK", "0")
+    route("SCRI_AMD_NO_SEPARABLE_SYNTHESIS", None)
+    route("SCRI_AMD_NO_AXIS_BOOST_SEPARABLE", None)
     monkeypatch.setattr(fuzz, "_random_kwargs", _axis_kwargs)
     fuzz.test_random_abd_transform(ctx, seed)
 
 
-def test_ring_tables_follow_the_transformation(ctx, monkeypatch):
+def test_ring_tables_follow_the_transformation(ctx, monkeypatch, route):
     """The ring tables are kept per shape together with the colatitudes they were built for: a second boost of another size (or
     sign) on the same shape must rebuild them, a repeat of the first must find them again."""
     import scri_amd
     from scri_amd import synthetic
 
-    monkeypatch.setenv("SCRI_AMD_AXIS_BOOST_MIN_WORK", "0")
-    monkeypatch.delenv("SCRI_AMD_NO_SEPARABLE_SYNTHESIS", raising=False)
+    route("SCRI_AMD_AXIS_BOOST_MIN_WORK", "0")
+    route("SCRI_AMD_NO_SEPARABLE_SYNTHESIS", None)
     t = np.linspace(-30.0, 40.0, 120)
     data = synthetic.chirp_modes(t, 2, 10, 21)
 
@@ -304,24 +304,24 @@ def test_ring_tables_follow_the_transformation(ctx, monkeypatch):
         return w.transform(boost_velocity=[0.0, 0.0, v], frame_rotation=_zrot(0.2))
 
     ref = {}
-    monkeypatch.setenv("SCRI_AMD_NO_AXIS_BOOST_SEPARABLE", "1")
+    route("SCRI_AMD_NO_AXIS_BOOST_SEPARABLE", "1")
     for v in (0.3, -0.45, 0.05):
         ref[v] = run(v)
-    monkeypatch.delenv("SCRI_AMD_NO_AXIS_BOOST_SEPARABLE")
+    route("SCRI_AMD_NO_AXIS_BOOST_SEPARABLE", None)
     for v in (0.3, -0.45, 0.3, 0.05, 0.05, -0.45):
         got = run(v)
         assert got.n_times == ref[v].n_times > 0
         assert np.abs(got.data - ref[v].data).max() < 2e-13 * max(1.0, np.abs(ref[v].data).max()), v
 
 
-def test_axis_boost_abd_pipelined_host_path(ctx, monkeypatch):
+def test_axis_boost_abd_pipelined_host_path(ctx, monkeypatch, route):
     """AsymptoticBondiData from host memory through the three-stream pipeline (bms_transform_abd_pipelined): every piece takes the
     separable route with the ring tables of the one transformation."""
     from scri_amd import engine
 
-    monkeypatch.setenv("SCRI_AMD_AXIS_BOOST_MIN_WORK", "0")
-    monkeypatch.delenv("SCRI_AMD_NO_SEPARABLE_SYNTHESIS", raising=False)
-    monkeypatch.delenv("SCRI_AMD_NO_AXIS_BOOST_SEPARABLE", raising=False)
+    route("SCRI_AMD_AXIS_BOOST_MIN_WORK", "0")
+    route("SCRI_AMD_NO_SEPARABLE_SYNTHESIS", None)
+    route("SCRI_AMD_NO_AXIS_BOOST_SEPARABLE", None)
     n, ell_max = 3000, 4
     o = smooth_abd(n, ell_max, 77, t0=0.0, t1=600.0)
     n_theta = 2 * (2 * ell_max) + 1

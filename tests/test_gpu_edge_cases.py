@@ -69,7 +69,7 @@ def test_dense_quadrature_path_for_very_fine_grids(ctx):
 
 
 @pytest.mark.parametrize("n_theta,n_phi,spin,ell_max,ell_min", [(45, 47, -2, 9, 2), (99, 99, 2, 24, 0), (64, 50, 0, 16, 0), (41, 96, -1, 20, 1), (104, 104, 1, 32, 0), (57, 60, -2, 3, 2)])
-def test_large_grid_analysis_variants(ctx, monkeypatch, n_theta, n_phi, spin, ell_max, ell_min):
+def test_large_grid_analysis_variants(ctx, monkeypatch, n_theta, n_phi, spin, ell_max, ell_min, route):
     """40 < n_theta <= 104: folded phi-DFT kernel + MFMA theta quadrature (odd and even rings, every template branch);
     the older phi-DFT GEMM + theta_quadrature_kernel pair stays reachable and must agree."""
     from scri_amd import engine
@@ -79,16 +79,16 @@ def test_large_grid_analysis_variants(ctx, monkeypatch, n_theta, n_phi, spin, el
     ref = spinsfast_ref.map2salm(f, spin, ell_max)[..., ell_min**2 :]
     got = engine.map2salm(f, spin, ell_max, ell_min=ell_min, ctx=ctx)
     assert np.abs(got - ref).max() < 2e-13 * max(1.0, np.abs(ref).max())
-    monkeypatch.setenv("SCRI_AMD_NO_LARGE_ANALYSIS", "1")
+    route("SCRI_AMD_NO_LARGE_ANALYSIS", "1")
     old = engine.map2salm(f, spin, ell_max, ell_min=ell_min, ctx=ctx)
     assert np.abs(old - ref).max() < 2e-13 * max(1.0, np.abs(ref).max())
 
 
 @pytest.mark.parametrize("n_theta,n_phi", [(20, 24), (31, 38), (19, 18), (39, 39), (17, 34)])
-def test_separable_synthesis_on_user_grids(ctx, n_theta, n_phi, monkeypatch):
+def test_separable_synthesis_on_user_grids(ctx, n_theta, n_phi, monkeypatch, route):
     """Boost-free transformations on caller-chosen grids, even n_phi included (a Nyquist column that is its own mirror image,
     side columns k = 17..19 of the 4x4x4 product) against the oracle."""
-    monkeypatch.setenv("SCRI_AMD_NO_SMALL_DENSE", "1")  # (shapes this small take the evaluating product by default: the separable kernels are meant)
+    route("SCRI_AMD_NO_SMALL_DENSE", "1")  # (shapes this small take the evaluating product by default: the separable kernels are meant)
     t = np.linspace(-5, 25, 180)
     _check(_wm(t, 6, 13), ctx, n_theta=n_theta, n_phi=n_phi, supertranslation=np.array([0.3, 0.1 - 0.2j, 0.15, -0.1 - 0.2j]),
            frame_rotation=np.array([0.8, -0.3, 0.4, 0.2]))
@@ -109,7 +109,7 @@ def test_separable_synthesis_on_user_grids(ctx, n_theta, n_phi, monkeypatch):
         (3, 5, 0, 1, 0, 7),       # the smallest grid the kernel takes
     ],
 )
-def test_fused_analysis_two_role_kernel_shapes(ctx, monkeypatch, n_theta, n_phi, spin, ell_max, ell_min, n_rows):
+def test_fused_analysis_two_role_kernel_shapes(ctx, monkeypatch, n_theta, n_phi, spin, ell_max, ell_min, n_rows, route):
     """n_theta <= 40, l_max <= 16: `analysis_split_kernel` (front waves: fold + MFMA, back waves: theta quadrature) for
     every combination of wave counts; the one-role kernel (SCRI_AMD_NO_SPLIT_ANALYSIS) stays reachable and must agree;
     repeated calls are bitwise equal."""
@@ -121,14 +121,14 @@ def test_fused_analysis_two_role_kernel_shapes(ctx, monkeypatch, n_theta, n_phi,
     got = engine.map2salm(f, spin, ell_max, ell_min=ell_min, ctx=ctx)
     assert np.abs(got - ref).max() < 2e-13 * max(1.0, np.abs(ref).max())
     assert np.array_equal(got, engine.map2salm(f, spin, ell_max, ell_min=ell_min, ctx=ctx))
-    monkeypatch.setenv("SCRI_AMD_NO_SPLIT_ANALYSIS", "1")
+    route("SCRI_AMD_NO_SPLIT_ANALYSIS", "1")
     old = engine.map2salm(f, spin, ell_max, ell_min=ell_min, ctx=ctx)
     assert np.abs(old - ref).max() < 2e-13 * max(1.0, np.abs(ref).max())
 
 
 @pytest.mark.parametrize("ell_max,n,data_type", [(8, 1501, "h"), (8, 700, "psi4"), (16, 901, "h"), (12, 333, "sigma"), (5, 64, "psi4")])
 @pytest.mark.parametrize("rotated", [False, True])
-def test_boost_free_transformations_take_the_separable_synthesis(ctx, monkeypatch, ell_max, n, data_type, rotated):
+def test_boost_free_transformations_take_the_separable_synthesis(ctx, monkeypatch, ell_max, n, data_type, rotated, route):
     """Without a boost the modes are rotated by the frame rotor and synthesised ring by ring (`synthesis_split_kernel`:
     theta stage on the VALU, folded phi stage on MFMA) instead of through the dense sYlm matrix; both routes must agree to
     rounding, with and without a frame rotation and with and without the inhomogeneous term of h / sigma."""
@@ -151,13 +151,13 @@ def test_boost_free_transformations_take_the_separable_synthesis(ctx, monkeypatc
                                    r_is_scaled_out=True, m_is_scaled_out=True, ctx=ctx)
         return w.transform(**kw)
 
-    monkeypatch.delenv("SCRI_AMD_NO_SEPARABLE_SYNTHESIS", raising=False)  # (the suite may be run with the switch set)
-    monkeypatch.setenv("SCRI_AMD_NO_SMALL_DENSE", "1")  # (up to l <= 8 the default is the evaluating product: next test)
+    route("SCRI_AMD_NO_SEPARABLE_SYNTHESIS", None)  # (the suite may be run with the switch set)
+    route("SCRI_AMD_NO_SMALL_DENSE", "1")  # (up to l <= 8 the default is the evaluating product: next test)
     ctx.enable_timing(True)
     ctx.get_timing(reset=True)
     got = run()
     assert rotated == ("rotate" in {k for k, v in ctx.get_timing(reset=True).items() if v[1]})  # the route was the separable one
-    monkeypatch.setenv("SCRI_AMD_NO_SEPARABLE_SYNTHESIS", "1")
+    route("SCRI_AMD_NO_SEPARABLE_SYNTHESIS", "1")
     ref = run()
     ctx.enable_timing(False)
     assert got.n_times == ref.n_times and np.array_equal(got.t, ref.t)
@@ -439,16 +439,16 @@ def test_reused_host_input_is_page_locked_and_released(ctx):
 
 
 @pytest.mark.parametrize("n", [6, 40])
-def test_separable_synthesis_reads_nothing_past_the_modes(ctx, monkeypatch, n):
+def test_separable_synthesis_reads_nothing_past_the_modes(ctx, monkeypatch, n, route):
     """Boost-free psi-type / slope-form transformations hand the one-kernel synthesis rows WITHOUT the constant column the h / sigma
     route appends: the kernel must not touch the element behind a row's modes (behind the last row: memory past the caller's
     buffer).  A device-resident series whose buffer is followed by NaNs shows it."""
-    monkeypatch.setenv("SCRI_AMD_NO_SMALL_DENSE", "1")
+    route("SCRI_AMD_NO_SMALL_DENSE", "1")
     import torch
     from scri_amd import engine, synthetic
 
-    monkeypatch.delenv("SCRI_AMD_NO_SEPARABLE_SYNTHESIS", raising=False)
-    monkeypatch.setenv("SCRI_AMD_NO_BSPLINE", "1")  # slope form: the synthesis reads the caller's rows directly
+    route("SCRI_AMD_NO_SEPARABLE_SYNTHESIS", None)
+    route("SCRI_AMD_NO_BSPLINE", "1")  # slope form: the synthesis reads the caller's rows directly
     ell_max = 8
     t = np.linspace(-3.0, 4.0, n)
     data = synthetic.chirp_modes(t, 2, ell_max, 17)
@@ -472,14 +472,14 @@ def test_separable_synthesis_reads_nothing_past_the_modes(ctx, monkeypatch, n):
 
     got = run()
     assert got.shape[0] > 0 and np.isfinite(got).all()
-    monkeypatch.setenv("SCRI_AMD_NO_SEPARABLE_SYNTHESIS", "1")  # the dense product reads exactly n_modes columns
+    route("SCRI_AMD_NO_SEPARABLE_SYNTHESIS", "1")  # the dense product reads exactly n_modes columns
     ref = run()
     assert got.shape == ref.shape and not np.array_equal(got, ref)
     assert np.abs(got - ref).max() < 1e-13 * max(1.0, np.abs(ref).max())
 
 
 @pytest.mark.parametrize("defect", ["swap", "repeat", "nan"])
-def test_defect_in_the_middle_of_the_time_axis_is_reported_by_the_late_walk(ctx, defect, monkeypatch):
+def test_defect_in_the_middle_of_the_time_axis_is_reported_by_the_late_walk(ctx, defect, monkeypatch, route):
     """The host walks the time axis while it waits for the per-direction tables (engine.hip, `walk_later`): by then the time axis is in
     HBM and the spline solve has been queued on it.  A defect found by that walk fails the call exactly as the walk-first order does,
     and the context is usable afterwards."""
@@ -504,19 +504,19 @@ def test_defect_in_the_middle_of_the_time_axis_is_reported_by_the_late_walk(ctx,
     messages = []
     for first in (False, True):
         if first:
-            monkeypatch.setenv("SCRI_AMD_WALK_FIRST", "1")
+            route("SCRI_AMD_WALK_FIRST", "1")
         with pytest.raises(ValueError, match=r"strictly increasing \(index 250[12]\)") as err:
             engine.transform_modes(bad, data, 2, ell_max, -2, -1, engine.BMS_TERM_H, tr, ctx=ctx)
         messages.append(str(err.value))
     assert messages[0] == messages[1]
-    monkeypatch.delenv("SCRI_AMD_WALK_FIRST")
+    route("SCRI_AMD_WALK_FIRST", None)
     again = engine.transform_modes(t, data, 2, ell_max, -2, -1, engine.BMS_TERM_H, tr, ctx=ctx)
     assert np.array_equal(again[0], good[0]) and np.array_equal(again[1], good[1])
 
 
 
 @pytest.mark.parametrize("ell_max,n,expect_dense", [(4, 300, True), (8, 900, True), (8, 9, True), (10, 400, False)])
-def test_small_boost_free_shapes_take_the_evaluating_product(ctx, monkeypatch, ell_max, n, expect_dense):
+def test_small_boost_free_shapes_take_the_evaluating_product(ctx, monkeypatch, ell_max, n, expect_dense, route):
     """Since the dense product evaluates the spline itself it beats separable synthesis + back substitution on the grid for small shapes
     (engine.hip, `small_dense`: n_modes x grid <= 40 000, i.e. up to l <= 8 on the default grid, and at least 8 rows): the route is chosen by
     that rule, and both routes agree to rounding."""
@@ -540,10 +540,10 @@ def test_small_boost_free_shapes_take_the_evaluating_product(ctx, monkeypatch, e
         return out, tags
 
     for k in ("SCRI_AMD_NO_SEPARABLE_SYNTHESIS", "SCRI_AMD_NO_SMALL_DENSE", "SCRI_AMD_NO_GEMM_EVAL"):
-        monkeypatch.delenv(k, raising=False)
+        route(k, None)
     got, tags = run()
     assert ("rotate" not in tags) == expect_dense  # (the separable route turns the modes into the rotated frame first)
-    monkeypatch.setenv("SCRI_AMD_NO_SMALL_DENSE", "1")
+    route("SCRI_AMD_NO_SMALL_DENSE", "1")
     ref, tags_ref = run()
     assert "rotate" in tags_ref
     assert np.array_equal(got.t, ref.t)
@@ -574,7 +574,7 @@ def _fused_case(ell_max, n, mesh, st_scale, seed):
 @pytest.mark.parametrize("mesh", ["uniform", "jitter", "graded", "rough"])
 @pytest.mark.parametrize("ell_max,n,st_scale", [(16, 700, 0.02), (16, 1900, 0.3), (12, 333, 0.3), (10, 5000, 0.2), (9, 64, 0.05), (16, 9, 0.01),
                                                  (14, 1100, 6.0)])
-def test_synthesis_with_the_evaluation_in_it_equals_the_two_pass_route_and_the_oracle(ctx, monkeypatch, mesh, ell_max, n, st_scale):
+def test_synthesis_with_the_evaluation_in_it_equals_the_two_pass_route_and_the_oracle(ctx, monkeypatch, mesh, ell_max, n, st_scale, route):
     """`synthesis_eval_kernel` (boost-free WaveformModes: the spline solved on the modes, evaluated by the synthesis kernel from the
     last four coefficient rows of each pixel) against the route it replaces -- elimination on the modes, `synthesis_split_kernel`,
     `bspline_backward_eval_kernel` -- and against the oracle: uniform, jittered, graded and rough time axes; supertranslations from
@@ -583,8 +583,8 @@ def test_synthesis_with_the_evaluation_in_it_equals_the_two_pass_route_and_the_o
     import scri_amd
 
     t, data, kw = _fused_case(ell_max, n, mesh, st_scale, 7 * ell_max + n)
-    monkeypatch.setenv("SCRI_AMD_NO_SMALL_DENSE", "1")
-    monkeypatch.delenv("SCRI_AMD_NO_SEPARABLE_SYNTHESIS", raising=False)
+    route("SCRI_AMD_NO_SMALL_DENSE", "1")
+    route("SCRI_AMD_NO_SEPARABLE_SYNTHESIS", None)
 
     def run():
         w = scri_amd.WaveformModes(t=t, data=data, ell_min=2, ell_max=ell_max, dataType=scri_amd.h, frameType=scri_amd.Inertial,
@@ -596,12 +596,12 @@ def test_synthesis_with_the_evaluation_in_it_equals_the_two_pass_route_and_the_o
         ctx.enable_timing(False)
         return out, tags
 
-    monkeypatch.setenv("SCRI_AMD_SYNTHESIS_EVAL", "1")
+    route("SCRI_AMD_SYNTHESIS_EVAL", "1")
     got, tags = run()
     dt_min = np.diff(t).min()
     if st_scale <= 0.3 and mesh in ("uniform", "jitter"):  # (elsewhere the bound on the spread of the skews may send the call to the old route)
         assert "spline_backward" not in tags, tags  # no pass over a grid of coefficients on this route
-    monkeypatch.delenv("SCRI_AMD_SYNTHESIS_EVAL", raising=False)
+    route("SCRI_AMD_SYNTHESIS_EVAL", None)
     ref, tags_ref = run()
     assert "spline_backward" in tags_ref
     assert got.n_times == ref.n_times and np.array_equal(got.t, ref.t)
@@ -613,7 +613,7 @@ def test_synthesis_with_the_evaluation_in_it_equals_the_two_pass_route_and_the_o
         assert np.abs(got.data - e.data).max() < 1e-12 * max(1.0, np.abs(e.data).max())
 
 
-def test_synthesis_with_the_evaluation_in_it_chunks_shards_and_grid_output(ctx, monkeypatch):
+def test_synthesis_with_the_evaluation_in_it_chunks_shards_and_grid_output(ctx, monkeypatch, route):
     """The same kernel under what the engine does around it: the time axis walked in chunks of a small work space (each chunk a
     launch with its own run-in rows), time shards with halos (what the ranks of a sharded run compute), a series long enough for
     several segments per workgroup, and the grid output of WaveformGrid.from_modes."""
@@ -622,15 +622,15 @@ def test_synthesis_with_the_evaluation_in_it_chunks_shards_and_grid_output(ctx, 
 
     ell_max, n = 16, 9000
     t, data, kw = _fused_case(ell_max, n, "jitter", 0.8, 99)
-    monkeypatch.setenv("SCRI_AMD_NO_SMALL_DENSE", "1")
-    monkeypatch.setenv("SCRI_AMD_SYNTHESIS_EVAL", "1")
+    route("SCRI_AMD_NO_SMALL_DENSE", "1")
+    route("SCRI_AMD_SYNTHESIS_EVAL", "1")
     n_theta = 2 * (ell_max + 3) + 1
     tr = engine.make_transformation(kw["supertranslation"], kw["frame_rotation"], [0.0, 0.0, 0.0], n_theta, n_theta, ell_max)
     t1, d1 = engine.transform_modes(t, data, 2, ell_max, -2, -1, engine.BMS_TERM_H, tr, ctx=ctx)
     d1 = np.array(d1)
-    monkeypatch.delenv("SCRI_AMD_SYNTHESIS_EVAL", raising=False)
+    route("SCRI_AMD_SYNTHESIS_EVAL", None)
     t0, d0 = engine.transform_modes(t, data, 2, ell_max, -2, -1, engine.BMS_TERM_H, tr, ctx=ctx)
-    monkeypatch.setenv("SCRI_AMD_SYNTHESIS_EVAL", "1")
+    route("SCRI_AMD_SYNTHESIS_EVAL", "1")
     scale = np.abs(d0).max()
     assert np.array_equal(t0, t1) and np.abs(d1 - d0).max() < 3e-13 * scale
     small = scri_amd.Context(0, workspace_limit=48 << 20)  # ~ 8 chunks
@@ -647,7 +647,7 @@ def test_synthesis_with_the_evaluation_in_it_chunks_shards_and_grid_output(ctx, 
     # from_modes on its own: the grid of samples in grid order, new route against old
     tg, g1 = engine.transform_modes(t[:1200], data[:1200], 2, ell_max, -2, -1, engine.BMS_TERM_H, tr, ctx=ctx, grid=True)
     g1 = np.array(g1)
-    monkeypatch.delenv("SCRI_AMD_SYNTHESIS_EVAL", raising=False)
+    route("SCRI_AMD_SYNTHESIS_EVAL", None)
     tg0, g0 = engine.transform_modes(t[:1200], data[:1200], 2, ell_max, -2, -1, engine.BMS_TERM_H, tr, ctx=ctx, grid=True)
     assert np.array_equal(tg, tg0) and g1.shape == g0.shape and np.abs(g1 - g0).max() < 3e-13 * max(1.0, np.abs(g0).max())
 

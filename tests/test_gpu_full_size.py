@@ -57,15 +57,15 @@ def test_cfg3_windows_match_oracle(cfg3):
         assert err < 1e-12 * max(1.0, np.abs(e.data).max()), (i0, err)
 
 
-def test_cfg3_size_without_boost_separable_equals_dense(cfg3, ctx, monkeypatch):
+def test_cfg3_size_without_boost_separable_equals_dense(cfg3, ctx, monkeypatch, route):
     """The cfg3 series (1e5 steps, l <= 16) through a boost-free transformation -- rotated modes + `synthesis_split_kernel` --
     against the dense sYlm product on the same grid, and a window of it against the oracle."""
     t, data, kw, _ = cfg3
     kw0 = {k: v for k, v in kw.items() if k != "boost_velocity"}
     got = _gpu_wm(t, data, 16, h, ctx).transform(**kw0)
-    monkeypatch.setenv("SCRI_AMD_NO_SEPARABLE_SYNTHESIS", "1")
+    route("SCRI_AMD_NO_SEPARABLE_SYNTHESIS", "1")
     ref = _gpu_wm(t, data, 16, h, ctx).transform(**kw0)
-    monkeypatch.delenv("SCRI_AMD_NO_SEPARABLE_SYNTHESIS")
+    route("SCRI_AMD_NO_SEPARABLE_SYNTHESIS", None)
     assert got.n_times == ref.n_times and np.array_equal(got.t, ref.t)
     assert np.abs(got.data - ref.data).max() < 1e-13 * max(1.0, np.abs(ref.data).max())
     i0 = 61_000
@@ -430,7 +430,7 @@ def test_cfg5_whole_series_equals_its_eight_shards_and_oracle_at_interior_seams(
         _abd_window_check(u_out[lo:hi], got_raw, kw, L, [(seam - 240, 480)])
 
 
-def test_cfg5_shard_size_without_boost_fused_route_equals_dense(ctx, monkeypatch):
+def test_cfg5_shard_size_without_boost_fused_route_equals_dense(ctx, monkeypatch, route):
     """One GPU's share of cfg5 (25 000 steps, six fields, l <= 24, 99 x 99 grid) under the workload's supertranslation and frame rotation
     WITHOUT its boost: elimination on the modes + two-kernel separable synthesis + phi stage fused with the mixing
     (kernels_synthesis_large.hip) against the six dense sYlm products + mixing and elimination on the grid (the route the oracle windows
@@ -447,15 +447,15 @@ def test_cfg5_shard_size_without_boost_fused_route_equals_dense(ctx, monkeypatch
     dev = torch.device("cuda", ctx.device)
     d_in = torch.from_numpy(raw).to(dev)
     outs = {}
-    for route, env in (("fused", {}), ("separable", {"SCRI_AMD_NO_FUSED_ABD_MIX": "1"}), ("dense", {"SCRI_AMD_NO_SEPARABLE_SYNTHESIS": "1"})):
+    for which, env in (("fused", {}), ("separable", {"SCRI_AMD_NO_FUSED_ABD_MIX": "1"}), ("dense", {"SCRI_AMD_NO_SEPARABLE_SYNTHESIS": "1"})):
         for k in ("SCRI_AMD_NO_FUSED_ABD_MIX", "SCRI_AMD_NO_SEPARABLE_SYNTHESIS"):
-            monkeypatch.delenv(k, raising=False)
+            route(k, None)
         for k, v in env.items():
-            monkeypatch.setenv(k, v)
+            route(k, v)
         d_out = torch.empty_like(d_in)
         torch.cuda.synchronize()
         u_out, n_new = engine.transform_abd(u, d_in.data_ptr(), L, tr, ctx=ctx, device=True, out_ptr=d_out.data_ptr())
-        outs[route] = (u_out, d_out[:, :n_new])
+        outs[which] = (u_out, d_out[:, :n_new])
     assert outs["dense"][1].shape[1] > n - 10
     scale = float(outs["dense"][1].abs().max())
     for route in ("fused", "separable"):

@@ -69,18 +69,8 @@ def test_random_waveform_transform(ctx, seed):
     aux_g = {k: gpu(v) for k, v in aux_o.items()}
     expect = grid_ref.transform(w, **kw, **aux_o)
     # (boost-free shapes this small take the evaluating product by default; odd seeds keep the separable kernels in the sweep)
-    import os
-
-    saved = os.environ.get("SCRI_AMD_NO_SMALL_DENSE")
-    if seed % 2:
-        os.environ["SCRI_AMD_NO_SMALL_DENSE"] = "1"
-    try:
+    with ctx.options(NO_SMALL_DENSE=seed % 2):
         got = gpu(w).transform(**kw, **aux_g)
-    finally:
-        if seed % 2:
-            os.environ.pop("SCRI_AMD_NO_SMALL_DENSE", None)
-            if saved is not None:
-                os.environ["SCRI_AMD_NO_SMALL_DENSE"] = saved
     info = (seed, dataType, ell_max, n, {k: (v if np.ndim(v) == 0 else np.round(np.asarray(v), 4).tolist()[:4]) for k, v in kw.items()})
     assert got.t.shape == expect.t.shape, info
     if expect.t.size:

@@ -58,16 +58,16 @@ WM_CASES = {
 
 @pytest.mark.parametrize("case", list(WM_CASES))
 @pytest.mark.parametrize("ell_max,n", [(8, 700), (16, 330), (5, 9)])
-def test_transform_modes_between_guards(ctx, monkeypatch, case, ell_max, n):
+def test_transform_modes_between_guards(ctx, monkeypatch, case, ell_max, n, route):
     from scri_amd import engine, synthetic
 
     spec = WM_CASES[case]
     for k in ("SCRI_AMD_NO_SEPARABLE_SYNTHESIS", "SCRI_AMD_NO_SPLIT_SYNTHESIS", "SCRI_AMD_AXIS_BOOST_MIN_WORK", "SCRI_AMD_NO_BSPLINE",
               "SCRI_AMD_NO_SPLIT_ANALYSIS", "SCRI_AMD_NO_AXIS_BOOST_SEPARABLE", "SCRI_AMD_GEMM_EVAL_STEP", "SCRI_AMD_TWO_SWEEPS", "SCRI_AMD_NO_GEMM_EVAL",
               "SCRI_AMD_NO_SMALL_DENSE", "SCRI_AMD_SYNTHESIS_EVAL"):
-        monkeypatch.delenv(k, raising=False)
+        route(k, None)
     for k, v in spec["env"].items():
-        monkeypatch.setenv(k, v)
+        route(k, v)
     t = np.linspace(-30.0, 40.0, n)
     data = synthetic.chirp_modes(t, 2, ell_max, 5 + ell_max)
     nm = data.shape[1]
@@ -95,14 +95,14 @@ def test_transform_modes_between_guards(ctx, monkeypatch, case, ell_max, n):
     ([0, 0, 0.05], _zrot(1.0), {"SCRI_AMD_AXIS_BOOST_MIN_WORK": "0"}),
 ])
 @pytest.mark.parametrize("ell_max,n", [(4, 300), (9, 90), (3, 3)])
-def test_transform_abd_between_guards(ctx, monkeypatch, boost, rot, env, ell_max, n):
+def test_transform_abd_between_guards(ctx, monkeypatch, boost, rot, env, ell_max, n, route):
     from scri_amd import engine
     from tests.test_gpu_transform_abd import real_st, smooth_abd
 
     for k in ("SCRI_AMD_NO_SEPARABLE_SYNTHESIS", "SCRI_AMD_NO_FUSED_ABD_MIX", "SCRI_AMD_AXIS_BOOST_MIN_WORK", "SCRI_AMD_NO_AXIS_BOOST_SEPARABLE"):
-        monkeypatch.delenv(k, raising=False)
+        route(k, None)
     for k, v in env.items():
-        monkeypatch.setenv(k, v)
+        route(k, v)
     o = smooth_abd(n, ell_max, 40 + n, t0=-1.0 if n < 4 else -15.0, t1=1.0 if n < 4 else 25.0)
     nm = (ell_max + 1) ** 2
     st = np.asarray(real_st(min(ell_max, 2), 3, 1e-3 if n < 4 else 0.05))
@@ -201,13 +201,13 @@ def test_device_series_operators_between_guards(ctx, ell_min, ell_max, spin, n):
     assert np.array_equal(view.cpu().numpy(), data)
 
 
-def test_psi_type_with_device_companions_and_a_shard_between_guards(ctx, monkeypatch):
+def test_psi_type_with_device_companions_and_a_shard_between_guards(ctx, monkeypatch, route):
     """psi3 with its psi4 companion from guarded device buffers, whole and as a time shard whose rows start mid-buffer: the
     shard's buffer holds ONLY the rows the plan names, so a read of any other row of the global series lands in the guards."""
     from scri_amd import engine, synthetic
 
     for k in ("SCRI_AMD_NO_SEPARABLE_SYNTHESIS", "SCRI_AMD_NO_BSPLINE"):
-        monkeypatch.delenv(k, raising=False)
+        route(k, None)
     n, ell_max = 1500, 7
     t = np.linspace(0.0, 150.0, n)
     psi3 = synthetic.chirp_modes(t, 1, ell_max, 3)
@@ -248,7 +248,7 @@ def test_psi_type_with_device_companions_and_a_shard_between_guards(ctx, monkeyp
 
 @pytest.mark.parametrize("env", [{}, {"SCRI_AMD_GEMM_EVAL_STEP": "61"}, {"SCRI_AMD_TWO_SWEEPS": "1"}])
 @pytest.mark.parametrize("boost_scale", [1.0, 40.0])
-def test_h_type_time_shard_through_the_evaluating_product_between_guards(ctx, monkeypatch, env, boost_scale):
+def test_h_type_time_shard_through_the_evaluating_product_between_guards(ctx, monkeypatch, env, boost_scale, route):
     """The dense route of the h type (spline solved on the modes in one pass, evaluated in the product's epilogue, straddle kernel)
     on a time shard from the middle of a series whose buffer holds ONLY the planned rows -- the solve kernel's run-in rows, the
     product's row tiles, the staged knot / abscissa windows and the side rows all end at the shard's edges -- and on the whole
@@ -256,7 +256,7 @@ def test_h_type_time_shard_through_the_evaluating_product_between_guards(ctx, mo
     from scri_amd import engine, synthetic
 
     for k in ("SCRI_AMD_GEMM_EVAL_STEP", "SCRI_AMD_TWO_SWEEPS", "SCRI_AMD_NO_GEMM_EVAL", "SCRI_AMD_NO_BSPLINE"):
-        monkeypatch.delenv(k, raising=False)
+        route(k, None)
     n, ell_max = 2100, 9
     t = np.linspace(0.0, 210.0, n) + 0.01 * np.sin(np.linspace(0.0, 60.0, n))  # (not quite uniform: the row guess has to be checked)
     data = synthetic.chirp_modes(t, 2, ell_max, 21)
@@ -264,11 +264,11 @@ def test_h_type_time_shard_through_the_evaluating_product_between_guards(ctx, mo
     st = synthetic.real_supertranslation(0.1 * (np.arange(9) - 2.0 + 0.5j * np.arange(9)))
     n_theta = 2 * (ell_max + 2) + 1
     tr = engine.make_transformation(st, [0.8, 0.2, -0.5, 0.1], list(boost_scale * np.array([2e-3, -1e-3, 3e-3])), n_theta, n_theta, ell_max)
-    monkeypatch.setenv("SCRI_AMD_NO_GEMM_EVAL", "1")
+    route("SCRI_AMD_NO_GEMM_EVAL", "1")
     t_ref, d_ref = engine.transform_modes(t, data, 2, ell_max, -2, -1, engine.BMS_TERM_H, tr, ctx=ctx)  # back substitution on the grid
-    monkeypatch.delenv("SCRI_AMD_NO_GEMM_EVAL")
+    route("SCRI_AMD_NO_GEMM_EVAL", None)
     for k, v in env.items():
-        monkeypatch.setenv(k, v)
+        route(k, v)
     scale = max(1.0, np.abs(d_ref).max())
     src, sp = _guarded_input(data)
     dst, dp = _guarded_output(n * nm)
@@ -291,14 +291,14 @@ def test_h_type_time_shard_through_the_evaluating_product_between_guards(ctx, mo
         _check_guards(dst, (o1 - o0) * nm)
 
 
-def test_abd_shard_and_column_parts_between_guards(ctx, monkeypatch):
+def test_abd_shard_and_column_parts_between_guards(ctx, monkeypatch, route):
     """An AsymptoticBondiData time shard from the middle of the series (its buffer holds only the planned rows of every field) and
     the WaveformModes grid-column parts (every part reads the whole series, writes its contribution to all output rows)."""
     from scri_amd import engine, synthetic
     from tests.test_gpu_transform_abd import smooth_abd
 
     for k in ("SCRI_AMD_NO_SEPARABLE_SYNTHESIS", "SCRI_AMD_NO_BSPLINE"):
-        monkeypatch.delenv(k, raising=False)
+        route(k, None)
     n, ell_max = 1200, 4
     o = smooth_abd(n, ell_max, 9, t0=0.0, t1=240.0)
     nm = (ell_max + 1) ** 2

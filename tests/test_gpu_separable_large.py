@@ -21,7 +21,7 @@ def _timing_tags(ctx):
 
 @pytest.mark.parametrize("ell_max,n,rotated,working", [(4, 300, False, None), (4, 301, True, None), (12, 96, True, None), (24, 40, True, None),
                                                       (24, 9, False, None), (6, 64, True, 9), (3, 3, True, None), (16, 50, True, 51)])
-def test_abd_boost_free_separable_equals_dense_and_oracle(ctx, monkeypatch, ell_max, n, rotated, working):
+def test_abd_boost_free_separable_equals_dense_and_oracle(ctx, monkeypatch, ell_max, n, rotated, working, route):
     import scri_amd
 
     o = smooth_abd(n, ell_max, 100 + ell_max + n, t0=-1.0 if n < 4 else -15.0, t1=1.0 if n < 4 else 25.0)
@@ -36,14 +36,14 @@ def test_abd_boost_free_separable_equals_dense_and_oracle(ctx, monkeypatch, ell_
         g._raw_data[:] = o.raw
         return g.transform(**kw)
 
-    monkeypatch.delenv("SCRI_AMD_NO_SEPARABLE_SYNTHESIS", raising=False)
+    route("SCRI_AMD_NO_SEPARABLE_SYNTHESIS", None)
     ctx.enable_timing(True)
     ctx.get_timing(reset=True)
     got = run()
     tags = _timing_tags(ctx)
     if got.n_times:  # (a window can come out empty for the 2-sample series: nothing is synthesised then)
         assert ("rotate" in tags) == rotated  # the separable route: the modes were rotated instead of the grid
-    monkeypatch.setenv("SCRI_AMD_NO_SEPARABLE_SYNTHESIS", "1")
+    route("SCRI_AMD_NO_SEPARABLE_SYNTHESIS", "1")
     ref = run()
     assert "rotate" not in _timing_tags(ctx)
     ctx.enable_timing(False)
@@ -57,7 +57,7 @@ def test_abd_boost_free_separable_equals_dense_and_oracle(ctx, monkeypatch, ell_
 
 
 @pytest.mark.parametrize("data_type,ell_max,rotated", [("psi2", 6, True), ("psi3", 8, False), ("psi2", 18, True), ("h", 20, True), ("h", 24, False)])
-def test_waveform_modes_boost_free_psi_types_and_large_ell(ctx, monkeypatch, data_type, ell_max, rotated):
+def test_waveform_modes_boost_free_psi_types_and_large_ell(ctx, monkeypatch, data_type, ell_max, rotated, route):
     """psi2 needs psi3 and psi4, psi3 needs psi4 (waveform_grid.py:417-426): each companion is synthesised with its own spin; h with
     l_max > 16 takes the same kernels with the elimination on the modes and the offset column."""
     import scri_amd
@@ -88,12 +88,12 @@ def test_waveform_modes_boost_free_psi_types_and_large_ell(ctx, monkeypatch, dat
         extra = {k: wrap(k[:4], v, abs(spins[k[:4]])) for k, v in aux.items()}
         return w.transform(**kw, **extra)
 
-    monkeypatch.delenv("SCRI_AMD_NO_SEPARABLE_SYNTHESIS", raising=False)
+    route("SCRI_AMD_NO_SEPARABLE_SYNTHESIS", None)
     ctx.enable_timing(True)
     ctx.get_timing(reset=True)
     got = run()
     assert ("rotate" in _timing_tags(ctx)) == rotated
-    monkeypatch.setenv("SCRI_AMD_NO_SEPARABLE_SYNTHESIS", "1")
+    route("SCRI_AMD_NO_SEPARABLE_SYNTHESIS", "1")
     ref = run()
     ctx.enable_timing(False)
     scale = max(1.0, np.abs(ref.data).max())
@@ -112,7 +112,7 @@ def test_waveform_modes_boost_free_psi_types_and_large_ell(ctx, monkeypatch, dat
 
 
 @pytest.mark.parametrize("seed", range(12))
-def test_random_boost_free_shapes_equal_the_dense_route(ctx, monkeypatch, seed):
+def test_random_boost_free_shapes_equal_the_dense_route(ctx, monkeypatch, seed, route):
     """Random shapes for the two-kernel separable synthesis: WaveformModes (h and psi3 with its psi4 companion) on user grids with odd and
     even n_theta / n_phi up to the kernels' limits, AsymptoticBondiData with random working grids; with and without a frame rotation;
     every case against the dense products of the same library."""
@@ -165,9 +165,9 @@ def test_random_boost_free_shapes_equal_the_dense_route(ctx, monkeypatch, seed):
             r = wrap(name, data, lmin).transform(**kw, **extra)
             return r.t, r.data
 
-    monkeypatch.delenv("SCRI_AMD_NO_SEPARABLE_SYNTHESIS", raising=False)
+    route("SCRI_AMD_NO_SEPARABLE_SYNTHESIS", None)
     t_sep, d_sep = run()
-    monkeypatch.setenv("SCRI_AMD_NO_SEPARABLE_SYNTHESIS", "1")
+    route("SCRI_AMD_NO_SEPARABLE_SYNTHESIS", "1")
     t_den, d_den = run()
     assert np.array_equal(t_sep, t_den) and t_den.size > 0
     assert np.abs(d_sep - d_den).max() < 3e-13 * max(1.0, np.abs(d_den).max()) * max(1.0, ell_max / 8.0), (flavour, ell_max, kw.get("n_theta"), kw.get("working_ell_max"))

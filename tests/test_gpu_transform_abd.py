@@ -204,7 +204,7 @@ def test_abd_host_pipeline_equals_one_call(ctx, monkeypatch, boosted):
 
 
 @pytest.mark.parametrize("n,ell_max,beta", [(300, 4, 3e-3), (2500, 8, 2e-2), (9, 3, 1e-3), (700, 12, 0.2)])
-def test_sigma_through_the_evaluating_product_equals_the_grid_route(ctx, monkeypatch, n, ell_max, beta):
+def test_sigma_through_the_evaluating_product_equals_the_grid_route(ctx, monkeypatch, n, ell_max, beta, route):
     """With a boost the six fields are synthesised by dense products; sigma' = (sigma - eth eth alpha) / k mixes with nothing, so its
     spline is solved on the modes and evaluated in the epilogue of its product (zgemm3m_eval_kernel), while psi0 .. psi4 go through the
     mixing + elimination pass and the back substitution as before.  Same results as with all six fields on the grid route
@@ -213,7 +213,7 @@ def test_sigma_through_the_evaluating_product_equals_the_grid_route(ctx, monkeyp
 
     o = smooth_abd(n, ell_max, 90 + n)
     kw = dict(supertranslation=real_st(2, 35, 0.05), frame_rotation=np.array([0.4, 1, -2, 0.3]), boost_velocity=np.array([0.3, 0.1, -0.2]) * beta / 0.374)
-    monkeypatch.delenv("SCRI_AMD_NO_SEPARABLE_SYNTHESIS", raising=False)
+    route("SCRI_AMD_NO_SEPARABLE_SYNTHESIS", None)
 
     def run():
         g = scri_amd.AsymptoticBondiData(o.u, o.ell_max, ctx=ctx)
@@ -225,9 +225,9 @@ def test_sigma_through_the_evaluating_product_equals_the_grid_route(ctx, monkeyp
         ctx.enable_timing(False)
         return out, tm
 
-    monkeypatch.delenv("SCRI_AMD_NO_ABD_SIGMA_EVAL", raising=False)
+    route("SCRI_AMD_NO_ABD_SIGMA_EVAL", None)
     got, tm = run()
-    monkeypatch.setenv("SCRI_AMD_NO_ABD_SIGMA_EVAL", "1")
+    route("SCRI_AMD_NO_ABD_SIGMA_EVAL", "1")
     ref, tm_ref = run()
     assert got.n_times == ref.n_times and np.array_equal(got.u, ref.u)
     if n >= 8 and got.n_times:
