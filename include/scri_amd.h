@@ -206,6 +206,14 @@ int bms_transform_modes_pipelined_part(bms_ctx* ctx, const bms_wm_input* in, con
 int bms_transform_abd_pipelined_part(bms_ctx* ctx, const double* u, const void* raw, int64_t n_times, int ell_max,
                                      const bms_transformation* tr, int pieces, int piece0, int piece1, double* u_out, void* raw_out,
                                      int64_t* n_times_out);
+/* Several series under one transformation: the extra trailing data dimensions of the reference's waveform objects
+ * (scri/waveform_grid.py:299-308 `final_dim`, :574-594): every trailing index is an independent series on the same time axis.
+ * in->data: c16[n_times][in->ld] with series j in columns [j n_modes, (j + 1) n_modes) (in->ld >= n_series n_modes); psi companions
+ * likewise.  Exactly one of data_out -- c16[n_series][n_times][n_out], the first *n_times_out rows of each block written -- and
+ * grid_out -- c16[n_series][n_times][n_theta n_phi], WaveformGrid.from_modes -- is non-NULL, in the memory space in->mem.  The
+ * block crosses PCIe once; time axis, spline tables, per-direction tables and window are set up once and shared by the series. */
+int bms_transform_modes_series(bms_ctx* ctx, const bms_wm_input* in, int n_series, const bms_transformation* tr, double* t_out,
+                               void* data_out, void* grid_out, int64_t* n_times_out);
 /* WaveformGrid.from_modes on its own (scri/waveform_grid.py:331-613): the first half of bms_transform_modes -- the field on the
  * boost-distorted grid at the new time slices, grid_out c16[n_times][n_theta * n_phi] (only the first *n_times_out rows are
  * written; grid order, theta-major), in the memory space in->mem.  bms_map2salm of it is WaveformGrid.to_modes (:274-329). */

@@ -107,6 +107,10 @@ SIGNATURES = {
         c_int,
         [c_vp, c_dp, c_vp, c_i64, c_int, ctypes.POINTER(bms_transformation), c_int, c_dp, c_vp, ctypes.POINTER(c_i64)],
     ),
+    "bms_transform_modes_series": (
+        c_int,
+        [c_vp, ctypes.POINTER(bms_wm_input), c_int, ctypes.POINTER(bms_transformation), c_dp, c_vp, c_vp, ctypes.POINTER(c_i64)],
+    ),
     "bms_transform_modes_pipelined_part": (
         c_int,
         [c_vp, ctypes.POINTER(bms_wm_input), ctypes.POINTER(bms_transformation), c_int, c_int, c_int, c_dp, c_vp, ctypes.POINTER(c_i64)],

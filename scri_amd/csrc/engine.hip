@@ -2037,6 +2037,95 @@ extern "C" int bms_modes_to_grid(bms_ctx* c, const bms_wm_input* in, const bms_t
   return with_smaller_chunks(c, [&] { return transform_modes_impl(c, in, tr, nullptr, t_out, nullptr, n_times_out, nullptr, grid_out); });
 }
 
+// Several series under ONE transformation (the extra trailing data dimensions of scri/waveform_grid.py:299-308, 574-594: every
+// trailing index is an independent series on the same time axis).  in->data: c16[n_times][>= n_series * n_modes], series j in columns
+// [j n_modes, (j + 1) n_modes) of every row (in->ld the row stride); the psi companions likewise with their own mode counts.
+// data_out: c16[n_series][n_times][n_out] (series-major; the first *n_times_out rows of each block are written), or grid_out:
+// c16[n_series][n_times][n_theta n_phi] for WaveformGrid.from_modes.  The series cross PCIe once as one block, and the time axis
+// with its spline tables, the per-direction tables and the window are set up once and shared (the mechanism of the pipelined call's
+// pieces); per series run the kernels only.
+extern "C" int bms_transform_modes_series(bms_ctx* c, const bms_wm_input* in, int n_series, const bms_transformation* tr, double* t_out,
+                                          void* data_out, void* grid_out, int64_t* n_times_out) {
+  if (!c) return BMS_ERR_INVALID;
+  if (!in || !tr || !t_out || !n_times_out || (!data_out == !grid_out)) return fail(c, BMS_ERR_INVALID, "NULL argument (exactly one of data_out / grid_out)");
+  if (n_series < 1) return fail(c, BMS_ERR_INVALID, "n_series must be positive");
+  if (in->ell_min < 0 || in->ell_max < in->ell_min || in->n_aux < 0 || in->n_aux > 4) return fail(c, BMS_ERR_INVALID, "bad ell range or n_aux");
+  HIP_TRY(c, hipSetDevice(c->device));
+  const int64_t n = in->n_times;
+  const int n_modes = LM_total_size(in->ell_min, in->ell_max);
+  if (in->ld < (int64_t)n_series * n_modes) return fail(c, BMS_ERR_INVALID, "ld = %lld is less than n_series * n_modes = %lld", (long long)in->ld, (long long)n_series * n_modes);
+  const int n_out = grid_out ? tr->n_theta * tr->n_phi : LM_total_size(std::abs(in->spin_weight), tr->ell_max_out);
+  if (n_out <= 0) return fail(c, BMS_ERR_INVALID, "empty output l range");
+  hipStream_t S = c->stream;
+  bms_wm_input dev = *in;
+  int aux_modes[4] = {0, 0, 0, 0};
+  int rc;
+  if (in->mem == BMS_HOST) {  // one upload of everything
+    double* d = nullptr;
+    if ((rc = dev_buf_t(c, "series_in", (size_t)n * in->ld * 2, &d))) return rc;
+    HIP_TRY(c, hipMemcpyAsync(d, in->data, (size_t)n * in->ld * 16, hipMemcpyHostToDevice, S));
+    dev.data = d;
+    dev.mem = BMS_DEVICE;
+  }
+  for (int i = 0; i < in->n_aux; ++i) {
+    if (in->aux_ell_min[i] < 0 || in->aux_ell_max[i] < in->aux_ell_min[i]) return fail(c, BMS_ERR_INVALID, "bad l range of auxiliary field %d", i);
+    aux_modes[i] = LM_total_size(in->aux_ell_min[i], in->aux_ell_max[i]);
+    if (in->aux_ld[i] < (int64_t)n_series * aux_modes[i]) return fail(c, BMS_ERR_INVALID, "auxiliary field %d: row stride too small for %d series", i, n_series);
+    if (in->mem == BMS_HOST) {
+      const char* names[4] = {"series_aux0", "series_aux1", "series_aux2", "series_aux3"};
+      double* d = nullptr;
+      if ((rc = dev_buf_t(c, names[i], (size_t)n * in->aux_ld[i] * 2, &d))) return rc;
+      HIP_TRY(c, hipMemcpyAsync(d, in->aux_data[i], (size_t)n * in->aux_ld[i] * 16, hipMemcpyHostToDevice, S));
+      dev.aux_data[i] = d;
+    }
+  }
+  double* d_res = (double*)(grid_out ? grid_out : data_out);
+  if (in->mem == BMS_HOST)
+    if ((rc = dev_buf_t(c, "series_out", (size_t)n_series * std::max<int64_t>(n, 1) * n_out * 2, &d_res))) return rc;
+  PieceTables shared_tables;
+  struct AsyncScope {
+    bms_ctx* c;
+    ~AsyncScope() {
+      c->async_pieces = false;
+      c->piece_tables_valid = false;
+      c->piece_tables = nullptr;
+    }
+  } scope{c};
+  c->piece_tables = &shared_tables;
+  c->piece_tables_valid = false;
+  c->async_pieces = true;
+  int64_t n_new = 0;
+  rc = BMS_OK;
+  for (int j = 0; j < n_series && rc == BMS_OK; ++j) {
+    bms_wm_input one = dev;
+    one.data = (const double*)dev.data + (size_t)2 * j * n_modes;
+    for (int i = 0; i < in->n_aux; ++i) one.aux_data[i] = (const double*)dev.aux_data[i] + (size_t)2 * j * aux_modes[i];
+    double* out_j = d_res + (size_t)j * std::max<int64_t>(n, 1) * n_out * 2;
+    int64_t got = 0;
+    rc = with_smaller_chunks(c, [&] {
+      return transform_modes_impl(c, &one, tr, nullptr, t_out, grid_out ? nullptr : out_j, &got, nullptr, grid_out ? out_j : nullptr);
+    });
+    if (rc == BMS_OK && j > 0 && got != n_new) rc = fail(c, BMS_ERR_HIP, "series %d produced %lld rows, series 0 %lld", j, (long long)got, (long long)n_new);
+    n_new = got;
+  }
+  if (rc == BMS_OK && in->mem == BMS_HOST && n_new > 0) {
+    char* host = (char*)(grid_out ? grid_out : data_out);
+    for (int j = 0; j < n_series; ++j) {
+      const hipError_t e = hipMemcpyAsync(host + (size_t)j * n * n_out * 16, d_res + (size_t)j * n * n_out * 2, (size_t)n_new * n_out * 16, hipMemcpyDeviceToHost, S);
+      if (e != hipSuccess) {
+        rc = fail(c, BMS_ERR_HIP, "download of series %d: %s", j, hipGetErrorString(e));
+        break;
+      }
+    }
+  }
+  const hipError_t es = hipStreamSynchronize(S);
+  if (c->aux) (void)hipStreamSynchronize(c->aux);
+  if (rc) return rc;
+  if (es != hipSuccess) return fail(c, BMS_ERR_HIP, "bms_transform_modes_series: %s", hipGetErrorString(es));
+  *n_times_out = n_new;
+  return BMS_OK;
+}
+
 static int transform_modes_impl(bms_ctx* c, const bms_wm_input* in, const bms_transformation* tr, const bms_shard* sh, double* t_out,
                                 void* data_out, int64_t* n_times_out, int64_t* first_index_out, void* grid_out, bool walk_first) {
   if (!in || !tr || !t_out || !n_times_out) return fail(c, BMS_ERR_INVALID, "NULL argument");

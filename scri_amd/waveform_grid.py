@@ -240,23 +240,18 @@ def transform(w_modes, **kwargs):
             data_new = rows
     elif trailing:
         # Extra trailing data dimensions (scri/waveform_grid.py:299-308, 574-594: `final_dim`): every trailing index is an
-        # independent series under the same transformation -- to_modes and the spline loop of from_modes walk them one by one --
-        # so each goes through the engine on its own and the results are stacked back.  (The reference's own from_modes cannot be
-        # run on such data: its tensordot puts the extra axes BEFORE the grid axes and the per-pixel loop then indexes the wrong
-        # axis -- IndexError at :581.  What is built here is what those loops say.)
+        # independent series under the same transformation -- to_modes and the spline loop of from_modes walk them one by one.
+        # Here they are the extra column blocks of ONE engine call (bms_transform_modes_series): transformation, time axis, tables and
+        # synthesis matrix are shared.  (The reference's own from_modes cannot be run on such data: its tensordot puts the extra axes
+        # BEFORE the grid axes and the per-pixel loop then indexes the wrong axis -- IndexError at :581.  What is built here is what
+        # those loops say.)
         if aux and any(np.shape(a[0])[2:] != trailing for a in aux):
             raise ValueError("auxiliary waveforms must carry the same trailing data dimensions")
         flat = np.reshape(w_modes.data, w_modes.data.shape[:2] + (-1,))
-        aux_flat = [np.reshape(a[0], np.shape(a[0])[:2] + (-1,)) for a in aux]
-        pieces = []
-        for f in range(flat.shape[2]):
-            aux_f = [(np.ascontiguousarray(af[:, :, f]),) + tuple(a[1:]) for af, a in zip(aux_flat, aux)]
-            t_new, d = engine.transform_modes(
-                w_modes.t, np.ascontiguousarray(flat[:, :, f]), w_modes.ell_min, w_modes.ell_max, s, w_modes.conformal_weight, type_term, tr,
-                aux=aux_f, ctx=w_modes._ctx,
-            )
-            pieces.append(np.array(d))
-        data_new = np.stack(pieces, axis=2).reshape(pieces[0].shape + trailing)
+        aux_flat = [(np.reshape(a[0], np.shape(a[0])[:2] + (-1,)),) + tuple(a[1:]) for a in aux]
+        t_new, d = engine.transform_modes_series(w_modes.t, flat, w_modes.ell_min, w_modes.ell_max, s, w_modes.conformal_weight, type_term, tr,
+                                                 aux=aux_flat, ctx=w_modes._ctx)
+        data_new = d.reshape(d.shape[:2] + trailing)
     elif getattr(w_modes, "is_device_resident", False) and not aux:
         # weights in HBM (WaveformModes.to_device): the transformation reads and writes them there
         from . import device_series
@@ -342,20 +337,14 @@ class WaveformGrid:
         supertranslation, frame_rotation, boost_velocity, n_theta, n_phi, type_term, aux = _prepare(w_modes, kwargs)
         tr = engine.make_transformation(supertranslation, frame_rotation, boost_velocity, n_theta, n_phi, w_modes.ell_max)
         trailing = tuple(np.shape(w_modes.data)[2:])
-        if trailing:  # every trailing index is a series of its own (see `transform`)
+        if trailing:  # every trailing index is a series of its own: the column blocks of one engine call (see `transform`)
             if aux and any(np.shape(a[0])[2:] != trailing for a in aux):
                 raise ValueError("auxiliary waveforms must carry the same trailing data dimensions")
             flat = np.reshape(w_modes.data, w_modes.data.shape[:2] + (-1,))
-            aux_flat = [np.reshape(a[0], np.shape(a[0])[:2] + (-1,)) for a in aux]
-            grids = []
-            for f in range(flat.shape[2]):
-                aux_f = [(np.ascontiguousarray(af[:, :, f]),) + tuple(a[1:]) for af, a in zip(aux_flat, aux)]
-                t_new, g = engine.transform_modes(
-                    w_modes.t, np.ascontiguousarray(flat[:, :, f]), w_modes.ell_min, w_modes.ell_max, w_modes.spin_weight,
-                    w_modes.conformal_weight, type_term, tr, aux=aux_f, ctx=w_modes._ctx, grid=True,
-                )
-                grids.append(np.array(g))
-            grid = np.stack(grids, axis=2).reshape(grids[0].shape + trailing)
+            aux_flat = [(np.reshape(a[0], np.shape(a[0])[:2] + (-1,)),) + tuple(a[1:]) for a in aux]
+            t_new, g = engine.transform_modes_series(w_modes.t, flat, w_modes.ell_min, w_modes.ell_max, w_modes.spin_weight,
+                                                     w_modes.conformal_weight, type_term, tr, aux=aux_flat, ctx=w_modes._ctx, grid=True)
+            grid = g.reshape(g.shape[:2] + trailing)
         else:
             t_new, grid = engine.transform_modes(
                 w_modes.t, w_modes.data, w_modes.ell_min, w_modes.ell_max, w_modes.spin_weight, w_modes.conformal_weight, type_term, tr,

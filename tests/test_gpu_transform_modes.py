@@ -151,3 +151,71 @@ def test_pipelined_host_path_matches_the_one_call_path(ctx, monkeypatch):
     piped_g = run(tg)
     assert len(calls) == 3
     assert np.array_equal(piped_g.data, plain_g.data)
+
+
+def test_trailing_dimensions_are_one_engine_call(ctx, monkeypatch):
+    """Extra trailing data dimensions (scri/waveform_grid.py:299-308, 574-594) are the column blocks of ONE bms_transform_modes_series
+    call -- transformation, time axis, tables and window set up once -- not one engine call per trailing index: the entry points are
+    counted, the result is the stack of the single-series transforms bit for bit (psi companions with trailing dimensions included),
+    and four series cost less than 1.3 x four single-series calls."""
+    import time
+
+    import scri_amd
+    from scri_amd import _lib, synthetic
+
+    n, L = 20000, 12
+    t, data, spec = synthetic.workload("cfg3", n_times=n)
+    kw = dict(spec["kwargs"])
+    nm = (L + 1) ** 2 - 4
+    base = np.ascontiguousarray(data[:, :nm])
+    four = np.stack([base * (1 + 0.25 * k) * np.exp(0.3j * k) for k in range(4)], axis=2)
+
+    def wm(d, dt=scri_amd.h, ell_min=2):
+        return scri_amd.WaveformModes(t=t, data=d, ell_min=ell_min, ell_max=L, dataType=dt, frameType=scri_amd.Inertial, r_is_scaled_out=True,
+                                      m_is_scaled_out=True, ctx=ctx)
+
+    lib = _lib.load()
+    calls = {"series": 0, "single": 0}
+    real_series, real_single = lib.bms_transform_modes_series, lib.bms_transform_modes_shard
+
+    class Counting:
+        def __init__(self, fn, key):
+            self.fn, self.key = fn, key
+
+        def __call__(self, *a):
+            calls[self.key] += 1
+            return self.fn(*a)
+
+    monkeypatch.setattr(lib, "bms_transform_modes_series", Counting(real_series, "series"))
+    monkeypatch.setattr(lib, "bms_transform_modes_shard", Counting(real_single, "single"))
+    got = wm(four).transform(**kw)
+    assert calls == {"series": 1, "single": 0}
+    singles = [wm(np.ascontiguousarray(four[:, :, k])).transform(**kw) for k in range(4)]
+    assert calls == {"series": 1, "single": 4}
+    assert got.data.shape == singles[0].data.shape + (4,)
+    for k in range(4):
+        assert np.array_equal(got.t, singles[k].t) and np.array_equal(got.data[:, :, k], singles[k].data), k
+    # psi3 with a psi4 companion, both [N, modes, 2]
+    psi4 = np.stack([base, 0.5j * base], axis=2)
+    m3 = synthetic.chirp_modes(t, 1, L, 77)
+    psi3 = np.stack([m3, -0.7 * m3], axis=2)
+    calls.update(series=0, single=0)
+    both = wm(psi3, scri_amd.psi3, 1).transform(psi4_modes=wm(psi4, scri_amd.psi4), **kw)
+    assert calls == {"series": 1, "single": 0}
+    for k in range(2):
+        one = wm(np.ascontiguousarray(psi3[:, :, k]), scri_amd.psi3, 1).transform(psi4_modes=wm(np.ascontiguousarray(psi4[:, :, k]), scri_amd.psi4), **kw)
+        assert np.array_equal(both.data[:, :, k], one.data), k
+    monkeypatch.undo()
+    # cost: four series in one call against four calls
+    w4, w1 = wm(four), wm(np.ascontiguousarray(four[:, :, 0]))
+    for _ in range(2):
+        w4.transform(**kw), w1.transform(**kw)
+    t0 = time.perf_counter()
+    for _ in range(3):
+        w4.transform(**kw)
+    t_four = (time.perf_counter() - t0) / 3
+    t0 = time.perf_counter()
+    for _ in range(3):
+        w1.transform(**kw)
+    t_one = (time.perf_counter() - t0) / 3
+    assert t_four < 1.3 * 4 * t_one, (t_four, t_one)
