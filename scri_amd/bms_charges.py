@@ -12,15 +12,16 @@ def mass_aspect(self, truncate_ell=max):
     """Bondi mass aspect M = -Re{psi2 + sigma d_t sigma-bar}  (bms_charges.py:14-47).
 
     truncate_ell: an int truncates every term to that ell_max (terms that are not needed are not computed); a callable is
-    used as the truncator of the product (default `max`: the larger ell_max of the two factors); a false value keeps
-    the full product."""
+    used as the truncator of the product (default `max`: the larger ell_max of the two factors); a false value leaves the
+    choice to the series' own multiplication_truncator (the reference's plain `sigma * sigma.bar.dot`: `max` for every
+    AsymptoticBondiData built by file_io, from_initial_values and map_to_superrest_frame, `sum` for a bare one)."""
     # one formula, three ways of choosing the band limit of its two terms
     if callable(truncate_ell):
         product_ell, psi2 = truncate_ell, self.psi2
     elif truncate_ell:
         product_ell, psi2 = (lambda ells: truncate_ell), self.psi2.truncate_ell(truncate_ell)
     else:
-        product_ell, psi2 = sum, self.psi2  # l_a + l_b: nothing of the product is dropped
+        product_ell, psi2 = None, self.psi2  # (None: the truncator the series carries)
     news_term = self.sigma.multiply(self.sigma.bar.dot, truncator=product_ell)
     return -((psi2 + news_term).real)
 

@@ -40,6 +40,18 @@ def test_charges_match_oracle_on_generic_data(ctx):
     tol = 5e-12
     assert np.abs(a.mass_aspect(1).ndarray - cref.mass_aspect(u, psi2, sigma, 1)).max() < tol
     assert np.abs(a.mass_aspect().ndarray - cref.mass_aspect(u, psi2, sigma, 4)).max() < tol  # default truncator: max
+    # a false truncate_ell leaves the band limit to the series' own multiplication_truncator (the reference's plain
+    # `sigma * sigma.bar.dot`, bms_charges.py:46): `sum` for a bare AsymptoticBondiData, `max` for those the file readers,
+    # from_initial_values and map_to_superrest_frame build -- there the result keeps ell_max = 4, not 8
+    full = a.mass_aspect(None)
+    assert full.ell_max == 8 and np.abs(full.ndarray - np.pad(cref.mass_aspect(u, psi2, sigma, 8), ((0, 0), (0, 0)))).max() < tol
+    import scri_amd
+
+    a_max = scri_amd.AsymptoticBondiData(u, 4, multiplication_truncator=max, ctx=ctx)
+    a_max._raw_data[:] = raw
+    for falsy in (None, 0, False):
+        kept = a_max.mass_aspect(falsy)
+        assert kept.ell_max == 4 and np.abs(kept.ndarray - cref.mass_aspect(u, psi2, sigma, 4)).max() < tol, falsy
     assert np.abs(a.bondi_four_momentum() - cref.four_momentum(u, psi2, sigma)).max() < tol
     assert np.abs(a.bondi_angular_momentum() - cref.angular_momentum(psi1, sigma)).max() < tol
     assert np.abs(a.bondi_CoM_charge() - cref.com_charge(psi1, sigma)).max() < tol
