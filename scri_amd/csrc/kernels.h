@@ -1,5 +1,6 @@
 // Launchers of the gfx950 kernels (C++ internal interface between the engine and the kernels).
 #pragma once
+#include <algorithm>
 #include <vector>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -19,19 +20,29 @@ constexpr long long GRID_Y_MAX = 65535;
 // everything the CU has beyond the kernel's static LDS: a per-launch value is a race between host threads that launch the same kernel
 // with different sizes (thread A sets 124 KB, thread B sets 60 KB, A's launch is refused) -- contexts are meant to be driven from
 // several threads (include/scri_amd.h).
+// The per-CU LDS size is asked of the device (the opt-in limit where the runtime reports one, else the per-block limit; this library
+// only runs on gfx950, whose 160 KB is the floor assumed when neither query answers with more than the 64 KB default).  Only a SUCCESS
+// is remembered: a transient failure is tried again by the next launch instead of failing that kernel for the life of the process.
 inline hipError_t allow_dynamic_lds(const void* fn) {
   static std::mutex mu;
-  static std::map<std::pair<const void*, int>, hipError_t> done;
+  static std::map<std::pair<const void*, int>, bool> done;
   int dev = 0;
   (void)hipGetDevice(&dev);
   std::lock_guard<std::mutex> guard(mu);
   const auto key = std::make_pair(fn, dev);
-  const auto it = done.find(key);
-  if (it != done.end()) return it->second;
+  if (done.count(key)) return hipSuccess;
+  int lds = 0, v = 0;
+  if (hipDeviceGetAttribute(&v, hipDeviceAttributeSharedMemPerBlockOptin, dev) == hipSuccess) lds = std::max(lds, v);
+  if (hipDeviceGetAttribute(&v, hipDeviceAttributeMaxSharedMemoryPerBlock, dev) == hipSuccess) lds = std::max(lds, v);
+  (void)hipGetLastError();
+  if (lds <= 64 * 1024) lds = 160 * 1024;
   hipFuncAttributes attr;
   hipError_t e = hipFuncGetAttributes(&attr, fn);
-  if (e == hipSuccess) e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - (int)attr.sharedSizeBytes);
-  done[key] = e;
+  if (e == hipSuccess) e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds - (int)attr.sharedSizeBytes);
+  if (e == hipSuccess)
+    done[key] = true;
+  else
+    (void)hipGetLastError();
   return e;
 }
 
