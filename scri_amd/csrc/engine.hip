@@ -2294,7 +2294,7 @@ static int transform_modes_impl(bms_ctx* c, const bms_wm_input* in, const bms_tr
   // Separable route without a boost, grids the one-kernel synthesis takes: the same step -- the whole solve on the modes, and the
   // synthesis kernel evaluates the spline from the last four coefficient rows it has produced (kernels_synthesis_eval.hip).  NOT the
   // default (SCRI_AMD_SYNTHESIS_EVAL selects it): built for VERDICT r4 item 1, correct on every axis, and slower than the two kernels
-  // it replaces -- 3.5 against 0.65 + 0.96 ms at l <= 16, 1e5 steps (profiles/r05_b_synthesis_eval_*).  A pixel's
+  // it replaces -- 3.5 against 0.65 + 0.96 ms at l <= 16, 1e5 steps (docs/HISTORY.md 4.0 (xxiii), profiles/r05_b_synthesis_eval_*).  A pixel's
   // samples trail its knots by skew_b / dt rows; the kernel stages a window of the time axis per segment, so the SPREAD of the skews
   // over the pixels has to stay within a few hundred rows: bounded here, before the per-direction tables exist, by the supertranslation's
   // coefficients (|Y_lm| <= sqrt((2 l + 1) / 4 pi); the l = 0 part is the time translation and shifts every pixel alike).

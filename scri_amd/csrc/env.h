@@ -1,7 +1,7 @@
 // Switches of the library, in two classes.
 //
 // Route options (bms::RouteOptions, one set PER CONTEXT)
-//     Choices between routes that produce the SAME results (to rounding): the A/B switches DESIGN.md lists, which the parity tests use
+//     Choices between routes that produce the SAME results (to rounding): the A/B switches DESIGN.md section 1 describes, which the parity tests use
 //     to reach every route.  A context reads the SCRI_AMD_<NAME> environment variables ONCE, in bms_ctx_create, as its defaults; after
 //     that only bms_ctx_set_option / bms_ctx_get_option (include/scri_amd.h) touch them.  No call path reads the environment, so two
 //     contexts of one process can run different routes side by side and a setenv in one thread cannot race a call in another.

@@ -1,5 +1,5 @@
 """Kernel times of the boost-free WaveformModes transformation (supertranslation + frame rotation of the cfg3 series, resident in HBM).
-Usage: python tools/boost_free_rate.py [n_times] [ell_max] [axis]      (env: the route switches of DESIGN.md 7b; probe builds: SCRI_AMD_SE_KNOCK)"""
+Usage: python tools/boost_free_rate.py [n_times] [ell_max] [axis]      (env: the route options of scri_amd/csrc/env.h, read by the context at creation; probe builds: SCRI_AMD_SE_KNOCK)"""
 import json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
