@@ -217,3 +217,70 @@ def test_one_context_shared_by_two_threads_under_the_callers_lock(cases):
         assert not bad, bad[:5]
     finally:
         c.close()
+
+
+def test_two_contexts_on_different_routes_concurrently(monkeypatch):
+    """Routes are options of a CONTEXT (bms_ctx_set_option; round 6), not of the process: context A on the dense product and the
+    two-pass boost-free route, context B on the separable synthesis and the fused route, driven from two threads at once -- every
+    result bit-identical to the same context's serial run, and the two contexts really took different kernels (their timing tags).
+    A variable set in the environment AFTER the contexts exist changes nothing (it is read in bms_ctx_create only)."""
+    from scri_amd import _lib, engine, synthetic
+
+    a, b = _lib.Context(0), _lib.Context(0)
+    try:
+        a.option("NO_SEPARABLE_SYNTHESIS", 1)  # dense sYlm product even without a boost
+        a.option("NO_SYNTHESIS_EVAL", 1)
+        b.option("SYNTHESIS_EVAL", 1)  # fused boost-free route at every l
+        b.option("NO_SMALL_DENSE", 1)
+        assert (a.option("NO_SEPARABLE_SYNTHESIS"), b.option("NO_SEPARABLE_SYNTHESIS")) == (1, 0)
+        with pytest.raises(ValueError, match="no route option"):
+            a.option("NO_SUCH_ROUTE", 1)
+        monkeypatch.setenv("SCRI_AMD_NO_GEMM_EVAL", "1")  # too late for a and b
+        assert a.option("NO_GEMM_EVAL") == 0 and b.option("NO_GEMM_EVAL") == 0
+
+        n, L = 20000, 16
+        t, data, spec = synthetic.workload("cfg3", n_times=n)
+        kw = spec["kwargs"]
+        n_theta = 2 * (L + 2) + 1
+        tr_free = engine.make_transformation(kw["supertranslation"], kw["frame_rotation"], [0, 0, 0], n_theta, n_theta, L)
+        tr_boost = engine.make_transformation(kw["supertranslation"], kw["frame_rotation"], kw["boost_velocity"], n_theta, n_theta, L)
+
+        def work(ctx, turns):
+            outs = []
+            for _ in range(turns):
+                for tr in (tr_free, tr_boost):
+                    _, d = engine.transform_modes(t, data, 2, L, -2, -1, engine.BMS_TERM_H, tr, ctx=ctx)
+                    outs.append(np.array(d))
+            return outs
+
+        serial = {}
+        tags = {}
+        for name, ctx in (("a", a), ("b", b)):
+            ctx.enable_timing(True)
+            ctx.get_timing(reset=True)
+            engine.transform_modes(t, data, 2, L, -2, -1, engine.BMS_TERM_H, tr_free, ctx=ctx)
+            tags[name] = {k for k, v in ctx.get_timing(reset=True).items() if v[1]}
+            ctx.enable_timing(False)
+            serial[name] = work(ctx, 1)
+        # the dense route has no rotation of the modes and no separable kernels; the fused route no back substitution on a grid
+        assert "rotate" not in tags["a"] and "rotate" in tags["b"] and "spline_backward" not in tags["b"]
+        assert np.abs(serial["a"][0] - serial["b"][0]).max() < 1e-13 * np.abs(serial["a"][0]).max()  # same results to rounding
+        got, errors = {}, []
+
+        def run(name, ctx):
+            try:
+                got[name] = work(ctx, 6)
+            except BaseException as e:  # noqa: BLE001
+                errors.append(e)
+
+        threads = [threading.Thread(target=run, args=(name, ctx)) for name, ctx in (("a", a), ("b", b))]
+        for th in threads:
+            th.start()
+        for th in threads:
+            th.join()
+        assert not errors, errors
+        for name in ("a", "b"):
+            for k, d in enumerate(got[name]):
+                assert np.array_equal(d, serial[name][k % 2]), (name, k)
+    finally:
+        a.close(), b.close()
