@@ -915,7 +915,7 @@ def main():
                 "traffic": traffic,
                 "traffic_source": traffic_note,
                 "traffic_unit": "HBM-side bytes per launch of the kernel (L2 misses: Infinity-Cache hits included); the A operand passes "
-                "each of the column panels ("Dense route")" + ("; `ms_per_launch` covers zgemm3m_eval_kernel AND spline_straddle_eval_kernel "
+                "each of the column panels (DESIGN.md section 4, 'Dense route')" + ("; `ms_per_launch` covers zgemm3m_eval_kernel AND spline_straddle_eval_kernel "
                 "(one timing tag), `traffic` is zgemm3m_eval_kernel's alone (the straddle kernel moves 0.31 GB more)" if "eval" in DOMINANT_KERNEL else ""),
                 "csrc_hash": csrc_hash(),
                 "flops_per_launch": flops_per_launch,

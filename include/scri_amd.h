@@ -208,10 +208,12 @@ int bms_transform_abd_pipelined_part(bms_ctx* ctx, const double* u, const void* 
                                      int64_t* n_times_out);
 /* Several series under one transformation: the extra trailing data dimensions of the reference's waveform objects
  * (scri/waveform_grid.py:299-308 `final_dim`, :574-594): every trailing index is an independent series on the same time axis.
- * in->data: c16[n_times][in->ld] with series j in columns [j n_modes, (j + 1) n_modes) (in->ld >= n_series n_modes); psi companions
- * likewise.  Exactly one of data_out -- c16[n_series][n_times][n_out], the first *n_times_out rows of each block written -- and
- * grid_out -- c16[n_series][n_times][n_theta n_phi], WaveformGrid.from_modes -- is non-NULL, in the memory space in->mem.  The
- * block crosses PCIe once; time axis, spline tables, per-direction tables and window are set up once and shared by the series. */
+ * Arrays are in the REFERENCE'S layout -- the trailing index fastest, as numpy stores data[N, n_modes, F]: in->data is
+ * c16[n_times][in->ld] with element (mode, j) of a row at column mode * n_series + j (in->ld >= n_modes n_series); psi companions
+ * likewise.  Exactly one of data_out -- c16[n_times][n_out n_series] -- and grid_out -- c16[n_times][n_theta n_phi n_series],
+ * WaveformGrid.from_modes -- is non-NULL, same convention, in the memory space in->mem; the first *n_times_out rows are written.
+ * The block crosses PCIe once as it is (the permutation to one block of columns per series and back runs on the device); time axis,
+ * spline tables, per-direction tables and window are set up once and shared by the series. */
 int bms_transform_modes_series(bms_ctx* ctx, const bms_wm_input* in, int n_series, const bms_transformation* tr, double* t_out,
                                void* data_out, void* grid_out, int64_t* n_times_out);
 /* WaveformGrid.from_modes on its own (scri/waveform_grid.py:331-613): the first half of bms_transform_modes -- the field on the

@@ -1,0 +1,892 @@
+// Planners and tables shared by the transformation entry points
+// (engine.h: the split of the engine by entry family; include/scri_amd.h: the C ABI)
+#include "engine.h"
+
+// ====================================================================================================== host math
+
+// R_jk of scri/waveform_grid.py:130-174 == boosted_grid, transformations.py:100-148 (host loop over pixel_rotor)
+void build_rotor_grid(const double fr[4], const double v[3], int n_theta, int n_phi, std::vector<Quat>& R) {
+  R.resize((size_t)n_theta * n_phi);
+  const Quat frq = {fr[0], fr[1], fr[2], fr[3]};
+  const BoostSpec bs = make_boost_spec(v);
+  for (int j = 0; j < n_theta; ++j)
+    for (int k = 0; k < n_phi; ++k) R[(size_t)j * n_phi + k] = pixel_rotor(frq, bs, j, k, n_theta, n_phi);
+}
+
+// theta quadrature weights of the equiangular analysis (spinsfast.map2salm; H&W 2010): with M = 2 n_theta - 2,
+//   q_j = (2 pi / M) e_j sum_{p even, -M/2 < p <= M/2} 2 cos(p theta_j) / (1 - p^2),  e_j = 1 at the poles else 2
+void theta_quadrature_weights(int n_theta, std::vector<double>& q) {
+  const int M = 2 * n_theta - 2;
+  q.assign(n_theta, 0.0);
+  for (int j = 0; j < n_theta; ++j) {
+    const double th = M_PI * j / (n_theta - 1);
+    double E = 0.0;
+    for (int p = -M / 2 + 1; p <= M / 2; ++p)
+      if ((p & 1) == 0) E += 2.0 / (1.0 - (double)p * p) * std::cos(p * th);
+    q[j] = (2 * M_PI / M) * E * ((j == 0 || j == n_theta - 1) ? 1.0 : 2.0);
+  }
+}
+
+// Delta^l = d^l(pi/2) in extended precision (same recurrence as DChain), packed for kernels_rotate.hip
+template <class T>
+void delta_matrix(int ell, std::vector<double>& D /* (2l+1)^2 row-major [mu][m] */) {
+  const int n = 2 * ell + 1;
+  D.assign((size_t)n * n, 0.0);
+  const T r = std::sqrt((T)0.5);
+  for (int mp = -ell; mp <= ell; ++mp)
+    for (int m = -ell; m <= ell; ++m) {
+      const int l0 = std::max(std::abs(mp), std::abs(m));
+      // start value
+      auto sb = [&](int k) {
+        T c = 1;
+        int nn = 2 * l0, kk = std::min(k, 2 * l0 - k);
+        for (int i = 1; i <= kk; ++i) c = c * (T)(nn - kk + i) / (T)i;
+        return std::sqrt(c);
+      };
+      T d0;
+      const T pw = std::pow(r, (T)(2 * l0));
+      if (l0 == mp)
+        d0 = (((l0 - m) & 1) ? -1 : 1) * sb(l0 - m) * pw;
+      else if (l0 == -mp)
+        d0 = sb(l0 + m) * pw;
+      else if (l0 == m)
+        d0 = sb(l0 - mp) * pw;
+      else
+        d0 = (((l0 + mp) & 1) ? -1 : 1) * sb(l0 + mp) * pw;
+      T dm1 = 0;
+      for (int l = l0; l < ell; ++l) {
+        T d1;
+        if (l == 0) {
+          d1 = 0;  // cos(pi/2) = 0
+        } else {
+          const T L = l, L1 = l + 1;
+          const T c1 = (2 * L + 1) * (-(T)(mp * m));  // l(l+1) cos(b) = 0
+          const T c2 = L1 * std::sqrt((L * L - (T)(mp * mp)) * (L * L - (T)(m * m)));
+          const T den = L * std::sqrt((L1 * L1 - (T)(mp * mp)) * (L1 * L1 - (T)(m * m)));
+          d1 = (c1 * d0 - c2 * dm1) / den;
+        }
+        dm1 = d0;
+        d0 = d1;
+      }
+      D[(size_t)(mp + ell) * n + (m + ell)] = (double)d0;
+    }
+}
+
+
+
+int ensure_delta(bms_ctx* c, int lmax, const double** d_delta, const long long** d_off) {
+  double* dd = nullptr;
+  long long* doff = nullptr;
+  if (c->delta_lmax >= lmax) {
+    *d_delta = (const double*)c->bufs["delta"].p;
+    *d_off = (const long long*)c->bufs["delta_off"].p;
+    return BMS_OK;
+  }
+  std::vector<long long> off(lmax + 1);
+  long long total = 0;
+  for (int l = 0; l <= lmax; ++l) {
+    off[l] = total;
+    const int n = 2 * l + 1, nblk = (n + ROT_MB - 1) / ROT_MB;
+    total += 2LL * nblk * ROT_MB * n;
+  }
+  std::vector<double> packed((size_t)total, 0.0), D;
+  for (int l = 0; l <= lmax; ++l) {
+    delta_matrix<long double>(l, D);
+    const int n = 2 * l + 1, nblk = (n + ROT_MB - 1) / ROT_MB;
+    double* direct = packed.data() + off[l];
+    double* transp = direct + (size_t)nblk * ROT_MB * n;
+    for (int b = 0; b < nblk; ++b)
+      for (int col = 0; col < n; ++col)
+        for (int j = 0; j < ROT_MB; ++j) {
+          const int row = b * ROT_MB + j;
+          if (row < n) {
+            direct[((size_t)b * n + col) * ROT_MB + j] = D[(size_t)row * n + col];  // Delta[mu=row][m'=col]
+            transp[((size_t)b * n + col) * ROT_MB + j] = D[(size_t)col * n + row];  // Delta[mu=col][m=row]
+          }
+        }
+  }
+  int rc = dev_buf_t(c, "delta", (size_t)total, &dd);
+  if (rc) return rc;
+  rc = dev_buf_t(c, "delta_off", (size_t)lmax + 1, &doff);
+  if (rc) return rc;
+  HIP_TRY(c, hipMemcpyAsync(dd, packed.data(), sizeof(double) * total, hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(c, hipMemcpyAsync(doff, off.data(), sizeof(long long) * (lmax + 1), hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));  // host vectors go out of scope
+  c->delta_lmax = lmax;
+  *d_delta = dd;
+  *d_off = doff;
+  return BMS_OK;
+}
+
+// B images for rotate_modes_mfma_kernel: per l, B1[k = m'][mu] = Delta[mu][m'] then B2[k = mu][m] = Delta[mu][m],
+// each [kpad][pd] zero padded
+int ensure_delta_mfma(bms_ctx* c, int lmax, const double** d_tab, const long long** d_off) {
+  if (c->delta_mfma_lmax >= lmax) {
+    *d_tab = (const double*)c->bufs["delta_mfma"].p;
+    *d_off = (const long long*)c->bufs["delta_mfma_off"].p;
+    return BMS_OK;
+  }
+  std::vector<long long> off(lmax + 1);
+  long long total = 0;
+  for (int l = 0; l <= lmax; ++l) {
+    int kpad, pd;
+    rotate_mfma_table_shape(l, &kpad, &pd);
+    off[l] = total;
+    total += 2LL * kpad * pd;
+  }
+  std::vector<double> packed((size_t)total, 0.0), D;
+  for (int l = 0; l <= lmax; ++l) {
+    int kpad, pd;
+    rotate_mfma_table_shape(l, &kpad, &pd);
+    delta_matrix<long double>(l, D);
+    const int n = 2 * l + 1;
+    double* B1 = packed.data() + off[l];
+    double* B2 = B1 + (size_t)kpad * pd;
+    for (int a = 0; a < n; ++a)
+      for (int b = 0; b < n; ++b) {
+        B1[(size_t)a * pd + b] = D[(size_t)b * n + a];  // k = m' = a, column mu = b
+        B2[(size_t)a * pd + b] = D[(size_t)a * n + b];  // k = mu = a, column m = b
+      }
+  }
+  double* dd = nullptr;
+  long long* doff = nullptr;
+  int rc = dev_buf_t(c, "delta_mfma", (size_t)total, &dd);
+  if (rc) return rc;
+  rc = dev_buf_t(c, "delta_mfma_off", (size_t)lmax + 1, &doff);
+  if (rc) return rc;
+  HIP_TRY(c, hipMemcpyAsync(dd, packed.data(), sizeof(double) * total, hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(c, hipMemcpyAsync(doff, off.data(), sizeof(long long) * (lmax + 1), hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  c->delta_mfma_lmax = lmax;
+  *d_tab = dd;
+  *d_off = doff;
+  return BMS_OK;
+}
+
+// LDS image of Delta^l for l = ell_min..ell_max (kernels_rotate_resident.hip); false if the range does not fit the LDS
+int ensure_delta_resident(bms_ctx* c, int ell_min, int ell_max, bool* ok, RotResPlan* P, size_t* lds_bytes,
+                                 const double** d_tab, unsigned int** d_counter) {
+  *ok = rotate_resident_plan(ell_min, ell_max, P, lds_bytes);
+  if (!*ok) return BMS_OK;
+  char name[64];
+  snprintf(name, sizeof name, "rot_res_tab_%d_%d", ell_min, ell_max);
+  int rc = dev_buf_t(c, "rot_res_counter", 4, d_counter);
+  if (rc) return rc;
+  if (!c->n_cu) {
+    hipDeviceProp_t prop;
+    HIP_TRY(c, hipGetDeviceProperties(&prop, c->device));
+    c->n_cu = prop.multiProcessorCount;
+  }
+  double* dt = nullptr;
+  if ((rc = dev_buf_t(c, name, (size_t)P->tab_doubles, &dt))) return rc;
+  *d_tab = dt;
+  if (c->rot_res_plans.count({ell_min, ell_max})) return BMS_OK;
+  std::vector<double> image((size_t)P->tab_doubles, 0.0), D;
+  for (int l = ell_min; l <= ell_max; ++l) {
+    delta_matrix<long double>(l, D);
+    rotate_resident_pack(*P, l, D.data(), image.data());
+  }
+  HIP_TRY(c, hipMemcpyAsync(dt, image.data(), sizeof(double) * image.size(), hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));  // the host vector goes out of scope
+  c->rot_res_plans[{ell_min, ell_max}] = *P;
+  return BMS_OK;
+}
+
+
+// scalars of the transformation + allocation of the host-side per-pixel arrays
+void init_pixel_tables(const bms_transformation* tr, PixelTables& T) {
+  T.n_theta = tr->n_theta;
+  T.n_phi = tr->n_phi;
+  T.n_pix = tr->n_theta * tr->n_phi;
+  const double* v = tr->boost_velocity;
+  T.beta = std::sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+  T.gamma = 1 / std::sqrt(1 - T.beta * T.beta);
+  const cplx* st = (const cplx*)tr->supertranslation;
+  const int nst = (tr->ell_max_supertranslation + 1) * (tr->ell_max_supertranslation + 1);
+  T.tt = st[0].re / std::sqrt(4 * M_PI);  // constant_from_ell_0_mode(supertranslation[0]).real
+  T.nontrivial = T.beta != 0;
+  for (int i = 1; i < nst; ++i)
+    if (st[i].re != 0 || st[i].im != 0) T.nontrivial = true;
+  T.k.resize(T.n_pix);
+  T.alpha.resize(T.n_pix);
+  T.skew_a.resize(T.n_pix);
+  T.skew_b.resize(T.n_pix);
+}
+
+PixelSpec base_pixel_spec(const bms_transformation* tr, const PixelTables& T) {
+  PixelSpec P{};
+  P.frq = {tr->frame_rotation[0], tr->frame_rotation[1], tr->frame_rotation[2], tr->frame_rotation[3]};
+  for (int i = 0; i < 3; ++i) P.v[i] = tr->boost_velocity[i];
+  P.bs = make_boost_spec(tr->boost_velocity);
+  P.gamma = T.gamma;
+  P.tt = T.tt;
+  P.n_theta = tr->n_theta;
+  P.n_phi = tr->n_phi;
+  P.lst = tr->ell_max_supertranslation;
+  P.mode = -1;
+  return P;
+}
+
+// host-only evaluation of the per-pixel scalars (bms_shard_plan: no GPU needed); same code as pixel_tables_kernel
+void build_pixel_tables(const bms_transformation* tr, PixelTables& T) {
+  init_pixel_tables(tr, T);
+  PixelSpec P = base_pixel_spec(tr, T);
+  P.st = (const cplx*)tr->supertranslation;
+  T.R.resize(T.n_pix);
+  PixelOut O{};
+  O.rotors = (double*)T.R.data();
+  O.k = T.k.data();
+  O.alpha = T.alpha.data();
+  O.skew_a = T.skew_a.data();
+  O.skew_b = T.skew_b.data();
+  for (int p = 0; p < T.n_pix; ++p) pixel_tables_one(P, O, p, p);
+}
+
+// output time window (waveform_grid.py:564-568 == transformations.py:391-396)
+void output_window(const PixelTables& T, const double* t, int64_t n, int64_t& i_lo, int64_t& i_hi) {
+  double umin = -INFINITY, umax = INFINITY;
+  for (int p = 0; p < T.n_pix; ++p) {
+    umin = std::max(umin, T.k[p] * (t[0] - T.alpha[p]));
+    umax = std::min(umax, T.k[p] * (t[n - 1] - T.alpha[p]));
+  }
+  const double ig = 1 / T.gamma;
+  // uprm_i = (1/gamma) (t_i - tt) is non-decreasing in i
+  i_lo = std::partition_point(t, t + n, [&](double ti) { return ig * (ti - T.tt) < umin; }) - t;
+  i_hi = std::partition_point(t, t + n, [&](double ti) { return ig * (ti - T.tt) <= umax; }) - t;
+  if (i_hi < i_lo) i_hi = i_lo;
+}
+
+// the AsymptoticBondiData flavour divides: timeprime = (u - tt) / gamma (transformations.py:391-396)
+void output_window_abd(const PixelTables& T, const double* u, int64_t n, int64_t& i_lo, int64_t& i_hi) {
+  double umin = -INFINITY, umax = INFINITY;
+  for (int p = 0; p < T.n_pix; ++p) {
+    umin = std::max(umin, T.k[p] * (u[0] - T.alpha[p]));
+    umax = std::min(umax, T.k[p] * (u[n - 1] - T.alpha[p]));
+  }
+  i_lo = std::partition_point(u, u + n, [&](double ui) { return (ui - T.tt) / T.gamma < umin; }) - u;
+  i_hi = std::partition_point(u, u + n, [&](double ui) { return (ui - T.tt) / T.gamma <= umax; }) - u;
+  if (i_hi < i_lo) i_hi = i_lo;
+}
+
+// knots needed to evaluate output samples [c0, c1): [ja, jb] inclusive (before halo)
+void needed_knots(const PixelTables& T, const double* t, int64_t n, int64_t c0, int64_t c1, int64_t& ja, int64_t& jb) {
+  double lo = INFINITY, hi = -INFINITY;
+  const double x0 = t[c0], x1 = t[c1 - 1];
+  for (int p = 0; p < T.n_pix; ++p) {
+    lo = std::min(lo, x0 + (T.skew_a[p] * (x0 - T.tt) + T.skew_b[p]));
+    hi = std::max(hi, x1 + (T.skew_a[p] * (x1 - T.tt) + T.skew_b[p]));
+  }
+  ja = (std::upper_bound(t, t + n, lo) - t) - 1;  // last knot <= lo
+  jb = std::lower_bound(t, t + n, hi) - t;        // first knot >= hi
+  ja = std::max<int64_t>(ja, 0);
+  jb = std::min<int64_t>(jb, n - 1);
+}
+
+
+
+
+int build_analysis(bms_ctx* c, const char* tag, int n_theta, int n_phi, int spin, int ell_min_out, int ell_max_out,
+                          AnalysisPlan& A) {
+  hipStream_t S = c->stream;
+  const std::array<int, 6> key = {n_theta, n_phi, spin, ell_min_out, ell_max_out, (c->opt.on(OPT_NO_FUSED_ANALYSIS) ? 1 : 0) + (c->opt.on(OPT_NO_LARGE_ANALYSIS) ? 2 : 0)};
+  {
+    auto it = c->plans.find(tag);
+    if (it != c->plans.end() && it->second.first == key && !c->opt.on(OPT_NO_PLAN_CACHE)) {
+      A = it->second.second;
+      return BMS_OK;
+    }
+    c->plans.erase(tag);
+  }
+  A.n_theta = n_theta;
+  A.n_phi = n_phi;
+  A.n_pix = n_theta * n_phi;
+  A.n_out = LM_total_size(ell_min_out, ell_max_out);
+  A.L = ell_max_out;
+  A.nm = 2 * ell_max_out + 1;
+  A.separable = n_theta <= MAX_THETA_SEPARABLE;
+  std::vector<double> qth;
+  theta_quadrature_weights(n_theta, qth);
+  int rc;
+  void* vp;
+  char nm_[64];
+  A.fused = A.separable && fused_analysis_supported(n_theta, n_phi, A.L, A.n_out) && !c->opt.on(OPT_NO_FUSED_ANALYSIS);
+  A.large = A.separable && !A.fused && large_analysis_supported(n_theta, n_phi, A.L) && !c->opt.on(OPT_NO_LARGE_ANALYSIS) &&
+            !c->opt.on(OPT_NO_FUSED_ANALYSIS);
+  A.ell_min_out = ell_min_out;
+  A.spin = spin;
+  if (A.separable) {
+    if (A.large) {
+      // twiddles are computed in the kernel; only the theta table below is needed
+    } else if (A.fused) {
+      const size_t nd = fused_dft_table_size(n_phi, A.L);
+      snprintf(nm_, sizeof nm_, "dcs_%d_%d", n_phi, A.L);
+      if ((rc = dev_buf_t(c, nm_, nd, &A.d_dcs))) return rc;
+      HIP_TRY(c, hipMemsetAsync(A.d_dcs, 0, sizeof(double) * nd, S));
+      TIMED(c, BMS_TAG_SETUP, launch_dft_cs_matrix(S, n_phi, A.L, A.d_dcs));
+    } else {
+      // phi-DFT matrix [2 n_phi -> 16] x [2 (2L+1) -> 128]
+      A.ld_dft = round_up(2LL * A.nm, 128);
+      const long long rows = round_up(2LL * n_phi, 16);
+      snprintf(nm_, sizeof nm_, "dft_%d_%d", n_phi, A.L);
+      if ((rc = dev_buf_t(c, nm_, (size_t)rows * A.ld_dft, &A.d_dft))) return rc;
+      HIP_TRY(c, hipMemsetAsync(A.d_dft, 0, sizeof(double) * rows * A.ld_dft, S));
+      TIMED(c, BMS_TAG_SETUP, launch_dft_matrix(S, n_phi, A.L, A.d_dft, A.ld_dft));
+    }
+    // theta table from sLambda_lm(theta_j) = sYlm(R(theta_j, 0))
+    std::vector<double> rot(4 * (size_t)n_theta), wth(n_theta);
+    std::vector<int> mindex(A.n_out);
+    for (int j = 0; j < n_theta; ++j) {
+      const Quat q = from_spherical_coords(M_PI * j / (n_theta - 1), 0.0);
+      rot[4 * j] = q.w, rot[4 * j + 1] = q.x, rot[4 * j + 2] = q.y, rot[4 * j + 3] = q.z;
+      wth[j] = qth[j] / n_phi;
+    }
+    for (int l = ell_min_out; l <= ell_max_out; ++l)
+      for (int m = -l; m <= l; ++m) mindex[LM_index(l, m, ell_min_out)] = m + A.L;
+    snprintf(nm_, sizeof nm_, "ana_rot_%s", tag);
+    if ((rc = upload(c, nm_, rot.data(), 8 * rot.size(), &vp))) return rc;
+    const double* d_rot = (const double*)vp;
+    snprintf(nm_, sizeof nm_, "ana_wth_%s", tag);
+    if ((rc = upload(c, nm_, wth.data(), 8 * wth.size(), &vp))) return rc;
+    const double* d_wth = (const double*)vp;
+    snprintf(nm_, sizeof nm_, "ana_mi_%s", tag);
+    if ((rc = upload(c, nm_, mindex.data(), sizeof(int) * mindex.size(), &vp))) return rc;
+    A.d_mindex = (int*)vp;
+    double* d_Y;
+    snprintf(nm_, sizeof nm_, "ana_Y_%s", tag);
+    if ((rc = dev_buf_t(c, nm_, (size_t)n_theta * A.n_out * 2, &d_Y))) return rc;
+    HIP_TRY(c, hipMemsetAsync(d_Y, 0, 16 * (size_t)n_theta * A.n_out, S));
+    TIMED(c, BMS_TAG_SETUP, launch_swsh_values(S, d_rot, n_theta, spin, ell_min_out, ell_max_out, d_Y));
+    snprintf(nm_, sizeof nm_, "ana_T_%s", tag);
+    if ((rc = dev_buf_t(c, nm_, (size_t)n_theta * A.n_out, &A.d_T))) return rc;
+    TIMED(c, BMS_TAG_SETUP, launch_theta_table(S, d_Y, d_wth, n_theta, A.n_out, A.d_T));
+    HIP_TRY(c, hipStreamSynchronize(S));  // host vectors above go out of scope
+  } else {
+    std::vector<double> wpix((size_t)A.n_pix), grid_rot(4 * (size_t)A.n_pix);
+    for (int j = 0; j < n_theta; ++j)
+      for (int k = 0; k < n_phi; ++k) {
+        const int p = j * n_phi + k;
+        wpix[p] = qth[j] / n_phi;
+        const Quat q = from_spherical_coords(M_PI * j / (n_theta - 1), (2 * M_PI) * k / n_phi);
+        grid_rot[4 * p] = q.w, grid_rot[4 * p + 1] = q.x, grid_rot[4 * p + 2] = q.y, grid_rot[4 * p + 3] = q.z;
+      }
+    if ((rc = upload(c, "grid_rotors", grid_rot.data(), 8 * grid_rot.size(), &vp))) return rc;
+    const double* d_grot = (const double*)vp;
+    if ((rc = upload(c, "wpix", wpix.data(), 8 * wpix.size(), &vp))) return rc;
+    const double* d_wpix = (const double*)vp;
+    A.ldw = round_up(2LL * A.n_out, 128);
+    const long long wrows = round_up(2LL * A.n_pix, 16);
+    snprintf(nm_, sizeof nm_, "Wana_%s", tag);
+    if ((rc = dev_buf_t(c, nm_, (size_t)wrows * A.ldw, &A.d_W))) return rc;
+    HIP_TRY(c, hipMemsetAsync(A.d_W, 0, sizeof(double) * wrows * A.ldw, S));
+    TIMED(c, BMS_TAG_SETUP, launch_quadrature_matrix(S, d_grot, d_wpix, A.n_pix, spin, ell_min_out, ell_max_out, A.d_W, A.ldw));
+    HIP_TRY(c, hipStreamSynchronize(S));
+  }
+  c->plans[tag] = {key, A};
+  return BMS_OK;
+}
+
+// G: [rows][2 n_pix] (row stride exactly 2 n_pix doubles) -> out[rows][ldo] complex modes
+
+int run_analysis(bms_ctx* c, const AnalysisPlan& A, const double* d_G, long long rows, double* d_out, long long ldo,
+                        const int* col_of_pixel, long long ld_cols) {
+  hipStream_t S = c->stream;
+  const long long P2 = 2LL * A.n_pix, ld = ld_cols ? ld_cols : P2;  // row stride of d_G
+  if (A.fused) {
+    TIMED(c, BMS_TAG_ANALYSIS_FUSED, launch_analysis_fused(S, d_G, ld, rows, A.n_theta, A.n_phi, A.L, A.n_out,
+                                                           A.d_mindex, A.d_T, A.d_dcs, d_out, ldo, col_of_pixel, A.spin, !c->opt.on(OPT_NO_SPLIT_ANALYSIS)));
+  } else if (A.large) {
+    if (col_of_pixel) return fail(c, BMS_ERR_UNSUPPORTED, "internal: sorted columns need the fused analysis");
+    double* d_F;
+    int rc = dev_buf_t(c, "Fphi", (size_t)rows * A.nm * large_analysis_jp(A.n_theta) * 2, &d_F);
+    if (rc) return rc;
+    TIMED(c, BMS_TAG_ANALYSIS_LARGE, launch_analysis_large(S, d_G, ld, rows, A.n_theta, A.n_phi, A.L, A.ell_min_out, A.d_T, d_F, d_out, ldo));
+  } else if (A.separable) {
+    if (col_of_pixel) return fail(c, BMS_ERR_UNSUPPORTED, "internal: sorted columns need the fused analysis");
+    if (ld != P2) return fail(c, BMS_ERR_UNSUPPORTED, "internal: the separable analysis reads contiguous rows");
+    double* d_F;
+    int rc = dev_buf_t(c, "Fphi", (size_t)rows * A.n_theta * 2 * A.nm, &d_F);
+    if (rc) return rc;
+    TIMED(c, BMS_TAG_GEMM_ANALYSIS, launch_dgemm(S, d_G, 2LL * A.n_phi, A.d_dft, A.ld_dft, d_F, 2LL * A.nm, rows * A.n_theta,
+                                                 2 * A.nm, 2 * A.n_phi, nullptr, nullptr));
+    TIMED(c, BMS_TAG_THETA_QUADRATURE,
+          launch_theta_quadrature(S, d_F, rows, A.n_theta, A.nm, A.n_out, A.d_mindex, A.d_T, d_out, ldo));
+  } else {
+    TIMED(c, BMS_TAG_GEMM_ANALYSIS, launch_dgemm(S, d_G, ld, A.d_W, A.ldw, d_out, ldo, rows, 2 * A.n_out, (int)P2, nullptr, nullptr));
+  }
+  return BMS_OK;
+}
+
+int upload(bms_ctx* c, const char* name, const void* host, size_t bytes, void** dev) {
+  int rc = dev_buf(c, name, bytes, dev);
+  if (rc) return rc;
+  HIP_TRY(c, hipMemcpyAsync(*dev, host, bytes, hipMemcpyHostToDevice, c->stream));
+  return BMS_OK;
+}
+
+// times [lo, hi) and the spline table of knots [j0, j1) on the device; both pointers are indexed by GLOBAL knot number
+int upload_times(bms_ctx* c, const double* t, int64_t n, int64_t lo, int64_t hi, int64_t j0, int64_t j1, double** d_x,
+                        SplineTable** d_tab) {
+  void* vp;
+  int rc = upload(c, "times", t + lo, 8 * (size_t)(hi - lo), &vp);
+  if (rc) return rc;
+  *d_x = (double*)vp - lo;
+  SplineTable* tab;
+  if ((rc = dev_buf_t(c, "spline_table", (size_t)(hi - lo), &tab))) return rc;
+  *d_tab = tab - lo;
+  TIMED(c, BMS_TAG_SETUP, launch_spline_table(c->stream, *d_x, n, *d_tab, std::max(j0, lo), std::min(j1, hi)));
+  return BMS_OK;
+}
+
+// the same for the B-spline form of the spline (kernels_bspline.hip)
+int upload_times_bspline(bms_ctx* c, const double* t, int64_t n, int64_t lo, int64_t hi, int64_t j0, int64_t j1, double** d_x,
+                                BsplineTable** d_tab, BsplineForward** d_fwd) {
+  void* vp;
+  int rc = upload(c, "times", t + lo, 8 * (size_t)(hi - lo), &vp);
+  if (rc) return rc;
+  *d_x = (double*)vp - lo;
+  BsplineTable* tab;
+  BsplineForward* fwd;
+  if ((rc = dev_buf_t(c, "bspline_table", (size_t)(hi - lo), &tab))) return rc;
+  if ((rc = dev_buf_t(c, "bspline_forward", (size_t)(hi - lo), &fwd))) return rc;
+  *d_tab = tab - lo;
+  *d_fwd = fwd - lo;
+  TIMED(c, BMS_TAG_SETUP, launch_bspline_table(c->stream, *d_x, n, *d_tab, *d_fwd, lo, std::max(j0, lo), std::min(j1, hi)));
+  return BMS_OK;
+}
+
+int stage_in(bms_ctx* c, const char* name, const void* src, int mem, size_t bytes, const double** dev) {
+  if (mem == BMS_DEVICE) {
+    *dev = (const double*)src;
+    return BMS_OK;
+  }
+  void* p;
+  int rc = upload(c, name, src, bytes, &p);
+  *dev = (const double*)p;
+  return rc;
+}
+
+void time_window(int64_t n, const bms_shard* sh, int64_t& lo, int64_t& hi) {
+  lo = 0, hi = n;
+  if (sh && sh->data_row0 >= 0 && sh->data_rows >= 0 && sh->data_row0 + sh->data_rows <= n) {
+    lo = std::max<int64_t>(0, sh->data_row0 - TIME_MARGIN);
+    hi = std::min<int64_t>(n, sh->data_row0 + sh->data_rows + TIME_MARGIN);
+  }
+}
+
+// `regular` (optional): whether the tiled spline recurrences may be trusted on this time axis.  Their truncated starts
+// rely on the factors of the spline systems decaying over a 32-knot halo; that holds for any mesh whose steps do not
+// grow or shrink geometrically over many knots in a row (a sudden jump of any size is harmless), and fails for sustained
+// grading: a ratio of 1.3 per step over 33 knots (steps varying 4e3-fold inside the halo) costs 5e-14, 1.4 already 2e-12,
+// 2.0 1e-5.  Criterion: steps within any 48 consecutive knots vary by at most 1e3 (then <= 1e-14); otherwise the caller
+// runs the exact single-tile recurrences of the slope form.
+// spline tile for the whole-series building blocks (slope form): one tile = exact recurrences on an irregular axis
+
+// (the two halves of validate_common, for the caller that has the GPU start on the call before the host walks the time axis)
+int validate_transformation(bms_ctx* c, int64_t n, const double* t, const bms_transformation* tr, int64_t n_min) {
+  if (n < n_min) return fail(c, BMS_ERR_INVALID, "need at least %lld time steps, got %lld", (long long)n_min, (long long)n);
+  if (!(t[n - 1] > t[0])) return fail(c, BMS_ERR_INVALID, "time array must be strictly increasing (first/last)");
+  if (tr->n_theta < 2 || tr->n_phi < 1) return fail(c, BMS_ERR_INVALID, "bad grid size %d x %d", tr->n_theta, tr->n_phi);
+  if (tr->ell_max_supertranslation < 1 || !tr->supertranslation) return fail(c, BMS_ERR_INVALID, "supertranslation must hold at least l <= 1");
+  const double* v = tr->boost_velocity;
+  if (!(v[0] * v[0] + v[1] * v[1] + v[2] * v[2] < 1.0)) return fail(c, BMS_ERR_INVALID, "boost speed must be < 1");
+  return BMS_OK;
+}
+int walk_time_axis(bms_ctx* c, const double* t, int64_t lo, int64_t hi, bool* regular) {
+  double bmin[3] = {INFINITY, INFINITY, INFINITY}, bmax[3] = {0.0, 0.0, 0.0};  // step range of the last three 16-step blocks
+  bool reg = true;
+  // (block by block, the block's minimum and maximum by a branch-free inner loop the compiler vectorises -- this walk is host
+  // time during which the GPU has nothing of the call yet: 63 us per 1e5 samples as an element-by-element loop with its early exit)
+  for (int64_t b0 = std::max<int64_t>(lo, 0) + 1; b0 < hi; b0 += 16) {
+    const int64_t b1 = std::min<int64_t>(b0 + 16, hi);
+    double mn_b = INFINITY, mx_b = -INFINITY;
+    bool nan_b = false;
+    for (int64_t i = b0; i < b1; ++i) {
+      const double h = t[i] - t[i - 1];
+      mn_b = h < mn_b ? h : mn_b;
+      mx_b = h > mx_b ? h : mx_b;
+      nan_b |= h != h;
+    }
+    if (!(mn_b > 0) || nan_b) {
+      for (int64_t i = b0; i < b1; ++i)
+        if (!(t[i] - t[i - 1] > 0)) return fail(c, BMS_ERR_INVALID, "time array must be strictly increasing (index %lld)", (long long)i);
+    }
+    bmin[2] = mn_b, bmax[2] = mx_b;
+    const double mn = std::min(bmin[0], std::min(bmin[1], bmin[2])), mx = std::max(bmax[0], std::max(bmax[1], bmax[2]));
+    if (mx > 1e3 * mn) reg = false;
+    bmin[0] = bmin[1], bmin[1] = bmin[2];
+    bmax[0] = bmax[1], bmax[1] = bmax[2];
+  }
+  if (regular) *regular = reg || BMS_PROBE_ENV("SCRI_AMD_ASSUME_REGULAR_MESH") != nullptr;  // (the switch exists to show what the guard prevents)
+  return BMS_OK;
+}
+int validate_common(bms_ctx* c, int64_t n, const double* t, const bms_transformation* tr, int64_t lo, int64_t hi,
+                           bool* regular, int64_t n_min) {
+  // (order of the checks as it always was: size, first/last, the walk, then the transformation)
+  if (n < n_min) return fail(c, BMS_ERR_INVALID, "need at least %lld time steps, got %lld", (long long)n_min, (long long)n);
+  if (!(t[n - 1] > t[0])) return fail(c, BMS_ERR_INVALID, "time array must be strictly increasing (first/last)");
+  int rc = walk_time_axis(c, t, lo, hi < 0 ? n : hi, regular);
+  if (rc) return rc;
+  return validate_transformation(c, n, t, tr, n_min);
+}
+
+
+int spline_tile_for(const double* x, int64_t n) {
+  double bmin[3] = {INFINITY, INFINITY, INFINITY}, bmax[3] = {0.0, 0.0, 0.0};
+  int64_t in_block = 0;
+  for (int64_t i = 1; i < n; ++i) {
+    const double h = x[i] - x[i - 1];
+    bmin[2] = std::min(bmin[2], h);
+    bmax[2] = std::max(bmax[2], h);
+    if (++in_block == 16 || i == n - 1) {
+      const double mn = std::min(bmin[0], std::min(bmin[1], bmin[2])), mx = std::max(bmax[0], std::max(bmax[1], bmax[2]));
+      if (mx > 1e3 * mn && !BMS_PROBE_ENV("SCRI_AMD_ASSUME_REGULAR_MESH")) return (int)std::min<int64_t>(n + 1, 0x7fffffff);
+      bmin[0] = bmin[1], bmin[1] = bmin[2], bmin[2] = INFINITY;
+      bmax[0] = bmax[1], bmax[1] = bmax[2], bmax[2] = 0.0;
+      in_block = 0;
+    }
+  }
+  return SPLINE_TILE;
+}
+
+// How far apart the lanes of a back-substitution wave can stand: ranges of the skew rate and offset within any block of 64
+// columns [cA + 64 b, ...) of the launch (host copies of the per-column tables).
+BsplineSpread skew_spread(const PixelTables& T, int cA, int cB, const double* x_host) {
+  BsplineSpread sp = {0.0, 0.0, x_host};
+  if ((int)T.skew_a.size() < cB || (int)T.skew_b.size() < cB) {
+    sp.x = nullptr;  // (no host copy: the kernel gathers)
+    return sp;
+  }
+  for (int c0 = cA; c0 < cB; c0 += 64) {
+    double a0 = T.skew_a[c0], a1 = a0, b0 = T.skew_b[c0], b1 = b0;
+    for (int p = c0; p < std::min(cB, c0 + 64); ++p) {
+      a0 = std::min(a0, T.skew_a[p]), a1 = std::max(a1, T.skew_a[p]);
+      b0 = std::min(b0, T.skew_b[p]), b1 = std::max(b1, T.skew_b[p]);
+    }
+    sp.skew_rate_range = std::max(sp.skew_rate_range, a1 - a0);
+    sp.skew_offset_range = std::max(sp.skew_offset_range, b1 - b0);
+  }
+  return sp;
+}
+
+// Bound on how many rows a sample can lie from the knots of its spline window within knots [g0, g1): |skew| / (mean step) with a margin
+// (the evaluation verifies the bracket it searches and falls back to the whole range: kernels_gemm_eval.hip).  0: no bound known.
+int eval_search_halfwidth(const PixelTables& T, int cA, int cB, const double* x_host, int64_t g0, int64_t g1) {
+  if ((int)T.skew_a.size() < cB || (int)T.skew_b.size() < cB || g1 - g0 < 2) return 0;
+  double am = 0.0, bm = 0.0;
+  for (int p = cA; p < cB; ++p) am = std::max(am, std::fabs(T.skew_a[p])), bm = std::max(bm, std::fabs(T.skew_b[p]));
+  const double xm = std::max(std::fabs(x_host[g0] - T.tt), std::fabs(x_host[g1 - 1] - T.tt));
+  // the SHORTEST local step counts (mean over 64 knots, tile by tile): on a graded axis the launch's mean step understates the rows a
+  // skew spans where the steps are short, and a bound that is too small sends every tile there through the global-memory search
+  double dx = (x_host[g1 - 1] - x_host[g0]) / (double)(g1 - 1 - g0);
+  for (int64_t k = g0; k + 64 < g1; k += 64) dx = std::min(dx, (x_host[k + 64] - x_host[k]) / 64.0);
+  if (!(dx > 0.0)) return 0;
+  const double rows = 1.25 * (am * xm + bm) / dx + 3.0;
+  if (!(rows < 1e6)) return 0;
+  return (int)std::ceil(rows);
+}
+
+// Is the rotor grid of this transformation of the form F R(Theta_j, phi'_k), rings of the rotated equiangular grid at
+// colatitudes Theta_j?  Always without a boost (Theta_j = theta'_j); with one exactly when it points along the polar axis of the
+// rotated grid: the aberration then moves whole rings, B'(r') F R(theta', phi') = F R(Theta(theta'), phi') with no spin phase
+// (scri/waveform_grid.py:141-161: the rotation is about r' x v, which lies in the ring's tangent plane).  SURVEY section 7,
+// step 4(b).  The form is CHECKED on the rotors themselves (pixel_rotor, the code the dense route uses), not assumed.
+// The two-kernel synthesis moves (2 l_max + 1) x n_theta numbers per time step through HBM twice; the dense product it replaces
+// costs n_modes x n_pix multiply-adds per step and overtakes it only from about l_max = 13 on the default grids (measured:
+// tools/axis_boost_probe.py; l <= 8 on 17 x 17: 0.45 ms dense, 0.81 ms separable per 10^5 steps; l <= 16 on 33 x 33: 4.2 and 2.3).
+bool large_synthesis_route(const bms_ctx* c, int n_theta, int n_phi, int ell_min, int ell_max) {
+  return !c->opt.on(OPT_NO_SEPARABLE_SYNTHESIS) && !c->opt.on(OPT_NO_LARGE_SYNTHESIS) && large_synthesis_supported(n_theta, n_phi, ell_min, ell_max) != 0;
+}
+bool axis_boost_pays(const bms_ctx* c, int n_modes, int n_theta, int n_phi) {
+  const long long o = c->opt.v[OPT_AXIS_BOOST_MIN_WORK];  // (< 0: the built-in threshold; 0: always)
+  const long long min_work = o < 0 ? 160000 : o;
+  return (long long)n_modes * n_theta * n_phi >= min_work;
+}
+bool separable_rotor_grid(const bms_transformation* tr, std::vector<double>& thetas, bool axis_boost_off) {
+  const int n_theta = tr->n_theta, n_phi = tr->n_phi;
+  const double* fr = tr->frame_rotation;
+  const Quat F = {fr[0], fr[1], fr[2], fr[3]};
+  const BoostSpec bs = make_boost_spec(tr->boost_velocity);
+  thetas.resize(n_theta);
+  if (!bs.boosted) {
+    for (int j = 0; j < n_theta; ++j) thetas[j] = M_PI * j / (n_theta - 1);
+    return true;
+  }
+  if (axis_boost_off) return false;
+  double zf[3];
+  rotate_z(F, zf);
+  const double cx = bs.vhat[1] * zf[2] - bs.vhat[2] * zf[1], cy = bs.vhat[2] * zf[0] - bs.vhat[0] * zf[2], cz = bs.vhat[0] * zf[1] - bs.vhat[1] * zf[0];
+  if (std::sqrt(cx * cx + cy * cy + cz * cz) > 1e-15) return false;  // (parallel to rounding, nothing looser)
+  const double n2 = F.w * F.w + F.x * F.x + F.y * F.y + F.z * F.z;
+  const Quat Finv = {F.w / n2, -F.x / n2, -F.y / n2, -F.z / n2};
+  // Every pixel of the two rings at either end (acos near 1 turns an ulp of r'.v into 1e-8 rad there, as it does in the reference:
+  // a frame whose axis is parallel to v only to rounding can fail right there and then keeps the dense route), a few per ring
+  // elsewhere.
+  const int ks[4] = {0, 1 % n_phi, n_phi / 3, n_phi - 1};
+  for (int j = 0; j < n_theta; ++j) {
+    double th = 0.0, ph = 0.0;
+    as_spherical_coords(qmul(Finv, pixel_rotor(F, bs, j, 0, n_theta, n_phi)), th, ph);
+    thetas[j] = th;
+    const bool end_ring = j < 2 || j >= n_theta - 2;
+    for (int i = 0; i < (end_ring ? n_phi : 4); ++i) {
+      const int k = end_ring ? i : ks[i];
+      const Quat G = qmul(Finv, pixel_rotor(F, bs, j, k, n_theta, n_phi));
+      const Quat E = from_spherical_coords(th, (2 * M_PI) * k / n_phi);
+      const double sgn = (G.w * E.w + G.x * E.x + G.y * E.y + G.z * E.z) < 0 ? -1.0 : 1.0;
+      const double d = std::fabs(G.w - sgn * E.w) + std::fabs(G.x - sgn * E.x) + std::fabs(G.y - sgn * E.y) + std::fabs(G.z - sgn * E.z);
+      if (!(d <= 1e-13)) return false;
+    }
+  }
+  return true;
+}
+
+// ... with the context remembering the last answer
+bool separable_rotor_grid(bms_ctx* c, const bms_transformation* tr, std::vector<double>& thetas) {
+  const double key[9] = {tr->frame_rotation[0], tr->frame_rotation[1], tr->frame_rotation[2], tr->frame_rotation[3], tr->boost_velocity[0],
+                         tr->boost_velocity[1], tr->boost_velocity[2], (double)tr->n_theta, (double)tr->n_phi};
+  const bool switched_off = c->opt.on(OPT_NO_AXIS_BOOST_SEPARABLE);
+  if (!switched_off && c->ring_verdict >= 0 && std::memcmp(key, c->ring_key, sizeof key) == 0) {
+    if (c->ring_verdict) thetas = c->ring_thetas;
+    return c->ring_verdict != 0;
+  }
+  const bool yes = separable_rotor_grid(tr, thetas, switched_off);
+  if (!switched_off) {
+    std::memcpy(c->ring_key, key, sizeof key);
+    c->ring_verdict = yes ? 1 : 0;
+    c->ring_thetas = yes ? thetas : std::vector<double>();
+  }
+  return yes;
+}
+
+// Tables of the separable synthesis, built once per (grid, spin, l range) and kept in the context.  Returns with P.nt = 0
+// and P.large = false when the shape is one neither kernel takes.
+// thetas != nullptr: the rings' colatitudes (a boost along the grid's polar axis): tables of their own, kept until a transformation
+// with other colatitudes asks for the same shape
+int build_synthesis(bms_ctx* c, int n_theta, int n_phi, int spin, int ell_min, int ell_max, SynthesisPlan& P,
+                           const std::vector<double>* thetas) {
+  const std::array<int, 5> key = {n_theta, n_phi, spin, ell_min, ell_max};
+  auto it = c->syn_plans.find(key);
+  if (!thetas && it != c->syn_plans.end()) {
+    P = it->second;
+    return BMS_OK;
+  }
+  if (thetas) {
+    auto ia = c->syn_plans_axis.find(key);
+    if (ia != c->syn_plans_axis.end() && ia->second.first == *thetas) {
+      P = ia->second.second;
+      return BMS_OK;
+    }
+  }
+  P = SynthesisPlan();
+  if (!c->n_cu) {
+    hipDeviceProp_t prop;
+    HIP_TRY(c, hipGetDeviceProperties(&prop, c->device));
+    c->n_cu = prop.multiProcessorCount;
+  }
+  std::vector<int> meta;
+  int len = 0;
+  if (c->opt.on(OPT_NO_SEPARABLE_SYNTHESIS) || !synthesis_split_plan(n_theta, n_phi, ell_min, ell_max, P.g, meta, P.lds, P.nt, len)) P.nt = 0;
+  // (behind an axis boost the one-kernel form also keeps the per-pixel scale in LDS)
+  if (thetas && P.nt && P.lds + synthesis_split_scale_bytes(n_theta, n_phi) > 160 * 1024) P.nt = 0;
+  P.large = !c->opt.on(OPT_NO_SEPARABLE_SYNTHESIS) && !c->opt.on(OPT_NO_LARGE_SYNTHESIS) && large_synthesis_supported(n_theta, n_phi, ell_min, ell_max) != 0;
+  P.n_theta = n_theta, P.n_phi = n_phi, P.ell_min = ell_min, P.ell_max = ell_max;
+  if (!P.nt && !P.large) return BMS_OK;
+  hipStream_t S = c->stream;
+  int rc;
+  void* vp;
+  char nm_[96];
+  const int n_modes = LM_total_size(ell_min, ell_max);
+  std::vector<double> rot(4 * (size_t)n_theta), one(n_theta, 1.0);
+  for (int j = 0; j < n_theta; ++j) {
+    const Quat q = from_spherical_coords(thetas ? (*thetas)[j] : M_PI * j / (n_theta - 1), 0.0);
+    rot[4 * j] = q.w, rot[4 * j + 1] = q.x, rot[4 * j + 2] = q.y, rot[4 * j + 3] = q.z;
+  }
+  snprintf(nm_, sizeof nm_, thetas ? "syn_rotb_%d" : "syn_rot_%d", n_theta);
+  if ((rc = upload(c, nm_, rot.data(), 8 * rot.size(), &vp))) return rc;
+  const double* d_rot = (const double*)vp;
+  snprintf(nm_, sizeof nm_, "syn_one_%d", n_theta);
+  if ((rc = upload(c, nm_, one.data(), 8 * one.size(), &vp))) return rc;
+  const double* d_one = (const double*)vp;
+  if (P.nt) {
+    snprintf(nm_, sizeof nm_, "syn_meta_%d_%d_%d_%d_%d", n_theta, n_phi, spin, ell_min, ell_max);
+    if ((rc = upload(c, nm_, meta.data(), sizeof(int) * meta.size(), &vp))) return rc;
+    P.d_meta = (int*)vp;
+  }
+  double* d_Y;
+  if ((rc = dev_buf_t(c, "syn_Y", (size_t)n_theta * n_modes * 2, &d_Y))) return rc;
+  HIP_TRY(c, hipMemsetAsync(d_Y, 0, 16 * (size_t)n_theta * n_modes, S));
+  TIMED(c, BMS_TAG_SETUP, launch_swsh_values(S, d_rot, n_theta, spin, ell_min, ell_max, d_Y));
+  if (thetas)  // (one buffer per cache entry: the key's n_phi is part of the name)
+    snprintf(nm_, sizeof nm_, "syn_Tb_%d_%d_%d_%d_%d", n_theta, n_phi, spin, ell_min, ell_max);
+  else
+    snprintf(nm_, sizeof nm_, "syn_T_%d_%d_%d_%d", n_theta, spin, ell_min, ell_max);
+  if ((rc = dev_buf_t(c, nm_, (size_t)n_theta * n_modes, &P.d_T))) return rc;
+  TIMED(c, BMS_TAG_SETUP, launch_theta_table(S, d_Y, d_one, n_theta, n_modes, P.d_T));  // weights 1: the plain sLambda values
+  HIP_TRY(c, hipStreamSynchronize(S));  // host vectors above go out of scope
+  if (!thetas)
+    c->syn_plans[key] = P;
+  else
+    c->syn_plans_axis[key] = std::make_pair(*thetas, P);
+  return BMS_OK;
+}
+
+// One separable synthesis: A[rows][lda] (complex; n_modes (+ 1 with `off`, always for the one-kernel form) per row) -> Y[rows][ldy]
+int run_synthesis(bms_ctx* c, const SynthesisPlan& P, const double* A, long long lda, long long rows, const double* off, double* Y,
+                         long long ldy, const double* scale) {
+  hipStream_t S = c->stream;
+  if (rows <= 0) return BMS_OK;
+  if (P.nt && rows >= 2 && !c->opt.on(OPT_NO_SPLIT_SYNTHESIS)) {
+    TIMED(c, BMS_TAG_GEMM_SYNTHESIS, launch_synthesis_split(S, A, lda, rows, P.g, P.nt, P.d_T, P.d_meta, off, Y, ldy, P.lds, c->n_cu, scale));
+  } else if (P.large) {
+    double* d_F;
+    int rc = dev_buf_t(c, "Fphi", (size_t)rows * (2 * P.ell_max + 1) * large_analysis_jp(P.n_theta) * 2, &d_F);
+    if (rc) return rc;
+    TIMED(c, BMS_TAG_GEMM_SYNTHESIS, launch_synthesis_large(S, A, lda, rows, P.n_theta, P.n_phi, P.ell_min, P.ell_max, P.d_T, off, d_F, Y, ldy, scale));
+  } else
+    return fail(c, BMS_ERR_UNSUPPORTED, "internal: no separable synthesis for a chunk of %lld row(s) of this shape", rows);
+  return BMS_OK;
+}
+
+// Column plan of the grids: 0 = one column per grid pixel, in grid order.  When the analysis can read the columns in any
+// order (the fused kernel) the two pole rings are stored once each (1) and, with a boost, whose time skew grows with |u|,
+// the columns are also sorted by the skew rate (2).
+int column_plan(const bms_ctx* c, const bms_transformation* tr, int n_out) {
+  if (c->opt.on(OPT_NO_COLUMN_SORT) || c->opt.on(OPT_NO_FUSED_ANALYSIS)) return 0;
+  if (tr->n_theta < 3 || tr->n_theta * tr->n_phi > pixel_sort_max() || tr->n_theta > MAX_THETA_SEPARABLE ||
+      !fused_analysis_supported(tr->n_theta, tr->n_phi, tr->ell_max_out, n_out))
+    return 0;
+  const double* v = tr->boost_velocity;
+  return (v[0] == 0 && v[1] == 0 && v[2] == 0) ? 1 : 2;
+}
+// On return T.n_pix is the number of COLUMNS (everything downstream is per column); T.n_theta * T.n_phi stays the grid.
+int device_pixel_tables(bms_ctx* c, const bms_transformation* tr, PixelTables& T, int mode, int spin, int cw,
+                               const std::vector<cplx>* coef0, const std::vector<cplx>* coef1, const cplx cv[4], DevPixel& D,
+                               int plan, hipStream_t PS,
+                               const std::function<int(hipStream_t, const DevPixel&, int)>& behind_tables,
+                               const std::function<void()>& while_waiting) {
+  if (!PS) PS = c->stream;
+  init_pixel_tables(tr, T);
+  const int n_pix = T.n_pix, lst = tr->ell_max_supertranslation, nst = (lst + 1) * (lst + 1);
+  const int n_cols = plan ? n_pix - 2 * (tr->n_phi - 1) : n_pix;
+  PixelSpec P = base_pixel_spec(tr, T);
+  P.mode = mode;
+  P.spin = spin;
+  P.conformal_weight = cw;
+  if (cv)
+    for (int i = 0; i < 4; ++i) P.cv[i] = cv[i];
+  // one upload for the (up to three) coefficient sets
+  std::vector<cplx> coefs((size_t)3 * nst, cplx{0.0, 0.0});
+  std::memcpy(coefs.data(), tr->supertranslation, sizeof(cplx) * nst);
+  if (coef0) std::memcpy(coefs.data() + nst, coef0->data(), sizeof(cplx) * nst);
+  if (coef1) std::memcpy(coefs.data() + 2 * nst, coef1->data(), sizeof(cplx) * nst);
+  cplx* d_coefs;
+  int rc = dev_buf_t(c, "pix_coefs", (size_t)3 * nst, &d_coefs);
+  if (rc) return rc;
+  HIP_TRY(c, hipMemcpyAsync(d_coefs, coefs.data(), sizeof(cplx) * 3 * nst, hipMemcpyHostToDevice, PS));
+  P.st = d_coefs;
+  P.c0 = coef0 ? d_coefs + nst : nullptr;
+  P.c1 = coef1 ? d_coefs + 2 * nst : nullptr;
+  // one device block for all per-pixel outputs: 4 (rotor) + 4 scalars + 4 (off, scale) + 4 (xa, xb) + 6 + 2 doubles per pixel
+  double* blk;
+  if ((rc = dev_buf_t(c, "pix_block", (size_t)24 * n_pix, &blk))) return rc;
+  D.rotors = blk;
+  D.k = blk + 4 * (size_t)n_pix;
+  D.alpha = D.k + n_pix;
+  D.skew_a = D.alpha + n_pix;
+  D.skew_b = D.skew_a + n_pix;
+  D.col_off = D.skew_b + n_pix;
+  D.col_scale = D.col_off + 2 * (size_t)n_pix;
+  D.xa = D.col_scale + 2 * (size_t)n_pix;
+  D.xb = D.xa + 2 * (size_t)n_pix;
+  D.ethk = D.xb + 2 * (size_t)n_pix;  // ABD block aliases nothing: 16 + 2 + 2 + 2 + 1 + 1 = 24
+  D.etha = D.col_off;                 // ABD never uses the WM arrays: reuse them
+  D.ethetha = D.xa;
+  D.ik = D.ethk + 2 * (size_t)n_pix;
+  D.ik3 = D.ik + n_pix;
+  PixelOut O{};
+  O.rotors = D.rotors, O.k = D.k, O.alpha = D.alpha, O.skew_a = D.skew_a, O.skew_b = D.skew_b;
+  O.col_off = D.col_off, O.col_scale = D.col_scale, O.xa = D.xa, O.xb = D.xb;
+  O.ethk = D.ethk, O.etha = D.etha, O.ethetha = D.ethetha, O.ik = D.ik, O.ik3 = D.ik3;
+  int* d_perm = nullptr;
+  if (plan) {
+    if ((rc = dev_buf_t(c, "pix_perm", (size_t)2 * n_pix, &d_perm))) return rc;
+    TIMED_ON(c, PS, BMS_TAG_SETUP, launch_pixel_sort(PS, P, tr->n_theta, tr->n_phi, plan == 2, d_perm, d_perm + n_pix));
+    D.col_of_pixel = d_perm + n_pix;
+  }
+  TIMED_ON(c, PS, BMS_TAG_SETUP, launch_pixel_tables(PS, P, O, n_cols, d_perm));
+  // k, alpha, skew_a, skew_b are contiguous (n_pix apart): one copy back, into page-locked memory
+  if (c->pix_back_cap < (size_t)4 * n_pix) {
+    if (c->pix_back_host) (void)hipHostFree(c->pix_back_host);
+    c->pix_back_host = nullptr, c->pix_back_cap = 0;
+    HIP_TRY(c, hipHostMalloc((void**)&c->pix_back_host, sizeof(double) * 4 * n_pix, hipHostMallocDefault));
+    c->pix_back_cap = (size_t)4 * n_pix;
+  }
+  const double* back = c->pix_back_host;
+  HIP_TRY(c, hipMemcpyAsync(c->pix_back_host, D.k, sizeof(double) * 4 * n_pix, hipMemcpyDeviceToHost, PS));
+  if (behind_tables && PS != c->stream) {
+    // what needs the device tables only (the synthesis matrix: the rotors) is queued behind them on the same stream: it runs while the
+    // main stream still works on the modes; the host waits for the copy alone, the main stream for all of it
+    if (!c->ev_tables) HIP_TRY(c, hipEventCreateWithFlags(&c->ev_tables, hipEventDisableTiming));
+    if (!c->ev_aux_done) HIP_TRY(c, hipEventCreateWithFlags(&c->ev_aux_done, hipEventDisableTiming));
+    HIP_TRY(c, hipEventRecord(c->ev_tables, PS));
+    rc = behind_tables(PS, D, n_cols);
+    HIP_TRY(c, hipEventRecord(c->ev_aux_done, PS));
+    HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev_aux_done, 0));
+    if (while_waiting) while_waiting();  // host work of the caller that needs nothing from here
+    HIP_TRY(c, hipEventSynchronize(c->ev_tables));
+    if (rc) return rc;
+  } else {
+    if (behind_tables && (rc = behind_tables(PS, D, n_cols))) return rc;
+    if (while_waiting) while_waiting();
+    HIP_TRY(c, hipStreamSynchronize(PS));
+  }
+  T.n_pix = n_cols;
+  T.k.assign(back, back + n_cols);
+  T.alpha.assign(back + n_pix, back + n_pix + n_cols);
+  T.skew_a.assign(back + 2 * (size_t)n_pix, back + 2 * (size_t)n_pix + n_cols);
+  T.skew_b.assign(back + 3 * (size_t)n_pix, back + 3 * (size_t)n_pix + n_cols);
+  return BMS_OK;
+}
+
+// unit maps: row r of the (zeroed) [n][2 n] matrix gets 1 + 0i in complex column r
+__global__ __launch_bounds__(256) void unit_maps_kernel(double* __restrict__ I, int n) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r < n) I[(size_t)r * 2 * n + 2 * r] = 1.0;
+}
+
+// pixel-column partition (plan B of SURVEY 8(e)): whole 64-column GEMM tiles [cA, cB) of the column plan
+int column_range(bms_ctx* c, const bms_shard* sh, int n_cols, int& cA, int& cB) {
+  cA = 0, cB = n_cols;
+  if (!sh || sh->col_parts <= 1) return BMS_OK;
+  if (sh->col_part < 0 || sh->col_part >= sh->col_parts) return fail(c, BMS_ERR_INVALID, "column part %d outside [0, %d)", sh->col_part, sh->col_parts);
+  const long long n_tiles = (n_cols + 63) / 64;
+  cA = (int)std::min<long long>(n_cols, 64 * (n_tiles * sh->col_part / sh->col_parts));
+  cB = (int)std::min<long long>(n_cols, 64 * (n_tiles * (sh->col_part + 1) / sh->col_parts));
+  return BMS_OK;
+}
+// The analysis is linear in the grid columns, so a part's contribution is G[:, cA:cB] . At[cA:cB, :] with At = the analysis
+// of the n_cols unit maps (row r = modes of "1 in column r"), produced by the same analysis kernel the unsplit path runs.
+int part_analysis_matrix(bms_ctx* c, const AnalysisPlan& A, const char* name, int n_cols, const int* col_of_pixel,
+                                double** d_At, long long* ld_at) {
+  hipStream_t S = c->stream;
+  *ld_at = round_up(2LL * A.n_out, 128);
+  const size_t at_rows = (size_t)round_up(n_cols, 8) + 8;
+  double* d_I;
+  int rc;
+  if ((rc = dev_buf_t(c, name, at_rows * *ld_at, d_At))) return rc;
+  if ((rc = dev_buf_t(c, "unit_maps", (size_t)n_cols * 2 * n_cols, &d_I))) return rc;
+  HIP_TRY(c, hipMemsetAsync(*d_At, 0, sizeof(double) * at_rows * *ld_at, S));
+  HIP_TRY(c, hipMemsetAsync(d_I, 0, sizeof(double) * (size_t)n_cols * 2 * n_cols, S));
+  hipLaunchKernelGGL(unit_maps_kernel, dim3((n_cols + 255) / 256), dim3(256), 0, S, d_I, n_cols);
+  HIP_TRY(c, hipGetLastError());
+  return run_analysis(c, A, d_I, n_cols, *d_At, *ld_at, col_of_pixel, 2LL * n_cols);
+}
+
+// The shared pipeline: `nf` synthesised fields -> pointwise stage -> spline -> analysis, chunked over time.
+// tiles + tile-boundary blocks one launch of the evaluating product works through (the denominator of bms_ctx_get_eval_stats): 64-row
+// tiles with a boundary block between neighbours, or overlapping tiles that advance 61 rows
+uint64_t eval_tile_count(long long rows, int n_cols, int step) {
+  const uint64_t nbn = (uint64_t)((n_cols + 63) / 64);
+  if (step == 61) return (uint64_t)std::max<long long>(0, (rows - 3 + 60) / 61) * nbn;
+  const uint64_t nbm = (uint64_t)((rows + 63) / 64);
+  return nbm * nbn + (nbm > 0 ? nbm - 1 : 0) * nbn;
+}

@@ -85,6 +85,9 @@ struct ModeMapSide {
 };
 // s_t = sum_j |data[t][j]|^2 (or its square root), terms added in column order without contraction (waveform_base.py:19-35)
 hipError_t launch_row_norm(hipStream_t stream, const double* data, long long ld, long long n_rows, int n_cols, int take_sqrt, double* out);
+// trailing data dimensions: the reference's layout (trailing index fastest) <-> one block of unit-stride columns per series
+hipError_t launch_series_to_blocks(hipStream_t stream, const double* in, long long ld_in, double* out, long long n_rows, int n_modes, int F);
+hipError_t launch_blocks_to_series(hipStream_t stream, const double* in, long long block_rows, double* out, long long n_rows, int n_cols, int F);
 hipError_t launch_mode_map(hipStream_t stream, double* out, long long ld_out, long long n_rows, int n_cols, const ModeMapSide& A,
                            const ModeMapSide& B, const double* row_scale);
 

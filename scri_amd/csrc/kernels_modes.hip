@@ -89,4 +89,44 @@ hipError_t launch_mode_map(hipStream_t stream, double* out, long long ld_out, lo
   return hipGetLastError();
 }
 
+// ---- several series in one row (trailing data dimensions, scri/waveform_grid.py:299-308): the reference stores the trailing index
+// FASTEST (element (t, mode, j) at (t n_modes + mode) F + j); the engine wants every series as a block of unit-stride columns.  Both
+// conversions are plain permutations at HBM rate, so the host never makes a strided copy.
+// in: c16[n_rows][ld_in] with (mode, j) at column mode * F + j   ->   out: c16[n_rows][F * n_modes] with series j in columns [j n_modes, ...)
+__global__ __launch_bounds__(256) void series_to_blocks_kernel(const double2* __restrict__ in, long long ld_in, double2* __restrict__ out,
+                                                               long long n_rows, int n_modes, int F) {
+  const long long per_row = (long long)n_modes * F, total = n_rows * per_row;
+  for (long long i = blockIdx.x * 256LL + threadIdx.x; i < total; i += gridDim.x * 256LL) {
+    const long long t = i / per_row;
+    const int c = (int)(i - t * per_row), j = c / n_modes, m = c - j * n_modes;
+    out[i] = in[t * ld_in + (long long)m * F + j];
+  }
+}
+// in: c16[F][block_rows][n_cols] (series-major results, the first n_rows rows of each block valid)   ->   out: c16[n_rows][n_cols * F]
+// with (col, j) at column col * F + j
+__global__ __launch_bounds__(256) void blocks_to_series_kernel(const double2* __restrict__ in, long long block_rows, double2* __restrict__ out,
+                                                               long long n_rows, int n_cols, int F) {
+  const long long per_row = (long long)n_cols * F, total = n_rows * per_row;
+  for (long long i = blockIdx.x * 256LL + threadIdx.x; i < total; i += gridDim.x * 256LL) {
+    const long long t = i / per_row;
+    const int c = (int)(i - t * per_row), col = c / F, j = c - col * F;
+    out[i] = in[((long long)j * block_rows + t) * n_cols + col];
+  }
+}
+
+hipError_t launch_series_to_blocks(hipStream_t stream, const double* in, long long ld_in, double* out, long long n_rows, int n_modes, int F) {
+  const long long total = n_rows * n_modes * F;
+  if (total <= 0) return hipSuccess;
+  const long long blocks = std::min<long long>((total + 255) / 256, 16384);
+  hipLaunchKernelGGL(series_to_blocks_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, (const double2*)in, ld_in, (double2*)out, n_rows, n_modes, F);
+  return hipGetLastError();
+}
+hipError_t launch_blocks_to_series(hipStream_t stream, const double* in, long long block_rows, double* out, long long n_rows, int n_cols, int F) {
+  const long long total = n_rows * n_cols * F;
+  if (total <= 0) return hipSuccess;
+  const long long blocks = std::min<long long>((total + 255) / 256, 16384);
+  hipLaunchKernelGGL(blocks_to_series_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, (const double2*)in, block_rows, (double2*)out, n_rows, n_cols, F);
+  return hipGetLastError();
+}
+
 }  // namespace bms

@@ -445,47 +445,42 @@ def transform_modes(
 def transform_modes_series(t, data, ell_min, ell_max, spin_weight, conformal_weight, type_term, transformation, aux=(), ctx=None, grid=False):
     """bms_transform_modes_series: data complex [N, n_modes, F] -- F independent series under one transformation, the reference's
     extra trailing data dimensions flattened (scri/waveform_grid.py:299-308, 574-594) -- -> (t_out[N'], out[N', n_out, F]) in ONE
-    engine call: the block crosses PCIe once and the set-up (time axis, spline tables, per-direction tables, window) is shared.
+    engine call.  The arrays cross PCIe as they are (the trailing index fastest: no strided copy on the host; the permutation to one
+    block of columns per series runs on the device) and the set-up (time axis, spline tables, per-direction tables, window) is shared.
     aux: (data [N, aux_modes, F], ell_min, ell_max, spin, coeff, power) per psi companion.  grid=True: the field on the grid instead
     (WaveformGrid.from_modes), out[N', n_theta n_phi, F]."""
     ctx = _ctx(ctx)
     t = np.ascontiguousarray(t, dtype=float)
     n = t.shape[0]
-    data = np.asarray(data)
+    data = _lib.as_c16(data)
     if data.ndim != 3 or data.shape[:2] != (n, LM_total_size(ell_min, ell_max)):
         raise ValueError(f"data shape {data.shape} inconsistent with {n} time steps, ell range [{ell_min}, {ell_max}] and one trailing axis")
     n_series = data.shape[2]
-
-    def blocks(a):  # [N, modes, F] -> rows that hold the F series one after the other
-        return np.ascontiguousarray(np.moveaxis(a, 2, 1).reshape(a.shape[0], -1), dtype=np.complex128)
-
     inp = bms_wm_input()
     inp.n_times = n
     inp.t = dptr(t)
-    block = blocks(data)
-    keep = [t, block]
-    inp.data, inp.ld, inp.mem = block.ctypes.data, block.shape[1], BMS_HOST
+    keep = [t, data]
+    inp.data, inp.ld, inp.mem = data.ctypes.data, data.shape[1] * n_series, BMS_HOST
     inp.ell_min, inp.ell_max = int(ell_min), int(ell_max)
     inp.spin_weight, inp.conformal_weight, inp.type_term = int(spin_weight), int(conformal_weight), int(type_term)
     inp.n_aux = len(aux)
     for i, a in enumerate(aux):
         adata, amin, amax, aspin, acoeff, apower = a[:6]
-        adata = np.asarray(adata)
+        adata = _lib.as_c16(adata)
         if adata.shape != (n, LM_total_size(amin, amax), n_series):
             raise ValueError("auxiliary data shape mismatch")
-        ablock = blocks(adata)
-        keep.append(ablock)
-        inp.aux_data[i], inp.aux_ld[i] = ablock.ctypes.data, ablock.shape[1]
+        keep.append(adata)
+        inp.aux_data[i], inp.aux_ld[i] = adata.ctypes.data, adata.shape[1] * n_series
         inp.aux_ell_min[i], inp.aux_ell_max[i], inp.aux_spin[i] = int(amin), int(amax), int(aspin)
         inp.aux_coeff[i], inp.aux_power[i] = float(acoeff), int(apower)
     n_out = transformation.n_theta * transformation.n_phi if grid else LM_total_size(abs(int(spin_weight)), transformation.ell_max_out)
-    out = _lib.pinned_empty((n_series, max(n, 1), n_out), np.complex128)
+    out = _lib.pinned_empty((max(n, 1), n_out, n_series), np.complex128)
     t_out = np.empty(max(n, 1), dtype=float)
     n_new = c_i64(0)
     rc = _lib.load().bms_transform_modes_series(ctx.handle, ctypes.byref(inp), n_series, ctypes.byref(transformation), dptr(t_out),
                                                 None if grid else vptr(out), vptr(out) if grid else None, ctypes.byref(n_new))
     ctx.check(rc, "bms_transform_modes_series")
-    return t_out[: n_new.value], np.ascontiguousarray(np.moveaxis(out[:, : n_new.value], 0, 2))
+    return t_out[: n_new.value], out[: n_new.value]
 
 
 def output_window(t, transformation, abd=False, ctx=None):

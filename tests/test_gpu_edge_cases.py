@@ -602,6 +602,7 @@ def test_synthesis_with_the_evaluation_in_it_equals_the_two_pass_route_and_the_o
     if st_scale <= 0.3 and mesh in ("uniform", "jitter"):  # (elsewhere the bound on the spread of the skews may send the call to the old route)
         assert "spline_backward" not in tags, tags  # no pass over a grid of coefficients on this route
     route("SCRI_AMD_SYNTHESIS_EVAL", None)
+    route("SCRI_AMD_NO_SYNTHESIS_EVAL", "1")  # (the fused route is the default from l_max = 15 on: the two-pass route is named)
     ref, tags_ref = run()
     assert "spline_backward" in tags_ref
     assert got.n_times == ref.n_times and np.array_equal(got.t, ref.t)
@@ -629,7 +630,9 @@ def test_synthesis_with_the_evaluation_in_it_chunks_shards_and_grid_output(ctx, 
     t1, d1 = engine.transform_modes(t, data, 2, ell_max, -2, -1, engine.BMS_TERM_H, tr, ctx=ctx)
     d1 = np.array(d1)
     route("SCRI_AMD_SYNTHESIS_EVAL", None)
+    route("SCRI_AMD_NO_SYNTHESIS_EVAL", "1")
     t0, d0 = engine.transform_modes(t, data, 2, ell_max, -2, -1, engine.BMS_TERM_H, tr, ctx=ctx)
+    route("SCRI_AMD_NO_SYNTHESIS_EVAL", None)
     route("SCRI_AMD_SYNTHESIS_EVAL", "1")
     scale = np.abs(d0).max()
     assert np.array_equal(t0, t1) and np.abs(d1 - d0).max() < 3e-13 * scale
@@ -648,6 +651,7 @@ def test_synthesis_with_the_evaluation_in_it_chunks_shards_and_grid_output(ctx, 
     tg, g1 = engine.transform_modes(t[:1200], data[:1200], 2, ell_max, -2, -1, engine.BMS_TERM_H, tr, ctx=ctx, grid=True)
     g1 = np.array(g1)
     route("SCRI_AMD_SYNTHESIS_EVAL", None)
+    route("SCRI_AMD_NO_SYNTHESIS_EVAL", "1")
     tg0, g0 = engine.transform_modes(t[:1200], data[:1200], 2, ell_max, -2, -1, engine.BMS_TERM_H, tr, ctx=ctx, grid=True)
     assert np.array_equal(tg, tg0) and g1.shape == g0.shape and np.abs(g1 - g0).max() < 3e-13 * max(1.0, np.abs(g0).max())
 

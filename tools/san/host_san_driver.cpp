@@ -1,9 +1,14 @@
 // Host-side sanitizer run (no GPU sanitizer exists on this pool: ASan / UBSan cover what runs on the host).
-// `make -C scri_amd/csrc SAN=1` compiles this file -- which INCLUDES engine.hip, so that the static planning helpers are
-// reachable -- host-only with -fsanitize=address,undefined and runs it: shard plans, output windows, knot ranges, column
+// `make -C scri_amd/csrc SAN=1` compiles this file -- which INCLUDES the host side of the engine (engine_*.hip, split by entry family
+// behind engine.h), so that every planning helper is instrumented -- host-only with -fsanitize=address,undefined and runs it: shard plans, output windows, knot ranges, column
 // parts, chunk walks, rotor / harmonic / conformal tables and the frame integrator over the five BASELINE shapes, 1..8 shards,
 // 1..8 column parts, series of 2..9 samples and odd grids.  Nothing here touches a device.
-#include "../../scri_amd/csrc/engine.hip"
+#include "../../scri_amd/csrc/engine_context.hip"
+#include "../../scri_amd/csrc/engine_tables.hip"
+#include "../../scri_amd/csrc/engine_rotate.hip"
+#include "../../scri_amd/csrc/engine_modes.hip"
+#include "../../scri_amd/csrc/engine_abd.hip"
+#include "../../scri_amd/csrc/engine_blocks.hip"
 
 #include <cstdio>
 #include <random>
