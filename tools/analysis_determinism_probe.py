@@ -9,9 +9,9 @@ bad = 0
 for (nth, nph, L, s) in [(37, 37, 16, -2), (13, 13, 6, -2), (15, 15, 6, 0), (27, 27, 12, 1), (21, 21, 8, -2), (9, 9, 4, 2), (17, 19, 8, -1), (33, 33, 16, 0)]:
     for n in (2, 3, 5, 64, 257, 1001, 4097):
         g = rng.standard_normal((n, nth, nph)) + 1j * rng.standard_normal((n, nth, nph))
-        os.environ.pop("SCRI_AMD_NO_SPLIT_ANALYSIS", None)
+        ctx.option("NO_SPLIT_ANALYSIS", 0)
         a = [engine.map2salm(g, s, L, ell_min=abs(s), ctx=ctx) for _ in range(4)]
-        os.environ["SCRI_AMD_NO_SPLIT_ANALYSIS"] = "1"
+        ctx.option("NO_SPLIT_ANALYSIS", 1)
         b = engine.map2salm(g, s, L, ell_min=abs(s), ctx=ctx)
         same = all(np.array_equal(a[0], x) for x in a[1:])
         err = np.abs(a[0] - b).max() / np.abs(b).max()

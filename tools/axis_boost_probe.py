@@ -23,9 +23,9 @@ def routes(call):
     res = {}
     for route in ("dense", "separable"):
         if route == "dense":
-            os.environ["SCRI_AMD_NO_AXIS_BOOST_SEPARABLE"] = "1"
+            ctx.option("NO_AXIS_BOOST_SEPARABLE", 1)
         else:
-            os.environ.pop("SCRI_AMD_NO_AXIS_BOOST_SEPARABLE", None)
+            ctx.option("NO_AXIS_BOOST_SEPARABLE", 0)
         call()
         ctx.synchronize()
         ctx.get_timing(reset=True)

@@ -28,9 +28,9 @@ for name, lmax, n in (("cfg2", 8, 3001), ("cfg2", 8, 100000), ("cfg3", 16, 10000
     for label, kw in (("supertranslation only", dict(supertranslation=st)),
                       ("supertranslation + frame rotation", dict(supertranslation=st, frame_rotation=q))):
         for dt in (h, psi4):
-            os.environ["SCRI_AMD_NO_SEPARABLE_SYNTHESIS"] = "1"
+            ctx.option("NO_SEPARABLE_SYNTHESIS", 1)
             ref, tr = run(t, data, lmax, kw, dt)
-            os.environ.pop("SCRI_AMD_NO_SEPARABLE_SYNTHESIS")
+            ctx.option("NO_SEPARABLE_SYNTHESIS", 0)
             got, tg = run(t, data, lmax, kw, dt)
             got, tg = run(t, data, lmax, kw, dt)
             err = np.abs(got.data - ref.data).max() / np.abs(ref.data).max()

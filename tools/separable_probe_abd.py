@@ -30,9 +30,9 @@ for label, boost in (("boost-free", [0, 0, 0]), ("with the workload's boost", kw
     res = {}
     for route in ("dense", "separable"):
         if route == "dense":
-            os.environ["SCRI_AMD_NO_SEPARABLE_SYNTHESIS"] = "1"
+            ctx.option("NO_SEPARABLE_SYNTHESIS", 1)
         else:
-            os.environ.pop("SCRI_AMD_NO_SEPARABLE_SYNTHESIS", None)
+            ctx.option("NO_SEPARABLE_SYNTHESIS", 0)
         engine.transform_abd(u, d_in.data_ptr(), ell_max, tr, ctx=ctx, device=True, out_ptr=d_out.data_ptr())
         ctx.synchronize()
         ctx.get_timing(reset=True)

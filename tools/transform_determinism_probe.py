@@ -18,9 +18,9 @@ def wm(t, data, lmax):
 
 for name, lmax, n in (("cfg2", 8, 2001), ("cfg2", 8, 30000), ("cfg3", 16, 1501), ("cfg3", 16, 4000), ("cfg3", 16, 20001)):
     t, data, spec = synthetic.workload(name, n_times=n)
-    os.environ.pop("SCRI_AMD_NO_SPLIT_ANALYSIS", None)
+    ctx.option("NO_SPLIT_ANALYSIS", 0)
     outs = [wm(t, data, lmax).transform(**spec["kwargs"]).data.copy() for _ in range(5)]
-    os.environ["SCRI_AMD_NO_SPLIT_ANALYSIS"] = "1"
+    ctx.option("NO_SPLIT_ANALYSIS", 1)
     ref = wm(t, data, lmax).transform(**spec["kwargs"]).data
     same = all(np.array_equal(outs[0], x) for x in outs[1:])
     err = max(np.abs(x - ref).max() for x in outs) / np.abs(ref).max()
@@ -33,9 +33,9 @@ a = scri_amd.AsymptoticBondiData(u, 6, ctx=ctx)
 a._raw_data[:] = kerr_schild_abd(2.0, 0.456, 6, u)
 st = np.array([0.0, 3e-2 - 1j * 5e-3, 1e-3, -3e-2 - 1j * 5e-3, 2e-4 + 1j * 1e-4, 1j * 3e-3, 1e-2, 1j * 3e-3, 2e-4 - 1j * 1e-4])
 kw = dict(supertranslation=st, frame_rotation=np.array([1.0, 2, 3, 4]) / np.sqrt(30), boost_velocity=np.array([2e-4, -3e-5, 2e-4]))
-os.environ.pop("SCRI_AMD_NO_SPLIT_ANALYSIS", None)
+ctx.option("NO_SPLIT_ANALYSIS", 0)
 outs = [a.transform(**kw)._raw_data.copy() for _ in range(8)]
-os.environ["SCRI_AMD_NO_SPLIT_ANALYSIS"] = "1"
+ctx.option("NO_SPLIT_ANALYSIS", 1)
 ref = a.transform(**kw)._raw_data
 same = all(np.array_equal(outs[0], x) for x in outs[1:])
 err = max(np.abs(x - ref).max() for x in outs) / np.abs(ref).max()
