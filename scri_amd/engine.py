@@ -48,16 +48,53 @@ def total_size_D_matrices(ell_min, ell_max):
 # ---------------------------------------------------------------------------------- rotation
 
 
-def rotate_const(data, ell_min, ell_max, quaternion, ctx=None):
+def _row_blocks(n_rows, ctxs):
+    """contiguous, near-equal blocks of rows, one per context (rotations act on every time step independently: no halo)"""
+    k = len(ctxs)
+    return [((n_rows * i) // k, (n_rows * (i + 1)) // k) for i in range(k)]
+
+
+def _rotate_dealt(data, devices, ctx, call):
+    """call(ctx, row0, row1) on one host thread per device: each context uploads, rotates and downloads its own block of rows"""
+    ctxs = contexts_for(devices, first=ctx)
+    blocks = _row_blocks(data.shape[0], ctxs)
+    errors = [None] * len(ctxs)
+
+    def run(i):
+        try:
+            if blocks[i][1] > blocks[i][0]:
+                call(ctxs[i], *blocks[i])
+        except BaseException as e:  # noqa: BLE001 -- re-raised by the caller's thread
+            errors[i] = e
+
+    threads = [threading.Thread(target=run, args=(i,)) for i in range(1, len(ctxs))]
+    for th in threads:
+        th.start()
+    run(0)
+    for th in threads:
+        th.join()
+    for e in errors:
+        if e is not None:
+            raise e
+    return data
+
+
+def rotate_const(data, ell_min, ell_max, quaternion, ctx=None, devices=None):
     """In place: data[t, l, m] <- sum_m' data[t, l, m'] D^l_{m',m}(q)   (scri/rotations.py:346-367).
-    `data`: C-contiguous complex128 [N, >= n_modes] numpy array."""
-    ctx = _ctx(ctx)
+    `data`: C-contiguous complex128 [N, >= n_modes] numpy array.  devices: the GPUs of this process the rows are dealt over
+    (one context and one host thread each; default SCRI_AMD_DEVICES, else the one context)."""
     assert data.dtype == np.complex128 and data.ndim == 2 and data.strides[1] == 16
     q = np.ascontiguousarray(quaternion, dtype=float)
-    rc = _lib.load().bms_rotate_const(
-        ctx.handle, vptr(data), BMS_HOST, data.shape[0], data.strides[0] // 16, ell_min, ell_max, dptr(q)
-    )
-    ctx.check(rc, "bms_rotate_const")
+    devices = devices if devices is not None else default_devices()
+
+    def call(cx, r0, r1):
+        block = data[r0:r1]
+        rc = _lib.load().bms_rotate_const(cx.handle, vptr(block), BMS_HOST, block.shape[0], data.strides[0] // 16, ell_min, ell_max, dptr(q))
+        cx.check(rc, "bms_rotate_const")
+
+    if devices and len(devices) > 1 and data.shape[0] >= 2 * len(devices):
+        return _rotate_dealt(data, devices, ctx, call)
+    call(_ctx(ctx), 0, data.shape[0])
     return data
 
 
@@ -76,18 +113,23 @@ def rotate_const_D(data, ell_min, ell_max, D, ctx=None):
     return data
 
 
-def rotate_series(data, ell_min, ell_max, spinors, ctx=None):
+def rotate_series(data, ell_min, ell_max, spinors, ctx=None, devices=None):
     """In place, one rotor per time step; spinors complex128 [N, 2] = (w + i z, y + i x)
-    (scri/rotations.py:370-392)."""
-    ctx = _ctx(ctx)
+    (scri/rotations.py:370-392).  devices: as rotate_const -- contiguous blocks of time steps per GPU, no exchange."""
     assert data.dtype == np.complex128 and data.ndim == 2 and data.strides[1] == 16
     sp = np.ascontiguousarray(spinors, dtype=np.complex128)
     if sp.shape != (data.shape[0], 2):
         raise ValueError(f"spinors must have shape ({data.shape[0]}, 2), got {sp.shape}")
-    rc = _lib.load().bms_rotate_series(
-        ctx.handle, vptr(data), BMS_HOST, data.shape[0], data.strides[0] // 16, ell_min, ell_max, vptr(sp)
-    )
-    ctx.check(rc, "bms_rotate_series")
+    devices = devices if devices is not None else default_devices()
+
+    def call(cx, r0, r1):
+        block = data[r0:r1]
+        rc = _lib.load().bms_rotate_series(cx.handle, vptr(block), BMS_HOST, block.shape[0], data.strides[0] // 16, ell_min, ell_max, vptr(sp[r0:r1]))
+        cx.check(rc, "bms_rotate_series")
+
+    if devices and len(devices) > 1 and data.shape[0] >= 2 * len(devices):
+        return _rotate_dealt(data, devices, ctx, call)
+    call(_ctx(ctx), 0, data.shape[0])
     return data
 
 

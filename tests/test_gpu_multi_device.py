@@ -100,3 +100,20 @@ def test_errors_of_one_context_reach_the_caller(ctx):
         engine.transform_modes(t, data, 2, 8, -2, -1, engine.BMS_TERM_H, tr, ctx=ctx, devices=[0, 99])
     with pytest.raises(ValueError, match="devices"):
         engine.transform_modes(t, data, 2, 8, -2, -1, engine.BMS_TERM_H, tr, ctx=ctx, devices=[0, 0], shard=(0, 4000, 0, 4000))
+
+
+def test_rotations_dealt_over_contexts_are_bit_identical(ctx):
+    """rotations act on every time step independently (scri/rotations.py:346-392; SURVEY 8(e): "contiguous time blocks, no
+    collective"): blocks of rows on several contexts give the bits of the one-context call"""
+    from scri_amd import engine, synthetic
+
+    t, data, _ = synthetic.workload("cfg3", n_times=30001)
+    rng = np.random.default_rng(3)
+    R = rng.normal(size=(t.size, 4))
+    R /= np.linalg.norm(R, axis=1)[:, None]
+    sp = np.stack([R[:, 0] + 1j * R[:, 3], R[:, 2] + 1j * R[:, 1]], axis=1)
+    one = engine.rotate_series(data.copy(), 2, 16, sp, ctx=ctx)
+    for devs in ([0, 0], [0, 0, 0, 0, 0]):
+        assert np.array_equal(engine.rotate_series(data.copy(), 2, 16, sp, ctx=ctx, devices=devs), one)
+    q = np.array([1.0, 2, 3, 4]) / np.sqrt(30)
+    assert np.array_equal(engine.rotate_const(data.copy(), 2, 16, q, ctx=ctx, devices=[0, 0, 0]), engine.rotate_const(data.copy(), 2, 16, q, ctx=ctx))
