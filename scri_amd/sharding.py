@@ -364,6 +364,13 @@ class ShardedTransform:
 
         as_numpy = not isinstance(local, torch.Tensor)
         loc = torch.from_numpy(np.ascontiguousarray(local, dtype=np.complex128)) if as_numpy else local
+        if self.backend == "nccl" and loc.device.type == "cpu" and self._compute is None:
+            # RCCL moves device memory: a host-resident series goes to this rank's GPU once and its result comes back to the host
+            from . import _lib
+
+            ctx = self.ctx if self.ctx is not None else _lib.default_context()
+            self.ctx = ctx
+            loc = loc.to(torch.device("cuda", ctx.device))
         rows_axis = 1 if self.kind == "abd" else 0
         if loc.shape[rows_axis] != self.own:
             raise ValueError(f"rank {self.rank} owns rows [{self.have[self.rank][0]}, {self.have[self.rank][1]}): got {loc.shape[rows_axis]} rows")
