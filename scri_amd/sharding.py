@@ -309,6 +309,8 @@ class ShardedTransform:
             host = ext.cpu().numpy() if isinstance(ext, torch.Tensor) else np.asarray(ext)
             return self._compute(self.t_global, host, tuple(int(x) for x in shard))
         on_device = isinstance(ext, torch.Tensor) and ext.device.type == "cuda"
+        if on_device:
+            self._sync_before_engine(ext)  # (whatever torch queued on its stream -- copies, halo rows -- is in place before the kernels read it)
         if not on_device:
             host = np.ascontiguousarray(ext.numpy() if isinstance(ext, torch.Tensor) else ext)
             if self.kind == "abd":
@@ -341,7 +343,7 @@ class ShardedTransform:
         if not isinstance(tensor, torch.Tensor) or tensor.device.type != "cuda" or self._compute is not None:
             return
         same = getattr(self.ctx, "stream_handle", None) == torch.cuda.current_stream(tensor.device).cuda_stream
-        if not (same and self.backend == "nccl"):
+        if not same:
             torch.cuda.synchronize(tensor.device)
 
     def own_rows_view(self, like=None):
@@ -392,7 +394,6 @@ class ShardedTransform:
             n = len(self.t_global)
             n_new_all = self.window[1] - self.window[0]
             total, _ = padded_rows(n_new_all, world)
-            self._sync_before_engine(full)
             t_all, part, first = self._engine_call(full, (0, n, 0, n, rank, world))
             if not isinstance(part, torch.Tensor):
                 part = torch.from_numpy(np.ascontiguousarray(part))
@@ -408,7 +409,6 @@ class ShardedTransform:
             return back((np.empty(0), torch.empty(shape, dtype=torch.complex128, device=loc.device), max(i0, self.window[0])))
         if self.kind == "abd":
             ext = exchange_halos(loc, self.have[rank], self.need[rank], self.have, self.need, group=self.group, dim=1)
-            self._sync_before_engine(ext)
             return back(self._engine_call(ext, (n0, ext.shape[1], i0, i1), out=out))
         view = self.own_rows_view(like=loc)
         if view.data_ptr() != loc.data_ptr():
@@ -416,7 +416,6 @@ class ShardedTransform:
         ext_buf = self._ext[: n1 - n0]
         if self.interior is None:
             ext = exchange_halos(view, self.have[rank], self.need[rank], self.have, self.need, group=self.group, out=ext_buf)
-            self._sync_before_engine(ext)
             return back(self._engine_call(ext, (n0, ext.shape[0], i0, i1), out=out))
         # interior outputs from own rows while the halos travel; then the two edges from the completed rows
         a, b = self.interior
@@ -434,7 +433,6 @@ class ShardedTransform:
 
         mid = piece(view, i0, a, b)  # own rows only: runs under the exchange
         ext = pending()
-        self._sync_before_engine(ext)
         parts = [p for p in (piece(ext, n0, i0, a), mid, piece(ext, n0, b, i1)) if p is not None]
         t_out = np.concatenate([np.asarray(p[0]) for p in parts]) if parts else np.empty(0)
         if out is not None:
