@@ -238,7 +238,7 @@ def test_axis_boost_time_shards_and_pipelined_pieces(ctx, monkeypatch, route):
     monkeypatch.delenv("SCRI_AMD_NO_PIPELINE")
     calls = []
     real = engine._transform_modes_pipelined
-    monkeypatch.setattr(engine, "_transform_modes_pipelined", lambda *a: calls.append(1) or real(*a))
+    monkeypatch.setattr(engine, "_transform_modes_pipelined", lambda *a, **k: calls.append(1) or real(*a, **k))
     monkeypatch.setattr(engine, "PIPELINE_MIN_BYTES", 1 << 16)
     piped = run()
     assert calls == [1] and np.array_equal(piped.t, plain.t)

@@ -69,7 +69,7 @@ def test_devices_keyword_of_the_scri_level_calls(ctx, monkeypatch):
     assert np.array_equal(env.t, ref.t) and np.abs(env.data - ref.data).max() < 1e-14 * np.abs(ref.data).max()
     monkeypatch.delenv("SCRI_AMD_DEVICES")
 
-    from test_gpu_sharding import _abd_case
+    from tests.test_gpu_sharding import _abd_case
 
     u, raw, _, L = _abd_case(n=2000, ell_max=4)
     abd = scri_amd.AsymptoticBondiData(u, L, ctx=ctx)

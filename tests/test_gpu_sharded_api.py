@@ -28,7 +28,7 @@ def _free_port():
 def test_group_keyword_equals_single_gpu(ctx, tmp_path, world):
     import scri_amd
     from scri_amd import synthetic
-    from test_gpu_sharding import _abd_case
+    from tests.test_gpu_sharding import _abd_case
 
     port = _free_port()
     procs = []

@@ -126,7 +126,7 @@ def test_pipelined_host_path_matches_the_one_call_path(ctx, monkeypatch):
     monkeypatch.delenv("SCRI_AMD_NO_PIPELINE")
     calls = []
     real = engine._transform_modes_pipelined
-    monkeypatch.setattr(engine, "_transform_modes_pipelined", lambda *a: calls.append(1) or real(*a))
+    monkeypatch.setattr(engine, "_transform_modes_pipelined", lambda *a, **k: calls.append(1) or real(*a, **k))
     monkeypatch.setattr(engine, "PIPELINE_MIN_BYTES", 1 << 16)
     piped = run(t)
     assert calls == [1]
