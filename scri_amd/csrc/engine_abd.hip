@@ -215,7 +215,11 @@ static int transform_abd_impl(bms_ctx* c, const double* u, const void* raw, int 
     if ((rc = dev_buf_t(c, "abd_As", (size_t)rows_avail * ld_af, &d_As))) return rc;
     TIMED(c, BMS_TAG_SPLINE_FORWARD, launch_bspline_solve_modes(S, d_raw + (size_t)5 * rows_avail * nm * 2, 2LL * nm, nm, d_As, ld_af, row0, rows_avail,
                                                                 d_bsfwd, d_bstab, 1));
-    // row nm of the spin-2 harmonics (psi0 shares them and stops at row nm - 1) multiplies the solved constant series: -eth eth alpha
+    // row nm of the spin-2 harmonics (psi0 shares them and stops at row nm - 1) multiplies the solved constant series: -eth eth alpha.
+    // Two invariants keep psi0's product, which shares the matrix, correct: the matrix has that row and the 8 rows a K chunk may read
+    // past it (checked here), and launch_zgemm3m multiplies rows k >= K of B by ZERO-guarded A (kernels.h says so), because psi0's last
+    // K chunk reads this now non-zero row.
+    if (brows < (long long)nm + 1 + 8) return fail(c, BMS_ERR_HIP, "internal: the spin-2 matrix has %lld rows, sigma's offset row needs %d", brows, nm + 9);
     TIMED(c, BMS_TAG_SETUP, launch_negated_row(S, DP.ethetha, d_B[4] + (size_t)nm * ldb, 2 * n_cols));
   }
 

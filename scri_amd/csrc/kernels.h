@@ -198,7 +198,9 @@ hipError_t launch_dgemm(hipStream_t stream, const double* A, long long lda, cons
 
 // ---- complex128 GEMM on MFMA with 3 real products per complex one: C = (A . B - col_off) * col_scale
 // A[M x K], B[K x N], C[M x N] complex interleaved, row-major, pitches lda/ldb/ldc in DOUBLES; B zero padded to a multiple
-// of 64 complex columns and 8 rows; col_off/col_scale per real column (2N entries) or null.
+// of 64 complex columns and 8 rows; col_off/col_scale per real column (2N entries) or null.  The last K chunk reads up to 7 rows of B
+// past row K - 1: the kernel zero-guards A for k >= K, so those rows need not be zero (AsymptoticBondiData keeps sigma's offset row
+// right behind the rows psi0 multiplies) -- they only have to exist.
 hipError_t launch_zgemm3m(hipStream_t stream, const double* A, long long lda, const double* B, long long ldb, double* C,
                           long long ldc, long long M, int N, int K, const double* col_off, const double* col_scale);
 

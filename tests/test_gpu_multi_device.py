@@ -102,9 +102,11 @@ def test_errors_of_one_context_reach_the_caller(ctx):
         engine.transform_modes(t, data, 2, 8, -2, -1, engine.BMS_TERM_H, tr, ctx=ctx, devices=[0, 0], shard=(0, 4000, 0, 4000))
 
 
-def test_rotations_dealt_over_contexts_are_bit_identical(ctx):
+def test_rotations_dealt_over_contexts_equal_the_one_context_call(ctx):
     """rotations act on every time step independently (scri/rotations.py:346-392; SURVEY 8(e): "contiguous time blocks, no
-    collective"): blocks of rows on several contexts give the bits of the one-context call"""
+    collective"): blocks of rows on several contexts against the one-context call.  Not bit for bit: the resident kernel deals
+    (16-step tile, l group) units to its waves by the launch's geometry, and which group order a row meets moves its last bit
+    (tools/probes/rot_block_probe.py: 5e-16 on O(1) data, also for two serial launches on ONE context) -- so the bar is rounding."""
     from scri_amd import engine, synthetic
 
     t, data, _ = synthetic.workload("cfg3", n_times=30001)
@@ -113,7 +115,11 @@ def test_rotations_dealt_over_contexts_are_bit_identical(ctx):
     R /= np.linalg.norm(R, axis=1)[:, None]
     sp = np.stack([R[:, 0] + 1j * R[:, 3], R[:, 2] + 1j * R[:, 1]], axis=1)
     one = engine.rotate_series(data.copy(), 2, 16, sp, ctx=ctx)
+    bar = 4 * np.finfo(float).eps * np.abs(one).max()
     for devs in ([0, 0], [0, 0, 0, 0, 0]):
-        assert np.array_equal(engine.rotate_series(data.copy(), 2, 16, sp, ctx=ctx, devices=devs), one)
+        got = engine.rotate_series(data.copy(), 2, 16, sp, ctx=ctx, devices=devs)
+        assert np.abs(got - one).max() <= bar, devs
+        assert np.array_equal(got, engine.rotate_series(data.copy(), 2, 16, sp, ctx=ctx, devices=devs))  # deterministic for a given dealing
     q = np.array([1.0, 2, 3, 4]) / np.sqrt(30)
-    assert np.array_equal(engine.rotate_const(data.copy(), 2, 16, q, ctx=ctx, devices=[0, 0, 0]), engine.rotate_const(data.copy(), 2, 16, q, ctx=ctx))
+    ref = engine.rotate_const(data.copy(), 2, 16, q, ctx=ctx)
+    assert np.abs(engine.rotate_const(data.copy(), 2, 16, q, ctx=ctx, devices=[0, 0, 0]) - ref).max() <= bar
