@@ -484,16 +484,37 @@ def transform_modes(
     return res + (first.value,) if shard is not None else res
 
 
-def transform_modes_series(t, data, ell_min, ell_max, spin_weight, conformal_weight, type_term, transformation, aux=(), ctx=None, grid=False):
+def transform_modes_series(t, data, ell_min, ell_max, spin_weight, conformal_weight, type_term, transformation, aux=(), ctx=None, grid=False,
+                           device=False, n_series=None, out_ptr=None):
     """bms_transform_modes_series: data complex [N, n_modes, F] -- F independent series under one transformation, the reference's
     extra trailing data dimensions flattened (scri/waveform_grid.py:299-308, 574-594) -- -> (t_out[N'], out[N', n_out, F]) in ONE
     engine call.  The arrays cross PCIe as they are (the trailing index fastest: no strided copy on the host; the permutation to one
     block of columns per series runs on the device) and the set-up (time axis, spline tables, per-direction tables, window) is shared.
     aux: (data [N, aux_modes, F], ell_min, ell_max, spin, coeff, power) per psi companion.  grid=True: the field on the grid instead
-    (WaveformGrid.from_modes), out[N', n_theta n_phi, F]."""
+    (WaveformGrid.from_modes), out[N', n_theta n_phi, F].
+    device=True: `data` (and each aux data) is a device address of c16[N][n_modes * n_series] in that same layout, `out_ptr` a device
+    buffer of N * n_out * n_series complex; nothing crosses PCIe; returns (t_out, N')."""
     ctx = _ctx(ctx)
     t = np.ascontiguousarray(t, dtype=float)
     n = t.shape[0]
+    if device:
+        inp = bms_wm_input()
+        inp.n_times, inp.t = n, dptr(t)
+        inp.data, inp.ld, inp.mem = int(data), LM_total_size(ell_min, ell_max) * int(n_series), BMS_DEVICE
+        inp.ell_min, inp.ell_max = int(ell_min), int(ell_max)
+        inp.spin_weight, inp.conformal_weight, inp.type_term = int(spin_weight), int(conformal_weight), int(type_term)
+        inp.n_aux = len(aux)
+        for i, a in enumerate(aux):
+            adata, amin, amax, aspin, acoeff, apower = a[:6]
+            inp.aux_data[i], inp.aux_ld[i] = int(adata), LM_total_size(amin, amax) * int(n_series)
+            inp.aux_ell_min[i], inp.aux_ell_max[i], inp.aux_spin[i] = int(amin), int(amax), int(aspin)
+            inp.aux_coeff[i], inp.aux_power[i] = float(acoeff), int(apower)
+        t_out = np.empty(max(n, 1), dtype=float)
+        n_new = c_i64(0)
+        rc = _lib.load().bms_transform_modes_series(ctx.handle, ctypes.byref(inp), int(n_series), ctypes.byref(transformation), dptr(t_out),
+                                                    None if grid else c_vp(int(out_ptr)), c_vp(int(out_ptr)) if grid else None, ctypes.byref(n_new))
+        ctx.check(rc, "bms_transform_modes_series")
+        return t_out[: n_new.value], n_new.value
     data = _lib.as_c16(data)
     if data.ndim != 3 or data.shape[:2] != (n, LM_total_size(ell_min, ell_max)):
         raise ValueError(f"data shape {data.shape} inconsistent with {n} time steps, ell range [{ell_min}, {ell_max}] and one trailing axis")

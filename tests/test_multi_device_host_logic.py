@@ -1,0 +1,90 @@
+"""Host logic of the one-process multi-device path (scri_amd/engine.py: `devices=`), without a GPU: how the time shards of a
+pipelined call are dealt over the contexts, how one context's failure reaches the caller, how SCRI_AMD_DEVICES is read."""
+import numpy as np
+import pytest
+
+
+class _FakeContext:
+    def __init__(self, device):
+        self.device = device
+        self.handle = object()
+
+
+def test_every_shard_is_dealt_exactly_once_in_contiguous_runs():
+    from scri_amd import engine
+
+    for n_ctx in (1, 2, 3, 4, 5, 8):
+        for pieces in (1, 2, 3, 7, 10, 12, 24, 25):
+            ctxs = [_FakeContext(0) for _ in range(n_ctx)]
+            seen = []
+
+            def call(ctx, p0, p1):
+                seen.append((ctxs.index(ctx), p0, p1))
+
+            errors = engine._run_dealt(ctxs, pieces, call)
+            assert errors == [None] * n_ctx
+            seen.sort(key=lambda x: x[1])
+            covered = [p for _, p0, p1 in seen for p in range(p0, p1)]
+            assert covered == list(range(pieces)), (n_ctx, pieces)  # once each, and a context's shards are one run
+            assert [k for k, _, _ in seen] == sorted(k for k, _, _ in seen)  # earlier contexts take earlier times
+            sizes = [p1 - p0 for _, p0, p1 in seen]
+            assert max(sizes) - min(sizes + [pieces // n_ctx]) <= 1
+
+
+def test_shard_counts_keep_three_shards_per_context():
+    from scri_amd import engine
+
+    assert engine.pieces_for([0]) == max(3, engine.PIPELINE_PIECES)
+    assert engine.pieces_for([0, 0, 0, 0]) == 12 and engine.pieces_for(list(range(8))) == 24
+    for n in range(1, 17):
+        p = engine.pieces_for([0] * n)
+        assert p % n == 0 and p // n >= 3 and p >= engine.PIPELINE_PIECES
+
+
+def test_a_failing_context_reaches_the_caller():
+    from scri_amd import engine
+
+    ctxs = [_FakeContext(0) for _ in range(3)]
+
+    def call(ctx, p0, p1):
+        if ctx is ctxs[1]:
+            raise ValueError("device 1: halo too small")
+
+    errors = engine._run_dealt(ctxs, 9, call)
+    assert errors[0] is None and isinstance(errors[1], ValueError) and errors[2] is None
+    with pytest.raises(ValueError, match="halo too small"):
+        engine._raise_dealt(errors)
+    # a series the engine does not shard (graded time steps) falls back to the one-call path instead of raising
+    assert engine._raise_dealt([None, NotImplementedError("not sharded"), ValueError("x")]) == "unsupported"
+    assert engine._raise_dealt([None, None]) is None
+
+
+def test_default_devices_from_the_environment(monkeypatch):
+    from scri_amd import engine
+
+    monkeypatch.delenv("SCRI_AMD_DEVICES", raising=False)
+    assert engine.default_devices() is None
+    monkeypatch.setenv("SCRI_AMD_DEVICES", "0, 2,3")
+    assert engine.default_devices() == [0, 2, 3]
+    monkeypatch.setenv("SCRI_AMD_DEVICES", "all")
+    assert engine.default_devices() == [0] or len(engine.default_devices()) >= 1  # (no GPU here: one entry)
+
+
+def test_row_blocks_of_the_dealt_rotation_cover_the_series():
+    from scri_amd import engine
+
+    for n_rows in (2, 7, 100, 30001):
+        for k in (1, 2, 5):
+            blocks = engine._row_blocks(n_rows, [None] * k)
+            assert blocks[0][0] == 0 and blocks[-1][1] == n_rows and all(a[1] == b[0] for a, b in zip(blocks, blocks[1:]))
+
+
+def test_devices_refuse_shards_and_device_pointers():
+    from scri_amd import engine
+
+    tr = engine.make_transformation(np.zeros(4, dtype=complex), [1, 0, 0, 0], [0, 0, 0], 9, 9, 2)
+    t = np.arange(40.0)
+    with pytest.raises(ValueError, match="devices"):
+        engine.transform_modes(t, np.zeros((40, 5), dtype=complex), 2, 2, -2, -1, engine.BMS_TERM_H, tr, devices=[0, 0], shard=(0, 40, 0, 40))
+    with pytest.raises(ValueError, match="devices"):
+        engine.transform_abd(t, 0, 2, tr, devices=[0, 0], device=True, out_ptr=0)
