@@ -438,3 +438,63 @@ def test_two_rank_library_abd_equals_global(tmp_path):
     assert np.abs(np.concatenate([p["u"] for p in parts]) - ref.u).max() < 1e-13
     got = np.concatenate([p["raw"] for p in parts], axis=1)
     assert got.shape == ref.raw.shape and np.abs(got - ref.raw).max() < 1e-12 * max(1.0, np.abs(ref.raw).max())
+
+
+def _trimmed_kw():
+    from scri_amd import synthetic
+
+    return dict(supertranslation=np.array(synthetic.S9, dtype=complex), frame_rotation=np.array([1.0, 2, 3, 4]) / np.sqrt(30),
+                boost_velocity=np.array([1.0, 2.0, 3.0]) * 1e-3)
+
+
+def _no_output_worker(rank, world, port, n_times, ell_max, tmpdir):
+    import torch.distributed as dist
+
+    from scri_amd import engine, synthetic, sharding
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        t, _, _ = synthetic.workload("cfg3", n_times=n_times)
+        kw = _trimmed_kw()
+        n_theta = 2 * (ell_max + 2) + 1
+        nm = (ell_max + 1) ** 2 - 4
+        tr = engine.make_transformation(kw["supertranslation"], kw["frame_rotation"], kw["boost_velocity"], n_theta, n_theta, ell_max)
+        # four ranks: rank 0's one row lies outside the window of valid outputs (it produces nothing, but rank 1 needs it), rank 2 holds NO rows
+        have = [(0, 1), (1, 420), (420, 420), (420, n_times)]
+        st = sharding.ShardedTransform("modes", t, tr, 2, ell_max, -2, -1, engine.BMS_TERM_H, have=have, compute=_oracle_compute_modes(kw, ell_max))
+        assert st.window[0] >= 1 and st.need[0][0] == st.need[0][1] and st.need[2][0] == st.need[2][1] and st.need[1][0] == 0
+        _, mine, _ = synthetic.workload("cfg3", n_times=n_times, rows=have[rank])
+        t_out, rows, first = st(np.ascontiguousarray(mine[:, :nm]))
+        assert rows.shape == (t_out.size, nm) and t_out.size == st.n_out_rows
+        if rank in (0, 2):
+            assert t_out.size == 0
+        np.savez(os.path.join(tmpdir, f"trim{rank}.npz"), t=t_out, data=rows, first=first, window=np.array(st.window))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(900)
+def test_ranks_without_output_and_without_rows(tmp_path):
+    """the window of valid outputs leaves the first rank (one row) without output; another rank owns no rows at all: both
+    still take part in the exchange (their neighbours may need their rows) and return empty blocks"""
+    import torch.multiprocessing as mp
+
+    from oracle import waveform_grid_ref as grid_ref
+    from oracle.containers import WM, h
+    from scri_amd import synthetic
+
+    n_times, ell_max, world = 600, 4, 4
+    mp.spawn(_no_output_worker, args=(world, _free_port(), n_times, ell_max, str(tmp_path)), nprocs=world, join=True)
+    parts = [np.load(tmp_path / f"trim{r}.npz") for r in range(world)]
+    t, data, _ = synthetic.workload("cfg3", n_times=n_times)
+    nm = (ell_max + 1) ** 2 - 4
+    ref = grid_ref.transform(WM(t=t, data=data[:, :nm], ell_min=2, ell_max=ell_max, dataType=h), **_trimmed_kw())
+    window = parts[0]["window"]
+    assert ref.t.size == window[1] - window[0] and window[0] >= 1
+    t_sh = np.concatenate([p["t"] for p in parts])
+    d_sh = np.concatenate([p["data"] for p in parts])
+    assert np.abs(t_sh - ref.t).max() < 1e-13
+    assert np.abs(d_sh - ref.data).max() < 1e-13 * max(1.0, np.abs(ref.data).max())
+    assert int(parts[1]["first"]) == window[0]
