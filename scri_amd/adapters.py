@@ -84,11 +84,20 @@ def install(scri, ctx=None):
         for k in ("frame_rotation",):
             if k in kwargs:
                 kwargs[k] = _quaternion_components(kwargs[k])
+        # scri_amd's two multi-GPU keywords: the devices of this process, or the process group over whose ranks
+        # the time axis is split (this object then holds the rank's block of rows)
+        devices, group = kwargs.pop("devices", None), kwargs.pop("group", None)
         frame_rotation, boost_velocity, supertranslation, working_ell_max, output_ell_max = _abd_kwargs(self.ell_max, **kwargs)
         n_theta = 2 * working_ell_max + 1
         tr = engine.make_transformation(supertranslation, frame_rotation, boost_velocity, n_theta, n_theta, output_ell_max)
         raw = np.ascontiguousarray(np.asarray(self._raw_data).view(np.ndarray), dtype=np.complex128)
-        u_new, raw_new = engine.transform_abd(np.asarray(self.u, dtype=float), raw, self.ell_max, tr, ctx=ctx)
+        if group is not None:
+            from . import sharding
+
+            u_global, have = sharding.gather_time_axis(np.asarray(self.u, dtype=float), group)
+            u_new, raw_new, _ = sharding.transform_abd_sharded(raw, u_global, self.ell_max, tr, group=group, have=have, ctx=ctx)
+        else:
+            u_new, raw_new = engine.transform_abd(np.asarray(self.u, dtype=float), raw, self.ell_max, tr, ctx=ctx, devices=devices)
         abdprime = type(self)(u_new, output_ell_max)  # transformations.py:417
         abdprime.psi0, abdprime.psi1, abdprime.psi2, abdprime.psi3, abdprime.psi4, abdprime.sigma = raw_new
         return abdprime
