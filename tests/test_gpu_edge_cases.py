@@ -550,6 +550,49 @@ def test_small_boost_free_shapes_take_the_evaluating_product(ctx, monkeypatch, e
     assert np.abs(got.data - ref.data).max() < 1e-13 * max(1.0, np.abs(ref.data).max())
 
 
+@pytest.mark.parametrize("ell_max,expect", [(8, "dense"), (12, "two-pass"), (14, "two-pass"), (15, "fused"), (16, "fused")])
+def test_boost_free_route_follows_the_shape_rules(ctx, route, ell_max, expect):
+    """The three boost-free routes of WaveformModes by shape (engine_modes.hip): the evaluating product up to l <= 8
+    (`small_dense`), separable synthesis + back substitution on the grid up to l_max = 14, and from l_max = 15 on the separable synthesis
+    that evaluates the spline itself (`SYN_EVAL_MIN_ELL`: measured crossover, profiles/r06_b_boost_free_routes_by_ell.txt) -- read off
+    the kernels' timing tags; the options force either side and all routes agree to rounding."""
+    import scri_amd
+    from scri_amd import synthetic
+    from oracle import containers
+
+    n = 900
+    t = np.linspace(-20.0, 30.0, n)
+    data = synthetic.chirp_modes(t, 2, ell_max, 3 + ell_max)
+    kw = dict(supertranslation=np.asarray(synthetic.S9) * 30, frame_rotation=np.array([0.3, -0.5, 0.7, 0.41]) / np.linalg.norm([0.3, -0.5, 0.7, 0.41]))
+
+    def run():
+        w = scri_amd.WaveformModes(t=t, data=data, ell_min=2, ell_max=ell_max, dataType=containers.h, frameType=scri_amd.Inertial,
+                                   r_is_scaled_out=True, m_is_scaled_out=True, ctx=ctx)
+        ctx.enable_timing(True)
+        ctx.get_timing(reset=True)
+        out = w.transform(**kw)
+        tags = {k for k, v in ctx.get_timing(reset=True).items() if v[1]}
+        ctx.enable_timing(False)
+        return out, tags
+
+    def which(tags):
+        if "rotate" not in tags:
+            return "dense"
+        return "two-pass" if "spline_backward" in tags else "fused"
+
+    for k in ("SCRI_AMD_NO_SEPARABLE_SYNTHESIS", "SCRI_AMD_NO_SMALL_DENSE", "SCRI_AMD_NO_GEMM_EVAL", "SCRI_AMD_SYNTHESIS_EVAL", "SCRI_AMD_NO_SYNTHESIS_EVAL"):
+        route(k, None)
+    got, tags = run()
+    assert which(tags) == expect, tags
+    # the other side of the rule, forced through the context's options
+    route("SCRI_AMD_NO_SMALL_DENSE", "1")
+    route("SCRI_AMD_NO_SYNTHESIS_EVAL" if expect == "fused" else "SCRI_AMD_SYNTHESIS_EVAL", "1")
+    other, tags_other = run()
+    assert which(tags_other) == ("two-pass" if expect == "fused" else "fused"), tags_other
+    assert np.array_equal(got.t, other.t)
+    assert np.abs(got.data - other.data).max() < 3e-13 * max(1.0, np.abs(other.data).max())
+
+
 def _fused_case(ell_max, n, mesh, st_scale, seed):
     from scri_amd import synthetic
 
