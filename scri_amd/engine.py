@@ -85,7 +85,7 @@ def rotate_const(data, ell_min, ell_max, quaternion, ctx=None, devices=None):
     (one context and one host thread each; default SCRI_AMD_DEVICES, else the one context)."""
     assert data.dtype == np.complex128 and data.ndim == 2 and data.strides[1] == 16
     q = np.ascontiguousarray(quaternion, dtype=float)
-    devices = devices if devices is not None else default_devices()
+    devices = devices if devices is not None else (default_devices() if data.nbytes >= PIPELINE_MIN_BYTES else None)
 
     def call(cx, r0, r1):
         block = data[r0:r1]
@@ -120,7 +120,7 @@ def rotate_series(data, ell_min, ell_max, spinors, ctx=None, devices=None):
     sp = np.ascontiguousarray(spinors, dtype=np.complex128)
     if sp.shape != (data.shape[0], 2):
         raise ValueError(f"spinors must have shape ({data.shape[0]}, 2), got {sp.shape}")
-    devices = devices if devices is not None else default_devices()
+    devices = devices if devices is not None else (default_devices() if data.nbytes >= PIPELINE_MIN_BYTES else None)
 
     def call(cx, r0, r1):
         block = data[r0:r1]
@@ -396,8 +396,8 @@ def transform_modes(
     context and one host thread per entry, e.g. [0, 1, ..., 7] (default: SCRI_AMD_DEVICES, else the one context `ctx`); every
     device receives its own rows + halo at upload time.  pieces: the number of time shards (default PIPELINE_PIECES on one
     context, pieces_for(devices) on several); the result depends on `pieces` only (to rounding), not on how they are dealt."""
-    if devices is None and not device and shard is None and not grid and not aux:
-        devices = default_devices()
+    if devices is None and not device and shard is None and not grid and not aux and np.asarray(data).nbytes >= PIPELINE_MIN_BYTES:
+        devices = default_devices()  # (the environment's default is for LONG series: a short one is not worth k threads and k set-ups)
     if devices is not None and (device or shard is not None or grid or aux):
         raise ValueError("`devices` deals a whole host-memory series over several GPUs: no shard, no device pointers, no psi companions")
     ctx = _ctx(ctx) if not devices else contexts_for(devices[:1], first=ctx)[0]
@@ -578,7 +578,7 @@ def transform_abd(u, raw, ell_max, transformation, ctx=None, shard=None, device=
     c16[6][out_i1 - out_i0][n_out]); returns (u_out, n_new[, first]).
     devices / pieces (host arrays, no shard): as transform_modes -- the time shards of the pipelined call dealt over one context
     per device of this process."""
-    if devices is None and not device and shard is None:
+    if devices is None and not device and shard is None and np.asarray(raw).nbytes >= PIPELINE_MIN_BYTES:
         devices = default_devices()
     if devices is not None and (device or shard is not None):
         raise ValueError("`devices` deals a whole host-memory series over several GPUs: no shard, no device pointers")

@@ -63,11 +63,22 @@ def test_devices_keyword_of_the_scri_level_calls(ctx, monkeypatch):
     ref = w.transform(**kw)
     got = w.transform(devices=[0, 0], **kw)
     assert np.array_equal(got.t, ref.t) and np.abs(got.data - ref.data).max() < 1e-14 * np.abs(ref.data).max()
+    # the environment's default serves unchanged callers of LONG series (>= 64 MB of input); short ones stay on one context
     monkeypatch.setenv("SCRI_AMD_DEVICES", "0,0,0")
     assert engine.default_devices() == [0, 0, 0]
-    env = w.transform(**kw)  # an unchanged caller
-    assert np.array_equal(env.t, ref.t) and np.abs(env.data - ref.data).max() < 1e-14 * np.abs(ref.data).max()
+    dealt = []
+    real = engine._transform_modes_multi
+    monkeypatch.setattr(engine, "_transform_modes_multi", lambda *a, **k: dealt.append(len(a[5])) or real(*a, **k))
+    env = w.transform(**kw)
+    assert dealt == [] and np.array_equal(env.data, ref.data)
+    t_l, d_l, _ = synthetic.workload("cfg3", n_times=20000)  # 91 MB
+    w_l = scri_amd.WaveformModes(t=t_l, data=d_l, ell_min=2, ell_max=16, dataType=scri_amd.h, frameType=scri_amd.Inertial,
+                                 r_is_scaled_out=True, m_is_scaled_out=True, ctx=ctx)
+    env_l = w_l.transform(**kw)  # an unchanged caller
+    assert dealt == [3]
     monkeypatch.delenv("SCRI_AMD_DEVICES")
+    ref_l = w_l.transform(**kw)
+    assert dealt == [3] and np.array_equal(env_l.t, ref_l.t) and np.abs(env_l.data - ref_l.data).max() < 1e-14 * np.abs(ref_l.data).max()
 
     from tests.test_gpu_sharding import _abd_case
 
