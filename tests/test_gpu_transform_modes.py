@@ -210,14 +210,16 @@ def test_trailing_dimensions_are_one_engine_call(ctx, monkeypatch):
     w4, w1 = wm(four), wm(np.ascontiguousarray(four[:, :, 0]))
     for _ in range(2):
         w4.transform(**kw), w1.transform(**kw)
-    t0 = time.perf_counter()
-    for _ in range(3):
-        w4.transform(**kw)
-    t_four = (time.perf_counter() - t0) / 3
-    t0 = time.perf_counter()
-    for _ in range(3):
-        w1.transform(**kw)
-    t_one = (time.perf_counter() - t0) / 3
+
+    def best_of(w, reps=5):  # (the fastest of a few runs: the comparison is of costs, not of the box's noise)
+        times = []
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            w.transform(**kw)
+            times.append(time.perf_counter() - t0)
+        return min(times)
+
+    t_four, t_one = best_of(w4), best_of(w1)
     assert t_four < 1.3 * 4 * t_one, (t_four, t_one)
 
 
