@@ -206,6 +206,14 @@ int bms_transform_modes_pipelined_part(bms_ctx* ctx, const bms_wm_input* in, con
 int bms_transform_abd_pipelined_part(bms_ctx* ctx, const double* u, const void* raw, int64_t n_times, int ell_max,
                                      const bms_transformation* tr, int pieces, int piece0, int piece1, double* u_out, void* raw_out,
                                      int64_t* n_times_out);
+/* The dealing itself, for bindings that do not want to manage threads: ONE call takes the n_ctx contexts (one per device; created
+ * by the caller with bms_ctx_create, each listed once), deals the `pieces` time shards over them in contiguous runs and runs
+ * bms_transform_*_pipelined_part on one host thread per context.  Host arrays in and out as above.  On failure the status of the first
+ * failing context is returned and bms_last_error(ctxs[0]) names it ("context k (device d): ..."). */
+int bms_transform_modes_multi(bms_ctx* const* ctxs, int n_ctx, const bms_wm_input* in, const bms_transformation* tr, int pieces,
+                              double* t_out, void* data_out, int64_t* n_times_out);
+int bms_transform_abd_multi(bms_ctx* const* ctxs, int n_ctx, const double* u, const void* raw, int64_t n_times, int ell_max,
+                            const bms_transformation* tr, int pieces, double* u_out, void* raw_out, int64_t* n_times_out);
 /* Several series under one transformation: the extra trailing data dimensions of the reference's waveform objects
  * (scri/waveform_grid.py:299-308 `final_dim`, :574-594): every trailing index is an independent series on the same time axis.
  * Arrays are in the REFERENCE'S layout -- the trailing index fastest, as numpy stores data[N, n_modes, F]: in->data is

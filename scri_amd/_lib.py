@@ -119,6 +119,14 @@ SIGNATURES = {
         c_int,
         [c_vp, c_dp, c_vp, c_i64, c_int, ctypes.POINTER(bms_transformation), c_int, c_int, c_int, c_dp, c_vp, ctypes.POINTER(c_i64)],
     ),
+    "bms_transform_modes_multi": (
+        c_int,
+        [ctypes.POINTER(c_vp), c_int, ctypes.POINTER(bms_wm_input), ctypes.POINTER(bms_transformation), c_int, c_dp, c_vp, ctypes.POINTER(c_i64)],
+    ),
+    "bms_transform_abd_multi": (
+        c_int,
+        [ctypes.POINTER(c_vp), c_int, c_dp, c_vp, c_i64, c_int, ctypes.POINTER(bms_transformation), c_int, c_dp, c_vp, ctypes.POINTER(c_i64)],
+    ),
     "bms_rotate_const": (c_int, [c_vp, c_vp, c_int, c_i64, c_i64, c_int, c_int, c_dp]),
     "bms_rotate_series": (c_int, [c_vp, c_vp, c_int, c_i64, c_i64, c_int, c_int, c_vp]),
     "bms_rotate_const_D": (c_int, [c_vp, c_vp, c_int, c_i64, c_i64, c_int, c_int, c_vp]),

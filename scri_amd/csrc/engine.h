@@ -19,6 +19,7 @@
 #include <functional>
 #include <map>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/scri_amd.h"
@@ -301,6 +302,46 @@ inline int with_smaller_chunks(bms_ctx* c, F call) {
   if (rc == BMS_ERR_NOMEM) c->err = first;
   return rc;
 }
+
+// the dealing of the one-process multi-device entry points (bms_transform_modes_multi, bms_transform_abd_multi)
+template <class PartCall>
+inline int run_dealt_over_contexts(bms_ctx* const* ctxs, int n_ctx, int pieces, int64_t* n_times_out, PartCall part) {
+  if (!ctxs || n_ctx < 1) return BMS_ERR_INVALID;
+  for (int k = 0; k < n_ctx; ++k)
+    if (!ctxs[k]) return BMS_ERR_INVALID;
+  for (int k = 0; k < n_ctx; ++k)
+    for (int j = 0; j < k; ++j)
+      if (ctxs[j] == ctxs[k]) return fail(ctxs[0], BMS_ERR_INVALID, "context %d is listed twice: one context serves one host thread at a time", k);
+  if (pieces < 1) pieces = 1;
+  std::vector<int> rc(n_ctx, BMS_OK);
+  std::vector<int64_t> got(n_ctx, -1);
+  auto run = [&](int k) {
+    const int p0 = (int)(((long long)pieces * k) / n_ctx), p1 = (int)(((long long)pieces * (k + 1)) / n_ctx);
+    if (p1 > p0) rc[k] = part(ctxs[k], p0, p1, &got[k]);
+  };
+  std::vector<std::thread> threads;
+  for (int k = 1; k < n_ctx; ++k) threads.emplace_back(run, k);
+  run(0);
+  for (auto& th : threads) th.join();
+  for (int k = 0; k < n_ctx; ++k)
+    if (rc[k] != BMS_OK) {
+      if (k != 0) {
+        const std::string msg = ctxs[k]->err;
+        return fail(ctxs[0], rc[k], "context %d (device %d): %s", k, ctxs[k]->device, msg.c_str());
+      }
+      return rc[k];
+    }
+  int64_t n_new = -1;
+  for (int k = 0; k < n_ctx; ++k) {
+    if (got[k] < 0) continue;  // (a context without a shard of its own)
+    if (n_new >= 0 && got[k] != n_new)
+      return fail(ctxs[0], BMS_ERR_HIP, "the output window has %lld rows on context %d and %lld on another", (long long)got[k], k, (long long)n_new);
+    n_new = got[k];
+  }
+  if (n_times_out) *n_times_out = std::max<int64_t>(n_new, 0);
+  return BMS_OK;
+}
+
 
 // ====================================================================================================== tables of one transformation
 

@@ -465,6 +465,14 @@ extern "C" int bms_transform_abd_pipelined_part(bms_ctx* c, const double* u, con
   return BMS_OK;
 }
 
+// the six fields over several contexts of one process (see bms_transform_modes_multi)
+extern "C" int bms_transform_abd_multi(bms_ctx* const* ctxs, int n_ctx, const double* u, const void* raw, int64_t n, int ell_max,
+                                       const bms_transformation* tr, int pieces, double* u_out, void* raw_out, int64_t* n_times_out) {
+  return run_dealt_over_contexts(ctxs, n_ctx, pieces, n_times_out, [&](bms_ctx* c, int p0, int p1, int64_t* got) {
+    return bms_transform_abd_pipelined_part(c, u, raw, n, ell_max, tr, pieces < 1 ? 1 : pieces, p0, p1, u_out, raw_out, got);
+  });
+}
+
 extern "C" int bms_transform_abd(bms_ctx* c, const double* u, const void* raw, int mem, int64_t n_times, int ell_max,
                                  const bms_transformation* tr, double* u_out, void* raw_out, int64_t* n_times_out) {
   return bms_transform_abd_shard(c, u, raw, mem, n_times, ell_max, tr, nullptr, u_out, raw_out, n_times_out, nullptr);

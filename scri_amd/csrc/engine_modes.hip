@@ -238,6 +238,17 @@ extern "C" int bms_transform_modes_pipelined_part(bms_ctx* c, const bms_wm_input
   return BMS_OK;
 }
 
+// One process, several GPUs, ONE call: the `pieces` time shards of the pipelined plan dealt in contiguous runs over the n_ctx contexts
+// (one per device; several on one device are allowed), one host thread each, every context running bms_transform_modes_pipelined_part
+// on its run.  Every device receives its own rows + halo at upload time: no GPU-to-GPU traffic.  The result depends on `pieces` only.
+// On failure the status of the first failing context is returned and its message is copied to ctxs[0] ("context k (device d): ...").
+extern "C" int bms_transform_modes_multi(bms_ctx* const* ctxs, int n_ctx, const bms_wm_input* in, const bms_transformation* tr, int pieces,
+                                         double* t_out, void* data_out, int64_t* n_times_out) {
+  return run_dealt_over_contexts(ctxs, n_ctx, pieces, n_times_out, [&](bms_ctx* c, int p0, int p1, int64_t* got) {
+    return bms_transform_modes_pipelined_part(c, in, tr, pieces < 1 ? 1 : pieces, p0, p1, t_out, data_out, got);
+  });
+}
+
 // WaveformGrid.from_modes on its own (scri/waveform_grid.py:331-613): the field on the distorted grid at the new time slices,
 // c16[N'][n_theta * n_phi] in grid order (no column plan), without the analysis back to modes
 extern "C" int bms_modes_to_grid(bms_ctx* c, const bms_wm_input* in, const bms_transformation* tr, double* t_out, void* grid_out,

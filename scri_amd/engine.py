@@ -48,31 +48,9 @@ def total_size_D_matrices(ell_min, ell_max):
 # ---------------------------------------------------------------------------------- rotation
 
 
-def _row_blocks(n_rows, ctxs):
-    """contiguous, near-equal blocks of rows, one per context (rotations act on every time step independently: no halo)"""
-    k = len(ctxs)
-    return [((n_rows * i) // k, (n_rows * (i + 1)) // k) for i in range(k)]
-
-
 def _rotate_dealt(data, devices, ctx, call):
     """call(ctx, row0, row1) on one host thread per device: each context uploads, rotates and downloads its own block of rows"""
-    ctxs = contexts_for(devices, first=ctx)
-    blocks = _row_blocks(data.shape[0], ctxs)
-    errors = [None] * len(ctxs)
-
-    def run(i):
-        try:
-            if blocks[i][1] > blocks[i][0]:
-                call(ctxs[i], *blocks[i])
-        except BaseException as e:  # noqa: BLE001 -- re-raised by the caller's thread
-            errors[i] = e
-
-    threads = [threading.Thread(target=run, args=(i,)) for i in range(1, len(ctxs))]
-    for th in threads:
-        th.start()
-    run(0)
-    for th in threads:
-        th.join()
+    errors = _run_dealt(contexts_for(devices, first=ctx), data.shape[0], call)
     for e in errors:
         if e is not None:
             raise e
@@ -223,8 +201,10 @@ def pieces_for(devices):
 
 
 def _run_dealt(ctxs, pieces, call):
-    """call(ctx, piece0, piece1) on one host thread per context (ctypes releases the GIL inside the library; a context is used
-    by one thread at a time: the threading contract of include/scri_amd.h).  Returns the exceptions, per context."""
+    """call(ctx, item0, item1) for contiguous runs of `pieces` items on one host thread per context (ctypes releases the GIL inside
+    the library; a context is used by one thread at a time: the threading contract of include/scri_amd.h).  Returns the exceptions,
+    per context.  The rotations deal their rows with it; the transformations' time shards are dealt inside the library by the
+    same rule (bms_transform_modes_multi / bms_transform_abd_multi)."""
     n = len(ctxs)
     errors = [None] * n
 
@@ -245,19 +225,15 @@ def _run_dealt(ctxs, pieces, call):
     return errors
 
 
-def _raise_dealt(errors):
-    """None if every context finished; "unsupported" if the series is one the engine does not shard; raises anything else"""
-    if any(isinstance(e, NotImplementedError) for e in errors):
-        return "unsupported"
-    for e in errors:
-        if e is not None:
-            raise e
-    return None
+def _context_array(ctxs):
+    arr = (c_vp * len(ctxs))(*[c.handle for c in ctxs])
+    return arr
 
 
 def _transform_modes_multi(t, data, inp, transformation, n_out, ctxs, pieces):
-    """bms_transform_modes_pipelined_part on one context per device: the `pieces` time shards of the output window dealt in
-    contiguous runs over the contexts, slice + halo shipped at upload time (no GPU-to-GPU traffic).  None: not sharded."""
+    """bms_transform_modes_multi: the `pieces` time shards of the output window dealt in contiguous runs over one context per
+    device, one host thread each inside the library, slice + halo shipped at upload time (no GPU-to-GPU traffic).  None: a series
+    the engine does not shard (the one-call path takes it)."""
     if not np.all(np.diff(t) > 0):
         return None
     i_lo, i_hi = output_window(t, transformation, ctx=ctxs[0])
@@ -266,18 +242,15 @@ def _transform_modes_multi(t, data, inp, transformation, n_out, ctxs, pieces):
         return None
     out = _lib.pinned_empty((n_new, n_out), np.complex128)
     t_out = np.empty(n_new, dtype=float)
-    lib = _lib.load()
-
-    def call(ctx, p0, p1):
-        got = c_i64(0)
-        rc = lib.bms_transform_modes_pipelined_part(ctx.handle, ctypes.byref(inp), ctypes.byref(transformation), pieces, p0, p1,
-                                                    dptr(t_out), vptr(out), ctypes.byref(got))
-        ctx.check(rc, "bms_transform_modes_pipelined_part")
-        if got.value != n_new:
-            raise RuntimeError(f"pieces [{p0}, {p1}): the window has {got.value} rows on device {ctx.device}, {n_new} here")
-
-    if _raise_dealt(_run_dealt(ctxs, pieces, call)) == "unsupported":
+    got = c_i64(0)
+    rc = _lib.load().bms_transform_modes_multi(_context_array(ctxs), len(ctxs), ctypes.byref(inp), ctypes.byref(transformation), int(pieces),
+                                               dptr(t_out), vptr(out), ctypes.byref(got))
+    try:
+        ctxs[0].check(rc, "bms_transform_modes_multi")
+    except NotImplementedError:
         return None
+    if got.value != n_new:
+        raise RuntimeError(f"the dealt transform produced a window of {got.value} rows, {n_new} expected")
     return t_out, out
 
 
@@ -619,17 +592,17 @@ def transform_abd(u, raw, ell_max, transformation, ctx=None, shard=None, device=
     n_pieces = int(pieces or (pieces_for(devices) if devices else PIPELINE_PIECES))
     if devices and fs_out >= 8 * n_pieces and np.all(np.diff(u) > 0):
         # one process, several GPUs: the time shards dealt over one context per device, rows + halo shipped at upload time
-        lib = _lib.load()
-
-        def call(cx, p0, p1):
-            got = c_i64(0)
-            rc_ = lib.bms_transform_abd_pipelined_part(cx.handle, dptr(u), vptr(raw), n, int(ell_max), ctypes.byref(transformation), n_pieces,
-                                                       p0, p1, dptr(u_out), vptr(out), ctypes.byref(got))
-            cx.check(rc_, "bms_transform_abd_pipelined_part")
+        ctxs = contexts_for(devices, first=ctx)
+        got = c_i64(0)
+        rc = _lib.load().bms_transform_abd_multi(_context_array(ctxs), len(ctxs), dptr(u), vptr(raw), n, int(ell_max), ctypes.byref(transformation),
+                                                 n_pieces, dptr(u_out), vptr(out), ctypes.byref(got))
+        try:
+            ctxs[0].check(rc, "bms_transform_abd_multi")
+        except NotImplementedError:
+            rc = None  # graded time steps are not sharded: the one-call path below takes them
+        if rc is not None:
             if got.value != out.shape[1]:
-                raise RuntimeError(f"pieces [{p0}, {p1}): the window has {got.value} rows on device {cx.device}, {out.shape[1]} here")
-
-        if _raise_dealt(_run_dealt(contexts_for(devices, first=ctx), n_pieces, call)) is None:
+                raise RuntimeError(f"the dealt ABD transform produced a window of {got.value} rows, {out.shape[1]} expected")
             return u_out, out
     elif (shard is None and (pieces is not None or raw.nbytes >= PIPELINE_MIN_BYTES) and fs_out >= 8 * n_pieces
           and not os.environ.get("SCRI_AMD_NO_PIPELINE")):

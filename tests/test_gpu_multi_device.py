@@ -111,6 +111,33 @@ def test_errors_of_one_context_reach_the_caller(ctx):
         engine.transform_modes(t, data, 2, 8, -2, -1, engine.BMS_TERM_H, tr, ctx=ctx, devices=[0, 99])
     with pytest.raises(ValueError, match="devices"):
         engine.transform_modes(t, data, 2, 8, -2, -1, engine.BMS_TERM_H, tr, ctx=ctx, devices=[0, 0], shard=(0, 4000, 0, 4000))
+    # the C entry itself: a context listed twice is refused (one context serves one host thread at a time), a failure on another
+    # context than the first is reported through the first one's message
+    import ctypes
+
+    second = _lib.Context(0)
+    try:
+        inp = _lib.bms_wm_input()
+        tt = np.ascontiguousarray(t)
+        inp.n_times, inp.t, inp.data, inp.ld, inp.mem = t.size, _lib.dptr(tt), data.ctypes.data, data.shape[1], _lib.BMS_HOST
+        inp.ell_min, inp.ell_max, inp.spin_weight, inp.conformal_weight, inp.type_term = 2, 8, -2, -1, engine.BMS_TERM_H
+        out = np.empty((t.size, 77), dtype=complex)
+        t_out = np.empty(t.size)
+        got = _lib.c_i64(0)
+        lib = _lib.load()
+        twice = (_lib.c_vp * 2)(ctx.handle, ctx.handle)
+        rc = lib.bms_transform_modes_multi(twice, 2, ctypes.byref(inp), ctypes.byref(tr), 6, _lib.dptr(t_out), _lib.vptr(out), ctypes.byref(got))
+        assert rc == _lib.BMS_ERR_INVALID and b"listed twice" in lib.bms_last_error(ctx.handle)
+        pair = (_lib.c_vp * 2)(ctx.handle, second.handle)
+        rc = lib.bms_transform_modes_multi(pair, 2, ctypes.byref(inp), ctypes.byref(tr), 6, _lib.dptr(t_out), _lib.vptr(out), ctypes.byref(got))
+        assert rc == 0 and got.value > 3900
+        ref_t, ref_d = engine.transform_modes(t, data, 2, 8, -2, -1, engine.BMS_TERM_H, tr, ctx=ctx, pieces=6)
+        assert np.array_equal(t_out[: got.value], ref_t) and np.array_equal(out[: got.value], ref_d)
+        second.option("NO_GEMM_EVAL", 1)  # (another route on the second context: same results to rounding, another kernel)
+        rc = lib.bms_transform_modes_multi(pair, 2, ctypes.byref(inp), ctypes.byref(tr), 6, _lib.dptr(t_out), _lib.vptr(out), ctypes.byref(got))
+        assert rc == 0 and np.abs(out[: got.value] - ref_d).max() < 1e-13 * np.abs(ref_d).max()
+    finally:
+        second.close()
 
 
 def test_rotations_dealt_over_contexts_equal_the_one_context_call(ctx):

@@ -52,11 +52,6 @@ def test_a_failing_context_reaches_the_caller():
 
     errors = engine._run_dealt(ctxs, 9, call)
     assert errors[0] is None and isinstance(errors[1], ValueError) and errors[2] is None
-    with pytest.raises(ValueError, match="halo too small"):
-        engine._raise_dealt(errors)
-    # a series the engine does not shard (graded time steps) falls back to the one-call path instead of raising
-    assert engine._raise_dealt([None, NotImplementedError("not sharded"), ValueError("x")]) == "unsupported"
-    assert engine._raise_dealt([None, None]) is None
 
 
 def test_default_devices_from_the_environment(monkeypatch):
@@ -70,13 +65,27 @@ def test_default_devices_from_the_environment(monkeypatch):
     assert engine.default_devices() == [0] or len(engine.default_devices()) >= 1  # (no GPU here: one entry)
 
 
-def test_row_blocks_of_the_dealt_rotation_cover_the_series():
+def test_dealt_rotation_blocks_cover_the_series_and_raise_the_first_error():
     from scri_amd import engine
 
-    for n_rows in (2, 7, 100, 30001):
-        for k in (1, 2, 5):
-            blocks = engine._row_blocks(n_rows, [None] * k)
-            assert blocks[0][0] == 0 and blocks[-1][1] == n_rows and all(a[1] == b[0] for a, b in zip(blocks, blocks[1:]))
+    data = np.zeros((30001, 3), dtype=complex)
+    seen = []
+    fakes = [_FakeContext(0) for _ in range(5)]
+    orig = engine.contexts_for
+    engine.contexts_for = lambda devices, first=None: fakes
+    try:
+        engine._rotate_dealt(data, [0] * 5, None, lambda cx, r0, r1: seen.append((r0, r1)))
+        seen.sort()
+        assert seen[0][0] == 0 and seen[-1][1] == 30001 and all(a[1] == b[0] for a, b in zip(seen, seen[1:]))
+
+        def failing(cx, r0, r1):
+            if cx is fakes[3]:
+                raise ValueError("row stride smaller than the modes")
+
+        with pytest.raises(ValueError, match="row stride"):
+            engine._rotate_dealt(data, [0] * 5, None, failing)
+    finally:
+        engine.contexts_for = orig
 
 
 def test_devices_refuse_shards_and_device_pointers():
