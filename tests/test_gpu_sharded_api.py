@@ -105,7 +105,7 @@ rows = torch.from_numpy(np.ascontiguousarray(data[:, :nm])).cuda()
 for _ in range(3):
     t_out, out, first = st(rows)
 torch.cuda.synchronize()
-assert first == 1 and np.array_equal(t_out, ref.t) and np.array_equal(out.cpu().numpy(), ref.data)
+assert first == st.window[0] and np.array_equal(t_out, ref.t) and np.abs(out.cpu().numpy() - ref.data).max() < 1e-14 * np.abs(ref.data).max()
 u = np.arange(1500) * 0.1
 abd = scri_amd.AsymptoticBondiData(u, 3)
 rng = np.random.default_rng(2)
