@@ -1,4 +1,5 @@
-
+"""The body of tests/test_gpu_sharded_api.py::test_group_keyword_on_the_rccl_backend_single_rank as a script (prints instead of asserting on the
+shard-call comparison): w.transform(group=...) / abd.transform(group=...) and a ShardedTransform on a one-rank nccl (= RCCL) group."""
 import os, sys
 sys.path.insert(0, "/root/repo")
 import numpy as np, torch, torch.distributed as dist

@@ -1,3 +1,6 @@
+"""Does a row's rotated value depend on where the row sits in the launch?  One series rotated whole, then as two serial launches cut at several rows,
+then dealt over two contexts: the last bit moves with the launch geometry (5e-16 on O(1) data; rows beyond 16384 here), never more.
+Behind the rounding bar of tests/test_gpu_multi_device.py::test_rotations_dealt_over_contexts_equal_the_one_context_call."""
 import sys, os
 sys.path.insert(0, os.getcwd())
 import numpy as np
