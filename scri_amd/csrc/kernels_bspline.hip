@@ -382,7 +382,7 @@ hipError_t launch_bspline_solve_modes(hipStream_t stream, const double* A, long 
 // The Horner mixing of the six AsymptoticBondiData fields (kernels_swsh.hip, abd_mix_kernel; transformations.py:340-385)
 // has time-dependent coefficients, so the elimination cannot move onto the modes -- but the two grid passes can be one:
 // read the six synthesised fields once, mix in registers, run the six recurrences, write the six eliminated fields.
-// NF = 6: psi0 .. psi4 and sigma; NF = 5: sigma stays out (it mixes with nothing and takes the evaluating product: engine.hip)
+// NF = 6: psi0 .. psi4 and sigma; NF = 5: sigma stays out (it mixes with nothing and takes the evaluating product: engine_abd.hip)
 template <int NF>
 __global__ __launch_bounds__(64) void abd_mix_forward_kernel(AbdGrids Yg, AbdGrids Rg, long long ld, int n_cols, long long g0,
                                                              long long n_rows, const BsplineForward* __restrict__ table, int tile,

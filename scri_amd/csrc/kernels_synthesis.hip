@@ -16,7 +16,7 @@
 //                m = 1..16 (K) by k = 1..16 (one 16-column tile) plus a four-block 4x4x4 product for k = 0, 17, 18, 19,
 //                twiddles in registers; the epilogue adds F_0, subtracts the
 //                per-pixel offset times the row's eliminated-constant value (the inhomogeneous term of h and sigma,
-//                engine.hip) and stores both halves of the ring, 16 bytes per lane, 256-byte runs.
+//                engine_modes.hip) and stores both halves of the ring, 16 bytes per lane, 256-byte runs.
 //   F is double buffered in LDS: one barrier per trip.
 // HBM traffic = the algorithmic minimum: 16 (n_modes + 1) bytes read, 16 n_pix written per step.
 #include <hip/hip_runtime.h>
@@ -36,7 +36,7 @@ constexpr int SYN_XCOLS = 3;  // ring columns beyond k = 16: the side product ha
 constexpr int SYN_META_FLUSH = 1 << 16, SYN_META_VALID = 1 << 17;
 
 // SCALED: every result is multiplied by scale[pixel] (2 doubles per pixel, equal: the conformal factor's power behind a boost along
-// the grid's axis, engine.hip::separable_rotor_grid), kept in LDS next to the offsets
+// the grid's axis, engine_tables.hip::separable_rotor_grid), kept in LDS next to the offsets
 template <int NT, int LEN, bool SCALED>
 __global__ __launch_bounds__(640, 1) void synthesis_split_kernel(const double* __restrict__ A, long long lda, long long n_rows,
                                                                  SynGeom g, const double* __restrict__ Tsyn,

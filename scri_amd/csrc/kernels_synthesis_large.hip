@@ -195,7 +195,7 @@ __global__ __launch_bounds__(64) void phi_synthesis_folded_kernel(const double* 
       }
     }
     // results: rows fk + 4 r = (Re, Im) of ring fk, (Re, Im) of ring fk + 4; column k = 16 n + fi
-    const double cv = off ? cst[t * ldc] : 0.0;  // the row's eliminated-constant value (real: engine.hip)
+    const double cv = off ? cst[t * ldc] : 0.0;  // the row's eliminated-constant value (real: engine_abd.hip)
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
       const int ring = fk + 4 * h;
@@ -228,7 +228,7 @@ __global__ __launch_bounds__(64) void phi_synthesis_folded_kernel(const double* 
     double* y = Y + t * ldy + 2LL * (8 * rt) * n_phi;
     const int n_el = rings * n_phi;
     if (scale) {
-      const double* sc = scale + 2LL * (8 * rt) * n_phi;  // (stored twice per pixel: engine.hip's col_scale)
+      const double* sc = scale + 2LL * (8 * rt) * n_phi;  // (stored twice per pixel: engine_tables.hip's col_scale)
       for (int e = lane; e < n_el; e += 64) {
         const double2 g = Gt[e];
         const double w = sc[2 * e];

@@ -236,12 +236,13 @@ def _transform_modes_multi(t, data, inp, transformation, n_out, ctxs, pieces):
     the engine does not shard (the one-call path takes it)."""
     if not np.all(np.diff(t) > 0):
         return None
-    i_lo, i_hi = output_window(t, transformation, ctx=ctxs[0])
-    n_new = i_hi - i_lo
-    if n_new < 8 * pieces:
+    n = t.shape[0]
+    if n < 8 * pieces + 16:
         return None
-    out = _lib.pinned_empty((n_new, n_out), np.complex128)
-    t_out = np.empty(n_new, dtype=float)
+    # (sized for the whole series: the window of valid outputs is at most that, and asking for it first would cost a round trip to
+    # the device before anything is dealt; the result is the leading rows, a view)
+    out = _lib.pinned_empty((n, n_out), np.complex128)
+    t_out = np.empty(n, dtype=float)
     got = c_i64(0)
     rc = _lib.load().bms_transform_modes_multi(_context_array(ctxs), len(ctxs), ctypes.byref(inp), ctypes.byref(transformation), int(pieces),
                                                dptr(t_out), vptr(out), ctypes.byref(got))
@@ -249,9 +250,7 @@ def _transform_modes_multi(t, data, inp, transformation, n_out, ctxs, pieces):
         ctxs[0].check(rc, "bms_transform_modes_multi")
     except NotImplementedError:
         return None
-    if got.value != n_new:
-        raise RuntimeError(f"the dealt transform produced a window of {got.value} rows, {n_new} expected")
-    return t_out, out
+    return t_out[: got.value], out[: got.value]
 
 
 def _transform_modes_pipelined(t, data, inp, transformation, n_out, ctx, pieces=None):
@@ -266,12 +265,12 @@ def _transform_modes_pipelined(t, data, inp, transformation, n_out, ctx, pieces=
         pieces = int(pieces or PIPELINE_PIECES)
         if not np.all(np.diff(t) > 0):
             return None  # the one-call path raises the ValueError the reference's callers expect
-        i_lo, i_hi = output_window(t, transformation, ctx=ctx)
-        n_new = i_hi - i_lo
-        if n_new < 8 * pieces:
+        n = t.shape[0]
+        if n < 8 * pieces + 16:
             return None
-        out = _lib.pinned_empty((n_new, n_out), np.complex128)
-        t_out = np.empty(n_new, dtype=float)
+        # (sized for the whole series instead of asking the device for the window first: one round trip less per call)
+        out = _lib.pinned_empty((n, n_out), np.complex128)
+        t_out = np.empty(n, dtype=float)
         got = c_i64(0)
         rc = _lib.load().bms_transform_modes_pipelined(ctx.handle, ctypes.byref(inp), ctypes.byref(transformation), pieces,
                                                        dptr(t_out), vptr(out), ctypes.byref(got))

@@ -480,7 +480,7 @@ def test_separable_synthesis_reads_nothing_past_the_modes(ctx, monkeypatch, n, r
 
 @pytest.mark.parametrize("defect", ["swap", "repeat", "nan"])
 def test_defect_in_the_middle_of_the_time_axis_is_reported_by_the_late_walk(ctx, defect, monkeypatch, route):
-    """The host walks the time axis while it waits for the per-direction tables (engine.hip, `walk_later`): by then the time axis is in
+    """The host walks the time axis while it waits for the per-direction tables (engine_modes.hip, `walk_later`): by then the time axis is in
     HBM and the spline solve has been queued on it.  A defect found by that walk fails the call exactly as the walk-first order does,
     and the context is usable afterwards."""
     from scri_amd import engine
@@ -518,7 +518,7 @@ def test_defect_in_the_middle_of_the_time_axis_is_reported_by_the_late_walk(ctx,
 @pytest.mark.parametrize("ell_max,n,expect_dense", [(4, 300, True), (8, 900, True), (8, 9, True), (10, 400, False)])
 def test_small_boost_free_shapes_take_the_evaluating_product(ctx, monkeypatch, ell_max, n, expect_dense, route):
     """Since the dense product evaluates the spline itself it beats separable synthesis + back substitution on the grid for small shapes
-    (engine.hip, `small_dense`: n_modes x grid <= 40 000, i.e. up to l <= 8 on the default grid, and at least 8 rows): the route is chosen by
+    (engine_modes.hip, `small_dense`: n_modes x grid <= 40 000, i.e. up to l <= 8 on the default grid, and at least 8 rows): the route is chosen by
     that rule, and both routes agree to rounding."""
     import scri_amd
     from scri_amd import synthetic
