@@ -46,6 +46,12 @@ quaternion, spherical_functions, spinsfast) and writes
                             lengths beyond one 360-word block), index_is_monotonic.  Integer / bit work: every byte is the
                             reference's own (no arithmetic stand-in is involved).
 
+  g18_ref_modes_time_series.npz  scri/modes_time_series.py:72-202 on a NON-uniform time axis (N = 70; a spin -1, l <= 5 and a spin 2, l <= 4 series):
+                            interpolate at every derivative order -2 .. 3, dot / ddot / int / iint, eth_GHP / ethbar_GHP, grid_multiply with
+                            its defaults and with explicit working / output l_max -- the reference's bookkeeping (which l_max the grid and
+                            the result get, the product's spin weight, where the antiderivative starts); scipy's CubicSpline underneath is
+                            live third party, salm2map / map2salm and the ladder factors are the stand-ins'.
+
 Only the .npz files travel; tests/test_golden.py checks the oracle (CPU) and the HIP path (GPU) against them.
 """
 import os
@@ -414,10 +420,41 @@ def g17():
     np.savez_compressed(os.path.join(HERE, "g17_ref_bit_transforms.npz"), source="scri/utilities.py:194-406, scri/SpEC/file_io/__init__.py:50-70 (the reference's files, identity njit)", **out)
 
 
+def g18():
+    from scri.modes_time_series import ModesTimeSeries
+    import spherical_functions as sf
+
+    rng = np.random.default_rng(181)
+    n = 70
+    u = np.sort(rng.uniform(-4.0, 11.0, n)) + np.arange(n) * 1e-3
+    a = synthetic.chirp_modes(u, 0, 5, 182) * (1 + 0.03 * u[:, None])
+    a[:, :1] = 0  # spin -1: nothing below l = 1
+    b = synthetic.chirp_modes(u, 0, 4, 183)
+    b[:, :4] = 0  # spin 2
+    A = ModesTimeSeries(a, time=u, spin_weight=-1, ell_min=0, ell_max=5, multiplication_truncator=max)
+    B = ModesTimeSeries(b, time=u, spin_weight=2, ell_min=0, ell_max=4, multiplication_truncator=max)
+    new_time = np.concatenate([np.linspace(u[0], u[-1], 41), u[::9]])
+    out = dict(u=u, a=a, b=b, new_time=new_time)
+    arr = lambda m: np.asarray(m).view(np.ndarray)
+    for order in (-2, -1, 0, 1, 2, 3):
+        out[f"a_interp_{order}"] = arr(A.interpolate(new_time, derivative_order=order))
+    for name in ("dot", "ddot", "int", "iint", "eth_GHP", "ethbar_GHP"):
+        r = getattr(A, name)
+        out[f"a_{name}"] = arr(r)
+        out[f"a_{name}_meta"] = np.array([r.spin_weight, r.ell_min, r.ell_max])
+    for tag, kw in (("default", {}), ("wide", dict(working_ell_max=12, output_ell_max=7)), ("narrow", dict(working_ell_max=9, output_ell_max=2))):
+        P = A.grid_multiply(B, **kw)
+        out[f"ab_{tag}"] = arr(P)
+        out[f"ab_{tag}_meta"] = np.array([P.spin_weight, P.ell_min, P.ell_max])
+    P = B.grid_multiply(A)  # output l_max follows the FIRST factor
+    out["ba_default"], out["ba_default_meta"] = arr(P), np.array([P.spin_weight, P.ell_min, P.ell_max])
+    np.savez_compressed(os.path.join(HERE, "g18_ref_modes_time_series.npz"), source="scri/modes_time_series.py:72-202 (the reference's file, stand-ins underneath)", **out)
+
+
 if __name__ == "__main__":
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
-        every = (g10, g8, g9, g11, g12, g13, g14, g15, g16, g17)
+        every = (g10, g8, g9, g11, g12, g13, g14, g15, g16, g17, g18)
         only = [f for f in every if "--" + f.__name__ in sys.argv]
         for f in only or every:
             f()

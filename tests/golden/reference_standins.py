@@ -539,6 +539,10 @@ def make_sf_module():
     m.theta_phi = theta_phi
     m.Modes = Modes
     m.Grid = Grid
+    swsh_modes = types.ModuleType("spherical_functions.SWSH_modes")  # (scri/modes_time_series.py:190 names the class through its module)
+    swsh_modes.Modes = Modes
+    m.SWSH_modes = swsh_modes
+    sys.modules["spherical_functions.SWSH_modes"] = swsh_modes
     return m
 
 

@@ -175,3 +175,62 @@ def test_g17_gpu_bit_transforms_vs_reference(ctx):
         assert np.array_equal(utilities.multishuffle(widths, forward=False, ctx=ctx)(out.copy()), data), (bits, widths)
     for tag, d, expect in fletcher:
         assert int(utilities.fletcher32(d, ctx=ctx)) == expect, tag
+
+
+# ------------------------------------------------------------------------------------------------- g18: ModesTimeSeries
+G18 = os.path.join(HERE, "golden", "g18_ref_modes_time_series.npz")
+_G18_ORDER_BAR = {3: 2e-9, 2: 2e-11, 1: 5e-12}  # a spline's derivatives amplify rounding by 1/h^k (h ~ 0.05 here)
+
+
+def _check_g18(A, B, g, arr):
+    """A (spin -1, l <= 5), B (spin 2, l <= 4): series objects with the reference's interface; arr(series) -> numpy weights"""
+    for order in (-2, -1, 0, 1, 2, 3):
+        ref = g[f"a_interp_{order}"]
+        got = arr(A.interpolate(g["new_time"], derivative_order=order))
+        assert got.shape == ref.shape and np.abs(got - ref).max() < _G18_ORDER_BAR.get(order, 1e-12) * max(1.0, np.abs(ref).max()), order
+    for name, order in (("dot", 1), ("ddot", 2), ("int", -1), ("iint", -2), ("eth_GHP", 0), ("ethbar_GHP", 0)):
+        r = getattr(A, name)
+        ref = g[f"a_{name}"]
+        assert [r.spin_weight, r.ell_min, r.ell_max] == list(g[f"a_{name}_meta"]), name
+        assert np.abs(arr(r) - ref).max() < _G18_ORDER_BAR.get(order, 1e-12) * max(1.0, np.abs(ref).max()), name
+    for tag, kw in (("default", {}), ("wide", dict(working_ell_max=12, output_ell_max=7)), ("narrow", dict(working_ell_max=9, output_ell_max=2))):
+        P = A.grid_multiply(B, **kw)
+        assert [P.spin_weight, P.ell_min, P.ell_max] == list(g[f"ab_{tag}_meta"]), tag
+        assert np.abs(arr(P) - g[f"ab_{tag}"]).max() < 1e-12 * max(1.0, np.abs(g[f"ab_{tag}"]).max()), tag
+    P = B.grid_multiply(A)
+    assert [P.spin_weight, P.ell_min, P.ell_max] == list(g["ba_default_meta"])  # (the output l_max follows the FIRST factor)
+    assert np.abs(arr(P) - g["ba_default"]).max() < 1e-12 * max(1.0, np.abs(g["ba_default"]).max())
+
+
+def test_g18_oracle_series_calculus_vs_reference():
+    """oracle/modes_time_series_ref.py against scri/modes_time_series.py:72-202 run by the reference's own file"""
+    from oracle import modes_time_series_ref as mref
+    from oracle import wigner
+
+    g = np.load(G18)
+    u, a, b = g["u"], g["a"], g["b"]
+    for order in (-2, -1, 0, 1, 2, 3):
+        ref = g[f"a_interp_{order}"]
+        assert np.abs(mref.interpolate(u, a, g["new_time"], order) - ref).max() < 1e-12 * max(1.0, np.abs(ref).max()), order
+    for name, order in (("dot", 1), ("ddot", 2), ("int", -1), ("iint", -2)):
+        assert np.abs(mref.interpolate(u, a, u, order) - g[f"a_{name}"]).max() < 1e-12 * max(1.0, np.abs(g[f"a_{name}"]).max()), name
+    assert np.abs(wigner.eth_GHP(a, -1, 0) - g["a_eth_GHP"]).max() < 1e-13 and np.abs(wigner.ethbar_GHP(a, -1, 0) - g["a_ethbar_GHP"]).max() < 1e-13
+    for tag, w, o in (("default", None, None), ("wide", 12, 7), ("narrow", 9, 2)):
+        got = mref.grid_multiply(a, -1, 5, b, 2, 4, working_ell_max=w, output_ell_max=o)
+        assert got.shape == g[f"ab_{tag}"].shape and np.abs(got - g[f"ab_{tag}"]).max() < 1e-13 * max(1.0, np.abs(g[f"ab_{tag}"]).max()), tag
+    assert np.abs(mref.grid_multiply(b, 2, 4, a, -1, 5) - g["ba_default"]).max() < 1e-13 * max(1.0, np.abs(g["ba_default"]).max())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("device", [False, True])
+def test_g18_gpu_series_calculus_vs_reference(ctx, device):
+    """scri_amd.ModesTimeSeries (host-resident) and DeviceModesTimeSeries (weights in HBM) against the reference's values"""
+    from scri_amd import ModesTimeSeries
+    from scri_amd.device_series import DeviceModesTimeSeries
+
+    g = np.load(G18)
+    A = ModesTimeSeries(g["a"], g["u"], spin_weight=-1, ell_min=0, ell_max=5, multiplication_truncator=max)
+    B = ModesTimeSeries(g["b"], g["u"], spin_weight=2, ell_min=0, ell_max=4, multiplication_truncator=max)
+    if device:
+        A, B = DeviceModesTimeSeries.from_host(A, ctx=ctx), DeviceModesTimeSeries.from_host(B, ctx=ctx)
+    _check_g18(A, B, g, lambda m: np.asarray(m.ndarray))
