@@ -52,6 +52,13 @@ quaternion, spherical_functions, spinsfast) and writes
                             the result get, the product's spin weight, where the antiderivative starts); scipy's CubicSpline underneath is
                             live third party, salm2map / map2salm and the ladder factors are the stand-ins'.
 
+  g19_ref_superrest_helpers.npz  the building blocks of scri/asymptotic_bondi_data/map_to_superrest_frame.py:76-507,666-684 on generic smooth data
+                            (l <= 4, N = 60): the operator pair, rest mass and conformal factor on the grid, the Moreschi supermomentum in a
+                            supertranslated frame, the first-order supertranslation, three iterations of
+                            supertranslation_to_map_to_superrest_frame (which transforms with the reference's own abd.transform), the
+                            centre-of-mass fit, rotation_from_spin_charge with and without a fixed plane, time_translation.  The
+                            statements are the reference's; grids, spline and quaternion arithmetic underneath are stand-ins / scipy.
+
 Only the .npz files travel; tests/test_golden.py checks the oracle (CPU) and the HIP path (GPU) against them.
 """
 import os
@@ -451,10 +458,54 @@ def g18():
     np.savez_compressed(os.path.join(HERE, "g18_ref_modes_time_series.npz"), source="scri/modes_time_series.py:72-202 (the reference's file, stand-ins underneath)", **out)
 
 
+def g19():
+    import scri.asymptotic_bondi_data.map_to_superrest_frame as ms
+
+    L, n = 4, 60
+    u = np.linspace(-30.0, 40.0, n)
+    raw = np.zeros((6, n, (L + 1) ** 2), dtype=complex)
+    for f, s_ in enumerate(synthetic.ABD_SPINS):
+        raw[f] = 0.05 * synthetic.chirp_modes(u, 0, L, 190 + f) * (1 + 0.01 * u[:, None])
+        raw[f, :, : s_ * s_] = 0
+    raw[2, :, 0] -= 1.0 * np.sqrt(4 * np.pi)  # a unit mass monopole: timelike four-momentum
+    abd = scri.AsymptoticBondiData(u, L)
+    abd.psi0, abd.psi1, abd.psi2, abd.psi3, abd.psi4, abd.sigma = raw
+    arr = lambda m: np.asarray(m).view(np.ndarray)
+    out = dict(u=u, raw=raw, ell_max=L)
+    out["D"], out["Dinv"] = ms.𝔇(np.array(raw[2]), L), ms.𝔇inverse(np.array(raw[2]), L)
+    PsiM = abd.supermomentum("Moreschi")
+    out["PsiM"] = arr(PsiM)
+    M_Grid, K_Grid = ms.compute_bondi_rest_mass_and_conformal_factor(np.array(PsiM), L)
+    out["M_Grid"], out["K_Grid"] = np.asarray(M_Grid), np.asarray(K_Grid)
+    # a smooth real supertranslation on the (2 L + 1)^2 grid, a few time units in size (the supermomentum is evaluated at u = alpha)
+    import spinsfast
+
+    alpha = spinsfast.salm2map(_real_supertranslation(3, 191, 1.5), 0, 3, 2 * L + 1, 2 * L + 1).real
+    out["alpha"] = alpha
+    moreschi = ms.compute_Moreschi_supermomentum(PsiM, alpha, L)
+    out["PsiM_at_alpha"] = arr(moreschi)
+    M1, K1 = ms.compute_bondi_rest_mass_and_conformal_factor(np.array(moreschi), L)
+    out["M_at_alpha"], out["K_at_alpha"] = np.asarray(M1), np.asarray(K1)
+    out["alpha_perturbation"] = np.asarray(ms.compute_alpha_perturbation(moreschi, M1, K1, L))
+    B, rel_errs = ms.supertranslation_to_map_to_superrest_frame(abd, N_itr_max=3, ell_max=L)
+    out["superrest_supertranslation"], out["superrest_rel_errs"] = np.array(B.supertranslation), np.array(rel_errs[1:])
+    G = abd.bondi_CoM_charge() / abd.bondi_four_momentum()[:, 0, None]
+    Bc = ms.transformation_from_CoM_charge(G, u)
+    out["com_G"], out["com_supertranslation"], out["com_boost"], out["com_order"] = G, np.array(Bc.supertranslation), np.array(Bc.boost_velocity), np.array("|".join(Bc.order))
+    chi = np.array([[0.1 + 0.001 * k, -0.2, 0.6] for k in range(n)])
+    for tag, kw in (("free", {}), ("xz", dict(fix_xz_plane=True)), ("yz", dict(fix_yz_plane=True))):
+        out[f"spin_rotation_{tag}"] = np.array(ms.rotation_from_spin_charge(chi, u, **kw).frame_rotation.components)
+    out["chi"] = chi
+    tt = ms.time_translation(abd, 3.0)
+    out["time_translation_u"], out["time_translation_raw"] = np.array(tt.t), np.array([arr(getattr(tt, f)) for f in ("psi0", "psi1", "psi2", "psi3", "psi4", "sigma")])
+    np.savez_compressed(os.path.join(HERE, "g19_ref_superrest_helpers.npz"),
+                        source="scri/asymptotic_bondi_data/map_to_superrest_frame.py:76-507,666-684 (the reference's file, stand-ins underneath)", **out)
+
+
 if __name__ == "__main__":
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
-        every = (g10, g8, g9, g11, g12, g13, g14, g15, g16, g17, g18)
+        every = (g10, g8, g9, g11, g12, g13, g14, g15, g16, g17, g18, g19)
         only = [f for f in every if "--" + f.__name__ in sys.argv]
         for f in only or every:
             f()

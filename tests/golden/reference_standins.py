@@ -149,6 +149,12 @@ class quaternion:
     def __sub__(self, o):
         return quaternion(*(self.components - (o.components if isinstance(o, quaternion) else np.array([float(o), 0, 0, 0]))))
 
+    def __radd__(self, o):  # scalar + q: the scalar is the real quaternion (numpy-quaternion's ufunc loops for mixed operands)
+        return quaternion(*(np.array([float(o), 0, 0, 0]) + self.components))
+
+    def __rsub__(self, o):
+        return quaternion(*(np.array([float(o), 0, 0, 0]) - self.components))
+
     def __neg__(self):
         return quaternion(*(-self.components))
 
@@ -276,7 +282,15 @@ def make_quaternion_module():
     m.from_spherical_coords = from_spherical_coords
     m.as_spherical_coords = as_spherical_coords
     m.rotate_vectors = rotate_vectors
+    m.from_rotation_vector = from_rotation_vector
+    m.as_vector_part = lambda q: np.array(q.vec) if isinstance(q, quaternion) else _q_float(q)[..., 1:]
     return m
+
+
+def from_rotation_vector(rot):
+    """quaternion.from_rotation_vector: exp(v / 2) for the rotation vector v (axis x angle)"""
+    rot = np.asarray(rot, dtype=float)
+    return quaternion(0.0, *(rot / 2.0)).exp()
 
 
 # ----------------------------------------------------------------------------------------------- spherical_functions
@@ -445,6 +459,15 @@ class Modes(np.ndarray):
     def norm(self):
         return np.linalg.norm(self.view(np.ndarray), axis=-1)
 
+    def grid(self, n_theta=None, n_phi=None, **kwargs):
+        """sf.Modes.grid: the function on the equiangular grid spinsfast.salm2map gives, (2 ell_max + 1)^2 points unless told otherwise,
+        as an sf.Grid carrying the spin weight"""
+        n_theta = 2 * self.ell_max + 1 if n_theta is None else int(n_theta)
+        n_phi = n_theta if n_phi is None else int(n_phi)
+        if self.ell_min != 0:
+            raise NotImplementedError
+        return Grid(spinsfast_ref.salm2map(self.view(np.ndarray), self.s, self.ell_max, n_theta, n_phi), spin_weight=self.s)
+
     def multiply(self, other, truncator=None):
         """sf.Modes.multiply: the exact product of two band-limited functions (Wigner-3j sums there; here both are put on a grid
         that resolves the product, multiplied and analysed -- the same modes to rounding), truncated at truncator((l_a, l_b))."""
@@ -539,6 +562,10 @@ def make_sf_module():
     m.theta_phi = theta_phi
     m.Modes = Modes
     m.Grid = Grid
+    swsh_grids = types.ModuleType("spherical_functions.SWSH_grids")  # (map_to_superrest_frame.py:172 names Grid through its module)
+    swsh_grids.Grid = Grid
+    m.SWSH_grids = swsh_grids
+    sys.modules["spherical_functions.SWSH_grids"] = swsh_grids
     swsh_modes = types.ModuleType("spherical_functions.SWSH_modes")  # (scri/modes_time_series.py:190 names the class through its module)
     swsh_modes.Modes = Modes
     m.SWSH_modes = swsh_modes

@@ -234,3 +234,60 @@ def test_g18_gpu_series_calculus_vs_reference(ctx, device):
     if device:
         A, B = DeviceModesTimeSeries.from_host(A, ctx=ctx), DeviceModesTimeSeries.from_host(B, ctx=ctx)
     _check_g18(A, B, g, lambda m: np.asarray(m.ndarray))
+
+
+# ------------------------------------------------------------------------------------------------- g19: superrest building blocks
+G19 = os.path.join(HERE, "golden", "g19_ref_superrest_helpers.npz")
+
+
+def test_g19_host_superrest_helpers_vs_reference():
+    """the pieces of scri_amd/map_to_superrest_frame.py that are pure host arithmetic (no grid): the operator pair, the centre-of-mass
+    fit, rotation_from_spin_charge -- against scri/asymptotic_bondi_data/map_to_superrest_frame.py:76-105, 322-366, 468-507 run by the
+    reference's own file"""
+    from scri_amd import map_to_superrest_frame as m
+
+    g = np.load(G19)
+    L = int(g["ell_max"])
+    psi2 = g["raw"][2]
+    assert np.abs(m.D_operator(psi2, L) - g["D"]).max() < 1e-13 * np.abs(g["D"]).max()
+    assert np.abs(m.D_inverse(psi2, L) - g["Dinv"]).max() < 1e-13 * np.abs(g["Dinv"]).max()
+    assert m.𝔇 is m.D_operator and m.𝔇inverse is m.D_inverse
+    B = m.transformation_from_CoM_charge(g["com_G"], g["u"])
+    assert "|".join(B.order) == str(g["com_order"])
+    assert np.abs(B.boost_velocity - g["com_boost"]).max() < 1e-13 * np.abs(g["com_boost"]).max()
+    assert np.abs(B.supertranslation[:4] - g["com_supertranslation"][:4]).max() < 1e-13 * np.abs(g["com_supertranslation"]).max()
+    assert not np.any(g["com_supertranslation"][4:]) and not np.any(B.supertranslation[4:])
+    for tag, kw in (("free", {}), ("xz", dict(fix_xz_plane=True)), ("yz", dict(fix_yz_plane=True))):
+        q = m.rotation_from_spin_charge(g["chi"], g["u"], **kw).frame_rotation.components
+        assert np.abs(q - g[f"spin_rotation_{tag}"]).max() < 1e-14, tag
+
+
+@pytest.mark.gpu
+def test_g19_gpu_superrest_helpers_vs_reference(ctx):
+    """the grid pieces on the engine: rest mass and conformal factor, the supermomentum in a supertranslated frame, the first-order
+    supertranslation, three iterations of the supertranslation solve (every iteration a GPU abd.transform), time_translation"""
+    import scri_amd
+    from scri_amd import map_to_superrest_frame as m
+
+    g = np.load(G19)
+    L = int(g["ell_max"])
+    abd = scri_amd.AsymptoticBondiData(g["u"], L, ctx=ctx)
+    abd._raw_data[:] = g["raw"]
+    PsiM = abd.supermomentum("Moreschi")
+    assert np.abs(np.asarray(PsiM.ndarray) - g["PsiM"]).max() < 1e-12 * np.abs(g["PsiM"]).max()
+    M_Grid, K_Grid = m.compute_bondi_rest_mass_and_conformal_factor(PsiM.ndarray, L, ctx)
+    assert np.abs(M_Grid - g["M_Grid"]).max() < 1e-12 and np.abs(K_Grid - g["K_Grid"]).max() < 1e-12
+    at_alpha = m.compute_Moreschi_supermomentum(PsiM, g["alpha"], L, ctx)
+    assert np.abs(at_alpha - g["PsiM_at_alpha"]).max() < 1e-12 * np.abs(g["PsiM_at_alpha"]).max()
+    M1, K1 = m.compute_bondi_rest_mass_and_conformal_factor(at_alpha, L, ctx)
+    assert abs(M1 - float(g["M_at_alpha"])) < 1e-12 and np.abs(K1 - g["K_at_alpha"]).max() < 1e-12
+    da = m.compute_alpha_perturbation(at_alpha, M1, K1, L, ctx)
+    assert np.abs(da - g["alpha_perturbation"]).max() < 1e-12 * max(1.0, np.abs(g["alpha_perturbation"]).max())
+    B, rel_errs = m.supertranslation_to_map_to_superrest_frame(abd, N_itr_max=3, ell_max=L)
+    ref_st = g["superrest_supertranslation"]
+    assert not np.any(ref_st[(L + 1) ** 2 :])  # (the reference pads to its default l_max = 12)
+    assert np.abs(B.supertranslation - ref_st[: (L + 1) ** 2]).max() < 1e-11 * np.abs(ref_st).max()
+    assert np.allclose(rel_errs[1:], g["superrest_rel_errs"], rtol=1e-8, atol=1e-14)
+    tt = m.time_translation(abd, 3.0)
+    assert np.abs(tt.t - g["time_translation_u"]).max() < 1e-13
+    assert np.abs(tt._raw_data - g["time_translation_raw"]).max() < 1e-12 * max(1.0, np.abs(g["time_translation_raw"]).max())
