@@ -59,6 +59,13 @@ quaternion, spherical_functions, spinsfast) and writes
                             centre-of-mass fit, rotation_from_spin_charge with and without a fixed plane, time_translation.  The
                             statements are the reference's; grids, spline and quaternion arithmetic underneath are stand-ins / scipy.
 
+  g20_ref_map_to_superrest_frame.npz  the frame-fixing loop itself, scri/asymptotic_bondi_data/map_to_superrest_frame.py:369-465, 529-663, 719-1035 on
+                            the g19 data: com_transformation_to_map_to_superrest_frame and rotation_to_map_to_superrest_frame (two
+                            iterations each), rel_err_for_abd_in_superrest, and map_to_superrest_frame at t_0 = 2 with a padding of 25 and
+                            two passes of (supertranslation, rotation, CoM) -- every transformation inside by the reference's own
+                            abd.transform, every composition / reordering by its own BMSTransformation; quaternion.calculus'
+                            indefinite_integral is restated (scipy's degree-3 InterpolatedUnivariateSpline antiderivative).
+
 Only the .npz files travel; tests/test_golden.py checks the oracle (CPU) and the HIP path (GPU) against them.
 """
 import os
@@ -502,10 +509,50 @@ def g19():
                         source="scri/asymptotic_bondi_data/map_to_superrest_frame.py:76-507,666-684 (the reference's file, stand-ins underneath)", **out)
 
 
+def _g19_abd():
+    L, n = 4, 60
+    u = np.linspace(-30.0, 40.0, n)
+    raw = np.zeros((6, n, (L + 1) ** 2), dtype=complex)
+    for f, s_ in enumerate(synthetic.ABD_SPINS):
+        raw[f] = 0.05 * synthetic.chirp_modes(u, 0, L, 190 + f) * (1 + 0.01 * u[:, None])
+        raw[f, :, : s_ * s_] = 0
+    raw[2, :, 0] -= 1.0 * np.sqrt(4 * np.pi)
+    abd = scri.AsymptoticBondiData(u, L)
+    abd.psi0, abd.psi1, abd.psi2, abd.psi3, abd.psi4, abd.sigma = raw
+    return u, raw, L, abd
+
+
+def g20():
+    import scri.asymptotic_bondi_data.map_to_superrest_frame as ms
+
+    u, raw, L, abd = _g19_abd()
+    arr = lambda m: np.asarray(m).view(np.ndarray)
+    fields = lambda a: np.array([arr(getattr(a, f)) for f in ("psi0", "psi1", "psi2", "psi3", "psi4", "sigma")])
+
+    def parts(B):
+        return np.array(B.supertranslation), np.array(B.frame_rotation.components, dtype=float), np.array(B.boost_velocity, dtype=float), np.array("|".join(B.order))
+
+    out = dict(u=u, raw=raw, ell_max=L)
+    B, errs = ms.com_transformation_to_map_to_superrest_frame(abd, N_itr_max=2)
+    out["com_S"], out["com_q"], out["com_v"], out["com_order"] = parts(B)
+    out["com_rel_errs"] = np.array(errs[1:], dtype=float)
+    B, errs = ms.rotation_to_map_to_superrest_frame(abd, N_itr_max=2)
+    out["rot_S"], out["rot_q"], out["rot_v"], out["rot_order"] = parts(B)
+    out["rot_rel_errs"] = np.array(errs[1:], dtype=float)
+    out["rel_err_in_superrest"] = np.array(ms.rel_err_for_abd_in_superrest(abd, None, None), dtype=float)
+    iters = {"superrest": 2, "CoM_transformation": 2, "rotation": 2, "supertranslation": 2}
+    abd_prime, B, best = ms.map_to_superrest_frame(abd, t_0=2.0, padding_time=25, N_itr_maxes=iters, ell_max=L)
+    out["whole_S"], out["whole_q"], out["whole_v"], out["whole_order"] = parts(B)
+    out["whole_best_rel_err"] = np.array(best, dtype=float)
+    out["whole_u"], out["whole_raw"] = np.array(abd_prime.t), fields(abd_prime)
+    np.savez_compressed(os.path.join(HERE, "g20_ref_map_to_superrest_frame.npz"),
+                        source="scri/asymptotic_bondi_data/map_to_superrest_frame.py:369-1035 (the reference's file, stand-ins underneath)", **out)
+
+
 if __name__ == "__main__":
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
-        every = (g10, g8, g9, g11, g12, g13, g14, g15, g16, g17, g18, g19)
+        every = (g10, g8, g9, g11, g12, g13, g14, g15, g16, g17, g18, g19, g20)
         only = [f for f in every if "--" + f.__name__ in sys.argv]
         for f in only or every:
             f()

@@ -283,8 +283,32 @@ def make_quaternion_module():
     m.as_spherical_coords = as_spherical_coords
     m.rotate_vectors = rotate_vectors
     m.from_rotation_vector = from_rotation_vector
+    calculus = sys.modules.get("quaternion.calculus") or _PermissiveModule("quaternion.calculus")  # numpy-quaternion's calculus.py: FITPACK cubic splines through scipy
+    calculus.__path__ = []
+    calculus.indefinite_integral = calculus.spline_indefinite_integral = _spline_indefinite_integral
+    m.calculus = calculus
+    sys.modules["quaternion.calculus"] = calculus
     m.as_vector_part = lambda q: np.array(q.vec) if isinstance(q, quaternion) else _q_float(q)[..., 1:]
     return m
+
+
+def _spline_indefinite_integral(f, t, t_out=None, axis=0):
+    """quaternion.calculus.spline_indefinite_integral: the antiderivative (zero at t[0]) of the degree-3 InterpolatedUnivariateSpline
+    through f(t), evaluated at t_out (default t), along `axis`"""
+    from scipy.interpolate import InterpolatedUnivariateSpline
+
+    f = np.asarray(f)
+    t = np.asarray(t, dtype=float)
+    t_out = t if t_out is None else np.asarray(t_out, dtype=float)
+    fm = np.moveaxis(f, axis, 0)
+    flat = fm.reshape(fm.shape[0], -1)
+
+    def one(col):
+        return InterpolatedUnivariateSpline(t, col, k=3).antiderivative()(t_out)
+
+    cols = [one(flat[:, i].real) + (1j * one(flat[:, i].imag) if np.iscomplexobj(flat) else 0) for i in range(flat.shape[1])]
+    out = np.stack(cols, axis=1).reshape((t_out.size,) + fm.shape[1:])
+    return np.moveaxis(out, 0, axis)
 
 
 def from_rotation_vector(rot):
