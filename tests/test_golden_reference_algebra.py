@@ -337,12 +337,9 @@ def _g20_diffs(ctx):
 def test_g20_gpu_map_to_superrest_frame_vs_reference(ctx):
     """scri_amd's frame-fixing loop (every transformation on the GPU, the window device-resident) against the reference's own
     map_to_superrest_frame.py run on the same data: the CoM and rotation iterations, the error measures, and the whole loop at
-    t_0 = 2 -- transformation found, error triple, transformed data.  The reference composes its BMSTransformations at its default
-    l_max = 12 whatever the data's, this implementation at the data's l_max = 4: a boosted supertranslation is not band limited, so
-    the two agree to (boost) x (what l <= 4 cannot hold), not to rounding -- the bars below are that, the logic is pinned far
-    below any sign or ordering error (which would show at order one)."""
+    t_0 = 2 -- transformation found, error triple, transformed data.  Measured on the GPU: supertranslation 1.2e-12, rotor 3e-16,
+    boost 3e-11 (relative; it is a least-squares fit of a 1e-4 velocity), error triples 1e-12, transformed fields 2e-13.  The bar
+    leaves room for the iterations' amplification of rounding on other boxes; a sign or ordering error would show at order one."""
     d = _g20_diffs(ctx)
-    print(d)
     for k, v in d.items():
-        bar = {"com_S_beyond": 1.0, "rot_S_beyond": 1.0, "whole_S_beyond": 1.0}.get(k, 1e-6)
-        assert v <= bar, (k, v, d)
+        assert v <= 1e-9, (k, v, d)
