@@ -545,6 +545,15 @@ def g20():
     out["whole_S"], out["whole_q"], out["whole_v"], out["whole_order"] = parts(B)
     out["whole_best_rel_err"] = np.array(best, dtype=float)
     out["whole_u"], out["whole_raw"] = np.array(abd_prime.t), fields(abd_prime)
+    # the same loop towards a TARGET Moreschi supermomentum (map_to_superrest_frame.py:268-276, 293-305, 848-859): that of the same data
+    # supertranslated a little, handed over as the reference's callers do (a WaveformModes of the supermomentum)
+    target_abd = abd.transform(supertranslation=_real_supertranslation(2, 201, 0.4))
+    target = ms.MT_to_WM(target_abd.supermomentum("Moreschi"), dataType=scri.psi2)
+    out["target_t"], out["target_modes"] = np.array(target.t), np.array(target.data)
+    abd_prime, B, best = ms.map_to_superrest_frame(abd, t_0=2.0, target_PsiM_input=target, padding_time=20, N_itr_maxes=iters, ell_max=L)
+    out["target_S"], out["target_q"], out["target_v"], out["target_order"] = parts(B)
+    out["target_best_rel_err"] = np.array(best, dtype=float)
+    out["target_u"], out["target_raw"] = np.array(abd_prime.t), fields(abd_prime)
     np.savez_compressed(os.path.join(HERE, "g20_ref_map_to_superrest_frame.npz"),
                         source="scri/asymptotic_bondi_data/map_to_superrest_frame.py:369-1035 (the reference's file, stand-ins underneath)", **out)
 

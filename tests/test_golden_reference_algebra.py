@@ -330,6 +330,14 @@ def _g20_diffs(ctx):
     d["whole_u"] = np.abs(abd_prime.t - g["whole_u"]).max() if abd_prime.t.shape == g["whole_u"].shape else np.inf
     raw = np.asarray(abd_prime._raw_data)
     d["whole_raw"] = np.abs(raw - g["whole_raw"]).max() / np.abs(g["whole_raw"]).max() if raw.shape == g["whole_raw"].shape else np.inf
+    # towards a target supermomentum
+    target = scri_amd.ModesTimeSeries(g["target_modes"], g["target_t"], spin_weight=0, ell_min=0, ell_max=L, multiplication_truncator=max)
+    abd_prime, B, best = abd.map_to_superrest_frame(t_0=2.0, target_PsiM_input=target, padding_time=20, N_itr_maxes=iters, ell_max=L)
+    parts("target", B)
+    d["target_best_rel_err"] = np.abs(np.array(best) / g["target_best_rel_err"] - 1).max()
+    raw = np.asarray(abd_prime._raw_data)
+    d["target_u"] = np.abs(abd_prime.t - g["target_u"]).max() if abd_prime.t.shape == g["target_u"].shape else np.inf
+    d["target_raw"] = np.abs(raw - g["target_raw"]).max() / np.abs(g["target_raw"]).max() if raw.shape == g["target_raw"].shape else np.inf
     return d
 
 
