@@ -66,6 +66,11 @@ quaternion, spherical_functions, spinsfast) and writes
                             abd.transform, every composition / reordering by its own BMSTransformation; quaternion.calculus'
                             indefinite_integral is restated (scipy's degree-3 InterpolatedUnivariateSpline antiderivative).
 
+  g21_ref_map_to_abd_frame.npz  scri/asymptotic_bondi_data/map_to_abd_frame.py:21-290 on the g19 data against a BMS-transformed copy of itself:
+                            rel_err_between_abds, and map_to_abd_frame without the time / phase alignment (that step is sxs' align2d,
+                            absent here): the target's and the object's own superrest loops, the composition
+                            (transformation2^-1 * transformation1 * BMS) and the final transform, two passes.
+
 Only the .npz files travel; tests/test_golden.py checks the oracle (CPU) and the HIP path (GPU) against them.
 """
 import os
@@ -558,10 +563,30 @@ def g20():
                         source="scri/asymptotic_bondi_data/map_to_superrest_frame.py:369-1035 (the reference's file, stand-ins underneath)", **out)
 
 
+def g21():
+    import scri.asymptotic_bondi_data.map_to_abd_frame as ma
+
+    u, raw, L, abd = _g19_abd()
+    arr = lambda m: np.asarray(m).view(np.ndarray)
+    fields = lambda a: np.array([arr(getattr(a, f)) for f in ("psi0", "psi1", "psi2", "psi3", "psi4", "sigma")])
+    kw = dict(supertranslation=_real_supertranslation(2, 211, 0.3), frame_rotation=np.array([0.99, 0.05, -0.08, 0.1]) / np.linalg.norm([0.99, 0.05, -0.08, 0.1]),
+              boost_velocity=np.array([1e-4, -2e-4, 1.5e-4]))
+    target = abd.transform(**kw)
+    out = dict(u=u, raw=raw, ell_max=L, target_u=np.array(target.t), target_raw=fields(target), **{"kw_" + k: v for k, v in kw.items()})
+    out["rel_err_between"] = np.array(ma.rel_err_between_abds(abd, target, -10.0, 10.0))
+    iters = {"abd": 2, "superrest": 1, "CoM_transformation": 2, "rotation": 2, "supertranslation": 2}
+    abd_prime, B, rel_err = abd.map_to_abd_frame(target, t_0=2.0, padding_time=18, N_itr_maxes=iters, ell_max=L, fix_time_phase_freedom=False)
+    out["S"], out["q"], out["v"] = np.array(B.supertranslation), np.array(B.frame_rotation.components, dtype=float), np.array(B.boost_velocity, dtype=float)
+    out["order"], out["rel_err"] = np.array("|".join(B.order)), np.array(rel_err, dtype=float)
+    out["prime_u"], out["prime_raw"] = np.array(abd_prime.t), fields(abd_prime)
+    np.savez_compressed(os.path.join(HERE, "g21_ref_map_to_abd_frame.npz"),
+                        source="scri/asymptotic_bondi_data/map_to_abd_frame.py:21-290 (the reference's file, stand-ins underneath)", **out)
+
+
 if __name__ == "__main__":
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
-        every = (g10, g8, g9, g11, g12, g13, g14, g15, g16, g17, g18, g19, g20)
+        every = (g10, g8, g9, g11, g12, g13, g14, g15, g16, g17, g18, g19, g20, g21)
         only = [f for f in every if "--" + f.__name__ in sys.argv]
         for f in only or every:
             f()
