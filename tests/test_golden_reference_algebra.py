@@ -386,6 +386,5 @@ def test_g21_gpu_map_to_abd_frame_vs_reference(ctx):
         "u": np.abs(abd_prime.t - g["prime_u"]).max() if abd_prime.t.shape == g["prime_u"].shape else np.inf,
         "raw": np.abs(abd_prime._raw_data - g["prime_raw"]).max() / np.abs(g["prime_raw"]).max() if abd_prime._raw_data.shape == g["prime_raw"].shape else np.inf,
     }
-    print(d)
-    for k, v in d.items():
+    for k, v in d.items():  # (measured on the GPU: transformation 4e-11 .. 2e-10, fields 2e-12)
         assert v <= 1e-8, (k, v, d)
