@@ -27,7 +27,8 @@ from .mode_algebra import (
 def _parse_translations(kwargs, impose_reality):
     """Supertranslation / translation arguments, identical in the two flavours except that the
     WaveformModes flavour *checks* reality (waveform_grid.py:46-58) while the ABD flavour *imposes* it
-    (asymptotic_bondi_data/transformations.py:36-44)."""
+    (asymptotic_bondi_data/transformations.py:36-44) -- and that two of the AsymptoticBondiData flavour's messages are worded
+    differently (`impose_reality` marks the flavour; tests/golden/g22 holds both sets word for word)."""
     supertranslation = np.zeros((4,), dtype=complex)
     ell_max_supertranslation = 1
     if "supertranslation" in kwargs:
@@ -42,6 +43,14 @@ def _parse_translations(kwargs, impose_reality):
                 supertranslation, (0, 4 - supertranslation.size), "constant", constant_values=(0.0,)
             )
         ell_max_supertranslation = int(np.sqrt(len(supertranslation))) - 1
+        if (ell_max_supertranslation + 1) ** 2 != len(supertranslation) and impose_reality:
+            # (transformations.py:29-35: a plain string -- the length is not filled in -- and the source's indentation in it)
+            pad = "\n" + " " * 11
+            raise ValueError(
+                "Input supertranslation parameter must contain modes from ell=0 up to some ell_max, including" + pad
+                + "all relevant m modes in standard order (see `spherical_functions` documentation for details)." + pad
+                + "Thus, it must be an array with length given by a perfect square; its length is {len(supertranslation)}"
+            )
         if (ell_max_supertranslation + 1) ** 2 != len(supertranslation):
             raise ValueError(
                 "\nInput supertranslation parameter must contain modes from ell=0 up to some ell_max, "
@@ -88,6 +97,8 @@ def _parse_translations(kwargs, impose_reality):
         supertranslation[1:4] = vector_as_ell_1_modes(-spacetime_translation[1:4])
     if "time_translation" in kwargs:
         t_trans = kwargs.pop("time_translation")
+        if not isinstance(t_trans, float) and impose_reality:  # (transformations.py:71)
+            raise TypeError("Input argument `time_translation` should be a single float.  " f"Got {t_trans}")
         if not isinstance(t_trans, float):
             raise TypeError("\nInput argument `time_translation` should be a single float.\n" "Got {}.".format(t_trans))
         spacetime_translation[0] = t_trans
@@ -97,6 +108,10 @@ def _parse_translations(kwargs, impose_reality):
 
 def _parse_lorentz(kwargs, single=False):
     fr = kwargs.pop("frame_rotation", [1, 0, 0, 0])
+    if not quaternions.is_quaternion_object(fr) and np.ndim(fr) == 1 and np.size(fr) in (1, 3):
+        # np.quaternion(*components), as the reference builds it (waveform_grid.py:112): one number is the scalar part, three are the
+        # vector part of a pure quaternion
+        fr = [float(np.asarray(fr)[0]), 0.0, 0.0, 0.0] if np.size(fr) == 1 else [0.0, *np.asarray(fr, dtype=float)]
     frame_rotation = np.array(quaternions.as_float_array(fr), dtype=float).reshape(-1)[:4]
     norm = math.sqrt(float(np.sum(frame_rotation**2)))
     if norm < 3e-16:
@@ -332,7 +347,9 @@ class WaveformGrid:
         from .waveform_modes import WaveformModes
 
         if not isinstance(w_modes, WaveformModes):
-            raise TypeError("Expected WaveformModes object in argument 1; " "got `{}` instead.".format(type(w_modes).__name__))
+            raise TypeError(  # (from_modes' own wording, scri/waveform_grid.py:417-421; `transform` has another, :626-629)
+                "\nInput waveform object must be an instance of `WaveformModes`; " "this is of type `{}`".format(type(w_modes).__name__)
+            )
         original_kwargs = kwargs.copy()
         supertranslation, frame_rotation, boost_velocity, n_theta, n_phi, type_term, aux = _prepare(w_modes, kwargs)
         tr = engine.make_transformation(supertranslation, frame_rotation, boost_velocity, n_theta, n_phi, w_modes.ell_max)

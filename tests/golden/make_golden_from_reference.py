@@ -71,7 +71,12 @@ quaternion, spherical_functions, spinsfast) and writes
                             absent here): the target's and the object's own superrest loops, the composition
                             (transformation2^-1 * transformation1 * BMS) and the final transform, two passes.
 
-Only the .npz files travel; tests/test_golden.py checks the oracle (CPU) and the HIP path (GPU) against them.
+  g22_ref_error_behaviour.json  what the reference raises or warns, word for word: scri/waveform_grid.py:20-190 and
+                            scri/asymptotic_bondi_data/transformations.py:8-97 on 27 keyword sets (wrong shapes and types, precedence of the
+                            translations, grids too small or small, rotors and velocities out of range, unknown keywords), and the
+                            transform's own checks (argument type, missing / mismatched psi companions).
+
+Only the .npz and .json files travel; tests/test_golden.py checks the oracle (CPU) and the HIP path (GPU) against them.
 """
 import os
 import sys
@@ -583,10 +588,96 @@ def g21():
                         source="scri/asymptotic_bondi_data/map_to_abd_frame.py:21-290 (the reference's file, stand-ins underneath)", **out)
 
 
+def g22():
+    """error and warning behaviour: (callable, kwargs) -> exception type + text, or the warnings' texts, as the reference produces them"""
+    import json
+    import scri.waveform_grid as wg
+    import scri.asymptotic_bondi_data.transformations as tr_mod
+
+    st9 = (np.array([1, 2 + 4j, 3, -2 + 4j, 7 - 5j, -3 - 2j, 4, 3 - 2j, 7 + 5j]) * 1e-3)
+    real9 = synthetic.real_supertranslation(st9)
+
+    def enc(v):
+        if isinstance(v, np.ndarray):
+            if np.iscomplexobj(v):
+                return {"__complex__": [[float(z.real), float(z.imag)] for z in v.ravel()], "shape": list(v.shape)}
+            return {"__array__": v.tolist()}
+        if isinstance(v, (list, tuple)):
+            return [enc(x) for x in v]
+        if isinstance(v, (np.floating, np.integer)):
+            return v.item()
+        return v
+
+    kw_cases = [
+        dict(supertranslation=np.zeros(7, dtype=complex)),
+        dict(supertranslation=np.array([0, 1.0, 0, 0.5], dtype=complex)),
+        dict(supertranslation=st9),
+        dict(supertranslation=real9),
+        dict(time_translation=1),
+        dict(time_translation=1.5),
+        dict(time_translation=[1.0, 2.0]),
+        dict(space_translation=[1.0, 2.0]),
+        dict(space_translation=np.array([0.1, 0.2, -0.3])),
+        dict(spacetime_translation=[1.0, 2.0, 3.0]),
+        dict(spacetime_translation=np.array([0.5, 0.1, 0.2, 0.3]), time_translation=-1.0),
+        dict(supertranslation=real9, space_translation=np.array([0.1, 0.2, -0.3]), time_translation=2.0),
+        dict(n_theta=5),
+        dict(n_phi=5),
+        dict(space_translation=np.array([1.0, 0, 0]), n_theta=17),
+        dict(space_translation=np.array([1.0, 0, 0]), n_phi=17),
+        dict(supertranslation=real9, n_theta=18, n_phi=19),
+        dict(frame_rotation=[0, 0, 0, 0]),
+        dict(frame_rotation=[1.0, 2.0, 3.0]),
+        dict(frame_rotation=[1, 2, 3, 4]),
+        dict(boost_velocity=[1.0, 0.0, 0.0]),
+        dict(boost_velocity=[0.1, 0.2]),
+        dict(boost_velocity=[0.6, 0.6, 0.6]),
+        dict(boost_velocity=np.array([0.1, 0.0, -0.2]), frame_rotation=np.array([1.0, 2, 3, 4]), space_translation=np.array([1.0, 0.0, 0.0])),
+        dict(working_ell_max=3),
+        dict(working_ell_max=20, output_ell_max=5),
+        dict(unknown_keyword=3),
+    ]
+
+    def run(fn, *a, **kw):
+        with warnings.catch_warnings(record=True) as ws:
+            warnings.simplefilter("always")
+            try:
+                res = fn(*a, **kw)
+            except Exception as e:  # noqa: BLE001
+                return {"raises": type(e).__name__, "text": str(e), "warnings": [str(w.message) for w in ws]}
+        return {"raises": None, "warnings": [str(w.message) for w in ws], "n_returned": len(res) if isinstance(res, tuple) else None}
+
+    cases = []
+    for kw in kw_cases:
+        if not any(k in kw for k in ("working_ell_max", "output_ell_max")):
+            cases.append({"fn": "wm_kwargs", "ell_max": 8, "kwargs": {k: enc(v) for k, v in kw.items()},
+                          "outcome": run(wg.process_transformation_kwargs, 8, **{k: (v.copy() if isinstance(v, np.ndarray) else v) for k, v in kw.items()})})
+        if not any(k in kw for k in ("n_theta", "n_phi")):
+            cases.append({"fn": "abd_kwargs", "ell_max": 8, "kwargs": {k: enc(v) for k, v in kw.items()},
+                          "outcome": run(tr_mod._process_transformation_kwargs, 8, **{k: (v.copy() if isinstance(v, np.ndarray) else v) for k, v in kw.items()})})
+    # the transform itself: wrong argument type, missing psi companions, unused kwargs
+    t = np.linspace(0.0, 10.0, 12)
+    w_psi2 = _wm(t, synthetic.chirp_modes(t, 0, 3, 1), 0, 3, scri.psi2)
+    w_psi3 = _wm(t, synthetic.chirp_modes(t, 1, 3, 2), 1, 3, scri.psi3)
+    w_psi4_short = _wm(t[:10], synthetic.chirp_modes(t[:10], 2, 3, 3), 2, 3, scri.psi4)
+    cases.append({"fn": "from_modes_type", "outcome": run(scri.WaveformGrid.from_modes, 3)})
+    cases.append({"fn": "transform_type", "outcome": run(scri.WaveformGrid.transform, "not a waveform")})
+    cases.append({"fn": "psi2_without_companions", "outcome": run(w_psi2.transform, space_translation=np.array([0.1, 0, 0]))})
+    cases.append({"fn": "psi2_with_one_companion", "outcome": run(w_psi2.transform, space_translation=np.array([0.1, 0, 0]), psi3_modes=w_psi3)})
+    cases.append({"fn": "psi3_with_short_companion", "outcome": run(w_psi3.transform, space_translation=np.array([0.1, 0, 0]), psi4_modes=w_psi4_short)})
+    w_corot = scri.WaveformModes(t=t, data=synthetic.chirp_modes(t, 2, 3, 4), ell_min=2, ell_max=3, frameType=scri.Corotating, dataType=scri.h,
+                                 r_is_scaled_out=True, m_is_scaled_out=True)
+    cases.append({"fn": "non_inertial_frame", "outcome": run(w_corot.transform, space_translation=np.array([0.1, 0, 0]))})
+    cases.append({"fn": "psi3_with_wrong_type_companion", "outcome": run(w_psi3.transform, space_translation=np.array([0.1, 0, 0]), psi4_modes=w_psi3)})
+    with open(os.path.join(HERE, "g22_ref_error_behaviour.json"), "w") as f:
+        json.dump({"source": "scri/waveform_grid.py:20-190,417-426,529-532,610-630; scri/asymptotic_bondi_data/transformations.py:8-97 (the reference's files)",
+                   "cases": cases}, f, indent=1)
+
+
 if __name__ == "__main__":
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
-        every = (g10, g8, g9, g11, g12, g13, g14, g15, g16, g17, g18, g19, g20, g21)
+        every = (g10, g8, g9, g11, g12, g13, g14, g15, g16, g17, g18, g19, g20, g21, g22)
         only = [f for f in every if "--" + f.__name__ in sys.argv]
         for f in only or every:
             f()
