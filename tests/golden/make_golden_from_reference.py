@@ -668,6 +668,13 @@ def g22():
     w_corot = scri.WaveformModes(t=t, data=synthetic.chirp_modes(t, 2, 3, 4), ell_min=2, ell_max=3, frameType=scri.Corotating, dataType=scri.h,
                                  r_is_scaled_out=True, m_is_scaled_out=True)
     cases.append({"fn": "non_inertial_frame", "outcome": run(w_corot.transform, space_translation=np.array([0.1, 0, 0]))})
+    # rotate_decomposition_basis' own checks (scri/rotations.py:301-310)
+    import quaternion as qmod
+
+    w_h = _wm(t, synthetic.chirp_modes(t, 2, 3, 5), 2, 3, scri.h)
+    five = qmod.as_quat_array(synthetic.rotor_series(t[:5], 3))
+    cases.append({"fn": "rotate_wrong_length", "outcome": run(w_h.rotate_decomposition_basis, five)})
+    cases.append({"fn": "rotate_two_dimensional", "outcome": run(w_h.rotate_decomposition_basis, np.array([list(five), list(five)]))})
     cases.append({"fn": "psi3_with_wrong_type_companion", "outcome": run(w_psi3.transform, space_translation=np.array([0.1, 0, 0]), psi4_modes=w_psi3)})
     with open(os.path.join(HERE, "g22_ref_error_behaviour.json"), "w") as f:
         json.dump({"source": "scri/waveform_grid.py:20-190,417-426,529-532,610-630; scri/asymptotic_bondi_data/transformations.py:8-97 (the reference's files)",

@@ -464,6 +464,18 @@ def test_g22_error_and_warning_texts_vs_reference():
             w_corot = scri_amd.WaveformModes(t=t, data=synthetic.chirp_modes(t, 2, 3, 4), ell_min=2, ell_max=3, dataType=scri_amd.h,
                                              frameType=scri_amd.Corotating, r_is_scaled_out=True, m_is_scaled_out=True)
             got = _outcome(w_corot.transform, **shift)
+        elif c["fn"] == "rotate_wrong_length":
+            w_h = wm(synthetic.chirp_modes(t, 2, 3, 5), 2, scri_amd.h)
+            got = _outcome(w_h.rotate_decomposition_basis, synthetic.rotor_series(t[:5], 3))
+        elif c["fn"] == "rotate_two_dimensional":
+            # the reference means a ValueError here and raises an IndexError from its own message's format string
+            # (scri/rotations.py:305: "{1}".format(one argument)); the intended exception is what this implementation raises
+            assert ref["raises"] == "IndexError"
+            w_h = wm(synthetic.chirp_modes(t, 2, 3, 5), 2, scri_amd.h)
+            five = synthetic.rotor_series(t[:5], 3)
+            got = _outcome(w_h.rotate_decomposition_basis, np.array([five, five]))
+            assert got[0] == "ValueError" and got[1].startswith("Input dimension mismatch.  R_basis.shape=")
+            continue
         elif c["fn"] == "psi3_with_short_companion":
             got = _outcome(w_psi3.transform, psi4_modes=w_psi4_short, **shift)
             assert got[0] == ref["raises"] == "ValueError"  # (the reference's text is numpy's broadcasting complaint; here the cause is named)
