@@ -76,6 +76,10 @@ quaternion, spherical_functions, spinsfast) and writes
                             translations, grids too small or small, rotors and velocities out of range, unknown keywords), and the
                             transform's own checks (argument type, missing / mismatched psi companions).
 
+  g23_ref_sample_waveforms.npz  the deterministic generators of scri/sample_waveforms.py:195-381, among them the analytic answer of the reference's
+                            hyper-translation test (a single mode proportional to time under a supertranslation, :312-381; its 3-j symbols
+                            from sympy): three (s, l, m) each, a generic supertranslation and a plain space translation.
+
 Only the .npz and .json files travel; tests/test_golden.py checks the oracle (CPU) and the HIP path (GPU) against them.
 """
 import os
@@ -681,10 +685,28 @@ def g22():
                    "cases": cases}, f, indent=1)
 
 
+def g23():
+    import scri.sample_waveforms as sw
+
+    st = np.zeros(16, dtype=complex)
+    st[[0, 2, 5, 7, 12]] = [0.3, 0.1, 0.02 - 0.01j, 0.02 + 0.01j, 0.005]
+    out = dict(supertranslation=st, space_translation=np.array([0.2, -0.1, 0.4]))
+    kws = (dict(), dict(s=-1, ell=3, m=2), dict(s=0, ell=2, m=-1, ell_max=5, t_0=-3.0, t_1=4.0, dt=0.25))
+    for i, kw in enumerate(kws):
+        for tag, w in (("rot", sw.single_mode_constant_rotation(omega=0.3 + 0.02j, **kw)), ("prop", sw.single_mode_proportional_to_time(beta=2.0 - 1j, **kw)),
+                       ("super", sw.single_mode_proportional_to_time_supertranslated(supertranslation=st, **kw)),
+                       ("space", sw.single_mode_proportional_to_time_supertranslated(space_translation=[0.2, -0.1, 0.4], **kw))):
+            out[f"{tag}_{i}_t"], out[f"{tag}_{i}_data"] = np.array(w.t), np.array(w.data)
+            out[f"{tag}_{i}_meta"] = np.array([w.ell_min, w.ell_max, int(w.dataType), int(w.frameType)])
+    c = sw.constant_waveform()
+    out["constant_row"], out["constant_shape"] = np.array(c.data[0]), np.array(c.data.shape)
+    np.savez_compressed(os.path.join(HERE, "g23_ref_sample_waveforms.npz"), source="scri/sample_waveforms.py:60-381 (the reference's file, stand-ins underneath)", **out)
+
+
 if __name__ == "__main__":
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
-        every = (g10, g8, g9, g11, g12, g13, g14, g15, g16, g17, g18, g19, g20, g21, g22)
+        every = (g10, g8, g9, g11, g12, g13, g14, g15, g16, g17, g18, g19, g20, g21, g22, g23)
         only = [f for f in every if "--" + f.__name__ in sys.argv]
         for f in only or every:
             f()

@@ -556,6 +556,17 @@ def theta_phi(n_theta, n_phi):
 
 
 _CG_CACHE = {}
+_W3J_CACHE = {}
+
+
+def _wigner_3j(j1, j2, j3, m1, m2, m3):
+    """sf.Wigner3j(j_1, j_2, j_3, m_1, m_2, m_3), from sympy's exact value"""
+    key = (int(j1), int(j2), int(j3), int(m1), int(m2), int(m3))
+    if key not in _W3J_CACHE:
+        from sympy.physics.wigner import wigner_3j
+
+        _W3J_CACHE[key] = float(wigner_3j(*key))
+    return _W3J_CACHE[key]
 
 
 def _clebsch_gordan(j1, m1, j2, m2, j3, m3):
@@ -580,6 +591,7 @@ def make_sf_module():
     m.SWSH_grid = SWSH_grid
     m.ladder_operator_coefficient = lambda ell, m_: math.sqrt(ell * (ell + 1) - m_ * (m_ + 1))  # <l, m+1| L+ |l, m>
     m.clebsch_gordan = _clebsch_gordan
+    m.Wigner3j = _wigner_3j  # (scri/sample_waveforms.py:364: exact values from sympy here)
     m._Wigner_D_matrices = _Wigner_D_matrices
     m._linear_matrix_offset = wigner.linear_matrix_offset
     m.WignerD = WignerD

@@ -75,3 +75,29 @@ def test_supertranslated_single_mode_is_what_the_transformation_gives(ctx):
         i0 = int(np.argmin(np.abs(expect.t - got.t[0])))
         assert np.abs(expect.t[i0 : i0 + got.n_times] - got.t).max() < 1e-12
         assert np.abs(got.data - expect.data[i0 : i0 + got.n_times]).max() < 5e-14 * np.abs(expect.data).max(), (s, ell, m)
+
+
+def test_g23_generators_vs_the_reference_itself():
+    """the deterministic generators against scri/sample_waveforms.py run by the reference's own file (tests/golden/g23): the rotating
+    and the linear-in-time single mode bit for bit, the analytically supertranslated one (the known answer of the reference's
+    hyper-translation test, :312-381) to rounding -- the oracle's restatement and this package's both"""
+    from scri_amd import sample_waveforms as sw
+
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "g23_ref_sample_waveforms.npz"))
+    st, space = g["supertranslation"], g["space_translation"]
+    kws = (dict(), dict(s=-1, ell=3, m=2), dict(s=0, ell=2, m=-1, ell_max=5, t_0=-3.0, t_1=4.0, dt=0.25))
+    for mod in (sw, sref):
+        for i, kw in enumerate(kws):
+            made = {
+                "rot": mod.single_mode_constant_rotation(omega=0.3 + 0.02j, **kw),
+                "prop": mod.single_mode_proportional_to_time(beta=2.0 - 1j, **kw),
+                "super": mod.single_mode_proportional_to_time_supertranslated(supertranslation=st, **kw),
+                "space": mod.single_mode_proportional_to_time_supertranslated(space_translation=list(space), **kw),
+            }
+            for tag, w in made.items():
+                ref = g[f"{tag}_{i}_data"]
+                assert np.array_equal(w.t, g[f"{tag}_{i}_t"]) and w.data.shape == ref.shape, (mod.__name__, tag, i)
+                assert [w.ell_min, w.ell_max, int(w.dataType), int(w.frameType)] == list(g[f"{tag}_{i}_meta"]), (mod.__name__, tag, i)
+                assert np.abs(w.data - ref).max() <= (0.0 if tag in ("rot", "prop") else 1e-14 * np.abs(ref).max()), (mod.__name__, tag, i)
+    c = sw.constant_waveform()
+    assert list(c.data.shape) == list(g["constant_shape"]) and np.array_equal(c.data[0], g["constant_row"])
