@@ -80,6 +80,11 @@ quaternion, spherical_functions, spinsfast) and writes
                             hyper-translation test (a single mode proportional to time under a supertranslation, :312-381; its 3-j symbols
                             from sympy): three (s, l, m) each, a generic supertranslation and a plain space translation.
 
+  g24_ref_containers.npz    the container operations around the path: WaveformModes.interpolate, data_dot / _ddot /
+                            _int / _iint, norm (scri/waveform_base.py:535-551, 685-705, 950-967), slicing along time and along l
+                            (scri/waveform_modes.py:976-1004), AsymptoticBondiData.interpolate, its time slice and its strain h
+                            (scri/asymptotic_bondi_data/__init__.py:119-131, 218-233).
+
 Only the .npz and .json files travel; tests/test_golden.py checks the oracle (CPU) and the HIP path (GPU) against them.
 """
 import os
@@ -703,10 +708,39 @@ def g23():
     np.savez_compressed(os.path.join(HERE, "g23_ref_sample_waveforms.npz"), source="scri/sample_waveforms.py:60-381 (the reference's file, stand-ins underneath)", **out)
 
 
+def g24():
+    u, raw, L, abd = _g19_abd()
+    tn = np.concatenate([np.linspace(-20.0, 30.0, 33), u[7:40:11]])
+    tn.sort()
+    arr = lambda m: np.asarray(m).view(np.ndarray)
+    fields = lambda a: np.array([arr(getattr(a, f)) for f in ("psi0", "psi1", "psi2", "psi3", "psi4", "sigma")])
+    rng = np.random.default_rng(241)
+    un = np.sort(rng.uniform(-30.0, 40.0, 60)) + np.arange(60) * 1e-3  # a non-uniform axis for the waveform
+    wdata = synthetic.chirp_modes(un, 2, 4, 7) * (1 + 0.01 * un[:, None])
+    w = _wm(un, wdata, 2, 4, scri.h)
+    out = dict(u=u, raw=raw, ell_max=L, new_times=tn, w_t=un, w_data=wdata)
+    wi = w.interpolate(tn)
+    out["w_interp_t"], out["w_interp_data"] = np.array(wi.t), np.array(wi.data)
+    for name in ("data_dot", "data_ddot", "data_int", "data_iint"):
+        out["w_" + name] = np.array(getattr(w, name))
+    out["w_norm"], out["w_norm_sqrt"] = np.array(w.norm()), np.array(w.norm(take_sqrt=True))
+    sl = w[:, 3:5]
+    out["w_ell_slice_data"], out["w_ell_slice_meta"] = np.array(sl.data), np.array([sl.ell_min, sl.ell_max, sl.n_times])
+    st = w[5:20]
+    out["w_t_slice_t"], out["w_t_slice_data"] = np.array(st.t), np.array(st.data)
+    ai = abd.interpolate(tn)
+    out["abd_interp_u"], out["abd_interp_raw"] = np.array(ai.t), fields(ai)
+    ak = abd[5:20]
+    out["abd_slice_u"], out["abd_slice_raw"] = np.array(ak.t), fields(ak)
+    h = abd.h
+    out["abd_h_t"], out["abd_h_data"], out["abd_h_meta"] = np.array(h.t), np.array(h.data), np.array([h.ell_min, h.ell_max, int(h.dataType), int(h.frameType)])
+    np.savez_compressed(os.path.join(HERE, "g24_ref_containers.npz"), source="scri/waveform_base.py, scri/waveform_modes.py, scri/asymptotic_bondi_data/__init__.py (the reference's files)", **out)
+
+
 if __name__ == "__main__":
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
-        every = (g10, g8, g9, g11, g12, g13, g14, g15, g16, g17, g18, g19, g20, g21, g22, g23)
+        every = (g10, g8, g9, g11, g12, g13, g14, g15, g16, g17, g18, g19, g20, g21, g22, g23, g24)
         only = [f for f in every if "--" + f.__name__ in sys.argv]
         for f in only or every:
             f()

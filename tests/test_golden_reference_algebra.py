@@ -486,3 +486,50 @@ def test_g22_error_and_warning_texts_vs_reference():
         if ref["raises"]:
             assert _same_text(got[1], ref["text"]), (c["fn"], kw, got[1], ref["text"])
         assert len(got[2]) == len(ref["warnings"]) and all(_same_text(a, b) for a, b in zip(got[2], ref["warnings"])), (c["fn"], kw, got[2], ref["warnings"])
+
+
+# ------------------------------------------------------------------------------------------------- g24: the containers around the path
+G24 = os.path.join(HERE, "golden", "g24_ref_containers.npz")
+
+
+def _g24_objects(ctx=None):
+    import scri_amd
+
+    g = np.load(G24)
+    L = int(g["ell_max"])
+    abd = scri_amd.AsymptoticBondiData(g["u"], L, ctx=ctx)
+    abd._raw_data[:] = g["raw"]
+    w = scri_amd.WaveformModes(t=g["w_t"], data=g["w_data"], ell_min=2, ell_max=4, dataType=scri_amd.h, frameType=scri_amd.Inertial,
+                               r_is_scaled_out=True, m_is_scaled_out=True, ctx=ctx)
+    return g, abd, w
+
+
+def test_g24_slices_and_strain_vs_reference():
+    """host-only container logic: slicing along time and along l (scri/waveform_modes.py:976-1004), AsymptoticBondiData's time slice and
+    its strain h = 2 sigma-bar (scri/asymptotic_bondi_data/__init__.py:119-131) -- bit for bit"""
+    g, abd, w = _g24_objects()
+    sl = w[:, 3:5]
+    assert [sl.ell_min, sl.ell_max, sl.n_times] == list(g["w_ell_slice_meta"]) and np.array_equal(sl.data, g["w_ell_slice_data"])
+    st = w[5:20]
+    assert np.array_equal(st.t, g["w_t_slice_t"]) and np.array_equal(st.data, g["w_t_slice_data"])
+    ak = abd[5:20]
+    assert np.array_equal(ak.t, g["abd_slice_u"]) and np.array_equal(ak._raw_data, g["abd_slice_raw"])
+    h = abd.h
+    assert [h.ell_min, h.ell_max, int(h.dataType), int(h.frameType)] == list(g["abd_h_meta"])
+    assert np.array_equal(h.t, g["abd_h_t"]) and np.array_equal(h.data, g["abd_h_data"])
+
+
+@pytest.mark.gpu
+def test_g24_gpu_interpolation_calculus_and_norm_vs_reference(ctx):
+    """the GPU-backed container operations (bms_cubic_spline, bms_spline_derivative, bms_row_norm) against the reference's values:
+    WaveformModes.interpolate / data_dot / data_ddot / data_int / data_iint / norm on a non-uniform axis, AsymptoticBondiData.interpolate"""
+    g, abd, w = _g24_objects(ctx)
+    wi = w.interpolate(g["new_times"])
+    assert np.array_equal(wi.t, g["w_interp_t"]) and np.abs(wi.data - g["w_interp_data"]).max() < 1e-12 * np.abs(g["w_interp_data"]).max()
+    for name, bar in (("data_dot", 1e-11), ("data_ddot", 1e-9), ("data_int", 1e-12), ("data_iint", 1e-12)):
+        ref = g["w_" + name]
+        assert np.abs(getattr(w, name) - ref).max() < bar * max(1.0, np.abs(ref).max()), name
+    assert np.array_equal(w.norm(), g["w_norm"]) and np.array_equal(w.norm(take_sqrt=True), g["w_norm_sqrt"])  # (the reference's summation order)
+    ai = abd.interpolate(g["new_times"])
+    assert np.array_equal(ai.t, g["abd_interp_u"])
+    assert np.abs(ai._raw_data - g["abd_interp_raw"]).max() < 1e-12 * np.abs(g["abd_interp_raw"]).max()
