@@ -85,6 +85,10 @@ quaternion, spherical_functions, spinsfast) and writes
                             (scri/waveform_modes.py:976-1004), AsymptoticBondiData.interpolate, its time slice and its strain h
                             (scri/asymptotic_bondi_data/__init__.py:119-131, 218-233).
 
+  g25_ref_supermomenta.npz  AsymptoticBondiData.supermomentum (scri/asymptotic_bondi_data/bms_charges.py:192-286) in its four definitions (Bondi-Sachs,
+                            Moreschi, Geroch, Geroch-Winicour), plain and integrated, with the default working l_max and a larger one; the
+                            remaining charges of the g19 data (CWWY angular momentum among them) and the text of the error for an unknown name.
+
 Only the .npz and .json files travel; tests/test_golden.py checks the oracle (CPU) and the HIP path (GPU) against them.
 """
 import os
@@ -737,10 +741,31 @@ def g24():
     np.savez_compressed(os.path.join(HERE, "g24_ref_containers.npz"), source="scri/waveform_base.py, scri/waveform_modes.py, scri/asymptotic_bondi_data/__init__.py (the reference's files)", **out)
 
 
+def g25():
+    u, raw, L, abd = _g19_abd()
+    arr = lambda m: np.asarray(m).view(np.ndarray)
+    out = dict(u=u, raw=raw, ell_max=L)
+    for name in ("Bondi-Sachs", "Moreschi", "Geroch", "GW"):
+        for tag, kw in (("plain", {}), ("integrated", dict(integrated=True)), ("wide", dict(working_ell_max=6)), ("integrated_wide", dict(integrated=True, working_ell_max=6))):
+            r = abd.supermomentum(name, **kw)
+            out[f"{name}_{tag}"] = arr(r)
+            out[f"{name}_{tag}_meta"] = np.array([r.spin_weight, r.ell_min, r.ell_max])
+    for name in ("bondi_rest_mass", "bondi_four_momentum", "bondi_angular_momentum", "bondi_boost_charge", "bondi_CoM_charge", "bondi_dimensionless_spin",
+                 "CWWY_angular_momentum"):
+        if hasattr(abd, name):
+            out[name] = np.asarray(getattr(abd, name)())
+    try:
+        abd.supermomentum("Bondi")
+        out["unknown_name_error"] = np.array("")
+    except ValueError as e:
+        out["unknown_name_error"] = np.array(str(e))
+    np.savez_compressed(os.path.join(HERE, "g25_ref_supermomenta.npz"), source="scri/asymptotic_bondi_data/bms_charges.py:14-286 (the reference's file, stand-ins underneath)", **out)
+
+
 if __name__ == "__main__":
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
-        every = (g10, g8, g9, g11, g12, g13, g14, g15, g16, g17, g18, g19, g20, g21, g22, g23, g24)
+        every = (g10, g8, g9, g11, g12, g13, g14, g15, g16, g17, g18, g19, g20, g21, g22, g23, g24, g25)
         only = [f for f in every if "--" + f.__name__ in sys.argv]
         for f in only or every:
             f()

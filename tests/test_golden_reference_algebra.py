@@ -533,3 +533,51 @@ def test_g24_gpu_interpolation_calculus_and_norm_vs_reference(ctx):
     ai = abd.interpolate(g["new_times"])
     assert np.array_equal(ai.t, g["abd_interp_u"])
     assert np.abs(ai._raw_data - g["abd_interp_raw"]).max() < 1e-12 * np.abs(g["abd_interp_raw"]).max()
+
+
+# ------------------------------------------------------------------------------------------------- g25: supermomenta and charges
+G25 = os.path.join(HERE, "golden", "g25_ref_supermomenta.npz")
+
+
+def test_g25_oracle_supermomenta_vs_reference():
+    """oracle/bms_charges_ref.py against scri/asymptotic_bondi_data/bms_charges.py:192-286 run by the reference's own file"""
+    from oracle import bms_charges_ref as cref
+
+    g = np.load(G25)
+    u, raw = g["u"], g["raw"]
+    psi2, sigma = raw[2], raw[5]
+    for name in ("Bondi-Sachs", "Moreschi", "Geroch", "GW"):
+        for tag, kw in (("plain", {}), ("integrated", dict(integrated=True)), ("wide", dict(working_ell_max=6)),
+                        ("integrated_wide", dict(integrated=True, working_ell_max=6))):
+            ref = g[f"{name}_{tag}"]
+            got = cref.supermomentum(u, psi2, sigma, name, **kw)
+            assert got.shape == ref.shape and np.abs(got - ref).max() < 1e-12 * max(1.0, np.abs(ref).max()), (name, tag)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("device", [False, True])
+def test_g25_gpu_supermomenta_and_charges_vs_reference(ctx, device):
+    """AsymptoticBondiData.supermomentum in its four definitions, plain and integrated, two working l_max, and every Bondi charge, host-
+    and device-resident, against the reference's values; the error for an unknown definition word for word"""
+    import scri_amd
+
+    g = np.load(G25)
+    L = int(g["ell_max"])
+    abd = scri_amd.AsymptoticBondiData(g["u"], L, ctx=ctx)
+    abd._raw_data[:] = g["raw"]
+    if device:
+        abd = abd.to_device()
+    for name in ("Bondi-Sachs", "Moreschi", "Geroch", "GW"):
+        for tag, kw in (("plain", {}), ("integrated", dict(integrated=True)), ("wide", dict(working_ell_max=6)),
+                        ("integrated_wide", dict(integrated=True, working_ell_max=6))):
+            ref = g[f"{name}_{tag}"]
+            r = abd.supermomentum(name, **kw)
+            assert [r.spin_weight, r.ell_min, r.ell_max] == list(g[f"{name}_{tag}_meta"]), (name, tag)
+            assert np.abs(np.asarray(r.ndarray) - ref).max() < 1e-12 * max(1.0, np.abs(ref).max()), (name, tag)
+    for name in ("bondi_rest_mass", "bondi_four_momentum", "bondi_angular_momentum", "bondi_boost_charge", "bondi_CoM_charge",
+                 "bondi_dimensionless_spin", "CWWY_angular_momentum"):
+        ref = g[name]
+        assert np.abs(getattr(abd, name)() - ref).max() < 1e-11 * max(1.0, np.abs(ref).max()), name
+    with pytest.raises(ValueError) as e:
+        abd.supermomentum("Bondi")
+    assert str(e.value) == str(g["unknown_name_error"])
