@@ -143,10 +143,10 @@ def supermomentum(self, supermomentum_def, **kwargs):
     if name not in ("bondi-sachs", "bs", "moreschi", "m", "geroch", "g", "geroch-winicour", "gw"):
         raise ValueError(
             f"Supermomentum defintion '{supermomentum_def}' not recognized. Please choose one of "
-            "the following options:\\n"
-            "  * 'Bondi-Sachs' or 'BS'\\n"
-            "  * 'Moreschi' or 'M'\\n"
-            "  * 'Geroch' or 'G'\\n"
+            "the following options:\n"
+            "  * 'Bondi-Sachs' or 'BS'\n"
+            "  * 'Moreschi' or 'M'\n"
+            "  * 'Geroch' or 'G'\n"
             "  * 'Geroch-Winicour' or 'GW'"
         )
     base = self.psi2 + self.sigma.grid_multiply(self.sigma.bar.dot, **kwargs)
