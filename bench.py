@@ -741,8 +741,6 @@ def main():
     if view is not None:
         view.copy_(local)
         local = view
-    n_new_all = window[1] - window[0]
-    halo_rows = (have[rank][0] - need[rank][0], need[rank][1] - have[rank][1]) if world > 1 else (0, 0)
 
     # ---- cfg4 / cfg5 on several GPUs: the whole series on ONE GPU (rank 0's), in the same run: the reference of the strong-scaling line
     n1 = None
@@ -785,7 +783,7 @@ def main():
     last = {}
 
     def step():
-        t_out, rows, first = st(local, out=out)
+        _, rows, _ = st(local, out=out)
         last["rows"] = rows  # (time shards: a view of `out`; grid columns: this rank's block of the reduce-scatter)
         return rows.shape[1 if abd else 0]
 
