@@ -454,6 +454,12 @@ def g17():
     for tag, y in (("up", np.array([0.0, 1, 2, 2, 3, 2.5, 2.9, 3.0, 3.1, 10, 9, 11])), ("down", np.array([5.0, 4, 4.5, 3, 3, 2, 2.5, 1, 0])),
                    ("flat", np.array([1.0, 2, 0.5, 1.0])), ("noise", np.cumsum(rng.normal(0.3, 1.0, size=200)))):
         out[f"mono_{tag}_in"], out[f"mono_{tag}_out"] = y, np.array(index_is_monotonic(y))
+    # transition_function (scri/utilities.py:12-58; used by rotations.py when a frame is frozen)
+    x = np.linspace(-0.3, 1.4, 173)
+    for tag, args in (("a", (0.2, 0.8)), ("b", (0.0, 1.0, 3.0, -1.0)), ("c", (0.35, 0.351))):
+        f, i0, i1 = ut.transition_function(x, *args, return_indices=True)
+        out[f"transition_{tag}_args"], out[f"transition_{tag}_out"], out[f"transition_{tag}_idx"] = np.array(args), np.array(f), np.array([i0, i1])
+    out["transition_x"] = x
     np.savez_compressed(os.path.join(HERE, "g17_ref_bit_transforms.npz"), source="scri/utilities.py:194-406, scri/SpEC/file_io/__init__.py:50-70 (the reference's files, identity njit)", **out)
 
 

@@ -159,6 +159,17 @@ def test_g17_host_index_is_monotonic_vs_reference():
         assert np.array_equal(file_io.index_is_monotonic(y), expect), tag
 
 
+def test_g17_transition_function_vs_reference():
+    """the smooth step of scri/utilities.py:12-58 (rotations.py uses it to freeze a frame): values and the two indices it reports"""
+    from scri_amd.utilities import transition_function
+
+    g = np.load(G17)
+    for tag in ("a", "b", "c"):
+        f, i0, i1 = transition_function(g["transition_x"], *g[f"transition_{tag}_args"], return_indices=True)
+        assert [i0, i1] == list(g[f"transition_{tag}_idx"]), tag
+        assert np.abs(f - g[f"transition_{tag}_out"]).max() < 1e-15 * max(1.0, np.abs(g[f"transition_{tag}_out"]).max()), tag
+
+
 @pytest.mark.gpu
 def test_g17_gpu_bit_transforms_vs_reference(ctx):
     """kernels_bits.hip against the reference's own bytes"""
