@@ -89,3 +89,53 @@ def transition_function(x, x0, x1, y0=0.0, y1=1.0, return_indices=False):
         exponent = 1.0 / tau - 1.0 / (1.0 - tau)
         out[i0:i1] = np.where(exponent >= np.log(np.finfo(float).max), y0, y0 + (y1 - y0) / (1.0 + np.exp(exponent)))
     return (out, i0, i1) if return_indices else out
+
+
+_MAXEXP = np.log(np.finfo(float).max)
+
+
+def transition_function_derivative(x, x0, x1, y0=0.0, y1=1.0):
+    """d/dx of transition_function with the same parameters (scri/utilities.py:60-102); zero outside (x0, x1)."""
+    x = np.asarray(x, dtype=float)
+    out = np.zeros_like(x)
+    i0 = int(np.searchsorted(x, x0, side="right"))
+    i1 = int(np.searchsorted(x, x1, side="left"))
+    tau = (x[i0:i1] - x0) / (x1 - x0)
+    with np.errstate(over="ignore", divide="ignore", invalid="ignore"):
+        exponent = 1.0 / tau - 1.0 / (1.0 - tau)
+        e = np.exp(exponent)
+        slope = -(y1 - y0) * e * (-1.0 / tau**2 - 1.0 / (1.0 - tau) ** 2) * (1 / (x1 - x0)) / (1.0 + e) ** 2
+        out[i0:i1] = np.where(exponent >= _MAXEXP, 0.0, slope)
+    return out
+
+
+def bump_function(x, x0, x1, x2, x3, y0=0.0, y12=1.0, y3=0.0):
+    """Smooth bump: y0 up to x0, y12 on [x1, x2], y3 from x3, with the transition_function profile on either flank
+    (scri/utilities.py:105-158)."""
+    x = np.asarray(x, dtype=float)
+    out = np.empty_like(x)
+    i1 = int(np.searchsorted(x, x1, side="left"))
+    i2 = max(i1, int(np.searchsorted(x, x2, side="right")))
+    out[:i1] = transition_function(x[:i1], x0, x1, y0, y12)
+    out[i1:i2] = y12
+    out[i2:] = transition_function(x[i2:], x2, x3, y12, y3)
+    return out
+
+
+def transition_to_constant(f, t, t1, t2):
+    """f up to t1, a constant from t2, smooth in between: f times the falling transition minus the running integral of f times the
+    transition's derivative (scri/utilities.py:161-190; the integral is numpy-quaternion's `indefinite_integral`, the antiderivative of
+    the not-a-knot cubic spline through the samples, here scipy's CubicSpline)."""
+    from scipy.interpolate import CubicSpline
+
+    f, t = np.asarray(f), np.asarray(t, dtype=float)
+    transition, i1, i2 = transition_function(t, t1, t2, y0=1.0, y1=0.0, return_indices=True)
+    transition_dot = transition_function_derivative(t, t1, t2, y0=1.0, y1=0.0)
+    out = f * transition
+    if i2 - i1 >= 4:
+        spline = CubicSpline(t[i1:i2], f[i1:i2] * transition_dot[i1:i2])
+        out[i1:i2] -= spline.antiderivative()(t[i1:i2])
+    elif i2 > i1:
+        raise ValueError(f"transition_to_constant needs at least four samples inside ({t1}, {t2}); there are {i2 - i1}")
+    out[i2:] = out[i2 - 1]
+    return out

@@ -460,6 +460,15 @@ def g17():
         f, i0, i1 = ut.transition_function(x, *args, return_indices=True)
         out[f"transition_{tag}_args"], out[f"transition_{tag}_out"], out[f"transition_{tag}_idx"] = np.array(args), np.array(f), np.array([i0, i1])
     out["transition_x"] = x
+    # ... its derivative, the bump built from two of them, and transition_to_constant (utilities.py:60-190: sample_waveforms' helpers)
+    xs = np.linspace(-0.3, 1.4, 173)[:-3]  # (the reference's loops index past the end when x never reaches x1 / x3)
+    out["transition_deriv_x"] = xs
+    out["transition_deriv_out"] = ut.transition_function_derivative(xs, 0.2, 0.8, 1.0, -2.0)
+    out["bump_args"] = np.array([0.1, 0.4, 0.5, 1.2, 0.5, 2.0, -1.0])
+    out["bump_out"] = ut.bump_function(xs, *out["bump_args"])
+    tt = np.linspace(0.0, 10.0, 401)
+    ff = np.sin(1.3 * tt) + 0.2 * tt
+    out["to_constant_t"], out["to_constant_f"], out["to_constant_out"] = tt, ff, ut.transition_to_constant(ff.copy(), tt, 3.0, 7.5)
     np.savez_compressed(os.path.join(HERE, "g17_ref_bit_transforms.npz"), source="scri/utilities.py:194-406, scri/SpEC/file_io/__init__.py:50-70 (the reference's files, identity njit)", **out)
 
 

@@ -287,6 +287,7 @@ def make_quaternion_module():
     calculus.__path__ = []
     calculus.indefinite_integral = calculus.spline_indefinite_integral = _spline_indefinite_integral
     m.calculus = calculus
+    m.indefinite_integral = m.spline_indefinite_integral = _spline_indefinite_integral  # (numpy-quaternion re-exports them at the top level)
     sys.modules["quaternion.calculus"] = calculus
     m.as_vector_part = lambda q: np.array(q.vec) if isinstance(q, quaternion) else _q_float(q)[..., 1:]
     return m

@@ -170,6 +170,20 @@ def test_g17_transition_function_vs_reference():
         assert np.abs(f - g[f"transition_{tag}_out"]).max() < 1e-15 * max(1.0, np.abs(g[f"transition_{tag}_out"]).max()), tag
 
 
+def test_g17_transition_companions_vs_reference():
+    """transition_function_derivative, bump_function, transition_to_constant (scri/utilities.py:60-190) against the reference's values;
+    the last one integrates a cubic spline (numpy-quaternion's there, scipy's here: both the not-a-knot spline through the samples)"""
+    from scri_amd import utilities as ut
+
+    g = np.load(G17)
+    xs = g["transition_deriv_x"]
+    assert np.abs(ut.transition_function_derivative(xs, 0.2, 0.8, 1.0, -2.0) - g["transition_deriv_out"]).max() < 1e-14
+    assert np.abs(ut.bump_function(xs, *g["bump_args"]) - g["bump_out"]).max() < 1e-15
+    got = ut.transition_to_constant(g["to_constant_f"], g["to_constant_t"], 3.0, 7.5)
+    assert np.abs(got - g["to_constant_out"]).max() < 1e-13
+    assert np.all(got[g["to_constant_t"] > 7.5] == got[-1]) and np.array_equal(got[:100], g["to_constant_f"][:100])
+
+
 @pytest.mark.gpu
 def test_g17_gpu_bit_transforms_vs_reference(ctx):
     """kernels_bits.hip against the reference's own bytes"""
