@@ -35,9 +35,10 @@ enum bms_status {
   BMS_OK = 0,
   BMS_ERR_INVALID = -1,     /* bad argument (maps to ValueError in the shim) */
   BMS_ERR_HIP = -2,         /* HIP runtime failure */
-  BMS_ERR_NOMEM = -3,       /* device allocation failed */
+  BMS_ERR_NOMEM = -3,       /* device (or host) allocation failed */
   BMS_ERR_UNSUPPORTED = -4, /* valid request outside the implemented range */
-  BMS_ERR_NODEVICE = -5     /* no usable GPU */
+  BMS_ERR_NODEVICE = -5,    /* no usable GPU */
+  BMS_ERR_INTERNAL = -6     /* a C++ exception inside the library, caught at the boundary (none ever crosses it) */
 };
 
 enum bms_mem { BMS_HOST = 0, BMS_DEVICE = 1 };

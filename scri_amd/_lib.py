@@ -15,7 +15,7 @@ LIB_PATH = os.environ.get("SCRI_AMD_LIB_PATH") or os.path.join(_HERE, "libscri_a
 
 BMS_HOST, BMS_DEVICE = 0, 1
 BMS_TERM_NONE, BMS_TERM_H, BMS_TERM_SIGMA, BMS_TERM_PSI = 0, 1, 2, 3
-BMS_ERR_INVALID, BMS_ERR_HIP, BMS_ERR_NOMEM, BMS_ERR_UNSUPPORTED, BMS_ERR_NODEVICE = -1, -2, -3, -4, -5
+BMS_ERR_INVALID, BMS_ERR_HIP, BMS_ERR_NOMEM, BMS_ERR_UNSUPPORTED, BMS_ERR_NODEVICE, BMS_ERR_INTERNAL = -1, -2, -3, -4, -5, -6
 
 c_i64 = ctypes.c_int64
 c_int = ctypes.c_int

@@ -18,6 +18,7 @@
 #include <cstring>
 #include <functional>
 #include <map>
+#include <new>
 #include <string>
 #include <thread>
 #include <vector>
@@ -242,6 +243,13 @@ struct HostTrace {
 
 BMS_INTERNAL int fail(bms_ctx* c, int code, const char* fmt, ...);
 
+// No C++ exception leaves the library: its callers are C, cgo, ctypes, and an exception that unwinds into them ends the process.  Every
+// extern "C" entry that returns a status is a function-try-block closed by BMS_CATCH, which turns what was thrown -- std::bad_alloc
+// from the host-side tables, std::system_error from a thread that could not start -- into a status and a message on the context.
+BMS_INTERNAL int exception_status(bms_ctx* c) noexcept;
+#define BMS_CATCH(ctx) \
+  catch (...) { return exception_status(ctx); }
+
 #define HIP_TRY(ctx, expr)                                                                                   \
   do {                                                                                                       \
     hipError_t e__ = (expr);                                                                                 \
@@ -251,6 +259,8 @@ BMS_INTERNAL int fail(bms_ctx* c, int code, const char* fmt, ...);
                   hipGetErrorString(e__), __FILE__, __LINE__);                                               \
     }                                                                                                        \
   } while (0)
+
+inline bool valid_mem(int mem) { return mem == BMS_HOST || mem == BMS_DEVICE; }
 
 BMS_INTERNAL hipError_t create_download_stream(bms_ctx* c);
 BMS_INTERNAL int dev_buf(bms_ctx* c, const char* name, size_t bytes, void** out);
@@ -315,12 +325,22 @@ inline int run_dealt_over_contexts(bms_ctx* const* ctxs, int n_ctx, int pieces, 
   if (pieces < 1) pieces = 1;
   std::vector<int> rc(n_ctx, BMS_OK);
   std::vector<int64_t> got(n_ctx, -1);
-  auto run = [&](int k) {
+  auto run = [&](int k) noexcept {
     const int p0 = (int)(((long long)pieces * k) / n_ctx), p1 = (int)(((long long)pieces * (k + 1)) / n_ctx);
-    if (p1 > p0) rc[k] = part(ctxs[k], p0, p1, &got[k]);
+    try {
+      if (p1 > p0) rc[k] = part(ctxs[k], p0, p1, &got[k]);
+    } catch (...) {
+      rc[k] = exception_status(ctxs[k]);
+    }
   };
   std::vector<std::thread> threads;
-  for (int k = 1; k < n_ctx; ++k) threads.emplace_back(run, k);
+  threads.reserve(n_ctx);
+  int started = 1;
+  try {
+    for (; started < n_ctx; ++started) threads.emplace_back(run, started);
+  } catch (...) {  // a thread that could not start: the contexts without one report it, the others finish their share first
+    for (int k = started; k < n_ctx; ++k) rc[k] = exception_status(ctxs[k]);
+  }
   run(0);
   for (auto& th : threads) th.join();
   for (int k = 0; k < n_ctx; ++k)

@@ -9,15 +9,16 @@ static int transform_abd_impl(bms_ctx* c, const double* u, const void* raw, int 
 
 extern "C" int bms_transform_abd_shard(bms_ctx* c, const double* u, const void* raw, int mem, int64_t n_times, int ell_max,
                                        const bms_transformation* tr, const bms_shard* sh, double* u_out, void* raw_out,
-                                       int64_t* n_times_out, int64_t* first_index_out) {
+                                       int64_t* n_times_out, int64_t* first_index_out) try {
   if (!c) return BMS_ERR_INVALID;
   return with_smaller_chunks(c, [&] { return transform_abd_impl(c, u, raw, mem, n_times, ell_max, tr, sh, u_out, raw_out, n_times_out, first_index_out); });
-}
+} BMS_CATCH(c)
 
 static int transform_abd_impl(bms_ctx* c, const double* u, const void* raw, int mem, int64_t n_times, int ell_max,
                               const bms_transformation* tr, const bms_shard* sh, double* u_out, void* raw_out, int64_t* n_times_out,
                               int64_t* first_index_out) {
   if (!u || !raw || !tr || !u_out || !raw_out || !n_times_out) return fail(c, BMS_ERR_INVALID, "NULL argument");
+  if (!valid_mem(mem)) return fail(c, BMS_ERR_INVALID, "mem is BMS_HOST or BMS_DEVICE, got %d", mem);
   HIP_TRY(c, hipSetDevice(c->device));
   const int64_t n = n_times;
   int64_t t_lo, t_hi;
@@ -349,13 +350,13 @@ static int transform_abd_impl(bms_ctx* c, const double* u, const void* raw, int 
 // rows (+ halo) of the six fields of shard k + 1 travel up, the kernels of shard k run and the results of shard k - 1 travel
 // down at the same time.  raw: host c16[6][n][(ell_max+1)^2]; raw_out: host c16[6][i_hi - i_lo][n_out] (best page-locked).
 extern "C" int bms_transform_abd_pipelined(bms_ctx* c, const double* u, const void* raw, int64_t n, int ell_max,
-                                           const bms_transformation* tr, int pieces, double* u_out, void* raw_out, int64_t* n_times_out) {
+                                           const bms_transformation* tr, int pieces, double* u_out, void* raw_out, int64_t* n_times_out) try {
   return bms_transform_abd_pipelined_part(c, u, raw, n, ell_max, tr, pieces, 0, pieces < 1 ? 1 : pieces, u_out, raw_out, n_times_out);
-}
+} BMS_CATCH(c)
 
 // Pieces [piece0, piece1) of the same plan (see bms_transform_modes_pipelined_part): u_out / raw_out are the arrays of the whole window.
 extern "C" int bms_transform_abd_pipelined_part(bms_ctx* c, const double* u, const void* raw, int64_t n, int ell_max, const bms_transformation* tr,
-                                                int pieces, int piece0, int piece1, double* u_out, void* raw_out, int64_t* n_times_out) {
+                                                int pieces, int piece0, int piece1, double* u_out, void* raw_out, int64_t* n_times_out) try {
   if (!c) return BMS_ERR_INVALID;
   if (!u || !raw || !tr || !u_out || !raw_out || !n_times_out) return fail(c, BMS_ERR_INVALID, "NULL argument");
   HIP_TRY(c, hipSetDevice(c->device));
@@ -463,17 +464,17 @@ extern "C" int bms_transform_abd_pipelined_part(bms_ctx* c, const double* u, con
   if (rc) return rc;
   if (he != hipSuccess) return fail(c, BMS_ERR_HIP, "pipelined transfer: %s", hipGetErrorString(he));
   return BMS_OK;
-}
+} BMS_CATCH(c)
 
 // the six fields over several contexts of one process (see bms_transform_modes_multi)
 extern "C" int bms_transform_abd_multi(bms_ctx* const* ctxs, int n_ctx, const double* u, const void* raw, int64_t n, int ell_max,
-                                       const bms_transformation* tr, int pieces, double* u_out, void* raw_out, int64_t* n_times_out) {
+                                       const bms_transformation* tr, int pieces, double* u_out, void* raw_out, int64_t* n_times_out) try {
   return run_dealt_over_contexts(ctxs, n_ctx, pieces, n_times_out, [&](bms_ctx* c, int p0, int p1, int64_t* got) {
     return bms_transform_abd_pipelined_part(c, u, raw, n, ell_max, tr, pieces < 1 ? 1 : pieces, p0, p1, u_out, raw_out, got);
   });
-}
+} BMS_CATCH(ctxs && n_ctx > 0 ? ctxs[0] : nullptr)
 
 extern "C" int bms_transform_abd(bms_ctx* c, const double* u, const void* raw, int mem, int64_t n_times, int ell_max,
-                                 const bms_transformation* tr, double* u_out, void* raw_out, int64_t* n_times_out) {
+                                 const bms_transformation* tr, double* u_out, void* raw_out, int64_t* n_times_out) try {
   return bms_transform_abd_shard(c, u, raw, mem, n_times, ell_max, tr, nullptr, u_out, raw_out, n_times_out, nullptr);
-}
+} BMS_CATCH(c)

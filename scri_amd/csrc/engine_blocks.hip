@@ -4,7 +4,7 @@
 
 // ====================================================================================================== building blocks
 
-extern "C" int bms_ring_colatitudes(const double fr[4], const double v[3], int n_theta, int n_phi, double* thetas_out) {
+extern "C" int bms_ring_colatitudes(const double fr[4], const double v[3], int n_theta, int n_phi, double* thetas_out) try {
   if (!fr || !v || !thetas_out) return fail(nullptr, BMS_ERR_INVALID, "NULL argument");
   if (n_theta < 2 || n_phi < 1) return fail(nullptr, BMS_ERR_INVALID, "bad grid size");
   bms_transformation tr{};
@@ -15,9 +15,9 @@ extern "C" int bms_ring_colatitudes(const double fr[4], const double v[3], int n
   if (!separable_rotor_grid(&tr, thetas)) return 0;
   std::memcpy(thetas_out, thetas.data(), sizeof(double) * n_theta);
   return 1;
-}
+} BMS_CATCH(nullptr)
 
-extern "C" int bms_rotor_grid(bms_ctx* c, const double fr[4], const double v[3], int n_theta, int n_phi, double* out) {
+extern "C" int bms_rotor_grid(bms_ctx* c, const double fr[4], const double v[3], int n_theta, int n_phi, double* out) try {
   // ctx == NULL: pure host evaluation; otherwise the GPU kernel the transforms use (same pixel_math.h code)
   if (!fr || !v || !out) return fail(c, BMS_ERR_INVALID, "NULL argument");
   if (n_theta < 2 || n_phi < 1) return fail(c, BMS_ERR_INVALID, "bad grid size");
@@ -43,10 +43,10 @@ extern "C" int bms_rotor_grid(bms_ctx* c, const double fr[4], const double v[3],
   HIP_TRY(c, hipMemcpyAsync(out, DP.rotors, sizeof(double) * 4 * T.n_pix, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   return BMS_OK;
-}
+} BMS_CATCH(c)
 
 extern "C" int bms_conformal_factors(bms_ctx* c, const double v[3], const double* rotors, int64_t n, double* k, void* ethk_over_k,
-                                     double* one_over_k, double* one_over_k_cubed) {
+                                     double* one_over_k, double* one_over_k_cubed) try {
   if (!v || !rotors || !k || !ethk_over_k || !one_over_k || !one_over_k_cubed) return fail(c, BMS_ERR_INVALID, "NULL argument");
   const double b2 = v[0] * v[0] + v[1] * v[1] + v[2] * v[2];
   if (!(b2 < 1.0)) return fail(c, BMS_ERR_INVALID, "boost speed must be < 1");
@@ -69,9 +69,9 @@ extern "C" int bms_conformal_factors(bms_ctx* c, const double v[3], const double
     one_over_k_cubed[p] = one_over_k[p] * one_over_k[p] * one_over_k[p];
   }
   return BMS_OK;
-}
+} BMS_CATCH(c)
 
-extern "C" int bms_swsh_grid(bms_ctx* c, const double* rotors, int64_t n, int spin, int ell_min, int ell_max, void* Y) {
+extern "C" int bms_swsh_grid(bms_ctx* c, const double* rotors, int64_t n, int spin, int ell_min, int ell_max, void* Y) try {
   if (!rotors || !Y) return BMS_ERR_INVALID;
   if (!c) {  // host evaluation of the same header the kernel compiles (wigner.h: SwshChain), as bms_rotor_grid(ctx = NULL)
     const int nm = LM_total_size(ell_min, ell_max);
@@ -102,10 +102,10 @@ extern "C" int bms_swsh_grid(bms_ctx* c, const double* rotors, int64_t n, int sp
   HIP_TRY(c, hipMemcpyAsync(Y, dY, 16 * (size_t)n * nm, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   return BMS_OK;
-}
+} BMS_CATCH(c)
 
 extern "C" int bms_map2salm(bms_ctx* c, const void* grid, int mem, int64_t n_maps, int n_theta, int n_phi, int spin,
-                            int ell_min, int ell_max, void* modes_out) {
+                            int ell_min, int ell_max, void* modes_out) try {
   if (!c || !grid || !modes_out) return BMS_ERR_INVALID;
   HIP_TRY(c, hipSetDevice(c->device));
   if (n_theta < 2 || n_phi < 1 || ell_min < 0 || ell_max < ell_min) return fail(c, BMS_ERR_INVALID, "bad sizes");
@@ -123,10 +123,10 @@ extern "C" int bms_map2salm(bms_ctx* c, const void* grid, int mem, int64_t n_map
   if (mem == BMS_HOST) HIP_TRY(c, hipMemcpyAsync(modes_out, d_out, (size_t)n_maps * n_out * 16, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   return BMS_OK;
-}
+} BMS_CATCH(c)
 
 extern "C" int bms_cubic_spline(bms_ctx* c, const double* x, int64_t n, const void* y, int64_t ld, int64_t n_cols, int mem,
-                                const double* x_new, int64_t n_new, void* out) {
+                                const double* x_new, int64_t n_new, void* out) try {
   if (!c || !x || !y || !x_new || !out) return BMS_ERR_INVALID;
   HIP_TRY(c, hipSetDevice(c->device));
   if (n < 4) return fail(c, BMS_ERR_UNSUPPORTED, "cubic spline needs at least 4 knots, got %lld", (long long)n);
@@ -156,12 +156,12 @@ extern "C" int bms_cubic_spline(bms_ctx* c, const double* x, int64_t n, const vo
   if (mem == BMS_HOST) HIP_TRY(c, hipMemcpyAsync(out, d_out, (size_t)n_new * n_cols * 16, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   return BMS_OK;
-}
+} BMS_CATCH(c)
 
 // scipy CubicSpline(x, y).derivative(k) / .antiderivative(-k) evaluated at x_new (ModesTimeSeries.interpolate with
 // derivative_order, .dot / .ddot / .int / .iint: scri/modes_time_series.py:72-126)
 extern "C" int bms_spline_derivative(bms_ctx* c, const double* x, int64_t n, const void* y, int64_t ld, int64_t n_cols, int mem,
-                                     const double* x_new, int64_t n_new, int order, void* out) {
+                                     const double* x_new, int64_t n_new, int order, void* out) try {
   if (!c || !x || !y || !x_new || !out) return BMS_ERR_INVALID;
   HIP_TRY(c, hipSetDevice(c->device));
   if (n < 4) return fail(c, BMS_ERR_UNSUPPORTED, "cubic spline needs at least 4 knots, got %lld", (long long)n);
@@ -213,12 +213,12 @@ extern "C" int bms_spline_derivative(bms_ctx* c, const double* x, int64_t n, con
   if (mem == BMS_HOST) HIP_TRY(c, hipMemcpyAsync(out, d_out, (size_t)n_new * n_cols * 16, hipMemcpyDeviceToHost, S));
   HIP_TRY(c, hipStreamSynchronize(S));
   return BMS_OK;
-}
+} BMS_CATCH(c)
 
 // Angular velocity of a waveform from its modes (scri/mode_calculations.py:403-432 with LdtVector :46-57 and LLMatrix
 // :298-313; data_dot = CubicSpline(t, data).derivative()(t), scri/waveform_base.py:690-691 = the spline's knot slopes).
 extern "C" int bms_angular_velocity(bms_ctx* c, const double* t, int64_t n, const void* data, int64_t ld, int ell_min, int ell_max,
-                                    int mem, double* ldt_out, double* ll_out, double* omega_out) {
+                                    int mem, double* ldt_out, double* ll_out, double* omega_out) try {
   if (!c || !t || !data) return BMS_ERR_INVALID;
   HIP_TRY(c, hipSetDevice(c->device));
   if (n < 4) return fail(c, BMS_ERR_UNSUPPORTED, "the time derivative needs at least 4 time steps, got %lld", (long long)n);
@@ -248,7 +248,7 @@ extern "C" int bms_angular_velocity(bms_ctx* c, const double* t, int64_t n, cons
   if (omega_out) HIP_TRY(c, hipMemcpyAsync(omega_out, d_om, sizeof(double) * 3 * n, hipMemcpyDeviceToHost, S));
   HIP_TRY(c, hipStreamSynchronize(S));
   return BMS_OK;
-}
+} BMS_CATCH(c)
 
 // Frame from angular velocity: dR/dt = (1/2) Omega R with Omega(t) the not-a-knot cubic spline through omega[n][3]
 // (quaternion.integrate_angular_velocity as called by corotating_frame, scri/mode_calculations.py:470-471).  The state is
@@ -287,7 +287,7 @@ void host_spline_slopes(const double* x, int64_t n, const double* y, int64_t str
 }  // namespace
 
 extern "C" int bms_integrate_angular_velocity(bms_ctx* c, const double* t, int64_t n, const double* omega, const double R0[4],
-                                              double tolerance, double* R_out) {
+                                              double tolerance, double* R_out) try {
   // pure host routine: ctx may be NULL
   if (!t || !omega || !R0 || !R_out) return fail(c, BMS_ERR_INVALID, "NULL argument");
   if (n < 4) return fail(c, BMS_ERR_UNSUPPORTED, "the spline of the angular velocity needs at least 4 time steps, got %lld", (long long)n);
@@ -337,12 +337,12 @@ extern "C" int bms_integrate_angular_velocity(bms_ctx* c, const double* t, int64
     o[0] = R.w, o[1] = R.x, o[2] = R.y, o[3] = R.z;
   }
   return BMS_OK;
-}
+} BMS_CATCH(c)
 
 // spinsfast.salm2map(modes, s, ell_max, n_theta, n_phi): values on the equiangular grid (sf.Modes.grid, used by the
 // super-rest-frame iteration, scri/asymptotic_bondi_data/map_to_superrest_frame.py:171,216); modes from l = 0
 extern "C" int bms_salm2map(bms_ctx* c, const void* modes, int mem, int64_t n_maps, int spin, int ell_max, int n_theta, int n_phi,
-                            void* grid_out) {
+                            void* grid_out) try {
   if (!c || !modes || !grid_out) return BMS_ERR_INVALID;
   HIP_TRY(c, hipSetDevice(c->device));
   if (ell_max < 0 || n_theta < 2 || n_phi < 1 || std::abs(spin) > 4) return fail(c, BMS_ERR_INVALID, "bad sizes");
@@ -384,7 +384,7 @@ extern "C" int bms_salm2map(bms_ctx* c, const void* modes, int mem, int64_t n_ma
   if (mem == BMS_HOST) HIP_TRY(c, hipMemcpyAsync(grid_out, d_G, (size_t)n_maps * n_pix * 16, hipMemcpyDeviceToHost, S));
   HIP_TRY(c, hipStreamSynchronize(S));
   return BMS_OK;
-}
+} BMS_CATCH(c)
 
 // Mode-space operators of sf.Modes / ModesTimeSeries (eth, ethbar, bar, real, sums of different l ranges, scalar and per-row
 // factors) as one map along the mode axis, see kernels_modes.hip.  Tables idx_* / coef_* are host arrays of n_cols entries;
@@ -392,7 +392,7 @@ extern "C" int bms_salm2map(bms_ctx* c, const void* modes, int mem, int64_t n_ma
 // the identity.
 extern "C" int bms_mode_map(bms_ctx* c, void* out, int64_t ld_out, int64_t n_rows, int n_cols, const void* a, int64_t ld_a,
                             const int32_t* idx_a, const void* coef_a, int conj_a, const void* b, int64_t ld_b,
-                            const int32_t* idx_b, const void* coef_b, int conj_b, const double* row_scale, int mem) {
+                            const int32_t* idx_b, const void* coef_b, int conj_b, const double* row_scale, int mem) try {
   if (!c || !out || !a || !idx_a || !coef_a) return BMS_ERR_INVALID;
   if (b && (!idx_b || !coef_b)) return BMS_ERR_INVALID;
   HIP_TRY(c, hipSetDevice(c->device));
@@ -447,9 +447,9 @@ extern "C" int bms_mode_map(bms_ctx* c, void* out, int64_t ld_out, int64_t n_row
                                 hipMemcpyDeviceToHost, S));
   HIP_TRY(c, hipStreamSynchronize(S));  // the tables were staged from caller memory
   return BMS_OK;
-}
+} BMS_CATCH(c)
 
-extern "C" int bms_row_norm(bms_ctx* c, const void* data, int64_t ld, int64_t n_rows, int n_cols, int mem, int take_sqrt, double* out) {
+extern "C" int bms_row_norm(bms_ctx* c, const void* data, int64_t ld, int64_t n_rows, int n_cols, int mem, int take_sqrt, double* out) try {
   if (!c || !data || !out) return BMS_ERR_INVALID;
   HIP_TRY(c, hipSetDevice(c->device));
   if (n_rows < 0 || n_cols < 0 || ld < n_cols) return fail(c, BMS_ERR_INVALID, "bad sizes");
@@ -470,12 +470,12 @@ extern "C" int bms_row_norm(bms_ctx* c, const void* data, int64_t ld, int64_t n_
   if (mem == BMS_HOST) HIP_TRY(c, hipMemcpyAsync(out, d_out, sizeof(double) * n_rows, hipMemcpyDeviceToHost, S));
   HIP_TRY(c, hipStreamSynchronize(S));
   return BMS_OK;
-}
+} BMS_CATCH(c)
 
 // ModesTimeSeries.grid_multiply (scri/modes_time_series.py:142-202): both mode sets (l_min = 0) are synthesised on the
 // (2W+1) x (2W+1) equiangular grid, multiplied there, and the product (spin s_a + s_b) is analysed up to output_ell_max.
 extern "C" int bms_grid_multiply(bms_ctx* c, const void* a, int spin_a, int ell_max_a, const void* b, int spin_b, int ell_max_b,
-                                 int mem, int64_t n_times, int working_ell_max, int output_ell_max, void* out) {
+                                 int mem, int64_t n_times, int working_ell_max, int output_ell_max, void* out) try {
   if (!c || !a || !b || !out) return BMS_ERR_INVALID;
   HIP_TRY(c, hipSetDevice(c->device));
   if (ell_max_a < 0 || ell_max_b < 0 || working_ell_max < 1 || output_ell_max < 0 || output_ell_max > working_ell_max)
@@ -575,11 +575,11 @@ extern "C" int bms_grid_multiply(bms_ctx* c, const void* a, int spin_a, int ell_
   if (mem == BMS_HOST) HIP_TRY(c, hipMemcpyAsync(out, d_out, (size_t)n_times * n_out * 16, hipMemcpyDeviceToHost, S));
   HIP_TRY(c, hipStreamSynchronize(S));
   return BMS_OK;
-}
+} BMS_CATCH(c)
 
 // ====================================================================================================== storage formats
 // scri/utilities.py:194-232: XOR differencing of a time series in place (rows of 64-bit words)
-extern "C" int bms_xor_timeseries(bms_ctx* c, void* data, int mem, int64_t n_rows, int64_t words_per_row, int reverse) {
+extern "C" int bms_xor_timeseries(bms_ctx* c, void* data, int mem, int64_t n_rows, int64_t words_per_row, int reverse) try {
   if (!c || !data) return BMS_ERR_INVALID;
   HIP_TRY(c, hipSetDevice(c->device));
   if (n_rows < 0 || words_per_row < 0) return fail(c, BMS_ERR_INVALID, "negative size");
@@ -599,11 +599,11 @@ extern "C" int bms_xor_timeseries(bms_ctx* c, void* data, int mem, int64_t n_row
   HIP_TRY(c, hipMemcpyAsync(data, d_out, bytes, mem == BMS_HOST ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice, S));
   HIP_TRY(c, hipStreamSynchronize(S));
   return BMS_OK;
-}
+} BMS_CATCH(c)
 
 // scri/utilities.py:271-406: the function multishuffle(shuffle_widths, forward) returns, applied to n elements
 extern "C" int bms_multishuffle(bms_ctx* c, const void* in, void* out, int mem, int64_t n, const int* widths, int n_widths,
-                                int forward) {
+                                int forward) try {
   if (!c || !in || !out || !widths) return BMS_ERR_INVALID;
   HIP_TRY(c, hipSetDevice(c->device));
   int bit_width = 0;
@@ -631,10 +631,10 @@ extern "C" int bms_multishuffle(bms_ctx* c, const void* in, void* out, int mem, 
   if (mem == BMS_HOST) HIP_TRY(c, hipMemcpyAsync(out, d_out, bytes, hipMemcpyDeviceToHost, S));
   HIP_TRY(c, hipStreamSynchronize(S));
   return BMS_OK;
-}
+} BMS_CATCH(c)
 
 // scri/utilities.py:235-268: Fletcher-32 over the data viewed as 16-bit words (n_bytes must be even)
-extern "C" int bms_fletcher32(bms_ctx* c, const void* data, int mem, int64_t n_bytes, uint32_t* checksum) {
+extern "C" int bms_fletcher32(bms_ctx* c, const void* data, int mem, int64_t n_bytes, uint32_t* checksum) try {
   if (!c || !checksum || (!data && n_bytes)) return BMS_ERR_INVALID;
   HIP_TRY(c, hipSetDevice(c->device));
   if (n_bytes < 0 || (n_bytes & 1)) return fail(c, BMS_ERR_INVALID, "the data must be viewable as 16-bit words");
@@ -658,4 +658,4 @@ extern "C" int bms_fletcher32(bms_ctx* c, const void* data, int mem, int64_t n_b
   HIP_TRY(c, hipStreamSynchronize(S));
   *checksum = (uint32_t)((acc[1] % 65535) << 16 | (acc[0] % 65535));
   return BMS_OK;
-}
+} BMS_CATCH(c)

@@ -27,6 +27,26 @@ int fail(bms_ctx* c, int code, const char* fmt, ...) {
   return code;
 }
 
+int exception_status(bms_ctx* c) noexcept {
+  int code = BMS_ERR_INTERNAL;
+  char buf[512];
+  try {
+    throw;
+  } catch (const std::bad_alloc&) {
+    code = BMS_ERR_NOMEM;
+    snprintf(buf, sizeof buf, "host allocation failed (std::bad_alloc)");
+  } catch (const std::exception& e) {
+    snprintf(buf, sizeof buf, "unexpected C++ exception: %s", e.what());
+  } catch (...) {
+    snprintf(buf, sizeof buf, "unexpected C++ exception");
+  }
+  try {
+    (c ? c->err : g_create_error) = buf;
+  } catch (...) {
+  }
+  return code;
+}
+
 // The stream the results of a pipelined call leave on.  The runtime executes device-to-host copies as shader copies
 // (__amd_rocclr_copyBuffer) that take turns with the compute kernels on every CU.  SCRI_AMD_DOWN_CUS = n (experiment) confines the
 // stream to n CUs spread over the chip (hipExtStreamCreateWithCUMask).  Measured (tools/host_mode_rate.py, cfg3 from and to host
@@ -115,7 +135,7 @@ static uint64_t default_ws_limit() {
   return std::max<uint64_t>(lim, 256ull << 20);
 }
 
-extern "C" int bms_ctx_create(int device, bms_ctx** out) {
+extern "C" int bms_ctx_create(int device, bms_ctx** out) try {
   if (!out) return fail(nullptr, BMS_ERR_INVALID, "bms_ctx_create: ctx pointer is NULL");
   *out = nullptr;
   int n = 0;
@@ -148,11 +168,11 @@ extern "C" int bms_ctx_create(int device, bms_ctx** out) {
   c->opt.read_environment();  // the ONLY place the route switches meet the environment: they are this context's defaults from here on
   *out = c;
   return BMS_OK;
-}
+} BMS_CATCH(nullptr)
 
 // Route options of one context (env.h lists them; names with or without the SCRI_AMD_ prefix).  Setting one drops the context's cached
 // plans (their shape may depend on the route); like every entry point it must not run while another thread uses the same context.
-extern "C" int bms_ctx_set_option(bms_ctx* c, const char* name, int64_t value) {
+extern "C" int bms_ctx_set_option(bms_ctx* c, const char* name, int64_t value) try {
   if (!c) return BMS_ERR_INVALID;
   const int i = route_option_index(name);
   if (i < 0) return fail(c, BMS_ERR_INVALID, "bms_ctx_set_option: no route option named '%s'", name ? name : "(null)");
@@ -169,14 +189,14 @@ extern "C" int bms_ctx_set_option(bms_ctx* c, const char* name, int64_t value) {
   c->syn_plans_axis.clear();
   c->ring_verdict = -1;
   return BMS_OK;
-}
-extern "C" int bms_ctx_get_option(bms_ctx* c, const char* name, int64_t* value) {
+} BMS_CATCH(c)
+extern "C" int bms_ctx_get_option(bms_ctx* c, const char* name, int64_t* value) try {
   if (!c || !value) return BMS_ERR_INVALID;
   const int i = route_option_index(name);
   if (i < 0) return fail(c, BMS_ERR_INVALID, "bms_ctx_get_option: no route option named '%s'", name ? name : "(null)");
   *value = c->opt.v[i];
   return BMS_OK;
-}
+} BMS_CATCH(c)
 
 extern "C" void bms_ctx_destroy(bms_ctx* c) {
   if (!c) return;
@@ -216,22 +236,22 @@ extern "C" void bms_host_free(void* p) {
 // Page-lock a caller's array in place: uploads from it then run at PCIe rate without the runtime's staging copy.  Costs about
 // what one upload of the array costs, so it pays for arrays that are transformed more than once (scri_amd/engine.py does it
 // on the second sighting of an array and undoes it when the array is freed).
-extern "C" int bms_host_register(void* p, uint64_t bytes) {
+extern "C" int bms_host_register(void* p, uint64_t bytes) try {
   if (!p || !bytes) return BMS_ERR_INVALID;
   if (hipHostRegister(p, bytes, hipHostRegisterPortable) != hipSuccess) {
     (void)hipGetLastError();
     return BMS_ERR_HIP;
   }
   return BMS_OK;
-}
-extern "C" int bms_host_unregister(void* p) {
+} BMS_CATCH(nullptr)
+extern "C" int bms_host_unregister(void* p) try {
   if (!p) return BMS_ERR_INVALID;
   if (hipHostUnregister(p) != hipSuccess) {
     (void)hipGetLastError();
     return BMS_ERR_HIP;
   }
   return BMS_OK;
-}
+} BMS_CATCH(nullptr)
 
 // The page-locked rotor ring is reused once the stream has passed its slots: before the context moves to another stream the
 // old one is drained, so that no slot still waits for its copy on a stream nobody will synchronise any more.
@@ -246,26 +266,26 @@ static int switch_stream(bms_ctx* c, hipStream_t s) {
   return BMS_OK;
 }
 
-extern "C" int bms_ctx_set_stream(bms_ctx* c, void* s) {
+extern "C" int bms_ctx_set_stream(bms_ctx* c, void* s) try {
   if (!c) return BMS_ERR_INVALID;
   return switch_stream(c, s ? (hipStream_t)s : c->own_stream);
-}
+} BMS_CATCH(c)
 
 // The device's default (null) stream has the handle 0, which bms_ctx_set_stream reads as "back to the context's own
 // stream"; a caller whose allocations, copies and memsets are queued on the null stream (torch's default stream) names it
 // here, so that the engine's kernels are ordered behind them instead of racing them on a non-blocking stream.
-extern "C" int bms_ctx_use_default_stream(bms_ctx* c) {
+extern "C" int bms_ctx_use_default_stream(bms_ctx* c) try {
   if (!c) return BMS_ERR_INVALID;
   return switch_stream(c, nullptr);
-}
+} BMS_CATCH(c)
 
-extern "C" int bms_ctx_set_workspace_limit(bms_ctx* c, uint64_t bytes) {
+extern "C" int bms_ctx_set_workspace_limit(bms_ctx* c, uint64_t bytes) try {
   if (!c) return BMS_ERR_INVALID;
   c->ws_limit_set = bytes != 0;
   if (!bytes) HIP_TRY(c, hipSetDevice(c->device));  // (the default is sized from THIS context's device)
   c->ws_limit = bytes ? bytes : default_ws_limit();
   return BMS_OK;
-}
+} BMS_CATCH(c)
 
 // Device allocations are slow on this platform -- 70 to 120 ms per GB for the tens of GB a full-size call needs (measured inside the first
 // device-resident map_to_superrest_frame of a process: 'R' grows to 22.8 GB: 2 657 ms, to 32.1 GB: 2 342 ms), and memory a process has
@@ -274,7 +294,7 @@ extern "C" int bms_ctx_set_workspace_limit(bms_ctx* c, uint64_t bytes) {
 // that the context's named work-space buffers are carved from afterwards: the first full-size call of the process then allocates
 // nothing.  A buffer that outgrows its region gives it back to the slab and takes a larger one (first fit, neighbours coalesced: the
 // last buffer grows in place); without room it falls back to an allocation of its own.  Further calls add slabs.
-extern "C" int bms_ctx_reserve(bms_ctx* c, uint64_t bytes) {
+extern "C" int bms_ctx_reserve(bms_ctx* c, uint64_t bytes) try {
   if (!c) return BMS_ERR_INVALID;
   HIP_TRY(c, hipSetDevice(c->device));
   if (!bytes) {
@@ -298,12 +318,12 @@ extern "C" int bms_ctx_reserve(bms_ctx* c, uint64_t bytes) {
   sl.free[0] = bytes;
   c->slabs.push_back(sl);
   return BMS_OK;
-}
+} BMS_CATCH(c)
 
 // Diagnostics of the evaluating product: out[0] = tiles and tile-boundary blocks launched since the last reset, out[1] = those whose
 // samples did not fit the window of output abscissae staged in LDS (they search and read the axis in global memory: same results,
 // slower), out[2] = per-column marches that started in the window and had to go on from global memory.
-extern "C" int bms_ctx_get_eval_stats(bms_ctx* c, int64_t* out /*[3]*/, int reset) {
+extern "C" int bms_ctx_get_eval_stats(bms_ctx* c, int64_t* out /*[3]*/, int reset) try {
   if (!c || !out) return BMS_ERR_INVALID;
   HIP_TRY(c, hipSetDevice(c->device));
   unsigned long long h[2] = {0, 0};
@@ -319,16 +339,16 @@ extern "C" int bms_ctx_get_eval_stats(bms_ctx* c, int64_t* out /*[3]*/, int rese
   out[0] = (int64_t)c->eval_tiles, out[1] = (int64_t)h[0], out[2] = (int64_t)h[1];
   if (reset) c->eval_tiles = 0;
   return BMS_OK;
-}
+} BMS_CATCH(c)
 
-extern "C" int bms_ctx_enable_timing(bms_ctx* c, int on) {
+extern "C" int bms_ctx_enable_timing(bms_ctx* c, int on) try {
   if (!c) return BMS_ERR_INVALID;
   c->timing = on != 0;
   return BMS_OK;
-}
+} BMS_CATCH(c)
 
 // accumulate finished event pairs into per-tag totals; returns totals since the last reset
-extern "C" int bms_ctx_get_timing(bms_ctx* c, double* ms /*[BMS_TAG_COUNT]*/, int64_t* calls /*[BMS_TAG_COUNT]*/, int reset) {
+extern "C" int bms_ctx_get_timing(bms_ctx* c, double* ms /*[BMS_TAG_COUNT]*/, int64_t* calls /*[BMS_TAG_COUNT]*/, int reset) try {
   if (!c) return BMS_ERR_INVALID;
   HIP_TRY(c, hipSetDevice(c->device));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -351,11 +371,11 @@ extern "C" int bms_ctx_get_timing(bms_ctx* c, double* ms /*[BMS_TAG_COUNT]*/, in
     }
   }
   return BMS_OK;
-}
+} BMS_CATCH(c)
 
-extern "C" int bms_ctx_synchronize(bms_ctx* c) {
+extern "C" int bms_ctx_synchronize(bms_ctx* c) try {
   if (!c) return BMS_ERR_INVALID;
   HIP_TRY(c, hipSetDevice(c->device));
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   return BMS_OK;
-}
+} BMS_CATCH(c)

@@ -15,12 +15,12 @@ struct PointwiseWM {
 };
 
 extern "C" int bms_transform_modes(bms_ctx* c, const bms_wm_input* in, const bms_transformation* tr, double* t_out,
-                                   void* data_out, int64_t* n_times_out) {
+                                   void* data_out, int64_t* n_times_out) try {
   return bms_transform_modes_shard(c, in, tr, nullptr, t_out, data_out, n_times_out, nullptr);
-}
+} BMS_CATCH(c)
 
 extern "C" int bms_shard_plan(bms_ctx* c, const double* t, int64_t n, const bms_transformation* tr, int64_t out_i0,
-                              int64_t out_i1, int64_t need_rows[2], int64_t window[2]) {
+                              int64_t out_i1, int64_t need_rows[2], int64_t window[2]) try {
   // pure host planning: ctx may be NULL (errors then go to bms_last_error(NULL))
   if (!t || !tr || !need_rows || !window) return fail(c, BMS_ERR_INVALID, "NULL argument");
   int rc = validate_common(c, n, t, tr);
@@ -42,9 +42,9 @@ extern "C" int bms_shard_plan(bms_ctx* c, const double* t, int64_t n, const bms_
   need_rows[0] = std::max<int64_t>(0, ja - margin);
   need_rows[1] = std::min<int64_t>(n, jb + margin + 1);
   return BMS_OK;
-}
+} BMS_CATCH(c)
 
-extern "C" int bms_output_window(bms_ctx* c, const double* t, int64_t n, const bms_transformation* tr, int abd, int64_t window[2]) {
+extern "C" int bms_output_window(bms_ctx* c, const double* t, int64_t n, const bms_transformation* tr, int abd, int64_t window[2]) try {
   if (!c) return BMS_ERR_INVALID;
   if (!t || !tr || !window) return fail(c, BMS_ERR_INVALID, "NULL argument");
   HIP_TRY(c, hipSetDevice(c->device));
@@ -59,18 +59,18 @@ extern "C" int bms_output_window(bms_ctx* c, const double* t, int64_t n, const b
   else
     output_window(T, t, n, window[0], window[1]);
   return BMS_OK;
-}
+} BMS_CATCH(c)
 
 static int transform_modes_impl(bms_ctx* c, const bms_wm_input* in, const bms_transformation* tr, const bms_shard* sh, double* t_out,
                                 void* data_out, int64_t* n_times_out, int64_t* first_index_out, void* grid_out, bool walk_first = false);
 
 extern "C" int bms_transform_modes_shard(bms_ctx* c, const bms_wm_input* in, const bms_transformation* tr,
                                          const bms_shard* sh, double* t_out, void* data_out, int64_t* n_times_out,
-                                         int64_t* first_index_out) {
+                                         int64_t* first_index_out) try {
   if (!c) return BMS_ERR_INVALID;
   if (!data_out) return fail(c, BMS_ERR_INVALID, "NULL argument");
   return with_smaller_chunks(c, [&] { return transform_modes_impl(c, in, tr, sh, t_out, data_out, n_times_out, first_index_out, nullptr); });
-}
+} BMS_CATCH(c)
 
 // Host arrays in, host arrays out, as a three-stage pipeline over time shards of the OUTPUT range: the upload of shard k + 1
 // (its rows + halo, bms_shard_plan), the kernels of shard k and the download of shard k - 1 run on three streams, ordered by
@@ -80,9 +80,9 @@ extern "C" int bms_transform_modes_shard(bms_ctx* c, const bms_wm_input* in, con
 // bms_host_alloc); from pageable memory the runtime stages them.  data_out: host c16[i_hi - i_lo][n_out] (best page-locked).
 // Results are those of the sharded path (equal to the one-call path to rounding).  No psi companions (aux) here.
 extern "C" int bms_transform_modes_pipelined(bms_ctx* c, const bms_wm_input* in, const bms_transformation* tr, int pieces,
-                                             double* t_out, void* data_out, int64_t* n_times_out) {
+                                             double* t_out, void* data_out, int64_t* n_times_out) try {
   return bms_transform_modes_pipelined_part(c, in, tr, pieces, 0, pieces < 1 ? 1 : pieces, t_out, data_out, n_times_out);
-}
+} BMS_CATCH(c)
 
 // The same for pieces [piece0, piece1) of the `pieces` the output window is cut into: t_out / data_out are the arrays of the WHOLE
 // window (every piece lands at its own place), *n_times_out is the whole window's row count.  One process that owns several GPUs
@@ -90,10 +90,14 @@ extern "C" int bms_transform_modes_pipelined(bms_ctx* c, const bms_wm_input* in,
 // context ships its own rows + halo at upload time, so there is no GPU-to-GPU traffic at all, and the results are
 // those of the one-context call with the same `pieces`, bit for bit (a piece's arithmetic depends on its cut only).
 extern "C" int bms_transform_modes_pipelined_part(bms_ctx* c, const bms_wm_input* in, const bms_transformation* tr, int pieces, int piece0,
-                                                  int piece1, double* t_out, void* data_out, int64_t* n_times_out) {
+                                                  int piece1, double* t_out, void* data_out, int64_t* n_times_out) try {
   if (!c) return BMS_ERR_INVALID;
   if (!in || !tr || !t_out || !data_out || !n_times_out) return fail(c, BMS_ERR_INVALID, "NULL argument");
   if (in->mem != BMS_HOST || in->n_aux != 0) return fail(c, BMS_ERR_INVALID, "the pipelined path takes host data without auxiliary fields");
+  if (!in->t || !in->data) return fail(c, BMS_ERR_INVALID, "NULL argument");
+  if (in->ell_min < 0 || in->ell_max < in->ell_min) return fail(c, BMS_ERR_INVALID, "bad ell range");
+  if (in->ld < LM_total_size(in->ell_min, in->ell_max)) return fail(c, BMS_ERR_INVALID, "row stride smaller than the number of modes");
+  if (tr->ell_max_out < std::abs(in->spin_weight)) return fail(c, BMS_ERR_INVALID, "ell_max_out < |s|");
   HIP_TRY(c, hipSetDevice(c->device));
   const int64_t n = in->n_times;
   bool regular = true;
@@ -236,27 +240,27 @@ extern "C" int bms_transform_modes_pipelined_part(bms_ctx* c, const bms_wm_input
   if (rc) return rc;
   if (he != hipSuccess) return fail(c, BMS_ERR_HIP, "pipelined transfer: %s", hipGetErrorString(he));
   return BMS_OK;
-}
+} BMS_CATCH(c)
 
 // One process, several GPUs, ONE call: the `pieces` time shards of the pipelined plan dealt in contiguous runs over the n_ctx contexts
 // (one per device; several on one device are allowed), one host thread each, every context running bms_transform_modes_pipelined_part
 // on its run.  Every device receives its own rows + halo at upload time: no GPU-to-GPU traffic.  The result depends on `pieces` only.
 // On failure the status of the first failing context is returned and its message is copied to ctxs[0] ("context k (device d): ...").
 extern "C" int bms_transform_modes_multi(bms_ctx* const* ctxs, int n_ctx, const bms_wm_input* in, const bms_transformation* tr, int pieces,
-                                         double* t_out, void* data_out, int64_t* n_times_out) {
+                                         double* t_out, void* data_out, int64_t* n_times_out) try {
   return run_dealt_over_contexts(ctxs, n_ctx, pieces, n_times_out, [&](bms_ctx* c, int p0, int p1, int64_t* got) {
     return bms_transform_modes_pipelined_part(c, in, tr, pieces < 1 ? 1 : pieces, p0, p1, t_out, data_out, got);
   });
-}
+} BMS_CATCH(ctxs && n_ctx > 0 ? ctxs[0] : nullptr)
 
 // WaveformGrid.from_modes on its own (scri/waveform_grid.py:331-613): the field on the distorted grid at the new time slices,
 // c16[N'][n_theta * n_phi] in grid order (no column plan), without the analysis back to modes
 extern "C" int bms_modes_to_grid(bms_ctx* c, const bms_wm_input* in, const bms_transformation* tr, double* t_out, void* grid_out,
-                                 int64_t* n_times_out) {
+                                 int64_t* n_times_out) try {
   if (!c) return BMS_ERR_INVALID;
   if (!grid_out) return fail(c, BMS_ERR_INVALID, "NULL argument");
   return with_smaller_chunks(c, [&] { return transform_modes_impl(c, in, tr, nullptr, t_out, nullptr, n_times_out, nullptr, grid_out); });
-}
+} BMS_CATCH(c)
 
 // Several series under ONE transformation (the extra trailing data dimensions of scri/waveform_grid.py:299-308, 574-594: every
 // trailing index is an independent series on the same time axis), in the REFERENCE'S layout: in->data is c16[n_times][in->ld] with
@@ -267,9 +271,11 @@ extern "C" int bms_modes_to_grid(bms_ctx* c, const bms_wm_input* in, const bms_t
 // set up once and shared (the mechanism of the pipelined call's pieces), the kernels run per series, and the results are put back
 // into the reference's layout (blocks_to_series_kernel) before they leave.  No strided copy on the host.
 extern "C" int bms_transform_modes_series(bms_ctx* c, const bms_wm_input* in, int n_series, const bms_transformation* tr, double* t_out,
-                                          void* data_out, void* grid_out, int64_t* n_times_out) {
+                                          void* data_out, void* grid_out, int64_t* n_times_out) try {
   if (!c) return BMS_ERR_INVALID;
   if (!in || !tr || !t_out || !n_times_out || (!data_out == !grid_out)) return fail(c, BMS_ERR_INVALID, "NULL argument (exactly one of data_out / grid_out)");
+  if (!in->t || !in->data) return fail(c, BMS_ERR_INVALID, "NULL argument");
+  if (!valid_mem(in->mem)) return fail(c, BMS_ERR_INVALID, "mem is BMS_HOST or BMS_DEVICE, got %d", in->mem);
   if (n_series < 1) return fail(c, BMS_ERR_INVALID, "n_series must be positive");
   if (in->ell_min < 0 || in->ell_max < in->ell_min || in->n_aux < 0 || in->n_aux > 4) return fail(c, BMS_ERR_INVALID, "bad ell range or n_aux");
   HIP_TRY(c, hipSetDevice(c->device));
@@ -362,11 +368,15 @@ extern "C" int bms_transform_modes_series(bms_ctx* c, const bms_wm_input* in, in
   if (es != hipSuccess || ew != hipSuccess) return fail(c, BMS_ERR_HIP, "bms_transform_modes_series: %s", hipGetErrorString(es != hipSuccess ? es : ew));
   *n_times_out = n_new;
   return BMS_OK;
-}
+} BMS_CATCH(c)
 
 static int transform_modes_impl(bms_ctx* c, const bms_wm_input* in, const bms_transformation* tr, const bms_shard* sh, double* t_out,
                                 void* data_out, int64_t* n_times_out, int64_t* first_index_out, void* grid_out, bool walk_first) {
-  if (!in || !tr || !t_out || !n_times_out) return fail(c, BMS_ERR_INVALID, "NULL argument");
+  if (!in || !tr || !t_out || !n_times_out || !in->t || !in->data) return fail(c, BMS_ERR_INVALID, "NULL argument");
+  if (!valid_mem(in->mem)) return fail(c, BMS_ERR_INVALID, "mem is BMS_HOST or BMS_DEVICE, got %d", in->mem);
+  if (in->n_aux < 0 || in->n_aux > 4) return fail(c, BMS_ERR_INVALID, "0..4 auxiliary fields, got %d", in->n_aux);
+  for (int a = 0; a < in->n_aux; ++a)
+    if (!in->aux_data[a]) return fail(c, BMS_ERR_INVALID, "auxiliary field %d is NULL", a);
   HIP_TRY(c, hipSetDevice(c->device));
   const int64_t n = in->n_times;
   int64_t t_lo, t_hi;
@@ -465,6 +475,7 @@ static int transform_modes_impl(bms_ctx* c, const bms_wm_input* in, const bms_tr
   const int64_t row0 = sh ? sh->data_row0 : 0;
   const int64_t rows_avail = sh ? sh->data_rows : n;
   if (sh && (row0 < 0 || rows_avail < 0 || row0 + rows_avail > n)) return fail(c, BMS_ERR_INVALID, "shard rows outside [0, n_times)");
+  if (sh && sh->out_i1 < sh->out_i0) return fail(c, BMS_ERR_INVALID, "shard output range [%lld, %lld) is reversed", (long long)sh->out_i0, (long long)sh->out_i1);
   // Without psi mixing the map modes -> grid values is linear along the columns with time-independent coefficients, so
   // the spline's forward elimination is done on the modes (B-spline form, kernels_bspline.hip) and the grid is passed over
   // once, by the back substitution + evaluation.

@@ -14,6 +14,7 @@ int rotate_impl(bms_ctx* c, void* data, int mem, int64_t n_times, int64_t ld, in
   const int64_t n_modes = LM_total_size(ell_min, ell_max);
   if (ld < n_modes) return fail(c, BMS_ERR_INVALID, "row stride %lld smaller than %lld modes", (long long)ld, (long long)n_modes);
   if (n_times == 0) return BMS_OK;
+  if (!data) return fail(c, BMS_ERR_INVALID, "NULL data");
   // three kernels: tables resident in the LDS, tables staged per l (l <= 33), VALU beyond.  The l range is walked in
   // segments: as many leading l as fit the LDS-resident kernel (l <= 27 and 160 KB: 2..16 of the headline configurations in
   // one launch, 2..19 and 20..24 of an l <= 24 series), the rest through the staged / VALU kernel -- a segment is a column range of the
@@ -112,17 +113,17 @@ int rotate_impl(bms_ctx* c, void* data, int mem, int64_t n_times, int64_t ld, in
 }
 
 extern "C" int bms_rotate_const(bms_ctx* c, void* data, int mem, int64_t n_times, int64_t ld, int ell_min, int ell_max,
-                                const double q[4]) {
+                                const double q[4]) try {
   if (!c || !q) return BMS_ERR_INVALID;
   const double sp[4] = {q[0], q[3], q[2], q[1]};  // (w + i z, y + i x)
   return rotate_impl(c, data, mem, n_times, ld, ell_min, ell_max, sp, false);
-}
+} BMS_CATCH(c)
 
 extern "C" int bms_rotate_series(bms_ctx* c, void* data, int mem, int64_t n_times, int64_t ld, int ell_min,
-                                 int ell_max, const void* spinors) {
+                                 int ell_max, const void* spinors) try {
   if (!c || !spinors) return BMS_ERR_INVALID;
   return rotate_impl(c, data, mem, n_times, ld, ell_min, ell_max, spinors, true);
-}
+} BMS_CATCH(c)
 
 // The reference's numba kernel takes the packed Wigner matrices it is handed, not a rotor (scri/rotations.py:346-367:
 // `_rotate_decomposition_basis_by_constant(data, ell_min, ell_max, D, tmp)` with D from sf._Wigner_D_matrices, :327):
@@ -131,7 +132,7 @@ extern "C" int bms_rotate_series(bms_ctx* c, void* data, int mem, int64_t n_time
 // panels), out of place into a work buffer, then copied over the input.  This is the seam a binding replaces the numba
 // kernel at; callers that have the rotor use bms_rotate_const, which never forms D.
 extern "C" int bms_rotate_const_D(bms_ctx* c, void* data, int mem, int64_t n_times, int64_t ld, int ell_min, int ell_max,
-                                  const void* D_host) {
+                                  const void* D_host) try {
   if (!c || !data || !D_host) return BMS_ERR_INVALID;
   HIP_TRY(c, hipSetDevice(c->device));
   if (n_times < 0 || ell_min < 0 || ell_max < ell_min) return fail(c, BMS_ERR_INVALID, "bad sizes");
@@ -178,10 +179,10 @@ extern "C" int bms_rotate_const_D(bms_ctx* c, void* data, int mem, int64_t n_tim
   if (mem == BMS_HOST) HIP_TRY(c, hipMemcpyAsync(data, d_data, data_bytes, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(c, hipStreamSynchronize(c->stream));  // B was staged from a host vector
   return BMS_OK;
-}
+} BMS_CATCH(c)
 
 // D matrices through the rotation kernel itself: rotate the identity blocks (row (l, m') = delta_{m'})
-extern "C" int bms_wigner_D(bms_ctx* c, const double q[4], int ell_min, int ell_max, void* D_host) {
+extern "C" int bms_wigner_D(bms_ctx* c, const double q[4], int ell_min, int ell_max, void* D_host) try {
   if (!c || !q || !D_host) return BMS_ERR_INVALID;
   if (ell_min < 0 || ell_max < ell_min) return fail(c, BMS_ERR_INVALID, "bad ell range");
   const int n_modes = LM_total_size(ell_min, ell_max);
@@ -206,4 +207,4 @@ extern "C" int bms_wigner_D(bms_ctx* c, const double q[4], int ell_min, int ell_
       }
   }
   return BMS_OK;
-}
+} BMS_CATCH(c)

@@ -483,12 +483,17 @@ void time_window(int64_t n, const bms_shard* sh, int64_t& lo, int64_t& hi) {
 
 // (the two halves of validate_common, for the caller that has the GPU start on the call before the host walks the time axis)
 int validate_transformation(bms_ctx* c, int64_t n, const double* t, const bms_transformation* tr, int64_t n_min) {
+  if (!t || !tr) return fail(c, BMS_ERR_INVALID, "NULL argument");
   if (n < n_min) return fail(c, BMS_ERR_INVALID, "need at least %lld time steps, got %lld", (long long)n_min, (long long)n);
   if (!(t[n - 1] > t[0])) return fail(c, BMS_ERR_INVALID, "time array must be strictly increasing (first/last)");
   if (tr->n_theta < 2 || tr->n_phi < 1) return fail(c, BMS_ERR_INVALID, "bad grid size %d x %d", tr->n_theta, tr->n_phi);
   if (tr->ell_max_supertranslation < 1 || !tr->supertranslation) return fail(c, BMS_ERR_INVALID, "supertranslation must hold at least l <= 1");
   const double* v = tr->boost_velocity;
   if (!(v[0] * v[0] + v[1] * v[1] + v[2] * v[2] < 1.0)) return fail(c, BMS_ERR_INVALID, "boost speed must be < 1");
+  const double* q = tr->frame_rotation;
+  const double q2 = q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3];
+  if (!(q2 > 0.0) || !std::isfinite(q2)) return fail(c, BMS_ERR_INVALID, "frame_rotation must be a finite quaternion other than zero");
+  if ((long long)tr->n_theta * tr->n_phi > (1LL << 26)) return fail(c, BMS_ERR_UNSUPPORTED, "grid %d x %d: more than 2^26 directions", tr->n_theta, tr->n_phi);
   return BMS_OK;
 }
 int walk_time_axis(bms_ctx* c, const double* t, int64_t lo, int64_t hi, bool* regular) {
@@ -522,6 +527,7 @@ int walk_time_axis(bms_ctx* c, const double* t, int64_t lo, int64_t hi, bool* re
 int validate_common(bms_ctx* c, int64_t n, const double* t, const bms_transformation* tr, int64_t lo, int64_t hi,
                            bool* regular, int64_t n_min) {
   // (order of the checks as it always was: size, first/last, the walk, then the transformation)
+  if (!t || !tr) return fail(c, BMS_ERR_INVALID, "NULL argument");
   if (n < n_min) return fail(c, BMS_ERR_INVALID, "need at least %lld time steps, got %lld", (long long)n_min, (long long)n);
   if (!(t[n - 1] > t[0])) return fail(c, BMS_ERR_INVALID, "time array must be strictly increasing (first/last)");
   int rc = walk_time_axis(c, t, lo, hi < 0 ? n : hi, regular);

@@ -128,6 +128,37 @@ def test_one_hip_runtime_whichever_is_loaded_first():
     assert out.stdout.strip().splitlines()[-1] == "1"
 
 
+def test_no_cpp_exception_crosses_the_boundary():
+    """The callers are C / ctypes: a std::bad_alloc that unwound into them would end the process.  Every entry that returns a status is
+    a function-try-block (engine.h, BMS_CATCH); here a host-only entry is asked for a 1 GiB table under an address-space limit that
+    cannot hold it, in a child process: it must come back with BMS_ERR_NOMEM and a message, not abort."""
+    import subprocess
+    import sys
+
+    from scri_amd import _lib
+
+    code = (
+        "import ctypes, resource, sys; sys.path.insert(0, %r)\n"
+        "from scri_amd import _lib; lib = _lib.load()\n"
+        "vm = int([l for l in open('/proc/self/status') if l.startswith('VmSize')][0].split()[1]) * 1024\n"
+        "resource.setrlimit(resource.RLIMIT_AS, (vm + (256 << 20), resource.getrlimit(resource.RLIMIT_AS)[1]))\n"
+        "fr = (ctypes.c_double * 4)(1, 0, 0, 0); v = (ctypes.c_double * 3)(0, 0, 0.1); out = (ctypes.c_double * 4)()\n"
+        "lib.bms_ring_colatitudes.restype = ctypes.c_int\n"
+        "print(lib.bms_ring_colatitudes(fr, v, 1 << 27, 4, out), lib.bms_last_error(None).decode())\n"
+    ) % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, (out.returncode, out.stderr[-2000:])
+    status, message = out.stdout.strip().splitlines()[-1].split(" ", 1)
+    assert int(status) == _lib.BMS_ERR_NOMEM and "bad_alloc" in message
+    # ... and every status-returning definition in the engine carries the guard
+    csrc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scri_amd", "csrc")
+    for f in sorted(os.listdir(csrc)):
+        if f.startswith("engine_") and f.endswith(".hip"):
+            text = open(os.path.join(csrc, f)).read()
+            for m in re.finditer(r'^extern "C" int (bms_\w+)\(([^{;]*)\)\s*(try\s*)?\{', text, flags=re.M):
+                assert m.group(3) or m.group(1) == "bms_version", f"{f}: {m.group(1)} has no function-try-block"
+
+
 def test_probe_build_carries_the_probe_switches_and_the_same_abi():
     """`make PROBES=1` -> libscri_amd_probes.so: the variant the scripts under tools/probes load through SCRI_AMD_LIB_PATH.  It must keep
     building, export what the header declares, and -- unlike the default library -- contain the knock-out / trace switches."""
