@@ -35,6 +35,12 @@ from ._lib import Context, default_context, BMSError  # noqa: E402,F401
 from . import engine  # noqa: E402,F401
 from .waveform_modes import WaveformModes  # noqa: E402,F401
 from .waveform_grid import WaveformGrid  # noqa: E402,F401
+
+# scri/waveform_grid.py:640-641: the modes <-> grid conversions as capabilities of WaveformModes
+WaveformModes.to_grid = lambda w_modes, **kwargs: WaveformGrid.from_modes(w_modes, **kwargs)
+WaveformModes.from_grid = classmethod(lambda cls, w_grid, ell_max: WaveformGrid.to_modes(w_grid, ell_max))
+WaveformModes.to_grid.__doc__ = WaveformGrid.from_modes.__doc__
+WaveformModes.from_grid.__func__.__doc__ = WaveformGrid.to_modes.__doc__
 from .rotations import rotate_decomposition_basis, rotate_physical_system, to_inertial_frame, to_corotating_frame, to_coprecessing_frame  # noqa: E402,F401
 from .rotations import get_alignment_of_decomposition_frame_to_modes, align_decomposition_frame_to_modes  # noqa: E402,F401
 from .asymptotic_bondi_data import AsymptoticBondiData  # noqa: E402,F401
@@ -86,3 +92,21 @@ def unpatch_scri(scri=None):
     from . import adapters
 
     adapters.uninstall(scri)
+
+# The reference's dotted paths.  There `scri.asymptotic_bondi_data` is a package (bms_charges, constraints, from_initial_values,
+# map_to_abd_frame, map_to_superrest_frame, transformations: scri/asymptotic_bondi_data/__init__.py:235-263) and the readers live under
+# `scri.SpEC`; user code and the tutorials spell those paths out (docs/tutorial_abd.rst:88,340), so they resolve here too.
+from . import asymptotic_bondi_data, map_to_superrest_frame as _superrest, map_to_abd_frame as _abd_frame  # noqa: E402
+from . import bms_charges as _charges, abd_ivp as _ivp  # noqa: E402
+
+import sys as _sys  # noqa: E402
+import types as _types  # noqa: E402
+
+SpEC = _types.ModuleType(__name__ + ".SpEC")
+SpEC.file_io, SpEC.create_abd_from_h5 = file_io, create_abd_from_h5
+for _name, _module in (("map_to_superrest_frame", _superrest), ("map_to_abd_frame", _abd_frame), ("bms_charges", _charges),
+                       ("from_initial_values", _ivp), ("constraints", _ivp), ("transformations", asymptotic_bondi_data)):
+    setattr(asymptotic_bondi_data, _name, _module)
+    _sys.modules[f"{__name__}.asymptotic_bondi_data.{_name}"] = _module  # (`from scri_amd.asymptotic_bondi_data.bms_charges import ...`)
+_sys.modules[__name__ + ".SpEC"] = SpEC
+_sys.modules[__name__ + ".SpEC.file_io"] = file_io

@@ -261,6 +261,7 @@ BMS_INTERNAL int exception_status(bms_ctx* c) noexcept;
   } while (0)
 
 inline bool valid_mem(int mem) { return mem == BMS_HOST || mem == BMS_DEVICE; }
+constexpr int MAX_ELL = 8192;  // 2 (l + 1)^2 fits an int with room; tables of such an l are far beyond any device's memory anyway
 
 BMS_INTERNAL hipError_t create_download_stream(bms_ctx* c);
 BMS_INTERNAL int dev_buf(bms_ctx* c, const char* name, size_t bytes, void** out);

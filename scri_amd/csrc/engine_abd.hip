@@ -35,6 +35,7 @@ static int transform_abd_impl(bms_ctx* c, const double* u, const void* raw, int 
                 "the time steps vary by more than 1e3 within 48 samples: such a series is transformed with exact untiled spline "
                 "recurrences, which a time shard cannot provide");
   if (ell_max < 0 || tr->ell_max_out < 0) return fail(c, BMS_ERR_INVALID, "bad ell_max");
+  if (ell_max > MAX_ELL) return fail(c, BMS_ERR_UNSUPPORTED, "ell_max = %d is beyond %d", ell_max, MAX_ELL);
   static const int spins[6] = {2, 1, 0, -1, -2, 2};  // psi0..psi4, sigma
   const int nm = (ell_max + 1) * (ell_max + 1);
   const int n_out = (tr->ell_max_out + 1) * (tr->ell_max_out + 1);
@@ -365,6 +366,7 @@ extern "C" int bms_transform_abd_pipelined_part(bms_ctx* c, const double* u, con
   if (rc) return rc;
   if (!regular) return fail(c, BMS_ERR_UNSUPPORTED, "the time steps vary by more than 1e3 within 48 samples: not sharded");
   if (ell_max < 0 || tr->ell_max_out < 0) return fail(c, BMS_ERR_INVALID, "bad ell_max");
+  if (ell_max > MAX_ELL) return fail(c, BMS_ERR_UNSUPPORTED, "ell_max = %d is beyond %d", ell_max, MAX_ELL);
   PixelTables T;
   {
     DevPixel DP;

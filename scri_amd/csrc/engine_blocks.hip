@@ -73,6 +73,8 @@ extern "C" int bms_conformal_factors(bms_ctx* c, const double v[3], const double
 
 extern "C" int bms_swsh_grid(bms_ctx* c, const double* rotors, int64_t n, int spin, int ell_min, int ell_max, void* Y) try {
   if (!rotors || !Y) return BMS_ERR_INVALID;
+  if (n < 0 || ell_min < 0 || ell_max < ell_min) return fail(c, BMS_ERR_INVALID, "bad sizes");
+  if (ell_max > MAX_ELL) return fail(c, BMS_ERR_UNSUPPORTED, "ell_max = %d is beyond %d", ell_max, MAX_ELL);
   if (!c) {  // host evaluation of the same header the kernel compiles (wigner.h: SwshChain), as bms_rotor_grid(ctx = NULL)
     const int nm = LM_total_size(ell_min, ell_max);
     cplx* out = (cplx*)Y;
@@ -109,6 +111,7 @@ extern "C" int bms_map2salm(bms_ctx* c, const void* grid, int mem, int64_t n_map
   if (!c || !grid || !modes_out) return BMS_ERR_INVALID;
   HIP_TRY(c, hipSetDevice(c->device));
   if (n_theta < 2 || n_phi < 1 || ell_min < 0 || ell_max < ell_min) return fail(c, BMS_ERR_INVALID, "bad sizes");
+  if (ell_max > MAX_ELL || (long long)n_theta * n_phi > (1LL << 26)) return fail(c, BMS_ERR_UNSUPPORTED, "ell_max = %d on %d x %d: too large", ell_max, n_theta, n_phi);
   if (n_maps <= 0) return BMS_OK;
   const int n_pix = n_theta * n_phi, n_out = LM_total_size(ell_min, ell_max);
   int rc;
@@ -223,6 +226,7 @@ extern "C" int bms_angular_velocity(bms_ctx* c, const double* t, int64_t n, cons
   HIP_TRY(c, hipSetDevice(c->device));
   if (n < 4) return fail(c, BMS_ERR_UNSUPPORTED, "the time derivative needs at least 4 time steps, got %lld", (long long)n);
   if (ell_min < 0 || ell_max < ell_min) return fail(c, BMS_ERR_INVALID, "bad ell range");
+  if (ell_max > MAX_ELL) return fail(c, BMS_ERR_UNSUPPORTED, "ell_max = %d is beyond %d", ell_max, MAX_ELL);
   const int n_modes = LM_total_size(ell_min, ell_max);
   if (ld < n_modes) return fail(c, BMS_ERR_INVALID, "row stride smaller than the number of modes");
   for (int64_t i = 1; i < n; ++i)
@@ -346,6 +350,7 @@ extern "C" int bms_salm2map(bms_ctx* c, const void* modes, int mem, int64_t n_ma
   if (!c || !modes || !grid_out) return BMS_ERR_INVALID;
   HIP_TRY(c, hipSetDevice(c->device));
   if (ell_max < 0 || n_theta < 2 || n_phi < 1 || std::abs(spin) > 4) return fail(c, BMS_ERR_INVALID, "bad sizes");
+  if (ell_max > MAX_ELL || (long long)n_theta * n_phi > (1LL << 26)) return fail(c, BMS_ERR_UNSUPPORTED, "ell_max = %d on %d x %d: too large", ell_max, n_theta, n_phi);
   if (n_maps <= 0) return BMS_OK;
   const int n_pix = n_theta * n_phi, nm = (ell_max + 1) * (ell_max + 1);
   hipStream_t S = c->stream;
@@ -480,6 +485,7 @@ extern "C" int bms_grid_multiply(bms_ctx* c, const void* a, int spin_a, int ell_
   HIP_TRY(c, hipSetDevice(c->device));
   if (ell_max_a < 0 || ell_max_b < 0 || working_ell_max < 1 || output_ell_max < 0 || output_ell_max > working_ell_max)
     return fail(c, BMS_ERR_INVALID, "bad l ranges (need 0 <= output_ell_max <= working_ell_max)");
+  if (ell_max_a > MAX_ELL || ell_max_b > MAX_ELL || working_ell_max > MAX_ELL) return fail(c, BMS_ERR_UNSUPPORTED, "l beyond %d", MAX_ELL);
   // (factors up to |s| = 4, as bms_salm2map / bms_map2salm take them: the boost flux multiplies ethbar h, s = -3)
   if (std::abs(spin_a) > 4 || std::abs(spin_b) > 4 || std::abs(spin_a + spin_b) > 4)
     return fail(c, BMS_ERR_UNSUPPORTED, "spin weights beyond +-4 are not supported");

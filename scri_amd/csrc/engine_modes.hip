@@ -96,6 +96,7 @@ extern "C" int bms_transform_modes_pipelined_part(bms_ctx* c, const bms_wm_input
   if (in->mem != BMS_HOST || in->n_aux != 0) return fail(c, BMS_ERR_INVALID, "the pipelined path takes host data without auxiliary fields");
   if (!in->t || !in->data) return fail(c, BMS_ERR_INVALID, "NULL argument");
   if (in->ell_min < 0 || in->ell_max < in->ell_min) return fail(c, BMS_ERR_INVALID, "bad ell range");
+  if (in->ell_max > MAX_ELL) return fail(c, BMS_ERR_UNSUPPORTED, "ell_max = %d is beyond %d", in->ell_max, MAX_ELL);
   if (in->ld < LM_total_size(in->ell_min, in->ell_max)) return fail(c, BMS_ERR_INVALID, "row stride smaller than the number of modes");
   if (tr->ell_max_out < std::abs(in->spin_weight)) return fail(c, BMS_ERR_INVALID, "ell_max_out < |s|");
   HIP_TRY(c, hipSetDevice(c->device));
@@ -278,6 +279,7 @@ extern "C" int bms_transform_modes_series(bms_ctx* c, const bms_wm_input* in, in
   if (!valid_mem(in->mem)) return fail(c, BMS_ERR_INVALID, "mem is BMS_HOST or BMS_DEVICE, got %d", in->mem);
   if (n_series < 1) return fail(c, BMS_ERR_INVALID, "n_series must be positive");
   if (in->ell_min < 0 || in->ell_max < in->ell_min || in->n_aux < 0 || in->n_aux > 4) return fail(c, BMS_ERR_INVALID, "bad ell range or n_aux");
+  if (in->ell_max > MAX_ELL) return fail(c, BMS_ERR_UNSUPPORTED, "ell_max = %d is beyond %d", in->ell_max, MAX_ELL);
   HIP_TRY(c, hipSetDevice(c->device));
   const int64_t n = in->n_times;
   if (n < 1) return fail(c, BMS_ERR_INVALID, "n_times must be positive");
@@ -418,6 +420,7 @@ static int transform_modes_impl(bms_ctx* c, const bms_wm_input* in, const bms_tr
   trace0.mark("time upload + spline factors (enqueue), checks");
   const int s = in->spin_weight;
   if (in->ell_min < 0 || in->ell_max < in->ell_min) return fail(c, BMS_ERR_INVALID, "bad ell range");
+  if (in->ell_max > MAX_ELL) return fail(c, BMS_ERR_UNSUPPORTED, "ell_max = %d is beyond %d", in->ell_max, MAX_ELL);
   const int n_modes = LM_total_size(in->ell_min, in->ell_max);
   if (in->ld < n_modes) return fail(c, BMS_ERR_INVALID, "row stride smaller than the number of modes");
   if (tr->ell_max_out < std::abs(s)) return fail(c, BMS_ERR_INVALID, "ell_max_out < |s|");

@@ -11,6 +11,7 @@ int rotate_impl(bms_ctx* c, void* data, int mem, int64_t n_times, int64_t ld, in
   if (!c) return BMS_ERR_INVALID;
   HIP_TRY(c, hipSetDevice(c->device));
   if (n_times < 0 || ell_min < 0 || ell_max < ell_min) return fail(c, BMS_ERR_INVALID, "bad sizes");
+  if (ell_max > MAX_ELL) return fail(c, BMS_ERR_UNSUPPORTED, "ell_max = %d is beyond %d", ell_max, MAX_ELL);
   const int64_t n_modes = LM_total_size(ell_min, ell_max);
   if (ld < n_modes) return fail(c, BMS_ERR_INVALID, "row stride %lld smaller than %lld modes", (long long)ld, (long long)n_modes);
   if (n_times == 0) return BMS_OK;
@@ -136,6 +137,7 @@ extern "C" int bms_rotate_const_D(bms_ctx* c, void* data, int mem, int64_t n_tim
   if (!c || !data || !D_host) return BMS_ERR_INVALID;
   HIP_TRY(c, hipSetDevice(c->device));
   if (n_times < 0 || ell_min < 0 || ell_max < ell_min) return fail(c, BMS_ERR_INVALID, "bad sizes");
+  if (ell_max > MAX_ELL) return fail(c, BMS_ERR_UNSUPPORTED, "ell_max = %d is beyond %d", ell_max, MAX_ELL);
   const int64_t n_modes = LM_total_size(ell_min, ell_max);
   if (ld < n_modes) return fail(c, BMS_ERR_INVALID, "row stride %lld smaller than %lld modes", (long long)ld, (long long)n_modes);
   if (n_times == 0) return BMS_OK;
@@ -185,6 +187,7 @@ extern "C" int bms_rotate_const_D(bms_ctx* c, void* data, int mem, int64_t n_tim
 extern "C" int bms_wigner_D(bms_ctx* c, const double q[4], int ell_min, int ell_max, void* D_host) try {
   if (!c || !q || !D_host) return BMS_ERR_INVALID;
   if (ell_min < 0 || ell_max < ell_min) return fail(c, BMS_ERR_INVALID, "bad ell range");
+  if (ell_max > MAX_ELL) return fail(c, BMS_ERR_UNSUPPORTED, "ell_max = %d is beyond %d", ell_max, MAX_ELL);
   const int n_modes = LM_total_size(ell_min, ell_max);
   const int n_rows = 2 * ell_max + 1;  // row r: in every l block, unit vector at m' = r - l_max (if |m'| <= l)
   std::vector<double> buf((size_t)n_rows * n_modes * 2, 0.0);

@@ -493,6 +493,8 @@ int validate_transformation(bms_ctx* c, int64_t n, const double* t, const bms_tr
   const double* q = tr->frame_rotation;
   const double q2 = q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3];
   if (!(q2 > 0.0) || !std::isfinite(q2)) return fail(c, BMS_ERR_INVALID, "frame_rotation must be a finite quaternion other than zero");
+  if (tr->ell_max_out > MAX_ELL || tr->ell_max_supertranslation > MAX_ELL)
+    return fail(c, BMS_ERR_UNSUPPORTED, "ell_max_out = %d / ell_max_supertranslation = %d beyond %d", tr->ell_max_out, tr->ell_max_supertranslation, MAX_ELL);
   if ((long long)tr->n_theta * tr->n_phi > (1LL << 26)) return fail(c, BMS_ERR_UNSUPPORTED, "grid %d x %d: more than 2^26 directions", tr->n_theta, tr->n_phi);
   return BMS_OK;
 }

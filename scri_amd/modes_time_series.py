@@ -99,6 +99,14 @@ class ModesTimeSeries(np.ndarray):
     def ndarray(self):
         return self.view(np.ndarray)
 
+    def index(self, ell, m):
+        """Index of the (ell, m) mode along the last axis (spherical_functions.Modes.index; docs/tutorial_abd.rst:138)."""
+        from .mode_algebra import LM_index
+
+        if ell < self.ell_min or ell > self.ell_max or abs(m) > ell:
+            raise ValueError(f"Requested (ell,m)=({ell},{m}) value is not found in this Modes object")
+        return LM_index(ell, m, self.ell_min)
+
     @property
     def LM(self):
         return LM_range(self.ell_min, self.ell_max)

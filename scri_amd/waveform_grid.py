@@ -318,14 +318,35 @@ class WaveformGrid:
     `to_modes` analyses it back, `transform` does both.  data: complex [n_times, n_theta * n_phi, ...], theta-major; extra
     trailing dimensions are independent series (scri/waveform_grid.py:299-308, 574-594)."""
 
-    def __init__(self, t, data, n_theta, n_phi, frameType, dataType, r_is_scaled_out, m_is_scaled_out, history=(), ctx=None,
-                 constructor_statement=None):
-        self.t = np.array(t, dtype=float)
-        self.data = np.asarray(data, dtype=complex)
+    def __init__(self, t=None, data=None, n_theta=0, n_phi=0, frameType=None, dataType=None, r_is_scaled_out=False, m_is_scaled_out=False,
+                 history=(), ctx=None, constructor_statement=None, frame=None):
+        # Keywords with the reference's defaults (scri/waveform_base.py:220-231, waveform_grid.py:194-199), or one WaveformGrid to copy
+        # (waveform_base.py:240-252); the positional order is this package's own.
+        from . import UnknownDataType, UnknownFrameType
+
+        if isinstance(t, WaveformGrid):
+            if data is not None:
+                raise ValueError(
+                    "Did not understand input arguments to `WaveformGrid` constructor.\n"
+                    "Note that explicit data values must be passed as keywords,\n"
+                    "whereas objects to be copied must be passed as the sole argument."
+                )
+            o = t
+            t, data, n_theta, n_phi, frame = o.t.copy(), o.data.copy(), o.n_theta, o.n_phi, np.array(o.frame, copy=True)
+            frameType, dataType, r_is_scaled_out, m_is_scaled_out = o.frameType, o.dataType, o.r_is_scaled_out, o.m_is_scaled_out
+            history, ctx, constructor_statement = o.history, o._ctx, f"WaveformGrid({o})"
+        self.t = np.array(np.empty((0,)) if t is None else t, dtype=float)
+        self.data = np.asarray(np.empty((0, 0)) if data is None else data, dtype=complex)
         self.n_theta, self.n_phi = int(n_theta), int(n_phi)
-        self.frameType, self.dataType = frameType, dataType
+        self.frame = np.zeros((0, 4)) if frame is None or np.size(frame) == 0 else np.atleast_2d(quaternions.as_float_array(frame)).copy()
+        self.frameType = UnknownFrameType if frameType is None else frameType
+        self.dataType = UnknownDataType if dataType is None else dataType
         self.r_is_scaled_out, self.m_is_scaled_out = bool(r_is_scaled_out), bool(m_is_scaled_out)
-        self.history = list(history) + [constructor_statement or "WaveformGrid(...)"]
+        from .waveform_modes import _next_num  # (one counter for both containers, as the reference's WaveformBase keeps)
+
+        _next_num[0] += 1
+        self.num = _next_num[0]
+        self.history = list(history) + [f"{self} = {constructor_statement or 'WaveformGrid(...)'}"]
         self._ctx = ctx
         if self.data.ndim < 2 or self.data.shape[:2] != (self.t.size, self.n_theta * self.n_phi):
             raise ValueError(f"data.shape={self.data.shape} does not agree with n_times={self.t.size}, n_theta*n_phi={self.n_theta * self.n_phi}")
@@ -412,3 +433,16 @@ class WaveformGrid:
         """from_modes(...).to_modes(ell_max), `ell_max` defaulting to the input's (scri/waveform_grid.py:615-630); the fused
         engine call of the module-level `transform`."""
         return transform(w_modes, **kwargs)
+
+    def __str__(self):
+        return f"{type(self).__name__}_{self.num}"
+
+    def __repr__(self):
+        opts = np.get_printoptions()
+        np.set_printoptions(threshold=6, linewidth=150, precision=6)
+        try:
+            rep = (f"{type(self).__name__}(\n    t={self.t},\n    data={str(self.data)},\n    frameType={self.frameType}, dataType={self.dataType},\n"
+                   f"    r_is_scaled_out={self.r_is_scaled_out}, m_is_scaled_out={self.m_is_scaled_out})  # num = {self.num}")
+        finally:
+            np.set_printoptions(**opts)
+        return rep + f"\n# n_theta={self.n_theta}, n_phi={self.n_phi}"

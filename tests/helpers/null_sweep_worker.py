@@ -99,10 +99,10 @@ def structs(_mode):
     }
     nan = float("nan")
     wm_wrong = [("t", None), ("data", None), ("mem", 7), ("n_times", -1), ("n_times", 3), ("ld", nm - 1), ("ell_min", -1),
-                ("ell_max", lmin - 1), ("n_aux", 5), ("n_aux", -1), ("n_aux", 1), ("type_term", _lib.BMS_TERM_PSI)]
+                ("ell_max", lmin - 1), ("n_aux", 5), ("n_aux", -1), ("n_aux", 1), ("type_term", _lib.BMS_TERM_PSI), ("ell_max", 60000)]
     tr_wrong = [("supertranslation", None), ("ell_max_supertranslation", 0), ("frame_rotation", (0.0, 0.0, 0.0, 0.0)),
                 ("frame_rotation", (nan, 0.0, 0.0, 0.0)), ("boost_velocity", (0.0, 0.0, 1.0)), ("boost_velocity", (nan, 0.0, 0.0)),
-                ("n_theta", 1), ("n_phi", 0), ("ell_max_out", 1), ("n_theta", 40000)]
+                ("n_theta", 1), ("n_phi", 0), ("ell_max_out", 1), ("n_theta", 40000), ("ell_max_out", 60000)]
     count = 0
     for name, call in entries.items():
         out[:] = 0
@@ -155,7 +155,7 @@ def structs(_mode):
         print(abd(**kw), flush=True)
         count += 1
     for field, value in tr_wrong:
-        if field == "ell_max_out":
+        if field == "ell_max_out" and value == 1:
             value = -1
         T = engine.make_transformation(st, (1.0, 0.0, 0.0, 0.0), (0.0, 0.0, 0.1), 2 * L + 1, 2 * L + 1, L)
         if field == "n_theta" and value == 40000:

@@ -96,6 +96,13 @@ def test_waveform_grid_from_modes_and_to_modes(ctx):
         scri_amd.WaveformGrid.from_modes(w3, **kw)
     with pytest.raises(TypeError):
         scri_amd.WaveformGrid.from_modes(data, **kw)
+    # the two capabilities the reference hangs on WaveformModes (scri/waveform_grid.py:640-641), and a copy of a grid object
+    g2 = w_g.to_grid(**kw)
+    assert np.array_equal(g2.data, g.data) and np.array_equal(g2.t, g.t) and (g2.n_theta, g2.n_phi) == (g.n_theta, g.n_phi)
+    back = scri_amd.WaveformModes.from_grid(g, ell_max)
+    assert isinstance(back, scri_amd.WaveformModes) and np.array_equal(back.data, two_steps.data)
+    g3 = scri_amd.WaveformGrid(g)
+    assert np.array_equal(g3.data, g.data) and g3.data is not g.data and g3.num != g.num and g3.dataType == g.dataType
 
 
 def test_pipelined_host_path_matches_the_one_call_path(ctx, monkeypatch):

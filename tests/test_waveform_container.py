@@ -194,3 +194,61 @@ def test_pickling_and_repr():
         assert clone.history[: len(W.history)] == W.history and "unpickled as" in clone.history[len(W.history)]
     text = repr(W)
     assert text.strip().startswith("WaveformModes(") and f"# num = {W.num}" in text and "frameType=4, dataType=7" in text
+
+
+def test_waveform_grid_constructor_forms():
+    """scri.WaveformGrid takes keywords with defaults, or one object to copy (scri/waveform_base.py:220-258, waveform_grid.py:194-199);
+    the tutorial's statement (docs/tutorial_waveformmodes.rst:74-83) word for word"""
+    import scri_amd as scri
+
+    my_strain_grid_data = np.zeros((100, 144), dtype=complex)
+    h = scri.WaveformGrid(
+        dataType=scri.h,
+        t=np.linspace(0, 10, 100),
+        data=my_strain_grid_data,
+        n_theta=12,
+        n_phi=12,
+        frameType=scri.Inertial,
+        r_is_scaled_out=True,
+        m_is_scaled_out=True,
+    )
+    assert (h.n_theta, h.n_phi, h.n_times) == (12, 12, 100) and h.spin_weight == -2
+    assert str(h).startswith("WaveformGrid_") and repr(h).endswith("# n_theta=12, n_phi=12")
+    empty = scri.WaveformGrid()
+    assert empty.n_times == 0 and empty.dataType == scri.UnknownDataType and empty.frameType == scri.UnknownFrameType
+    assert not empty.r_is_scaled_out and not empty.m_is_scaled_out and (empty.n_theta, empty.n_phi) == (0, 0)
+    copy = scri.WaveformGrid(h)
+    assert copy.num != h.num and copy.history[-1] == f"{copy} = WaveformGrid({h})" and copy.history[:-1] == h.history
+    with pytest.raises(ValueError, match="objects to be copied must be passed as the sole argument"):
+        scri.WaveformGrid(h, my_strain_grid_data)
+    with pytest.raises(ValueError, match="does not agree"):
+        scri.WaveformGrid(t=np.linspace(0, 1, 5), data=np.zeros((5, 10), dtype=complex), n_theta=3, n_phi=3)
+    assert callable(scri.WaveformModes.to_grid) and callable(scri.WaveformModes.from_grid)
+
+
+def test_the_references_dotted_paths_resolve():
+    """scri/asymptotic_bondi_data/ is a package in the reference and the readers live under scri.SpEC; code written against it spells
+    the paths out (docs/tutorial_abd.rst:88,340; scri/asymptotic_bondi_data/__init__.py:235-263)"""
+    import importlib
+
+    import scri_amd as scri
+
+    for path, names in (
+        ("asymptotic_bondi_data", ["AsymptoticBondiData"]),
+        ("asymptotic_bondi_data.map_to_superrest_frame", ["map_to_superrest_frame", "MT_to_WM", "WM_to_MT"]),
+        ("asymptotic_bondi_data.map_to_abd_frame", ["map_to_abd_frame"]),
+        ("asymptotic_bondi_data.bms_charges", ["mass_aspect", "bondi_four_momentum", "supermomentum"]),
+        ("asymptotic_bondi_data.from_initial_values", ["from_initial_values"]),
+        ("asymptotic_bondi_data.constraints", ["bondi_constraints", "bondi_violation_norms"]),
+        ("asymptotic_bondi_data.transformations", ["AsymptoticBondiData"]),
+        ("SpEC.file_io", ["create_abd_from_h5"]),
+        ("bms_transformations", ["BMSTransformation", "LorentzTransformation"]),
+        ("modes_time_series", ["ModesTimeSeries"]),
+    ):
+        module = importlib.import_module("scri_amd." + path)
+        obj = scri
+        for part in path.split("."):
+            obj = getattr(obj, part)
+        assert obj is module, path
+        for n in names:
+            assert hasattr(module, n), (path, n)
