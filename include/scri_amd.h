@@ -295,6 +295,11 @@ int bms_swsh_grid(bms_ctx* ctx, const double* rotors_host /* f8[n][4] */, int64_
 /* spinsfast.map2salm(grid[n_maps][n_theta][n_phi], s, ell_max)[..., ell_min^2:] (waveform_grid.py:303-307) */
 int bms_map2salm(bms_ctx* ctx, const void* grid, int mem, int64_t n_maps, int n_theta, int n_phi, int spin,
                  int ell_min, int ell_max, void* modes_out);
+/* sf.Modes.evaluate(R): out[t][p] = sum_k modes[t][k] sY_k(R_p) at arbitrary rotors -- the dense contraction of
+ * scri/asymptotic_bondi_data/transformations.py:312-334, waveform_grid.py:475-484, bms_transformations.py:179 on its own.
+ * modes: c16[n_rows][ld] with l = ell_min..ell_max; rotors: host f8[n_rotors][4]; out: c16[n_rows][n_rotors] in `mem`. */
+int bms_evaluate_modes(bms_ctx* ctx, const void* modes, int mem, int64_t n_rows, int64_t ld, int spin, int ell_min,
+                       int ell_max, const double* rotors_host, int64_t n_rotors, void* out);
 /* spinsfast.salm2map(modes[n_maps][(ell_max+1)^2], s, ell_max, n_theta, n_phi) -> c16[n_maps][n_theta][n_phi] */
 int bms_salm2map(bms_ctx* ctx, const void* modes, int mem, int64_t n_maps, int spin, int ell_max, int n_theta, int n_phi,
                  void* grid_out);

@@ -157,6 +157,7 @@ SIGNATURES = {
     "bms_multishuffle": (c_int, [c_vp, c_vp, c_vp, c_int, c_i64, ctypes.POINTER(c_int), c_int, c_int]),
     "bms_fletcher32": (c_int, [c_vp, c_vp, c_int, c_i64, ctypes.POINTER(ctypes.c_uint32)]),
     "bms_salm2map": (c_int, [c_vp, c_vp, c_int, c_i64, c_int, c_int, c_int, c_int, c_vp]),
+    "bms_evaluate_modes": (c_int, [c_vp, c_vp, c_int, c_i64, c_i64, c_int, c_int, c_int, c_dp, c_i64, c_vp]),
     "bms_mode_map": (c_int, [c_vp, c_vp, c_i64, c_i64, c_int, c_vp, c_i64, ctypes.POINTER(ctypes.c_int32), c_vp, c_int, c_vp, c_i64,
                               ctypes.POINTER(ctypes.c_int32), c_vp, c_int, c_vp, c_int]),
     "bms_row_norm": (c_int, [c_vp, c_vp, c_i64, c_i64, c_int, c_int, c_int, c_vp]),

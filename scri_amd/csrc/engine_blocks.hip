@@ -391,6 +391,46 @@ extern "C" int bms_salm2map(bms_ctx* c, const void* modes, int mem, int64_t n_ma
   return BMS_OK;
 } BMS_CATCH(c)
 
+// sf.Modes.evaluate(R): the field at arbitrary directions / frames, out[t][p] = sum_k modes[t][k] sY_k(R_p) -- the dense contraction of
+// scri/asymptotic_bondi_data/transformations.py:312-334 (`self.psi0.evaluate(distorted_grid_rotors)`), waveform_grid.py:475-484 and
+// bms_transformations.py:179 as a building block of its own: the harmonics at the rotors (swsh_kernel) and one 3M product on the matrix
+// cores.  modes: c16[n_rows][ld] holding l = ell_min..ell_max; rotors: host f8[n_rotors][4]; out: c16[n_rows][n_rotors], where `mem` says.
+extern "C" int bms_evaluate_modes(bms_ctx* c, const void* modes, int mem, int64_t n_rows, int64_t ld, int spin, int ell_min, int ell_max,
+                                  const double* rotors, int64_t n_rotors, void* out) try {
+  if (!c || !modes || !rotors || !out) return BMS_ERR_INVALID;
+  HIP_TRY(c, hipSetDevice(c->device));
+  if (!valid_mem(mem)) return fail(c, BMS_ERR_INVALID, "mem is BMS_HOST or BMS_DEVICE, got %d", mem);
+  if (n_rows < 0 || n_rotors < 0 || ell_min < 0 || ell_max < ell_min) return fail(c, BMS_ERR_INVALID, "bad sizes");
+  if (ell_max > MAX_ELL || n_rotors > (1LL << 26)) return fail(c, BMS_ERR_UNSUPPORTED, "ell_max = %d at %lld directions: too large", ell_max, (long long)n_rotors);
+  const int nm = LM_total_size(ell_min, ell_max);
+  if (ld < nm) return fail(c, BMS_ERR_INVALID, "row stride smaller than the number of modes");
+  if (n_rows == 0 || n_rotors == 0) return BMS_OK;
+  hipStream_t S = c->stream;
+  int rc;
+  void* d_rot;
+  if ((rc = upload(c, "ev_rotors", rotors, 32 * (size_t)n_rotors, &d_rot))) return rc;
+  const int n_pix = (int)n_rotors;
+  const long long ldb = 2 * round_up(n_pix, 64), k_pad = round_up(nm, 8);
+  double* d_B;
+  if ((rc = dev_buf_t(c, "ev_B", (size_t)k_pad * ldb, &d_B))) return rc;
+  HIP_TRY(c, hipMemsetAsync(d_B, 0, sizeof(double) * k_pad * ldb, S));  // (padding, and the rows l < |s| the harmonics do not have)
+  TIMED(c, BMS_TAG_SETUP, launch_swsh_matrix_complex(S, (const double*)d_rot, n_pix, spin, ell_min, ell_max, d_B, ldb));
+  const double* d_a = (const double*)modes;
+  long long lda = 2 * ld;
+  double* d_out = (double*)out;
+  if (mem == BMS_HOST) {
+    double* a;
+    if ((rc = dev_buf_t(c, "in_data", (size_t)n_rows * nm * 2, &a))) return rc;
+    HIP_TRY(c, hipMemcpy2DAsync(a, (size_t)nm * 16, modes, (size_t)ld * 16, (size_t)nm * 16, (size_t)n_rows, hipMemcpyHostToDevice, S));
+    d_a = a, lda = 2LL * nm;
+    if ((rc = dev_buf_t(c, "out_data", (size_t)n_rows * n_pix * 2, &d_out))) return rc;
+  }
+  TIMED(c, BMS_TAG_GEMM_SYNTHESIS, launch_zgemm3m(S, d_a, lda, d_B, ldb, d_out, 2LL * n_pix, n_rows, n_pix, nm, nullptr, nullptr));
+  if (mem == BMS_HOST) HIP_TRY(c, hipMemcpyAsync(out, d_out, (size_t)n_rows * n_pix * 16, hipMemcpyDeviceToHost, S));
+  HIP_TRY(c, hipStreamSynchronize(S));  // (the rotors were staged from the caller's array)
+  return BMS_OK;
+} BMS_CATCH(c)
+
 // Mode-space operators of sf.Modes / ModesTimeSeries (eth, ethbar, bar, real, sums of different l ranges, scalar and per-row
 // factors) as one map along the mode axis, see kernels_modes.hip.  Tables idx_* / coef_* are host arrays of n_cols entries;
 // a, b, out and row_scale live in `mem`.  b may be NULL (one-sided map); out may alias neither input unless every idx is

@@ -688,6 +688,26 @@ def swsh_grid(rotors, spin, ell_min, ell_max, ctx=None, host=False):
     return out.reshape(shape + (out.shape[1],))
 
 
+def evaluate_modes(modes, spin, ell_min, ell_max, rotors, ctx=None):
+    """sf.Modes(modes, spin_weight=s, ell_min, ell_max).evaluate(R): modes[..., n_modes] at rotors[..., 4] -> [..., *rotors.shape[:-1]]
+    (the harmonics at the rotors and one product on the matrix cores: bms_evaluate_modes)."""
+    ctx = _ctx(ctx)
+    a = _lib.as_c16(modes)
+    nm = LM_total_size(ell_min, ell_max)
+    if a.shape[-1] != nm:
+        raise ValueError(f"modes must hold l = {ell_min}..{ell_max} ({nm} columns), got {a.shape[-1]}")
+    R = np.ascontiguousarray(rotors, dtype=float)
+    if R.shape[-1] != 4:
+        raise ValueError("rotors must be float quaternions [..., 4]")
+    R2 = R.reshape(-1, 4)
+    a2 = a.reshape(-1, nm)
+    out = np.empty((a2.shape[0], R2.shape[0]), dtype=np.complex128)
+    rc = _lib.load().bms_evaluate_modes(ctx.handle, vptr(a2), BMS_HOST, a2.shape[0], nm, int(spin), int(ell_min), int(ell_max), dptr(R2),
+                                        R2.shape[0], vptr(out))
+    ctx.check(rc, "bms_evaluate_modes")
+    return out.reshape(a.shape[:-1] + R.shape[:-1])
+
+
 def map2salm(grid, spin, ell_max, ell_min=0, ctx=None):
     """spinsfast.map2salm(grid[..., n_theta, n_phi], s, ell_max)[..., ell_min^2:]."""
     ctx = _ctx(ctx)

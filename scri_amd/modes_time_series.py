@@ -24,6 +24,67 @@ def _bar_tables(ell_min, ell_max, s):
     return perm, sign
 
 
+class Grid(np.ndarray):
+    """Values of a spin-weighted function on an equiangular (theta, phi) grid -- the last two axes -- with its spin weight `s`: what
+    `ModesTimeSeries.grid()` returns (the part of spherical_functions.Grid the charge and frame-fixing code relies on,
+    scri/asymptotic_bondi_data/map_to_superrest_frame.py:173: `PsiM.grid().real`).  Products add the weights, quotients subtract them,
+    conjugation flips the sign, sums want equal weights."""
+
+    def __new__(cls, values, spin_weight=0):
+        obj = np.asarray(values).view(cls)
+        obj._s = int(spin_weight)
+        return obj
+
+    def __array_finalize__(self, obj):
+        self._s = getattr(obj, "_s", 0)
+
+    @property
+    def s(self):
+        return self._s
+
+    spin_weight = s
+
+    @property
+    def n_theta(self):
+        return self.shape[-2]
+
+    @property
+    def n_phi(self):
+        return self.shape[-1]
+
+    @property
+    def ndarray(self):
+        return self.view(np.ndarray)
+
+    def __array_ufunc__(self, ufunc, method, *inputs, **kwargs):
+        weights = [x._s for x in inputs if isinstance(x, Grid)]
+        plain = [x.view(np.ndarray) if isinstance(x, Grid) else x for x in inputs]
+        if "out" in kwargs:
+            kwargs["out"] = tuple(o.view(np.ndarray) if isinstance(o, Grid) else o for o in kwargs["out"])
+        result = getattr(ufunc, method)(*plain, **kwargs)
+        if method != "__call__" or not isinstance(result, np.ndarray) or result.ndim < 2:
+            return result
+        if ufunc is np.multiply:
+            s = sum(weights)
+        elif ufunc in (np.divide, np.true_divide):
+            s = (inputs[0]._s if isinstance(inputs[0], Grid) else 0) - (inputs[1]._s if isinstance(inputs[1], Grid) else 0)
+        elif ufunc is np.conjugate:
+            s = -weights[0]
+        elif ufunc in (np.add, np.subtract) and len(set(weights)) > 1:
+            raise ValueError(f"The grids have spin weights {weights[0]} and {weights[1]}; their sum is not a spin-weighted function")
+        else:
+            s = weights[0]
+        return Grid(result, spin_weight=s)
+
+    @property
+    def real(self):
+        return Grid(self.view(np.ndarray).real, spin_weight=self._s)
+
+    @property
+    def imag(self):
+        return Grid(self.view(np.ndarray).imag, spin_weight=self._s)
+
+
 class ModesTimeSeries(np.ndarray):
     """complex ndarray [..., n_times, n_modes] + {time, spin_weight, ell_min, ell_max}."""
 
@@ -110,6 +171,35 @@ class ModesTimeSeries(np.ndarray):
     @property
     def LM(self):
         return LM_range(self.ell_min, self.ell_max)
+
+    def evaluate(self, *directions, ctx=None):
+        """The function at the given directions or frames (spherical_functions.Modes.evaluate, the contraction of
+        scri/asymptotic_bondi_data/transformations.py:312-334): one argument of rotors [..., 4] (or of [..., 2] = (theta, phi) pairs), or
+        two arguments theta, phi.  Returns complex [..., n_times, *directions.shape]; on the GPU (bms_evaluate_modes)."""
+        from . import quaternions
+
+        if len(directions) == 1:
+            R = np.asarray(directions[0], dtype=float)
+            if R.shape[-1] == 2:
+                R = quaternions.from_spherical_coords(R[..., 0], R[..., 1])
+            elif R.shape[-1] != 4:
+                raise ValueError(f"Directions must be rotors [..., 4] or (theta, phi) pairs [..., 2]; the last axis has size {R.shape[-1]}")
+        elif len(directions) == 2:
+            theta, phi = np.broadcast_arrays(np.asarray(directions[0], dtype=float), np.asarray(directions[1], dtype=float))
+            R = quaternions.from_spherical_coords(theta, phi)
+        else:
+            raise ValueError(f"Can only evaluate one array of rotors or (theta, phi) pairs, or theta and phi; got {len(directions)} arguments")
+        return engine.evaluate_modes(self.ndarray, self.s, self.ell_min, self.ell_max, R, ctx=ctx)
+
+    def grid(self, n_theta=None, n_phi=None, ctx=None):
+        """The function on the equiangular grid of n_theta x n_phi points (default 2 ell_max + 1 each): spherical_functions.Modes.grid,
+        i.e. spinsfast.salm2map on every time slice, as `Grid` [..., n_times, n_theta, n_phi] with this spin weight."""
+        n_theta = 2 * self.ell_max + 1 if n_theta is None else int(n_theta)
+        n_phi = n_theta if n_phi is None else int(n_phi)
+        a = self.ndarray
+        if self.ell_min > 0:
+            a = np.concatenate([np.zeros(a.shape[:-1] + (self.ell_min**2,), dtype=complex), a], axis=-1)
+        return Grid(engine.salm2map(a, self.s, self.ell_max, n_theta, n_phi, ctx=ctx), spin_weight=self.s)
 
     def _like(self, data, **changes):
         md = dict(self._metadata)

@@ -52,6 +52,14 @@ def conjugate(a):
     return np.asarray(a, dtype=float) * np.array([1.0, -1.0, -1.0, -1.0])
 
 
+def from_spherical_coords(theta, phi):
+    """The rotor R(theta, phi) = exp(phi z/2) exp(theta y/2) taking z to the direction (theta, phi) and x, y to the tangent vectors there
+    (quaternion.from_spherical_coords; scri/waveform_grid.py:138-140 builds its grid rotors from it): float array [..., 4]."""
+    theta, phi = np.broadcast_arrays(np.asarray(theta, dtype=float), np.asarray(phi, dtype=float))
+    ct, st, cp, sp = np.cos(theta / 2), np.sin(theta / 2), np.cos(phi / 2), np.sin(phi / 2)
+    return np.stack([cp * ct, -sp * st, cp * st, sp * ct], axis=-1)
+
+
 def as_spinor_array(q):
     """(w + i z, y + i x): quaternion.as_spinor_array (scri/rotations.py:311)."""
     q = np.asarray(q, dtype=float)

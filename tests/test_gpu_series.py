@@ -159,3 +159,47 @@ def test_grid_multiply_takes_factors_of_spin_three_and_four(ctx, sa, sb, la, lb)
         assert np.abs(got - expect).max() < 1e-13 * np.abs(expect).max()
     with pytest.raises(NotImplementedError, match="beyond"):
         engine.grid_multiply(a, 5, la, b, sb, lb, la + lb, 2, ctx=ctx)
+
+
+@pytest.mark.parametrize("s,ell_min,ell_max", [(-2, 2, 8), (0, 0, 5), (2, 0, 12), (1, 1, 3), (-1, 0, 17)])
+def test_modes_time_series_evaluate_and_grid(ctx, s, ell_min, ell_max):
+    """sf.Modes.evaluate / sf.Modes.grid on a ModesTimeSeries (scri/asymptotic_bondi_data/transformations.py:312-334,
+    map_to_superrest_frame.py:173): bms_evaluate_modes and bms_salm2map against the oracle's harmonics at the same rotors."""
+    from oracle import quat, wigner
+    from scri_amd import ModesTimeSeries
+    from scri_amd.modes_time_series import Grid
+
+    rng = np.random.default_rng(100 + ell_max)
+    n, nm = 23, (ell_max + 1) ** 2 - ell_min**2
+    a = rng.normal(size=(n, nm)) + 1j * rng.normal(size=(n, nm))
+    if abs(s) > ell_min:
+        a[:, : s * s - ell_min**2] = 0.0
+    mts = ModesTimeSeries(a, np.linspace(0.0, 1.0, n), spin_weight=s, ell_min=ell_min, ell_max=ell_max)
+    R = rng.normal(size=(5, 7, 4))
+    R /= np.linalg.norm(R, axis=-1, keepdims=True)
+    Y = wigner.swsh_grid(R, s, ell_max)[..., ell_min**2 :]
+    expect = np.einsum("tk,abk->tab", a, Y)
+    got = mts.evaluate(R, ctx=ctx)
+    assert got.shape == (n, 5, 7) and type(got) is np.ndarray
+    scale = np.abs(expect).max()
+    assert np.abs(got - expect).max() < 2e-13 * scale
+    # (theta, phi) in the two other spellings
+    th, ph = rng.uniform(0.0, np.pi, 9), rng.uniform(0.0, 2 * np.pi, 9)
+    by_rotor = mts.evaluate(quat.from_spherical_coords(th, ph), ctx=ctx)
+    assert np.array_equal(mts.evaluate(th, ph, ctx=ctx), by_rotor) and np.array_equal(mts.evaluate(np.stack([th, ph], axis=-1), ctx=ctx), by_rotor)
+    with pytest.raises(ValueError):
+        mts.evaluate(np.zeros((3, 5)), ctx=ctx)
+    with pytest.raises(ValueError):
+        mts.evaluate(th, ph, th, ctx=ctx)
+    # the equiangular grid, default and chosen sizes
+    for kw, (nt, nph) in (({}, (2 * ell_max + 1, 2 * ell_max + 1)), (dict(n_theta=2 * ell_max + 3, n_phi=2 * ell_max + 6), (2 * ell_max + 3, 2 * ell_max + 6))):
+        g = mts.grid(ctx=ctx, **kw)
+        assert isinstance(g, Grid) and g.shape == (n, nt, nph) and g.s == s and (g.n_theta, g.n_phi) == (nt, nph)
+        Rg = quat.from_spherical_coords(np.linspace(0.0, np.pi, nt)[:, None], np.linspace(0.0, 2 * np.pi, nph, endpoint=False)[None, :])
+        eg = np.einsum("tk,abk->tab", a, wigner.swsh_grid(Rg, s, ell_max)[..., ell_min**2 :])
+        assert np.abs(g.ndarray - eg).max() < 2e-13 * np.abs(eg).max()
+    assert g.real.s == s and (g * g).s == 2 * s and np.conjugate(g).s == -s and (g / g).s == 0 and (2.0 * g).s == s and (g + g).s == s
+    assert isinstance(g.real, Grid) and g.real.dtype == np.float64 and np.array_equal(g.real.ndarray, g.ndarray.real)
+    if s != 0:
+        with pytest.raises(ValueError):
+            g + np.conjugate(g)

@@ -75,3 +75,19 @@ def test_transition_function():
     assert np.allclose(f + transition_function(x, 0.2, 0.8, y0=1.0, y1=0.0), 1.0, atol=1e-15)
     g = transition_function(x, 0.2, 0.8, y0=3.0, y1=-1.0)
     assert g[0] == 3.0 and g[-1] == -1.0
+
+
+def test_from_spherical_coords_takes_z_to_the_direction():
+    from oracle import quat
+    from scri_amd import quaternions
+
+    rng = np.random.default_rng(2)
+    th, ph = rng.uniform(0, np.pi, (4, 6)), rng.uniform(0, 2 * np.pi, (4, 6))
+    R = quaternions.from_spherical_coords(th, ph)
+    assert R.shape == (4, 6, 4) and np.abs(np.linalg.norm(R, axis=-1) - 1).max() < 1e-15
+    assert np.abs(R - quat.from_spherical_coords(th, ph)).max() == 0.0
+    z = np.zeros((4, 6, 4))
+    z[..., 3] = 1.0
+    v = quaternions.multiply(quaternions.multiply(R, z), quaternions.conjugate(R))[..., 1:]
+    n = np.stack([np.sin(th) * np.cos(ph), np.sin(th) * np.sin(ph), np.cos(th)], axis=-1)
+    assert np.abs(v - n).max() < 1e-15
