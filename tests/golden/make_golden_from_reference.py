@@ -89,6 +89,12 @@ quaternion, spherical_functions, spinsfast) and writes
                             Moreschi, Geroch, Geroch-Winicour), plain and integrated, with the default working l_max and a larger one; the
                             remaining charges of the g19 data (CWWY angular momentum among them) and the text of the error for an unknown name.
 
+  g26_ref_initial_values.npz  AsymptoticBondiData.from_initial_values (scri/asymptotic_bondi_data/from_initial_values.py:1-220) in both of its branches
+                            -- sigma as a quadratic in u integrated exactly, and the same sigma given on the time axis and integrated through
+                            splines -- with generic initial psi2, psi1, psi0 (l <= 4, N = 41), and the two sides of the six Bondi-gauge
+                            relations and their violation norms on the results (constraints.py:9-110).  The products underneath are the
+                            stand-ins' Wigner-3j sums (sympy), the splines scipy's.
+
 Only the .npz and .json files travel; tests/test_golden.py checks the oracle (CPU) and the HIP path (GPU) against them.
 """
 import os
@@ -777,10 +783,39 @@ def g25():
     np.savez_compressed(os.path.join(HERE, "g25_ref_supermomenta.npz"), source="scri/asymptotic_bondi_data/bms_charges.py:14-286 (the reference's file, stand-ins underneath)", **out)
 
 
+def g26():
+    L, n = 4, 41
+    u = np.linspace(-4.0, 6.0, n)
+    rng = np.random.default_rng(260)
+
+    def modes(s_, scale=0.05):
+        a = scale * (rng.normal(size=(L + 1) ** 2) + 1j * rng.normal(size=(L + 1) ** 2))
+        a[: s_ * s_] = 0
+        return a
+
+    sigma0, sigmadot0, sigmaddot0 = modes(2), modes(2, 0.01), modes(2, 0.002)
+    psi2, psi1, psi0 = modes(0), modes(1), modes(2)
+    psi2[0] -= np.sqrt(4 * np.pi)
+    arr = lambda m: np.asarray(m).view(np.ndarray)
+    fields = lambda a: np.array([arr(getattr(a, f)) for f in ("psi0", "psi1", "psi2", "psi3", "psi4", "sigma")])
+    out = dict(u=u, ell_max=L, sigma0=sigma0, sigmadot0=sigmadot0, sigmaddot0=sigmaddot0, psi2=psi2, psi1=psi1, psi0=psi0)
+    sigma_of_u = sigma0[None, :] + u[:, None] * sigmadot0[None, :] + 0.5 * u[:, None] ** 2 * sigmaddot0[None, :]
+    out["sigma_of_u"] = sigma_of_u
+    for tag, abd in (("exact", scri.AsymptoticBondiData.from_initial_values(u, L, sigma0, sigmadot0, sigmaddot0, psi2, psi1, psi0)),
+                     ("numeric", scri.AsymptoticBondiData.from_initial_values(u, L, sigma_of_u, 0.0, 0.0, psi2, psi1, psi0))):
+        out[f"{tag}_raw"] = fields(abd)
+        out[f"{tag}_violation_norms"] = np.array(abd.bondi_violation_norms)
+        cons = abd.bondi_constraints()
+        out[f"{tag}_lhs"], out[f"{tag}_rhs"] = np.array([arr(c[0]) for c in cons[:5]]), np.array([arr(c[1]) for c in cons[:5]])
+        out[f"{tag}_mass_aspect_lhs"], out[f"{tag}_mass_aspect_rhs"] = arr(cons[5][0]), arr(cons[5][1])
+    np.savez_compressed(os.path.join(HERE, "g26_ref_initial_values.npz"),
+                        source="scri/asymptotic_bondi_data/from_initial_values.py, constraints.py (the reference's files, stand-ins underneath)", **out)
+
+
 if __name__ == "__main__":
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
-        every = (g10, g8, g9, g11, g12, g13, g14, g15, g16, g17, g18, g19, g20, g21, g22, g23, g24, g25)
+        every = (g10, g8, g9, g11, g12, g13, g14, g15, g16, g17, g18, g19, g20, g21, g22, g23, g24, g25, g26)
         only = [f for f in every if "--" + f.__name__ in sys.argv]
         for f in only or every:
             f()

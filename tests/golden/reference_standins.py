@@ -453,6 +453,18 @@ class Modes(np.ndarray):
         return self._with(out, self.s)
 
     @property
+    def imag(self):
+        """Modes of the imaginary part of the (spin-0) function, itself a real function: (f_lm - (-1)^m conj f_l,-m) / 2i
+        (scri/asymptotic_bondi_data/from_initial_values.py:106 subtracts 1j times it from psi2.real to set Im psi2)."""
+        a = self.view(np.ndarray)
+        out = np.empty_like(a)
+        for ell in range(self.ell_min, self.ell_max + 1):
+            for m in range(-ell, ell + 1):
+                i, j = self.index(ell, m), self.index(ell, -m)
+                out[..., i] = (a[..., i] - (-1.0) ** m * np.conj(a[..., j])) / 2j
+        return self._with(out, self.s)
+
+    @property
     def bar(self):
         """Modes of the conjugate function: spin -s, weights (-1)^(s+m) conj f_l,-m."""
         a = self.view(np.ndarray)

@@ -606,3 +606,37 @@ def test_g25_gpu_supermomenta_and_charges_vs_reference(ctx, device):
     with pytest.raises(ValueError) as e:
         abd.supermomentum("Bondi")
     assert str(e.value) == str(g["unknown_name_error"])
+
+
+# ------------------------------------------------------------------------------------------------- g26: initial-value construction
+G26 = os.path.join(HERE, "golden", "g26_ref_initial_values.npz")
+
+
+@pytest.mark.gpu
+def test_g26_gpu_from_initial_values_and_constraints_vs_reference(ctx):
+    """AsymptoticBondiData.from_initial_values in both branches (sigma quadratic in u, integrated exactly; sigma on the time axis,
+    integrated through splines) and the two sides of the six Bondi-gauge relations on the results, against the values of
+    scri/asymptotic_bondi_data/from_initial_values.py and constraints.py run by the reference's own files.  The reference multiplies
+    with Wigner-3j sums, this package on the grid: equal to rounding."""
+    import scri_amd
+
+    g = np.load(G26)
+    u, L = g["u"], int(g["ell_max"])
+    for tag, args in (("exact", (g["sigma0"], g["sigmadot0"], g["sigmaddot0"])), ("numeric", (g["sigma_of_u"], 0.0, 0.0))):
+        abd = scri_amd.AsymptoticBondiData.from_initial_values(u, L, *args, g["psi2"], g["psi1"], g["psi0"], ctx=ctx)
+        ref = g[f"{tag}_raw"]
+        for f, name in enumerate(("psi0", "psi1", "psi2", "psi3", "psi4", "sigma")):
+            err = np.abs(abd._raw_data[f] - ref[f]).max()
+            assert err < 2e-12 * max(1.0, np.abs(ref[f]).max()), (tag, name, err)
+        cons = abd.bondi_constraints()
+        for k in range(5):
+            for side, key in ((0, "lhs"), (1, "rhs")):
+                r = g[f"{tag}_{key}"][k]
+                assert np.abs(np.asarray(cons[k][side].ndarray) - r).max() < 1e-11 * max(1.0, np.abs(r).max()), (tag, k, key)
+        for side, key in ((0, "mass_aspect_lhs"), (1, "mass_aspect_rhs")):
+            r = g[f"{tag}_{key}"]
+            assert np.abs(np.asarray(cons[5][side].ndarray) - r).max() < 1e-11 * max(1.0, np.abs(r).max()), (tag, key)
+        norms = np.array(abd.bondi_violation_norms)
+        # (violations are differences of equal quantities: rounding noise there as here, compared as such)
+        assert norms.shape == g[f"{tag}_violation_norms"].shape
+        assert np.abs(norms - g[f"{tag}_violation_norms"]).max() < 1e-10
