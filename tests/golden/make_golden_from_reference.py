@@ -95,6 +95,10 @@ quaternion, spherical_functions, spinsfast) and writes
                             relations and their violation norms on the results (constraints.py:9-110).  The products underneath are the
                             stand-ins' Wigner-3j sums (sympy), the splines scipy's.
 
+  g27_ref_grids_and_containers.npz  boosted_grid and conformal_factors (scri/asymptotic_bondi_data/transformations.py:100-196) for a generic frame + boost, a
+                            boost alone and a rotation alone on a 9 x 11 grid; WaveformModes.SI_units for three data types and
+                            WaveformModes.compare on a resampled copy, with and without its two thresholds (scri/waveform_base.py:553-687).
+
 Only the .npz and .json files travel; tests/test_golden.py checks the oracle (CPU) and the HIP path (GPU) against them.
 """
 import os
@@ -812,10 +816,46 @@ def g26():
                         source="scri/asymptotic_bondi_data/from_initial_values.py, constraints.py (the reference's files, stand-ins underneath)", **out)
 
 
+def g27():
+    import quaternion
+    import scri.asymptotic_bondi_data.transformations as tr
+
+    out = {}
+    # the rotor grid and the conformal factors on it (transformations.py:100-196), a generic frame and boost on a non-square grid
+    fr = np.array([0.9, 0.1, -0.3, 0.2])
+    fr /= np.linalg.norm(fr)
+    v = np.array([0.11, -0.07, 0.2])
+    for tag, (q, vel) in (("generic", (fr, v)), ("boost_only", (np.array([1.0, 0, 0, 0]), np.array([0.0, 0.0, 0.3]))), ("rotation_only", (fr, np.zeros(3)))):
+        R = tr.boosted_grid(quaternion.quaternion(*q), vel, 9, 11)
+        k, ethk_over_k, one_over_k, one_over_k_cubed = tr.conformal_factors(vel, R)
+        out[f"{tag}_q"], out[f"{tag}_v"] = q, vel
+        out[f"{tag}_rotors"] = quaternion.as_float_array(R)
+        out[f"{tag}_k"], out[f"{tag}_ethk_over_k"] = np.asarray(k).view(np.ndarray), np.asarray(ethk_over_k).view(np.ndarray)
+        out[f"{tag}_one_over_k"], out[f"{tag}_one_over_k_cubed"] = np.asarray(one_over_k).view(np.ndarray), np.asarray(one_over_k_cubed).view(np.ndarray)
+    # SI_units and compare (scri/waveform_base.py:553-687) on a chirp and a resampled, slightly different copy of it
+    t = np.linspace(0, 50, 200)
+    data = synthetic.chirp_modes(t, 2, 5, 7)
+    for dt_name in ("h", "psi4", "news"):
+        w = _wm(t, data, 2, 5, getattr(scri, dt_name))
+        w = w.SI_units(60.0, 200.0)
+        out[f"SI_{dt_name}_t"], out[f"SI_{dt_name}_data"] = np.array(w.t), np.array(w.data)
+        out[f"SI_{dt_name}_flags"] = np.array([w.r_is_scaled_out, w.m_is_scaled_out])
+    a = _wm(t, data, 2, 5, scri.h)
+    t_b = np.sort(np.concatenate([t[::2] + 0.01, [13.3331, 27.7]]))
+    b = _wm(t_b, 1.01 * synthetic.chirp_modes(t_b, 2, 5, 7), 2, 5, scri.h)
+    c = b.compare(a)
+    out["compare_t_a"], out["compare_a"], out["compare_t_b"], out["compare_b"] = t, data, t_b, np.array(b.data)
+    out["compare_t"], out["compare_data"], out["compare_frame_size"] = np.array(c.t), np.array(c.data), np.array(np.size(c.frame))
+    c2 = b.compare(a, min_time_step=0.3, min_time=5.0)
+    out["compare2_t"], out["compare2_data"] = np.array(c2.t), np.array(c2.data)
+    np.savez_compressed(os.path.join(HERE, "g27_ref_grids_and_containers.npz"),
+                        source="scri/asymptotic_bondi_data/transformations.py:100-196, scri/waveform_base.py:553-687 (the reference's files, stand-ins underneath)", **out)
+
+
 if __name__ == "__main__":
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
-        every = (g10, g8, g9, g11, g12, g13, g14, g15, g16, g17, g18, g19, g20, g21, g22, g23, g24, g25, g26)
+        every = (g10, g8, g9, g11, g12, g13, g14, g15, g16, g17, g18, g19, g20, g21, g22, g23, g24, g25, g26, g27)
         only = [f for f in every if "--" + f.__name__ in sys.argv]
         for f in only or every:
             f()

@@ -640,3 +640,65 @@ def test_g26_gpu_from_initial_values_and_constraints_vs_reference(ctx):
         # (violations are differences of equal quantities: rounding noise there as here, compared as such)
         assert norms.shape == g[f"{tag}_violation_norms"].shape
         assert np.abs(norms - g[f"{tag}_violation_norms"]).max() < 1e-10
+
+
+# ------------------------------------------------------------------------------------------------- g27: rotor grid, conformal factors, SI units, compare
+G27 = os.path.join(HERE, "golden", "g27_ref_grids_and_containers.npz")
+
+
+def _g27_same_rotors(got, ref):
+    """rotors are defined up to sign"""
+    sign = np.sign(np.sum(got * ref, axis=-1, keepdims=True))
+    return np.abs(got - sign * ref).max()
+
+
+@pytest.mark.parametrize("tag", ["generic", "boost_only", "rotation_only"])
+def test_g27_host_rotor_grid_and_conformal_factors_vs_reference(tag):
+    """boosted_grid and conformal_factors (scri/asymptotic_bondi_data/transformations.py:100-196) run by the reference's file against the
+    host evaluation of the code the kernels compile (pixel_math.h; no GPU)"""
+    from scri_amd import asymptotic_bondi_data as abd_module
+
+    g = np.load(G27)
+    R = abd_module.boosted_grid(g[f"{tag}_q"], g[f"{tag}_v"], 9, 11)
+    # (at the two poles the reference's own rotor carries the 3e-8 rad of its arccos, oracle/quat.py: away from them 1e-15)
+    assert _g27_same_rotors(R[1:-1], g[f"{tag}_rotors"][1:-1]) < 5e-15
+    assert _g27_same_rotors(R, g[f"{tag}_rotors"]) < 1e-7
+    k, ethk_over_k, one_over_k, one_over_k_cubed = abd_module.conformal_factors(g[f"{tag}_v"], g[f"{tag}_rotors"])
+    for got, key in ((k, "k"), (ethk_over_k, "ethk_over_k"), (one_over_k, "one_over_k"), (one_over_k_cubed, "one_over_k_cubed")):
+        assert got.shape == g[f"{tag}_{key}"].shape == (1, 9, 11), key
+        assert np.abs(got - g[f"{tag}_{key}"]).max() < 4e-15 * max(1.0, np.abs(g[f"{tag}_{key}"]).max()), (tag, key)
+
+
+@pytest.mark.parametrize("name", ["h", "psi4", "news"])
+def test_g27_SI_units_vs_reference(name):
+    """WaveformModes.SI_units (scri/waveform_base.py:970-1045): a new object, times in seconds, data by the type's r and M scaling"""
+    import scri_amd
+
+    g = np.load(G27)
+    w = scri_amd.WaveformModes(t=g["compare_t_a"], data=g["compare_a"], ell_min=2, ell_max=5, frameType=scri_amd.Inertial,
+                               dataType=getattr(scri_amd, name), r_is_scaled_out=True, m_is_scaled_out=True)
+    si = w.SI_units(60.0, 200.0)
+    assert si is not w and np.array_equal(w.t, g["compare_t_a"])
+    assert np.abs(si.t - g[f"SI_{name}_t"]).max() <= 2e-16 * np.abs(g[f"SI_{name}_t"]).max()
+    assert np.abs(si.data - g[f"SI_{name}_data"]).max() <= 4e-16 * np.abs(g[f"SI_{name}_data"]).max()
+    assert [si.r_is_scaled_out, si.m_is_scaled_out] == list(g[f"SI_{name}_flags"])
+
+
+@pytest.mark.gpu
+def test_g27_gpu_compare_and_device_rotor_grid_vs_reference(ctx):
+    """WaveformModes.compare (scri/waveform_base.py:577-687) with and without its thresholds, and the rotor grid by the GPU kernel"""
+    import scri_amd
+    from scri_amd import engine
+
+    g = np.load(G27)
+    mk = lambda t, d: scri_amd.WaveformModes(t=t, data=d, ell_min=2, ell_max=5, frameType=scri_amd.Inertial, dataType=scri_amd.h,  # noqa: E731
+                                             r_is_scaled_out=True, m_is_scaled_out=True, ctx=ctx)
+    a, b = mk(g["compare_t_a"], g["compare_a"]), mk(g["compare_t_b"], g["compare_b"])
+    for tag, kw in (("compare", {}), ("compare2", dict(min_time_step=0.3, min_time=5.0))):
+        c = b.compare(a, **kw)
+        assert c.t.shape == g[f"{tag}_t"].shape and np.abs(c.t - g[f"{tag}_t"]).max() < 1e-13, tag
+        assert np.abs(c.data - g[f"{tag}_data"]).max() < 1e-12 * np.abs(g["compare_a"]).max(), tag
+    assert np.size(c.frame) == int(g["compare_frame_size"])
+    for tag in ("generic", "boost_only", "rotation_only"):
+        R = engine.rotor_grid(g[f"{tag}_q"], g[f"{tag}_v"], 9, 11, ctx=ctx, device=True)
+        assert _g27_same_rotors(R[1:-1], g[f"{tag}_rotors"][1:-1]) < 5e-15, tag
