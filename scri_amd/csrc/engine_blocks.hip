@@ -109,6 +109,7 @@ extern "C" int bms_swsh_grid(bms_ctx* c, const double* rotors, int64_t n, int sp
 extern "C" int bms_map2salm(bms_ctx* c, const void* grid, int mem, int64_t n_maps, int n_theta, int n_phi, int spin,
                             int ell_min, int ell_max, void* modes_out) try {
   if (!c || !grid || !modes_out) return BMS_ERR_INVALID;
+  if (!valid_mem(mem)) return fail(c, BMS_ERR_INVALID, "mem is BMS_HOST or BMS_DEVICE, got %d", mem);
   HIP_TRY(c, hipSetDevice(c->device));
   if (n_theta < 2 || n_phi < 1 || ell_min < 0 || ell_max < ell_min) return fail(c, BMS_ERR_INVALID, "bad sizes");
   if (ell_max > MAX_ELL || (long long)n_theta * n_phi > (1LL << 26)) return fail(c, BMS_ERR_UNSUPPORTED, "ell_max = %d on %d x %d: too large", ell_max, n_theta, n_phi);
@@ -131,6 +132,7 @@ extern "C" int bms_map2salm(bms_ctx* c, const void* grid, int mem, int64_t n_map
 extern "C" int bms_cubic_spline(bms_ctx* c, const double* x, int64_t n, const void* y, int64_t ld, int64_t n_cols, int mem,
                                 const double* x_new, int64_t n_new, void* out) try {
   if (!c || !x || !y || !x_new || !out) return BMS_ERR_INVALID;
+  if (!valid_mem(mem)) return fail(c, BMS_ERR_INVALID, "mem is BMS_HOST or BMS_DEVICE, got %d", mem);
   HIP_TRY(c, hipSetDevice(c->device));
   if (n < 4) return fail(c, BMS_ERR_UNSUPPORTED, "cubic spline needs at least 4 knots, got %lld", (long long)n);
   if (ld < n_cols || n_cols <= 0) return fail(c, BMS_ERR_INVALID, "bad column count / stride");
@@ -166,6 +168,7 @@ extern "C" int bms_cubic_spline(bms_ctx* c, const double* x, int64_t n, const vo
 extern "C" int bms_spline_derivative(bms_ctx* c, const double* x, int64_t n, const void* y, int64_t ld, int64_t n_cols, int mem,
                                      const double* x_new, int64_t n_new, int order, void* out) try {
   if (!c || !x || !y || !x_new || !out) return BMS_ERR_INVALID;
+  if (!valid_mem(mem)) return fail(c, BMS_ERR_INVALID, "mem is BMS_HOST or BMS_DEVICE, got %d", mem);
   HIP_TRY(c, hipSetDevice(c->device));
   if (n < 4) return fail(c, BMS_ERR_UNSUPPORTED, "cubic spline needs at least 4 knots, got %lld", (long long)n);
   if (ld < n_cols || n_cols <= 0) return fail(c, BMS_ERR_INVALID, "bad column count / stride");
@@ -223,6 +226,7 @@ extern "C" int bms_spline_derivative(bms_ctx* c, const double* x, int64_t n, con
 extern "C" int bms_angular_velocity(bms_ctx* c, const double* t, int64_t n, const void* data, int64_t ld, int ell_min, int ell_max,
                                     int mem, double* ldt_out, double* ll_out, double* omega_out) try {
   if (!c || !t || !data) return BMS_ERR_INVALID;
+  if (!valid_mem(mem)) return fail(c, BMS_ERR_INVALID, "mem is BMS_HOST or BMS_DEVICE, got %d", mem);
   HIP_TRY(c, hipSetDevice(c->device));
   if (n < 4) return fail(c, BMS_ERR_UNSUPPORTED, "the time derivative needs at least 4 time steps, got %lld", (long long)n);
   if (ell_min < 0 || ell_max < ell_min) return fail(c, BMS_ERR_INVALID, "bad ell range");
@@ -348,6 +352,7 @@ extern "C" int bms_integrate_angular_velocity(bms_ctx* c, const double* t, int64
 extern "C" int bms_salm2map(bms_ctx* c, const void* modes, int mem, int64_t n_maps, int spin, int ell_max, int n_theta, int n_phi,
                             void* grid_out) try {
   if (!c || !modes || !grid_out) return BMS_ERR_INVALID;
+  if (!valid_mem(mem)) return fail(c, BMS_ERR_INVALID, "mem is BMS_HOST or BMS_DEVICE, got %d", mem);
   HIP_TRY(c, hipSetDevice(c->device));
   if (ell_max < 0 || n_theta < 2 || n_phi < 1 || std::abs(spin) > 4) return fail(c, BMS_ERR_INVALID, "bad sizes");
   if (ell_max > MAX_ELL || (long long)n_theta * n_phi > (1LL << 26)) return fail(c, BMS_ERR_UNSUPPORTED, "ell_max = %d on %d x %d: too large", ell_max, n_theta, n_phi);
@@ -439,6 +444,7 @@ extern "C" int bms_mode_map(bms_ctx* c, void* out, int64_t ld_out, int64_t n_row
                             const int32_t* idx_a, const void* coef_a, int conj_a, const void* b, int64_t ld_b,
                             const int32_t* idx_b, const void* coef_b, int conj_b, const double* row_scale, int mem) try {
   if (!c || !out || !a || !idx_a || !coef_a) return BMS_ERR_INVALID;
+  if (!valid_mem(mem)) return fail(c, BMS_ERR_INVALID, "mem is BMS_HOST or BMS_DEVICE, got %d", mem);
   if (b && (!idx_b || !coef_b)) return BMS_ERR_INVALID;
   HIP_TRY(c, hipSetDevice(c->device));
   if (n_rows < 0 || n_cols <= 0 || ld_out < n_cols || ld_a <= 0 || (b && ld_b <= 0)) return fail(c, BMS_ERR_INVALID, "bad sizes");
@@ -496,6 +502,7 @@ extern "C" int bms_mode_map(bms_ctx* c, void* out, int64_t ld_out, int64_t n_row
 
 extern "C" int bms_row_norm(bms_ctx* c, const void* data, int64_t ld, int64_t n_rows, int n_cols, int mem, int take_sqrt, double* out) try {
   if (!c || !data || !out) return BMS_ERR_INVALID;
+  if (!valid_mem(mem)) return fail(c, BMS_ERR_INVALID, "mem is BMS_HOST or BMS_DEVICE, got %d", mem);
   HIP_TRY(c, hipSetDevice(c->device));
   if (n_rows < 0 || n_cols < 0 || ld < n_cols) return fail(c, BMS_ERR_INVALID, "bad sizes");
   if (n_rows == 0) return BMS_OK;
@@ -522,6 +529,7 @@ extern "C" int bms_row_norm(bms_ctx* c, const void* data, int64_t ld, int64_t n_
 extern "C" int bms_grid_multiply(bms_ctx* c, const void* a, int spin_a, int ell_max_a, const void* b, int spin_b, int ell_max_b,
                                  int mem, int64_t n_times, int working_ell_max, int output_ell_max, void* out) try {
   if (!c || !a || !b || !out) return BMS_ERR_INVALID;
+  if (!valid_mem(mem)) return fail(c, BMS_ERR_INVALID, "mem is BMS_HOST or BMS_DEVICE, got %d", mem);
   HIP_TRY(c, hipSetDevice(c->device));
   if (ell_max_a < 0 || ell_max_b < 0 || working_ell_max < 1 || output_ell_max < 0 || output_ell_max > working_ell_max)
     return fail(c, BMS_ERR_INVALID, "bad l ranges (need 0 <= output_ell_max <= working_ell_max)");
@@ -627,6 +635,7 @@ extern "C" int bms_grid_multiply(bms_ctx* c, const void* a, int spin_a, int ell_
 // scri/utilities.py:194-232: XOR differencing of a time series in place (rows of 64-bit words)
 extern "C" int bms_xor_timeseries(bms_ctx* c, void* data, int mem, int64_t n_rows, int64_t words_per_row, int reverse) try {
   if (!c || !data) return BMS_ERR_INVALID;
+  if (!valid_mem(mem)) return fail(c, BMS_ERR_INVALID, "mem is BMS_HOST or BMS_DEVICE, got %d", mem);
   HIP_TRY(c, hipSetDevice(c->device));
   if (n_rows < 0 || words_per_row < 0) return fail(c, BMS_ERR_INVALID, "negative size");
   if (n_rows == 0 || words_per_row == 0) return BMS_OK;
@@ -651,6 +660,7 @@ extern "C" int bms_xor_timeseries(bms_ctx* c, void* data, int mem, int64_t n_row
 extern "C" int bms_multishuffle(bms_ctx* c, const void* in, void* out, int mem, int64_t n, const int* widths, int n_widths,
                                 int forward) try {
   if (!c || !in || !out || !widths) return BMS_ERR_INVALID;
+  if (!valid_mem(mem)) return fail(c, BMS_ERR_INVALID, "mem is BMS_HOST or BMS_DEVICE, got %d", mem);
   HIP_TRY(c, hipSetDevice(c->device));
   int bit_width = 0;
   for (int i = 0; i < n_widths; ++i) {
@@ -682,6 +692,7 @@ extern "C" int bms_multishuffle(bms_ctx* c, const void* in, void* out, int mem, 
 // scri/utilities.py:235-268: Fletcher-32 over the data viewed as 16-bit words (n_bytes must be even)
 extern "C" int bms_fletcher32(bms_ctx* c, const void* data, int mem, int64_t n_bytes, uint32_t* checksum) try {
   if (!c || !checksum || (!data && n_bytes)) return BMS_ERR_INVALID;
+  if (!valid_mem(mem)) return fail(c, BMS_ERR_INVALID, "mem is BMS_HOST or BMS_DEVICE, got %d", mem);
   HIP_TRY(c, hipSetDevice(c->device));
   if (n_bytes < 0 || (n_bytes & 1)) return fail(c, BMS_ERR_INVALID, "the data must be viewable as 16-bit words");
   *checksum = 0;

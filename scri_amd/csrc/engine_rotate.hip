@@ -9,6 +9,7 @@ constexpr int ROT_RING = 64;
 int rotate_impl(bms_ctx* c, void* data, int mem, int64_t n_times, int64_t ld, int ell_min, int ell_max, const void* spinors, bool series,
                 bool sync_after) {
   if (!c) return BMS_ERR_INVALID;
+  if (!valid_mem(mem)) return fail(c, BMS_ERR_INVALID, "mem is BMS_HOST or BMS_DEVICE, got %d", mem);
   HIP_TRY(c, hipSetDevice(c->device));
   if (n_times < 0 || ell_min < 0 || ell_max < ell_min) return fail(c, BMS_ERR_INVALID, "bad sizes");
   if (ell_max > MAX_ELL) return fail(c, BMS_ERR_UNSUPPORTED, "ell_max = %d is beyond %d", ell_max, MAX_ELL);
@@ -135,6 +136,7 @@ extern "C" int bms_rotate_series(bms_ctx* c, void* data, int mem, int64_t n_time
 extern "C" int bms_rotate_const_D(bms_ctx* c, void* data, int mem, int64_t n_times, int64_t ld, int ell_min, int ell_max,
                                   const void* D_host) try {
   if (!c || !data || !D_host) return BMS_ERR_INVALID;
+  if (!valid_mem(mem)) return fail(c, BMS_ERR_INVALID, "mem is BMS_HOST or BMS_DEVICE, got %d", mem);
   HIP_TRY(c, hipSetDevice(c->device));
   if (n_times < 0 || ell_min < 0 || ell_max < ell_min) return fail(c, BMS_ERR_INVALID, "bad sizes");
   if (ell_max > MAX_ELL) return fail(c, BMS_ERR_UNSUPPORTED, "ell_max = %d is beyond %d", ell_max, MAX_ELL);
