@@ -1,7 +1,7 @@
 """Child process of tests/test_gpu_abi_robustness.py and tests/test_abi.py: calls every status-returning entry of the C ABI with NULL
 pointers and degenerate integers.  A library that dereferences one of them dies here, in the child, and the parent reports which call.
 
-    python null_sweep_worker.py {null-ctx | live-ctx | live-structs}
+    python null_sweep_worker.py {null-ctx | live-ctx | live-structs | live-blocks}
 
 Prints one line per call: `<entry> <integer fill> <status>`; the last line is `done <n calls>`."""
 import ctypes
@@ -171,5 +171,93 @@ def structs(_mode):
     print("done", count, flush=True)
 
 
+def blocks(_mode):
+    """The building blocks and series operators with real buffers and ONE wrong scalar each."""
+    import numpy as np
+
+    lib = _lib.load()
+    h = _lib.Context(0).handle
+    dp = ctypes.POINTER(ctypes.c_double)
+    vp = lambda a: ctypes.c_void_p(a.ctypes.data)  # noqa: E731
+    dpp = lambda a: a.ctypes.data_as(dp)  # noqa: E731
+    rng = np.random.default_rng(9)
+    n, L = 40, 4
+    nm = (L + 1) ** 2
+    nt = nph = 2 * L + 1
+    modes = rng.normal(size=(n, nm)) + 1j * rng.normal(size=(n, nm))
+    grid = np.zeros((n, nt * nph), dtype=complex)
+    modes2 = modes.copy()  # (a result array that outlives the call)
+    t = np.linspace(0.0, 4.0, n)
+    t_bad = t.copy()
+    t_bad[7] = t_bad[6]
+    x_new = np.linspace(0.5, 3.5, 11)
+    out_s = np.zeros((11, nm), dtype=complex)
+    q = (ctypes.c_double * 4)(1.0, 0.0, 0.0, 0.0)
+    spinors = np.tile(np.array([1.0, 0.0, 0.0, 0.0]), (n, 1))
+    D = np.zeros(sum((2 * l + 1) ** 2 for l in range(L + 1)), dtype=complex)
+    rot = np.tile(np.array([1.0, 0.0, 0.0, 0.0]), (5, 1))
+    ev_out = np.zeros((n, 5), dtype=complex)
+    widths = (ctypes.c_int * 2)(8, 8)
+    words = np.zeros(64, dtype=np.uint16)
+    words_out = np.zeros(64, dtype=np.uint16)
+    chk = ctypes.c_uint32(0)
+    norm_out = np.zeros(n)
+    H, bad = _lib.BMS_HOST, 7
+    cases = [
+        ("bms_salm2map well-formed", lambda: lib.bms_salm2map(h, vp(modes), H, n, 0, L, nt, nph, vp(grid)), 0),
+        ("bms_salm2map mem", lambda: lib.bms_salm2map(h, vp(modes), bad, n, 0, L, nt, nph, vp(grid)), -1),
+        ("bms_salm2map n_theta=1", lambda: lib.bms_salm2map(h, vp(modes), H, n, 0, L, 1, nph, vp(grid)), -1),
+        ("bms_salm2map spin=9", lambda: lib.bms_salm2map(h, vp(modes), H, n, 9, L, nt, nph, vp(grid)), -1),
+        ("bms_salm2map ell_max=-1", lambda: lib.bms_salm2map(h, vp(modes), H, n, 0, -1, nt, nph, vp(grid)), -1),
+        ("bms_salm2map ell_max=60000", lambda: lib.bms_salm2map(h, vp(modes), H, n, 0, 60000, nt, nph, vp(grid)), -1),
+        ("bms_map2salm well-formed", lambda: lib.bms_map2salm(h, vp(grid), H, n, nt, nph, 0, 0, L, vp(modes2)), 0),
+        ("bms_map2salm mem", lambda: lib.bms_map2salm(h, vp(grid), bad, n, nt, nph, 0, 0, L, vp(modes2)), -1),
+        ("bms_map2salm ell_min>ell_max", lambda: lib.bms_map2salm(h, vp(grid), H, n, nt, nph, 0, L + 1, L, vp(modes2)), -1),
+        ("bms_map2salm n_phi=0", lambda: lib.bms_map2salm(h, vp(grid), H, n, nt, 0, 0, 0, L, vp(modes2)), -1),
+        ("bms_cubic_spline well-formed", lambda: lib.bms_cubic_spline(h, dpp(t), n, vp(modes), nm, nm, H, dpp(x_new), 11, vp(out_s)), 0),
+        ("bms_cubic_spline mem", lambda: lib.bms_cubic_spline(h, dpp(t), n, vp(modes), nm, nm, bad, dpp(x_new), 11, vp(out_s)), -1),
+        ("bms_cubic_spline knots", lambda: lib.bms_cubic_spline(h, dpp(t_bad), n, vp(modes), nm, nm, H, dpp(x_new), 11, vp(out_s)), -1),
+        ("bms_cubic_spline n=3", lambda: lib.bms_cubic_spline(h, dpp(t), 3, vp(modes), nm, nm, H, dpp(x_new), 11, vp(out_s)), -1),
+        ("bms_cubic_spline ld<cols", lambda: lib.bms_cubic_spline(h, dpp(t), n, vp(modes), nm - 1, nm, H, dpp(x_new), 11, vp(out_s)), -1),
+        ("bms_spline_derivative order=9", lambda: lib.bms_spline_derivative(h, dpp(t), n, vp(modes), nm, nm, H, dpp(x_new), 11, 9, vp(out_s)), -1),
+        ("bms_spline_derivative mem", lambda: lib.bms_spline_derivative(h, dpp(t), n, vp(modes), nm, nm, bad, dpp(x_new), 11, 1, vp(out_s)), -1),
+        ("bms_rotate_const well-formed", lambda: lib.bms_rotate_const(h, vp(modes), H, n, nm, 0, L, q), 0),
+        ("bms_rotate_const mem", lambda: lib.bms_rotate_const(h, vp(modes), bad, n, nm, 0, L, q), -1),
+        ("bms_rotate_const ld", lambda: lib.bms_rotate_const(h, vp(modes), H, n, nm - 1, 0, L, q), -1),
+        ("bms_rotate_const ell", lambda: lib.bms_rotate_const(h, vp(modes), H, n, nm, 3, 2, q), -1),
+        ("bms_rotate_const ell_max=60000", lambda: lib.bms_rotate_const(h, vp(modes), H, n, 1 << 40, 0, 60000, q), -1),
+        ("bms_rotate_series mem", lambda: lib.bms_rotate_series(h, vp(modes), bad, n, nm, 0, L, vp(spinors)), -1),
+        ("bms_rotate_series n=-1", lambda: lib.bms_rotate_series(h, vp(modes), H, -1, nm, 0, L, vp(spinors)), -1),
+        ("bms_rotate_const_D mem", lambda: lib.bms_rotate_const_D(h, vp(modes), bad, n, nm, 0, L, vp(D)), -1),
+        ("bms_wigner_D ell", lambda: lib.bms_wigner_D(h, q, 2, 1, vp(D)), -1),
+        ("bms_wigner_D ell_max=60000", lambda: lib.bms_wigner_D(h, q, 0, 60000, vp(D)), -1),
+        ("bms_evaluate_modes well-formed", lambda: lib.bms_evaluate_modes(h, vp(modes), H, n, nm, 0, 0, L, dpp(rot), 5, vp(ev_out)), 0),
+        ("bms_evaluate_modes mem", lambda: lib.bms_evaluate_modes(h, vp(modes), bad, n, nm, 0, 0, L, dpp(rot), 5, vp(ev_out)), -1),
+        ("bms_evaluate_modes ld", lambda: lib.bms_evaluate_modes(h, vp(modes), H, n, nm - 1, 0, 0, L, dpp(rot), 5, vp(ev_out)), -1),
+        ("bms_evaluate_modes n_rot=-1", lambda: lib.bms_evaluate_modes(h, vp(modes), H, n, nm, 0, 0, L, dpp(rot), -1, vp(ev_out)), -1),
+        ("bms_row_norm well-formed", lambda: lib.bms_row_norm(h, vp(modes), nm, n, nm, H, 0, dpp(norm_out)), 0),
+        ("bms_row_norm mem", lambda: lib.bms_row_norm(h, vp(modes), nm, n, nm, bad, 0, dpp(norm_out)), -1),
+        ("bms_row_norm ld", lambda: lib.bms_row_norm(h, vp(modes), nm - 1, n, nm, H, 0, dpp(norm_out)), -1),
+        ("bms_grid_multiply mem", lambda: lib.bms_grid_multiply(h, vp(modes), 0, L, vp(modes), 0, L, bad, n, 2 * L, L, vp(modes2)), -1),
+        ("bms_grid_multiply spins", lambda: lib.bms_grid_multiply(h, vp(modes), 4, L, vp(modes), 4, L, H, n, 2 * L, L, vp(modes2)), -1),
+        ("bms_grid_multiply l", lambda: lib.bms_grid_multiply(h, vp(modes), 0, L, vp(modes), 0, L, H, n, 2, 3, vp(modes2)), -1),
+        ("bms_xor_timeseries mem", lambda: lib.bms_xor_timeseries(h, vp(modes), bad, n, 2 * nm, 0), -1),
+        ("bms_xor_timeseries words=-1", lambda: lib.bms_xor_timeseries(h, vp(modes), H, n, -1, 0), -1),
+        ("bms_multishuffle widths", lambda: lib.bms_multishuffle(h, vp(words), vp(words_out), H, 64, (ctypes.c_int * 2)(8, 9), 2, 1), -1),
+        ("bms_multishuffle mem", lambda: lib.bms_multishuffle(h, vp(words), vp(words_out), bad, 64, widths, 2, 1), -1),
+        ("bms_multishuffle well-formed", lambda: lib.bms_multishuffle(h, vp(words), vp(words_out), H, 64, widths, 2, 1), 0),
+        ("bms_fletcher32 odd", lambda: lib.bms_fletcher32(h, vp(words), H, 127, ctypes.byref(chk)), -1),
+        ("bms_fletcher32 mem", lambda: lib.bms_fletcher32(h, vp(words), bad, 128, ctypes.byref(chk)), -1),
+        ("bms_fletcher32 well-formed", lambda: lib.bms_fletcher32(h, vp(words), H, 128, ctypes.byref(chk)), 0),
+        ("bms_ctx_set_option unknown", lambda: lib.bms_ctx_set_option(h, b"NO_SUCH_ROUTE", 1), -1),
+        ("bms_ctx_set_option GEMM_EVAL_STEP=5", lambda: lib.bms_ctx_set_option(h, b"GEMM_EVAL_STEP", 5), -1),
+    ]
+    for label, call, want in cases:
+        print(label.replace(" ", ":"), end=" ", flush=True)
+        rc = call()
+        print("want0" if want == 0 else "wantneg", rc, flush=True)
+    print("done", len(cases), flush=True)
+
+
 if __name__ == "__main__":
-    (structs if sys.argv[1] == "live-structs" else main)(sys.argv[1])
+    {"live-structs": structs, "live-blocks": blocks}.get(sys.argv[1], main)(sys.argv[1])

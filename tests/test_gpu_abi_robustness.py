@@ -50,3 +50,12 @@ def test_one_wrong_field_at_a_time():
             assert int(parts[2]) == 0 and int(parts[3]) == 1, l  # the context still gives the first answer, bit for bit
         else:
             assert int(parts[-1]) < 0, l
+
+
+@pytest.mark.gpu
+def test_building_blocks_with_one_wrong_scalar():
+    lines, n = _run("live-blocks")
+    assert n > 40
+    for l in lines:
+        label, want, rc = l.split()
+        assert (int(rc) == 0) if want == "want0" else (int(rc) < 0), l
