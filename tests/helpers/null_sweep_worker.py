@@ -17,9 +17,10 @@ SKIP = {"bms_version", "bms_ctx_create", "bms_ctx_destroy", "bms_last_error", "b
 
 def main(mode):
     lib = _lib.load()
-    handle = None
+    handle = keep = None
     if mode == "live-ctx":
-        handle = _lib.Context(0).handle
+        keep = _lib.Context(0)  # (the object owns the bms_ctx: it must outlive the calls)
+        handle = keep.handle
     n = 0
     for name, (restype, argtypes) in sorted(_lib.SIGNATURES.items()):
         if name in SKIP or restype is not ctypes.c_int:
@@ -176,7 +177,8 @@ def blocks(_mode):
     import numpy as np
 
     lib = _lib.load()
-    h = _lib.Context(0).handle
+    keep = _lib.Context(0)  # (the object owns the bms_ctx: it must outlive the calls)
+    h = keep.handle
     dp = ctypes.POINTER(ctypes.c_double)
     vp = lambda a: ctypes.c_void_p(a.ctypes.data)  # noqa: E731
     dpp = lambda a: a.ctypes.data_as(dp)  # noqa: E731
