@@ -99,6 +99,9 @@ quaternion, spherical_functions, spinsfast) and writes
                             boost alone and a rotation alone on a 9 x 11 grid; WaveformModes.SI_units for three data types and
                             WaveformModes.compare on a resampled copy, with and without its two thresholds (scri/waveform_base.py:553-687).
 
+  g28_ref_relativistic_transforms.npz  g8 and g9 again where nothing is small: |v| = 0.35 / 0.30, a supertranslation of order one (l <= 4 / 3), l = 2..10 (h, news,
+                            psi4; psi1 with its three companions) and six fields at l <= 6, on NON-uniform time axes (N = 400 / 150).
+
 Only the .npz and .json files travel; tests/test_golden.py checks the oracle (CPU) and the HIP path (GPU) against them.
 """
 import os
@@ -852,10 +855,46 @@ def g27():
                         source="scri/asymptotic_bondi_data/transformations.py:100-196, scri/waveform_base.py:553-687 (the reference's files, stand-ins underneath)", **out)
 
 
+def g28():
+    # the same two transformations as g8 / g9 in the relativistic regime and on a non-uniform time axis: |v| = 0.35 and 0.3, a
+    # supertranslation of order one (l <= 4), higher l -- second-order boost terms, k^w weights and the psi mixing are of order one here
+    rng = np.random.default_rng(280)
+    n, L = 400, 10
+    t = np.sort(rng.uniform(-30.0, 90.0, n)) + np.arange(n) * 1e-3
+    kw = dict(supertranslation=_real_supertranslation(4, 281, 0.3), frame_rotation=np.array([-0.3, 0.8, 0.4, -0.2]) / np.linalg.norm([-0.3, 0.8, 0.4, -0.2]),
+              boost_velocity=np.array([0.21, -0.2, 0.19]))
+    out = dict(wm_t=t, wm_ell_max=L, **{"wm_" + k: v for k, v in kw.items()})
+    for name, dt, seed in (("h", scri.h, 282), ("news", scri.news, 283), ("psi4", scri.psi4, 284)):
+        data = synthetic.chirp_modes(t, 2, L, seed) * (1 + 0.004 * t[:, None])
+        w = _wm(t, data, 2, L, dt).transform(**kw)
+        out[f"{name}_t_out"], out[f"{name}_out"] = w.t, w.data[::4]  # (inputs: regenerated by the test from the same seeds; every 4th output row)
+    d1 = synthetic.chirp_modes(t, 1, 8, 285)
+    comp = {f"psi{k}_modes": _wm(t, synthetic.chirp_modes(t, s_, 8 - k + 2, 285 + k), s_, 8 - k + 2, getattr(scri, f"psi{k}")) for k, s_ in ((2, 0), (3, 1), (4, 2))}
+    w = _wm(t, d1, 1, 8, scri.psi1).transform(**comp, **kw)
+    out.update(psi1_t_out=w.t, psi1_out=w.data[::4], psi1_companion_ell=np.array([[v.ell_min, v.ell_max] for v in comp.values()]))
+    # AsymptoticBondiData, six fields, l <= 6
+    n2, L2 = 150, 6
+    u = np.sort(rng.uniform(-20.0, 60.0, n2)) + np.arange(n2) * 1e-3
+    abd = scri.AsymptoticBondiData(u, L2)
+    raw = np.zeros((6, n2, (L2 + 1) ** 2), dtype=complex)
+    for f, s_ in enumerate(synthetic.ABD_SPINS):
+        raw[f] = synthetic.chirp_modes(u, 0, L2, 290 + f) * (1 + 0.01 * u[:, None])
+        raw[f, :, : s_ * s_] = 0
+    abd.psi0, abd.psi1, abd.psi2, abd.psi3, abd.psi4, abd.sigma = raw
+    kw2 = dict(supertranslation=_real_supertranslation(3, 297, 0.25), frame_rotation=np.array([0.2, -0.5, 0.1, 0.9]) / np.linalg.norm([0.2, -0.5, 0.1, 0.9]),
+               boost_velocity=np.array([-0.17, 0.16, 0.19]))
+    new = abd.transform(**kw2)
+    arr = lambda m: np.asarray(m).view(np.ndarray)
+    out.update(abd_u=u, abd_ell_max=L2, **{"abd_" + k: v for k, v in kw2.items()}, abd_u_out=np.array(new.t),
+               abd_raw_out=np.array([arr(getattr(new, f)) for f in ("psi0", "psi1", "psi2", "psi3", "psi4", "sigma")]))
+    np.savez_compressed(os.path.join(HERE, "g28_ref_relativistic_transforms.npz"),
+                        source="scri/waveform_grid.py:331-630, scri/asymptotic_bondi_data/transformations.py:199-431 (the reference's files, stand-ins underneath)", **out)
+
+
 if __name__ == "__main__":
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
-        every = (g10, g8, g9, g11, g12, g13, g14, g15, g16, g17, g18, g19, g20, g21, g22, g23, g24, g25, g26, g27)
+        every = (g10, g8, g9, g11, g12, g13, g14, g15, g16, g17, g18, g19, g20, g21, g22, g23, g24, g25, g26, g27, g28)
         only = [f for f in every if "--" + f.__name__ in sys.argv]
         for f in only or every:
             f()

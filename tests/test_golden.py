@@ -522,3 +522,67 @@ def test_g14_gpu_vs_reference_fluxes(ctx):
         scri_amd.angular_momentum_flux(hdot)
     with pytest.raises(ValueError, match="can only be calculated from a `WaveformModes` object"):
         scri_amd.energy_flux(g["data"])
+
+
+# ------------------------------------------------------------------------------------------------ g28: the relativistic regime
+
+
+def _g28_inputs(g):
+    """the fixture holds outputs (every 4th row) and parameters; the inputs are regenerated from the generator's seeds"""
+    from scri_amd import synthetic
+
+    t, L = g["wm_t"], int(g["wm_ell_max"])
+    kw = dict(supertranslation=g["wm_supertranslation"], frame_rotation=g["wm_frame_rotation"], boost_velocity=g["wm_boost_velocity"])
+    wm = {name: synthetic.chirp_modes(t, 2, L, seed) * (1 + 0.004 * t[:, None]) for name, seed in (("h", 282), ("news", 283), ("psi4", 284))}
+    d1 = synthetic.chirp_modes(t, 1, 8, 285)
+    comp = {k: (s_, 8 - k + 2, synthetic.chirp_modes(t, s_, 8 - k + 2, 285 + k)) for k, s_ in ((2, 0), (3, 1), (4, 2))}
+    assert [[v[0], v[1]] for v in comp.values()] == g["psi1_companion_ell"].tolist()
+    u, L2 = g["abd_u"], int(g["abd_ell_max"])
+    raw = np.zeros((6, u.size, (L2 + 1) ** 2), dtype=complex)
+    for f, s_ in enumerate(synthetic.ABD_SPINS):
+        raw[f] = synthetic.chirp_modes(u, 0, L2, 290 + f) * (1 + 0.01 * u[:, None])
+        raw[f, :, : s_ * s_] = 0
+    kw2 = dict(supertranslation=g["abd_supertranslation"], frame_rotation=g["abd_frame_rotation"], boost_velocity=g["abd_boost_velocity"])
+    return t, L, kw, wm, d1, comp, u, L2, raw, kw2
+
+
+def test_g28_oracle_vs_reference_relativistic_transforms():
+    """g8 / g9 where nothing is small (|v| = 0.35 / 0.30, supertranslations of order one, l up to 10, non-uniform time axes): the
+    oracle against scri/waveform_grid.py:331-630 and scri/asymptotic_bondi_data/transformations.py:199-431 run by the reference's files"""
+    from oracle import containers as oc
+
+    g = load("g28_ref_relativistic_transforms.npz")
+    t, L, kw, wm, d1, comp, u, L2, raw, kw2 = _g28_inputs(g)
+    for name, data in wm.items():
+        o = grid_ref.transform(WM(t=t, data=data, ell_min=2, ell_max=L, dataType=getattr(oc, name)), **kw)
+        ref = g[f"{name}_out"]
+        assert np.array_equal(o.t, g[f"{name}_t_out"]) and np.abs(o.data[::4] - ref).max() < 1e-12 * np.abs(ref).max(), name
+    o = grid_ref.transform(WM(t=t, data=d1, ell_min=1, ell_max=8, dataType=oc.psi1),
+                           **{f"psi{k}_modes": WM(t=t, data=v[2], ell_min=v[0], ell_max=v[1], dataType=getattr(oc, f"psi{k}")) for k, v in comp.items()}, **kw)
+    assert np.array_equal(o.t, g["psi1_t_out"]) and np.abs(o.data[::4] - g["psi1_out"]).max() < 1e-12 * np.abs(g["psi1_out"]).max()
+    o = abd_ref.transform(ABD(u, raw, L2), **kw2)
+    assert np.array_equal(o.u, g["abd_u_out"])
+    for f in range(6):
+        assert np.abs(o.raw[f] - g["abd_raw_out"][f]).max() < 1e-12 * np.abs(g["abd_raw_out"][f]).max(), f
+
+
+@pytest.mark.gpu
+def test_g28_gpu_vs_reference_relativistic_transforms(ctx):
+    import scri_amd
+
+    g = load("g28_ref_relativistic_transforms.npz")
+    t, L, kw, wm, d1, comp, u, L2, raw, kw2 = _g28_inputs(g)
+    for name, data in wm.items():
+        o = _gpu_wm(t, data, 2, L, getattr(scri_amd, name), ctx).transform(**kw)
+        ref = g[f"{name}_out"]
+        assert o.t.shape == g[f"{name}_t_out"].shape and np.abs(o.t - g[f"{name}_t_out"]).max() < 1e-12, name
+        assert np.abs(o.data[::4] - ref).max() < 1e-12 * np.abs(ref).max(), name
+    o = _gpu_wm(t, d1, 1, 8, scri_amd.psi1, ctx).transform(
+        **{f"psi{k}_modes": _gpu_wm(t, v[2], v[0], v[1], getattr(scri_amd, f"psi{k}"), ctx) for k, v in comp.items()}, **kw)
+    assert o.t.shape == g["psi1_t_out"].shape and np.abs(o.data[::4] - g["psi1_out"]).max() < 1e-12 * np.abs(g["psi1_out"]).max()
+    a = scri_amd.AsymptoticBondiData(u, L2, ctx=ctx)
+    a._raw_data[:] = raw
+    o = a.transform(**kw2)
+    assert o.n_times == g["abd_u_out"].shape[0] and np.abs(o.u - g["abd_u_out"]).max() < 1e-12
+    for f in range(6):
+        assert np.abs(o._raw_data[f] - g["abd_raw_out"][f]).max() < 1e-12 * np.abs(g["abd_raw_out"][f]).max(), f
