@@ -72,7 +72,7 @@ def exchange_halos(local, have, need, all_have, all_need, group=None, dim=0, out
             ops.append(dist.P2POp(dist.isend, loc[a - have[0] : b - have[0]].contiguous().to(wire), peer, group))
     reqs = dist.batch_isend_irecv(ops) if ops else []
 
-    def finish():
+    def finish(_in_flight=ops):  # (the send buffers stay referenced until the exchange has been waited for)
         for req in reqs:
             req.wait()
         o = out
