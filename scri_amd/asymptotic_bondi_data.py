@@ -195,7 +195,7 @@ class AsymptoticBondiData:
         if group is not None:
             from . import sharding
 
-            u_global, have = sharding.gather_time_axis(self._time, group)
+            u_global, have = sharding.gather_time_axis(self._time, group, ctx=self._ctx)
             u_new, raw_new, _ = sharding.transform_abd_sharded(self._raw_dev if self._device else self._raw_data, u_global, self.ell_max, tr,
                                                               group=group, have=have, ctx=self._ctx)
             if self._device:

@@ -191,15 +191,26 @@ def reduce_scatter_rows(partial, n_rows, group=None):
 # WaveformModes.transform(group=...) and AsymptoticBondiData.transform(group=...) forward to them.
 
 
-def gather_time_axis(t_local, group=None):
+def gather_time_axis(t_local, group=None, ctx=None):
     """Every rank's block of the time axis -> (t_global, have): the global axis and the rows [i0, i1) each rank owns, in rank
-    order (8 bytes per sample: the one piece of metadata a rank-local series lacks)."""
+    order (8 bytes per sample: the one piece of metadata a rank-local series lacks).  ctx: this rank's engine context -- RCCL
+    moves objects through the CURRENT device, which a caller who never called torch.cuda.set_device leaves at 0 on every rank."""
+    import contextlib
+
     import numpy as np
     import torch.distributed as dist
 
     world = dist.get_world_size(group)
     blocks = [None] * world
-    dist.all_gather_object(blocks, np.ascontiguousarray(t_local, dtype=float), group=group)
+    on_device = contextlib.nullcontext()
+    if dist.get_backend(group) == "nccl":
+        import torch
+
+        from ._lib import default_context
+
+        on_device = torch.cuda.device(int((ctx or default_context()).device))
+    with on_device:
+        dist.all_gather_object(blocks, np.ascontiguousarray(t_local, dtype=float), group=group)
     have, i0 = [], 0
     for b in blocks:
         have.append((i0, i0 + b.shape[0]))

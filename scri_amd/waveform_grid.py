@@ -243,7 +243,7 @@ def transform(w_modes, **kwargs):
 
         if trailing or aux:
             raise NotImplementedError("a series sharded over a process group carries neither trailing data dimensions nor psi companions")
-        t_global, have = sharding.gather_time_axis(w_modes.t, group)
+        t_global, have = sharding.gather_time_axis(w_modes.t, group, ctx=w_modes._ctx)
         resident = getattr(w_modes, "is_device_resident", False)
         t_new, rows, _ = sharding.transform_modes_sharded(
             w_modes._dev if resident else w_modes.data, t_global, w_modes.ell_min, w_modes.ell_max, s, w_modes.conformal_weight, type_term, tr,
