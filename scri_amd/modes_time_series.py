@@ -68,12 +68,16 @@ class Grid(np.ndarray):
             s = sum(weights)
         elif ufunc in (np.divide, np.true_divide):
             s = (inputs[0]._s if isinstance(inputs[0], Grid) else 0) - (inputs[1]._s if isinstance(inputs[1], Grid) else 0)
-        elif ufunc is np.conjugate:
+        elif ufunc is np.conjugate and weights:
             s = -weights[0]
+        elif ufunc is np.absolute:
+            s = 0
+        elif ufunc in (np.power, np.float_power) and isinstance(inputs[0], Grid) and np.ndim(inputs[1]) == 0:
+            s = int(round(inputs[0]._s * float(np.real(inputs[1]))))
         elif ufunc in (np.add, np.subtract) and len(set(weights)) > 1:
             raise ValueError(f"The grids have spin weights {weights[0]} and {weights[1]}; their sum is not a spin-weighted function")
         else:
-            s = weights[0]
+            s = weights[0] if weights else 0
         return Grid(result, spin_weight=s)
 
     @property

@@ -199,6 +199,7 @@ def test_modes_time_series_evaluate_and_grid(ctx, s, ell_min, ell_max):
         eg = np.einsum("tk,abk->tab", a, wigner.swsh_grid(Rg, s, ell_max)[..., ell_min**2 :])
         assert np.abs(g.ndarray - eg).max() < 2e-13 * np.abs(eg).max()
     assert g.real.s == s and (g * g).s == 2 * s and np.conjugate(g).s == -s and (g / g).s == 0 and (2.0 * g).s == s and (g + g).s == s
+    assert abs(g).s == 0 and (g**3).s == 3 * s and (g**-1).s == -s
     assert isinstance(g.real, Grid) and g.real.dtype == np.float64 and np.array_equal(g.real.ndarray, g.ndarray.real)
     if s != 0:
         with pytest.raises(ValueError):
