@@ -72,6 +72,10 @@ class Grid(np.ndarray):
             s = -weights[0]
         elif ufunc is np.absolute:
             s = 0
+        elif ufunc is np.square:  # (what numpy makes of x**2, x**-1)
+            s = 2 * weights[0]
+        elif ufunc is np.reciprocal:
+            s = -weights[0]
         elif ufunc in (np.power, np.float_power) and isinstance(inputs[0], Grid) and np.ndim(inputs[1]) == 0:
             s = int(round(inputs[0]._s * float(np.real(inputs[1]))))
         elif ufunc in (np.add, np.subtract) and len(set(weights)) > 1:
