@@ -14,7 +14,6 @@ import numpy as np
 
 from . import engine
 from .mode_algebra import LM_index
-from .modes_time_series import ModesTimeSeries
 
 
 # ------------------------------------------------------------------------------------------------- helpers on [n, (L+1)^2] arrays
