@@ -551,7 +551,7 @@ def inprocess_line(args):
         },
         "parity": {"bit_identical_to_one_context_with_the_same_shards": same_bits, "max_abs_diff_vs_default_one_context_call": diff,
                    "scale_max_abs": scale, "bar": 1e-14 * scale, "within_bar": bool(same_bits and diff <= 1e-14 * scale)},
-        "one_context_same_run": {"ms_per_step": one_ctx_ms, "pieces": engine.PIPELINE_PIECES},
+        "one_context_same_run": {"ms_per_step": one_ctx_ms, "pieces": engine.PIPELINE_PIECES if abd else engine.auto_pieces(n_global, ell_max, data.nbytes)},
     }
     print("\n" + json.dumps(line), flush=True)
     return 0 if line["parity"]["within_bar"] else 1

@@ -154,6 +154,36 @@ def make_transformation(supertranslation, frame_rotation, boost_velocity, n_thet
 # Host arrays in and out: below this size one call moves the data and computes; above it the time axis is pipelined
 PIPELINE_MIN_BYTES = 64 << 20
 PIPELINE_PIECES = int(os.environ.get("SCRI_AMD_PIPELINE_PIECES", "10"))  # cfg3, round 2: 15.5 ms at 4 pieces, 15.0 at 6, 13.9 at 8, 13.6 at 10 (26.9 as one call)
+_PIECES_FORCED = "SCRI_AMD_PIPELINE_PIECES" in os.environ
+
+
+def auto_pieces(n_rows, ell_max, nbytes):
+    """Time shards of a host-memory WaveformModes call on ONE context, from the series' shape (profiles/r06_r_host_path_by_size.txt:
+    l <= 4, 8, 16, 24, 2.5e3 .. 4e5 rows, 1 .. 20 shards each).  More shards overlap more of the transfers with the kernels -- until a
+    shard falls below about 70 000 / l_max rows, where upload, kernels and download stop running side by side (the call is 50 % slower
+    from one shard count to the next, and bimodal at the edge).  So: shards of at least 100 000 / l_max rows, at most 20 of them; a
+    series too short for two such shards is still cut in two from 16 MB on (1.77 against 2.34 ms at 43 MB, l <= 16).  1: one call.
+    Against the fixed ten shards from 64 MB on that this replaces: 87 MB 3.79 -> 2.94 ms, 130 MB 5.28 -> 4.00, 44 MB 2.34 -> 1.77,
+    435 MB 11.0 -> 10.7 (l <= 16); 117 MB 4.74 -> 3.31 (l <= 8)."""
+    if _PIECES_FORCED:
+        return PIPELINE_PIECES if nbytes >= PIPELINE_MIN_BYTES else 1
+    rows_per_piece = -(-100000 // max(int(ell_max), 4))
+    pieces = min(int(n_rows) // rows_per_piece, 20)
+    if pieces < 2:
+        pieces = 2 if nbytes >= min(16 << 20, PIPELINE_MIN_BYTES) else 1  # (PIPELINE_MIN_BYTES: the threshold of the six-field call; tests lower it)
+    return pieces
+
+
+def auto_pieces_abd(nbytes):
+    """The same choice for the six-field call (profiles/r06_r_host_path_by_size.txt, second half): a shard of six fields costs about a
+    millisecond of set-up of its own (six synthesis matrices), so shards of at least 75 MB, at most ten, one call below 64 MB.  Against the
+    fixed ten shards this replaces: 77 MB 14.1 -> 6.3 ms, 155 MB 17.0 -> 10.4, 309 MB 23.0 -> 17.8 (l <= 12); 90 MB 10.2 -> 5.1 (l <= 6);
+    unchanged from 600 MB on."""
+    if _PIECES_FORCED:
+        return PIPELINE_PIECES if nbytes >= PIPELINE_MIN_BYTES else 1
+    if nbytes < PIPELINE_MIN_BYTES:
+        return 1
+    return max(2, min(int(nbytes // (75 << 20)), 10))
 
 
 _device_contexts = {}  # (device, slot) -> Context of the one-process multi-device calls (slot: the k-th context on that device)
@@ -442,10 +472,12 @@ def transform_modes(
         res = _transform_modes_multi(t, data, inp, transformation, n_out, ctxs, int(pieces or pieces_for(devices)))
         if res is not None:
             return res
-    elif shard is None and not aux and (pieces is not None or data.nbytes >= PIPELINE_MIN_BYTES) and not os.environ.get("SCRI_AMD_NO_PIPELINE"):
-        res = _transform_modes_pipelined(t, data, inp, transformation, n_out, ctx, pieces=pieces)
-        if res is not None:
-            return res
+    elif shard is None and not aux and not os.environ.get("SCRI_AMD_NO_PIPELINE"):
+        chosen = int(pieces) if pieces is not None else auto_pieces(n, ell_max, data.nbytes)
+        if pieces is not None or chosen >= 2:
+            res = _transform_modes_pipelined(t, data, inp, transformation, n_out, ctx, pieces=chosen)
+            if res is not None:
+                return res
     out = _lib.pinned_empty((max(n_alloc, 1), n_out), np.complex128)
     rc = _lib.load().bms_transform_modes_shard(
         ctx.handle, ctypes.byref(inp), ctypes.byref(transformation), shp, dptr(t_out), vptr(out), ctypes.byref(n_new),
@@ -588,7 +620,7 @@ def transform_abd(u, raw, ell_max, transformation, ctx=None, shard=None, device=
         fs_out = i_hi - i_lo
         u_out = np.empty(max(fs_out, 1), dtype=float)
     out = _lib.pinned_empty((6, max(fs_out, 1), n_out), np.complex128)
-    n_pieces = int(pieces or (pieces_for(devices) if devices else PIPELINE_PIECES))
+    n_pieces = int(pieces or (pieces_for(devices) if devices else auto_pieces_abd(raw.nbytes)))
     if devices and fs_out >= 8 * n_pieces and np.all(np.diff(u) > 0):
         # one process, several GPUs: the time shards dealt over one context per device, rows + halo shipped at upload time
         ctxs = contexts_for(devices, first=ctx)
@@ -603,7 +635,7 @@ def transform_abd(u, raw, ell_max, transformation, ctx=None, shard=None, device=
             if got.value != out.shape[1]:
                 raise RuntimeError(f"the dealt ABD transform produced a window of {got.value} rows, {out.shape[1]} expected")
             return u_out, out
-    elif (shard is None and (pieces is not None or raw.nbytes >= PIPELINE_MIN_BYTES) and fs_out >= 8 * n_pieces
+    elif (shard is None and (pieces is not None or n_pieces >= 2) and fs_out >= 8 * n_pieces
           and not os.environ.get("SCRI_AMD_NO_PIPELINE")):
         # a long series in host memory: uploads, kernels and downloads of consecutive time shards side by side
         rc = _lib.load().bms_transform_abd_pipelined(

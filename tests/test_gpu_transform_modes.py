@@ -184,6 +184,9 @@ def test_trailing_dimensions_are_one_engine_call(ctx, monkeypatch):
     lib = _lib.load()
     calls = {"series": 0, "single": 0}
     real_series, real_single = lib.bms_transform_modes_series, lib.bms_transform_modes_shard
+    # (the single-series calls as ONE engine call each: from 16 MB on a host-memory series is otherwise cut into time shards that overlap
+    # the transfers with the kernels, engine.auto_pieces -- equal to rounding, not bit for bit, and another entry point)
+    monkeypatch.setenv("SCRI_AMD_NO_PIPELINE", "1")
 
     class Counting:
         def __init__(self, fn, key):
@@ -213,6 +216,7 @@ def test_trailing_dimensions_are_one_engine_call(ctx, monkeypatch):
         one = wm(np.ascontiguousarray(psi3[:, :, k]), scri_amd.psi3, 1).transform(psi4_modes=wm(np.ascontiguousarray(psi4[:, :, k]), scri_amd.psi4), **kw)
         assert np.array_equal(both.data[:, :, k], one.data), k
     monkeypatch.undo()
+    monkeypatch.setenv("SCRI_AMD_NO_PIPELINE", "1")
     # cost: four series in one call against four calls
     w4, w1 = wm(four), wm(np.ascontiguousarray(four[:, :, 0]))
     for _ in range(2):

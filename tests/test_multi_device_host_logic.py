@@ -97,3 +97,22 @@ def test_devices_refuse_shards_and_device_pointers():
         engine.transform_modes(t, np.zeros((40, 5), dtype=complex), 2, 2, -2, -1, engine.BMS_TERM_H, tr, devices=[0, 0], shard=(0, 40, 0, 40))
     with pytest.raises(ValueError, match="devices"):
         engine.transform_abd(t, 0, 2, tr, devices=[0, 0], device=True, out_ptr=0)
+
+
+def test_time_shard_count_of_the_host_path_follows_the_series_shape():
+    """engine.auto_pieces: shards of at least 100 000 / l_max rows, at most 20, two from 16 MB on, one call below
+    (profiles/r06_r_host_path_by_size.txt)"""
+    from scri_amd import engine
+
+    row16 = 285 * 16
+    assert engine.auto_pieces(100_000, 16, 100_000 * row16) == 16  # cfg3
+    assert engine.auto_pieces(1_000_000, 16, 1_000_000 * row16) == 20  # cfg4: the cap
+    assert engine.auto_pieces(20_000, 16, 20_000 * row16) == 3
+    assert engine.auto_pieces(10_000, 16, 10_000 * row16) == 2  # 43 MB: too short for two full shards, cut in two all the same
+    assert engine.auto_pieces(2_000, 16, 2_000 * row16) == 1  # 9 MB: one call
+    assert engine.auto_pieces(100_000, 8, 100_000 * 77 * 16) == 8
+    assert engine.auto_pieces(2_000, 4, 2_000 * 21 * 16) == 1  # cfg1
+    for n in (10, 1000, 10**5, 10**7):
+        for L in (2, 8, 16, 32, 64):
+            p = engine.auto_pieces(n, L, n * ((L + 1) ** 2 - 4) * 16)
+            assert 1 <= p <= 20 and (p == 1 or n // p >= 1)
