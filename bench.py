@@ -508,7 +508,7 @@ def inprocess_line(args):
                                     n_theta, n_theta, ell_max)
     gen = synthetic.abd_workload if abd else synthetic.workload
     t, data, _ = gen(workload, n_times=n_global, axis=args.time_axis)
-    pieces = engine.pieces_for(devices)
+    pieces = engine.pieces_for(devices, n_global, ell_max, data.nbytes, abd=abd)
 
     def go(devs, pcs):
         if abd:

@@ -223,11 +223,21 @@ def contexts_for(devices, first=None):
     return out
 
 
-def pieces_for(devices):
-    """How many time shards a multi-device call cuts the output window into: at least three per context (upload, kernels and
-    download of neighbouring shards overlap inside each context as in the one-context pipeline)"""
+def pieces_for(devices, n_rows=None, ell_max=None, nbytes=None, abd=False):
+    """How many time shards a multi-device call cuts the output window into.  Every context runs the one-context pipeline on its share
+    of the series (its own link, its own three streams), so its share is cut by the one-context rule for a series of that size
+    (auto_pieces / auto_pieces_abd on n_rows / n, nbytes / n), at least two shards per context where the share allows it: upload,
+    kernels and download of neighbouring shards overlap inside each context.  Without the shape: three per context and at least
+    PIPELINE_PIECES in all (round 6's first rule -- which at cfg3 on eight devices cuts shards of 4 166 rows, on the edge
+    profiles/r06_r_host_path_by_size.txt shows)."""
     n = len(devices)
-    return n * max(3, -(-PIPELINE_PIECES // n))
+    if n_rows is None or nbytes is None or (ell_max is None and not abd) or _PIECES_FORCED:
+        return n * max(3, -(-PIPELINE_PIECES // n))
+    share_rows, share_bytes = int(n_rows) // n, int(nbytes) // n
+    per = auto_pieces_abd(share_bytes) if abd else auto_pieces(share_rows, ell_max, share_bytes)
+    if per < 2 and share_rows >= 64:
+        per = 2
+    return n * per
 
 
 def _run_dealt(ctxs, pieces, call):
@@ -469,7 +479,7 @@ def transform_modes(
         _lib.register_if_reused(data)  # an input array seen for the second time is page-locked in place: uploads at PCIe rate
     if devices:
         ctxs = contexts_for(devices, first=ctx)
-        res = _transform_modes_multi(t, data, inp, transformation, n_out, ctxs, int(pieces or pieces_for(devices)))
+        res = _transform_modes_multi(t, data, inp, transformation, n_out, ctxs, int(pieces or pieces_for(devices, n, ell_max, data.nbytes)))
         if res is not None:
             return res
     elif shard is None and not aux and not os.environ.get("SCRI_AMD_NO_PIPELINE"):
@@ -620,7 +630,7 @@ def transform_abd(u, raw, ell_max, transformation, ctx=None, shard=None, device=
         fs_out = i_hi - i_lo
         u_out = np.empty(max(fs_out, 1), dtype=float)
     out = _lib.pinned_empty((6, max(fs_out, 1), n_out), np.complex128)
-    n_pieces = int(pieces or (pieces_for(devices) if devices else auto_pieces_abd(raw.nbytes)))
+    n_pieces = int(pieces or (pieces_for(devices, n, None, raw.nbytes, abd=True) if devices else auto_pieces_abd(raw.nbytes)))
     if devices and fs_out >= 8 * n_pieces and np.all(np.diff(u) > 0):
         # one process, several GPUs: the time shards dealt over one context per device, rows + halo shipped at upload time
         ctxs = contexts_for(devices, first=ctx)

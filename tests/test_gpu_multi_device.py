@@ -18,16 +18,16 @@ def test_cfg3_four_contexts_bit_identical_to_one(ctx, axis):
     tr = engine.make_transformation(kw["supertranslation"], kw["frame_rotation"], kw["boost_velocity"], 37, 37, 16)
     args = (t, data, 2, 16, -2, -1, engine.BMS_TERM_H, tr)
     devices = [0, 0, 0, 0]
-    pieces = engine.pieces_for(devices)
-    assert pieces == 12
+    pieces = engine.pieces_for(devices, t.size, 16, data.nbytes)  # (each context's 25 000 rows cut by the one-context rule: four shards of 6 250)
+    assert pieces == 16
     t_one, d_one = engine.transform_modes(*args, ctx=ctx, pieces=pieces)
     t_four, d_four = engine.transform_modes(*args, ctx=ctx, devices=devices)
     assert np.array_equal(t_four, t_one) and np.array_equal(d_four, d_one)
-    # however the shards are dealt: three contexts, five contexts, the same twelve shards
+    # however the shards are dealt: three contexts, five contexts, the same sixteen shards
     for devs in ([0, 0, 0], [0] * 5):
         t_k, d_k = engine.transform_modes(*args, ctx=ctx, devices=devs, pieces=pieces)
         assert np.array_equal(t_k, t_one) and np.array_equal(d_k, d_one)
-    # against the default call (ten shards) and the one-call device path: rounding
+    # against the default one-context call (its own shard count) : rounding
     t_def, d_def = engine.transform_modes(*args, ctx=ctx)
     assert np.array_equal(t_def, t_one)
     assert np.abs(d_def - d_one).max() < 1e-14 * np.abs(d_def).max()
@@ -41,7 +41,8 @@ def test_cfg5_slice_four_contexts_bit_identical_to_one(ctx):
     n_theta = 2 * (2 * L + 1) + 1
     tr = engine.make_transformation(kw["supertranslation"], kw["frame_rotation"], kw["boost_velocity"], n_theta, n_theta, L)
     devices = [0, 0, 0, 0]
-    pieces = engine.pieces_for(devices)
+    pieces = engine.pieces_for(devices, u.size, None, raw.nbytes, abd=True)
+    assert pieces == 8
     u_one, r_one = engine.transform_abd(u, raw, L, tr, ctx=ctx, pieces=pieces)
     u_four, r_four = engine.transform_abd(u, raw, L, tr, ctx=ctx, devices=devices)
     assert np.array_equal(u_four, u_one) and np.array_equal(r_four, r_one)

@@ -39,6 +39,17 @@ def test_shard_counts_keep_three_shards_per_context():
     for n in range(1, 17):
         p = engine.pieces_for([0] * n)
         assert p % n == 0 and p // n >= 3 and p >= engine.PIPELINE_PIECES
+    # with the series' shape: every context's share cut by the one-context rule, two shards per context at least
+    row16 = 285 * 16
+    assert engine.pieces_for(list(range(8)), 100_000, 16, 100_000 * row16) == 8 * 2  # cfg3: 12 500 rows per device, two shards of 6 250
+    assert engine.pieces_for(list(range(8)), 1_000_000, 16, 1_000_000 * row16) == 8 * 20  # cfg4: 125 000 rows per device, the cap
+    assert engine.pieces_for([0, 1], 100_000, 16, 100_000 * row16) == 2 * 8
+    assert engine.pieces_for(list(range(8)), 200_000, None, 6 * 200_000 * 625 * 16, abd=True) == 8 * 10  # cfg5: 1.5 GB per device
+    assert engine.pieces_for(list(range(8)), 16_000, None, 6 * 16_000 * 625 * 16, abd=True) == 8 * 2
+    for n in (1, 2, 4, 8):
+        for rows in (500, 20_000, 3_000_000):
+            p = engine.pieces_for([0] * n, rows, 16, rows * row16)
+            assert p % n == 0 and 1 <= p // n <= 20
 
 
 def test_a_failing_context_reaches_the_caller():
