@@ -70,6 +70,74 @@ int rotate_impl(bms_ctx* c, void* data, int mem, int64_t n_times, int64_t ld, in
   const double* d_rot = (const double*)spinors;
   const size_t data_bytes = ((size_t)(n_times - 1) * ld + n_modes) * 16;  // a strided view ends with its last row's modes
   const size_t rot_bytes = (series ? (size_t)n_times : 1) * 32;
+  auto launch_segments = [&](double* base, int64_t rows, int64_t pitch, const double* rot) -> int {
+    for (const Segment& sg : segs) {
+      double* seg_data = base + 2 * ((long long)sg.lo * sg.lo - (long long)ell_min * ell_min);
+      if (sg.kind == 0)
+        TIMED(c, BMS_TAG_ROTATE, launch_rotate_modes_resident(c->stream, seg_data, rows, pitch, rot, series ? 4 : 0, sg.tab, sg.plan, sg.lds, nullptr, c->n_cu));
+      else if (sg.kind == 1)
+        TIMED(c, BMS_TAG_ROTATE, launch_rotate_modes_mfma(c->stream, seg_data, rows, pitch, sg.lo, sg.hi, rot, series ? 4 : 0, d_delta, d_off));
+      else
+        TIMED(c, BMS_TAG_ROTATE, launch_rotate_modes(c->stream, seg_data, rows, pitch, sg.lo, sg.hi, rot, series ? 4 : 0, d_delta, d_off));
+    }
+    return BMS_OK;
+  };
+  // A long series in HOST memory is all transfer (cfg2: 117 MB each way at 57 GB/s against 0.1 ms of kernel), and one call sends it, turns it
+  // and brings it back one after the other.  The link is full duplex: blocks of rows go up on one stream, are rotated on the context's
+  // stream and come back on a third, ordered by events, two staging buffers -- the rows are independent, so there is no halo; the
+  // result is the one-call result to the last bit or two (a row's rounding depends on the launch geometry of the kernel: 5e-16,
+  // tools/probes/rot_block_probe.py).  From page-locked memory (bms_host_register / bms_host_alloc) the copies run at the rate
+  // of the link and side by side (l <= 16, 1e5 steps: 16.3 -> 9 ms); from pageable memory the runtime stages them and little is gained.
+  const size_t row_bytes = (size_t)n_modes * 16;
+  int blocks = c->opt.on(OPT_NO_ROTATE_PIPELINE) ? 1 : (int)std::min<size_t>(16, (size_t)n_times * row_bytes / (12u << 20));  // (blocks of >= 12 MB, <= 16 of them: host_rotation_by_blocks.py)
+  if (const char* e = BMS_PROBE_ENV("SCRI_AMD_ROTATE_BLOCKS")) blocks = atoi(e);
+  if (mem == BMS_HOST && blocks >= 2 && n_times >= 64 * blocks) {
+    const int64_t rows_max = (n_times + blocks - 1) / blocks;
+    double* d_buf[2];
+    if ((rc = dev_buf_t(c, "rot_pipe0", (size_t)rows_max * n_modes * 2, &d_buf[0]))) return rc;
+    if ((rc = dev_buf_t(c, "rot_pipe1", (size_t)rows_max * n_modes * 2, &d_buf[1]))) return rc;
+    const double* d_r = nullptr;
+    {
+      double* r = nullptr;
+      if ((rc = dev_buf_t(c, "rot_spinors", rot_bytes / 8, &r))) return rc;
+      HIP_TRY(c, hipMemcpyAsync(r, spinors, rot_bytes, hipMemcpyHostToDevice, c->stream));
+      d_r = r;
+    }
+    if (!c->pipe_up) {
+      HIP_TRY(c, hipStreamCreateWithFlags(&c->pipe_up, hipStreamNonBlocking));
+      HIP_TRY(c, create_download_stream(c));
+    }
+    std::vector<hipEvent_t> ev(3 * (size_t)blocks);
+    for (auto& e : ev) e = ScopedTimer::get(c);
+    hipError_t he = hipSuccess;
+    char* host = (char*)data;
+    for (int k = 0; k < blocks && he == hipSuccess && rc == BMS_OK; ++k) {
+      const int64_t r0 = (int64_t)n_times * k / blocks, r1 = (int64_t)n_times * (k + 1) / blocks, rows = r1 - r0;
+      double* buf = d_buf[k & 1];
+      hipEvent_t up = ev[3 * k], done = ev[3 * k + 1], down = ev[3 * k + 2];
+      if (k >= 2 && (he = hipStreamWaitEvent(c->pipe_up, ev[3 * (k - 2) + 2], 0)) != hipSuccess) break;  // the buffer's last rows have left
+      if ((he = hipMemcpy2DAsync(buf, row_bytes, host + (size_t)r0 * ld * 16, (size_t)ld * 16, row_bytes, (size_t)rows, hipMemcpyHostToDevice,
+                                 c->pipe_up)) != hipSuccess)
+        break;
+      if ((he = hipEventRecord(up, c->pipe_up)) != hipSuccess) break;
+      if ((he = hipStreamWaitEvent(c->stream, up, 0)) != hipSuccess) break;
+      rc = launch_segments(buf, rows, n_modes, series ? d_r + 4 * r0 : d_r);
+      if (rc) break;
+      if ((he = hipEventRecord(done, c->stream)) != hipSuccess) break;
+      if ((he = hipStreamWaitEvent(c->pipe_down, done, 0)) != hipSuccess) break;
+      if ((he = hipMemcpy2DAsync(host + (size_t)r0 * ld * 16, (size_t)ld * 16, buf, row_bytes, row_bytes, (size_t)rows, hipMemcpyDeviceToHost,
+                                 c->pipe_down)) != hipSuccess)
+        break;
+      he = hipEventRecord(down, c->pipe_down);
+    }
+    (void)hipStreamSynchronize(c->pipe_up);
+    (void)hipStreamSynchronize(c->stream);
+    (void)hipStreamSynchronize(c->pipe_down);
+    for (auto e : ev) c->event_pool.push_back(e);
+    if (rc) return rc;
+    if (he != hipSuccess) return fail(c, BMS_ERR_HIP, "rotation of a host series in blocks: %s", hipGetErrorString(he));
+    return BMS_OK;
+  }
   if (!series && mem == BMS_DEVICE && !sync_after) {
     if (!c->rot_ring_host) {
       HIP_TRY(c, hipHostMalloc((void**)&c->rot_ring_host, 32 * ROT_RING, hipHostMallocDefault));
@@ -95,16 +163,7 @@ int rotate_impl(bms_ctx* c, void* data, int mem, int64_t n_times, int64_t ld, in
     if (rc) return rc;
     HIP_TRY(c, hipMemcpyAsync(d_data, data, data_bytes, hipMemcpyHostToDevice, c->stream));
   }
-  for (const Segment& sg : segs) {
-    double* seg_data = d_data + 2 * ((long long)sg.lo * sg.lo - (long long)ell_min * ell_min);
-    if (sg.kind == 0)
-      TIMED(c, BMS_TAG_ROTATE, launch_rotate_modes_resident(c->stream, seg_data, n_times, ld, d_rot, series ? 4 : 0, sg.tab, sg.plan, sg.lds,
-                                                            nullptr, c->n_cu));
-    else if (sg.kind == 1)
-      TIMED(c, BMS_TAG_ROTATE, launch_rotate_modes_mfma(c->stream, seg_data, n_times, ld, sg.lo, sg.hi, d_rot, series ? 4 : 0, d_delta, d_off));
-    else
-      TIMED(c, BMS_TAG_ROTATE, launch_rotate_modes(c->stream, seg_data, n_times, ld, sg.lo, sg.hi, d_rot, series ? 4 : 0, d_delta, d_off));
-  }
+  if ((rc = launch_segments(d_data, n_times, ld, d_rot))) return rc;
   if (mem == BMS_HOST) {
     HIP_TRY(c, hipMemcpyAsync(data, d_data, data_bytes, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));

@@ -42,7 +42,8 @@ namespace bms {
   X(GEMM_EVAL_STEP, "GEMM_EVAL_STEP")                          \
   X(GRID_MULTIPLY_FULL_GRID, "GRID_MULTIPLY_FULL_GRID")        \
   X(NO_ABD_SIGMA_EVAL, "NO_ABD_SIGMA_EVAL")                    \
-  X(NO_FUSED_ABD_MIX, "NO_FUSED_ABD_MIX")
+  X(NO_FUSED_ABD_MIX, "NO_FUSED_ABD_MIX")                      \
+  X(NO_ROTATE_PIPELINE, "NO_ROTATE_PIPELINE")
 
 enum RouteOpt : int {
 #define X(e, n) OPT_##e,

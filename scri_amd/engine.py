@@ -72,6 +72,7 @@ def rotate_const(data, ell_min, ell_max, quaternion, ctx=None, devices=None):
 
     if devices and len(devices) > 1 and data.shape[0] >= 2 * len(devices):
         return _rotate_dealt(data, devices, ctx, call)
+    _lib.register_if_reused(data)  # (seen a second time, a long series is page-locked in place: its blocks then go up and come back side by side)
     call(_ctx(ctx), 0, data.shape[0])
     return data
 
@@ -107,6 +108,7 @@ def rotate_series(data, ell_min, ell_max, spinors, ctx=None, devices=None):
 
     if devices and len(devices) > 1 and data.shape[0] >= 2 * len(devices):
         return _rotate_dealt(data, devices, ctx, call)
+    _lib.register_if_reused(data)
     call(_ctx(ctx), 0, data.shape[0])
     return data
 

@@ -44,7 +44,7 @@ ROUTE_OPTIONS = {
     "AXIS_BOOST_MIN_WORK", "GEMM_EVAL_STEP", "GRID_MULTIPLY_FULL_GRID", "NO_AXIS_BOOST_SEPARABLE", "NO_BSPLINE", "NO_COLUMN_SORT",
     "NO_FUSED_ABD_MIX", "NO_FUSED_ANALYSIS", "NO_GEMM_EVAL", "NO_LARGE_ANALYSIS", "NO_LARGE_SYNTHESIS", "NO_PLAN_CACHE",
     "NO_SEPARABLE_SYNTHESIS", "NO_SMALL_DENSE", "NO_SPLIT_ANALYSIS", "NO_SPLIT_SYNTHESIS", "ROTATE_STAGED", "ROTATE_VALU", "TRACE",
-    "TWO_SWEEPS", "WALK_FIRST", "SYNTHESIS_EVAL", "NO_SYNTHESIS_EVAL", "NO_ABD_SIGMA_EVAL",
+    "TWO_SWEEPS", "WALK_FIRST", "SYNTHESIS_EVAL", "NO_SYNTHESIS_EVAL", "NO_ABD_SIGMA_EVAL", "NO_ROTATE_PIPELINE",
 }
 
 

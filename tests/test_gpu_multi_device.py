@@ -162,3 +162,49 @@ def test_rotations_dealt_over_contexts_equal_the_one_context_call(ctx):
     q = np.array([1.0, 2, 3, 4]) / np.sqrt(30)
     ref = engine.rotate_const(data.copy(), 2, 16, q, ctx=ctx)
     assert np.abs(engine.rotate_const(data.copy(), 2, 16, q, ctx=ctx, devices=[0, 0, 0]) - ref).max() <= bar
+
+
+@pytest.mark.parametrize("series", [True, False])
+def test_host_rotation_in_blocks_equals_the_one_call_path(ctx, series):
+    """A long series in host memory is rotated in blocks of rows that go up, are turned and come back on three streams
+    (engine_rotate.hip; scri/rotations.py:346-392 on numpy arrays): equal to the one-call path (context option NO_ROTATE_PIPELINE) to the
+    last bits, to the oracle on a window, with a row stride wider than the modes and columns beside them left alone."""
+    from oracle import quat, rotations_ref, wigner
+    from scri_amd import engine, synthetic
+
+    n, L = 60000, 12  # 165 modes: 158 MB, 13 blocks
+    t = np.linspace(0.0, 600.0, n)
+    src = synthetic.chirp_modes(t, 2, L, 5)
+    nm = src.shape[1]
+    ang = 0.02 * t
+    sp = np.stack([np.cos(ang) * np.exp(0.3j * np.sin(0.01 * t)), np.sin(ang) * (0.6 + 0.8j)], axis=1)
+    q = np.array([0.5, -0.5, 0.5, 0.5])
+
+    def run(a):
+        if series:
+            engine.rotate_series(a, 2, L, sp, ctx=ctx)
+        else:
+            engine.rotate_const(a, 2, L, q, ctx=ctx)
+        return a
+
+    ctx.option("NO_ROTATE_PIPELINE", 1)
+    try:
+        whole = run(src.copy())
+    finally:
+        ctx.option("NO_ROTATE_PIPELINE", 0)
+    blocks = run(src.copy())
+    scale = np.abs(whole).max()
+    assert np.abs(blocks - whole).max() < 1e-14 * scale and not np.array_equal(blocks, src)
+    # a view with a wider row stride: the columns beside the modes are not touched
+    wide = np.full((n, nm + 7), 3.0 - 2.0j)
+    wide[:, :nm] = src
+    run(wide[:, :nm])
+    assert np.array_equal(wide[:, nm:], np.full((n, 7), 3.0 - 2.0j)) and np.abs(wide[:, :nm] - whole).max() < 1e-14 * scale
+    # the oracle on rows across a block boundary (60000 / 13 = 4615.4)
+    lo, hi = 4500, 4740
+    if series:
+        expect = rotations_ref.rotate_by_series(src[lo:hi], sp[lo:hi], 2, L)
+    else:
+        Ra, Rb = quat.as_spinor_array(q)
+        expect = rotations_ref.rotate_by_constant(src[lo:hi], 2, L, wigner.wigner_D_matrices(Ra, Rb, 2, L))
+    assert np.abs(blocks[lo:hi] - expect).max() < 1e-13 * scale
