@@ -225,6 +225,60 @@ extern "C" int bms_rotate_const_D(bms_ctx* c, void* data, int mem, int64_t n_tim
   const double* d_B = (const double*)vp;
   const size_t data_bytes = ((size_t)(n_times - 1) * ld + n_modes) * 16;  // a strided view ends with its last row's modes
   double* d_data = (double*)data;
+  // a long series in host memory: blocks of rows on three streams, as rotate_impl does (the product is out of place anyway: a block comes
+  // up into one buffer, its products go into a second one, and that one goes home -- no copy on the device)
+  const size_t row_bytes = (size_t)n_modes * 16;
+  const int blocks = c->opt.on(OPT_NO_ROTATE_PIPELINE) ? 1 : (int)std::min<size_t>(16, (size_t)n_times * row_bytes / (12u << 20));
+  if (mem == BMS_HOST && blocks >= 2 && n_times >= 64 * blocks) {
+    const int64_t rows_max = (n_times + blocks - 1) / blocks;
+    double *d_in[2], *d_out[2];
+    if ((rc = dev_buf_t(c, "rot_pipe0", (size_t)rows_max * n_modes * 2, &d_in[0]))) return rc;
+    if ((rc = dev_buf_t(c, "rot_pipe1", (size_t)rows_max * n_modes * 2, &d_in[1]))) return rc;
+    if ((rc = dev_buf_t(c, "rotD_pipe0", (size_t)rows_max * n_modes * 2, &d_out[0]))) return rc;
+    if ((rc = dev_buf_t(c, "rotD_pipe1", (size_t)rows_max * n_modes * 2, &d_out[1]))) return rc;
+    if (!c->pipe_up) {
+      HIP_TRY(c, hipStreamCreateWithFlags(&c->pipe_up, hipStreamNonBlocking));
+      HIP_TRY(c, create_download_stream(c));
+    }
+    std::vector<hipEvent_t> ev(3 * (size_t)blocks);
+    for (auto& e : ev) e = ScopedTimer::get(c);
+    auto products = [&](const double* in, double* out, int64_t rows) -> int {
+      for (int l = ell_min; l <= ell_max; ++l) {
+        const int n = 2 * l + 1;
+        const long long col = (long long)l * l - (long long)ell_min * ell_min;
+        TIMED(c, BMS_TAG_ROTATE, launch_zgemm3m(c->stream, in + 2 * col, 2 * n_modes, d_B + boff[l], round_up(n, 64) * 2, out + 2 * col, 2 * n_modes,
+                                                rows, n, n, nullptr, nullptr));
+      }
+      return BMS_OK;
+    };
+    hipError_t he = hipSuccess;
+    char* host = (char*)data;
+    for (int k = 0; k < blocks && he == hipSuccess && rc == BMS_OK; ++k) {
+      const int64_t r0 = (int64_t)n_times * k / blocks, r1 = (int64_t)n_times * (k + 1) / blocks, rows = r1 - r0;
+      hipEvent_t up = ev[3 * k], done = ev[3 * k + 1], down = ev[3 * k + 2];
+      if (k >= 2 && (he = hipStreamWaitEvent(c->pipe_up, ev[3 * (k - 2) + 1], 0)) != hipSuccess) break;  // the input buffer has been read
+      if ((he = hipMemcpy2DAsync(d_in[k & 1], row_bytes, host + (size_t)r0 * ld * 16, (size_t)ld * 16, row_bytes, (size_t)rows, hipMemcpyHostToDevice,
+                                 c->pipe_up)) != hipSuccess)
+        break;
+      if ((he = hipEventRecord(up, c->pipe_up)) != hipSuccess) break;
+      if ((he = hipStreamWaitEvent(c->stream, up, 0)) != hipSuccess) break;
+      if (k >= 2 && (he = hipStreamWaitEvent(c->stream, ev[3 * (k - 2) + 2], 0)) != hipSuccess) break;  // the output buffer has left
+      if ((rc = products(d_in[k & 1], d_out[k & 1], rows))) break;
+      if ((he = hipEventRecord(done, c->stream)) != hipSuccess) break;
+      if ((he = hipStreamWaitEvent(c->pipe_down, done, 0)) != hipSuccess) break;
+      if ((he = hipMemcpy2DAsync(host + (size_t)r0 * ld * 16, (size_t)ld * 16, d_out[k & 1], row_bytes, row_bytes, (size_t)rows, hipMemcpyDeviceToHost,
+                                 c->pipe_down)) != hipSuccess)
+        break;
+      he = hipEventRecord(down, c->pipe_down);
+    }
+    (void)hipStreamSynchronize(c->pipe_up);
+    (void)hipStreamSynchronize(c->stream);
+    (void)hipStreamSynchronize(c->pipe_down);
+    for (auto e : ev) c->event_pool.push_back(e);
+    if (rc) return rc;
+    if (he != hipSuccess) return fail(c, BMS_ERR_HIP, "rotation of a host series in blocks: %s", hipGetErrorString(he));
+    return BMS_OK;
+  }
   if (mem == BMS_HOST) {
     if ((rc = dev_buf_t(c, "rot_data", data_bytes / 8, &d_data))) return rc;
     HIP_TRY(c, hipMemcpyAsync(d_data, data, data_bytes, hipMemcpyHostToDevice, c->stream));

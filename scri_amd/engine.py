@@ -85,6 +85,7 @@ def rotate_const_D(data, ell_min, ell_max, D, ctx=None):
     D = np.ascontiguousarray(D, dtype=np.complex128)
     if D.shape != (total_size_D_matrices(ell_min, ell_max),):
         raise ValueError(f"D must hold {total_size_D_matrices(ell_min, ell_max)} elements, got shape {D.shape}")
+    _lib.register_if_reused(data)
     rc = _lib.load().bms_rotate_const_D(
         ctx.handle, vptr(data), BMS_HOST, data.shape[0], data.strides[0] // 16, ell_min, ell_max, vptr(D)
     )

@@ -164,7 +164,7 @@ def test_rotations_dealt_over_contexts_equal_the_one_context_call(ctx):
     assert np.abs(engine.rotate_const(data.copy(), 2, 16, q, ctx=ctx, devices=[0, 0, 0]) - ref).max() <= bar
 
 
-@pytest.mark.parametrize("series", [True, False])
+@pytest.mark.parametrize("series", [True, False, "D"])
 def test_host_rotation_in_blocks_equals_the_one_call_path(ctx, series):
     """A long series in host memory is rotated in blocks of rows that go up, are turned and come back on three streams
     (engine_rotate.hip; scri/rotations.py:346-392 on numpy arrays): equal to the one-call path (context option NO_ROTATE_PIPELINE) to the
@@ -180,8 +180,12 @@ def test_host_rotation_in_blocks_equals_the_one_call_path(ctx, series):
     sp = np.stack([np.cos(ang) * np.exp(0.3j * np.sin(0.01 * t)), np.sin(ang) * (0.6 + 0.8j)], axis=1)
     q = np.array([0.5, -0.5, 0.5, 0.5])
 
+    D = wigner.wigner_D_matrices(*quat.as_spinor_array(q), 2, L)
+
     def run(a):
-        if series:
+        if series == "D":  # (the seam of the reference's numba kernel: the packed matrices handed over, scri/rotations.py:346-367)
+            engine.rotate_const_D(a, 2, L, D, ctx=ctx)
+        elif series:
             engine.rotate_series(a, 2, L, sp, ctx=ctx)
         else:
             engine.rotate_const(a, 2, L, q, ctx=ctx)
@@ -202,9 +206,8 @@ def test_host_rotation_in_blocks_equals_the_one_call_path(ctx, series):
     assert np.array_equal(wide[:, nm:], np.full((n, 7), 3.0 - 2.0j)) and np.abs(wide[:, :nm] - whole).max() < 1e-14 * scale
     # the oracle on rows across a block boundary (60000 / 13 = 4615.4)
     lo, hi = 4500, 4740
-    if series:
+    if series is True:
         expect = rotations_ref.rotate_by_series(src[lo:hi], sp[lo:hi], 2, L)
     else:
-        Ra, Rb = quat.as_spinor_array(q)
-        expect = rotations_ref.rotate_by_constant(src[lo:hi], 2, L, wigner.wigner_D_matrices(Ra, Rb, 2, L))
+        expect = rotations_ref.rotate_by_constant(src[lo:hi], 2, L, D)
     assert np.abs(blocks[lo:hi] - expect).max() < 1e-13 * scale
