@@ -39,7 +39,7 @@ def dominant_kernel(abd):
 # the GPU it runs two short child passes of this same script under `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` (separate
 # passes, as MI355X_MICROARCH.md prescribes; traffic = 2 x FETCH_SIZE + WRITE_SIZE KiB on gfx950) and reads their counter CSVs.
 # Fallback: the committed summary of tools/run_profiles.sh, used only if it was taken on the same kernel sources.
-PMC_SUMMARY = os.path.join(ROOT, "profiles", "r06_u_pmc_cfg3.json")
+PMC_SUMMARY = os.path.join(ROOT, "profiles", "r06_v_pmc_cfg3.json")
 
 
 def csrc_hash():
