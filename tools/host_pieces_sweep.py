@@ -45,3 +45,33 @@ for seed in range(first, last):
         failures += 1
         print(f"FAILED seed {seed}: l <= {L} n {n} ({mb} MB) {axis} {kind} pieces {p}: shapes {t_def.shape} {t_one.shape} err {err:.2e}", flush=True)
 print(f"done, {last - first} cases, shard counts seen {sorted(pieces_seen)}, failures: {failures}")
+
+# the six-field call (engine.auto_pieces_abd): a third as many cases, 70 .. 400 MB
+pieces_seen = set()
+abd_failures = 0
+for seed in range(first, first + max(1, (last - first) // 3)):
+    rng = np.random.default_rng(9500 + seed)
+    L = int(rng.integers(4, 13))
+    nm = (L + 1) ** 2
+    mb = float(rng.choice([70, 100, 160, 250, 400]))
+    n = int(mb * 2**20 / (6 * nm * 16) * rng.uniform(0.9, 1.1))
+    u, raw, _ = synthetic.abd_workload("cfg5", n_times=n, ell_max=L, axis=str(rng.choice(["uniform", "sxs"])))
+    st = synthetic.real_supertranslation(0.05 * (rng.normal(size=9) + 1j * rng.normal(size=9)))
+    fr = rng.normal(size=4)
+    fr /= np.linalg.norm(fr)
+    v = 0.01 * rng.normal(size=3) if rng.uniform() < 0.6 else np.zeros(3)
+    tr = engine.make_transformation(st, fr, v, 4 * L + 1, 4 * L + 1, L)
+    os.environ["SCRI_AMD_NO_PIPELINE"] = "1"
+    try:
+        u_one, r_one = engine.transform_abd(u, raw, L, tr, ctx=ctx)
+    finally:
+        del os.environ["SCRI_AMD_NO_PIPELINE"]
+    u_def, r_def = engine.transform_abd(u, raw, L, tr, ctx=ctx)
+    pieces_seen.add(engine.auto_pieces_abd(raw.nbytes))
+    ok = u_def.shape == u_one.shape and np.array_equal(u_def, u_one)
+    err = np.abs(np.asarray(r_def) - np.asarray(r_one)).max() / np.abs(np.asarray(r_one)).max() if ok else float("nan")
+    if not (ok and err < 1e-13):
+        abd_failures += 1
+        print(f"FAILED six fields, seed {seed}: l <= {L} n {n} ({mb} MB) boost {bool(np.any(v))}: err {err:.2e}", flush=True)
+print(f"six fields: done, shard counts seen {sorted(pieces_seen)}, failures: {abd_failures}")
+sys.exit(1 if failures or abd_failures else 0)
